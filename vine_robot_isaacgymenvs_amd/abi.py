@@ -1,0 +1,153 @@
+"""ctypes mirror of ``include/vine.h`` (declarations only; no library is loaded here).
+
+Every name below restates one declaration of the header.  ``declare(lib)`` attaches
+argument/return types to the C-ABI entry points of a loaded shared library and raises
+``AttributeError`` if any symbol the header declares is missing.
+"""
+import ctypes as C
+
+VINE_ABI_VERSION = 1
+NUM_LINKS = 5
+NUM_DOFS = 6
+NUM_ACTIONS = 2
+NUM_REWARDS = 13
+MAX_OBS = 28
+MAX_DELAY = 8
+
+# VineStatus
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE, ERR_ALLOC = 0, -1, -2, -3, -4, -5
+
+# VineObsType (reference ObservationType enum, tasks/Vine5LinkMovingBase.py:67-73)
+OBS_POS_AND_FD_VEL_AND_OBJ_INFO = 0
+OBS_TIP_AND_CART_AND_OBJ_INFO = 1
+OBS_TYPE_BY_NAME = {
+    "POS_AND_FD_VEL_AND_OBJ_INFO": OBS_POS_AND_FD_VEL_AND_OBJ_INFO,
+    "TIP_AND_CART_AND_OBJ_INFO": OBS_TIP_AND_CART_AND_OBJ_INFO,
+}
+
+# VINE_FLAG_*
+FLAG_USE_SMOOTHED_FPAM = 1 << 0
+FLAG_FORCE_U_FPAM = 1 << 1
+FLAG_FORCE_U_RAIL_VELOCITY = 1 << 2
+FLAG_CREATE_SHELF = 1 << 3
+FLAG_RANDOMIZE_DOF_INIT = 1 << 4
+FLAG_RANDOMIZE_TARGETS = 1 << 5
+FLAG_USE_TARGET_REACHED_RESET = 1 << 6
+FLAG_USE_TIP_LIMIT_HIT_RESET = 1 << 7
+FLAG_USE_NONZERO_CONTACT_FORCE_RESET = 1 << 8
+FLAG_SCALE_OBSERVATIONS = 1 << 9
+FLAG_VINE_RANDOMIZE = 1 << 10
+FLAG_STALE_BODY_STATE_AFTER_RESET = 1 << 11
+FLAG_IMPLICIT_JOINT_DAMPING = 1 << 12
+FLAG_FPAM_DAMPING_HELD = 1 << 13
+
+# VineField
+VF_Q0 = 0
+VF_QD0 = 6
+VF_TIP_Y, VF_TIP_Z, VF_TIP_VY, VF_TIP_VZ = 12, 13, 14, 15
+VF_CART_Y, VF_CART_VY = 16, 17
+VF_TARGET_Y, VF_TARGET_Z = 18, 19
+VF_SMOOTHED_U, VF_U_FPAM, VF_U_RAIL, VF_PREV_U_RAIL = 20, 21, 22, 23
+VF_PREV_CART_VEL, VF_PREV_CART_VEL_ERR = 24, 25
+VF_OBJ_DEPTH, VF_OBJ_ANGLE = 26, 27
+VF_AGG_REW = 28
+VF_CONTACT, VF_CONTACT_MEAN = 29, 30
+VF_SHELF_Y, VF_SHELF_Z = 31, 32
+VF_RAIL_FORCE = 33
+VF_PREV_Q0 = 34
+VF_PREV_TIP_Y, VF_PREV_TIP_Z = 40, 41
+VF_FIFO0 = 42
+VF_COUNT = 42 + 2 * MAX_DELAY
+
+
+class VineConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("num_envs", C.c_int32),
+        ("obs_type", C.c_int32),
+        ("control_freq_inv", C.c_int32),
+        ("substeps", C.c_int32),
+        ("max_episode_length", C.c_int32),
+        ("action_delay", C.c_int32),
+        ("flags", C.c_uint32),
+        ("seed", C.c_uint64),
+        ("dt", C.c_float),
+        ("gravity", C.c_float),
+        ("clip_observations", C.c_float),
+        ("clip_actions", C.c_float),
+        ("fpam_min", C.c_float),
+        ("fpam_max", C.c_float),
+        ("rail_velocity_scale", C.c_float),
+        ("damping", C.c_float),
+        ("stiffness", C.c_float),
+        ("rail_soft_limit", C.c_float),
+        ("rail_p_gain", C.c_float),
+        ("rail_d_gain", C.c_float),
+        ("rail_acceleration", C.c_float),
+        ("smoothing_alpha_inflate", C.c_float),
+        ("smoothing_alpha_deflate", C.c_float),
+        ("random_init_cart_min_y", C.c_float),
+        ("random_init_cart_max_y", C.c_float),
+        ("success_dist", C.c_float),
+        ("min_target_depth", C.c_float),
+        ("max_target_depth", C.c_float),
+        ("min_target_y", C.c_float),
+        ("max_target_y", C.c_float),
+        ("min_target_z", C.c_float),
+        ("max_target_z", C.c_float),
+        ("reward_weights", C.c_float * NUM_REWARDS),
+        ("dyn_scale_min", C.c_float),
+        ("dyn_scale_max", C.c_float),
+        ("obs_noise_std", C.c_float),
+        ("action_noise_std", C.c_float),
+        ("cart_mass", C.c_float),
+        ("link_mass", C.c_float * NUM_LINKS),
+        ("link_inertia", C.c_float * NUM_LINKS),
+        ("link_length", C.c_float),
+        ("link_com", C.c_float),
+        ("joint1_z", C.c_float),
+        ("phi0", C.c_float),
+        ("link_angular_damping", C.c_float),
+        ("fpam_K", C.c_float * NUM_LINKS),
+        ("fpam_C", C.c_float * NUM_LINKS),
+        ("fpam_b", C.c_float * NUM_LINKS),
+        ("fpam_B", C.c_float * NUM_LINKS),
+        ("obs_scaling", C.c_float * MAX_OBS),
+    ]
+
+    def set_flag(self, flag, on):
+        self.flags = (self.flags | flag) if on else (self.flags & ~flag)
+
+    def has_flag(self, flag):
+        return bool(self.flags & flag)
+
+
+_P = C.POINTER
+_H = C.c_void_p  # VineHandle*
+
+# name -> (restype, argtypes); one row per declaration in include/vine.h
+PROTOTYPES = {
+    "vine_config_default": (C.c_int, [_P(VineConfig)]),
+    "vine_config_set_obs_type": (C.c_int, [_P(VineConfig), C.c_int, C.c_int]),
+    "vine_num_obs": (C.c_int, [_P(VineConfig)]),
+    "vine_create": (C.c_int, [_P(VineConfig), C.c_int, C.c_void_p, _P(_H)]),
+    "vine_destroy": (None, [_H]),
+    "vine_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vine_reset_idx": (C.c_int, [_H, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vine_bind_reset_values": (C.c_int, [_H, C.c_void_p]),
+    "vine_state_ptr": (C.c_void_p, [_H]),
+    "vine_get_step_count": (C.c_int64, [_H]),
+    "vine_set_step_count": (C.c_int, [_H, C.c_int64]),
+    "vine_bind_reward_matrix": (C.c_int, [_H, C.c_void_p]),
+    "vine_last_error": (C.c_char_p, []),
+    "vine_backend_name": (C.c_char_p, []),
+}
+
+
+def declare(lib):
+    """Attach prototypes; raises AttributeError naming the first missing symbol."""
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
