@@ -626,6 +626,39 @@ static void actuation(const VineConfig* c, const real* q, const real* qd, real c
     *prev_cart_vel_err = err;                                      /* V5:1097 */
     *prev_cart_vel = cart_vy;                                      /* V5:1098 */
 }
+/* compute_observations, V5:1339-1385 (before noise and before the VT:374 clamp). Returns the column count. */
+static int observations(const VineConfig* c, const real* q, const real* prev_q, const real* tip, real prev_tip_y,
+                        real prev_tip_z, real ty, real tz, real smoothed, real prev_u_rail, real obj_depth,
+                        real obj_angle, real* o) {
+    const real cdt = (real)c->dt * (real)c->control_freq_inv;        /* V5:228 */
+    int k = 0;
+    real fd_tip_y = (tip[0] - prev_tip_y) / cdt, fd_tip_z = (tip[1] - prev_tip_z) / cdt; /* V5:1348 */
+    if (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+        for (int i = 0; i < ND; ++i) o[k++] = q[i];
+        for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) / cdt;                  /* V5:1347 */
+    } else {
+        o[k++] = q[0];
+        o[k++] = (q[0] - prev_q[0]) / cdt;
+    }
+    o[k++] = 0; o[k++] = tip[0]; o[k++] = tip[1];
+    o[k++] = 0; o[k++] = fd_tip_y; o[k++] = fd_tip_z;
+    o[k++] = 0; o[k++] = ty; o[k++] = tz;
+    o[k++] = 0; o[k++] = 0; o[k++] = 0;                              /* target_velocities == 0, V5:916-918 */
+    o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
+    for (int i = 0; i < k; ++i) o[i] = o[i] / (real)c->obs_scaling[i];                   /* V5:1385 */
+    return k;
+}
+int vine_oracle_observations(const VineConfig* c, const double* q, const double* prev_q, const double* tip_yz,
+                             const double* prev_tip_yz, const double* target_yz, double smoothed, double prev_u_rail,
+                             const double* obj_info, double* obs) {
+    real rq[ND], rp[ND], t[4] = {(real)tip_yz[0], (real)tip_yz[1], 0, 0}, o[VINE_MAX_OBS];
+    for (int i = 0; i < ND; ++i) { rq[i] = (real)q[i]; rp[i] = (real)prev_q[i]; }
+    int k = observations(c, rq, rp, t, (real)prev_tip_yz[0], (real)prev_tip_yz[1], (real)target_yz[0], (real)target_yz[1],
+                         (real)smoothed, (real)prev_u_rail, (real)obj_info[0], (real)obj_info[1], o);
+    for (int i = 0; i < k; ++i) obs[i] = o[i];
+    return k;
+}
+
 /* compute_reward_jit, V5:1470-1537.  rm[13] = unweighted terms. */
 static real reward_terms(const VineConfig* c, real dist, int reached, real tip_vy, real tip_vz, real u_rail,
                          real u_fpam, real prev_u_rail, real smoothed, int limit_hit, int tip_limit_hit, real cart_y,
@@ -931,23 +964,8 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     }
     real obj_depth = ST(h, VF_OBJ_DEPTH, e), obj_angle = ST(h, VF_OBJ_ANGLE, e);
     /* compute_observations (V5:1339-1390) */
-    const real cdt = (real)c->dt * (real)c->control_freq_inv;        /* V5:228 */
     real o[VINE_MAX_OBS];
-    int k = 0;
-    real fd_tip_y = (tip[0] - prev_tip_y) / cdt, fd_tip_z = (tip[1] - prev_tip_z) / cdt; /* V5:1348 */
-    if (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
-        for (int i = 0; i < ND; ++i) o[k++] = q[i];
-        for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) / cdt;                  /* V5:1347 */
-    } else {
-        o[k++] = q[0];
-        o[k++] = (q[0] - prev_q[0]) / cdt;
-    }
-    o[k++] = 0; o[k++] = tip[0]; o[k++] = tip[1];
-    o[k++] = 0; o[k++] = fd_tip_y; o[k++] = fd_tip_z;
-    o[k++] = 0; o[k++] = ty; o[k++] = tz;
-    o[k++] = 0; o[k++] = 0; o[k++] = 0;                              /* target_velocities == 0, V5:916-918 */
-    o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
-    for (int i = 0; i < k; ++i) o[i] = o[i] / (real)c->obs_scaling[i];                   /* V5:1385 */
+    int k = observations(c, q, prev_q, tip, prev_tip_y, prev_tip_z, ty, tz, smoothed, prev_u_rail, obj_depth, obj_angle, o);
     if (randomize) {                                                 /* V5:1388-1390 */
         for (int i = 0; i < k; i += 4) {
             uint32_t r[4]; float nn[4];

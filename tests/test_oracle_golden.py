@@ -1,0 +1,183 @@
+"""Pins the CPU oracle's glue (rows S1, T1-T8 of SURVEY 8a) against golden vectors produced by the
+reference's own Python (tests/golden/make_golden.py).  Tolerances: the reference computes in
+float32; the f32 oracle must agree to a few ulp, the f64 oracle to float32 rounding."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vine_oracle as vo
+from vine_robot_isaacgymenvs_amd import abi
+from tests.helpers import base_cfg, f6_cfg
+
+PRECISIONS = ["f32", "f64"]
+D = C.POINTER(C.c_double)
+
+
+def dp(a):
+    return a.ctypes.data_as(D)
+
+
+@pytest.mark.parametrize("delay", [0, 1, 3])
+def test_f1_pre_physics_step(golden, delay):
+    """rescale (V5:1458-1463), FIFO delay (V5:935-937), EMA smoothing (V5:999-1005)."""
+    g = golden("f1_pre_delay%d" % delay)
+    acts = g["actions"]
+    T, N, _ = acts.shape
+    cfg = base_cfg(N, action_delay=delay)
+    env = vo.OracleEnv(cfg, "f32")
+    for t in range(T):
+        env.step(acts[t])          # the step clamps to +-clipActions like VT:333
+        st = env.state
+        np.testing.assert_allclose(st[abi.VF_U_RAIL], g["u_rail"][t][:, 0], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(st[abi.VF_U_FPAM], g["u_fpam"][t][:, 0], rtol=0, atol=5e-7)
+        np.testing.assert_allclose(st[abi.VF_SMOOTHED_U], g["smoothed"][t][:, 0], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("randomize", [0, 1])
+def test_f1_actuation(golden, precision, randomize):
+    """FPAM torque model + rail controller (V5:1028-1106), incl. the captured scaling tensor."""
+    g = golden("f1_actuation_rand%d" % randomize)
+    lib = vo.load(precision)
+    N = g["q"].shape[0]
+    cfg = base_cfg(N)
+    branch = np.abs(g["u_rail"][:, 0] - g["cart_vy"]) > 0.1
+    assert branch.any() and (~branch).any()      # both controller branches are covered
+    for e in range(N):
+        q, qd = g["q"][e].astype(np.float64), g["qd"][e].astype(np.float64)
+        scale = g["scale"][e].astype(np.float64) if randomize else np.ones(20)
+        pv = C.c_double(float(g["prev_cart_vel"][e, 0]))
+        pe = C.c_double(float(g["prev_cart_vel_err"][e, 0]))
+        eff = np.zeros(6)
+        lib.vine_oracle_actuation(C.byref(cfg), dp(q), dp(qd), float(g["cart_vy"][e]), float(g["u_rail"][e, 0]),
+                                  float(g["smoothed"][e, 0]), dp(scale), C.byref(pv), C.byref(pe), dp(eff))
+        # accel term divides by dt: float32 cancellation error of (v - v_prev) is amplified by 0.3/dt = 36
+        np.testing.assert_allclose(eff[1:], g["efforts"][e, 1:], rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(eff[0], g["efforts"][e, 0], rtol=1e-5, atol=2e-5)
+        assert abs(pv.value - g["prev_cart_vel_out"][e, 0]) < 1e-7
+        assert abs(pe.value - g["prev_cart_vel_err_out"][e, 0]) < 2e-7
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name,obs_type", [("POS_AND_FD_VEL_AND_OBJ_INFO", 0), ("TIP_AND_CART_AND_OBJ_INFO", 1)])
+def test_f2_observations(golden, precision, name, obs_type):
+    """compute_observations (V5:1339-1385) for both scalable observation types."""
+    g = golden("f2_obs_" + name)
+    lib = vo.load(precision)
+    N, nobs = g["obs"].shape
+    cfg = base_cfg(N, obs_type)
+    assert lib.vine_num_obs(C.byref(cfg)) == nobs
+    np.testing.assert_allclose(np.array(cfg.obs_scaling[:nobs]), g["obs_scaling"], rtol=1e-7)
+    assert abs(cfg.dt * cfg.control_freq_inv - float(g["control_dt"])) < 1e-8
+    for e in range(N):
+        out = np.zeros(28)
+        k = lib.vine_oracle_observations(
+            C.byref(cfg), dp(g["q"][e].astype(np.float64)), dp(g["prev_q"][e].astype(np.float64)),
+            dp(g["tip"][e, 1:3].astype(np.float64)), dp(g["prev_tip"][e, 1:3].astype(np.float64)),
+            dp(g["target"][e, 1:3].astype(np.float64)), float(g["smoothed"][e, 0]), float(g["prev_u_rail"][e, 0]),
+            dp(g["obj_info"][e].astype(np.float64)), dp(out))
+        assert k == nobs
+        # finite differences divide float32 differences by control_dt*scale: allow cancellation noise
+        np.testing.assert_allclose(out[:nobs], g["obs"][e], rtol=3e-5, atol=3e-5)
+    assert (np.abs(g["obs"]) > 5).any()          # the fixture exercises the VT:374 clamp
+    assert np.abs(g["obs_clamped"]).max() <= 5.0
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("tag", ["default", "allones"])
+def test_f3_reward(golden, precision, tag):
+    """compute_reward_jit (V5:1470-1537): 13 terms, weights, total."""
+    g = golden("f3_reward_" + tag)
+    lib = vo.load(precision)
+    cfg = base_cfg(1)
+    for i in range(abi.NUM_REWARDS):
+        cfg.reward_weights[i] = float(g["weights"][i])
+    for e in range(g["dist"].shape[0]):
+        rm = np.zeros(13)
+        total = lib.vine_oracle_reward(
+            C.byref(cfg), float(g["dist"][e]), int(g["reached"][e]), float(g["tip_v"][e, 1]), float(g["tip_v"][e, 2]),
+            float(g["u_rail"][e, 0]), float(g["u_fpam"][e, 0]), float(g["prev_u_rail"][e, 0]), float(g["smoothed"][e, 0]),
+            int(g["limit_hit"][e]), int(g["tip_limit"][e]), float(g["cart_y"][e]), float(g["contact"][e]), dp(rm))
+        np.testing.assert_allclose(rm, g["matrix"][e], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(total, g["total"][e], rtol=2e-6, atol=2e-5)
+    assert g["total"].dtype == np.float32        # fp32 despite .double() intermediates
+
+
+def test_f4_reset_truth_table(golden):
+    """compute_reset_jit (V5:1540-1558): all 2*4*16*8 combinations, bit-exact."""
+    g = golden("f4_reset_table")
+    lib = vo.load("f64")
+    cfg = base_cfg(1, max_episode_length=int(g["max_episode_length"]))
+    for row in g["table"]:
+        reset_in, prog, reached, limit, tip_limit, contact, f_reach, f_tip, f_contact, expect = [int(x) for x in row]
+        cfg.set_flag(abi.FLAG_USE_TARGET_REACHED_RESET, f_reach)
+        cfg.set_flag(abi.FLAG_USE_TIP_LIMIT_HIT_RESET, f_tip)
+        cfg.set_flag(abi.FLAG_USE_NONZERO_CONTACT_FORCE_RESET, f_contact)
+        got = lib.vine_oracle_reset_logic(C.byref(cfg), reset_in, prog, reached, limit, tip_limit, contact)
+        assert got == expect, row
+
+
+@pytest.mark.parametrize("shelf", [0, 1])
+def test_f5_reset_sampling(golden, shelf):
+    """reset_idx (V5:774-839): structure exactly, distributions statistically (the reference draws from
+    torch's CPU generator, the build from Philox: streams cannot match, SURVEY 7 'RNG')."""
+    from scipy import stats
+    g = golden("f5_reset_shelf%d" % shelf)
+    N = g["q"].shape[0]
+    rad10, cmin, cmax, ymin, ymax, zmin, zmax, dmin, dmax = g["ranges"]
+    # structure of the reference's own output
+    assert np.all(g["qd"] == 0) and np.array_equal(g["prev_q"], g["q"]) and np.all(g["target"][:, 0] == 0)
+    cfg = base_cfg(N)
+    cfg.set_flag(abi.FLAG_CREATE_SHELF, shelf)
+    env = vo.OracleEnv(cfg, "f64")
+    env.reset_idx(np.arange(N))
+    st = env.state
+    assert np.all(st[abi.VF_QD0:abi.VF_QD0 + 6] == 0)
+    assert np.array_equal(st[abi.VF_PREV_Q0:abi.VF_PREV_Q0 + 6], st[abi.VF_Q0:abi.VF_Q0 + 6])
+    pairs = [(st[abi.VF_Q0 + 1 + j], g["q"][:, 1 + j], -rad10, rad10) for j in range(5)]
+    pairs += [(st[abi.VF_Q0], g["q"][:, 0], cmin, cmax), (st[abi.VF_TARGET_Y], g["target"][:, 1], ymin, ymax),
+              (st[abi.VF_TARGET_Z], g["target"][:, 2], zmin, zmax)]
+    if shelf:
+        pairs.append((st[abi.VF_OBJ_DEPTH], g["obj_info"][:, 0], dmin, dmax))
+        # shelf root = target + (0, -0.2 + depth, -0.01)  (V5:818-831), in both
+        np.testing.assert_allclose(g["shelf_root"][:, 1], g["target"][:, 1] - 0.2 + g["obj_info"][:, 0], atol=1e-6)
+        np.testing.assert_allclose(g["shelf_root"][:, 2], g["target"][:, 2] - 0.01, atol=1e-6)
+        np.testing.assert_allclose(st[abi.VF_SHELF_Y], st[abi.VF_TARGET_Y] - 0.2 + st[abi.VF_OBJ_DEPTH], atol=1e-12)
+        np.testing.assert_allclose(st[abi.VF_SHELF_Z], st[abi.VF_TARGET_Z] - 0.01, atol=1e-12)
+    else:
+        assert np.all(g["obj_info"] == 0) and np.all(st[abi.VF_OBJ_DEPTH] == 0)
+    for ours, ref, lo, hi in pairs:
+        assert ours.min() >= lo - 1e-6 and ours.max() <= hi + 1e-6
+        assert ref.min() >= lo - 1e-6 and ref.max() <= hi + 1e-6
+        assert stats.ks_2samp(ours, ref).pvalue > 1e-3
+    # draws of different quantities are independent
+    assert abs(np.corrcoef(st[abi.VF_Q0 + 1], st[abi.VF_Q0 + 2])[0, 1]) < 0.12
+
+
+@pytest.mark.parametrize("tag,delay,obs_type", [("delay1", 1, 0), ("delay0_tipobs", 0, 1), ("delay2", 2, 0)])
+def test_f6_step_sequencing(golden, tag, delay, obs_type):
+    """The reference's real VecTask.step (VT:319-380) for 64 steps over FakeGym (physics = this oracle, f32,
+    held-torque mode): pins reset-next-step ordering, the stale tip after reset, 4x actuation, FIFO, timeouts."""
+    g = golden("f6_traj_" + tag)
+    T, N, _ = g["actions"].shape
+    cfg = f6_cfg(N, delay, obs_type)
+    env = vo.OracleEnv(cfg, "f32")
+    np.testing.assert_array_equal(g["first_obs"], 0)     # reset() returns the zero buffer (VT:398-410)
+    assert g["did_reset"][0].all()                       # reset_buf starts at ones (VT:275)
+    n_resets = n_timeouts = 0
+    for t in range(T):
+        env.bind_reset_values(g["reset_values"][t])
+        will_reset = env.reset_buf.astype(bool).copy()
+        np.testing.assert_array_equal(will_reset, g["did_reset"][t])
+        obs, rew, rst, to = env.step(g["actions"][t])
+        np.testing.assert_array_equal(rst, g["reset"][t])
+        np.testing.assert_array_equal(to.astype(bool), g["timeouts"][t])
+        np.testing.assert_array_equal(env.progress, g["progress"][t])
+        np.testing.assert_allclose(env.state[abi.VF_Q0:abi.VF_Q0 + 6].T, g["q"][t], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(rew, g["rew"][t], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(env.state[abi.VF_AGG_REW], g["agg"][t], rtol=1e-5, atol=1e-3)
+        n_resets += int(will_reset.sum())
+        n_timeouts += int(to.sum())
+    assert n_resets > N and n_timeouts > 0               # the trajectory exercises resets and timeouts

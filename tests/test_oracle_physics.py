@@ -1,0 +1,206 @@
+"""Row P1: the reference's physics is PhysX (closed, absent) => parity unpinned.  These tests pin the
+oracle's rigid-body model against itself: three independent formulations, conservation laws and
+closed-form small-motion results derived from the URDF constants."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vine_oracle as vo
+from vine_robot_isaacgymenvs_amd import abi
+
+H = 0.00833 / 10
+
+
+def cfg_with(implicit=True, damping=None, cad=0.0):
+    cfg = vo.default_config()
+    cfg.set_flag(abi.FLAG_IMPLICIT_JOINT_DAMPING, implicit)
+    if damping is not None:
+        cfg.damping = damping
+    cfg.link_angular_damping = cad
+    return cfg
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    lib = vo.load("f64")
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, expect in kat:
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        lib.vine_oracle_philox(c, k, o)
+        assert list(o) == expect
+
+
+@pytest.mark.parametrize("implicit", [False, True])
+def test_three_formulations_agree(implicit):
+    """Jacobian CRBA (relative coords), planar ABA, absolute-angle Lagrangian: same accelerations."""
+    cfg = cfg_with(implicit)
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        q = rng.uniform(-1.0, 1.0, 6)
+        qd = rng.uniform(-5, 5, 6)
+        eff = rng.uniform(-0.5, 0.5, 6)
+        cj = rng.uniform(0.01, 0.08, 6)
+        a = [vo.forward_dynamics(cfg, q, qd, eff, H, f, cj=cj) for f in (vo.FORM_CRBA, vo.FORM_ABA, vo.FORM_ABS)]
+        scale = 1 + np.abs(a[0]).max()
+        assert np.abs(a[0] - a[1]).max() / scale < 1e-10
+        assert np.abs(a[0] - a[2]).max() / scale < 1e-10
+
+
+def test_link_angular_damping_consistent():
+    """The optional per-link angular damping switch: CRBA and absolute-angle forms agree."""
+    for implicit in (False, True):
+        cfg = cfg_with(implicit, cad=0.5)
+        rng = np.random.default_rng(1)
+        for _ in range(50):
+            q, qd, eff = rng.uniform(-1, 1, 6), rng.uniform(-5, 5, 6), rng.uniform(-0.5, 0.5, 6)
+            a0 = vo.forward_dynamics(cfg, q, qd, eff, H, vo.FORM_CRBA)
+            a2 = vo.forward_dynamics(cfg, q, qd, eff, H, vo.FORM_ABS)
+            assert np.abs(a0 - a2).max() / (1 + np.abs(a0).max()) < 1e-10
+
+
+def test_f32_matches_f64():
+    cfg = cfg_with(True)
+    rng = np.random.default_rng(2)
+    worst = 0
+    for _ in range(200):
+        q, qd, eff = rng.uniform(-0.6, 0.6, 6), rng.uniform(-3, 3, 6), rng.uniform(-0.3, 0.3, 6)
+        a64 = vo.forward_dynamics(cfg, q, qd, eff, H, vo.FORM_ABS, "f64")
+        a32 = vo.forward_dynamics(cfg, q, qd, eff, H, vo.FORM_ABS, "f32")
+        worst = max(worst, np.abs(a64 - a32).max() / (1 + np.abs(a64).max()))
+    assert worst < 5e-3      # M is ill-conditioned (5 g links carrying a 100 g link): fp32 solve, cond ~1e3-1e4
+
+
+def test_energy_conservation_undamped():
+    """tau = 0, damping = 0: semi-implicit Euler keeps the energy error O(h), with no drift."""
+    cfg = cfg_with(False, damping=0.0)
+    q = np.array([0.05, 0.3, -0.2, 0.25, -0.1, 0.2])
+    qd = np.zeros(6)
+    e0 = vo.energy(cfg, q, qd)
+    swing = abs(vo.energy(cfg, q, qd) - vo.energy(cfg, np.zeros(6), qd))
+    errs = []
+    for h in (H / 8, H / 16):
+        qq, qqd = q.copy(), qd.copy()
+        worst = 0
+        n = int(round(0.5 / h))
+        for _ in range(20):
+            qq, qqd = vo.simulate(cfg, qq, qqd, np.zeros(6), h, n // 20, vo.FORM_CRBA)
+            worst = max(worst, abs(vo.energy(cfg, qq, qqd) - e0))
+        errs.append(worst)
+    assert errs[0] < 0.05 * swing
+    assert errs[1] < 0.7 * errs[0]          # first-order convergence
+
+
+def test_momentum_of_free_cart():
+    """No rail force, no damping: horizontal momentum of cart + links is conserved (to O(h))."""
+    cfg = cfg_with(False, damping=0.0)
+    q = np.array([0.0, 0.4, 0.1, -0.3, 0.2, 0.1])
+    qd = np.array([0.3, 0, 0, 0, 0, 0])
+
+    def py(q, qd):   # d(E)/d(vy) at fixed rest = horizontal momentum; finite difference of the energy
+        eps = 1e-6
+        return (vo.energy(cfg, q, qd + np.array([eps, 0, 0, 0, 0, 0])) - vo.energy(cfg, q, qd - np.array([eps, 0, 0, 0, 0, 0]))) / (2 * eps)
+
+    p0 = py(q, qd)
+    errs = []
+    for div in (4, 16):      # the integrator is first order: the momentum error shrinks with h
+        q1, qd1 = vo.simulate(cfg, q, qd, np.zeros(6), H / div, 500 * div, vo.FORM_ABS)
+        errs.append(abs(py(q1, qd1) - p0))
+    assert errs[0] < 2e-3 * abs(p0)
+    assert errs[1] < 0.5 * errs[0]
+
+
+def test_static_equilibrium_and_rest_pose():
+    """phi0 = 3.1415 (not pi): the hanging equilibrium sits at q1 ~ +9.27e-5 and the rest tip at
+    z = 1 - 0.025 - 0.01 - 5*0.0885 = 0.5225."""
+    cfg = cfg_with(True)
+    q = np.zeros(6)
+    q[1] = np.pi - 3.1415
+    a = vo.forward_dynamics(cfg, q, np.zeros(6), np.zeros(6), H, vo.FORM_CRBA)
+    assert np.abs(a).max() < 1e-3          # float32 constants in VineConfig leave a tiny residual
+    t = vo.tip(cfg, q, np.zeros(6))
+    assert abs(t[1] - 0.5225) < 1e-6 and abs(t[0]) < 1e-6
+    t0 = vo.tip(cfg, np.zeros(6), np.zeros(6))
+    assert abs(t0[0] - (-0.4425 * np.sin(3.1415))) < 1e-6
+
+
+def test_total_mass_and_cart_acceleration():
+    """With all revolute joints locked by symmetry (straight chain hanging at equilibrium) a rail force F
+    accelerates the cart by more than F/m_total (the chain lags) and less than F/m_cart."""
+    cfg = cfg_with(False, damping=0.0)
+    q = np.zeros(6)
+    q[1] = np.pi - 3.1415
+    a = vo.forward_dynamics(cfg, q, np.zeros(6), np.array([1.0, 0, 0, 0, 0, 0]), H, vo.FORM_ABA)
+    assert 1.0 / 0.52 < a[0] < 1.0 / 0.4
+
+
+def test_small_angle_pendulum_frequency():
+    """Lock the model into a single rigid pendulum by making joints 2..5 very stiff: the swing frequency of
+    joint 1 must match sqrt(m g r / I_pivot) of the composite body computed from the URDF constants."""
+    cfg = cfg_with(False, damping=0.0)
+    m = np.array(cfg.link_mass[:])
+    inertia = np.array(cfg.link_inertia[:])
+    L, l = cfg.link_length, cfg.link_com
+    r = np.array([k * L + l for k in range(5)])
+    mt, rc = m.sum(), (m * r).sum() / m.sum()
+    ip = (inertia + m * r ** 2).sum()
+    omega = np.sqrt(mt * 9.81 * rc / ip)
+    # analytic check through the mass matrix: d2q1/dt2 for a small straight-chain deflection with a fixed cart
+    eps = 1e-4
+    q = np.zeros(6)
+    q[1] = (np.pi - 3.1415) + eps
+    cfg.cart_mass = 1e6            # effectively fixed cart
+    # a straight chain is not an eigenmode of the 5-link chain, so compare the energy Hessian instead:
+    # potential energy of a rigid deflection eps must be 0.5 * (mt g rc) eps^2
+    e0 = vo.energy(cfg, np.array([0, np.pi - 3.1415, 0, 0, 0, 0.0]), np.zeros(6))
+    e1 = vo.energy(cfg, q, np.zeros(6))
+    assert abs((e1 - e0) - 0.5 * mt * 9.81 * rc * eps ** 2) < 1e-3 * 0.5 * mt * 9.81 * rc * eps ** 2 + 1e-12
+    # kinetic energy of a rigid rotation rate w about joint 1 must be 0.5 * ip * w^2
+    w = 0.7
+    ek = vo.energy(cfg, np.array([0, np.pi - 3.1415, 0, 0, 0, 0.0]), np.array([0, w, 0, 0, 0, 0.0])) - e0
+    assert abs(ek - 0.5 * ip * w * w) < 1e-9
+    assert 5.0 < omega < 7.0       # ~0.95 Hz: plausible for a 0.44 m hanging arm
+
+
+def test_default_parameters_are_stable():
+    """Random and bang-bang actions for 400 control steps stay bounded (the held-C variant does not)."""
+    for mode in ("random", "bang"):
+        cfg = vo.default_config(num_envs=32)
+        cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, False)
+        env = vo.OracleEnv(cfg, "f64")
+        rng = np.random.default_rng(3)
+        a = np.zeros((32, 2))
+        for s in range(400):
+            if mode == "random":
+                a = rng.uniform(-1, 1, (32, 2))
+            elif s % 10 == 0:
+                a = np.sign(rng.uniform(-1, 1, (32, 2)))
+            env.step(a)
+            st = env.state
+            assert np.isfinite(st).all()
+            assert np.abs(st[abi.VF_QD0 + 1:abi.VF_QD0 + 6]).max() < 30
+            assert np.abs(st[abi.VF_Q0 + 1:abi.VF_Q0 + 6]).max() < 1.5
+
+
+def test_held_velocity_feedback_is_unstable():
+    """Documents assumption P4: with the reference's literal held C*qd torque the sampled
+    system diverges in this integrator, which is why the default moves C into the DOF damping."""
+    cfg = vo.default_config(num_envs=8)
+    cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, False)
+    cfg.set_flag(abi.FLAG_FPAM_DAMPING_HELD, True)
+    env = vo.OracleEnv(cfg, "f64")
+    rng = np.random.default_rng(4)
+    blew = False
+    for s in range(50):
+        env.step(rng.uniform(-1, 1, (8, 2)))
+        if not np.isfinite(env.state).all() or np.abs(env.state[abi.VF_QD0 + 1:abi.VF_QD0 + 6]).max() > 1e3:
+            blew = True
+            break
+    assert blew
