@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the Vine5LinkMovingBase hot path on MI355X (BASELINE.json: env-steps/sec at 16384 envs per GPU,
+PPO iters/sec).
+
+    python bench.py --gpus 1 --steps K --warmup W [--mode ppo|env] [--num-envs 16384]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One rank per GPU; every rank owns `num_envs` independent envs (weak scaling, BASELINE configs 3/4).
+mode=ppo (default once the learner is available): a "step" is one full PPO iteration = horizon x [policy
+  inference + env step] + GAE + mini-epoch updates with the RCCL gradient all-reduce; value = env-steps/sec of the
+  whole job (N x horizon x ranks / iteration time), ppo_iters_per_sec reported beside it.
+mode=env: a "step" is one VecTask.step over resident random actions (the hand-written HIP kernel alone).
+Rank 0 prints ONE JSON line.  The `roofline` object prices the dominant hand-written kernel (vine_step_kernel) with
+HIP events recorded on the launching stream inside the timed region; `cpu_baseline` times the CPU oracle
+(oracle/, OpenMP over envs) on a bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+ALGO_BYTES_PER_ENV_STEP = {28: 320, 18: 280}   # reads 112 B + writes 205 B (obs 28) -> 320 B
+HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=None)
+    p.add_argument("--warmup", type=int, default=None)
+    p.add_argument("--mode", choices=["env", "ppo"], default=None)
+    p.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (BASELINE config 3: 16384)")
+    p.add_argument("--randomize", type=int, default=1, help="task.vine_randomize (task YAML default: True)")
+    p.add_argument("--obs-type", default="POS_AND_FD_VEL_AND_OBJ_INFO")
+    p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="env mode: eager launches instead of hipGraph replay")
+    return p.parse_args()
+
+
+def make_env(args, rank, device_index):
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    ov = ["task=Vine5LinkMovingBase", "num_envs=%d" % args.num_envs, "vine_randomize=%s" % bool(args.randomize),
+          "OBSERVATION_TYPE=%s" % args.obs_type, "headless=True", "sim_device=cuda:%d" % device_index,
+          "rl_device=cuda:%d" % device_index, "multi_gpu=%s" % (args.gpus > 1)]
+    cfg = load_config(overrides=ov)
+    cfg["task"]["seed"] = 42 + 2 * rank        # train.py:78 + utils.py:50: the rank is added twice
+    dev = "cuda:%d" % device_index
+    env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device=dev, sim_device=dev,
+                                                  graphics_device_id=device_index, headless=True,
+                                                  virtual_screen_capture=False, force_render=False)
+    return env, cfg
+
+
+def cpu_baseline(args, seconds):
+    """CPU restatement of the reference path (oracle/, float32, OpenMP over envs) on a bounded sample."""
+    import numpy as np
+    from oracle import vine_oracle as vo
+    from vine_robot_isaacgymenvs_amd import abi
+    lib = vo.load("f32", omp=True)
+    cores = lib.vine_oracle_set_threads(os.cpu_count() or 1)
+    cfg = vo.default_config(lib, num_envs=args.num_envs)
+    lib.vine_config_set_obs_type(cfg, abi.OBS_TYPE_BY_NAME[args.obs_type], 1)
+    cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, bool(args.randomize))
+    env = vo.OracleEnv(cfg, "f32", omp=True)
+    rng = np.random.default_rng(42)
+    acts = rng.uniform(-1, 1, (4, args.num_envs, 2)).astype(np.float32)
+    env.step(acts[0])
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        env.step(acts[n % 4])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 1000:
+            break
+    return {"value": args.num_envs * n / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d VecTask.step calls x %d envs (env step only, random actions), oracle/ float32 + OpenMP, %.1f s"
+                      % (n, args.num_envs, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    try:
+        from vine_robot_isaacgymenvs_amd.learning import a2c_continuous  # noqa: F401
+        have_ppo = True
+    except ImportError:
+        have_ppo = False
+    mode = args.mode or ("ppo" if have_ppo else "env")
+    steps = args.steps if args.steps is not None else (10 if mode == "ppo" else 2000)
+    warmup = args.warmup if args.warmup is not None else (3 if mode == "ppo" else 100)
+
+    env, cfg = make_env(args, rank, local_rank)
+    n = env.num_envs
+    extra = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if mode == "env":
+        g = torch.Generator(device=dev).manual_seed(42 + rank)
+        pool = [torch.rand((n, 2), device=dev, generator=g) * 2 - 1 for _ in range(64)]
+        for i in range(warmup):
+            env.step(pool[i % 64])
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ev[i][0].record()
+            env._native_step(pool[i % 64], env.obs_buf)     # the C-ABI launch (VecTask.step minus dict marshalling)
+            ev[i][1].record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+        units_per_step = n
+    else:
+        from vine_robot_isaacgymenvs_amd.learning.bench_support import run_ppo_bench
+        elapsed, kernel_ms, units_per_step, extra = run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank)
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        value = units_per_step * world * steps / elapsed
+        algo_bytes = ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec Vine5LinkMovingBase %d envs per GPU" % n,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Vine5LinkMovingBase num_envs=%d per GPU, obs=%d, vine_randomize=%s, mode=%s "
+                                   "(BASELINE.json configs[2]; x8 ranks = configs[3])"
+                                   % (n, env.num_obs, bool(args.randomize), mode),
+                       "mode": mode, "num_envs_per_gpu": n, "parallelism": "env-sharded dp%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "vine_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
+        print(json.dumps(out))
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,9 @@
 #include "../include/vine.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,6 +53,16 @@ static int fail(int code, const char* msg) {
 const char* vine_last_error(void) { return g_err; }
 const char* vine_backend_name(void) { return sizeof(real) == 8 ? "oracle-f64" : "oracle-f32"; }
 int vine_oracle_real_bytes(void) { return (int)sizeof(real); }
+/* threads used by vine_step in the -fopenmp build (cpu_baseline leg of bench.py); returns the count in force */
+int vine_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------- */
 /* Counter-based RNG: Philox4x32-10 (Salmon et al. 2011).  The reference draws

@@ -38,6 +38,8 @@ def load(precision="f64", omp=False):
     lib = abi.declare(C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0)))
     P = C.POINTER(abi.VineConfig)
     lib.vine_oracle_real_bytes.restype = C.c_int
+    lib.vine_oracle_set_threads.argtypes = [C.c_int]
+    lib.vine_oracle_set_threads.restype = C.c_int
     lib.vine_oracle_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
     lib.vine_oracle_forward_dynamics.argtypes = [P, C.c_int, _D, _D, _D, _D, C.c_double, _D]
     lib.vine_oracle_forward_dynamics.restype = C.c_int

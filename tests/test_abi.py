@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in boundary: the product library loads, exports every symbol that
+include/vine.h declares, agrees with the oracle on defaults, and refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from oracle import vine_oracle as vo
+from vine_robot_isaacgymenvs_amd import abi, native
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(REPO, "include", "vine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vine_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_ctypes_mirror_agree():
+    assert header_functions() == sorted(abi.PROTOTYPES)
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    native.build()
+    return native.load()
+
+
+def test_product_library_exports_every_symbol(hip_lib):
+    for name in header_functions():
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.vine_backend_name() == b"hip-gfx950"
+
+
+def test_oracle_exports_every_symbol():
+    for prec in ("f32", "f64"):
+        lib = vo.load(prec)
+        for name in header_functions():
+            assert hasattr(lib, name), name
+
+
+def test_struct_layout_and_defaults_match_oracle(hip_lib):
+    """Same VineConfig bytes from both implementations of vine_config_default / set_obs_type."""
+    a, b = abi.VineConfig(), abi.VineConfig()
+    assert hip_lib.vine_config_default(C.byref(a)) == 0
+    assert vo.load("f64").vine_config_default(C.byref(b)) == 0
+    assert bytes(a) == bytes(b)
+    for obs_type in (0, 1):
+        for scale in (0, 1):
+            assert hip_lib.vine_config_set_obs_type(C.byref(a), obs_type, scale) == 0
+            assert vo.load("f64").vine_config_set_obs_type(C.byref(b), obs_type, scale) == 0
+            assert bytes(a) == bytes(b)
+            assert hip_lib.vine_num_obs(C.byref(a)) == (28 if obs_type == 0 else 18)
+    assert hip_lib.vine_config_set_obs_type(C.byref(a), 7, 1) == abi.ERR_UNSUPPORTED
+
+
+def test_field_enum_matches_header():
+    text = open(os.path.join(REPO, "include", "vine.h")).read()
+    for name, val in re.findall(r"\b(VF_[A-Z_0-9]+)\s*=\s*(\d+)\s*[,/]", text):
+        assert getattr(abi, name) == int(val), name
+    for name, shift in re.findall(r"\bVINE_(FLAG_[A-Z_]+)\s*=\s*1u << (\d+)", text):
+        assert getattr(abi, name) == 1 << int(shift), name
+
+
+def test_invalid_configs_are_rejected(hip_lib):
+    c = abi.VineConfig()
+    hip_lib.vine_config_default(C.byref(c))
+    h = C.c_void_p()
+    c.num_envs = 0
+    assert hip_lib.vine_create(C.byref(c), 0, None, C.byref(h)) == abi.ERR_INVALID_ARG
+    c.num_envs = 8
+    c.action_delay = abi.MAX_DELAY + 1
+    assert hip_lib.vine_create(C.byref(c), 0, None, C.byref(h)) == abi.ERR_INVALID_ARG
+    c.action_delay = 1
+    c.abi_version = 99
+    assert hip_lib.vine_create(C.byref(c), 0, None, C.byref(h)) == abi.ERR_INVALID_ARG
+    assert b"abi_version" in hip_lib.vine_last_error()
+
+
+def test_product_fails_loudly_without_gpu(hip_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    c = abi.VineConfig()
+    hip_lib.vine_config_default(C.byref(c))
+    c.num_envs = 8
+    h = C.c_void_p()
+    rc = hip_lib.vine_create(C.byref(c), 0, None, C.byref(h))
+    assert rc == abi.ERR_NO_DEVICE
+    assert b"no CPU path" in hip_lib.vine_last_error()
+    with pytest.raises(RuntimeError):
+        native.check(rc, hip_lib)
+
+
+def test_task_class_refuses_cpu_device():
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    from vine_robot_isaacgymenvs_amd.utils.config import load_task_config
+    cfg = load_task_config("Vine5LinkMovingBase", overrides=["num_envs=8"])
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg, rl_device="cpu", sim_device="cpu", graphics_device_id=-1,
+                                                headless=True, virtual_screen_capture=False, force_render=False)

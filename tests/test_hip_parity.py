@@ -1,0 +1,240 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of libvine_hip.so) against the CPU oracle on
+identical seeded inputs, against the golden fixtures made from the reference's Python, and -- at
+BASELINE.json's full size -- through size-independent properties.
+
+Tolerances (north_star: "stated fp32 tolerance"): integer outputs (reset/progress/time_outs) bit-exact;
+single-step float outputs vs the float32 oracle (same formulation) 2e-5 abs on positions, 2e-3 on velocities
+(the 6x6 mass matrix of a chain of 5 g links carrying a 100 g link has condition number ~1e3-1e4, so float32
+accelerations carry ~1e-4 relative error whatever the instruction order); vs the float64 oracle 1e-4 / 1e-2.
+"""
+import numpy as np
+import pytest
+
+from oracle import vine_oracle as vo
+from vine_robot_isaacgymenvs_amd import abi
+from tests.helpers import base_cfg, f6_cfg, random_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def HipEnv():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (the product has no CPU fallback)")
+    from tests.hip_env import HipEnv as H
+    return H
+
+
+def pair(HipEnv, cfg, precision="f32"):
+    return HipEnv(cfg), vo.OracleEnv(cfg, precision)
+
+
+def seed_both(hip, orc, rng, n, cfg):
+    st = random_state(rng, n, cfg)
+    hip.set_state(st)
+    orc.state[:] = st.astype(orc.real)
+    reset = (rng.uniform(size=n) < 0.15).astype(np.int64)
+    progress = rng.integers(0, cfg.max_episode_length - 1, n)
+    progress[: n // 16] = cfg.max_episode_length - 2      # a block of envs hits the time limit this step
+    hip.set_flags(reset, progress)
+    orc.reset_buf[:] = reset
+    orc.progress[:] = progress
+    return st
+
+
+QPOS = slice(abi.VF_Q0, abi.VF_Q0 + 6)
+QVEL = slice(abi.VF_QD0, abi.VF_QD0 + 6)
+
+
+def compare_step(hip_out, orc, hip, pos_tol, vel_tol, obs_tol):
+    obs, rew, rst, to = hip_out
+    hs, os_ = hip.state, orc.state.astype(np.float64)
+    np.testing.assert_array_equal(rst, orc.reset_buf)
+    np.testing.assert_array_equal(hip.progress, orc.progress)
+    np.testing.assert_array_equal(to, orc.timeouts)
+    np.testing.assert_allclose(hs[QPOS], os_[QPOS], rtol=0, atol=pos_tol)
+    np.testing.assert_allclose(hs[QVEL], os_[QVEL], rtol=0, atol=vel_tol)
+    for f in (abi.VF_TIP_Y, abi.VF_TIP_Z, abi.VF_CART_Y, abi.VF_TARGET_Y, abi.VF_TARGET_Z, abi.VF_SMOOTHED_U,
+              abi.VF_U_FPAM, abi.VF_U_RAIL, abi.VF_PREV_U_RAIL, abi.VF_PREV_TIP_Y, abi.VF_PREV_TIP_Z):
+        np.testing.assert_allclose(hs[f], os_[f], rtol=0, atol=pos_tol, err_msg="field %d" % f)
+    for f in (abi.VF_TIP_VY, abi.VF_TIP_VZ, abi.VF_CART_VY, abi.VF_PREV_CART_VEL, abi.VF_PREV_CART_VEL_ERR):
+        np.testing.assert_allclose(hs[f], os_[f], rtol=0, atol=vel_tol, err_msg="field %d" % f)
+    np.testing.assert_allclose(hs[abi.VF_RAIL_FORCE], os_[abi.VF_RAIL_FORCE], rtol=1e-3, atol=30 * vel_tol)
+    np.testing.assert_allclose(obs, orc.obs, rtol=0, atol=obs_tol)
+    np.testing.assert_allclose(rew, orc.rew, rtol=1e-5, atol=max(1e-4, 0.2 * vel_tol))
+    np.testing.assert_allclose(hs[abi.VF_AGG_REW], os_[abi.VF_AGG_REW], rtol=1e-5, atol=max(1e-3, 0.2 * vel_tol))
+
+
+@pytest.mark.parametrize("obs_type", [0, 1])
+@pytest.mark.parametrize("randomize", [False, True])
+@pytest.mark.parametrize("delay", [0, 1, 3])
+def test_single_step_matches_oracle(HipEnv, obs_type, randomize, delay):
+    """One VecTask.step from identical random mid-episode states, incl. resets, time-outs, RNG draws."""
+    n = 1000   # ragged: not a multiple of the 64-wide workgroup
+    cfg = base_cfg(n, obs_type, randomize, action_delay=delay, seed=1234 + delay)
+    if randomize:
+        cfg.obs_noise_std, cfg.action_noise_std = 0.01, 0.02
+        cfg.dyn_scale_min, cfg.dyn_scale_max = 0.9, 1.1
+    rng = np.random.default_rng(10 * obs_type + delay)
+    for precision, tol in (("f32", (2e-5, 2e-3, 2e-3)), ("f64", (1e-4, 1e-2, 1e-2))):
+        hip, orc = pair(HipEnv, cfg, precision)
+        seed_both(hip, orc, rng, n, cfg)
+        hip.step_count = 7
+        orc.step_count = 7
+        hip.bind_reward_matrix()
+        orc.bind_reward_matrix()
+        actions = rng.uniform(-1.3, 1.3, (n, 2))
+        out = hip.step(actions)
+        orc.step(actions)
+        compare_step(out, orc, hip, *tol)
+        np.testing.assert_allclose(hip.reward_matrix_t.cpu().numpy(), orc.reward_matrix, rtol=1e-4, atol=10 * tol[1])
+        assert hip.step_count == 8
+        assert orc.reset_buf.sum() > 0 and orc.timeouts.sum() > 0
+        hip.close(); orc.close()
+
+
+def test_first_step_resets_everything(HipEnv):
+    """reset_buf starts at ones (vec_task.py:275): the first step simulates the zero pose, then resets all envs."""
+    n = 512
+    cfg = base_cfg(n)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    a = np.zeros((n, 2))
+    out = hip.step(a)
+    orc.step(a)
+    compare_step(out, orc, hip, 1e-6, 1e-4, 1e-4)
+    assert (hip.progress == 0).all()
+    st = hip.state
+    assert np.abs(st[abi.VF_Q0 + 1:abi.VF_Q0 + 6]).max() <= np.radians(10) + 1e-6
+    assert (st[QVEL] == 0).all()
+
+
+def test_trajectory_tracks_oracle(HipEnv):
+    """40 consecutive steps (1600 substeps) with resets: float32 round-off may grow, flags must stay identical
+    for every env whose decision margins are not within round-off."""
+    n, T = 256, 40
+    cfg = base_cfg(n, max_episode_length=25)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    rng = np.random.default_rng(5)
+    worst_q = 0.0
+    mismatched = np.zeros(n, bool)
+    for t in range(T):
+        a = rng.uniform(-1, 1, (n, 2))
+        obs, rew, rst, to = hip.step(a)
+        orc.step(a)
+        mismatched |= (rst != orc.reset_buf)
+        ok = ~mismatched
+        worst_q = max(worst_q, np.abs(hip.state[QPOS][:, ok] - orc.state[QPOS][:, ok]).max())
+    assert mismatched.mean() < 0.02          # threshold decisions flipped by round-off only
+    assert worst_q < 5e-3
+
+
+@pytest.mark.parametrize("tag,delay,obs_type", [("delay1", 1, 0), ("delay0_tipobs", 0, 1), ("delay2", 2, 0)])
+def test_golden_trajectory_from_reference(HipEnv, golden, tag, delay, obs_type):
+    """F6: the reference's real VecTask.step over 64 steps (fixture), replayed on the GPU."""
+    g = golden("f6_traj_" + tag)
+    T, N, _ = g["actions"].shape
+    cfg = f6_cfg(N, delay, obs_type)
+    hip = HipEnv(cfg)
+    for t in range(T):
+        hip.bind_reset_values(g["reset_values"][t])
+        np.testing.assert_array_equal(hip.reset_buf.astype(bool), g["did_reset"][t])
+        obs, rew, rst, to = hip.step(g["actions"][t])
+        np.testing.assert_array_equal(rst, g["reset"][t])
+        np.testing.assert_array_equal(to.astype(bool), g["timeouts"][t])
+        np.testing.assert_array_equal(hip.progress, g["progress"][t])
+        np.testing.assert_allclose(hip.state[QPOS].T, g["q"][t], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-3, atol=3e-3)
+        np.testing.assert_allclose(rew, g["rew"][t], rtol=1e-4, atol=1e-3)
+
+
+def test_reset_idx_outside_step(HipEnv):
+    n = 300
+    cfg = base_cfg(n)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    ids = np.arange(0, n, 3)
+    hip.reset_idx(ids)
+    orc.reset_idx(ids)
+    np.testing.assert_allclose(hip.state, orc.state, rtol=0, atol=1e-6)
+    assert (hip.reset_buf[ids] == 0).all() and (hip.reset_buf[1::3] == 1).all()
+    hip.reset_idx(np.zeros(0, np.int64))    # empty id list is a no-op
+
+
+def test_full_size_properties(HipEnv):
+    """BASELINE config 3 size (16384 envs): determinism, bounds, episode bookkeeping over 600 steps."""
+    import torch
+    n, T = 16384, 600
+    cfg = base_cfg(n, randomize=True)
+    runs = []
+    for rep in range(2):
+        hip = HipEnv(cfg)
+        g = torch.Generator(device=hip.dev).manual_seed(0)
+        n_done = torch.zeros((), device=hip.dev)
+        n_to = torch.zeros((), device=hip.dev)
+        max_prog = 0
+        for t in range(T):
+            a = torch.rand((n, 2), device=hip.dev, generator=g) * 2 - 1
+            hip.step_t(a, sync=False)
+            n_done += hip.reset_t.sum()
+            n_to += hip.timeouts_t.sum()
+            assert bool(((hip.timeouts_t == 0) | (hip.reset_t != 0)).all()) if t % 100 == 0 else True
+        torch.cuda.synchronize()
+        st = hip.state_t.clone()
+        assert torch.isfinite(st).all()
+        assert float(hip.obs_t.abs().max()) <= 5.0
+        assert int(hip.progress_t.max()) <= cfg.max_episode_length - 1
+        assert float(st[abi.VF_QD0 + 1:abi.VF_QD0 + 6].abs().max()) < 50
+        assert float(n_done) > 0 and float(n_to) > 0
+        runs.append((st, hip.obs_t.clone(), hip.rew_t.clone(), float(n_done)))
+        assert hip.step_count == T
+        hip.close()
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][3] == runs[1][3]
+
+
+def test_envs_are_independent_of_batch_position(HipEnv):
+    """Sharding property used by the multi-GPU path: env i of a big batch == the same env stepped alone,
+    given the same state, action and (seed, env id, step) RNG key."""
+    n = 256
+    cfg = base_cfg(n, randomize=False)
+    rng = np.random.default_rng(3)
+    hip = HipEnv(cfg)
+    st = random_state(rng, n, cfg)
+    hip.set_state(st)
+    hip.set_flags(np.zeros(n, np.int64), np.full(n, 5))
+    a = rng.uniform(-1, 1, (n, 2))
+    obs, rew, rst, to = hip.step(a)
+    sub = slice(64, 128)
+    cfg2 = base_cfg(64, randomize=False)
+    hip2 = HipEnv(cfg2)
+    hip2.set_state(st[:, sub])
+    hip2.set_flags(np.zeros(64, np.int64), np.full(64, 5))
+    obs2, rew2, rst2, to2 = hip2.step(a[sub])
+    np.testing.assert_array_equal(obs[sub], obs2)
+    np.testing.assert_array_equal(rew[sub], rew2)
+    np.testing.assert_array_equal(rst[sub], rst2)
+
+
+def test_task_class_step_contract(HipEnv):
+    """The Python drop-in: shapes, dtypes, devices and first-step semantics of VecTask.step/reset."""
+    import torch
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    from vine_robot_isaacgymenvs_amd.utils.config import load_task_config
+    cfg = load_task_config("Vine5LinkMovingBase", overrides=["num_envs=128", "task.env.CREATE_PIPE=False"])
+    env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg, rl_device="cuda:0", sim_device="cuda:0",
+                                                  graphics_device_id=0, headless=True, virtual_screen_capture=False,
+                                                  force_render=False)
+    assert env.num_envs == 128 and env.num_obs == 28 and env.num_acts == 2 and env.num_states == 0
+    assert env.observation_space.shape == (28,) and env.action_space.shape == (2,)
+    first = env.reset()
+    assert first["obs"].shape == (128, 28) and float(first["obs"].abs().max()) == 0.0
+    obs, rew, done, info = env.step(env.zero_actions())
+    assert obs["obs"].shape == (128, 28) and obs["obs"].dtype == torch.float32
+    assert rew.shape == (128,) and done.dtype == torch.long and info["time_outs"].dtype == torch.bool
+    assert int(env.progress_buf.max()) == 0                      # everything was reset inside the first step
+    assert env.dof_pos.shape == (128, 6) and env.tip_positions.shape == (128, 3)
+    for _ in range(5):
+        obs, rew, done, info = env.step(torch.rand(128, 2, device="cuda:0") * 2 - 1)
+    assert int(env.progress_buf.max()) == 5
+    assert float(obs["obs"].abs().max()) <= 5.0
+    env.close()

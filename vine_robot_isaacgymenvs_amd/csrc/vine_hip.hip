@@ -1,0 +1,869 @@
+// vine_hip.hip — Vine5LinkMovingBase env step for MI355X (gfx950), hand-written HIP.
+//
+// One kernel launch = one VecTask.step for all envs (reference call stack: vec_task.py:319-380 ->
+// Vine5LinkMovingBase.py:922-945, 1028-1106, 1110-1120, 774-839, 1339-1390, 1218-1331, 1540-1558;
+// `gym.simulate` (PhysX, closed) is replaced by a closed-form planar 6-DoF articulation solve).
+//
+// Design:
+//  * env-major SoA state (`state[field * N + env]`): every load/store of a wave is one contiguous
+//    256-B segment per field.
+//  * the whole step (pre -> 4 x [actuation, 10 substeps] -> reset -> obs -> reward -> reset flags)
+//    runs out of registers; HBM sees ~320 B per env-step.
+//  * dynamics in absolute link angles: M_ij = a_ij cos(th_i - th_j) with constant a_ij, so the
+//    mass matrix costs 5 sincos + 20 FMAs; 6x6 Cholesky fully unrolled in VGPRs.
+//  * model constants travel in the kernarg segment (scalar loads into SGPRs), not in LDS.
+//  * no host sync, no allocation, no device-wide barrier inside a step: graph-capturable.
+//    The step counter (RNG counter / FIFO slot) lives in device memory and is advanced by the
+//    last workgroup to finish (ticket), so a captured launch replays correctly.
+//
+// Exports the C ABI of include/vine.h.  There is no CPU fallback in this library.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/vine.h"
+
+#define NL VINE_NUM_LINKS
+#define ND VINE_NUM_DOFS
+
+namespace {
+
+thread_local char g_err[256];
+int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return VINE_ERR_DEVICE;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+// Everything the kernels need, precomputed on the host from VineConfig; passed by value (kernarg).
+struct DevParams {
+    int n, num_obs, obs_type, cfi, substeps, max_len, delay;
+    unsigned flags, seed_lo, seed_hi;
+    float hsub, dt, cdt, clip_obs, clip_act;
+    float fpam_min, fpam_span, rail_scale, damping, kq, cad;
+    float soft_limit, p_gain, d_gain, rail_acc, alpha_inf, alpha_def, success_dist;
+    float cart_min, cart_span, ty_min, ty_span, tz_min, tz_span, depth_min, depth_span, ty_max, tz_fixed;
+    float dyn_min, dyn_span, obs_noise, act_noise;
+    float g, mtot, s0, c0, L, z1;
+    float b[NL], gb[NL], I[NL];
+    float a[NL][NL];
+    float K[NL], C[NL], bb[NL], B[NL];
+    float rw[VINE_NUM_REWARDS];
+    float obs_scale[VINE_MAX_OBS];
+};
+
+enum { RNG_RESET = 1, RNG_ACTION_NOISE = 2, RNG_DYN_SCALE = 3, RNG_OBS_NOISE = 4 };
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                              unsigned k1, unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void rng4(const DevParams& P, unsigned env, unsigned long long step, unsigned purpose,
+                                     unsigned idx, unsigned out[4]) {
+    philox4x32_10(env, (unsigned)step, purpose | ((unsigned)(step >> 32) << 8), idx, P.seed_lo, P.seed_hi, out);
+}
+__device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void normal2(unsigned a, unsigned b, float& n0, float& n1) {
+    float u1 = 1.0f - u01(a), u2 = u01(b);
+    float r = sqrtf(-2.0f * logf(u1));
+    float t = 6.283185307179586f * u2;
+    n0 = r * cosf(t);
+    n1 = r * sinf(t);
+}
+
+// Articulation state in absolute coordinates: cart (y, vy), link angles th_k = sum_{i<=k} q_i, rates w_k.
+struct Dyn {
+    float y, vy, th[NL], w[NL];
+};
+
+// One semi-implicit Euler substep.  eff[6] = held efforts (rail force, joint torques), cj[6] = per-DOF
+// damping, hc[6] = h * cj (implicit part), all constant over one `simulate`.
+//   row 0:  mtot*ydd - sum_i b_i cos(phi_i) thdd_i = F - cj0*vy - sum_i b_i sin(phi_i) w_i^2
+//   row i: -b_i cos(phi_i) ydd + sum_j a_ij cos(th_i-th_j) thdd_j
+//            = T_i - T_{i+1} - cad*I_i*w_i - sum_j a_ij sin(th_i-th_j) w_j^2 + g b_i sin(phi_i)
+template <bool IMPLICIT>
+__device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float (&eff)[ND], const float (&cj)[ND],
+                                        const float (&hc)[ND]) {
+    float sn[NL], cs[NL], sp[NL], cp[NL], w2[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        sincosf(s.th[i], &sn[i], &cs[i]);
+        sp[i] = P.s0 * cs[i] + P.c0 * sn[i];
+        cp[i] = P.c0 * cs[i] - P.s0 * sn[i];
+        w2[i] = s.w[i] * s.w[i];
+    }
+    float T[NL + 1];
+    T[0] = eff[1] - cj[1] * s.w[0] - P.kq * s.th[0];
+#pragma unroll
+    for (int i = 1; i < NL; ++i) T[i] = eff[i + 1] - cj[i + 1] * (s.w[i] - s.w[i - 1]) - P.kq * (s.th[i] - s.th[i - 1]);
+    T[NL] = 0.0f;
+
+    float A[ND][ND];  // lower triangle used
+    float r[ND];
+    A[0][0] = P.mtot;
+    r[0] = eff[0] - cj[0] * s.vy;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        A[i + 1][0] = -P.b[i] * cp[i];
+        r[0] -= P.b[i] * sp[i] * w2[i];
+        r[i + 1] = T[i] - T[i + 1] - P.cad * P.I[i] * s.w[i] + P.gb[i] * sp[i];
+        A[i + 1][i + 1] = P.a[i][i];
+    }
+#pragma unroll
+    for (int i = 1; i < NL; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            float cd = cs[i] * cs[j] + sn[i] * sn[j];
+            float sd = sn[i] * cs[j] - cs[i] * sn[j];
+            float asd = P.a[i][j] * sd;
+            A[i + 1][j + 1] = P.a[i][j] * cd;
+            r[i + 1] -= asd * w2[j];
+            r[j + 1] += asd * w2[i];
+        }
+    }
+    if (IMPLICIT) {
+        A[0][0] += hc[0];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            float cn = (i < NL - 1) ? hc[i + 2] : 0.0f;
+            A[i + 1][i + 1] += hc[i + 1] + cn + P.hsub * P.cad * P.I[i];
+            if (i < NL - 1) A[i + 2][i + 1] -= cn;
+        }
+    }
+    // Cholesky A = L L^T in place (lower), then forward/back substitution; fully unrolled.
+    float inv[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        float d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+        float ri = rsqrtf(d);
+        inv[j] = ri;
+#pragma unroll
+        for (int i = j + 1; i < ND; ++i) {
+            float t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
+            A[i][j] = t * ri;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        float t = r[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= A[i][k] * r[k];
+        r[i] = t * inv[i];
+    }
+#pragma unroll
+    for (int i = ND - 1; i >= 0; --i) {
+        float t = r[i];
+#pragma unroll
+        for (int k = i + 1; k < ND; ++k) t -= A[k][i] * r[k];
+        r[i] = t * inv[i];
+    }
+    s.vy += P.hsub * r[0];
+    s.y += P.hsub * s.vy;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        s.w[i] += P.hsub * r[i + 1];
+        s.th[i] += P.hsub * s.w[i];
+    }
+}
+
+__device__ __forceinline__ float clampf(float v, float lim) { return fminf(fmaxf(v, -lim), lim); }
+
+#define ST(f) st[(size_t)(f) * n + e]
+
+// reset_idx for one env (Vine5LinkMovingBase.py:774-839, 887-914).  Writes the persistent fields and
+// returns the new relative joint positions / target in registers.
+__device__ __forceinline__ void reset_env(const DevParams& P, float* __restrict__ st, int n, int e,
+                                          unsigned long long step, const float* __restrict__ reset_values,
+                                          float (&qn)[ND], float& ty, float& tz) {
+    const float ten = 0.17453292519943295f;  // math.radians(10)
+    float depth;
+    if (reset_values) {
+        const float* v = reset_values + (size_t)e * 10;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) qn[k + 1] = v[k];
+        qn[0] = v[5]; ty = v[7]; tz = v[8]; depth = v[9];
+    } else {
+        unsigned r0[4], r1[4], r2[4];
+        rng4(P, (unsigned)e, step, RNG_RESET, 0, r0);
+        rng4(P, (unsigned)e, step, RNG_RESET, 1, r1);
+        rng4(P, (unsigned)e, step, RNG_RESET, 2, r2);
+        qn[1] = -ten + (2.0f * ten) * u01(r0[0]);
+        qn[2] = -ten + (2.0f * ten) * u01(r0[1]);
+        qn[3] = -ten + (2.0f * ten) * u01(r0[2]);
+        qn[4] = -ten + (2.0f * ten) * u01(r0[3]);
+        qn[5] = -ten + (2.0f * ten) * u01(r1[0]);
+        qn[0] = P.cart_min + P.cart_span * u01(r1[1]);
+        ty = P.ty_min + P.ty_span * u01(r1[3]);
+        tz = P.tz_min + P.tz_span * u01(r2[0]);
+        depth = P.depth_min + P.depth_span * u01(r2[1]);
+    }
+    if (!(P.flags & VINE_FLAG_RANDOMIZE_DOF_INIT)) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) qn[i] = 0.0f;
+    }
+    if (!(P.flags & VINE_FLAG_RANDOMIZE_TARGETS)) { ty = P.ty_max; tz = P.tz_fixed; }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        ST(VF_Q0 + i) = qn[i];
+        ST(VF_QD0 + i) = 0.0f;
+        ST(VF_PREV_Q0 + i) = qn[i];
+    }
+    ST(VF_TARGET_Y) = ty;
+    ST(VF_TARGET_Z) = tz;
+    if (P.flags & VINE_FLAG_CREATE_SHELF) {
+        ST(VF_SHELF_Y) = ty + (-0.2f + depth);
+        ST(VF_SHELF_Z) = tz - 0.01f;
+        ST(VF_OBJ_DEPTH) = depth;
+    }
+}
+
+// Forward kinematics of the tip body from absolute angles.
+__device__ __forceinline__ void tip_fk(const DevParams& P, float y, float vy, const float (&th)[NL],
+                                       const float (&w)[NL], float (&tip)[4]) {
+    float ty = y, tz = P.z1, tvy = vy, tvz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        float s, c;
+        sincosf(th[k], &s, &c);
+        float sp = P.s0 * c + P.c0 * s, cp = P.c0 * c - P.s0 * s;
+        ty -= P.L * sp; tz += P.L * cp;
+        tvy -= P.L * w[k] * cp; tvz -= P.L * w[k] * sp;
+    }
+    tip[0] = ty; tip[1] = tz; tip[2] = tvy; tip[3] = tvz;
+}
+
+template <int OBS_TYPE, bool RANDOMIZE>
+__global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float* __restrict__ st,
+                                                       const float* __restrict__ actions, float* __restrict__ obs,
+                                                       float* __restrict__ rew, long long* __restrict__ reset,
+                                                       long long* __restrict__ progress,
+                                                       unsigned char* __restrict__ timeouts,
+                                                       float* __restrict__ reward_matrix,
+                                                       const float* __restrict__ reset_values,
+                                                       unsigned long long* __restrict__ counters) {
+    const int n = P.n;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long step = counters[0];
+    if (e < n) {
+        // ---- VecTask.step: clamp actions (vec_task.py:333) ----
+        const float2 act = reinterpret_cast<const float2*>(actions)[e];
+        float a0 = clampf(act.x, P.clip_act), a1 = clampf(act.y, P.clip_act);
+        // ---- pre_physics_step (V5:922-945) ----
+        if (RANDOMIZE && P.act_noise != 0.0f) {
+            unsigned r[4];
+            float n0, n1;
+            rng4(P, (unsigned)e, step, RNG_ACTION_NOISE, 0, r);
+            normal2(r[0], r[1], n0, n1);
+            a0 += P.act_noise * n0;
+            a1 += P.act_noise * n1;
+        }
+        float new_rail = a0 * P.rail_scale;
+        float new_fpam = (a1 + 1.0f) / 2.0f * P.fpam_span + P.fpam_min;
+        float u_rail = new_rail, u_fpam = new_fpam;
+        if (P.delay > 0) {
+            int slot = (int)(step % (unsigned long long)P.delay);
+            u_rail = ST(VF_FIFO0 + 2 * slot);
+            u_fpam = ST(VF_FIFO0 + 2 * slot + 1);
+            ST(VF_FIFO0 + 2 * slot) = new_rail;
+            ST(VF_FIFO0 + 2 * slot + 1) = new_fpam;
+        }
+        if (P.flags & VINE_FLAG_FORCE_U_FPAM) u_fpam = 0.0f;
+        if (P.flags & VINE_FLAG_FORCE_U_RAIL_VELOCITY) u_rail = 0.0f;
+        float smoothed = ST(VF_SMOOTHED_U);
+        {
+            float alpha = (u_fpam > smoothed) ? P.alpha_inf : P.alpha_def;
+            smoothed = alpha * smoothed + (1.0f - alpha) * u_fpam;
+        }
+        float q[ND], qd[ND], prev_q[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            q[i] = ST(VF_Q0 + i);
+            qd[i] = ST(VF_QD0 + i);
+            prev_q[i] = q[i];
+        }
+        float tip[4] = {ST(VF_TIP_Y), ST(VF_TIP_Z), ST(VF_TIP_VY), ST(VF_TIP_VZ)};
+        float prev_tip_y = tip[0], prev_tip_z = tip[1];
+        float prev_u_rail = u_rail;
+        float cart_y = ST(VF_CART_Y), cart_vy = ST(VF_CART_VY);
+        float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
+        float rail_force = 0.0f;
+        const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
+        const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
+
+        Dyn s;
+        s.y = q[0];
+        s.vy = qd[0];
+        {
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                a += q[k + 1];
+                b += qd[k + 1];
+                s.th[k] = a;
+                s.w[k] = b;
+            }
+        }
+        // ---- control_freq_inv x [refresh, actuation (V5:1028-1106), simulate] (vec_task.py:338-356) ----
+        for (int it = 0; it < P.cfi; ++it) {
+            float sc[20];
+            if (RANDOMIZE && P.dyn_span != 0.0f) {
+#pragma unroll
+                for (int g = 0; g < 5; ++g) {
+                    unsigned r[4];
+                    rng4(P, (unsigned)e, step, RNG_DYN_SCALE, (unsigned)(it * 5 + g), r);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sc[g * 4 + k] = P.dyn_min + P.dyn_span * u01(r[k]);
+                }
+            } else if (RANDOMIZE) {
+#pragma unroll
+                for (int k = 0; k < 20; ++k) sc[k] = P.dyn_min;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 20; ++k) sc[k] = 1.0f;
+            }
+            float eff[ND], cj[ND], hc[ND];
+            cj[0] = P.damping;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                float qj = (j == 0) ? s.th[0] : s.th[j] - s.th[j - 1];
+                float qdj = (j == 0) ? s.w[0] : s.w[j] - s.w[j - 1];
+                float t = P.K[j] * sc[j] * qj;
+                float cv = P.C[j] * sc[5 + j];
+                if (held) t += cv * qdj;
+                t += P.bb[j] * sc[10 + j];
+                t += P.B[j] * sc[15 + j] * u_used;
+                eff[j + 1] = -t;
+                cj[j + 1] = P.damping + (held ? 0.0f : cv);
+            }
+            {
+                float err = u_rail - cart_vy;
+                float fmax = P.rail_acc / 2.0f;
+                float minmax = (err > 0.0f) ? fmax : -fmax;
+                float accel = (cart_vy - pcv) / P.dt;
+                float accel_target = (err > 0.0f) ? P.rail_acc : -P.rail_acc;
+                minmax += 0.30f * (accel_target - accel);
+                float pid = P.p_gain * err + P.d_gain * (err - pce);
+                eff[0] = (fabsf(err) > 0.1f) ? minmax : pid;
+                pce = err;
+                pcv = cart_vy;
+                rail_force = eff[0];
+            }
+#pragma unroll
+            for (int i = 0; i < ND; ++i) hc[i] = P.hsub * cj[i];
+            if (P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) {
+                for (int k = 0; k < P.substeps; ++k) substep<true>(P, s, eff, cj, hc);
+            } else {
+                for (int k = 0; k < P.substeps; ++k) substep<false>(P, s, eff, cj, hc);
+            }
+            cart_y = s.y;
+            cart_vy = s.vy;
+        }
+        // refreshed rigid-body states after the last simulate
+        tip_fk(P, s.y, s.vy, s.th, s.w, tip);
+        q[0] = s.y;
+        qd[0] = s.vy;
+        q[1] = s.th[0];
+        qd[1] = s.w[0];
+#pragma unroll
+        for (int k = 1; k < NL; ++k) {
+            q[k + 1] = s.th[k] - s.th[k - 1];
+            qd[k + 1] = s.w[k] - s.w[k - 1];
+        }
+
+        // ---- post_physics_step (V5:1110-1120) ----
+        long long prog = progress[e] + 1;
+        long long rst = reset[e];
+        float agg = ST(VF_AGG_REW);
+        float ty = ST(VF_TARGET_Y), tz = ST(VF_TARGET_Z);
+        if (rst != 0) {  // reset requested by the previous step's reward pass (V5:1114-1116)
+            float qn[ND];
+            reset_env(P, st, n, e, step, reset_values, qn, ty, tz);
+            rst = 0;
+            prog = 0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                q[i] = qn[i];
+                qd[i] = 0.0f;
+                prev_q[i] = qn[i];
+            }
+            if (P.flags & VINE_FLAG_STALE_BODY_STATE_AFTER_RESET) {
+                // tip/cart rigid-body states keep their pre-reset values (V5:796-797 TODO)
+                prev_tip_y = tip[0];
+                prev_tip_z = tip[1];
+            } else {
+                float th[NL], w[NL] = {0, 0, 0, 0, 0};
+                float a = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NL; ++k) { a += qn[k + 1]; th[k] = a; }
+                tip_fk(P, qn[0], 0.0f, th, w, tip);
+                prev_tip_y = tip[0];
+                prev_tip_z = tip[1];
+                cart_y = qn[0];
+                cart_vy = 0.0f;
+            }
+            prev_u_rail = 0.0f;
+            pce = 0.0f;
+            agg = 0.0f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                ST(VF_Q0 + i) = q[i];
+                ST(VF_QD0 + i) = qd[i];
+                ST(VF_PREV_Q0 + i) = prev_q[i];
+            }
+        }
+        const float obj_depth = ST(VF_OBJ_DEPTH), obj_angle = ST(VF_OBJ_ANGLE);
+
+        // compute_observations (V5:1339-1390)
+        float o[VINE_MAX_OBS];
+        int k = 0;
+        if (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) o[k++] = q[i];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) / P.cdt;
+        } else {
+            o[k++] = q[0];
+            o[k++] = (q[0] - prev_q[0]) / P.cdt;
+        }
+        o[k++] = 0.0f; o[k++] = tip[0]; o[k++] = tip[1];
+        o[k++] = 0.0f; o[k++] = (tip[0] - prev_tip_y) / P.cdt; o[k++] = (tip[1] - prev_tip_z) / P.cdt;
+        o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
+        o[k++] = 0.0f; o[k++] = 0.0f; o[k++] = 0.0f;
+        o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
+        constexpr int NOBS = (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) ? 28 : 18;
+#pragma unroll
+        for (int i = 0; i < NOBS; ++i) o[i] = o[i] / P.obs_scale[i];
+        if (RANDOMIZE && P.obs_noise != 0.0f) {
+#pragma unroll
+            for (int i = 0; i < NOBS; i += 4) {
+                unsigned r[4];
+                float nn[4];
+                rng4(P, (unsigned)e, step, RNG_OBS_NOISE, (unsigned)(i / 4), r);
+                normal2(r[0], r[1], nn[0], nn[1]);
+                normal2(r[2], r[3], nn[2], nn[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j < NOBS) o[i + j] += P.obs_noise * nn[j];
+            }
+        }
+        // compute_reward (V5:1218-1331) + compute_reward_jit (V5:1470-1537)
+        const float dy = tip[0] - ty, dz = tip[1] - tz;
+        const float dist = sqrtf(dy * dy + dz * dz);
+        const bool reached = dist < P.success_dist;
+        const bool limit_hit = (cart_y > P.soft_limit) || (cart_y < -P.soft_limit);
+        const bool tip_limit_hit = tip[0] < ty;
+        const float cmean = 0.0f;  // CREATE_SHELF contacts: not built in this kernel yet
+        const float vnorm = sqrtf(tip[2] * tip[2] + tip[3] * tip[3]);
+        float rm[VINE_NUM_REWARDS];
+        rm[0] = -dist;
+        rm[1] = -1.0f;
+        rm[2] = reached ? 1000.0f : 0.0f;
+        rm[3] = -(reached ? vnorm : 0.0f);
+        rm[4] = vnorm;
+        rm[5] = -fabsf(u_rail);
+        rm[6] = -fabsf(u_fpam);
+        rm[7] = -fabsf(u_rail - prev_u_rail);
+        rm[8] = -fabsf(u_fpam - smoothed);
+        rm[9] = limit_hit ? -100.0f : 0.0f;
+        rm[10] = -fabsf(cart_y);
+        rm[11] = tip_limit_hit ? -100.0f : 0.0f;
+        rm[12] = -((cmean > 0.0f) ? cmean : 0.0f);
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VINE_NUM_REWARDS; ++i) total += rm[i] * P.rw[i];
+        agg += total;
+        // compute_reset_jit (V5:1540-1558)
+        if (prog >= (long long)P.max_len - 1) rst = 1;
+        if (reached && (P.flags & VINE_FLAG_USE_TARGET_REACHED_RESET)) rst = 1;
+        if (tip_limit_hit && (P.flags & VINE_FLAG_USE_TIP_LIMIT_HIT_RESET)) rst = 1;
+        if (limit_hit) rst = 1;
+        // ---- VecTask.step epilogue (vec_task.py:366-380) ----
+        const unsigned char to = (prog >= (long long)P.max_len - 1) && (rst != 0);
+        float* orow = obs + (size_t)e * NOBS;
+        if (NOBS % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < NOBS; i += 4)
+                reinterpret_cast<float4*>(orow)[i / 4] = make_float4(clampf(o[i], P.clip_obs), clampf(o[i + 1], P.clip_obs),
+                                                                     clampf(o[i + 2], P.clip_obs), clampf(o[i + 3], P.clip_obs));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NOBS; i += 2)
+                reinterpret_cast<float2*>(orow)[i / 2] = make_float2(clampf(o[i], P.clip_obs), clampf(o[i + 1], P.clip_obs));
+        }
+        rew[e] = total;
+        reset[e] = rst;
+        progress[e] = prog;
+        timeouts[e] = to;
+        if (reward_matrix) {
+#pragma unroll
+            for (int i = 0; i < VINE_NUM_REWARDS; ++i) reward_matrix[(size_t)e * VINE_NUM_REWARDS + i] = rm[i];
+        }
+        // persistent state
+        ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1]; ST(VF_TIP_VY) = tip[2]; ST(VF_TIP_VZ) = tip[3];
+        ST(VF_CART_Y) = cart_y; ST(VF_CART_VY) = cart_vy;
+        ST(VF_PREV_TIP_Y) = prev_tip_y; ST(VF_PREV_TIP_Z) = prev_tip_z;
+        ST(VF_SMOOTHED_U) = smoothed; ST(VF_U_FPAM) = u_fpam; ST(VF_U_RAIL) = u_rail;
+        ST(VF_PREV_U_RAIL) = prev_u_rail;
+        ST(VF_PREV_CART_VEL) = pcv; ST(VF_PREV_CART_VEL_ERR) = pce;
+        ST(VF_AGG_REW) = agg; ST(VF_RAIL_FORCE) = rail_force;
+    }
+    // ---- advance the step counter once every workgroup has read it (ticket) ----
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned long long ticket = atomicAdd(&counters[1], 1ull);
+        if (ticket == (unsigned long long)gridDim.x - 1) {
+            counters[1] = 0ull;
+            counters[0] = step + 1ull;
+            __threadfence();
+        }
+    }
+}
+
+// reset_idx(env_ids) from outside the step (vec_task.py:412-427; V5:715-718).
+__global__ void vine_reset_idx_kernel(const DevParams P, float* __restrict__ st, const long long* __restrict__ env_ids,
+                                      long long count, float* __restrict__ rew, long long* __restrict__ reset,
+                                      long long* __restrict__ progress, const float* __restrict__ reset_values,
+                                      const unsigned long long* __restrict__ counters) {
+    const int n = P.n;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    long long id = env_ids[i];
+    if (id < 0 || id >= n) return;
+    const int e = (int)id;
+    const unsigned long long step = counters[0] | (1ull << 62);
+    float qn[ND], ty, tz;
+    reset_env(P, st, n, e, step, reset_values, qn, ty, tz);
+    ST(VF_PREV_TIP_Y) = ST(VF_TIP_Y);
+    ST(VF_PREV_TIP_Z) = ST(VF_TIP_Z);
+    ST(VF_PREV_U_RAIL) = 0.0f;
+    ST(VF_PREV_CART_VEL_ERR) = 0.0f;
+    ST(VF_AGG_REW) = 0.0f;
+    if (!(P.flags & VINE_FLAG_STALE_BODY_STATE_AFTER_RESET)) {
+        float th[NL], w[NL] = {0, 0, 0, 0, 0}, tip[4];
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { a += qn[k + 1]; th[k] = a; }
+        tip_fk(P, qn[0], 0.0f, th, w, tip);
+        ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1]; ST(VF_TIP_VY) = 0.0f; ST(VF_TIP_VZ) = 0.0f;
+        ST(VF_PREV_TIP_Y) = tip[0]; ST(VF_PREV_TIP_Z) = tip[1];
+        ST(VF_CART_Y) = qn[0]; ST(VF_CART_VY) = 0.0f;
+    }
+    if (reset) reset[e] = 0;
+    if (progress) progress[e] = 0;
+    if (rew) rew[e] = 0.0f;
+}
+
+// Initial asset pose: all DOFs zero (V5:440-445), body states from FK, shelf at (0, 0.2, 0) (V5:468-470).
+__global__ void vine_init_kernel(const DevParams P, float* __restrict__ st) {
+    const int n = P.n;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float th[NL] = {0, 0, 0, 0, 0}, w[NL] = {0, 0, 0, 0, 0}, tip[4];
+    tip_fk(P, 0.0f, 0.0f, th, w, tip);
+    ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1];
+    ST(VF_PREV_TIP_Y) = tip[0]; ST(VF_PREV_TIP_Z) = tip[1];
+    ST(VF_SHELF_Y) = 0.2f;
+}
+
+int validate(const VineConfig* c) {
+    if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
+    if (c->abi_version != VINE_ABI_VERSION) return fail(VINE_ERR_INVALID_ARG, "abi_version mismatch");
+    if (c->num_envs <= 0) return fail(VINE_ERR_INVALID_ARG, "num_envs must be positive");
+    if (c->control_freq_inv <= 0 || c->substeps <= 0)
+        return fail(VINE_ERR_INVALID_ARG, "control_freq_inv/substeps must be positive");
+    if (c->action_delay < 0 || c->action_delay > VINE_MAX_DELAY)
+        return fail(VINE_ERR_INVALID_ARG, "ACTION_DELAY out of range");
+    if (vine_num_obs(c) < 0) return VINE_ERR_UNSUPPORTED;
+    if (c->flags & VINE_FLAG_CREATE_SHELF)
+        return fail(VINE_ERR_UNSUPPORTED, "CREATE_SHELF contacts are not built into the HIP path yet");
+    return VINE_OK;
+}
+
+void make_params(const VineConfig& c, DevParams& P) {
+    memset(&P, 0, sizeof P);
+    P.n = c.num_envs; P.num_obs = vine_num_obs(&c); P.obs_type = c.obs_type; P.cfi = c.control_freq_inv;
+    P.substeps = c.substeps; P.max_len = c.max_episode_length; P.delay = c.action_delay; P.flags = c.flags;
+    P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32);
+    P.dt = c.dt; P.hsub = c.dt / (float)c.substeps; P.cdt = c.dt * (float)c.control_freq_inv;
+    P.clip_obs = c.clip_observations; P.clip_act = c.clip_actions;
+    P.fpam_min = c.fpam_min; P.fpam_span = (float)((double)c.fpam_max - (double)c.fpam_min);
+    P.rail_scale = c.rail_velocity_scale; P.damping = c.damping; P.kq = c.stiffness; P.cad = c.link_angular_damping;
+    P.soft_limit = c.rail_soft_limit; P.p_gain = c.rail_p_gain; P.d_gain = c.rail_d_gain; P.rail_acc = c.rail_acceleration;
+    P.alpha_inf = c.smoothing_alpha_inflate; P.alpha_def = c.smoothing_alpha_deflate; P.success_dist = c.success_dist;
+    P.cart_min = c.random_init_cart_min_y; P.cart_span = c.random_init_cart_max_y - c.random_init_cart_min_y;
+    P.ty_min = c.min_target_y; P.ty_span = c.max_target_y - c.min_target_y; P.ty_max = c.max_target_y;
+    P.tz_min = c.min_target_z; P.tz_span = c.max_target_z - c.min_target_z; P.tz_fixed = c.min_target_z;
+    P.depth_min = c.min_target_depth; P.depth_span = c.max_target_depth - c.min_target_depth;
+    P.dyn_min = c.dyn_scale_min; P.dyn_span = c.dyn_scale_max - c.dyn_scale_min;
+    P.obs_noise = c.obs_noise_std; P.act_noise = c.action_noise_std;
+    P.g = c.gravity; P.L = c.link_length; P.z1 = c.joint1_z;
+    P.s0 = (float)sin((double)c.phi0); P.c0 = (float)cos((double)c.phi0);
+    // composite constants of the absolute-angle Lagrangian, accumulated in double
+    double m[NL], mt = c.cart_mass, L = c.link_length, l = c.link_com;
+    for (int i = 0; i < NL; ++i) { m[i] = c.link_mass[i]; mt += m[i]; }
+    P.mtot = (float)mt;
+    double b[NL];
+    for (int i = 0; i < NL; ++i) {
+        double distal = 0;
+        for (int k = i + 1; k < NL; ++k) distal += m[k];
+        b[i] = m[i] * l + L * distal;
+        P.b[i] = (float)b[i];
+        P.gb[i] = (float)((double)c.gravity * b[i]);
+        P.I[i] = c.link_inertia[i];
+        P.a[i][i] = (float)(m[i] * l * l + L * L * distal + (double)c.link_inertia[i]);
+    }
+    for (int i = 0; i < NL; ++i)
+        for (int j = 0; j < NL; ++j)
+            if (i != j) P.a[i][j] = (float)(L * b[i > j ? i : j]);
+    for (int i = 0; i < NL; ++i) { P.K[i] = c.fpam_K[i]; P.C[i] = c.fpam_C[i]; P.bb[i] = c.fpam_b[i]; P.B[i] = c.fpam_B[i]; }
+    for (int i = 0; i < VINE_NUM_REWARDS; ++i) P.rw[i] = c.reward_weights[i];
+    for (int i = 0; i < VINE_MAX_OBS; ++i) P.obs_scale[i] = c.obs_scaling[i];
+}
+
+}  // namespace
+
+struct VineHandle {
+    VineConfig cfg;
+    DevParams P;
+    int device;
+    float* state;
+    bool owns_state;
+    unsigned long long* counters;  // [0] step count, [1] workgroup ticket
+    const float* reset_values;
+    float* reward_matrix;
+};
+
+namespace {
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+extern "C" {
+
+const char* vine_last_error(void) { return g_err; }
+const char* vine_backend_name(void) { return "hip-gfx950"; }
+
+int vine_config_default(VineConfig* c) {
+    if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
+    memset(c, 0, sizeof *c);
+    c->abi_version = VINE_ABI_VERSION;
+    c->num_envs = 4096;
+    c->control_freq_inv = 4;
+    c->substeps = 10;
+    c->max_episode_length = 500;
+    c->action_delay = 1;
+    c->flags = VINE_FLAG_USE_SMOOTHED_FPAM | VINE_FLAG_RANDOMIZE_DOF_INIT | VINE_FLAG_RANDOMIZE_TARGETS |
+               VINE_FLAG_USE_TARGET_REACHED_RESET | VINE_FLAG_VINE_RANDOMIZE | VINE_FLAG_STALE_BODY_STATE_AFTER_RESET |
+               VINE_FLAG_IMPLICIT_JOINT_DAMPING;
+    c->seed = 42;
+    c->dt = 0.00833f; c->gravity = 9.81f; c->clip_observations = 5.0f; c->clip_actions = 1.0f;
+    c->fpam_min = -0.1f; c->fpam_max = 3.0f; c->rail_velocity_scale = 1.0f;
+    c->damping = 2e-2f; c->stiffness = 0.0f;
+    c->rail_soft_limit = 0.3f; c->rail_p_gain = 10.0f; c->rail_d_gain = 0.0f; c->rail_acceleration = 8.0f;
+    c->smoothing_alpha_inflate = 0.81f; c->smoothing_alpha_deflate = 0.86f;
+    c->random_init_cart_min_y = (float)(-0.1 * 0.3); c->random_init_cart_max_y = 0.3f;
+    c->success_dist = 0.08f;
+    c->min_target_depth = -0.05f; c->max_target_depth = 0.2f;
+    c->min_target_y = -0.48f; c->max_target_y = -0.4f; c->min_target_z = 0.58f; c->max_target_z = 0.67f;
+    const float w[VINE_NUM_REWARDS] = {0, 0, 1.0f, 0, 0.1f, 0, 0, 0, 0, 1.0f, 0, 0, 0.10f};
+    memcpy(c->reward_weights, w, sizeof w);
+    c->dyn_scale_min = 0.999f; c->dyn_scale_max = 1.001f;
+    c->cart_mass = 0.4f;
+    for (int i = 0; i < NL; ++i) { c->link_mass[i] = 0.005f; c->link_inertia[i] = 0.00000689246f; }
+    c->link_mass[4] = 0.1f; c->link_inertia[4] = 0.000101559f;
+    c->link_length = 0.0885f; c->link_com = 0.04425f;
+    c->joint1_z = (float)(1.0 - 0.025 - 0.01); c->phi0 = 3.1415f;
+    const float K[NL] = {0.8385f, 1.5400f, 1.5109f, 1.2887f, 0.4347f};
+    const float C[NL] = {0.0178f, 0.0304f, 0.0528f, 0.0367f, 0.0223f};
+    const float b[NL] = {0.0007f, 0.0062f, 0.0402f, 0.0160f, 0.0133f};
+    const float B[NL] = {0.0247f, 0.0616f, 0.0779f, 0.0498f, 0.0268f};
+    memcpy(c->fpam_K, K, sizeof K); memcpy(c->fpam_C, C, sizeof C);
+    memcpy(c->fpam_b, b, sizeof b); memcpy(c->fpam_B, B, sizeof B);
+    return vine_config_set_obs_type(c, VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, 1);
+}
+
+int vine_config_set_obs_type(VineConfig* c, int obs_type, int scale_observations) {
+    if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
+    // per-column scales of the two observation layouts the reference can scale (V5:246-266)
+    const float joint_pos[6] = {0.12f, 0.269f, 0.148f, 0.249f, 0.148f, 0.344f};
+    const float joint_vel[6] = {0.67f, 2.22f, 1.47f, 1.14f, 0.903f, 0.716f};
+    const float tail[16] = {0.0656f, 0.238f, 0.0656f, 0.732f, 2.0f, 0.732f, 0.02f, 0.0235f,
+                            0.02f, 0.732f, 2.0f, 0.732f, 0.845f, 0.86f, 0.0385f, 0.5f};
+    if (obs_type != VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO && obs_type != VINE_OBS_TIP_AND_CART_AND_OBJ_INFO)
+        return fail(VINE_ERR_UNSUPPORTED, "observation type not supported (only the two scalable types)");
+    c->obs_type = obs_type;
+    for (int i = 0; i < VINE_MAX_OBS; ++i) c->obs_scaling[i] = 1.0f;
+    if (scale_observations) {
+        c->flags |= VINE_FLAG_SCALE_OBSERVATIONS;
+        int k = 0;
+        const int nj = (obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) ? 6 : 1;
+        for (int i = 0; i < nj; ++i) c->obs_scaling[k++] = joint_pos[i];
+        for (int i = 0; i < nj; ++i) c->obs_scaling[k++] = joint_vel[i];
+        for (int i = 0; i < 16; ++i) c->obs_scaling[k++] = tail[i];
+    } else {
+        c->flags &= ~(uint32_t)VINE_FLAG_SCALE_OBSERVATIONS;
+    }
+    return VINE_OK;
+}
+
+int vine_num_obs(const VineConfig* c) {
+    if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
+    if (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) return 28;
+    if (c->obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO) return 18;
+    return fail(VINE_ERR_UNSUPPORTED, "observation type not supported");
+}
+
+int vine_create(const VineConfig* cfg, int device_id, float* state_storage, VineHandle** out) {
+    int rc = validate(cfg);
+    if (rc) return rc;
+    if (!out) return fail(VINE_ERR_INVALID_ARG, "out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(VINE_ERR_NO_DEVICE, "no HIP device: libvine_hip has no CPU path (MI355X/gfx950 only)");
+    if (device_id < 0 || device_id >= ndev) return fail(VINE_ERR_INVALID_ARG, "device_id out of range");
+    DeviceGuard guard(device_id);
+    if (!guard.ok) return fail(VINE_ERR_DEVICE, "hipSetDevice failed");
+    VineHandle* h = new (std::nothrow) VineHandle();
+    if (!h) return fail(VINE_ERR_ALLOC, "out of host memory");
+    h->cfg = *cfg;
+    h->device = device_id;
+    make_params(*cfg, h->P);
+    h->reset_values = nullptr;
+    h->reward_matrix = nullptr;
+    const size_t bytes = (size_t)VF_COUNT * cfg->num_envs * sizeof(float);
+    if (state_storage) {
+        h->state = state_storage;
+        h->owns_state = false;
+    } else {
+        hipError_t e = hipMalloc(&h->state, bytes);
+        if (e != hipSuccess) { delete h; return hip_fail(e, "hipMalloc(state)"); }
+        h->owns_state = true;
+    }
+    hipError_t e = hipMalloc(&h->counters, 2 * sizeof(unsigned long long));
+    if (e != hipSuccess) { if (h->owns_state) (void)hipFree(h->state); delete h; return hip_fail(e, "hipMalloc(counters)"); }
+    HIP_TRY(hipMemset(h->state, 0, bytes));
+    HIP_TRY(hipMemset(h->counters, 0, 2 * sizeof(unsigned long long)));
+    const int threads = 256, blocks = (cfg->num_envs + threads - 1) / threads;
+    hipLaunchKernelGGL(vine_init_kernel, dim3(blocks), dim3(threads), 0, 0, h->P, h->state);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    *out = h;
+    return VINE_OK;
+}
+
+void vine_destroy(VineHandle* h) {
+    if (!h) return;
+    DeviceGuard guard(h->device);
+    if (h->owns_state) (void)hipFree(h->state);
+    (void)hipFree(h->counters);
+    delete h;
+}
+
+int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64_t* reset, int64_t* progress,
+              uint8_t* timeouts, void* stream) {
+    if (!h || !actions || !obs || !rew || !reset || !progress || !timeouts)
+        return fail(VINE_ERR_INVALID_ARG, "null argument to vine_step");
+    DeviceGuard guard(h->device);
+    const int threads = 64;
+    const int blocks = (h->P.n + threads - 1) / threads;
+    hipStream_t s = (hipStream_t)stream;
+    const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
+#define LAUNCH(OT, RND)                                                                                      \
+    hipLaunchKernelGGL((vine_step_kernel<OT, RND>), dim3(blocks), dim3(threads), 0, s, h->P, h->state, actions, obs, \
+                       rew, (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,   \
+                       h->reset_values, h->counters)
+    if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+        if (rnd) LAUNCH(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, true);
+        else LAUNCH(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, false);
+    } else {
+        if (rnd) LAUNCH(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, true);
+        else LAUNCH(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, false);
+    }
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return VINE_OK;
+}
+
+int vine_reset_idx(VineHandle* h, const int64_t* env_ids, int64_t n, float* rew, int64_t* reset, int64_t* progress,
+                   void* stream) {
+    if (!h || (!env_ids && n > 0)) return fail(VINE_ERR_INVALID_ARG, "null argument to vine_reset_idx");
+    if (n <= 0) return VINE_OK;
+    DeviceGuard guard(h->device);
+    const int threads = 256;
+    const int blocks = (int)((n + threads - 1) / threads);
+    hipLaunchKernelGGL(vine_reset_idx_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, h->P, h->state,
+                       (const long long*)env_ids, (long long)n, rew, (long long*)reset, (long long*)progress,
+                       h->reset_values, h->counters);
+    HIP_TRY(hipGetLastError());
+    return VINE_OK;
+}
+
+int vine_bind_reset_values(VineHandle* h, const float* values) {
+    if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
+    h->reset_values = values;
+    return VINE_OK;
+}
+
+int vine_bind_reward_matrix(VineHandle* h, float* reward_matrix) {
+    if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
+    h->reward_matrix = reward_matrix;
+    return VINE_OK;
+}
+
+float* vine_state_ptr(VineHandle* h) { return h ? h->state : nullptr; }
+
+int64_t vine_get_step_count(VineHandle* h) {
+    if (!h) return -1;
+    DeviceGuard guard(h->device);
+    unsigned long long v = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&v, h->counters, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
+int vine_set_step_count(VineHandle* h, int64_t step_count) {
+    if (!h || step_count < 0) return fail(VINE_ERR_INVALID_ARG, "bad step count");
+    DeviceGuard guard(h->device);
+    unsigned long long v[2] = {(unsigned long long)step_count, 0ull};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->counters, v, sizeof v, hipMemcpyHostToDevice));
+    return VINE_OK;
+}
+
+}  // extern "C"

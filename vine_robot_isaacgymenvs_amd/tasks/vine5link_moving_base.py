@@ -1,0 +1,323 @@
+"""``Vine5LinkMovingBase`` task: host-side mirror of the reference task class
+(isaacgymenvs/tasks/Vine5LinkMovingBase.py:90-1455) on top of the fused HIP step.
+
+The per-step work of the reference's hooks -- ``pre_physics_step`` (V5:922), the 4x
+``compute_and_set_dof_actuation_force_tensor`` + ``gym.simulate`` loop (V5:1028; vec_task.py:338-356),
+``post_physics_step`` (V5:1110) with ``reset_idx`` (V5:774), ``compute_observations`` (V5:1339) and
+``compute_reward`` (V5:1218) -- is one kernel launch behind ``vine_step`` (include/vine.h).
+This class keeps the constructor signature, the buffers and the attributes callers read.
+"""
+import ctypes as C
+import logging
+import warnings
+from enum import Enum
+
+import torch
+
+from .. import abi, native
+from .base.vec_task import VecTask
+
+# Same constants as V5:48-88
+NUM_XYZ = 3
+NUM_OBJECT_INFO = 2
+N_REVOLUTE_DOFS = 5
+N_PRISMATIC_DOFS = 1
+N_PRESSURE_ACTIONS = 1
+INIT_X, INIT_Y, INIT_Z = 0.0, 0.0, 1.0
+CART_Z = 0.975  # 1.0 - 0.025 (URDF slider_to_cart origin)
+
+REWARD_NAMES = ["Position", "Const Negative", "Position Success",
+                "Velocity Success", "Velocity", "Rail Velocity Control",
+                "FPAM Control", "Rail Velocity Change", "FPAM Change", "Rail Limit",
+                "Cart Y", "Tip Y", "Contact Force"]
+_REWARD_KEYS = ["POSITION", "CONST_NEGATIVE", "POSITION_SUCCESS", "VELOCITY_SUCCESS", "VELOCITY",
+                "U_RAIL_VELOCITY_CONTROL", "U_FPAM_CONTROL", "RAIL_VELOCITY_CHANGE", "U_FPAM_CHANGE",
+                "RAIL_LIMIT", "CART_Y", "TIP_Y", "CONTACT_FORCE"]
+
+
+class ObservationType(Enum):
+    POS_ONLY = "POS_ONLY"
+    POS_AND_VEL = "POS_AND_VEL"
+    POS_AND_FD_VEL = "POS_AND_FD_VEL"
+    POS_AND_PREV_POS = "POS_AND_PREV_POS"
+    POS_AND_FD_VEL_AND_OBJ_INFO = "POS_AND_FD_VEL_AND_OBJ_INFO"
+    TIP_AND_CART_AND_OBJ_INFO = "TIP_AND_CART_AND_OBJ_INFO"
+
+
+def num_observations(observation_type: ObservationType) -> int:
+    """V5:152-170."""
+    if observation_type == ObservationType.POS_ONLY:
+        return N_REVOLUTE_DOFS + N_PRISMATIC_DOFS + NUM_XYZ + NUM_XYZ + N_PRESSURE_ACTIONS + N_PRISMATIC_DOFS
+    if observation_type == ObservationType.TIP_AND_CART_AND_OBJ_INFO:
+        return 2 * (N_PRISMATIC_DOFS + NUM_XYZ + NUM_XYZ) + N_PRESSURE_ACTIONS + N_PRISMATIC_DOFS + NUM_OBJECT_INFO
+    n = 2 * (N_REVOLUTE_DOFS + N_PRISMATIC_DOFS + NUM_XYZ + NUM_XYZ) + N_PRESSURE_ACTIONS + N_PRISMATIC_DOFS
+    if observation_type == ObservationType.POS_AND_FD_VEL_AND_OBJ_INFO:
+        n += NUM_OBJECT_INFO
+    return n
+
+
+def vine_config_from_cfg(cfg, lib, seed=None):
+    """Freeze the task config dict (reference YAML keys, cfg/task/Vine5LinkMovingBase.yaml) into the flat
+    ``VineConfig`` handed to the C ABI.  Raises like the reference for what it cannot do."""
+    env, sim, task = cfg["env"], cfg["sim"], cfg["task"]
+    c = abi.VineConfig()
+    native.check(lib.vine_config_default(C.byref(c)), lib)
+    observation_type = ObservationType[env["OBSERVATION_TYPE"]]
+    if observation_type.value not in abi.OBS_TYPE_BY_NAME:
+        # the reference raises the same for these types whenever SCALE_OBSERVATIONS is on (V5:267-268)
+        raise NotImplementedError(f"Observation scaling not implemented for {observation_type}")
+    native.check(lib.vine_config_set_obs_type(C.byref(c), abi.OBS_TYPE_BY_NAME[observation_type.value],
+                                              int(bool(env.get("SCALE_OBSERVATIONS", True)))), lib)
+    if not env.get("USE_MOVING_BASE", True):
+        raise NotImplementedError("Not implemented for non-moving base")   # V5:898
+    if len(env.get("MAT_FILE", "")) > 0:
+        raise NotImplementedError("MAT_FILE replay is out of scope of the MI355X path")
+    c.num_envs = int(env["numEnvs"])
+    c.control_freq_inv = int(env.get("controlFrequencyInv", 1))
+    c.max_episode_length = int(env["maxEpisodeLength"])
+    c.action_delay = int(env.get("ACTION_DELAY", 0))
+    c.clip_observations = float(env.get("clipObservations", float("inf")))
+    c.clip_actions = float(env.get("clipActions", float("inf")))
+    c.dt = float(sim["dt"])
+    c.substeps = int(sim.get("substeps", 2))
+    gravity = sim.get("gravity", [0.0, 0.0, -9.81])
+    if sim.get("up_axis", "z") != "z" or float(gravity[0]) != 0.0 or float(gravity[1]) != 0.0:
+        raise ValueError("Vine5LinkMovingBase requires up_axis 'z' and gravity along -z (V5:441)")
+    c.gravity = -float(gravity[2])
+    for key, field in [("FPAM_MIN", "fpam_min"), ("FPAM_MAX", "fpam_max"), ("RAIL_VELOCITY_SCALE", "rail_velocity_scale"),
+                       ("DAMPING", "damping"), ("STIFFNESS", "stiffness"), ("RAIL_SOFT_LIMIT", "rail_soft_limit"),
+                       ("RAIL_P_GAIN", "rail_p_gain"), ("RAIL_D_GAIN", "rail_d_gain"),
+                       ("RAIL_ACCELERATION", "rail_acceleration"),
+                       ("SMOOTHING_ALPHA_INFLATE", "smoothing_alpha_inflate"),
+                       ("SMOOTHING_ALPHA_DEFLATE", "smoothing_alpha_deflate"),
+                       ("RANDOM_INIT_CART_MIN_Y", "random_init_cart_min_y"),
+                       ("RANDOM_INIT_CART_MAX_Y", "random_init_cart_max_y"), ("SUCCESS_DIST", "success_dist"),
+                       ("MIN_TARGET_DEPTH_IN_OBSTACLE", "min_target_depth"),
+                       ("MAX_TARGET_DEPTH_IN_OBSTACLE", "max_target_depth"),
+                       ("MIN_TARGET_Y", "min_target_y"), ("MAX_TARGET_Y", "max_target_y"),
+                       ("MIN_TARGET_Z", "min_target_z"), ("MAX_TARGET_Z", "max_target_z")]:
+        setattr(c, field, float(env[key]))
+    for i, key in enumerate(_REWARD_KEYS):
+        c.reward_weights[i] = float(env[key + "_REWARD_WEIGHT"])
+    rp = task.get("randomization_parameters", {})
+    c.dyn_scale_min = float(rp.get("DYNAMICS_SCALING_MIN", 1.0))
+    c.dyn_scale_max = float(rp.get("DYNAMICS_SCALING_MAX", 1.0))
+    c.obs_noise_std = float(rp.get("OBSERVATION_NOISE_STD", 0.0))
+    c.action_noise_std = float(rp.get("ACTION_NOISE_STD", 0.0))
+    for flag, on in [(abi.FLAG_USE_SMOOTHED_FPAM, env.get("USE_SMOOTHED_FPAM", True)),
+                     (abi.FLAG_FORCE_U_FPAM, env.get("FORCE_U_FPAM", False)),
+                     (abi.FLAG_FORCE_U_RAIL_VELOCITY, env.get("FORCE_U_RAIL_VELOCITY", False)),
+                     (abi.FLAG_CREATE_SHELF, env.get("CREATE_SHELF", False)),
+                     (abi.FLAG_RANDOMIZE_DOF_INIT, env.get("RANDOMIZE_DOF_INIT", True)),
+                     (abi.FLAG_RANDOMIZE_TARGETS, env.get("RANDOMIZE_TARGETS", True)),
+                     (abi.FLAG_USE_TARGET_REACHED_RESET, env.get("USE_TARGET_REACHED_RESET", True)),
+                     (abi.FLAG_USE_TIP_LIMIT_HIT_RESET, env.get("USE_TIP_LIMIT_HIT_RESET", False)),
+                     (abi.FLAG_USE_NONZERO_CONTACT_FORCE_RESET, env.get("USE_NONZERO_CONTACT_FORCE_RESET", False)),
+                     (abi.FLAG_VINE_RANDOMIZE, task.get("vine_randomize", False))]:
+        c.set_flag(flag, bool(on))
+    # physics-model switches of this build (not reference keys; see DESIGN.md "assumptions")
+    model = env.get("physicsModel", {})
+    c.set_flag(abi.FLAG_STALE_BODY_STATE_AFTER_RESET, bool(model.get("staleBodyStateAfterReset", True)))
+    c.set_flag(abi.FLAG_IMPLICIT_JOINT_DAMPING, bool(model.get("implicitJointDamping", True)))
+    c.set_flag(abi.FLAG_FPAM_DAMPING_HELD, bool(model.get("fpamDampingHeld", False)))
+    c.link_angular_damping = float(model.get("linkAngularDamping", 0.0))
+    if seed is not None:
+        c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return c
+
+
+class Vine5LinkMovingBase(VecTask):
+    """Drop-in for ``isaacgym_task_map["Vine5LinkMovingBase"]`` (rlgames_utils.py:78-86)."""
+
+    def __init__(self, cfg, rl_device, sim_device, graphics_device_id, headless, virtual_screen_capture=False,
+                 force_render=False):
+        self.cfg = cfg
+        self.logger = logging.getLogger(__name__)
+        self.max_episode_length = self.cfg["env"]["maxEpisodeLength"]
+        self.vine_randomize = self.cfg["task"]["vine_randomize"]
+
+        observation_type = ObservationType[self.cfg["env"]["OBSERVATION_TYPE"]]
+        self.cfg["env"]["numObservations"] = num_observations(observation_type)
+        self.cfg["env"]["numActions"] = N_PRESSURE_ACTIONS + N_PRISMATIC_DOFS
+        if self.cfg["env"].get("CREATE_PIPE", False):
+            warnings.warn("CREATE_PIPE: the pipe mesh obstacle is not simulated by the MI355X path (mesh collision "
+                          "is out of scope); set CREATE_PIPE=False to silence this warning")
+        if self.cfg["env"].get("CAPTURE_VIDEO", False):
+            self.logger.info("CAPTURE_VIDEO is accepted and ignored (no renderer on the target)")
+
+        self._lib = None
+        self._handle = None
+        super().__init__(config=self.cfg, rl_device=rl_device, sim_device=sim_device,
+                         graphics_device_id=graphics_device_id, headless=headless,
+                         virtual_screen_capture=virtual_screen_capture, force_render=force_render)
+
+        self.num_dof = N_REVOLUTE_DOFS + N_PRISMATIC_DOFS
+        self.reward_weights = torch.tensor([[self.cfg["env"][k + "_REWARD_WEIGHT"] for k in _REWARD_KEYS]],
+                                           device=self.device, dtype=torch.float)
+        self.index_to_view = int(0.1 * self.num_envs)
+        self.num_steps = 0
+        self.dt = self.cfg["sim"]["dt"]
+        self.control_dt = self.dt * self.control_freq_inv
+        self.obs_scaling = torch.tensor(list(self._vcfg.obs_scaling[:self.num_obs]), device=self.device)
+        self.wandb_dict = {}
+        self._reward_matrix = None
+
+    # ------------------------------------------------------------------ native handle
+    def create_sim(self):
+        """Replaces create_sim/_create_envs/prepare_sim (V5:364-556): one ``vine_create``."""
+        self._lib = native.load()
+        seed = self.cfg.get("seed", None)
+        self._vcfg = vine_config_from_cfg(self.cfg, self._lib, seed=seed)
+        if not torch.cuda.is_available():
+            raise RuntimeError("no MI355X visible to PyTorch-ROCm; vine_robot_isaacgymenvs_amd has no CPU path")
+        # torch owns the SoA state block so that the reference's state views are zero-copy tensors
+        self._state = torch.zeros((abi.VF_COUNT, self.num_envs), device=self.device, dtype=torch.float32)
+        h = C.c_void_p()
+        native.check(self._lib.vine_create(C.byref(self._vcfg), self.device_id, self._state.data_ptr(), C.byref(h)),
+                     self._lib)
+        self._handle = h
+
+    def close(self):
+        if self._handle is not None and self._lib is not None:
+            torch.cuda.synchronize(self.device)
+            self._lib.vine_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _native_step(self, actions, obs_out):
+        native.check(self._lib.vine_step(self._handle, actions.data_ptr(), obs_out.data_ptr(), self.rew_buf.data_ptr(),
+                                         self.reset_buf.data_ptr(), self.progress_buf.data_ptr(),
+                                         self.timeout_buf.data_ptr(), self._stream()), self._lib)
+        self.num_steps += 1
+
+    def reset_idx(self, env_ids):
+        """V5:774-839 for callers outside the step (reset_done, V5:715-718)."""
+        ids = torch.as_tensor(env_ids, device=self.device).to(torch.long).contiguous()
+        if ids.numel() == 0:
+            return
+        native.check(self._lib.vine_reset_idx(self._handle, ids.data_ptr(), ids.numel(), self.rew_buf.data_ptr(),
+                                              self.reset_buf.data_ptr(), self.progress_buf.data_ptr(), self._stream()),
+                     self._lib)
+
+    # ------------------------------------------------------------------ test / tooling hooks
+    def bind_reward_matrix(self):
+        """Ask the kernel to also write the [N,13] unweighted reward matrix (V5:1272) each step."""
+        self._reward_matrix = torch.zeros((self.num_envs, abi.NUM_REWARDS), device=self.device)
+        native.check(self._lib.vine_bind_reward_matrix(self._handle, self._reward_matrix.data_ptr()), self._lib)
+        return self._reward_matrix
+
+    def bind_reset_values(self, values):
+        """Deterministic reset draws ([N,10], see include/vine.h); ``None`` restores the counter RNG."""
+        if values is None:
+            self._reset_values = None
+            native.check(self._lib.vine_bind_reset_values(self._handle, None), self._lib)
+        else:
+            self._reset_values = torch.as_tensor(values, dtype=torch.float32, device=self.device).contiguous()
+            assert self._reset_values.shape == (self.num_envs, 10)
+            native.check(self._lib.vine_bind_reset_values(self._handle, self._reset_values.data_ptr()), self._lib)
+
+    @property
+    def step_count(self):
+        return self._lib.vine_get_step_count(self._handle)
+
+    @step_count.setter
+    def step_count(self, v):
+        native.check(self._lib.vine_set_step_count(self._handle, int(v)), self._lib)
+
+    @property
+    def state(self):
+        """The [VF_COUNT, N] SoA block (fields: include/vine.h VineField)."""
+        return self._state
+
+    # ------------------------------------------------------------------ reference attribute names (views)
+    def _col(self, f):
+        return self._state[f].unsqueeze(-1)
+
+    def _xyz(self, fy, fz, x=0.0):
+        return torch.stack([torch.full_like(self._state[fy], x), self._state[fy], self._state[fz]], dim=-1)
+
+    @property
+    def dof_pos(self):            # V5:303
+        return self._state[abi.VF_Q0:abi.VF_Q0 + 6].t()
+
+    @property
+    def dof_vel(self):            # V5:304
+        return self._state[abi.VF_QD0:abi.VF_QD0 + 6].t()
+
+    @property
+    def prev_dof_pos(self):       # V5:231
+        return self._state[abi.VF_PREV_Q0:abi.VF_PREV_Q0 + 6].t()
+
+    @property
+    def tip_positions(self):      # V5:357
+        return self._xyz(abi.VF_TIP_Y, abi.VF_TIP_Z)
+
+    @property
+    def tip_velocities(self):     # V5:361
+        return self._xyz(abi.VF_TIP_VY, abi.VF_TIP_VZ)
+
+    @property
+    def prev_tip_positions(self):  # V5:232
+        return self._xyz(abi.VF_PREV_TIP_Y, abi.VF_PREV_TIP_Z)
+
+    @property
+    def cart_positions(self):     # V5:358
+        z = torch.full_like(self._state[abi.VF_CART_Y], CART_Z)
+        return torch.stack([torch.zeros_like(z), self._state[abi.VF_CART_Y], z], dim=-1)
+
+    @property
+    def cart_velocities(self):    # V5:362
+        z = torch.zeros_like(self._state[abi.VF_CART_VY])
+        return torch.stack([z, self._state[abi.VF_CART_VY], z], dim=-1)
+
+    @property
+    def target_positions(self):   # V5:179
+        return self._xyz(abi.VF_TARGET_Y, abi.VF_TARGET_Z)
+
+    @property
+    def target_velocities(self):  # V5:180 (always zero, V5:916-918)
+        return torch.zeros(self.num_envs, NUM_XYZ, device=self.device)
+
+    @property
+    def smoothed_u_fpam(self):    # V5:224
+        return self._col(abi.VF_SMOOTHED_U)
+
+    @property
+    def u_fpam(self):             # V5:937
+        return self._col(abi.VF_U_FPAM)
+
+    @property
+    def u_rail_velocity(self):    # V5:937
+        return self._col(abi.VF_U_RAIL)
+
+    @property
+    def prev_u_rail_velocity(self):  # V5:233
+        return self._col(abi.VF_PREV_U_RAIL)
+
+    @property
+    def prev_cart_vel(self):      # V5:235
+        return self._col(abi.VF_PREV_CART_VEL)
+
+    @property
+    def prev_cart_vel_error(self):  # V5:234
+        return self._col(abi.VF_PREV_CART_VEL_ERR)
+
+    @property
+    def rail_force(self):         # V5:1094
+        return self._col(abi.VF_RAIL_FORCE)
+
+    @property
+    def object_info(self):        # V5:238
+        return self._state[abi.VF_OBJ_DEPTH:abi.VF_OBJ_DEPTH + 2].t()
+
+    @property
+    def aggregated_rew_buf(self):  # V5:183
+        return self._state[abi.VF_AGG_REW]

@@ -1,0 +1,61 @@
+"""Adapter layer between the RL runner and the task (isaacgymenvs/utils/rlgames_utils.py:41-180).
+
+rl_games is not a dependency: ``RLGPUEnv`` keeps the ``IVecEnv`` method set rl_games calls
+(step/reset/reset_done/get_number_of_agents/get_env_info) so that either the built-in PPO
+(``learning/``) or an installed rl_games can drive it.
+"""
+from typing import Callable
+
+from ..tasks import isaacgym_task_map
+
+env_configurations = {}   # name -> {'env_creator': thunk, 'vecenv_type': str}  (rl_games.common.env_configurations)
+
+
+def register_env(name, config):
+    env_configurations[name] = config
+
+
+def get_rlgames_env_creator(seed: int, task_config: dict, task_name: str, sim_device: str, rl_device: str,
+                            graphics_device_id: int, headless: bool, multi_gpu: bool = False,
+                            post_create_hook: Callable = None, virtual_screen_capture: bool = False,
+                            force_render: bool = False):
+    """rlgames_utils.py:41-92: returns a thunk that builds the task from ``isaacgym_task_map``."""
+
+    def create_rlgpu_env():
+        task_config.setdefault("seed", seed)
+        env = isaacgym_task_map[task_name](
+            cfg=task_config, rl_device=rl_device, sim_device=sim_device, graphics_device_id=graphics_device_id,
+            headless=headless, virtual_screen_capture=virtual_screen_capture, force_render=force_render)
+        if post_create_hook is not None:
+            post_create_hook()
+        return env
+
+    return create_rlgpu_env
+
+
+class RLGPUEnv:
+    """rlgames_utils.py:151-180."""
+
+    def __init__(self, config_name, num_actors, **kwargs):
+        self.env = env_configurations[config_name]["env_creator"](**kwargs)
+
+    def step(self, actions):
+        return self.env.step(actions)
+
+    def reset(self):
+        return self.env.reset()
+
+    def reset_done(self):
+        return self.env.reset_done()
+
+    def get_number_of_agents(self):
+        return self.env.get_number_of_agents()
+
+    def get_env_info(self):
+        info = {"action_space": self.env.action_space, "observation_space": self.env.observation_space}
+        if self.env.num_states > 0:
+            info["state_space"] = self.env.state_space
+            print(info["action_space"], info["observation_space"], info["state_space"])
+        else:
+            print(info["action_space"], info["observation_space"])
+        return info
