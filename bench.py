@@ -58,13 +58,25 @@ def make_env(args, rank, device_index):
     return env, cfg
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, seconds):
     """CPU restatement of the reference path (oracle/, float32, OpenMP over envs) on a bounded sample."""
     import numpy as np
     from oracle import vine_oracle as vo
     from vine_robot_isaacgymenvs_amd import abi
     lib = vo.load("f32", omp=True)
-    cores = lib.vine_oracle_set_threads(os.cpu_count() or 1)
+    cores = lib.vine_oracle_set_threads(usable_cores())
     cfg = vo.default_config(lib, num_envs=args.num_envs)
     lib.vine_config_set_obs_type(cfg, abi.OBS_TYPE_BY_NAME[args.obs_type], 1)
     cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, bool(args.randomize))

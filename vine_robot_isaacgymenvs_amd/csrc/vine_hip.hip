@@ -92,9 +92,15 @@ __device__ __forceinline__ void normal2(unsigned a, unsigned b, float& n0, float
 }
 
 // Articulation state in absolute coordinates: cart (y, vy), link angles th_k = sum_{i<=k} q_i, rates w_k.
+// sn/cs = sin/cos of th, carried along by exact-to-rounding incremental rotations (see substep).
 struct Dyn {
-    float y, vy, th[NL], w[NL];
+    float y, vy, th[NL], w[NL], sn[NL], cs[NL];
 };
+
+__device__ __forceinline__ void dyn_sync_trig(Dyn& s) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) sincosf(s.th[i], &s.sn[i], &s.cs[i]);
+}
 
 // One semi-implicit Euler substep.  eff[6] = held efforts (rail force, joint torques), cj[6] = per-DOF
 // damping, hc[6] = h * cj (implicit part), all constant over one `simulate`.
@@ -104,10 +110,11 @@ struct Dyn {
 template <bool IMPLICIT>
 __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float (&eff)[ND], const float (&cj)[ND],
                                         const float (&hc)[ND]) {
-    float sn[NL], cs[NL], sp[NL], cp[NL], w2[NL];
+    float sp[NL], cp[NL], w2[NL];
+    const float (&sn)[NL] = s.sn;
+    const float (&cs)[NL] = s.cs;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        sincosf(s.th[i], &sn[i], &cs[i]);
         sp[i] = P.s0 * cs[i] + P.c0 * sn[i];
         cp[i] = P.c0 * cs[i] - P.s0 * sn[i];
         w2[i] = s.w[i] * s.w[i];
@@ -157,7 +164,7 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
         float d = A[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
-        float ri = rsqrtf(d);
+        float ri = __builtin_amdgcn_rsqf(d);  // raw v_rsq_f32 (1 ulp); pivots are O(1e-4..1), never denormal
         inv[j] = ri;
 #pragma unroll
         for (int i = j + 1; i < ND; ++i) {
@@ -186,7 +193,16 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         s.w[i] += P.hsub * r[i + 1];
-        s.th[i] += P.hsub * s.w[i];
+        const float d = P.hsub * s.w[i];
+        s.th[i] += d;
+        // rotate (sn, cs) by d: |d| = h*|w| < 0.06 rad even at 64 rad/s, so the degree-5/4 Taylor
+        // polynomials are exact to float rounding (next terms d^7/5040, d^6/720 < 1e-10)
+        const float d2 = d * d;
+        const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+        const float sd = d * fmaf(d2, fmaf(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
+        const float s_old = s.sn[i], c_old = s.cs[i];
+        s.sn[i] = fmaf(s_old, cd, c_old * sd);
+        s.cs[i] = fmaf(c_old, cd, -(s_old * sd));
     }
 }
 
@@ -242,6 +258,17 @@ __device__ __forceinline__ void reset_env(const DevParams& P, float* __restrict_
 }
 
 // Forward kinematics of the tip body from absolute angles.
+__device__ __forceinline__ void tip_fk_sc(const DevParams& P, float y, float vy, const float (&sn)[NL],
+                                          const float (&cs)[NL], const float (&w)[NL], float (&tip)[4]) {
+    float ty = y, tz = P.z1, tvy = vy, tvz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        float sp = P.s0 * cs[k] + P.c0 * sn[k], cp = P.c0 * cs[k] - P.s0 * sn[k];
+        ty -= P.L * sp; tz += P.L * cp;
+        tvy -= P.L * w[k] * cp; tvz -= P.L * w[k] * sp;
+    }
+    tip[0] = ty; tip[1] = tz; tip[2] = tvy; tip[3] = tvz;
+}
 __device__ __forceinline__ void tip_fk(const DevParams& P, float y, float vy, const float (&th)[NL],
                                        const float (&w)[NL], float (&tip)[4]) {
     float ty = y, tz = P.z1, tvy = vy, tvz = 0.0f;
@@ -327,6 +354,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
                 s.w[k] = b;
             }
         }
+        dyn_sync_trig(s);
         // ---- control_freq_inv x [refresh, actuation (V5:1028-1106), simulate] (vec_task.py:338-356) ----
         for (int it = 0; it < P.cfi; ++it) {
             float sc[20];
@@ -383,7 +411,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             cart_vy = s.vy;
         }
         // refreshed rigid-body states after the last simulate
-        tip_fk(P, s.y, s.vy, s.th, s.w, tip);
+        tip_fk_sc(P, s.y, s.vy, s.sn, s.cs, s.w, tip);
         q[0] = s.y;
         qd[0] = s.vy;
         q[1] = s.th[0];

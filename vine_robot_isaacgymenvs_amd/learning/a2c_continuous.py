@@ -1,0 +1,651 @@
+"""``A2CAgent``: PPO with an LSTM actor-critic as rl_games' ``a2c_continuous`` runs it for
+cfg/train/Vine5LinkMovingBasePPO.yaml (rows R1-R6 of SURVEY 8a; in-tree text of the same arithmetic:
+isaacgymenvs/learning/common_agent.py:184-255 train_epoch, 257-317 play_steps, 319-411 calc_gradients,
+413-435 discount_values/bound_loss).
+
+MI355X-first choices (none changes the arithmetic):
+  * everything in the rollout and in the update stays on the device: done-handling uses masks instead of
+    index lists, the adaptive-KL learning rate (``schedule_type: legacy``: after EVERY minibatch) lives in a
+    device scalar read by the fused Adam kernel -- no ``.item()`` inside an iteration;
+  * gradients live in ONE flat buffer (``param.grad`` are views into it): the multi-GPU step is a single
+    in-place RCCL all-reduce of 1.63 MB over xGMI per optimiser step, no concat / scatter copies;
+  * the 16-step rollout can be captured in one hipGraph (``use_graphs``): policy GEMMs + the fused env-step
+    kernel + bookkeeping replay with a single launch.
+"""
+import copy
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .network import ModelA2CContinuousLogStd
+
+
+def swap_and_flatten01(arr):
+    """[T, N, ...] -> [N*T, ...] with index = env * T + t (each env's steps contiguous)."""
+    if arr is None:
+        return arr
+    s = arr.size()
+    return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+
+def policy_kl(p0_mu, p0_sigma, p1_mu, p1_sigma):
+    """KL(p0 || p1) of diagonal Gaussians with rl_games' +1e-5 guards, mean over the batch."""
+    c1 = torch.log(p1_sigma / p0_sigma + 1e-5)
+    c2 = (p0_sigma ** 2 + (p1_mu - p0_mu) ** 2) / (2.0 * (p1_sigma ** 2 + 1e-5))
+    kl = (c1 + c2 - 0.5).sum(dim=-1)
+    return kl.mean()
+
+
+def actor_loss(old_neglogp, neglogp, advantage, e_clip):
+    """Clipped surrogate, common_agent.py:482-493."""
+    ratio = torch.exp(old_neglogp - neglogp)
+    surr1 = advantage * ratio
+    surr2 = advantage * torch.clamp(ratio, 1.0 - e_clip, 1.0 + e_clip)
+    return torch.max(-surr1, -surr2)
+
+
+def critic_loss(value_preds, values, e_clip, returns, clip_value):
+    """common_agent.py:503-511."""
+    if clip_value:
+        value_pred_clipped = value_preds + (values - value_preds).clamp(-e_clip, e_clip)
+        return torch.max((values - returns) ** 2, (value_pred_clipped - returns) ** 2)
+    return (returns - values) ** 2
+
+
+def bound_loss(mu, soft_bound=1.1):
+    """common_agent.py:427-435 with rl_games' soft bound of 1.1 (the in-tree AMP copy uses 1.0)."""
+    mu_loss_high = torch.clamp_min(mu - soft_bound, 0.0) ** 2
+    mu_loss_low = torch.clamp_max(mu + soft_bound, 0.0) ** 2
+    return (mu_loss_low + mu_loss_high).sum(dim=-1)
+
+
+def discount_values(gamma, tau, fdones, last_values, mb_fdones, mb_values, mb_rewards):
+    """GAE in next-nonterminal form (rl_games a2c_common.discount_values)."""
+    horizon = mb_rewards.shape[0]
+    lastgaelam = torch.zeros_like(last_values)
+    mb_advs = torch.zeros_like(mb_rewards)
+    for t in reversed(range(horizon)):
+        if t == horizon - 1:
+            nextnonterminal = 1.0 - fdones
+            nextvalues = last_values
+        else:
+            nextnonterminal = 1.0 - mb_fdones[t + 1]
+            nextvalues = mb_values[t + 1]
+        nextnonterminal = nextnonterminal.unsqueeze(1)
+        delta = mb_rewards[t] + gamma * nextvalues * nextnonterminal - mb_values[t]
+        lastgaelam = delta + gamma * tau * nextnonterminal * lastgaelam
+        mb_advs[t] = lastgaelam
+    return mb_advs
+
+
+class DeviceAverageMeter:
+    """rl_games ``AverageMeter`` (windowed mean of finished-episode returns) with masked, sync-free updates."""
+
+    def __init__(self, in_shape, max_size, device):
+        self.max_size = float(max_size)
+        self.current_size = torch.zeros((), device=device)
+        self.mean = torch.zeros(in_shape, device=device)
+
+    def update(self, values, mask):
+        """values [N, in_shape], mask [N] (1 where an episode just finished)."""
+        m = mask.to(values.dtype)
+        size = m.sum()
+        new_mean = (values * m.unsqueeze(-1)).sum(0) / torch.clamp(size, min=1.0)
+        size_c = torch.clamp(size, 0.0, self.max_size)
+        old_size = torch.minimum(self.max_size - size_c, self.current_size)
+        size_sum = old_size + size_c
+        mean = (self.mean * old_size + new_mean * size_c) / torch.clamp(size_sum, min=1.0)
+        has = (size > 0).to(values.dtype)
+        self.mean = has * mean + (1.0 - has) * self.mean
+        self.current_size = has * size_sum + (1.0 - has) * self.current_size
+
+    def clear(self):
+        self.current_size.zero_()
+        self.mean.zero_()
+
+    def get_mean(self):
+        return self.mean
+
+
+class ScalarLog:
+    """Stand-in for the TensorBoard ``SummaryWriter`` rl_games uses (tensorboard is not on the image):
+    same ``add_scalar(tag, value, step)`` call, appended to ``summaries/scalars.csv``."""
+
+    def __init__(self, directory):
+        os.makedirs(directory, exist_ok=True)
+        self.path = os.path.join(directory, "scalars.csv")
+        self._f = open(self.path, "a")
+
+    def add_scalar(self, tag, value, step):
+        self._f.write("%s,%s,%s\n" % (tag, float(value), int(step)))
+
+    def flush(self):
+        self._f.flush()
+
+
+class A2CAgent:
+    def __init__(self, base_name, params, vec_env=None, algo_observer=None):
+        self.params = params
+        self.config = config = params["config"]
+        self.network_params = params["network"]
+        self.vec_env = vec_env
+        if self.vec_env is None:
+            from ..utils.rlgames_utils import RLGPUEnv
+            self.vec_env = RLGPUEnv(config["env_name"], config["num_actors"])
+        self.env_info = self.vec_env.get_env_info()
+
+        self.multi_gpu = bool(config.get("multi_gpu", False))
+        self.rank, self.rank_size = 0, 1
+        if self.multi_gpu:
+            self.rank = int(os.getenv("LOCAL_RANK", "0"))
+            self.rank_size = int(os.getenv("WORLD_SIZE", "1"))
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                backend = "nccl" if str(config.get("device", "cuda")).startswith("cuda") else "gloo"
+                dist.init_process_group(backend, rank=int(os.getenv("RANK", self.rank)), world_size=self.rank_size)
+            if str(config.get("device", "cuda:0")).startswith("cuda"):
+                config["device"] = "cuda:" + str(self.rank)
+        self.ppo_device = self.device = torch.device(config.get("device", "cuda:0"))
+        self.is_cuda = self.device.type == "cuda"
+
+        self.name = base_name
+        self.ppo = config.get("ppo", True)
+        self.max_epochs = config.get("max_epochs", 1e6)
+        self.num_actors = config["num_actors"]
+        self.num_agents = 1
+        self.horizon_length = config["horizon_length"]
+        self.seq_len = config.get("seq_len", 4)
+        self.normalize_advantage = config["normalize_advantage"]
+        self.normalize_input = config["normalize_input"]
+        self.normalize_value = config.get("normalize_value", False)
+        self.truncate_grads = config.get("truncate_grads", False)
+        self.grad_norm = config["grad_norm"]
+        self.gamma, self.tau = config["gamma"], config["tau"]
+        self.e_clip = config["e_clip"]
+        self.clip_value = config["clip_value"]
+        self.critic_coef = config["critic_coef"]
+        self.entropy_coef = config["entropy_coef"]
+        self.bounds_loss_coef = config.get("bounds_loss_coef", None)
+        self.mini_epochs_num = config["mini_epochs"]
+        self.value_bootstrap = config.get("value_bootstrap")
+        self.reward_scale = config.get("reward_shaper", {}).get("scale_value", 1.0)
+        self.reward_shift = config.get("reward_shaper", {}).get("shift_value", 0.0)
+        self.mixed_precision = bool(config.get("mixed_precision", False)) and self.is_cuda
+        self.amp_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[config.get("mixed_precision_dtype", "fp16")]
+        self.save_freq = config.get("save_frequency", 0)
+        self.save_best_after = config.get("save_best_after", 100)
+        self.print_stats = config.get("print_stats", True)
+        self.games_to_track = config.get("games_to_track", 100)
+        self.use_graphs = bool(config.get("use_graphs", False)) and self.is_cuda
+        self.schedule_type = config.get("schedule_type", "legacy")
+        self.is_adaptive_lr = config["lr_schedule"] == "adaptive"
+        self.kl_threshold = config.get("kl_threshold", 0.008)
+        self.min_lr, self.max_lr = 1e-6, 1e-2
+
+        self.batch_size = self.horizon_length * self.num_actors * self.num_agents
+        self.batch_size_envs = self.horizon_length * self.num_actors
+        self.minibatch_size = config["minibatch_size"]
+        self.num_minibatches = self.batch_size // self.minibatch_size
+        # the same three constraints rl_games asserts
+        assert self.batch_size % self.minibatch_size == 0, "batch_size (%d) %% minibatch_size (%d) != 0" % (
+            self.batch_size, self.minibatch_size)
+        assert self.minibatch_size % self.seq_len == 0, "minibatch_size %% seq_len != 0"
+        assert self.horizon_length % self.seq_len == 0, "horizon_length %% seq_len != 0"
+
+        self.observation_space = self.env_info["observation_space"]
+        self.obs_shape = tuple(self.observation_space.shape)
+        self.actions_num = self.env_info["action_space"].shape[0]
+        self.actions_low = torch.from_numpy(self.env_info["action_space"].low.copy()).float().to(self.device)
+        self.actions_high = torch.from_numpy(self.env_info["action_space"].high.copy()).float().to(self.device)
+        self.clip_actions = config.get("clip_actions", True)
+
+        self.model = ModelA2CContinuousLogStd(self.network_params, self.actions_num, self.obs_shape,
+                                              self.normalize_value, self.normalize_input).to(self.device)
+        self.last_lr = float(config["learning_rate"])
+        self.lr = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
+        self._setup_flat_grads()
+        adam_kw = dict(fused=True) if self.is_cuda else dict(foreach=False)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr, eps=1e-08,
+                                          weight_decay=config.get("weight_decay", 0.0), **adam_kw)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision and self.amp_dtype == torch.float16)
+
+        self.frame = 0
+        self.epoch_num = 0
+        self.curr_frames = 0
+        self.last_mean_rewards = -100500
+        self.mean_rewards = None
+        self.algo_observer = algo_observer
+
+        self.experiment_name = config.get("full_experiment_name") or config["name"]
+        self.train_dir = config.get("train_dir", "runs")
+        self.experiment_dir = os.path.join(self.train_dir, self.experiment_name)
+        self.nn_dir = os.path.join(self.experiment_dir, "nn")
+        self.summaries_dir = os.path.join(self.experiment_dir, "summaries")
+        self.writer = None
+        if self.rank == 0 and config.get("write_files", True):
+            os.makedirs(self.nn_dir, exist_ok=True)
+            self.writer = ScalarLog(self.summaries_dir)
+        self._rollout_graph = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _setup_flat_grads(self):
+        """One contiguous gradient buffer; every ``param.grad`` is a view into it."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        self.flat_grads = torch.zeros(total, device=self.device, dtype=torch.float32)
+        off = 0
+        for p in params:
+            p.grad = self.flat_grads[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.num_params = total
+
+    def set_eval(self):
+        self.model.eval()
+
+    def set_train(self):
+        self.model.train()
+
+    def broadcast_parameters(self):
+        """Rank 0's weights and normaliser statistics to every rank (rl_games broadcasts the state dict)."""
+        if not self.multi_gpu:
+            return
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            dist.broadcast(t.data, 0)
+
+    def preprocess_actions(self, actions):
+        if self.clip_actions:
+            clamped = torch.clamp(actions, -1.0, 1.0)
+            d = (self.actions_high - self.actions_low) / 2.0
+            m = (self.actions_high + self.actions_low) / 2.0
+            return clamped * d + m
+        return actions
+
+    def env_step(self, actions):
+        obs, rewards, dones, infos = self.vec_env.step(self.preprocess_actions(actions))
+        return obs, rewards.unsqueeze(1).to(self.device), dones.to(self.device), infos
+
+    def env_reset(self):
+        return self.vec_env.reset()
+
+    def init_tensors(self):
+        T, N, dev = self.horizon_length, self.num_actors, self.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.buf = {
+            "obses": torch.zeros((T, N) + self.obs_shape, **f32),
+            "rewards": torch.zeros((T, N, 1), **f32),
+            "values": torch.zeros((T, N, 1), **f32),
+            "neglogpacs": torch.zeros((T, N), **f32),
+            "dones": torch.zeros((T, N), device=dev, dtype=torch.uint8),
+            "actions": torch.zeros((T, N, self.actions_num), **f32),
+            "mus": torch.zeros((T, N, self.actions_num), **f32),
+            "sigmas": torch.zeros((T, N, self.actions_num), **f32),
+        }
+        self.current_rewards = torch.zeros((N, 1), **f32)
+        self.current_lengths = torch.zeros(N, **f32)
+        self.dones = torch.ones(N, device=dev, dtype=torch.uint8)
+        self.game_rewards = DeviceAverageMeter(1, self.games_to_track, dev)
+        self.game_lengths = DeviceAverageMeter(1, self.games_to_track, dev)
+        self.rnn_states = [s.clone() for s in self.model.get_default_rnn_state(N, dev)]
+        n_chunks = T // self.seq_len
+        self.mb_rnn_states = [torch.zeros((n_chunks, 1, N, s.shape[-1]), **f32) for s in self.rnn_states]
+        self.last_values = torch.zeros((N, 1), **f32)
+
+    # ------------------------------------------------------------------ rollout (R1)
+    def get_action_values(self, obs):
+        self.model.eval()
+        with torch.no_grad():
+            return self.model({"is_train": False, "prev_actions": None, "obs": obs, "rnn_states": self.rnn_states})
+
+    def _rollout_body(self):
+        """``play_steps_rnn``: horizon x {store; policy forward (eval); env step; shape reward; bootstrap;
+        zero the LSTM state of finished envs}; then last values.  Fixed shapes, no host sync."""
+        buf = self.buf
+        obs = self.obs
+        for n in range(self.horizon_length):
+            if n % self.seq_len == 0:
+                for s, mb_s in zip(self.rnn_states, self.mb_rnn_states):
+                    mb_s[n // self.seq_len].copy_(s)
+            res = self.get_action_values(obs)
+            self.rnn_states = list(res["rnn_states"])
+            buf["obses"][n].copy_(obs)
+            buf["dones"][n].copy_(self.dones)
+            buf["actions"][n].copy_(res["actions"])
+            buf["neglogpacs"][n].copy_(res["neglogpacs"])
+            buf["values"][n].copy_(res["values"])
+            buf["mus"][n].copy_(res["mus"])
+            buf["sigmas"][n].copy_(res["sigmas"])
+            obs_d, rewards, dones, infos = self.env_step(res["actions"])
+            obs = obs_d["obs"]
+            shaped = (rewards + self.reward_shift) * self.reward_scale
+            if self.value_bootstrap and "time_outs" in infos:
+                shaped = shaped + self.gamma * res["values"] * infos["time_outs"].to(self.device).unsqueeze(1).float()
+            buf["rewards"][n].copy_(shaped)
+            self.dones = dones.to(torch.uint8)
+            self.current_rewards += rewards
+            self.current_lengths += 1
+            done_f = dones.float()
+            self.game_rewards.update(self.current_rewards, done_f)
+            self.game_lengths.update(self.current_lengths.unsqueeze(1), done_f)
+            not_dones = 1.0 - done_f
+            self.rnn_states = [s * not_dones.view(1, -1, 1) for s in self.rnn_states]
+            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+            self.current_lengths = self.current_lengths * not_dones
+        self.obs = obs
+        self.last_values.copy_(self.get_action_values(obs)["values"])
+
+    def play_steps_rnn(self):
+        if self.use_graphs:
+            self._play_graphed()
+        else:
+            self._rollout_body()
+        buf = self.buf
+        fdones = self.dones.float()
+        mb_fdones = buf["dones"].float()
+        mb_advs = discount_values(self.gamma, self.tau, fdones, self.last_values, mb_fdones, buf["values"], buf["rewards"])
+        mb_returns = mb_advs + buf["values"]
+        batch = {k: swap_and_flatten01(buf[k]) for k in ("obses", "actions", "neglogpacs", "values", "mus", "sigmas", "dones")}
+        batch["returns"] = swap_and_flatten01(mb_returns)
+        batch["played_frames"] = self.batch_size
+        states = []
+        for mb_s in self.mb_rnn_states:
+            t_size = mb_s.size()[0] * mb_s.size()[2]
+            states.append(mb_s.permute(1, 2, 0, 3).reshape(-1, t_size, mb_s.size()[3]))
+        batch["rnn_states"] = states
+        return batch
+
+    def _play_graphed(self):
+        """Capture the whole rollout once, then replay it.  Live state that the captured code rebinds
+        (obs, dones, LSTM state, episode accumulators) is kept in static tensors copied in and out."""
+        if self._rollout_graph is None:
+            self._g_obs = self.obs.clone()
+            self._g_in = [self._g_obs, self.dones.clone(), [s.clone() for s in self.rnn_states],
+                          self.current_rewards.clone(), self.current_lengths.clone(),
+                          self.game_rewards.mean.clone(), self.game_rewards.current_size.clone(),
+                          self.game_lengths.mean.clone(), self.game_lengths.current_size.clone()]
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):     # warm-up outside capture (lazy inits of libraries)
+                snap = self._snapshot_env()
+                self._load_live(self._g_in)
+                self._rollout_body()
+                self._restore_env(snap)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self._rollout_graph = torch.cuda.CUDAGraph()
+            self._load_live(self._g_in)
+            with torch.cuda.graph(self._rollout_graph):
+                self._load_live(self._g_in)
+                self._rollout_body()
+                self._g_out = [self.obs, self.dones, self.rnn_states, self.current_rewards, self.current_lengths,
+                               self.game_rewards.mean, self.game_rewards.current_size, self.game_lengths.mean,
+                               self.game_lengths.current_size]
+            self._restore_env(snap)
+        self._rollout_graph.replay()
+        # carry the outputs over to the static inputs of the next replay
+        o = self._g_out
+        self._g_in[0].copy_(o[0]); self._g_in[1].copy_(o[1])
+        for a, b in zip(self._g_in[2], o[2]):
+            a.copy_(b)
+        for i in range(3, 9):
+            self._g_in[i].copy_(o[i])
+        self._load_live(self._g_in)
+
+    def _load_live(self, g):
+        self.obs, self.dones = g[0], g[1]
+        self.rnn_states = list(g[2])
+        self.current_rewards, self.current_lengths = g[3], g[4]
+        self.game_rewards.mean, self.game_rewards.current_size = g[5], g[6]
+        self.game_lengths.mean, self.game_lengths.current_size = g[7], g[8]
+
+    def _snapshot_env(self):
+        env = getattr(self.vec_env, "env", self.vec_env)
+        return {"state": env.state.clone(), "reset": env.reset_buf.clone(), "progress": env.progress_buf.clone(),
+                "step": env.step_count, "rng": torch.cuda.get_rng_state(self.device)}
+
+    def _restore_env(self, snap):
+        env = getattr(self.vec_env, "env", self.vec_env)
+        torch.cuda.synchronize(self.device)
+        env.state.copy_(snap["state"]); env.reset_buf.copy_(snap["reset"]); env.progress_buf.copy_(snap["progress"])
+        env.step_count = snap["step"]
+        torch.cuda.set_rng_state(snap["rng"], self.device)
+
+    # ------------------------------------------------------------------ dataset (R5)
+    def prepare_dataset(self, batch):
+        returns, values = batch["returns"], batch["values"]
+        advantages = returns - values
+        if self.normalize_value:
+            self.model.value_mean_std.train()
+            values = self.model.value_mean_std(values)
+            returns = self.model.value_mean_std(returns)
+            self.model.value_mean_std.eval()
+        advantages = torch.sum(advantages, dim=1)
+        if self.normalize_advantage:
+            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+        self.dataset = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages,
+                        "returns": returns, "actions": batch["actions"], "obs": batch["obses"],
+                        "dones": batch["dones"], "rnn_states": batch["rnn_states"],
+                        "mu": batch["mus"].clone(), "sigma": batch["sigmas"].clone()}
+
+    def get_minibatch(self, idx):
+        """Contiguous slices, no shuffling (rl_games PPODataset._get_item_rnn)."""
+        games = self.minibatch_size // self.seq_len
+        gstart, gend = idx * games, (idx + 1) * games
+        start, end = gstart * self.seq_len, gend * self.seq_len
+        mb = {k: v[start:end] for k, v in self.dataset.items() if k != "rnn_states"}
+        mb["rnn_states"] = [s[:, gstart:gend, :].contiguous() for s in self.dataset["rnn_states"]]
+        mb["range"] = (start, end)
+        return mb
+
+    # ------------------------------------------------------------------ update (R3, R4, R6)
+    def calc_gradients(self, mb):
+        batch_dict = {"is_train": True, "prev_actions": mb["actions"], "obs": mb["obs"], "rnn_states": mb["rnn_states"],
+                      "seq_length": self.seq_len, "dones": mb["dones"]}
+        with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.mixed_precision):
+            res = self.model(batch_dict)
+            action_log_probs, values, entropy = res["prev_neglogp"], res["values"], res["entropy"]
+            mu, sigma = res["mus"], res["sigmas"]
+            a_loss = actor_loss(mb["old_logp_actions"], action_log_probs, mb["advantages"], self.e_clip).mean()
+            c_loss = critic_loss(mb["old_values"], values, self.e_clip, mb["returns"], self.clip_value).mean()
+            b_loss = bound_loss(mu).mean() if self.bounds_loss_coef is not None else torch.zeros((), device=self.device)
+            entropy = entropy.mean()
+            loss = (a_loss + 0.5 * c_loss * self.critic_coef - entropy * self.entropy_coef
+                    + b_loss * (self.bounds_loss_coef or 0.0))
+        self.flat_grads.zero_()
+        self.scaler.scale(loss).backward()
+        self.truncate_gradients_and_step()
+        with torch.no_grad():
+            kl = policy_kl(mu.detach().float(), sigma.detach().float(), mb["mu"], mb["sigma"])
+        return a_loss.detach(), c_loss.detach(), entropy.detach(), kl, b_loss.detach(), mu.detach(), sigma.detach()
+
+    def truncate_gradients_and_step(self):
+        if self.multi_gpu:
+            dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM)     # RCCL over xGMI, in place, 1.63 MB
+            self.flat_grads.div_(self.rank_size)
+        if self.truncate_grads:
+            self.scaler.unscale_(self.optimizer)
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+
+    def update_lr_from_kl(self, kl):
+        """AdaptiveScheduler of rl_games on a device scalar (common_agent.py:217-221 shows the call site)."""
+        if self.multi_gpu:
+            kl = kl.clone()
+            dist.all_reduce(kl, op=dist.ReduceOp.SUM)
+            kl = kl / self.rank_size
+        lr = self.lr
+        down = torch.clamp(lr / 1.5, min=self.min_lr)
+        up = torch.clamp(lr * 1.5, max=self.max_lr)
+        new = torch.where(kl > 2.0 * self.kl_threshold, down, torch.where(kl < 0.5 * self.kl_threshold, up, lr))
+        self.lr.copy_(new)
+
+    def train_epoch(self):
+        t_play = time.time()
+        self.set_eval()
+        with torch.no_grad():
+            batch = self.play_steps_rnn()
+        if self.is_cuda:
+            torch.cuda.synchronize(self.device)
+        play_time = time.time() - t_play
+        t_upd = time.time()
+        self.set_train()
+        self.curr_frames = batch.pop("played_frames")
+        self.prepare_dataset(batch)
+        a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
+        for mini_ep in range(self.mini_epochs_num):
+            ep_kls = []
+            for i in range(self.num_minibatches):
+                mb = self.get_minibatch(i)
+                a_loss, c_loss, entropy, kl, b_loss, cmu, csigma = self.calc_gradients(mb)
+                start, end = mb["range"]
+                self.dataset["mu"][start:end] = cmu.float()          # dataset.update_mu_sigma
+                self.dataset["sigma"][start:end] = csigma.float()
+                a_losses.append(a_loss); c_losses.append(c_loss); b_losses.append(b_loss)
+                entropies.append(entropy); ep_kls.append(kl)
+                if self.is_adaptive_lr and self.schedule_type == "legacy":
+                    self.update_lr_from_kl(kl)
+            av_kls = torch.stack(ep_kls).mean()
+            if self.is_adaptive_lr and self.schedule_type == "standard":
+                self.update_lr_from_kl(av_kls)
+            kls.append(av_kls)
+            if self.normalize_input:
+                self.model.running_mean_std.eval()   # statistics are updated during the first mini-epoch only
+        if self.is_cuda:
+            torch.cuda.synchronize(self.device)
+        update_time = time.time() - t_upd
+        stats = {k: torch.stack(v).mean() for k, v in
+                 dict(a_loss=a_losses, c_loss=c_losses, b_loss=b_losses, entropy=entropies, kl=kls).items()}
+        return play_time, update_time, stats
+
+    # ------------------------------------------------------------------ checkpoint (aux: resume)
+    def get_full_state_weights(self):
+        return {"model": self.model.state_dict(), "epoch": self.epoch_num, "optimizer": self.optimizer.state_dict(),
+                "frame": self.frame, "last_mean_rewards": self.last_mean_rewards, "last_lr": float(self.lr)}
+
+    def save(self, fn):
+        state = self.get_full_state_weights()
+        torch.save(state, fn + ".pth")
+        return fn + ".pth"
+
+    def restore(self, fn):
+        ckpt = torch.load(fn, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ckpt["model"])
+        self.epoch_num = ckpt.get("epoch", 0)
+        self.frame = ckpt.get("frame", 0)
+        self.last_mean_rewards = ckpt.get("last_mean_rewards", -100500)
+        if "optimizer" in ckpt:
+            self.optimizer.load_state_dict(ckpt["optimizer"])
+            for group in self.optimizer.param_groups:
+                group["lr"] = self.lr
+        if "last_lr" in ckpt:
+            self.lr.fill_(ckpt["last_lr"])
+
+    # ------------------------------------------------------------------ main loop
+    def train(self):
+        self.init_tensors()
+        self.obs = self.env_reset()["obs"].to(self.device)
+        self.broadcast_parameters()
+        total_time = 0.0
+        while True:
+            self.epoch_num += 1
+            epoch_num = self.epoch_num
+            play_time, update_time, stats = self.train_epoch()
+            sum_time = play_time + update_time
+            total_time += sum_time
+            curr_frames = self.curr_frames * self.rank_size
+            self.frame += curr_frames
+            should_exit = False
+            if self.rank == 0:
+                self.last_lr = float(self.lr)
+                if self.print_stats:   # the reference's console line (common_agent.py:145-148)
+                    print(f"fps step and policy inference: {curr_frames / play_time:.0f} "
+                          f"fps total: {curr_frames / sum_time:.0f} epoch: {epoch_num}/{self.max_epochs}")
+                self.write_stats(total_time, epoch_num, play_time, update_time, stats, curr_frames)
+                if float(self.game_rewards.current_size) > 0:
+                    mean_rewards = float(self.game_rewards.get_mean()[0])
+                    mean_lengths = float(self.game_lengths.get_mean()[0])
+                    self.mean_rewards = mean_rewards
+                    if self.writer:
+                        for suffix, x in (("step", self.frame), ("iter", epoch_num), ("time", total_time)):
+                            self.writer.add_scalar("rewards/" + suffix, mean_rewards, x)
+                            self.writer.add_scalar("episode_lengths/" + suffix, mean_lengths, x)
+                    checkpoint_name = self.config["name"] + "_ep_" + str(epoch_num) + "_rew_" + str(mean_rewards)
+                    if self.writer and self.save_freq > 0 and epoch_num % self.save_freq == 0 \
+                            and mean_rewards <= self.last_mean_rewards:
+                        self.save(os.path.join(self.nn_dir, "last_" + checkpoint_name))
+                    if mean_rewards > self.last_mean_rewards and epoch_num >= self.save_best_after:
+                        print("saving next best rewards: ", mean_rewards)
+                        self.last_mean_rewards = mean_rewards
+                        if self.writer:
+                            self.save(os.path.join(self.nn_dir, self.config["name"]))
+                        if self.last_mean_rewards > self.config.get("score_to_win", float("inf")):
+                            print("Network won!")
+                            should_exit = True
+                if epoch_num >= self.max_epochs:
+                    if self.writer:
+                        self.save(os.path.join(self.nn_dir, "last_" + self.config["name"] + "ep" + str(epoch_num)
+                                               + "rew" + str(self.mean_rewards)))
+                    print("MAX EPOCHS NUM!")
+                    should_exit = True
+                if self.writer:
+                    self.writer.flush()
+            if self.multi_gpu:
+                flag = torch.tensor(float(should_exit), device=self.device)
+                dist.broadcast(flag, 0)
+                should_exit = bool(flag.item())
+            if should_exit:
+                return self.last_mean_rewards, epoch_num
+
+    def write_stats(self, total_time, epoch_num, play_time, update_time, stats, curr_frames):
+        if not self.writer:
+            return
+        frame = self.frame
+        w = self.writer
+        w.add_scalar("performance/step_inference_rl_update_fps", curr_frames / (play_time + update_time), frame)
+        w.add_scalar("performance/step_inference_fps", curr_frames / play_time, frame)
+        w.add_scalar("performance/rl_update_time", update_time, frame)
+        w.add_scalar("performance/step_inference_time", play_time, frame)
+        w.add_scalar("losses/a_loss", stats["a_loss"], frame)
+        w.add_scalar("losses/c_loss", stats["c_loss"], frame)
+        w.add_scalar("losses/entropy", stats["entropy"], frame)
+        w.add_scalar("losses/bounds_loss", stats["b_loss"], frame)
+        w.add_scalar("info/last_lr", self.last_lr, frame)
+        w.add_scalar("info/e_clip", self.e_clip, frame)
+        w.add_scalar("info/kl", stats["kl"], frame)
+        w.add_scalar("info/epochs", epoch_num, frame)
+
+
+class Runner:
+    """The slice of ``rl_games.torch_runner.Runner`` train.py uses (train.py:139-171): load / reset / run."""
+
+    def __init__(self, algo_observer=None):
+        self.algo_observer = algo_observer
+
+    def load(self, yaml_conf):
+        self.default_config = yaml_conf["params"]
+        self.params = copy.deepcopy(self.default_config)
+        self.seed = self.params.get("seed", None)
+        self.algo_name = self.params["algo"]["name"]
+        if self.algo_name != "a2c_continuous":
+            raise NotImplementedError("algo %r: only a2c_continuous is built" % self.algo_name)
+        self.exp_config = None
+
+    def reset(self):
+        pass
+
+    def run(self, args):
+        if args.get("train", True):
+            agent = A2CAgent("run", copy.deepcopy(self.params), vec_env=args.get("vec_env"),
+                             algo_observer=self.algo_observer)
+            ckpt = args.get("checkpoint")
+            if ckpt:
+                agent.restore(ckpt)
+            return agent.train()
+        from .player import PpoPlayerContinuous
+        player = PpoPlayerContinuous(copy.deepcopy(self.params), vec_env=args.get("vec_env"))
+        if args.get("checkpoint"):
+            player.restore(args["checkpoint"])
+        return player.run()

@@ -1,0 +1,41 @@
+"""Running mean/variance normaliser (rl_games ``RunningMeanStd`` semantics: float64 statistics updated by
+the parallel-variance formula in training mode, output clamped to +-5; ``normalize_input``/``normalize_value``
+of cfg/train/Vine5LinkMovingBasePPO.yaml:54-55)."""
+import torch
+import torch.nn as nn
+
+
+class RunningMeanStd(nn.Module):
+    def __init__(self, insize, epsilon=1e-05):
+        super().__init__()
+        self.insize = insize if isinstance(insize, (tuple, list)) else (insize,)
+        self.epsilon = epsilon
+        self.register_buffer("running_mean", torch.zeros(self.insize, dtype=torch.float64))
+        self.register_buffer("running_var", torch.ones(self.insize, dtype=torch.float64))
+        self.register_buffer("count", torch.ones((), dtype=torch.float64))
+
+    @torch.no_grad()
+    def update(self, x):
+        """Chan et al. merge of the batch moments into the running moments."""
+        x = x.reshape(-1, *self.insize)
+        batch_mean = x.mean(0).double()
+        batch_var = x.var(0, unbiased=True).double() if x.shape[0] > 1 else torch.zeros_like(batch_mean)
+        batch_count = float(x.shape[0])
+        delta = batch_mean - self.running_mean
+        tot = self.count + batch_count
+        new_mean = self.running_mean + delta * batch_count / tot
+        m2 = self.running_var * self.count + batch_var * batch_count + delta.pow(2) * self.count * batch_count / tot
+        self.running_mean.copy_(new_mean)
+        self.running_var.copy_(m2 / tot)
+        self.count.copy_(tot)
+
+    def forward(self, x, unnorm=False):
+        if self.training and not unnorm:
+            self.update(x)
+        mean = self.running_mean.float()
+        std = torch.sqrt(self.running_var.float() + self.epsilon)
+        if unnorm:
+            y = torch.clamp(x, min=-5.0, max=5.0)
+            return std * y + mean
+        y = (x - mean) / std
+        return torch.clamp(y, min=-5.0, max=5.0)

@@ -23,10 +23,13 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-fno-slp-vectorize",
            "-Wall", "-Wno-unused-function", "-o", LIB, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    extra = os.environ.get("VINE_HIPCC_FLAGS")       # experiments only (e.g. "-fslp-vectorize")
+    if extra:
+        cmd[1:1] = extra.split()
     subprocess.check_call(cmd)
     return LIB
 
@@ -35,6 +38,9 @@ def load():
     """Return the ctypes handle of libvine_hip.so with prototypes attached."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64.so.7; it must be the HIP runtime of the process, so it is
+        # loaded first (two runtimes in one process do not both see the device).
+        import torch  # noqa: F401
         if not os.path.exists(LIB):
             raise RuntimeError(
                 "libvine_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
