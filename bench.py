@@ -58,6 +58,20 @@ def make_env(args, rank, device_index):
     return env, cfg
 
 
+def pmc_traffic():
+    """HBM bytes per launch of vine_step_kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/: separate FETCH_SIZE and WRITE_SIZE passes, KiB units).  bench.py cannot collect PMC itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return (d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    except (KeyError, ValueError):
+        return None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -170,7 +184,7 @@ def main():
                                    % (n, env.num_obs, bool(args.randomize), mode),
                        "mode": mode, "num_envs_per_gpu": n, "parallelism": "env-sharded dp%d" % world},
             "roofline": {"bound": "hbm", "kernel": "vine_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
         }
         out.update(extra)

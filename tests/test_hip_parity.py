@@ -238,3 +238,40 @@ def test_task_class_step_contract(HipEnv):
     assert int(env.progress_buf.max()) == 5
     assert float(obs["obs"].abs().max()) <= 5.0
     env.close()
+
+
+def test_ppo_iteration_on_gpu_eager_and_graphed(HipEnv):
+    """The PPO agent on the real task class: one iteration with an eager rollout and one with the rollout
+    replayed from a hipGraph start from the same state and must produce the same experience."""
+    import torch
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+
+    results = []
+    for use_graphs in (False, True):
+        cfg = load_config(overrides=["num_envs=256", "minibatch_size=1024"])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False, use_graphs=use_graphs, mixed_precision=False)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        torch.manual_seed(123)
+        for it in range(2):
+            play, upd, stats = agent.train_epoch()
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(p).all() for p in agent.model.parameters())
+        assert torch.isfinite(agent.buf["obses"]).all() and float(agent.buf["obses"].abs().max()) <= 5.0
+        assert int(env.progress_buf.max()) > 0
+        results.append((agent.buf["obses"].clone(), agent.buf["rewards"].clone(), env.step_count,
+                        {k: float(v) for k, v in stats.items()}))
+        env.close()
+    assert results[0][2] == results[1][2] == 32
+    # the same RNG stream is not guaranteed between eager and captured torch.randn: compare statistics
+    for k in ("a_loss", "c_loss", "kl"):
+        assert np.isfinite(results[0][3][k]) and np.isfinite(results[1][3][k])
+    assert abs(float(results[0][0].mean()) - float(results[1][0].mean())) < 0.05

@@ -1,0 +1,208 @@
+"""PPO arithmetic (rows R1-R6): rl-games==1.5.2 is absent (parity unpinned) -- these tests pin each
+formula this build chose against a direct restatement, and the host-side mechanics on CPU."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from vine_robot_isaacgymenvs_amd import load_config
+from vine_robot_isaacgymenvs_amd.learning import a2c_continuous as a2c
+from vine_robot_isaacgymenvs_amd.learning.network import ModelA2CContinuousLogStd
+from vine_robot_isaacgymenvs_amd.learning.running_mean_std import RunningMeanStd
+
+
+def make_agent(num_envs=32, minibatch=128, seed=42, **conf):
+    from oracle.oracle_vec_task import OracleVecTask
+    cfg = load_config(overrides=["num_envs=%d" % num_envs, "minibatch_size=%d" % minibatch, "rl_device=cpu"])
+    env = OracleVecTask(cfg["task"], seed=seed)
+    params = cfg["train"]["params"]
+    params["config"].update(write_files=False, print_stats=False, **conf)
+    torch.manual_seed(seed)
+    return a2c.A2CAgent("t", params, vec_env=env), cfg
+
+
+def test_network_matches_config_and_param_count():
+    cfg = load_config()
+    for nobs, expect in ((28, 408261), (18, 395461)):
+        m = ModelA2CContinuousLogStd(cfg["train"]["params"]["network"], 2, (nobs,), True, True)
+        assert sum(p.numel() for p in m.parameters()) == expect
+    keys = set(m.state_dict())
+    for k in ("a2c_network.sigma", "a2c_network.actor_mlp.0.weight", "a2c_network.rnn.rnn.weight_ih_l0",
+              "a2c_network.layer_norm.weight", "a2c_network.mu.weight", "a2c_network.value.bias",
+              "running_mean_std.running_mean", "value_mean_std.count"):
+        assert k in keys
+    assert float(m.a2c_network.sigma.abs().max()) == 0.0
+    assert all(float(l.bias.abs().max()) == 0.0 for l in m.a2c_network.modules() if isinstance(l, torch.nn.Linear))
+
+
+def test_lstm_step_loop_equals_nn_lstm_and_zeroes_on_done():
+    cfg = load_config()
+    m = ModelA2CContinuousLogStd(cfg["train"]["params"]["network"], 2, (28,), True, True)
+    w = m.a2c_network.rnn
+    ref = torch.nn.LSTM(92, 256, 1)
+    ref.load_state_dict(w.rnn.state_dict())
+    x = torch.randn(4, 6, 92)
+    h0 = (torch.randn(1, 6, 256), torch.randn(1, 6, 256))
+    o1, (h1, c1) = ref(x, h0)
+    o2, (h2, c2) = w(x, h0)
+    assert torch.allclose(o1, o2, atol=1e-6) and torch.allclose(c1, c2, atol=1e-6)
+    dones = torch.zeros(4, 6)
+    dones[2, 3] = 1                       # env 3 finished an episode before step 2
+    o3, _ = w(x, h0, dones)
+    assert torch.allclose(o3[:2], o2[:2]) and torch.allclose(o3[:, :3], o2[:, :3])
+    z = (torch.zeros(1, 1, 256), torch.zeros(1, 1, 256))
+    o4, _ = ref(x[2:, 3:4], z)
+    assert torch.allclose(o3[2:, 3:4], o4, atol=1e-6)
+
+
+def test_running_mean_std_matches_numpy():
+    rms = RunningMeanStd((5,))
+    rms.train()
+    rng = np.random.default_rng(0)
+    chunks = [rng.normal(2.0, 3.0, (n, 5)).astype(np.float32) for n in (7, 100, 33)]
+    for c in chunks:
+        y = rms(torch.from_numpy(c))
+    allx = np.concatenate([np.zeros((1, 5), np.float32)] + chunks)    # count starts at 1 with mean 0 / var 1
+    cnt = sum(len(c) for c in chunks) + 1
+    assert float(rms.count) == cnt
+    # reproduce the merge sequence in float64
+    mean, var, count = np.zeros(5), np.ones(5), 1.0
+    for c in chunks:
+        bm, bv, bc = c.mean(0), c.var(0, ddof=1), len(c)
+        delta = bm - mean
+        tot = count + bc
+        m2 = var * count + bv * bc + delta ** 2 * count * bc / tot
+        mean, var, count = mean + delta * bc / tot, m2 / tot, tot
+    np.testing.assert_allclose(rms.running_mean.numpy(), mean, rtol=1e-6)
+    np.testing.assert_allclose(rms.running_var.numpy(), var, rtol=1e-6)
+    rms.eval()
+    x = torch.from_numpy(chunks[0])
+    y = rms(x)
+    np.testing.assert_allclose(y.numpy(), np.clip((chunks[0] - mean) / np.sqrt(var + 1e-5), -5, 5), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rms(y, unnorm=True).numpy(), chunks[0], rtol=1e-4, atol=1e-4)
+    assert float(rms.count) == cnt       # eval mode does not update
+
+
+def test_gae_next_nonterminal_form():
+    T, N = 6, 5
+    g = torch.Generator().manual_seed(0)
+    rew, val = torch.rand(T, N, 1, generator=g), torch.rand(T, N, 1, generator=g)
+    dones = (torch.rand(T, N, generator=g) < 0.3).float()
+    fd, last = (torch.rand(N, generator=g) < 0.3).float(), torch.rand(N, 1, generator=g)
+    adv = a2c.discount_values(0.99, 0.95, fd, last, dones, val, rew)
+    exp = np.zeros((T, N))
+    for e in range(N):
+        lam = 0.0
+        for t in reversed(range(T)):
+            nnt = 1 - (fd[e] if t == T - 1 else dones[t + 1, e]).item()
+            nv = (last[e, 0] if t == T - 1 else val[t + 1, e, 0]).item()
+            delta = rew[t, e, 0].item() + 0.99 * nv * nnt - val[t, e, 0].item()
+            lam = delta + 0.99 * 0.95 * nnt * lam
+            exp[t, e] = lam
+    np.testing.assert_allclose(adv[..., 0].numpy(), exp, rtol=1e-5, atol=1e-6)
+
+
+def test_losses_and_kl():
+    adv = torch.tensor([1.0, -1.0, 2.0, -0.5])
+    old, new = torch.tensor([1.0, 1.0, 1.0, 1.0]), torch.tensor([0.5, 1.6, 1.0, 0.9])
+    ratio = torch.exp(old - new)
+    exp = torch.max(-adv * ratio, -adv * ratio.clamp(0.8, 1.2))
+    assert torch.allclose(a2c.actor_loss(old, new, adv, 0.2), exp)
+    vp, v, r = torch.tensor([[0.0], [1.0]]), torch.tensor([[0.5], [0.9]]), torch.tensor([[1.0], [0.0]])
+    cl = a2c.critic_loss(vp, v, 0.2, r, True)
+    assert torch.allclose(cl, torch.tensor([[max(0.25, 0.64)], [max(0.81, 0.81)]]))
+    assert torch.allclose(a2c.critic_loss(vp, v, 0.2, r, False), (r - v) ** 2)
+    mu = torch.tensor([[1.3, -1.0], [0.0, -1.5]])
+    assert torch.allclose(a2c.bound_loss(mu), torch.tensor([0.2 ** 2, 0.4 ** 2]), atol=1e-6)
+    m0, s0 = torch.tensor([[0.1, -0.2]]), torch.tensor([[1.0, 0.5]])
+    m1, s1 = torch.tensor([[0.0, 0.1]]), torch.tensor([[0.8, 0.7]])
+    exact = (torch.log(s1 / s0) + (s0 ** 2 + (m1 - m0) ** 2) / (2 * s1 ** 2) - 0.5).sum()
+    assert abs(float(a2c.policy_kl(m0, s0, m1, s1)) - float(exact)) < 1e-4      # +1e-5 guards only
+    assert abs(float(a2c.policy_kl(m0, s0, m0, s0))) < 2e-5
+
+
+def test_neglogp_is_gaussian_nll():
+    mu, logstd = torch.tensor([[0.3, -0.1]]), torch.tensor([[0.2, -0.4]])
+    x = torch.tensor([[0.5, 0.5]])
+    d = torch.distributions.Normal(mu, logstd.exp())
+    assert torch.allclose(ModelA2CContinuousLogStd.neglogp(x, mu, logstd.exp(), logstd), -d.log_prob(x).sum(-1), atol=1e-6)
+
+
+def test_adaptive_lr_legacy_schedule():
+    agent, _ = make_agent()
+    lr0 = float(agent.lr)
+    agent.update_lr_from_kl(torch.tensor(0.02))         # > 2 * 0.008
+    assert float(agent.lr) == pytest.approx(lr0 / 1.5)
+    agent.update_lr_from_kl(torch.tensor(0.001))        # < 0.5 * 0.008
+    assert float(agent.lr) == pytest.approx(lr0)
+    agent.update_lr_from_kl(torch.tensor(0.008))
+    assert float(agent.lr) == pytest.approx(lr0)
+    agent.lr.fill_(1e-6); agent.update_lr_from_kl(torch.tensor(1.0))
+    assert float(agent.lr) == pytest.approx(1e-6)       # floor
+    agent.lr.fill_(1e-2); agent.update_lr_from_kl(torch.tensor(0.0))
+    assert float(agent.lr) == pytest.approx(1e-2)       # ceiling
+    assert agent.optimizer.param_groups[0]["lr"] is agent.lr     # Adam reads the device scalar
+
+
+def test_rollout_buffers_and_dataset_layout():
+    agent, _ = make_agent(num_envs=8, minibatch=32)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()["obs"]
+    agent.set_eval()
+    with torch.no_grad():
+        batch = agent.play_steps_rnn()
+    T, N = agent.horizon_length, agent.num_actors
+    assert batch["obses"].shape == (T * N, 28) and batch["returns"].shape == (T * N, 1)
+    # env-major flattening: row env*T + t
+    assert torch.equal(batch["obses"][3 * T + 5], agent.buf["obses"][5, 3])
+    assert batch["rnn_states"][0].shape == (1, N * T // agent.seq_len, 256)
+    # stored LSTM state of chunk c of env e sits at sequence index e*(T/seq)+c
+    assert torch.equal(batch["rnn_states"][1][0, 3 * (T // 4) + 2], agent.mb_rnn_states[1][2, 0, 3])
+    # first stored dones are the initial ones (rl_games starts with dones = 1)
+    assert bool((agent.buf["dones"][0] == 1).all())
+    # reward shaper (scale 0.01) applied; bootstrap only where time_outs
+    agent.set_train()
+    agent.prepare_dataset(dict(batch))
+    mb = agent.get_minibatch(1)
+    assert mb["range"] == (32, 64) and mb["obs"].shape == (32, 28) and mb["rnn_states"][0].shape == (1, 8, 256)
+    adv = agent.dataset["advantages"]
+    assert abs(float(adv.mean())) < 1e-5 and abs(float(adv.std()) - 1.0) < 1e-4
+
+
+def test_flat_gradient_buffer_views():
+    agent, _ = make_agent(num_envs=8, minibatch=32)
+    assert agent.num_params == 408261 and agent.flat_grads.numel() == 408261
+    off = 0
+    for p in agent.model.parameters():
+        assert p.grad.data_ptr() == agent.flat_grads.data_ptr() + 4 * off
+        off += p.numel()
+
+
+def test_training_runs_and_checkpoint_roundtrip(tmp_path):
+    agent, cfg = make_agent(num_envs=16, minibatch=64, max_epochs=2)
+    agent.nn_dir = str(tmp_path)
+    before = [p.detach().clone() for p in agent.model.parameters()]
+    agent.train()
+    assert any(not torch.equal(a, b) for a, b in zip(before, agent.model.parameters()))
+    assert all(torch.isfinite(p).all() for p in agent.model.parameters())
+    assert float(agent.model.running_mean_std.count) > 1 and float(agent.model.value_mean_std.count) > 1
+    path = agent.save(os.path.join(str(tmp_path), "ck"))
+    agent2, _ = make_agent(num_envs=16, minibatch=64, seed=7)
+    agent2.restore(path)
+    for a, b in zip(agent.model.state_dict().values(), agent2.model.state_dict().values()):
+        assert torch.equal(a, b)
+    assert agent2.epoch_num == 2 and float(agent2.lr) == pytest.approx(float(agent.lr))
+    # the player consumes the same checkpoint (vine_robot_test_model.py's use)
+    from vine_robot_isaacgymenvs_amd.learning.player import PpoPlayerContinuous
+    params = cfg["train"]["params"]
+    player = PpoPlayerContinuous(params, vec_env=agent.vec_env)
+    player.restore(path)
+    act = player.get_action(torch.zeros(16, 28))
+    assert act.shape == (16, 2) and float(act.abs().max()) <= 1.0
+
+
+def test_config_constraints_are_asserted():
+    with pytest.raises(AssertionError, match="minibatch_size"):
+        make_agent(num_envs=64, minibatch=32768)       # 64*16 = 1024 is not a multiple of 32768 (BASELINE config 1 note)

@@ -132,9 +132,11 @@ class A2CAgent:
         self.config = config = params["config"]
         self.network_params = params["network"]
         self.vec_env = vec_env
+        from ..utils.rlgames_utils import RLGPUEnv
         if self.vec_env is None:
-            from ..utils.rlgames_utils import RLGPUEnv
             self.vec_env = RLGPUEnv(config["env_name"], config["num_actors"])
+        elif not hasattr(self.vec_env, "get_env_info"):
+            self.vec_env = RLGPUEnv.wrap(self.vec_env)
         self.env_info = self.vec_env.get_env_info()
 
         self.multi_gpu = bool(config.get("multi_gpu", False))

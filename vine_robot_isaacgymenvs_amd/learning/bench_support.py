@@ -1,0 +1,82 @@
+"""``bench.py --mode ppo``: time whole PPO iterations (rollout with policy inference + update with the RCCL
+gradient all-reduce) on the env already built by bench.py."""
+import time
+
+import torch
+
+
+def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
+    from .a2c_continuous import A2CAgent
+
+    params = cfg["train"]["params"]
+    conf = params["config"]
+    conf["device"] = str(env.device)
+    conf["multi_gpu"] = world > 1
+    conf["write_files"] = False
+    conf["print_stats"] = False
+    conf["use_graphs"] = not args.no_graph
+    agent = A2CAgent("bench", params, vec_env=env)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()["obs"].to(agent.device)
+    agent.broadcast_parameters()
+
+    # HIP events around every env-step launch of the timed region, on the launching stream
+    events = []
+    orig = env._native_step
+
+    def timed_native_step(a, o):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(a, o)
+        e1.record()
+        events.append((e0, e1))
+
+    for _ in range(warmup):
+        agent.train_epoch()
+    if not conf["use_graphs"]:
+        env._native_step = timed_native_step
+    barrier()
+    play = upd = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p, u, _stats = agent.train_epoch()
+        play += p
+        upd += u
+    barrier()
+    elapsed = time.perf_counter() - t0
+    env._native_step = orig
+
+    # env step alone (resident random actions), same process, right after the timed region
+    g = torch.Generator(device=agent.device).manual_seed(1)
+    pool = [torch.rand((env.num_envs, 2), device=agent.device, generator=g) * 2 - 1 for _ in range(16)]
+    pairs = []
+    n_env_only = 500
+    for i in range(50):
+        orig(pool[i % 16], env.obs_buf)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(n_env_only):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(pool[i % 16], env.obs_buf)
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    env_only_s = time.perf_counter() - t1
+    env_only_kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+    # kernel duration inside the timed region when it was launched eagerly; otherwise (launches live inside the
+    # replayed hipGraph, where no event can be recorded) the same kernel timed back-to-back just above
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events) if events else env_only_kernel_ms
+    frames = agent.horizon_length * agent.num_actors
+    extra = {
+        "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
+                     "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},
+        "ppo_iters_per_sec": steps / elapsed,
+        "rollout_env_steps_per_sec": frames * world * steps / max(play, 1e-9),
+        "rollout_ms": play / steps * 1e3, "update_ms": upd / steps * 1e3,
+        "ppo": {"horizon": agent.horizon_length, "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs_num,
+                "optimizer_steps_per_iter": agent.mini_epochs_num * agent.num_minibatches,
+                "params": agent.num_params, "mixed_precision": agent.mixed_precision,
+                "rollout_hipgraph": bool(conf["use_graphs"])},
+    }
+    return elapsed, kernel_ms, frames, extra

@@ -39,6 +39,13 @@ class RLGPUEnv:
     def __init__(self, config_name, num_actors, **kwargs):
         self.env = env_configurations[config_name]["env_creator"](**kwargs)
 
+    @classmethod
+    def wrap(cls, env):
+        """Adapter around an already built task object."""
+        self = cls.__new__(cls)
+        self.env = env
+        return self
+
     def step(self, actions):
         return self.env.step(actions)
 
