@@ -522,22 +522,26 @@ int vine_oracle_simulate(const VineConfig* cfg, int form, double* q, double* qd,
 }
 
 /* ------------------------------------------------------------------------- */
-/* Planar shelf contact (config 5).  Frictionless penalty
- * contact of the link rectangles against the three shelf boxes; only the force
- * on the `shelf_link` front-edge strip is reported (V5:329-336; VT:349-351).
- * The contact solver is the build's own choice (PhysX unavailable): unpinned. */
-#define SHELF_NBOX 3
-static const real SHELF_BOX[SHELF_NBOX][4] = {
-    /* cy,      cz,   hy,     hz   (shelf frame; custom_shelf.urdf:82-93, 139-152) */
-    {-0.001f, 0.0f, 0.1995f, 0.005f},  /* board A on link `shelf` */
-    {0.0f, 0.2f, 0.2f, 0.005f},        /* board B on link `shelf` */
-    {0.199f, 0.0f, 0.001f, 0.005f},    /* front-edge strip on `shelf_link` (reported) */
+/* Planar shelf contact (config 5).  The contact solver is the build's own choice
+ * (PhysX is unavailable: unpinned): frictionless penalty contacts, explicit per substep.
+ *   (a) six points of every link rectangle (4 corners + 2 mid-edge) against the two boards of link `shelf`
+ *       (custom_shelf.urdf:82-93), axis-aligned boxes in the world;
+ *   (b) the two front corners of the 2 mm front-edge strip on `shelf_link` (custom_shelf.urdf:139-152) against
+ *       every link rectangle; only (b) feeds the reported contact force (V5:329-336; VT:349-351).
+ * Link rectangle in link-local (y, z): y in [-0.0381, +0.0719] (main cylinder r = 0.0381 + FPAM cylinder at
+ * y = 0.055, r = 0.0169; URDF:95-115), z in [0, L] (link_0: length 0.1 centred at 0.04425 -> [-0.00575, 0.09425]).
+ * Local z maps to d = (-sin phi, cos phi), local y to l = (cos phi, sin phi) in world (y, z). */
+#define CONTACT_K ((real)2000.0)  /* N/m   penalty stiffness */
+#define CONTACT_C ((real)2.0)     /* N s/m penalty damping   */
+#define LINK_Y0 ((real)-0.0381)
+#define LINK_Y1 ((real)0.0719)
+static const real BOARD[2][4] = {
+    /* cy,      cz,   hy,     hz   in the shelf frame */
+    {-0.001f, 0.0f, 0.1995f, 0.005f},
+    {0.0f, 0.2f, 0.2f, 0.005f},
 };
-#define CONTACT_STIFFNESS ((real)2000.0)  /* N/m   penalty spring     */
-#define CONTACT_DAMPING ((real)2.0)       /* N s/m penalty damper     */
-#define CONTACT_NPTS 4                    /* sample points per link edge */
 
-/* Adds contact generalised forces (relative coords) to Qc and returns |F| on the strip. */
+/* Adds the contact generalised forces (relative coordinates) to Qc; returns |F| on the strip. */
 static real shelf_contact(const Model* M, const real* q, const real* qd, real shelf_y, real shelf_z, real* Qc) {
     real strip_fy = 0, strip_fz = 0;
     real ang = M->phi0, om = 0;
@@ -546,51 +550,73 @@ static real shelf_contact(const Model* M, const real* q, const real* qd, real sh
     for (int k = 0; k < NL; ++k) {
         ang += q[k + 1]; om += qd[k + 1];
         real s = (real)sin((double)ang), c = (real)cos((double)ang);
-        real dy = -s, dz = c, ny = -c, nz = -s; /* link axis and its +90deg normal (local +y maps to -n?) */
-        /* local frame of link k: local z along d; local y = rotate(d, -90deg) about x = (c, s)?  The URDF
-         * places the FPAM cylinder at local +y.  With roll phi about x, local y axis in world (y,z) is
-         * (cos phi, sin phi) = (c, s) = -n. */
-        real ly = c, lz = s;
-        /* rectangle local y in [-0.0381, +0.0719], local z in [0, L]; sample the two long edges */
-        static const real edge_off[2] = {-0.0381f, 0.0719f};
+        real dy = -s, dz = c, ly = c, lz = s;
+        real z0 = (k == 0) ? (real)-0.00575 : 0, z1 = (k == 0) ? (real)0.09425 : M->L;
+        real fy_tot = 0, fz_tot = 0;   /* applied to this link, with moments about every proximal joint */
+        real mom[NL];
+        for (int j = 0; j <= k; ++j) mom[j] = 0;
+        /* (a) link points vs boards */
         for (int e = 0; e < 2; ++e)
-            for (int t = 0; t <= CONTACT_NPTS; ++t) {
-                real zl = M->L * (real)t / CONTACT_NPTS;
-                real ry = zl * dy + edge_off[e] * ly, rz = zl * dz + edge_off[e] * lz; /* from joint k */
+            for (int t = 0; t < 3; ++t) {
+                real yl = e ? LINK_Y1 : LINK_Y0;
+                real zl = (t == 0) ? z0 : (t == 1 ? (real)0.5 * (z0 + z1) : z1);
+                real ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
                 real wy = py[k] + ry, wz = pz[k] + rz;
-                real vy = pvy + om * (-rz), vz = pvz + om * (ry);
-                for (int bx = 0; bx < SHELF_NBOX; ++bx) {
-                    real by = shelf_y + SHELF_BOX[bx][0], bz = shelf_z + SHELF_BOX[bx][1];
-                    real ex = SHELF_BOX[bx][2] - (real)fabs((double)(wy - by));
-                    real ez = SHELF_BOX[bx][3] - (real)fabs((double)(wz - bz));
-                    if (ex <= 0 || ez <= 0) continue;
-                    /* push out along the axis of least penetration */
+                real vy = pvy - om * rz, vz = pvz + om * ry;
+                for (int bx = 0; bx < 2; ++bx) {
+                    real ddy = wy - (shelf_y + BOARD[bx][0]), ddz = wz - (shelf_z + BOARD[bx][1]);
+                    real ey = BOARD[bx][2] - (real)fabs((double)ddy), ez = BOARD[bx][3] - (real)fabs((double)ddz);
+                    if (ey <= 0 || ez <= 0) continue;
                     real fy = 0, fz = 0;
-                    if (ex < ez) {
-                        real sgn = (wy > by) ? 1 : -1;
-                        real f = CONTACT_STIFFNESS * ex - CONTACT_DAMPING * sgn * vy;
-                        if (f < 0) f = 0;
-                        fy = sgn * f;
+                    if (ey < ez) {
+                        real sg = (ddy > 0) ? (real)1 : (real)-1;
+                        real f = CONTACT_K * ey - CONTACT_C * sg * vy;
+                        fy = sg * (f > 0 ? f : 0);
                     } else {
-                        real sgn = (wz > bz) ? 1 : -1;
-                        real f = CONTACT_STIFFNESS * ez - CONTACT_DAMPING * sgn * vz;
-                        if (f < 0) f = 0;
-                        fz = sgn * f;
+                        real sg = (ddz > 0) ? (real)1 : (real)-1;
+                        real f = CONTACT_K * ez - CONTACT_C * sg * vz;
+                        fz = sg * (f > 0 ? f : 0);
                     }
-                    if (bx == 2) { strip_fy -= fy; strip_fz -= fz; }
-                    /* J^T f: cart + every joint j <= k */
-                    Qc[0] += fy;
-                    for (int j = 0; j <= k; ++j) {
-                        real ay = wy - py[j], az = wz - pz[j];
-                        Qc[j + 1] += (-az) * fy + ay * fz;
-                    }
+                    fy_tot += fy; fz_tot += fz;
+                    for (int j = 0; j <= k; ++j) mom[j] += (wy - py[j]) * fz - (wz - pz[j]) * fy;
                 }
             }
-        (void)ny; (void)nz;
+        /* (b) strip front corners vs this link's rectangle */
+        for (int e = 0; e < 2; ++e) {
+            real wy = shelf_y + (real)0.2, wz = shelf_z + (e ? (real)0.005 : (real)-0.005);
+            real ry = wy - py[k], rz = wz - pz[k];
+            real zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+            if (!(zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1)) continue;
+            /* exit through the nearest face: outward normal n, depth dep */
+            real dep = zl - z0, ny = -dy, nz = -dz;
+            if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+            if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+            if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+            real vy = pvy - om * rz, vz = pvz + om * ry;          /* link material velocity at the point */
+            real f = CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz);
+            if (f < 0) f = 0;
+            strip_fy += f * ny; strip_fz += f * nz;               /* on the strip */
+            real fy = -f * ny, fz = -f * nz;                      /* on the link  */
+            fy_tot += fy; fz_tot += fz;
+            for (int j = 0; j <= k; ++j) mom[j] += (wy - py[j]) * fz - (wz - pz[j]) * fy;
+        }
+        Qc[0] += fy_tot;
+        for (int j = 0; j <= k; ++j) Qc[j + 1] += mom[j];
+        (void)fz_tot;
         py[k + 1] = py[k] + M->L * dy; pz[k + 1] = pz[k] + M->L * dz;
         pvy += M->L * om * (-c); pvz += M->L * om * (-s);
     }
     return (real)sqrt((double)(strip_fy * strip_fy + strip_fz * strip_fz));
+}
+/* exported for tests */
+double vine_oracle_shelf_contact(const VineConfig* cfg, const double* q, const double* qd, double shelf_y,
+                                 double shelf_z, double* Qc) {
+    Model M; model_init(&M, cfg);
+    real rq[ND], rqd[ND], Q[ND];
+    for (int i = 0; i < ND; ++i) { rq[i] = (real)q[i]; rqd[i] = (real)qd[i]; Q[i] = 0; }
+    real f = shelf_contact(&M, rq, rqd, (real)shelf_y, (real)shelf_z, Q);
+    for (int i = 0; i < ND; ++i) Qc[i] = Q[i];
+    return f;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -94,6 +94,39 @@ def test_single_step_matches_oracle(HipEnv, obs_type, randomize, delay):
         hip.close(); orc.close()
 
 
+def test_shelf_contacts_match_oracle(HipEnv):
+    """BASELINE config 5: vine_randomize + CREATE_SHELF + ACTION_DELAY=1.  The shelf is placed around each env's
+    tip so that board and front-edge contacts are active in a good fraction of envs."""
+    n = 768
+    cfg = base_cfg(n, 0, True, action_delay=1, seed=77)
+    cfg.set_flag(abi.FLAG_CREATE_SHELF, True)
+    cfg.set_flag(abi.FLAG_USE_NONZERO_CONTACT_FORCE_RESET, True)
+    rng = np.random.default_rng(21)
+    for precision, tol in (("f32", (5e-5, 1e-2, 1e-2)), ("f64", (2e-4, 3e-2, 3e-2))):
+        hip, orc = pair(HipEnv, cfg, precision)
+        st = seed_both(hip, orc, rng, n, cfg)
+        st[abi.VF_SHELF_Y] = st[abi.VF_TIP_Y] - 0.2 - 0.05 + rng.uniform(-0.04, 0.04, n)
+        st[abi.VF_SHELF_Z] = st[abi.VF_TIP_Z] + rng.uniform(-0.06, 0.06, n)
+        st[abi.VF_CONTACT] = rng.uniform(0, 1, n) * (rng.uniform(size=n) < 0.3)
+        hip.set_state(st)
+        orc.state[:] = st.astype(orc.real)
+        actions = rng.uniform(-1, 1, (n, 2))
+        out = hip.step(actions)
+        orc.step(actions)
+        hs, os_ = hip.state, orc.state.astype(np.float64)
+        touched = os_[abi.VF_CONTACT_MEAN] > 0
+        assert touched.mean() > 0.05
+        # a contact that opens/closes within round-off flips discrete decisions: compare envs whose contact state agrees
+        same = (hs[abi.VF_CONTACT_MEAN] > 0) == touched
+        assert same.mean() > 0.98
+        np.testing.assert_allclose(hs[QPOS][:, same], os_[QPOS][:, same], rtol=0, atol=tol[0] * 4)
+        np.testing.assert_allclose(hs[QVEL][:, same], os_[QVEL][:, same], rtol=0, atol=tol[1] * 4)
+        np.testing.assert_allclose(hs[abi.VF_CONTACT_MEAN][same], os_[abi.VF_CONTACT_MEAN][same], rtol=2e-2, atol=2e-2)
+        np.testing.assert_allclose(hs[abi.VF_CONTACT][same], os_[abi.VF_CONTACT][same], rtol=2e-2, atol=2e-2)
+        np.testing.assert_array_equal(out[2][same], orc.reset_buf[same])
+        hip.close(); orc.close()
+
+
 def test_first_step_resets_everything(HipEnv):
     """reset_buf starts at ones (vec_task.py:275): the first step simulates the zero pose, then resets all envs."""
     n = 512

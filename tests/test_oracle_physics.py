@@ -204,3 +204,58 @@ def test_held_velocity_feedback_is_unstable():
             blew = True
             break
     assert blew
+
+
+def test_shelf_contact_model():
+    """Config 5 contacts (solver unpinned): zero away from the shelf; the strip force is
+    reported only for front-edge contacts; generalised forces equal J^T F (checked by virtual work)."""
+    import ctypes as C
+    lib = vo.load("f64")
+    cfg = vo.default_config()
+    D = C.POINTER(C.c_double)
+
+    def contact(q, qd, sy, sz):
+        q, qd = np.ascontiguousarray(q, np.float64), np.ascontiguousarray(qd, np.float64)
+        Q = np.zeros(6)
+        f = lib.vine_oracle_shelf_contact(C.byref(cfg), q.ctypes.data_as(D), qd.ctypes.data_as(D), sy, sz,
+                                          Q.ctypes.data_as(D))
+        return f, Q
+
+    q0 = np.zeros(6)
+    f, Q = contact(q0, np.zeros(6), 0.2 + 1.0, 0.0)          # shelf far away
+    assert f == 0 and not Q.any()
+    # hanging chain, tip at (0, 0.5225): put the strip's front corner 5 mm inside the last link, on its -y side
+    t = vo.tip(cfg, q0, np.zeros(6))
+    sy = t[0] - 0.2 - 0.0719 + 0.005        # front face x = shelf_y + 0.2 sits 5 mm inside the FPAM-side face (world -y)
+    sz = t[1] + 0.03
+    f, Q = contact(q0, np.zeros(6), sy, sz)
+    assert f > 0                                              # strip is touched
+    assert abs(f - 2 * 2000.0 * 0.005) < 0.5                  # two corners, 5 mm deep, k = 2000 N/m
+    assert Q[0] > 0                                           # the link (and the cart) is pushed towards +y, out of the shelf
+    # virtual work: Q . dq == sum F . dx ; here all force is along y on link 5: Q0 = Fy_total = f
+    assert abs(Q[0] - f) < 1e-5 * f                           # phi0 = 3.1415 tilts the face normal by 9e-5 rad
+    # moment about joint 1 = lever arm (vertical distance) x force
+    lever = (0.965 - sz)
+    assert abs(abs(Q[1]) - f * lever) < 0.02 * f * lever
+    # board contact alone does not touch the strip: lay the tip corner on the top of board A
+    sy2, sz2 = t[0] - 0.1, t[1] - 0.003                       # board top = sz2 + 0.005 is 2 mm above the link's end
+    f2, Q2 = contact(q0, np.zeros(6), sy2, sz2)
+    assert f2 == 0 and Q2.any()
+
+
+def test_shelf_run_is_stable():
+    cfg = vo.default_config(num_envs=64)
+    cfg.set_flag(abi.FLAG_CREATE_SHELF, True)
+    cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, False)
+    env = vo.OracleEnv(cfg, "f64")
+    rng = np.random.default_rng(0)
+    touched = 0
+    a = np.zeros((64, 2))
+    for s in range(300):
+        if s % 8 == 0:
+            a = np.sign(rng.uniform(-1, 1, (64, 2)))
+        env.step(a)
+        assert np.isfinite(env.state).all()
+        assert np.abs(env.state[abi.VF_QD0 + 1:abi.VF_QD0 + 6]).max() < 60
+        touched += int((env.state[abi.VF_CONTACT_MEAN] > 0).sum())
+    assert touched > 0

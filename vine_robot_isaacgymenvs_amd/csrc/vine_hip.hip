@@ -107,9 +107,9 @@ __device__ __forceinline__ void dyn_sync_trig(Dyn& s) {
 //   row 0:  mtot*ydd - sum_i b_i cos(phi_i) thdd_i = F - cj0*vy - sum_i b_i sin(phi_i) w_i^2
 //   row i: -b_i cos(phi_i) ydd + sum_j a_ij cos(th_i-th_j) thdd_j
 //            = T_i - T_{i+1} - cad*I_i*w_i - sum_j a_ij sin(th_i-th_j) w_j^2 + g b_i sin(phi_i)
-template <bool IMPLICIT>
+template <bool IMPLICIT, bool CONTACT>
 __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float (&eff)[ND], const float (&cj)[ND],
-                                        const float (&hc)[ND]) {
+                                        const float (&hc)[ND], const float (&qa)[ND]) {
     float sp[NL], cp[NL], w2[NL];
     const float (&sn)[NL] = s.sn;
     const float (&cs)[NL] = s.cs;
@@ -129,11 +129,13 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
     float r[ND];
     A[0][0] = P.mtot;
     r[0] = eff[0] - cj[0] * s.vy;
+    if (CONTACT) r[0] += qa[0];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         A[i + 1][0] = -P.b[i] * cp[i];
         r[0] -= P.b[i] * sp[i] * w2[i];
         r[i + 1] = T[i] - T[i + 1] - P.cad * P.I[i] * s.w[i] + P.gb[i] * sp[i];
+        if (CONTACT) r[i + 1] += qa[i + 1];
         A[i + 1][i + 1] = P.a[i][i];
     }
 #pragma unroll
@@ -204,6 +206,90 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
         s.sn[i] = fmaf(s_old, cd, c_old * sd);
         s.cs[i] = fmaf(c_old, cd, -(s_old * sd));
     }
+}
+
+// Planar frictionless penalty contact against the shelf (CREATE_SHELF; DESIGN.md section 3, oracle/vine_oracle.c
+// shelf_contact): (a) 6 points of every link rectangle vs the two boards, (b) the two front corners of the
+// `shelf_link` strip vs every link rectangle.  Writes generalised forces in ABSOLUTE coordinates
+// (d x / d th_i = L n_i for i < k, z n_k + y d_k for i = k) and returns |F| on the strip.
+#define CONTACT_K 2000.0f
+#define CONTACT_C 2.0f
+#define LINK_Y0 (-0.0381f)
+#define LINK_Y1 0.0719f
+__device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s, float shelf_y, float shelf_z,
+                                               float (&qa)[ND]) {
+    const float board[2][4] = {{-0.001f, 0.0f, 0.1995f, 0.005f}, {0.0f, 0.2f, 0.2f, 0.005f}};
+    float strip_fy = 0.0f, strip_fz = 0.0f;
+    float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
+    float Fy[NL], Fz[NL], ny_[NL], nz_[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const float sp = P.s0 * s.cs[k] + P.c0 * s.sn[k], cp = P.c0 * s.cs[k] - P.s0 * s.sn[k];
+        const float dy = -sp, dz = cp, ly = cp, lz = sp;     // link axis d, lateral l; n = d(d)/d(phi) = (-cp, -sp) = -l
+        const float om = s.w[k];
+        const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
+        float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
+        ny_[k] = -cp; nz_[k] = -sp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float yl = e ? LINK_Y1 : LINK_Y0;
+                const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+                const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                const float wy = py + ry, wz = pz + rz;
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+#pragma unroll
+                for (int bx = 0; bx < 2; ++bx) {
+                    const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
+                    const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
+                    if (ey > 0.0f && ez > 0.0f) {
+                        float fy = 0.0f, fz = 0.0f;
+                        if (ey < ez) {
+                            const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                            fy = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vy, 0.0f);
+                        } else {
+                            const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                            fz = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vz, 0.0f);
+                        }
+                        fy_tot += fy; fz_tot += fz;
+                        mom += -rz * fy + ry * fz;          // F . (z n_k + y d_k) = r x F about joint k
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float wy = shelf_y + 0.2f, wz = shelf_z + (e ? 0.005f : -0.005f);
+            const float ry = wy - py, rz = wz - pz;
+            const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+            if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                float dep = zl - z0, ny = -dy, nz = -dz;
+                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                strip_fy += f * ny; strip_fz += f * nz;
+                const float fy = -f * ny, fz = -f * nz;
+                fy_tot += fy; fz_tot += fz;
+                mom += -rz * fy + ry * fz;
+            }
+        }
+        Fy[k] = fy_tot; Fz[k] = fz_tot;
+        qa[k + 1] = mom;
+        py += P.L * dy; pz += P.L * dz;
+        pvy += P.L * om * (-cp); pvz += P.L * om * (-sp);
+    }
+    // forces on distal links act on joint i through the lever L n_i
+    float sy = 0.0f, sz = 0.0f;
+#pragma unroll
+    for (int i = NL - 1; i >= 0; --i) {
+        qa[i + 1] += P.L * (ny_[i] * sy + nz_[i] * sz);
+        sy += Fy[i]; sz += Fz[i];
+    }
+    qa[0] = sy;
+    return sqrtf(strip_fy * strip_fy + strip_fz * strip_fz);
 }
 
 __device__ __forceinline__ float clampf(float v, float lim) { return fminf(fmaxf(v, -lim), lim); }
@@ -283,7 +369,7 @@ __device__ __forceinline__ void tip_fk(const DevParams& P, float y, float vy, co
     tip[0] = ty; tip[1] = tz; tip[2] = tvy; tip[3] = tvz;
 }
 
-template <int OBS_TYPE, bool RANDOMIZE>
+template <int OBS_TYPE, bool RANDOMIZE, bool SHELF>
 __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float* __restrict__ st,
                                                        const float* __restrict__ actions, float* __restrict__ obs,
                                                        float* __restrict__ rew, long long* __restrict__ reset,
@@ -338,6 +424,8 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
         float cart_y = ST(VF_CART_Y), cart_vy = ST(VF_CART_VY);
         float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
         float rail_force = 0.0f;
+        float contact = SHELF ? ST(VF_CONTACT) : 0.0f, contact_sum = 0.0f;
+        const float shelf_y = SHELF ? ST(VF_SHELF_Y) : 0.0f, shelf_z = SHELF ? ST(VF_SHELF_Z) : 0.0f;
         const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
         const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
 
@@ -402,11 +490,21 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             }
 #pragma unroll
             for (int i = 0; i < ND; ++i) hc[i] = P.hsub * cj[i];
+            float qa[ND] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float csum = 0.0f;
+            if (SHELF) contact_sum += contact;            // vec_task.py:348-351: force left by the previous simulate
             if (P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) {
-                for (int k = 0; k < P.substeps; ++k) substep<true>(P, s, eff, cj, hc);
+                for (int k = 0; k < P.substeps; ++k) {
+                    if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);
+                    substep<true, SHELF>(P, s, eff, cj, hc, qa);
+                }
             } else {
-                for (int k = 0; k < P.substeps; ++k) substep<false>(P, s, eff, cj, hc);
+                for (int k = 0; k < P.substeps; ++k) {
+                    if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);
+                    substep<false, SHELF>(P, s, eff, cj, hc, qa);
+                }
             }
+            if (SHELF) contact = csum / (float)P.substeps;
             cart_y = s.y;
             cart_vy = s.vy;
         }
@@ -505,7 +603,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
         const bool reached = dist < P.success_dist;
         const bool limit_hit = (cart_y > P.soft_limit) || (cart_y < -P.soft_limit);
         const bool tip_limit_hit = tip[0] < ty;
-        const float cmean = 0.0f;  // CREATE_SHELF contacts: not built in this kernel yet
+        const float cmean = SHELF ? contact_sum / (float)P.cfi : 0.0f;      // V5:1242-1248
         const float vnorm = sqrtf(tip[2] * tip[2] + tip[3] * tip[3]);
         float rm[VINE_NUM_REWARDS];
         rm[0] = -dist;
@@ -530,6 +628,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
         if (reached && (P.flags & VINE_FLAG_USE_TARGET_REACHED_RESET)) rst = 1;
         if (tip_limit_hit && (P.flags & VINE_FLAG_USE_TIP_LIMIT_HIT_RESET)) rst = 1;
         if (limit_hit) rst = 1;
+        if (SHELF && cmean > 0.0f && (P.flags & VINE_FLAG_USE_NONZERO_CONTACT_FORCE_RESET)) rst = 1;
         // ---- VecTask.step epilogue (vec_task.py:366-380) ----
         const unsigned char to = (prog >= (long long)P.max_len - 1) && (rst != 0);
         float* orow = obs + (size_t)e * NOBS;
@@ -559,6 +658,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
         ST(VF_PREV_U_RAIL) = prev_u_rail;
         ST(VF_PREV_CART_VEL) = pcv; ST(VF_PREV_CART_VEL_ERR) = pce;
         ST(VF_AGG_REW) = agg; ST(VF_RAIL_FORCE) = rail_force;
+        if (SHELF) { ST(VF_CONTACT) = contact; ST(VF_CONTACT_MEAN) = cmean; }
     }
     // ---- advance the step counter once every workgroup has read it (ticket) ----
     __syncthreads();
@@ -628,8 +728,6 @@ int validate(const VineConfig* c) {
     if (c->action_delay < 0 || c->action_delay > VINE_MAX_DELAY)
         return fail(VINE_ERR_INVALID_ARG, "ACTION_DELAY out of range");
     if (vine_num_obs(c) < 0) return VINE_ERR_UNSUPPORTED;
-    if (c->flags & VINE_FLAG_CREATE_SHELF)
-        return fail(VINE_ERR_UNSUPPORTED, "CREATE_SHELF contacts are not built into the HIP path yet");
     return VINE_OK;
 }
 
@@ -832,17 +930,21 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     const int blocks = (h->P.n + threads - 1) / threads;
     hipStream_t s = (hipStream_t)stream;
     const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
-#define LAUNCH(OT, RND)                                                                                      \
-    hipLaunchKernelGGL((vine_step_kernel<OT, RND>), dim3(blocks), dim3(threads), 0, s, h->P, h->state, actions, obs, \
-                       rew, (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,   \
-                       h->reset_values, h->counters)
-    if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
-        if (rnd) LAUNCH(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, true);
-        else LAUNCH(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, false);
-    } else {
-        if (rnd) LAUNCH(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, true);
-        else LAUNCH(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, false);
-    }
+    const bool shelf = (h->P.flags & VINE_FLAG_CREATE_SHELF) != 0;
+#define LAUNCH(OT, RND, SH)                                                                                      \
+    hipLaunchKernelGGL((vine_step_kernel<OT, RND, SH>), dim3(blocks), dim3(threads), 0, s, h->P, h->state, actions, \
+                       obs, rew, (long long*)reset, (long long*)progress, (unsigned char*)timeouts,                 \
+                       h->reward_matrix, h->reset_values, h->counters)
+#define LAUNCH_OT(OT)                               \
+    do {                                            \
+        if (rnd && shelf) LAUNCH(OT, true, true);   \
+        else if (rnd) LAUNCH(OT, true, false);      \
+        else if (shelf) LAUNCH(OT, false, true);    \
+        else LAUNCH(OT, false, false);              \
+    } while (0)
+    if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) LAUNCH_OT(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO);
+    else LAUNCH_OT(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
+#undef LAUNCH_OT
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return VINE_OK;
