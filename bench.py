@@ -39,7 +39,9 @@ def parse_args():
     p.add_argument("--obs-type", default="POS_AND_FD_VEL_AND_OBJ_INFO")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-graph", action="store_true", help="env mode: eager launches instead of hipGraph replay")
+    p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
+    p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
+                   help="ppo mode: autocast dtype of the update (default: the train YAML: mixed_precision fp16)")
     return p.parse_args()
 
 
@@ -121,10 +123,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # Rehearsal hook (one-GPU box): VINE_BENCH_SHARE_DEVICE=1 maps every rank onto cuda:0 and uses gloo, so the
+    # multi-process code path can be exercised without N GPUs.  Never set by the driver.
+    share = os.environ.get("VINE_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     try:

@@ -11,7 +11,7 @@ f = glob.glob('$OUT/trace/*/*_kernel_stats.csv')[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print('total kernel ms', tot/1e6)
-for r in rows[:40]:
+for r in rows[:28]:
     print('%8.2f ms %6s calls %8.1f us avg  %5.1f%%  %s' % (float(r['TotalDurationNs'])/1e6, r['Calls'], float(r['AverageNs'])/1e3, float(r['Percentage']), r['Name'][:110]))
 PY
 tail -2 $OUT/bench.log | cut -c1-400

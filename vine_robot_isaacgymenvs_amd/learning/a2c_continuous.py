@@ -148,7 +148,7 @@ class A2CAgent:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 backend = "nccl" if str(config.get("device", "cuda")).startswith("cuda") else "gloo"
                 dist.init_process_group(backend, rank=int(os.getenv("RANK", self.rank)), world_size=self.rank_size)
-            if str(config.get("device", "cuda:0")).startswith("cuda"):
+            if str(config.get("device", "cuda:0")).startswith("cuda") and not config.get("device_pinned", False):
                 config["device"] = "cuda:" + str(self.rank)
         self.ppo_device = self.device = torch.device(config.get("device", "cuda:0"))
         self.is_cuda = self.device.type == "cuda"

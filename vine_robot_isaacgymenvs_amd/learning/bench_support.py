@@ -11,10 +11,15 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     params = cfg["train"]["params"]
     conf = params["config"]
     conf["device"] = str(env.device)
+    conf["device_pinned"] = True          # bench.py already chose the device of this rank
     conf["multi_gpu"] = world > 1
     conf["write_files"] = False
     conf["print_stats"] = False
     conf["use_graphs"] = not args.no_graph
+    if args.amp == "off":
+        conf["mixed_precision"] = False
+    elif args.amp:
+        conf["mixed_precision"], conf["mixed_precision_dtype"] = True, args.amp
     agent = A2CAgent("bench", params, vec_env=env)
     agent.init_tensors()
     agent.obs = agent.env_reset()["obs"].to(agent.device)
