@@ -1,0 +1,57 @@
+/*
+ * vine_ppo.h — C ABI of the fused PPO-update ops (rows R1, R3 of SURVEY 8a) exported by libvine_hip.so.
+ *
+ * The reference runs these through rl_games 1.5.2 (absent; PY = cfg/train/Vine5LinkMovingBasePPO.yaml):
+ *   - LSTM cell pointwise math of `rnn: lstm, units 256` (PY:31-37), stepped seq_len = 4 (PY:80) in the update and
+ *     1 step at a time in the rollout, with the hidden state zeroed where `dones` is set;
+ *   - the PPO loss of calc_gradients (in-tree text: isaacgymenvs/learning/common_agent.py:319-411, 427-435,
+ *     482-516): clipped surrogate, clipped value loss, bound loss, entropy, KL.
+ * GEMMs stay in hipBLASLt/rocBLAS (MFMA); these kernels fuse the surrounding pointwise work, which otherwise
+ * costs ~300 tiny launches per optimiser step.
+ *
+ * All pointers are device pointers owned by the caller (PyTorch); calls enqueue on `stream` and never synchronise.
+ * Returns 0 or a negative VineStatus (vine.h); message via vine_last_error().
+ */
+#ifndef VINE_PPO_H
+#define VINE_PPO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One LSTM step for B sequences, hidden size H (gate order i, f, g, o as torch.nn.LSTM).
+ *   gates = igates[b] + keep_b * hgates[b] + bias;  c' = f * (keep_b * c_prev) + i * g;  h' = o * tanh(c')
+ * keep_b = 1 - done[b * done_stride] (done == NULL: keep = 1).
+ * igates rows are `ig_stride` floats apart (a [B, T, 4H] tensor viewed at time t), h_out rows `h_stride` apart.
+ * gates_act (nullable, [B,4H]) receives the activated gates for the backward pass. */
+int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
+                           const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
+                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* stream);
+
+/* Backward of the step above.
+ *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
+ * g_rec / dc_next = gradients w.r.t. the MASKED (h_t, c_t) consumed by step t+1 (NULL at the last step),
+ * keep_next = 1 - done_next.  Writes the pre-activation gate gradients (rows dg_stride apart) and the gradient
+ * w.r.t. the masked c_{t-1} (dc_prev = dc * f). */
+int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
+                            const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
+                            const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
+                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev, void* stream);
+
+/* PPO loss of one minibatch of n samples with A action dims, forward AND backward in one pass:
+ *   loss = mean(a_loss) + 0.5 * critic_coef * mean(c_loss) - entropy_coef * mean(entropy) + bounds_coef * mean(b_loss)
+ * Outputs d(loss)/d(mu) [n,A], d(loss)/d(value) [n], d(loss)/d(logstd) [A] and
+ * stats[8] = {mean a_loss, mean c_loss, mean b_loss, mean entropy, mean kl(old||new), loss, 0, 0}.
+ * grad_logstd and stats are zeroed by the call. */
+int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, const float* value, const float* actions,
+                  const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
+                  const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
+                  float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
+                  float* grad_logstd, float* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VINE_PPO_H */

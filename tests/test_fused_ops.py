@@ -1,0 +1,141 @@
+"""Numerics of the hand-written PPO-update kernels (csrc/ppo_kernels.hip) against the plain PyTorch fp32 composition
+they replace.  Tolerances: fp32 with different summation orders / exp-based tanh -> 2e-5 relative on activations,
+1e-4 on gradients reduced over 32768 rows."""
+import numpy as np
+import pytest
+import torch
+
+from vine_robot_isaacgymenvs_amd.learning import fused
+
+
+def test_lstm_reference_matches_time_major_loop():
+    """CPU: the sequence-major reference used as fallback == the module's time-major loop == nn.LSTM."""
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.network import ModelA2CContinuousLogStd
+    m = ModelA2CContinuousLogStd(load_config()["train"]["params"]["network"], 2, (28,), True, True)
+    w = m.a2c_network.rnn
+    B, T = 6, 4
+    x = torch.randn(B * T, 92)
+    h0, c0 = torch.randn(1, B, 256), torch.randn(1, B, 256)
+    dones = (torch.rand(B * T) < 0.3).to(torch.uint8)
+    out, (h, c) = w.forward_flat(x, (h0, c0), dones, T)
+    xt = x.view(B, T, -1).transpose(0, 1)
+    dt = dones.view(B, T).transpose(0, 1)
+    out2, (h2, c2) = w(xt, (h0, c0), dt)
+    assert torch.allclose(out.view(B, T, -1).transpose(0, 1), out2, atol=1e-6)
+    assert torch.allclose(h, h2, atol=1e-6) and torch.allclose(c, c2, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_dones", [False, True])
+def test_lstm_sequence_forward_backward(use_dones):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    B, T, Fin, H = 2048, 4, 92, 256
+    k = 1.0 / np.sqrt(H)
+    params = [torch.empty(s, device=dev).uniform_(-k, k).requires_grad_() for s in ((4 * H, Fin), (4 * H, H), (4 * H,), (4 * H,))]
+    x = torch.randn(B * T, Fin, device=dev, requires_grad=True)
+    h0, c0 = torch.randn(B, H, device=dev) * 0.5, torch.randn(B, H, device=dev) * 0.5
+    dones = (torch.rand(B * T, device=dev) < 0.2).to(torch.uint8) if use_dones else None
+    gout = torch.randn(B * T, H, device=dev)
+
+    def run(fn):
+        for p in params + [x]:
+            p.grad = None
+        out, h, c = fn(x, *params, h0, c0, dones, T)
+        out.backward(gout)
+        return [out.detach(), h.detach(), c.detach(), x.grad.clone()] + [p.grad.clone() for p in params]
+
+    a = run(fused.lstm_sequence)
+    b = run(fused._lstm_reference)
+    names = ["out", "hT", "cT", "dx", "dW_ih", "dW_hh", "db_ih", "db_hh"]
+    for n, u, v in zip(names, a, b):
+        scale = float(v.abs().max()) + 1e-6
+        assert float((u - v).abs().max()) / scale < 2e-4, n
+    # rollout shape: T = 1, no grad
+    with torch.no_grad():
+        o1, h1, c1 = fused.lstm_sequence(x[:B].detach(), *params, h0, c0, None, 1)
+        o2, h2, c2 = fused._lstm_reference(x[:B].detach(), *params, h0, c0, None, 1)
+    assert torch.allclose(o1, o2, atol=2e-5) and torch.allclose(c1, c2, atol=2e-5) and torch.equal(o1, h1)
+
+
+@pytest.mark.gpu
+def test_splitk_linear_gradients():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    x = torch.randn(32768, 92, device=dev, requires_grad=True)
+    w = torch.randn(64, 92, device=dev, requires_grad=True)
+    b = torch.randn(64, device=dev, requires_grad=True)
+    g = torch.randn(32768, 64, device=dev)
+    y = fused.linear(x, w, b)
+    y.backward(g)
+    got = [y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+    for p in (x, w, b):
+        p.grad = None
+    y2 = torch.nn.functional.linear(x, w, b)
+    y2.backward(g)
+    for u, v in zip(got, [y2.detach(), x.grad, w.grad, b.grad]):
+        assert float((u - v).abs().max()) / (float(v.abs().max()) + 1e-6) < 1e-4
+    assert fused.splitk_tn(g, x.detach()).shape == (64, 92)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip_value", [True, False])
+def test_ppo_loss_kernel_matches_autograd(clip_value):
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    n, A = 32768, 2
+    mu = (torch.randn(n, A, device=dev) * 0.8).requires_grad_()      # some |mu| > 1.1: bound loss active
+    logstd = torch.tensor([0.1, -0.3], device=dev, requires_grad=True)
+    value = torch.randn(n, 1, device=dev, requires_grad=True)
+    actions = mu.detach() + torch.randn(n, A, device=dev) * 0.9
+    old_neglogp = torch.randn(n, device=dev) * 0.3 + 2.0
+    adv = torch.randn(n, device=dev)
+    old_values = value.detach() + torch.randn(n, 1, device=dev) * 0.3
+    returns = torch.randn(n, 1, device=dev)
+    old_mu = mu.detach() + torch.randn(n, A, device=dev) * 0.05
+    old_sigma = torch.full((n, A), 1.05, device=dev)
+    cfg = dict(e_clip=0.2, clip_value=clip_value, critic_coef=2.0, entropy_coef=0.01, bounds_coef=1e-4)
+    loss, st = fused.ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu,
+                                        old_sigma, **cfg)
+    loss.backward()
+    g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns,
+                                                    old_mu, old_sigma, **cfg)
+    torch.cuda.synchronize()
+    assert abs(float(stats[5]) - float(loss)) < 1e-4 * (1 + abs(float(loss)))
+    for idx, key in ((0, "a_loss"), (1, "c_loss"), (2, "b_loss"), (3, "entropy"), (4, "kl")):
+        assert abs(float(stats[idx]) - float(st[key])) < 1e-4 * (1 + abs(float(st[key]))), key
+    for u, v, name in ((g_mu, mu.grad, "mu"), (g_val, value.grad, "value"), (g_ls, logstd.grad, "logstd")):
+        assert float((u - v).abs().max()) / (float(v.abs().max()) + 1e-12) < 2e-4, name
+
+
+@pytest.mark.gpu
+def test_fused_update_equals_stock_update():
+    """One optimiser step of the agent through the fused path and through the stock composition, from the same
+    weights and minibatch: same loss statistics, same updated parameters (to fp32 reduction-order noise)."""
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    outs = []
+    for use_fused in (True, False):
+        cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048"])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False, use_graphs=False, use_fused_ops=use_fused,
+                                mini_epochs=1)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        torch.manual_seed(5)
+        play, upd, stats = agent.train_epoch()
+        torch.cuda.synchronize()
+        outs.append((torch.cat([p.detach().flatten() for p in agent.model.parameters()]),
+                     {k: float(v) for k, v in stats.items()}))
+        env.close()
+    (p1, s1), (p2, s2) = outs
+    for k in s1:
+        assert abs(s1[k] - s2[k]) < 2e-3 * (1 + abs(s2[k])), (k, s1[k], s2[k])
+    assert float((p1 - p2).abs().max()) < 2e-3      # 4 Adam steps of 3e-4.. lr: identical sign pattern of the updates

@@ -144,6 +144,26 @@ PROTOTYPES = {
 }
 
 
+_I64 = C.c_int64
+_VP = C.c_void_p
+# include/vine_ppo.h (product library only; the oracle does not implement these)
+PPO_PROTOTYPES = {
+    "vine_lstm_cell_forward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _VP, _VP]),
+    "vine_lstm_cell_backward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP,
+                                          _I64, _VP, _VP]),
+    "vine_ppo_loss": (C.c_int, [_I64, C.c_int32] + [_VP] * 10 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
+                                                                C.c_float] + [_VP] * 5),
+}
+
+
+def declare_ppo(lib):
+    for name, (restype, argtypes) in PPO_PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
 def declare(lib):
     """Attach prototypes; raises AttributeError naming the first missing symbol."""
     for name, (restype, argtypes) in PROTOTYPES.items():

@@ -1,0 +1,286 @@
+// ppo_kernels.hip — fused pointwise kernels of the PPO update for gfx950 (C ABI: include/vine_ppo.h).
+// HBM-bound elementwise work: one thread per float4 of hidden units, 16-B loads/stores, grid capped and strided.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "../../include/vine.h"
+#include "../../include/vine_ppo.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // tanh via exp of -2|x|: accurate to ~1e-7 relative, no overflow
+    const float ax = fabsf(x);
+    const float e = __expf(-2.0f * ax);
+    const float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ igates, long long ig_stride,
+                                const float* __restrict__ hgates, const float* __restrict__ bias,
+                                const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
+                                long long done_stride, float* __restrict__ h_out, long long h_stride,
+                                float* __restrict__ c_out, float* __restrict__ gates_act) {
+    const int H4 = H >> 2;
+    const long long total = B * H4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / H4;
+        const int j = (int)(idx - b * H4) << 2;
+        const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+        const float* ig = igates + b * ig_stride;
+        const float* hg = hgates + b * 4LL * H;
+        float4 g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 a = ld4(ig + k * H + j), h = ld4(hg + k * H + j), bb = ld4(bias + k * H + j);
+            g[k] = make_float4(a.x + keep * h.x + bb.x, a.y + keep * h.y + bb.y, a.z + keep * h.z + bb.z,
+                               a.w + keep * h.w + bb.w);
+        }
+        const float4 cp = ld4(c_prev + b * H + j);
+        float gi[4] = {g[0].x, g[0].y, g[0].z, g[0].w}, gf[4] = {g[1].x, g[1].y, g[1].z, g[1].w};
+        float gg[4] = {g[2].x, g[2].y, g[2].z, g[2].w}, go[4] = {g[3].x, g[3].y, g[3].z, g[3].w};
+        const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+        float cn[4], hn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gi[u] = sigmoidf_(gi[u]);
+            gf[u] = sigmoidf_(gf[u]);
+            gg[u] = tanhf_(gg[u]);
+            go[u] = sigmoidf_(go[u]);
+            cn[u] = gf[u] * (keep * cpv[u]) + gi[u] * gg[u];
+            hn[u] = go[u] * tanhf_(cn[u]);
+        }
+        st4(c_out + b * H + j, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        if (gates_act) {
+            float* ga = gates_act + b * 4LL * H;
+            st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
+            st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
+            st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
+            st4(ga + 3 * H + j, make_float4(go[0], go[1], go[2], go[3]));
+        }
+    }
+}
+
+__global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
+                                const float* __restrict__ g_rec, const float* __restrict__ dc_next,
+                                const unsigned char* __restrict__ done_next, long long done_next_stride,
+                                const float* __restrict__ gates_act, const float* __restrict__ c_new,
+                                const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
+                                long long done_stride, float* __restrict__ dgates, long long dg_stride,
+                                float* __restrict__ dc_prev) {
+    const int H4 = H >> 2;
+    const long long total = B * H4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / H4;
+        const int j = (int)(idx - b * H4) << 2;
+        const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+        const float keep_n = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+        const float4 go4 = ld4(g_out + b * g_stride + j);
+        float dh[4] = {go4.x, go4.y, go4.z, go4.w};
+        float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (g_rec) {
+            const float4 r = ld4(g_rec + b * H + j);
+            dh[0] += keep_n * r.x; dh[1] += keep_n * r.y; dh[2] += keep_n * r.z; dh[3] += keep_n * r.w;
+        }
+        if (dc_next) {
+            const float4 r = ld4(dc_next + b * H + j);
+            dc[0] = keep_n * r.x; dc[1] = keep_n * r.y; dc[2] = keep_n * r.z; dc[3] = keep_n * r.w;
+        }
+        const float* ga = gates_act + b * 4LL * H;
+        const float4 i4 = ld4(ga + j), f4 = ld4(ga + H + j), g4 = ld4(ga + 2 * H + j), o4 = ld4(ga + 3 * H + j);
+        const float4 cn4 = ld4(c_new + b * H + j), cp4 = ld4(c_prev + b * H + j);
+        const float gi[4] = {i4.x, i4.y, i4.z, i4.w}, gf[4] = {f4.x, f4.y, f4.z, f4.w};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, go[4] = {o4.x, o4.y, o4.z, o4.w};
+        const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+        float di[4], df[4], dg[4], dout[4], dcp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float tc = tanhf_(cn[u]);
+            const float d_o = dh[u] * tc;
+            const float d_c = dc[u] + dh[u] * go[u] * (1.0f - tc * tc);
+            di[u] = d_c * gg[u] * gi[u] * (1.0f - gi[u]);
+            df[u] = d_c * (keep * cp[u]) * gf[u] * (1.0f - gf[u]);
+            dg[u] = d_c * gi[u] * (1.0f - gg[u] * gg[u]);
+            dout[u] = d_o * go[u] * (1.0f - go[u]);
+            dcp[u] = d_c * gf[u];
+        }
+        float* dgp = dgates + b * dg_stride;
+        st4(dgp + 0 * H + j, make_float4(di[0], di[1], di[2], di[3]));
+        st4(dgp + 1 * H + j, make_float4(df[0], df[1], df[2], df[3]));
+        st4(dgp + 2 * H + j, make_float4(dg[0], dg[1], dg[2], dg[3]));
+        st4(dgp + 3 * H + j, make_float4(dout[0], dout[1], dout[2], dout[3]));
+        st4(dc_prev + b * H + j, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+    }
+}
+
+#define PPO_MAX_A 8
+__global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const float* __restrict__ mu,
+                                                       const float* __restrict__ logstd, const float* __restrict__ value,
+                                                       const float* __restrict__ actions, const float* __restrict__ old_neglogp,
+                                                       const float* __restrict__ adv, const float* __restrict__ old_values,
+                                                       const float* __restrict__ returns, const float* __restrict__ old_mu,
+                                                       const float* __restrict__ old_sigma, float e_clip, int clip_value,
+                                                       float critic_coef, float entropy_coef, float bounds_coef,
+                                                       float soft_bound, float* __restrict__ grad_mu,
+                                                       float* __restrict__ grad_value, float* __restrict__ grad_logstd,
+                                                       float* __restrict__ stats) {
+    const float inv_n = 1.0f / (float)n;
+    float ls[PPO_MAX_A], sg[PPO_MAX_A], isg2[PPO_MAX_A];
+    float sum_ls = 0.0f;
+    for (int k = 0; k < A; ++k) {
+        ls[k] = logstd[k];
+        sg[k] = __expf(ls[k]);
+        isg2[k] = 1.0f / (sg[k] * sg[k]);
+        sum_ls += ls[k];
+    }
+    const float ent = A * (0.5f + 0.9189385332046727f) + sum_ls;   // 0.5 + 0.5*log(2*pi) per dim + logstd
+    float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                   // a, c, b, kl, (unused)
+    float gls[PPO_MAX_A];
+    for (int k = 0; k < A; ++k) gls[k] = 0.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float z2[PPO_MAX_A], dm[PPO_MAX_A], m[PPO_MAX_A];
+        float nlp = 0.9189385332046727f * A + sum_ls;
+        for (int k = 0; k < A; ++k) {
+            m[k] = mu[i * A + k];
+            dm[k] = actions[i * A + k] - m[k];
+            z2[k] = dm[k] * dm[k] * isg2[k];
+            nlp += 0.5f * z2[k];
+        }
+        const float a = adv[i];
+        const float ratio = __expf(old_neglogp[i] - nlp);
+        const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
+        const float s1 = -a * ratio, s2 = -a * rc;
+        const bool first = s1 >= s2;                     // torch.max sends the tie's gradient to the first operand
+        const float a_loss = first ? s1 : s2;
+        const float inside = (ratio > 1.0f - e_clip && ratio < 1.0f + e_clip) ? 1.0f : 0.0f;
+        const float dL_dratio = first ? -a : -a * inside;
+        const float dL_dnlp = -ratio * dL_dratio * inv_n;    // d ratio / d nlp = -ratio
+        // value loss
+        const float v = value[i], vp = old_values[i], R = returns[i];
+        float c_loss, dL_dv;
+        if (clip_value) {
+            const float dv = v - vp;
+            const float vc = vp + fminf(fmaxf(dv, -e_clip), e_clip);
+            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            if (l1 >= l2) { c_loss = l1; dL_dv = 2.0f * (v - R); }
+            else { c_loss = l2; dL_dv = (dv > -e_clip && dv < e_clip) ? 2.0f * (vc - R) : 0.0f; }
+        } else {
+            c_loss = (R - v) * (R - v);
+            dL_dv = 2.0f * (v - R);
+        }
+        grad_value[i] = 0.5f * critic_coef * dL_dv * inv_n;
+        float b_loss = 0.0f, kl = 0.0f;
+        for (int k = 0; k < A; ++k) {
+            const float hi = fmaxf(m[k] - soft_bound, 0.0f), lo = fminf(m[k] + soft_bound, 0.0f);
+            b_loss += hi * hi + lo * lo;
+            // d nlp / d mu = -(a - mu)/sigma^2 ; d nlp / d logstd = 1 - z^2
+            grad_mu[i * A + k] = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
+            gls[k] += dL_dnlp * (1.0f - z2[k]);
+            const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
+            const float c1 = __logf(os / sg[k] + 1e-5f);
+            const float c2 = (sg[k] * sg[k] + (om - m[k]) * (om - m[k])) / (2.0f * (os * os + 1e-5f));
+            kl += c1 + c2 - 0.5f;
+        }
+        acc[0] += a_loss; acc[1] += c_loss; acc[2] += b_loss; acc[3] += kl;
+    }
+    // block reduction (wave shuffles, then LDS across the 4 waves), one atomic per block and quantity
+    __shared__ float red[4][5 + PPO_MAX_A];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float vals[5 + PPO_MAX_A];
+    for (int q = 0; q < 4; ++q) vals[q] = acc[q];
+    vals[4] = 0.0f;
+    for (int k = 0; k < PPO_MAX_A; ++k) vals[5 + k] = (k < A) ? gls[k] : 0.0f;
+    for (int q = 0; q < 5 + PPO_MAX_A; ++q) {
+        float x = vals[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) red[wave][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 + PPO_MAX_A) {
+        const int q = threadIdx.x;
+        const float x = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+        if (q < 4) {
+            const float mean = x * inv_n;
+            atomicAdd(&stats[q == 3 ? 4 : q], mean);
+            const float w = (q == 0) ? 1.0f : (q == 1) ? 0.5f * critic_coef : (q == 2) ? bounds_coef : 0.0f;
+            if (w != 0.0f) atomicAdd(&stats[5], w * mean);
+        } else if (q >= 5 && q - 5 < A) {
+            atomicAdd(&grad_logstd[q - 5], x);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&stats[3], ent);
+        atomicAdd(&stats[5], -entropy_coef * ent);
+        for (int k = 0; k < A; ++k) atomicAdd(&grad_logstd[k], -entropy_coef);
+    }
+}
+
+int grid_for(long long work, int threads) {
+    long long blocks = (work + threads - 1) / threads;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // 16 workgroups per CU, grid-stride beyond
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
+                           const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
+                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* stream) {
+    if (B <= 0 || H <= 0 || (H & 3) || (ig_stride & 3) || (h_stride & 3) || !igates || !hgates || !bias || !c_prev ||
+        !h_out || !c_out)
+        return VINE_ERR_INVALID_ARG;
+    const int threads = 256;
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(grid_for(B * (H / 4), threads)), dim3(threads), 0, (hipStream_t)stream,
+                       (long long)B, (int)H, igates, (long long)ig_stride, hgates, bias, c_prev, done,
+                       (long long)done_stride, h_out, (long long)h_stride, c_out, gates_act);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
+                            const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
+                            const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
+                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev, void* stream) {
+    if (B <= 0 || H <= 0 || (H & 3) || (g_stride & 3) || (dg_stride & 3) || !g_out || !gates_act || !c_new || !c_prev ||
+        !dgates || !dc_prev)
+        return VINE_ERR_INVALID_ARG;
+    const int threads = 256;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for(B * (H / 4), threads)), dim3(threads), 0, (hipStream_t)stream,
+                       (long long)B, (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next,
+                       (long long)done_next_stride, gates_act, c_new, c_prev, done, (long long)done_stride, dgates,
+                       (long long)dg_stride, dc_prev);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, const float* value, const float* actions,
+                  const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
+                  const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
+                  float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
+                  float* grad_logstd, float* stats, void* stream) {
+    if (n <= 0 || A <= 0 || A > PPO_MAX_A || !mu || !logstd || !value || !actions || !old_neglogp || !advantages ||
+        !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats)
+        return VINE_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(stats, 0, 8 * sizeof(float), s) != hipSuccess) return VINE_ERR_DEVICE;
+    if (hipMemsetAsync(grad_logstd, 0, A * sizeof(float), s) != hipSuccess) return VINE_ERR_DEVICE;
+    const int threads = 256;
+    int blocks = (int)((n + threads - 1) / threads);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(threads), 0, s, (long long)n, (int)A, mu, logstd, value,
+                       actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
+                       critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+}  // extern "C"

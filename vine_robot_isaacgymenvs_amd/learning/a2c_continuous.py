@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import fused
 from .network import ModelA2CContinuousLogStd
 
 
@@ -182,6 +183,7 @@ class A2CAgent:
         self.print_stats = config.get("print_stats", True)
         self.games_to_track = config.get("games_to_track", 100)
         self.use_graphs = bool(config.get("use_graphs", False)) and self.is_cuda
+        self.use_fused = bool(config.get("use_fused_ops", True))
         self.schedule_type = config.get("schedule_type", "legacy")
         self.is_adaptive_lr = config["lr_schedule"] == "adaptive"
         self.kl_threshold = config.get("kl_threshold", 0.008)
@@ -442,7 +444,26 @@ class A2CAgent:
         return mb
 
     # ------------------------------------------------------------------ update (R3, R4, R6)
+    def calc_gradients_fused(self, mb):
+        """GPU fp32 path: network forward, then ONE kernel for the whole PPO loss and its gradient w.r.t.
+        (mu, value, logstd); autograd carries on from there.  Same arithmetic as ``calc_gradients``."""
+        batch_dict = {"obs": mb["obs"], "rnn_states": mb["rnn_states"], "seq_length": self.seq_len, "dones": mb["dones"]}
+        mu, value, logstd, _ = self.model.forward_raw(batch_dict)
+        g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(
+            mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
+            mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef, self.entropy_coef,
+            self.bounds_loss_coef or 0.0)
+        self.flat_grads.zero_()
+        torch.autograd.backward([mu, value], [g_mu, g_val])
+        self.model.a2c_network.sigma.grad.add_(g_ls)
+        self.truncate_gradients_and_step()
+        mu_d = mu.detach()
+        sigma_d = torch.exp(logstd.detach()).expand_as(mu_d)
+        return stats[0], stats[1], stats[3], stats[4], stats[2], mu_d, sigma_d
+
     def calc_gradients(self, mb):
+        if self.is_cuda and not self.mixed_precision and self.use_fused:
+            return self.calc_gradients_fused(mb)
         batch_dict = {"is_train": True, "prev_actions": mb["actions"], "obs": mb["obs"], "rnn_states": mb["rnn_states"],
                       "seq_length": self.seq_len, "dones": mb["dones"]}
         with torch.autocast(device_type=self.device.type, dtype=self.amp_dtype, enabled=self.mixed_precision):

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .running_mean_std import RunningMeanStd
 
 _ACTIVATIONS = {"elu": nn.ELU, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "selu": nn.SELU,
@@ -58,6 +59,14 @@ class _RnnWrap(nn.Module):
             outs.append(h)
         return torch.stack(outs, 0), (h.unsqueeze(0), c.unsqueeze(0))
 
+    def forward_flat(self, x, states, dones, seq_length):
+        """Sequence-major rows (index = seq * seq_length + t): the layout of the rollout buffers and minibatches.
+        On the GPU this is the fused path (one input GEMM for all steps + hand-written pointwise kernels)."""
+        r = self.rnn
+        out, h, c = fused.lstm_sequence(x, r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0,
+                                        states[0][0], states[1][0], dones, seq_length)
+        return out, (h.unsqueeze(0), c.unsqueeze(0))
+
 
 class A2CNetwork(nn.Module):
     def __init__(self, params, actions_num, input_shape):
@@ -73,7 +82,7 @@ class A2CNetwork(nn.Module):
         num_inputs = int(input_shape[0])
         layers, in_size = [], num_inputs
         for u in self.units:
-            layers += [nn.Linear(in_size, u), act()]
+            layers += [fused.SplitKLinear(in_size, u), act()]
             in_size = u
         self.actor_mlp = nn.Sequential(*layers)
         self.rnn_units = int(rnn["units"])
@@ -83,8 +92,8 @@ class A2CNetwork(nn.Module):
         self.rnn_ln = bool(rnn.get("layer_norm", False))
         if self.rnn_ln:
             self.layer_norm = nn.LayerNorm(self.rnn_units)
-        self.value = nn.Linear(self.rnn_units, 1)
-        self.mu = nn.Linear(self.rnn_units, actions_num)
+        self.value = fused.SplitKLinear(self.rnn_units, 1)
+        self.mu = fused.SplitKLinear(self.rnn_units, actions_num)
         space = params["space"]["continuous"]
         if not space.get("fixed_sigma", True):
             raise NotImplementedError("fixed_sigma: False")
@@ -104,13 +113,7 @@ class A2CNetwork(nn.Module):
         out = self.actor_mlp(obs)
         if self.rnn_concat_input:
             out = torch.cat([out, obs], dim=1)
-        batch = out.shape[0]
-        num_seqs = batch // seq_length
-        out = out.reshape(num_seqs, seq_length, -1).transpose(0, 1)
-        if dones is not None:
-            dones = dones.reshape(num_seqs, seq_length).transpose(0, 1)
-        out, states = self.rnn(out, states, dones)
-        out = out.transpose(0, 1).contiguous().reshape(batch, -1)
+        out, states = self.rnn.forward_flat(out, states, dones, seq_length)
         if self.rnn_ln:
             out = self.layer_norm(out)
         value = self.value(out)
@@ -146,6 +149,13 @@ class ModelA2CContinuousLogStd(nn.Module):
     def neglogp(x, mean, std, logstd):
         return (0.5 * (((x - mean) / std) ** 2).sum(dim=-1) + 0.5 * np.log(2.0 * np.pi) * x.size()[-1]
                 + logstd.sum(dim=-1))
+
+    def forward_raw(self, input_dict):
+        """Training forward for the fused loss: (mu [n,A], value [n,1], logstd parameter [A], rnn states)."""
+        obs = self.norm_obs(input_dict["obs"])
+        mu, _logstd, value, states = self.a2c_network(obs, input_dict["rnn_states"], input_dict.get("seq_length", 1),
+                                                     input_dict.get("dones", None))
+        return mu, value, self.a2c_network.sigma, states
 
     def forward(self, input_dict):
         is_train = input_dict.get("is_train", True)

@@ -11,6 +11,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "vine_hip.hip")
+SRC_PPO = os.path.join(_HERE, "csrc", "ppo_kernels.hip")
 LIB = os.path.join(_HERE, "libvine_hip.so")
 ARCH = "gfx950"
 
@@ -19,12 +20,13 @@ _lib = None
 
 def build(force=False, verbose=False):
     """hipcc cross-compiles for gfx950 (works without a GPU); output stays in-tree."""
-    deps = [SRC, os.path.join(os.path.dirname(_HERE), "include", "vine.h")]
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    deps = [SRC, SRC_PPO, os.path.join(inc, "vine.h"), os.path.join(inc, "vine_ppo.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-fno-slp-vectorize",
-           "-Wall", "-Wno-unused-function", "-o", LIB, SRC]
+           "-Wall", "-Wno-unused-function", "-o", LIB, SRC, SRC_PPO]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     extra = os.environ.get("VINE_HIPCC_FLAGS")       # experiments only (e.g. "-fslp-vectorize")
@@ -45,7 +47,7 @@ def load():
             raise RuntimeError(
                 "libvine_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or vine_robot_isaacgymenvs_amd.native.build(); this package has no CPU fallback." % LIB)
-        _lib = abi.declare(C.CDLL(LIB))
+        _lib = abi.declare_ppo(abi.declare(C.CDLL(LIB)))
     return _lib
 
 
