@@ -270,6 +270,17 @@ def test_task_class_step_contract(HipEnv):
         obs, rew, done, info = env.step(torch.rand(128, 2, device="cuda:0") * 2 - 1)
     assert int(env.progress_buf.max()) == 5
     assert float(obs["obs"].abs().max()) <= 5.0
+    # metrics side channel: same keys as the reference's wandb_dict (V5:1250-1322)
+    env.bind_reward_matrix()
+    env.step(torch.rand(128, 2, device="cuda:0") * 2 - 1)
+    stats = env.collect_stats()
+    for key in ("dist_tip_to_target", "target_reached", "limit_hit", "tip_velocities_max", "Aggregated Reward",
+                "prismatic_q0 at self.index_to_view", "finite_diff_qd4 at self.index_to_view",
+                "tip_pos_z at self.index_to_view", "Mean Position Success Reward", "Weighted Max Contact Force Reward",
+                "Mean Total Reward", "progress_buf"):
+        assert key in stats and np.isfinite(stats[key]), key
+    assert len(stats) >= 118
+    assert abs(stats["Mean Const Negative Reward"] + 1.0) < 1e-6 and stats["progress_buf"] == 6.0
     env.close()
 
 

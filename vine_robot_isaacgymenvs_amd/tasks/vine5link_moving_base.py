@@ -207,6 +207,94 @@ class Vine5LinkMovingBase(VecTask):
                                               self.reset_buf.data_ptr(), self.progress_buf.data_ptr(), self._stream()),
                      self._lib)
 
+    # ------------------------------------------------------------------ metrics side channel (V5:1250-1322)
+    def collect_stats(self):
+        """The ~120 scalars the reference puts into ``wandb_dict`` EVERY step with one ``.item()`` sync each
+        (V5:1250-1322), computed here on demand from the device state in one pass and ONE device->host copy.
+        Same key names, so dashboards carry over.  Needs ``bind_reward_matrix()`` for the per-term entries."""
+        st = self._state
+        f = abi
+        tip_y, tip_z = st[f.VF_TIP_Y], st[f.VF_TIP_Z]
+        tip_v = torch.sqrt(st[f.VF_TIP_VY] ** 2 + st[f.VF_TIP_VZ] ** 2)
+        dist = torch.sqrt((tip_y - st[f.VF_TARGET_Y]) ** 2 + (tip_z - st[f.VF_TARGET_Z]) ** 2)
+        cart_y = st[f.VF_CART_Y]
+        lim = float(self.cfg["env"]["RAIL_SOFT_LIMIT"])
+        agg = st[f.VF_AGG_REW]
+        contact = st[f.VF_CONTACT_MEAN]
+        names, vals = [], []
+
+        def put(name, v):
+            names.append(name)
+            vals.append(v.float().reshape(()))
+
+        put("dist_tip_to_target", dist.mean())
+        put("target_reached", (dist < float(self.cfg["env"]["SUCCESS_DIST"])).float().mean())
+        put("limit_hit", ((cart_y > lim) | (cart_y < -lim)).float().mean())
+        put("tip_limit_hit", (tip_y < st[f.VF_TARGET_Y]).float().mean())
+        put("abs_tip_y", tip_y.abs().mean())
+        put("tip_z", tip_z.mean())
+        put("max_abs_tip_y", tip_y.abs().max())
+        put("max_tip_z", tip_z.max())
+        put("tip_velocities", tip_v.mean())
+        put("tip_velocities_max", tip_v.max())
+        put("u_rail_velocity", st[f.VF_U_RAIL].abs().mean())
+        put("prev_u_rail_velocity", st[f.VF_PREV_U_RAIL].abs().mean())
+        put("rail_force", st[f.VF_RAIL_FORCE].abs().mean())
+        put("u_fpam", st[f.VF_U_FPAM].abs().mean())
+        put("smoothed_u_fpam", st[f.VF_SMOOTHED_U].abs().mean())
+        put("tip_target_velocity_difference", tip_v.mean())
+        put("progress_buf", self.progress_buf.float().mean())
+        put("contact_forces", contact.mean())
+        put("nonzero_contact_force", (contact > 0).float().mean())
+        put("Aggregated Reward", agg.mean())
+        put("Aggregated Reward 1 Std Up", agg.mean() + agg.std())
+        put("Aggregated Reward 1 Std Down", agg.mean() - agg.std())
+        i = self.index_to_view
+        fd = (st[f.VF_Q0:f.VF_Q0 + 6, i] - st[f.VF_PREV_Q0:f.VF_PREV_Q0 + 6, i]) / self.control_dt
+        put("prismatic_q0 at self.index_to_view", st[f.VF_Q0, i])
+        put("prismatic_qd0 at self.index_to_view", st[f.VF_QD0, i])
+        put("prismatic_finite_diff_qd0 at self.index_to_view", fd[0])
+        for j in range(N_REVOLUTE_DOFS):
+            put(f"q{j} at self.index_to_view", st[f.VF_Q0 + 1 + j, i])
+            put(f"qd{j} at self.index_to_view", st[f.VF_QD0 + 1 + j, i])
+            put(f"finite_diff_qd{j} at self.index_to_view", fd[1 + j])
+        zero = torch.zeros((), device=st.device)
+        fd_tip = [(st[f.VF_TIP_Y, i] - st[f.VF_PREV_TIP_Y, i]) / self.control_dt,
+                  (st[f.VF_TIP_Z, i] - st[f.VF_PREV_TIP_Z, i]) / self.control_dt]
+        per_dir = {
+            "x": (zero, zero, zero, zero, zero, zero, zero),
+            "y": (st[f.VF_TIP_VY, i], st[f.VF_CART_VY, i], zero, fd_tip[0], tip_y[i], cart_y[i], st[f.VF_TARGET_Y, i]),
+            "z": (st[f.VF_TIP_VZ, i], zero, zero, fd_tip[1], tip_z[i], torch.full((), CART_Z, device=st.device),
+                  st[f.VF_TARGET_Z, i]),
+        }
+        for d, (tv, cv, gv, ftv, tp, cp, gp) in per_dir.items():
+            put(f"tip_vel_{d} at self.index_to_view", tv)
+            put(f"cart_vel_{d} at self.index_to_view", cv)
+            put(f"target_vel_{d} at self.index_to_view", gv)
+            put(f"finite_diff_tip_vel_{d} at self.index_to_view", ftv)
+            put(f"tip_pos_{d} at self.index_to_view", tp)
+            put(f"cart_pos_{d} at self.index_to_view", cp)
+            put(f"target_pos_{d} at self.index_to_view", gp)
+        put("u_fpam at self.index_to_view", st[f.VF_U_FPAM, i])
+        put("smoothed u_fpam at self.index_to_view", st[f.VF_SMOOTHED_U, i])
+        put("u_rail_velocity at self.index_to_view", st[f.VF_U_RAIL, i])
+        put("rail_force at self.index_to_view", st[f.VF_RAIL_FORCE, i])
+        put("contact_force at self.index_to_view", contact[i])
+        put("nonzero_contact_force at self.index_to_view", (contact[i] > 0).float())
+        if self._reward_matrix is not None:
+            rm = self._reward_matrix
+            wrm = rm * self.reward_weights
+            for k, name in enumerate(REWARD_NAMES):
+                put(f"Mean {name} Reward", rm[:, k].mean())
+                put(f"Max {name} Reward", rm[:, k].max())
+                put(f"Weighted Mean {name} Reward", wrm[:, k].mean())
+                put(f"Weighted Max {name} Reward", wrm[:, k].max())
+        put("Mean Total Reward", self.rew_buf.mean())
+        put("Max Total Reward", self.rew_buf.max())
+        host = torch.stack(vals).cpu().tolist()          # the only synchronisation
+        self.wandb_dict = dict(zip(names, host))
+        return self.wandb_dict
+
     # ------------------------------------------------------------------ test / tooling hooks
     def bind_reward_matrix(self):
         """Ask the kernel to also write the [N,13] unweighted reward matrix (V5:1272) each step."""
