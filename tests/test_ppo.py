@@ -203,6 +203,16 @@ def test_training_runs_and_checkpoint_roundtrip(tmp_path):
     assert act.shape == (16, 2) and float(act.abs().max()) <= 1.0
 
 
+def test_baseline_config1_cpu_reference_path():
+    """BASELINE.json configs[0]: 64 envs on the CPU path, 1 PPO iteration (minibatch 1024 = 64 x 16, since the
+    default 32768 does not divide it -- SURVEY 8d).  Runs the oracle-backed env + the same agent code."""
+    agent, _ = make_agent(num_envs=64, minibatch=1024, max_epochs=1)
+    assert agent.num_minibatches == 1 and agent.batch_size == 1024
+    last, epoch = agent.train()
+    assert epoch == 1 and agent.frame == 1024
+    assert all(torch.isfinite(p).all() for p in agent.model.parameters())
+
+
 def test_config_constraints_are_asserted():
     with pytest.raises(AssertionError, match="minibatch_size"):
         make_agent(num_envs=64, minibatch=32768)       # 64*16 = 1024 is not a multiple of 32768 (BASELINE config 1 note)

@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     extra = os.environ.get("VINE_HIPCC_FLAGS")       # experiments only (e.g. "-fslp-vectorize")
     if extra:
-        cmd[1:1] = extra.split()
+        cmd[-4:-4] = extra.split()      # after the default flags (before "-o"), so that they win
     subprocess.check_call(cmd)
     return LIB
 
