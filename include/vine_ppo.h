@@ -51,6 +51,19 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, void* stream);
 
+/* Adam step on FLAT buffers (all parameters of the model live in one contiguous block, likewise gradients and
+ * moments): torch.optim.Adam arithmetic (rl_games: Adam(lr, eps=1e-8), common_agent.py:80) in ONE launch instead of a
+ * multi-tensor kernel over 17 small tensors.  `lr` and `step` are device scalars (the adaptive-KL schedule updates lr
+ * on the device; `step` is incremented by the kernel).  g is pre-scaled by grad_scale (1/world after the all-reduce)
+ * and zeroed after use. */
+int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
+                   float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+/* rl_games' AdaptiveScheduler on device scalars (`schedule_type: legacy`, PY:64-66):
+ * kl > 2*thr -> lr = max(lr/1.5, min_lr); kl < 0.5*thr -> lr = min(lr*1.5, max_lr).  kl_scale = 1/world. */
+int vine_adaptive_lr(float* lr, const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,45 @@ def test_fused_update_equals_stock_update():
     for k in s1:
         assert abs(s1[k] - s2[k]) < 2e-3 * (1 + abs(s2[k])), (k, s1[k], s2[k])
     assert float((p1 - p2).abs().max()) < 2e-3      # 4 Adam steps of 3e-4.. lr: identical sign pattern of the updates
+
+
+def _adam_pair(device):
+    from vine_robot_isaacgymenvs_amd.learning.flat_adam import FlatAdam
+    torch.manual_seed(3)
+    shapes = [(64, 28), (64,), (1024, 92), (3,), (2,)]
+    a = [torch.randn(s, device=device).requires_grad_() for s in shapes]
+    b = [t.detach().clone().requires_grad_() for t in a]
+    lr = torch.tensor(3e-4, device=device)
+    flat = FlatAdam(a, lr, eps=1e-8)
+    ref = torch.optim.Adam(b, lr=3e-4, eps=1e-8)
+    for it in range(5):
+        grads = [torch.randn(s, device=device) for s in shapes]
+        for p, q, g in zip(a, b, grads):
+            p.grad.copy_(2.0 * g)          # as if summed over 2 ranks
+            q.grad = g.clone()
+        flat.step(grad_scale=0.5)
+        ref.step()
+        if it == 2:                        # the schedule changes the device scalar between steps
+            lr.mul_(1.5)
+            ref.param_groups[0]["lr"] *= 1.5
+    return a, b, flat, ref
+
+
+def test_flat_adam_cpu_matches_torch_adam():
+    a, b, flat, ref = _adam_pair(torch.device("cpu"))
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7)
+    assert float(flat.flat_grads.abs().max()) == 0.0
+    sd = flat.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5
+
+
+@pytest.mark.gpu
+def test_flat_adam_kernel_matches_torch_adam():
+    a, b, flat, ref = _adam_pair(torch.device("cuda:0"))
+    torch.cuda.synchronize()
+    for p, q in zip(a, b):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-7)
+    assert float(flat.flat_grads.abs().max()) == 0.0 and float(flat.step_t) == 5.0
+    for i, q in enumerate(b):
+        assert torch.allclose(flat.state_dict()["state"][i]["exp_avg_sq"], ref.state[q]["exp_avg_sq"], rtol=1e-4, atol=1e-8)

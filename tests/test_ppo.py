@@ -173,11 +173,10 @@ def test_rollout_buffers_and_dataset_layout():
 
 def test_flat_gradient_buffer_views():
     agent, _ = make_agent(num_envs=8, minibatch=32)
-    assert agent.num_params == 408261 and agent.flat_grads.numel() == 408261
-    off = 0
-    for p in agent.model.parameters():
-        assert p.grad.data_ptr() == agent.flat_grads.data_ptr() + 4 * off
-        off += p.numel()
+    assert agent.num_params == 408261 and agent.flat_grads.numel() >= 408261
+    for p, off in zip(agent.optimizer.params, agent.optimizer.offsets):
+        assert p.grad.data_ptr() == agent.flat_grads.data_ptr() + 4 * off and off % 64 == 0
+        assert p.data_ptr() == agent.optimizer.flat_params.data_ptr() + 4 * off
 
 
 def test_training_runs_and_checkpoint_roundtrip(tmp_path):

@@ -224,6 +224,50 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
     }
 }
 
+__global__ void adam_kernel(long long n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, const float* __restrict__ lr_p, float* __restrict__ step_p,
+                            float beta1, float beta2, float eps, float wd, float gscale) {
+    const float step = *step_p + 1.0f;                    // every thread reads the old value; block 0 writes it back
+    const float lr = *lr_p;
+    const float bc1 = 1.0f - __powf(beta1, step), bc2 = 1.0f - __powf(beta2, step);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 pp = ld4(p + 4 * i), gg = ld4(g + 4 * i), mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+        float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w};
+        float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float gr = ga[u] * gscale + wd * pa[u];
+            ma[u] = beta1 * ma[u] + (1.0f - beta1) * gr;
+            va[u] = beta2 * va[u] + (1.0f - beta2) * gr * gr;
+            pa[u] -= step_size * ma[u] / (sqrtf(va[u]) * inv_sqrt_bc2 + eps);
+        }
+        st4(p + 4 * i, make_float4(pa[0], pa[1], pa[2], pa[3]));
+        st4(m + 4 * i, make_float4(ma[0], ma[1], ma[2], ma[3]));
+        st4(v + 4 * i, make_float4(va[0], va[1], va[2], va[3]));
+        st4(g + 4 * i, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    }
+    // tail (n not a multiple of 4)
+    const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        float gr = g[t] * gscale + wd * p[t];
+        float mt = beta1 * m[t] + (1.0f - beta1) * gr, vt = beta2 * v[t] + (1.0f - beta2) * gr * gr;
+        p[t] -= step_size * mt / (sqrtf(vt) * inv_sqrt_bc2 + eps);
+        m[t] = mt; v[t] = vt; g[t] = 0.0f;
+    }
+}
+// the step counter is bumped by a separate 1-thread kernel AFTER the update (all blocks above read the old value)
+__global__ void adam_bump_kernel(float* step_p) { *step_p += 1.0f; }
+
+__global__ void adaptive_lr_kernel(float* lr, const float* kl, float kl_scale, float thr, float min_lr, float max_lr) {
+    const float k = *kl * kl_scale, l = *lr;
+    float out = l;
+    if (k > 2.0f * thr) out = fmaxf(l / 1.5f, min_lr);
+    if (k < 0.5f * thr) out = fminf(l * 1.5f, max_lr);
+    *lr = out;
+}
+
 int grid_for(long long work, int threads) {
     long long blocks = (work + threads - 1) / threads;
     if (blocks > 256 * 16) blocks = 256 * 16;   // 16 workgroups per CU, grid-stride beyond
@@ -280,6 +324,25 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(threads), 0, s, (long long)n, (int)A, mu, logstd, value,
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
+                   float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step) return VINE_ERR_INVALID_ARG;
+    const int threads = 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, threads)), dim3(threads), 0, s, (long long)n, params, grads,
+                       exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_adaptive_lr(float* lr, const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr,
+                     void* stream) {
+    if (!lr || !kl) return VINE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(adaptive_lr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, lr, kl, kl_scale, kl_threshold, min_lr,
+                       max_lr);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

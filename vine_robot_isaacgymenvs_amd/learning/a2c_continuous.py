@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import fused
+from .flat_adam import FlatAdam
 from .network import ModelA2CContinuousLogStd
 
 
@@ -210,11 +211,18 @@ class A2CAgent:
                                               self.normalize_value, self.normalize_input).to(self.device)
         self.last_lr = float(config["learning_rate"])
         self.lr = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
-        self._setup_flat_grads()
-        adam_kw = dict(fused=True) if self.is_cuda else dict(foreach=False)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr, eps=1e-08,
-                                          weight_decay=config.get("weight_decay", 0.0), **adam_kw)
-        self.scaler = torch.amp.GradScaler("cuda", enabled=self.mixed_precision and self.amp_dtype == torch.float16)
+        self.use_grad_scaler = self.mixed_precision and self.amp_dtype == torch.float16
+        if self.use_grad_scaler:
+            # fp16 autocast (the reference's mixed_precision: True) needs GradScaler, which drives a torch optimiser
+            self._setup_flat_grads()
+            self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.lr, eps=1e-08,
+                                              weight_decay=config.get("weight_decay", 0.0), fused=True)
+        else:
+            self.optimizer = FlatAdam(self.model.parameters(), self.lr, eps=1e-08,
+                                      weight_decay=config.get("weight_decay", 0.0))
+            self.flat_grads = self.optimizer.flat_grads
+            self.num_params = self.optimizer.num_params
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_grad_scaler)
 
         self.frame = 0
         self.epoch_num = 0
@@ -453,8 +461,7 @@ class A2CAgent:
             mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
             mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef, self.entropy_coef,
             self.bounds_loss_coef or 0.0)
-        self.flat_grads.zero_()
-        torch.autograd.backward([mu, value], [g_mu, g_val])
+        torch.autograd.backward([mu, value], [g_mu, g_val])     # the gradient block was left zeroed by the last Adam step
         self.model.a2c_network.sigma.grad.add_(g_ls)
         self.truncate_gradients_and_step()
         mu_d = mu.detach()
@@ -486,6 +493,16 @@ class A2CAgent:
     def truncate_gradients_and_step(self):
         if self.multi_gpu:
             dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM)     # RCCL over xGMI, in place, 1.63 MB
+        if not self.use_grad_scaler:
+            if self.truncate_grads:
+                if self.multi_gpu:
+                    self.flat_grads.div_(self.rank_size)
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+                self.optimizer.step()
+            else:
+                self.optimizer.step(grad_scale=1.0 / self.rank_size)   # /world folded into the Adam kernel
+            return
+        if self.multi_gpu:
             self.flat_grads.div_(self.rank_size)
         if self.truncate_grads:
             self.scaler.unscale_(self.optimizer)
@@ -498,7 +515,13 @@ class A2CAgent:
         if self.multi_gpu:
             kl = kl.clone()
             dist.all_reduce(kl, op=dist.ReduceOp.SUM)
-            kl = kl / self.rank_size
+        if self.is_cuda:
+            rc = fused._lib().vine_adaptive_lr(self.lr.data_ptr(), kl.contiguous().data_ptr(), 1.0 / self.rank_size,
+                                               self.kl_threshold, self.min_lr, self.max_lr,
+                                               torch.cuda.current_stream(self.device).cuda_stream)
+            assert rc == 0
+            return
+        kl = kl / self.rank_size
         lr = self.lr
         down = torch.clamp(lr / 1.5, min=self.min_lr)
         up = torch.clamp(lr * 1.5, max=self.max_lr)

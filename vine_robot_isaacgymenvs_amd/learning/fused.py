@@ -35,22 +35,31 @@ def _check(rc, what):
 
 
 # --------------------------------------------------------------------------- split-K weight gradient
-def splitk_tn(dy, x):
-    """``dy^T @ x`` for tall-skinny operands: dy [K, M], x [K, N] -> [M, N]."""
+def splitk_tn(dy, x, out=None):
+    """``dy^T @ x`` for tall-skinny operands: dy [K, M], x [K, N] -> [M, N] (written into ``out`` when given)."""
     K = dy.shape[0]
     s = 1
     while K % (s * 2) == 0 and K // (s * 2) >= 1024 and s < 64:
         s *= 2
     if s == 1 or not dy.is_cuda:
-        return dy.t().mm(x)
+        return torch.mm(dy.t(), x, out=out) if out is not None else dy.t().mm(x)
     part = torch.bmm(dy.view(s, K // s, dy.shape[1]).transpose(1, 2), x.view(s, K // s, x.shape[1]))
-    return part.sum(0)
+    return torch.sum(part, 0, out=out) if out is not None else part.sum(0)
+
+
+def _grad_slot(p):
+    """The parameter's persistent gradient buffer (a view into the optimiser's flat gradient block) if it can be
+    written in place: the custom backward then stores the gradient there directly and returns None, which saves
+    autograd's accumulate-add launch per parameter.  Each parameter is used once per forward, so overwrite == add."""
+    g = getattr(p, "grad", None)
+    return g if (g is not None and g.is_contiguous() and g.is_cuda) else None
 
 
 class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
+        ctx.slots = (_grad_slot(weight), _grad_slot(bias))
         return torch.addmm(bias, x, weight.t())
 
     @staticmethod
@@ -58,7 +67,10 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy.mm(weight) if ctx.needs_input_grad[0] else None
-        return gx, splitk_tn(gy, x), gy.sum(0)
+        wslot, bslot = ctx.slots
+        gw = splitk_tn(gy, x, out=wslot)
+        gb = torch.sum(gy, 0, out=bslot) if bslot is not None else gy.sum(0)
+        return gx, (None if wslot is not None else gw), (None if bslot is not None else gb)
 
 
 def linear(x, weight, bias):
@@ -118,6 +130,7 @@ class _LSTMSeq(torch.autograd.Function):
                 c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None, st), "vine_lstm_cell_forward")
         ctx.T = T
         ctx.has_dones = dones is not None
+        ctx.slots = (_grad_slot(w_ih), _grad_slot(w_hh), _grad_slot(b_ih), _grad_slot(b_hh))
         if need_grad:
             ctx.save_for_backward(x, w_ih, w_hh, h0, out, c_all, gates, dones if dones is not None else x.new_empty(0))
         hT = out3[:, T - 1].contiguous()
@@ -156,8 +169,17 @@ class _LSTMSeq(torch.autograd.Function):
             hp = hp * (1.0 - dones.view(B, T, 1).to(hp.dtype))
         hp = hp.reshape(BT, H)
         gx = dG.mm(w_ih) if ctx.needs_input_grad[0] else None
-        gb = dG.sum(0)
-        return gx, splitk_tn(dG, x), splitk_tn(dG, hp), gb, gb, None, None, None, None
+        s_ih, s_hh, s_bi, s_bh = ctx.slots
+        g_ih = splitk_tn(dG, x, out=s_ih)
+        g_hh = splitk_tn(dG, hp, out=s_hh)
+        if s_bi is not None and s_bh is not None:
+            torch.sum(dG, 0, out=s_bi)
+            s_bh.copy_(s_bi)
+            gbi = gbh = None
+        else:
+            gbi = gbh = dG.sum(0)
+        return (gx, None if s_ih is not None else g_ih, None if s_hh is not None else g_hh, gbi, gbh,
+                None, None, None, None)
 
 
 def lstm_sequence(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
