@@ -107,3 +107,11 @@ def test_loader_reads_the_reference_yaml_files_unchanged():
     for k, v in ref.items():
         if k not in ("task", "train"):
             assert k in ours and ours[k] == v, k
+
+
+def test_dump_yaml_roundtrip(tmp_path):
+    """The packaged defaults written out as a Hydra-style directory compose to the same config."""
+    d = cf.dump_default_yaml(str(tmp_path / "cfg"))
+    a = cf.load_config(overrides=["num_envs=77"])
+    b = cf.load_config(overrides=["num_envs=77"], config_dir=d)
+    assert a == b

@@ -17,7 +17,8 @@ import re
 
 import yaml
 
-CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfg")
+# config_dir=None -> the packaged defaults (cfg/defaults.py, Python literals); a path -> a Hydra-style YAML directory
+# (config.yaml + task/<name>.yaml + train/<name>.yaml), e.g. the reference's own isaacgymenvs/cfg.
 
 
 class ConfigError(ValueError):
@@ -230,6 +231,25 @@ def _read(path):
         return _yaml_load(f.read()) or {}
 
 
+def _load_primary(config_dir, config_name):
+    if config_dir is None:
+        from ..cfg import defaults
+        if config_name != "config":
+            raise ConfigError("packaged defaults only provide the root config 'config'")
+        return copy.deepcopy(defaults.ROOT)
+    return _read(os.path.join(config_dir, config_name + ".yaml"))
+
+
+def _load_group(config_dir, group, name):
+    if config_dir is None:
+        from ..cfg import defaults
+        table = {"task": defaults.TASK, "train": defaults.TRAIN}.get(group, {})
+        if name not in table:
+            raise ConfigError("no packaged %s config named %r (available: %s)" % (group, name, sorted(table)))
+        return copy.deepcopy(table[name])
+    return _read(os.path.join(config_dir, group, str(name) + ".yaml"))
+
+
 def _deep_merge(dst, src):
     for k, v in src.items():
         if isinstance(v, dict) and isinstance(dst.get(k), dict):
@@ -257,8 +277,7 @@ def _set_path(cfg, dotted, value, add):
 
 def compose(config_name="config", overrides=(), config_dir=None):
     """Hydra-style composition; returns the UNRESOLVED merged dict (interpolations still as strings)."""
-    config_dir = config_dir or CFG_DIR
-    primary = _read(os.path.join(config_dir, config_name + ".yaml"))
+    primary = _load_primary(config_dir, config_name)
     defaults = primary.pop("defaults", ["_self_"])
     primary.pop("hydra", None)
     group_choice, plain = {}, []
@@ -282,7 +301,7 @@ def compose(config_name="config", overrides=(), config_dir=None):
             if isinstance(choice, str) and "${" in choice:      # e.g. train: ${task}PPO
                 choice = re.sub(r"\$\{([A-Za-z_]+)\}", lambda m: str(chosen[m.group(1)]), choice)
             chosen[group] = choice
-            _deep_merge(cfg, {group: _read(os.path.join(config_dir, group, str(choice) + ".yaml"))})
+            _deep_merge(cfg, {group: _load_group(config_dir, group, choice)})
         else:
             raise ConfigError("unsupported defaults entry %r" % (d,))
     if "_self_" not in defaults:
@@ -306,3 +325,27 @@ def load_task_config(task="Vine5LinkMovingBase", overrides=(), config_dir=None):
 
 def to_yaml(cfg):
     return yaml.safe_dump(cfg, sort_keys=False, default_flow_style=False)
+
+
+def dump_default_yaml(directory):
+    """Write the packaged defaults as an editable Hydra-style directory (config.yaml, task/, train/)."""
+    from ..cfg import defaults
+    os.makedirs(os.path.join(directory, "task"), exist_ok=True)
+    os.makedirs(os.path.join(directory, "train"), exist_ok=True)
+    with open(os.path.join(directory, "config.yaml"), "w") as f:
+        f.write(to_yaml(defaults.ROOT))
+    for name, tree in defaults.TASK.items():
+        with open(os.path.join(directory, "task", name + ".yaml"), "w") as f:
+            f.write(to_yaml(tree))
+    for name, tree in defaults.TRAIN.items():
+        with open(os.path.join(directory, "train", name + ".yaml"), "w") as f:
+            f.write(to_yaml(tree))
+    return directory
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 3 and sys.argv[1] == "--dump-yaml":
+        print("wrote", dump_default_yaml(sys.argv[2]))
+    else:
+        print(to_yaml(load_config(overrides=sys.argv[1:])))

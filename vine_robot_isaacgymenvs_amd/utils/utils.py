@@ -1,4 +1,12 @@
-"""Seeding helper with the reference's semantics (isaacgymenvs/utils/utils.py:43-71)."""
+"""Process-wide seeding with the reference's rule (isaacgymenvs/utils/utils.py:43-71 ``set_seed``):
+
+    seed == -1 and deterministic  -> 42 + rank
+    seed == -1                    -> random in [0, 10000)
+    otherwise                     -> seed + rank
+
+train.py adds the rank to cfg.seed *before* calling this (train.py:78), so rank r ends up at 42 + 2r with the
+default seed; bench.py and the multi-GPU tests rely on that number.
+"""
 import os
 import random
 
@@ -7,31 +15,26 @@ import torch
 
 
 def set_np_formatting():
-    np.set_printoptions(edgeitems=30, infstr="inf", linewidth=4000, nanstr="nan", precision=2, suppress=False,
-                        threshold=10000, formatter=None)
+    np.set_printoptions(precision=2, linewidth=4000, threshold=10000, edgeitems=30, suppress=False)
+
+
+def resolve_seed(seed, torch_deterministic=False, rank=0):
+    if seed != -1:
+        return seed + rank
+    return 42 + rank if torch_deterministic else int(np.random.randint(0, 10000))
 
 
 def set_seed(seed, torch_deterministic=False, rank=0):
-    """seed == -1 -> 42 + rank when deterministic, else random; otherwise seed + rank.
-    NB train.py adds the rank once more before calling this (train.py:78), so rank r trains with 42 + 2r."""
-    if seed == -1 and torch_deterministic:
-        seed = 42 + rank
-    elif seed == -1:
-        seed = np.random.randint(0, 10000)
-    else:
-        seed = seed + rank
-    print("Setting seed: {}".format(seed))
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    seed = resolve_seed(seed, torch_deterministic, rank)
+    print(f"Setting seed: {seed}")
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     os.environ["PYTHONHASHSEED"] = str(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+    # MIOpen/hipBLASLt autotuning on unless bit-reproducibility was requested
+    torch.backends.cudnn.benchmark = not torch_deterministic
+    torch.backends.cudnn.deterministic = bool(torch_deterministic)
     if torch_deterministic:
-        torch.backends.cudnn.benchmark = False
-        torch.backends.cudnn.deterministic = True
         torch.use_deterministic_algorithms(True, warn_only=True)
-    else:
-        torch.backends.cudnn.benchmark = True
-        torch.backends.cudnn.deterministic = False
     return seed
