@@ -268,6 +268,137 @@ __global__ void adaptive_lr_kernel(float* lr, const float* kl, float kl_scale, f
     *lr = out;
 }
 
+__device__ __forceinline__ void philox4(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                        unsigned (&o)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// One wave handles envs e = wave_id, wave_id + n_waves, ...; lane l owns hidden units 4l..4l+3 (H == 256) or a
+// strided subset (general H): partial dot products in registers, butterfly reduction across the 64 lanes.
+#define HEAD_MAX_A 8
+__global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, int H, const float* __restrict__ y,
+                                                          const float* __restrict__ w_mu, const float* __restrict__ b_mu,
+                                                          const float* __restrict__ w_v, const float* __restrict__ b_v,
+                                                          const float* __restrict__ logstd, const float* __restrict__ vmean,
+                                                          const float* __restrict__ vstd, int normalize_value,
+                                                          unsigned seed_lo, unsigned seed_hi,
+                                                          const long long* __restrict__ counter, float* __restrict__ mu_out,
+                                                          float* __restrict__ sigma_out, float* __restrict__ value_out,
+                                                          float* __restrict__ action_out, float* __restrict__ neglogp_out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const unsigned long long ctr = (unsigned long long)counter[0];
+    for (long long e = wave; e < N; e += n_waves) {
+        float acc[HEAD_MAX_A + 1];
+#pragma unroll
+        for (int k = 0; k <= HEAD_MAX_A; ++k) acc[k] = 0.0f;
+        for (int j = lane * 4; j < H; j += 256) {
+            const float4 yy = ld4(y + e * H + j);
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_A; ++k) {
+                if (k < A) {
+                    const float4 w = ld4(w_mu + (long long)k * H + j);
+                    acc[k] += yy.x * w.x + yy.y * w.y + yy.z * w.z + yy.w * w.w;
+                }
+            }
+            const float4 w = ld4(w_v + j);
+            acc[HEAD_MAX_A] += yy.x * w.x + yy.y * w.y + yy.z * w.z + yy.w * w.w;
+        }
+#pragma unroll
+        for (int k = 0; k <= HEAD_MAX_A; ++k) {
+            if (k < A || k == HEAD_MAX_A) {
+                float x = acc[k];
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+                acc[k] = x;
+            }
+        }
+        if (lane == 0) {
+            float v = acc[HEAD_MAX_A] + b_v[0];
+            if (normalize_value) v = fminf(fmaxf(v, -5.0f), 5.0f) * vstd[0] + vmean[0];
+            value_out[e] = v;
+            float nlp = 0.9189385332046727f * A;
+            unsigned r[4];
+            for (int k = 0; k < A; k += 2) {
+                philox4((unsigned)e, (unsigned)ctr, 0x504f4c59u | 0u, (unsigned)(k >> 1), seed_lo, seed_hi, r);
+                const float u1 = 1.0f - (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+                const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+                const float rad = sqrtf(-2.0f * __logf(u1));
+                float sn, cs;
+                __sincosf(6.283185307179586f * u2, &sn, &cs);
+                const float eps2[2] = {rad * cs, rad * sn};
+                for (int q = 0; q < 2 && k + q < A; ++q) {
+                    const int kk = k + q;
+                    const float m = acc[kk] + b_mu[kk], ls = logstd[kk], sg = __expf(ls);
+                    const float a = m + sg * eps2[q];
+                    mu_out[e * A + kk] = m;
+                    sigma_out[e * A + kk] = sg;
+                    action_out[e * A + kk] = a;
+                    nlp += 0.5f * eps2[q] * eps2[q] + ls;
+                }
+            }
+            neglogp_out[e] = nlp;
+        }
+    }
+}
+
+__global__ void rollout_post_kernel(long long N, int H, const float* __restrict__ rew, const long long* __restrict__ reset,
+                                    const unsigned char* __restrict__ timeouts, const float* __restrict__ values,
+                                    float shift, float scale, float gamma_b, float* __restrict__ shaped,
+                                    unsigned char* __restrict__ dones, float* __restrict__ cur_r, float* __restrict__ cur_l,
+                                    float* __restrict__ h_state, float* __restrict__ c_state, float* __restrict__ meter) {
+    float sr = 0.0f, sl = 0.0f, cnt = 0.0f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N; e += (long long)gridDim.x * blockDim.x) {
+        const float r = rew[e];
+        const bool done = reset[e] != 0;
+        float s = (r + shift) * scale;
+        if (gamma_b != 0.0f && timeouts[e]) s += gamma_b * values[e];
+        shaped[e] = s;
+        dones[e] = done ? 1 : 0;
+        const float cr = cur_r[e] + r, cl = cur_l[e] + 1.0f;
+        if (done) {
+            sr += cr; sl += cl; cnt += 1.0f;
+            cur_r[e] = 0.0f; cur_l[e] = 0.0f;
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int j = 0; j < H; j += 4) { st4(h_state + e * H + j, z); st4(c_state + e * H + j, z); }
+        } else {
+            cur_r[e] = cr; cur_l[e] = cl;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sr += __shfl_down(sr, off, 64); sl += __shfl_down(sl, off, 64); cnt += __shfl_down(cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt > 0.0f) {
+        atomicAdd(&meter[4], sr); atomicAdd(&meter[5], sl); atomicAdd(&meter[6], cnt);
+    }
+}
+
+// rl_games AverageMeter.update for both meters from the step's (sum, count); then clear the temporaries.
+__global__ void rollout_finalize_kernel(float* __restrict__ meter, float max_size, long long* __restrict__ counter) {
+    const float size = meter[6];
+    if (size > 0.0f) {
+        const float sc = fminf(size, max_size);
+        for (int m = 0; m < 2; ++m) {
+            const float new_mean = meter[4 + m] / size;
+            const float cur = meter[2 * m + 1];
+            const float old_size = fminf(max_size - sc, cur);
+            const float sum = old_size + sc;
+            meter[2 * m] = (meter[2 * m] * old_size + new_mean * sc) / sum;
+            meter[2 * m + 1] = sum;
+        }
+    }
+    meter[4] = 0.0f; meter[5] = 0.0f; meter[6] = 0.0f;
+    counter[0] += 1;
+}
+
 int grid_for(long long work, int threads) {
     long long blocks = (work + threads - 1) / threads;
     if (blocks > 256 * 16) blocks = 256 * 16;   // 16 workgroups per CU, grid-stride beyond
@@ -324,6 +455,41 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(threads), 0, s, (long long)n, (int)A, mu, logstd, value,
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
+                     const float* w_v, const float* b_v, const float* logstd, const float* value_mean,
+                     const float* value_std, int32_t normalize_value, uint64_t seed, const int64_t* counter,
+                     float* mu_out, float* sigma_out, float* value_out, float* action_out, float* neglogp_out,
+                     void* stream) {
+    if (N <= 0 || A <= 0 || A > HEAD_MAX_A || H <= 0 || (H & 3) || !y || !w_mu || !b_mu || !w_v || !b_v || !logstd ||
+        !counter || !mu_out || !sigma_out || !value_out || !action_out || !neglogp_out ||
+        (normalize_value && (!value_mean || !value_std)))
+        return VINE_ERR_INVALID_ARG;
+    const int threads = 256;                     // 4 waves per workgroup, one env per wave at a time
+    long long blocks = (N + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(policy_head_kernel, dim3((int)blocks), dim3(threads), 0, (hipStream_t)stream, (long long)N, (int)A,
+                       (int)H, y, w_mu, b_mu, w_v, b_v, logstd, value_mean, value_std, (int)normalize_value,
+                       (unsigned)seed, (unsigned)(seed >> 32), (const long long*)counter, mu_out, sigma_out, value_out,
+                       action_out, neglogp_out);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
+                      const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
+                      float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
+                      float* c_state, float* meter, float max_size, int64_t* counter, void* stream) {
+    if (N <= 0 || H <= 0 || (H & 3) || !rew || !reset || !timeouts || !values || !shaped_out || !dones_out ||
+        !cur_rewards || !cur_lengths || !h_state || !c_state || !meter || !counter)
+        return VINE_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = 256;
+    hipLaunchKernelGGL(rollout_post_kernel, dim3(grid_for(N, threads)), dim3(threads), 0, s, (long long)N, (int)H, rew,
+                       (const long long*)reset, timeouts, values, reward_shift, reward_scale, gamma_bootstrap, shaped_out,
+                       dones_out, cur_rewards, cur_lengths, h_state, c_state, meter);
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, s, meter, max_size, (long long*)counter);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -300,16 +300,86 @@ class A2CAgent:
         self.dones = torch.ones(N, device=dev, dtype=torch.uint8)
         self.game_rewards = DeviceAverageMeter(1, self.games_to_track, dev)
         self.game_lengths = DeviceAverageMeter(1, self.games_to_track, dev)
+        self.fused_rollout = self.is_cuda and self.use_fused and not self.mixed_precision
+        if self.fused_rollout:
+            # {rew_mean, rew_size, len_mean, len_size, tmp...}: written by vine_rollout_post; the meters are views
+            self.meter = torch.zeros(8, **f32)
+            self.game_rewards.mean, self.game_rewards.current_size = self.meter[0:1], self.meter[1]
+            self.game_lengths.mean, self.game_lengths.current_size = self.meter[2:3], self.meter[3]
+            self.roll_counter = torch.zeros(1, device=dev, dtype=torch.int64)
+            self.head_seed = (int(self.params.get("seed", 0) or 0) + 7919 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF
         self.rnn_states = [s.clone() for s in self.model.get_default_rnn_state(N, dev)]
         n_chunks = T // self.seq_len
         self.mb_rnn_states = [torch.zeros((n_chunks, 1, N, s.shape[-1]), **f32) for s in self.rnn_states]
         self.last_values = torch.zeros((N, 1), **f32)
+        self._head_scratch = [torch.zeros((N, self.actions_num), **f32) for _ in range(3)] + [torch.zeros(N, **f32)]
 
     # ------------------------------------------------------------------ rollout (R1)
     def get_action_values(self, obs):
         self.model.eval()
         with torch.no_grad():
             return self.model({"is_train": False, "prev_actions": None, "obs": obs, "rnn_states": self.rnn_states})
+
+    def _rollout_body_fused(self):
+        """Same sequence as ``_rollout_body`` with the pointwise work in three hand-written kernels per step:
+        policy head (mu/value GEMV + sampling + neglogp + value un-normalisation, written straight into the rollout
+        buffers), the fused env step, and the post-step bookkeeping (reward shaping, bootstrap, dones, episode
+        accumulators, windowed means, LSTM-state zeroing).  ~30 launches per step instead of ~125."""
+        lib = fused._lib()
+        buf, m = self.buf, self.model
+        net = m.a2c_network
+        env = getattr(self.vec_env, "env", self.vec_env)
+        N, A, H = self.num_actors, self.actions_num, net.rnn_units
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if self.normalize_value:
+            vmean = m.value_mean_std.running_mean.float()
+            vstd = torch.sqrt(m.value_mean_std.running_var.float() + m.value_mean_std.epsilon)
+        else:
+            vmean = vstd = None
+        gamma_b = float(self.gamma) if self.value_bootstrap else 0.0
+        obs = self.obs
+
+        def head(x, n_slot, value_out, mu_out, sigma_out, act_out, nlp_out):
+            fused._check(lib.vine_policy_head(
+                N, A, H, x.data_ptr(), net.mu.weight.data_ptr(), net.mu.bias.data_ptr(), net.value.weight.data_ptr(),
+                net.value.bias.data_ptr(), net.sigma.data_ptr(), vmean.data_ptr() if vmean is not None else None,
+                vstd.data_ptr() if vstd is not None else None, int(self.normalize_value), self.head_seed,
+                self.roll_counter.data_ptr(), mu_out.data_ptr(), sigma_out.data_ptr(), value_out.data_ptr(),
+                act_out.data_ptr(), nlp_out.data_ptr(), st), "vine_policy_head")
+
+        def trunk(o):
+            x = m.norm_obs(o)
+            y = net.actor_mlp(x)
+            if net.rnn_concat_input:
+                y = torch.cat([y, x], dim=1)
+            y, states = net.rnn.forward_flat(y, self.rnn_states, None, 1)
+            if net.rnn_ln:
+                y = net.layer_norm(y)
+            return y.contiguous(), states
+
+        for n in range(self.horizon_length):
+            if n % self.seq_len == 0:
+                for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
+                    mb_s[n // self.seq_len].copy_(s_)
+            y, states = trunk(obs)
+            self.rnn_states = [states[0].contiguous(), states[1].contiguous()]
+            buf["obses"][n].copy_(obs)
+            buf["dones"][n].copy_(self.dones)
+            head(y, n, buf["values"][n], buf["mus"][n], buf["sigmas"][n], buf["actions"][n], buf["neglogpacs"][n])
+            # the env kernel clamps to +-clipActions itself (vec_task.py:333); with the [-1, 1] action space
+            # rl_games' preprocess_actions (clamp + affine rescale) is the identity on top of that
+            obs_d, rewards, dones, infos = self.vec_env.step(buf["actions"][n])
+            obs = obs_d["obs"]
+            fused._check(lib.vine_rollout_post(
+                N, H, env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), env.timeout_buf.data_ptr(),
+                buf["values"][n].data_ptr(), float(self.reward_shift), float(self.reward_scale), gamma_b,
+                buf["rewards"][n].data_ptr(), self.dones.data_ptr(), self.current_rewards.data_ptr(),
+                self.current_lengths.data_ptr(), self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr(),
+                self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(), st), "vine_rollout_post")
+        self.obs = obs
+        y, _ = trunk(obs)
+        scratch = self._head_scratch
+        head(y, 0, self.last_values, scratch[0], scratch[1], scratch[2], scratch[3])
 
     def _rollout_body(self):
         """``play_steps_rnn``: horizon x {store; policy forward (eval); env step; shape reward; bootstrap;
@@ -349,10 +419,11 @@ class A2CAgent:
         self.last_values.copy_(self.get_action_values(obs)["values"])
 
     def play_steps_rnn(self):
+        body = self._rollout_body_fused if self._can_fuse_rollout() else self._rollout_body
         if self.use_graphs:
-            self._play_graphed()
+            self._play_graphed(body)
         else:
-            self._rollout_body()
+            body()
         buf = self.buf
         fdones = self.dones.float()
         mb_fdones = buf["dones"].float()
@@ -368,41 +439,53 @@ class A2CAgent:
         batch["rnn_states"] = states
         return batch
 
-    def _play_graphed(self):
+    def _can_fuse_rollout(self):
+        if not getattr(self, "fused_rollout", False):
+            return False
+        env = getattr(self.vec_env, "env", self.vec_env)
+        lo, hi = self.env_info["action_space"].low, self.env_info["action_space"].high
+        return (hasattr(env, "timeout_buf") and env.rew_buf.is_cuda and float(lo.min()) == -1.0 and float(hi.max()) == 1.0
+                and float(getattr(env, "clip_actions", 1.0)) <= 1.0)
+
+    def _play_graphed(self, body):
         """Capture the whole rollout once, then replay it.  Live state that the captured code rebinds
         (obs, dones, LSTM state, episode accumulators) is kept in static tensors copied in and out."""
         if self._rollout_graph is None:
-            self._g_obs = self.obs.clone()
-            self._g_in = [self._g_obs, self.dones.clone(), [s.clone() for s in self.rnn_states],
+            fused_mode = body == self._rollout_body_fused
+            keep = (lambda t: t) if fused_mode else (lambda t: t.clone())   # meters are views of self.meter when fused
+            self._g_in = [self.obs.clone(), self.dones.clone(), [s.clone() for s in self.rnn_states],
                           self.current_rewards.clone(), self.current_lengths.clone(),
-                          self.game_rewards.mean.clone(), self.game_rewards.current_size.clone(),
-                          self.game_lengths.mean.clone(), self.game_lengths.current_size.clone()]
+                          keep(self.game_rewards.mean), keep(self.game_rewards.current_size),
+                          keep(self.game_lengths.mean), keep(self.game_lengths.current_size)]
+            flat = [self._g_in[0], self._g_in[1]] + self._g_in[2] + self._g_in[3:5]
+            backup = [t.clone() for t in flat]
+            snap = self._snapshot_env()
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):     # warm-up outside capture (lazy inits of libraries)
-                snap = self._snapshot_env()
+            with torch.cuda.stream(side):     # warm-up outside capture (lazy inits of libraries, autotuning)
                 self._load_live(self._g_in)
-                self._rollout_body()
-                self._restore_env(snap)
+                body()
             torch.cuda.current_stream(self.device).wait_stream(side)
+            self._restore_env(snap)
+            for t, b in zip(flat, backup):
+                t.copy_(b)
             torch.cuda.synchronize(self.device)
             self._rollout_graph = torch.cuda.CUDAGraph()
             self._load_live(self._g_in)
             with torch.cuda.graph(self._rollout_graph):
                 self._load_live(self._g_in)
-                self._rollout_body()
+                body()
                 self._g_out = [self.obs, self.dones, self.rnn_states, self.current_rewards, self.current_lengths,
                                self.game_rewards.mean, self.game_rewards.current_size, self.game_lengths.mean,
                                self.game_lengths.current_size]
-            self._restore_env(snap)
         self._rollout_graph.replay()
         # carry the outputs over to the static inputs of the next replay
         o = self._g_out
-        self._g_in[0].copy_(o[0]); self._g_in[1].copy_(o[1])
-        for a, b in zip(self._g_in[2], o[2]):
-            a.copy_(b)
-        for i in range(3, 9):
-            self._g_in[i].copy_(o[i])
+        pairs = [(self._g_in[0], o[0]), (self._g_in[1], o[1])] + list(zip(self._g_in[2], o[2]))
+        pairs += [(self._g_in[i], o[i]) for i in range(3, 9)]
+        for a, b in pairs:
+            if a.data_ptr() != b.data_ptr():      # quantities the kernels update in place need no carry-over
+                a.copy_(b)
         self._load_live(self._g_in)
 
     def _load_live(self, g):
@@ -414,8 +497,11 @@ class A2CAgent:
 
     def _snapshot_env(self):
         env = getattr(self.vec_env, "env", self.vec_env)
-        return {"state": env.state.clone(), "reset": env.reset_buf.clone(), "progress": env.progress_buf.clone(),
+        snap = {"state": env.state.clone(), "reset": env.reset_buf.clone(), "progress": env.progress_buf.clone(),
                 "step": env.step_count, "rng": torch.cuda.get_rng_state(self.device)}
+        if getattr(self, "fused_rollout", False):
+            snap["agent"] = [t.clone() for t in (self.meter, self.roll_counter)]
+        return snap
 
     def _restore_env(self, snap):
         env = getattr(self.vec_env, "env", self.vec_env)
@@ -423,6 +509,9 @@ class A2CAgent:
         env.state.copy_(snap["state"]); env.reset_buf.copy_(snap["reset"]); env.progress_buf.copy_(snap["progress"])
         env.step_count = snap["step"]
         torch.cuda.set_rng_state(snap["rng"], self.device)
+        if "agent" in snap:
+            self.meter.copy_(snap["agent"][0])
+            self.roll_counter.copy_(snap["agent"][1])
 
     # ------------------------------------------------------------------ dataset (R5)
     def prepare_dataset(self, batch):
