@@ -128,6 +128,9 @@ def test_fused_update_equals_stock_update():
         torch.manual_seed(0)
         agent = A2CAgent("t", params, vec_env=env)
         agent.init_tensors()
+        agent.fused_rollout = False          # same (stock, torch.randn) rollout for both; only the update differs
+        agent.game_rewards.mean, agent.game_rewards.current_size = torch.zeros(1, device="cuda:0"), torch.zeros((), device="cuda:0")
+        agent.game_lengths.mean, agent.game_lengths.current_size = torch.zeros(1, device="cuda:0"), torch.zeros((), device="cuda:0")
         agent.obs = agent.env_reset()["obs"]
         torch.manual_seed(5)
         play, upd, stats = agent.train_epoch()
