@@ -367,3 +367,32 @@ def test_ppo_iteration_on_gpu_eager_and_graphed(HipEnv):
     for k in ("a_loss", "c_loss", "kl"):
         assert np.isfinite(results[0][3][k]) and np.isfinite(results[1][3][k])
     assert abs(float(results[0][0].mean()) - float(results[1][0].mean())) < 0.05
+
+
+def test_train_entry_checkpoint_and_play(HipEnv, tmp_path, monkeypatch):
+    """train.py semantics end to end (train.py:35-171): compose config from CLI overrides, train a few iterations,
+    write runs/<name>/config.yaml + the config pickle + checkpoints, then `test=True checkpoint=...` plays it."""
+    import glob
+    import os
+    import pickle
+    from vine_robot_isaacgymenvs_amd.train import main
+    monkeypatch.chdir(tmp_path)
+    ov = ["task=Vine5LinkMovingBase", "num_envs=256", "minibatch_size=1024", "max_iterations=3", "headless=True",
+          "experiment=unit", "train.params.config.save_frequency=1", "train.params.config.save_best_after=0"]
+    last_mean, epoch = main(ov)
+    assert epoch == 3
+    run = tmp_path / "runs" / "unit"
+    assert (run / "config.yaml").exists() and glob.glob(str(run / "*_rlg_config_dict.pkl"))
+    cfgd = pickle.load(open(glob.glob(str(run / "*_rlg_config_dict.pkl"))[0], "rb"))
+    assert cfgd["params"]["config"]["name"] == "unit" and cfgd["params"]["network"]["rnn"]["units"] == 256
+    ckpts = glob.glob(str(run / "nn" / "*.pth"))
+    assert ckpts, "no checkpoint written"
+    scal = (run / "summaries" / "scalars.csv").read_text()
+    for tag in ("performance/step_inference_rl_update_fps", "losses/a_loss", "info/kl", "info/last_lr"):
+        assert tag in scal
+    # resume + play
+    ck = sorted(ckpts)[-1]
+    main(ov[:-2] + ["checkpoint=" + ck, "max_iterations=4"])
+    reward, steps = main(["task=Vine5LinkMovingBase", "num_envs=256", "test=True", "checkpoint=" + ck, "headless=True",
+                          "+train.params.config.player={max_steps: 40}"])
+    assert np.isfinite(reward) and steps > 0

@@ -62,8 +62,6 @@ def parse_scalar(text):
         v = _yaml_load(s)
     except yaml.YAMLError:
         return s
-    if isinstance(v, (dict,)):
-        return s
     return v
 
 
