@@ -49,7 +49,9 @@ def make_env(args, rank, device_index):
     from vine_robot_isaacgymenvs_amd import load_config
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
     ov = ["task=Vine5LinkMovingBase", "num_envs=%d" % args.num_envs, "vine_randomize=%s" % bool(args.randomize),
-          "OBSERVATION_TYPE=%s" % args.obs_type, "headless=True", "sim_device=cuda:%d" % device_index,
+          "OBSERVATION_TYPE=%s" % args.obs_type, "headless=True",
+          "task.env.CREATE_PIPE=False",      # default task YAML except CREATE_PIPE / CAPTURE_VIDEO
+          "sim_device=cuda:%d" % device_index,
           "rl_device=cuda:%d" % device_index, "multi_gpu=%s" % (args.gpus > 1)]
     cfg = load_config(overrides=ov)
     cfg["task"]["seed"] = 42 + 2 * rank        # train.py:78 + utils.py:50: the rank is added twice

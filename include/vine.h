@@ -72,9 +72,11 @@ enum {
     /* Physics-model switches (PhysX is closed: see DESIGN.md "assumptions"). */
     VINE_FLAG_STALE_BODY_STATE_AFTER_RESET   = 1u << 11, /* V5:796-797: tip/cart body states are not refreshed by reset_idx */
     VINE_FLAG_IMPLICIT_JOINT_DAMPING         = 1u << 12, /* DOF damping integrated implicitly (articulation drive) instead of explicitly */
-    VINE_FLAG_FPAM_DAMPING_HELD              = 1u << 13  /* hold the C*qd torque term over the sim step exactly as V5:1062 does
+    VINE_FLAG_FPAM_DAMPING_HELD              = 1u << 13, /* hold the C*qd torque term over the sim step exactly as V5:1062 does
                                                             (unstable with the reference coefficients in this integrator; default off:
                                                             C joins the implicitly integrated DOF damping) */
+    VINE_FLAG_CREATE_PIPE                    = 1u << 14  /* TY:35 CREATE_PIPE: the 13.8 cm-ID tube of assets/urdf/pipe as its planar
+                                                            cross-section (two walls), pose and object_info per V5:841-885 */
 };
 
 /* Flat POD configuration = TY `env.*`, `sim.*`, `task.*` + URDF constants. */
@@ -160,7 +162,9 @@ typedef enum VineField {
     VF_PREV_TIP_Y = 40,   /* prev_tip_positions[:,1:3]             (V5:232, 944) */
     VF_PREV_TIP_Z = 41,
     VF_FIFO0 = 42,        /* actions_history ring: slot s holds (u_rail, u_fpam) at 42+2s, 43+2s (V5:289-291) */
-    VF_COUNT = 42 + 2 * VINE_MAX_DELAY
+    VF_PIPE_Y = 42 + 2 * VINE_MAX_DELAY,      /* pipe root position y,z (V5:873-874); its angle theta' is VF_OBJ_ANGLE */
+    VF_PIPE_Z = 43 + 2 * VINE_MAX_DELAY,
+    VF_COUNT = 44 + 2 * VINE_MAX_DELAY
 } VineField;
 
 typedef struct VineHandle VineHandle;
@@ -206,7 +210,7 @@ int vine_reset_idx(VineHandle* h, const int64_t* env_ids, int64_t n,
                    float* rew, int64_t* reset, int64_t* progress, void* stream);
 
 /* Deterministic reset values for parity tests: values[e*10 + k] =
- * (q1..q5, cart_y, target_x(ignored), target_y, target_z, shelf_depth) used INSTEAD of the
+ * (q1..q5, cart_y, pipe_depth (CREATE_PIPE; else ignored), target_y, target_z, shelf_depth) used INSTEAD of the
  * counter-based draw for every later reset (the reference draws them from the torch
  * CPU generator, V5:780-788, 904-909, 822-823).  NULL switches back to the RNG.
  * The buffer lives on the handle's device and must stay valid while bound. */

@@ -619,6 +619,97 @@ double vine_oracle_shelf_contact(const VineConfig* cfg, const double* q, const d
     return f;
 }
 
+/* Planar pipe contact (CREATE_PIPE; V5:841-885, assets/urdf/pipe: mesh cylinder-13_8cm-ID.STL scaled by
+ * 0.001 * PIPE_ADDITIONAL_SCALING = 0.00105 -> tube of length 0.34125, inner radius 0.07245, wall 0.00525, whose
+ * local origin is a corner of its bounding box and whose axis runs along local z).  The root is rotated about x by
+ * theta = theta' + 90 deg; in the vine's plane (the tube axis sits at world x = 0.0042) the obstacle is two wall
+ * rectangles in the pipe frame: y_l in [0, 0.00525] and [0.15015, 0.1554], z_l in [0, 0.34125].
+ * Same penalty model as the shelf: (a) 6 points per link vs the two walls, (b) the 4 rim corners of the entrance
+ * (z_l = 0) and of the far end vs every link rectangle.  No contact force is reported for the pipe (V5:1246). */
+#define PIPE_LEN ((real)0.34125)
+#define PIPE_WALL ((real)0.00525)
+#define PIPE_OUTER ((real)0.1554)
+static void pipe_contact(const Model* M, const real* q, const real* qd, real pipe_y, real pipe_z, real theta_prime,
+                         real* Qc) {
+    const real th = theta_prime + (real)1.5707963267948966;
+    const real ct = (real)cos((double)th), st = (real)sin((double)th);
+    /* pipe-frame axes in world (y,z): e_y = (ct, st), e_z = (-st, ct) */
+    const real wall_lo[2] = {0, PIPE_OUTER - PIPE_WALL};
+    real ang = M->phi0, om = 0;
+    real py[NL + 1], pz[NL + 1], pvy = qd[0], pvz = 0;
+    py[0] = q[0]; pz[0] = M->z1;
+    for (int k = 0; k < NL; ++k) {
+        ang += q[k + 1]; om += qd[k + 1];
+        real s = (real)sin((double)ang), c = (real)cos((double)ang);
+        real dy = -s, dz = c, ly = c, lz = s;
+        real z0 = (k == 0) ? (real)-0.00575 : 0, z1 = (k == 0) ? (real)0.09425 : M->L;
+        real fy_tot = 0, mom[NL];
+        for (int j = 0; j <= k; ++j) mom[j] = 0;
+        for (int e = 0; e < 2; ++e)
+            for (int t = 0; t < 3; ++t) {
+                real yl = e ? LINK_Y1 : LINK_Y0;
+                real zl = (t == 0) ? z0 : (t == 1 ? (real)0.5 * (z0 + z1) : z1);
+                real ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                real wy = py[k] + ry, wz = pz[k] + rz;
+                real vy = pvy - om * rz, vz = pvz + om * ry;
+                /* into the pipe frame */
+                real gy = wy - pipe_y, gz = wz - pipe_z;
+                real pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
+                real vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
+                for (int w = 0; w < 2; ++w) {
+                    real cy = wall_lo[w] + (real)0.5 * PIPE_WALL, cz = (real)0.5 * PIPE_LEN;
+                    real ddy = pyl - cy, ddz = pzl - cz;
+                    real ey = (real)0.5 * PIPE_WALL - (real)fabs((double)ddy), ez = (real)0.5 * PIPE_LEN - (real)fabs((double)ddz);
+                    if (ey <= 0 || ez <= 0) continue;
+                    real fyl = 0, fzl = 0;
+                    if (ey < ez) {
+                        real sg = (ddy > 0) ? (real)1 : (real)-1;
+                        real f = CONTACT_K * ey - CONTACT_C * sg * vyl;
+                        fyl = sg * (f > 0 ? f : 0);
+                    } else {
+                        real sg = (ddz > 0) ? (real)1 : (real)-1;
+                        real f = CONTACT_K * ez - CONTACT_C * sg * vzl;
+                        fzl = sg * (f > 0 ? f : 0);
+                    }
+                    real fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;   /* back to world */
+                    fy_tot += fy;
+                    for (int j = 0; j <= k; ++j) mom[j] += (wy - py[j]) * fz - (wz - pz[j]) * fy;
+                }
+            }
+        /* rim corners of both walls at both ends vs this link's rectangle */
+        for (int w = 0; w < 2; ++w)
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                real pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0), pzl = (cidx & 2) ? PIPE_LEN : 0;
+                real wy = pipe_y + pyl * ct - pzl * st, wz = pipe_z + pyl * st + pzl * ct;
+                real ry = wy - py[k], rz = wz - pz[k];
+                real zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+                if (!(zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1)) continue;
+                real dep = zl - z0, ny = -dy, nz = -dz;
+                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                real vy = pvy - om * rz, vz = pvz + om * ry;
+                real f = CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz);
+                if (f < 0) f = 0;
+                real fy = -f * ny, fz = -f * nz;
+                fy_tot += fy;
+                for (int j = 0; j <= k; ++j) mom[j] += (wy - py[j]) * fz - (wz - pz[j]) * fy;
+            }
+        Qc[0] += fy_tot;
+        for (int j = 0; j <= k; ++j) Qc[j + 1] += mom[j];
+        py[k + 1] = py[k] + M->L * dy; pz[k + 1] = pz[k] + M->L * dz;
+        pvy += M->L * om * (-c); pvz += M->L * om * (-s);
+    }
+}
+void vine_oracle_pipe_contact(const VineConfig* cfg, const double* q, const double* qd, double pipe_y, double pipe_z,
+                              double theta_prime, double* Qc) {
+    Model M; model_init(&M, cfg);
+    real rq[ND], rqd[ND], Q[ND];
+    for (int i = 0; i < ND; ++i) { rq[i] = (real)q[i]; rqd[i] = (real)qd[i]; Q[i] = 0; }
+    pipe_contact(&M, rq, rqd, (real)pipe_y, (real)pipe_z, (real)theta_prime, Q);
+    for (int i = 0; i < ND; ++i) Qc[i] = Q[i];
+}
+
 /* ------------------------------------------------------------------------- */
 /* Glue, as pure per-env functions (float-typed like the reference tensors when real=float). */
 
@@ -823,6 +914,10 @@ int vine_create(const VineConfig* cfg, int device_id, float* state_storage, Vine
         ST(h, VF_TIP_Y, e) = tip[0]; ST(h, VF_TIP_Z, e) = tip[1];
         ST(h, VF_PREV_TIP_Y, e) = tip[0]; ST(h, VF_PREV_TIP_Z, e) = tip[1];
         ST(h, VF_SHELF_Y, e) = (real)0.2; ST(h, VF_SHELF_Z, e) = 0;
+        if (cfg->flags & VINE_FLAG_CREATE_PIPE) {   /* V5:482-484 initial pose, identity orientation (theta = 0) */
+            ST(h, VF_PIPE_Y, e) = (real)-0.4; ST(h, VF_PIPE_Z, e) = (real)0.5;
+            ST(h, VF_OBJ_ANGLE, e) = (real)-1.5707963267948966;
+        }
     }
     sync_mirror(h);
     *out = h;
@@ -844,12 +939,12 @@ int vine_bind_reward_matrix(VineHandle* h, float* rm) { h->reward_matrix = rm; r
  * Body states (tip, cart) are left untouched when STALE_BODY_STATE_AFTER_RESET (V5:796-797). */
 static void reset_env(VineHandle* h, int e, uint64_t step) {
     const VineConfig* c = &h->cfg;
-    real qn[ND], ty, tz, depth;
+    real qn[ND], ty, tz, depth, pdepth;
     const real ten = (real)(10.0 * 3.14159265358979323846 / 180.0); /* math.radians(10), V5:778-779 */
     if (h->reset_values) {
         const float* v = h->reset_values + (size_t)e * 10;
         for (int k = 0; k < NL; ++k) qn[k + 1] = v[k];
-        qn[0] = v[5]; ty = v[7]; tz = v[8]; depth = v[9];
+        qn[0] = v[5]; pdepth = v[6]; ty = v[7]; tz = v[8]; depth = v[9];
     } else {
         uint32_t r0[4], r1[4], r2[4];
         rng4(c->seed, (uint32_t)e, step, RNG_RESET, 0, r0);
@@ -863,6 +958,7 @@ static void reset_env(VineHandle* h, int e, uint64_t step) {
         ty = (real)c->min_target_y + ((real)c->max_target_y - (real)c->min_target_y) * (real)u[7];
         tz = (real)c->min_target_z + ((real)c->max_target_z - (real)c->min_target_z) * (real)u[8];
         depth = (real)c->min_target_depth + ((real)c->max_target_depth - (real)c->min_target_depth) * (real)u[9];
+        pdepth = (real)c->min_target_depth + ((real)c->max_target_depth - (real)c->min_target_depth) * (real)u[6];
     }
     if (!(c->flags & VINE_FLAG_RANDOMIZE_DOF_INIT)) for (int i = 0; i < ND; ++i) qn[i] = 0;  /* V5:790 */
     if (!(c->flags & VINE_FLAG_RANDOMIZE_TARGETS)) { ty = (real)c->max_target_y; tz = (real)c->min_target_z; } /* V5:911-912 */
@@ -881,6 +977,17 @@ static void reset_env(VineHandle* h, int e, uint64_t step) {
         ST(h, VF_SHELF_Y, e) = ty + (-(real)0.2 + depth);
         ST(h, VF_SHELF_Z, e) = tz - (real)0.01;
         ST(h, VF_OBJ_DEPTH, e) = depth;
+    }
+    if (c->flags & VINE_FLAG_CREATE_PIPE) {          /* V5:841-885 */
+        const real R = (real)(0.07 * 1.05);           /* PIPE_RADIUS, V5:88 */
+        real ez = (real)1.0 - tz;                    /* effective_z = INIT_Z - target z */
+        real deg = (((real)13199.0 * ez - (real)12276.0) * ez + (real)4045.0) * ez - (real)447.0;   /* polyval, V5:855-857 */
+        real tp = deg * (real)(3.14159265358979323846 / 180.0);
+        real ctp = (real)cos((double)tp), stp = (real)sin((double)tp);
+        ST(h, VF_PIPE_Y, e) = ty + pdepth * ctp + R * stp;       /* V5:867-869 */
+        ST(h, VF_PIPE_Z, e) = tz + pdepth * stp - R * ctp;       /* V5:868-870 */
+        ST(h, VF_OBJ_DEPTH, e) = pdepth;                         /* V5:884 (overrides the shelf's entry) */
+        ST(h, VF_OBJ_ANGLE, e) = tp;                             /* V5:885 */
     }
     if (!(c->flags & VINE_FLAG_STALE_BODY_STATE_AFTER_RESET)) {
         real qd0[ND] = {0}, tip[4];
@@ -915,6 +1022,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     const uint64_t step = (uint64_t)h->step_count;
     const int randomize = (c->flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
     const int shelf = (c->flags & VINE_FLAG_CREATE_SHELF) != 0;
+    const int pipe = (c->flags & VINE_FLAG_CREATE_PIPE) != 0;
 
     /* ---- VecTask.step: clamp (VT:333) ---- */
     real a0 = (real)actions[2 * e], a1 = (real)actions[2 * e + 1];
@@ -948,6 +1056,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     real pcv = ST(h, VF_PREV_CART_VEL, e), pce = ST(h, VF_PREV_CART_VEL_ERR, e);
     real contact = ST(h, VF_CONTACT, e), contact_sum = 0, rail_force = 0;
     real shelf_y = ST(h, VF_SHELF_Y, e), shelf_z = ST(h, VF_SHELF_Z, e);
+    real pipe_y = ST(h, VF_PIPE_Y, e), pipe_z = ST(h, VF_PIPE_Z, e), pipe_tp = ST(h, VF_OBJ_ANGLE, e);
     real u_used = (c->flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam; /* V5:1059 */
     const real hsub = (real)c->dt / (real)c->substeps;
 
@@ -972,6 +1081,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
             real effc[ND];
             for (int i = 0; i < ND; ++i) effc[i] = eff[i];
             if (shelf) csum += shelf_contact(M, q, qd, shelf_y, shelf_z, effc);
+            if (pipe) pipe_contact(M, q, qd, pipe_y, pipe_z, pipe_tp, effc);
             substep(M, h->form, cj, q, qd, effc, hsub);
         }
         contact = shelf ? csum / (real)c->substeps : 0;

@@ -61,6 +61,7 @@ def load(precision="f64", omp=False):
     lib.vine_oracle_reset_logic.restype = C.c_int64
     lib.vine_oracle_shelf_contact.argtypes = [P, _D, _D, C.c_double, C.c_double, _D]
     lib.vine_oracle_shelf_contact.restype = C.c_double
+    lib.vine_oracle_pipe_contact.argtypes = [P, _D, _D, C.c_double, C.c_double, C.c_double, _D]
     lib.vine_oracle_state.argtypes = [C.c_void_p]
     lib.vine_oracle_state.restype = C.c_void_p
     lib.vine_oracle_set_formulation.argtypes = [C.c_void_p, C.c_int]

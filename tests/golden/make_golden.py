@@ -113,7 +113,12 @@ def install_stubs():
     torch_utils = types.ModuleType("isaacgym.torch_utils")
     torch_utils.to_torch = lambda x, dtype=torch.float, device="cpu", requires_grad=False: torch.tensor(
         x, dtype=dtype, device=device, requires_grad=requires_grad)
-    torch_utils.quat_from_angle_axis = None
+
+    def _quat_from_angle_axis(angle, axis):      # stand-in for isaacgym.torch_utils (unit axis assumed, xyzw)
+        xyz = axis * torch.sin(angle / 2).unsqueeze(-1)
+        return torch.cat([xyz, torch.cos(angle / 2).unsqueeze(-1)], dim=-1)
+
+    torch_utils.quat_from_angle_axis = _quat_from_angle_axis
     isaacgym = types.ModuleType("isaacgym")
     isaacgym.gymapi, isaacgym.gymtorch, isaacgym.gymutil, isaacgym.torch_utils = gymapi, gymtorch, gymutil, torch_utils
     sys.modules.update({"isaacgym": isaacgym, "isaacgym.gymapi": gymapi, "isaacgym.gymtorch": gymtorch,
@@ -177,16 +182,17 @@ class FakeGym:
 
     instance = None
 
-    def __init__(self, num_envs, create_shelf, oracle_cfg):
+    def __init__(self, num_envs, create_shelf, oracle_cfg, create_pipe=False):
         FakeGym.instance = self
         self.n = num_envs
         self.shelf = create_shelf
+        self.pipe = create_pipe
         self.ocfg = oracle_cfg
-        self.nb = N_VINE_BODIES + (N_SHELF_BODIES if create_shelf else 0)
-        self.vine_body_off = N_SHELF_BODIES if create_shelf else 0
+        self.vine_body_off = (N_SHELF_BODIES if create_shelf else 0) + (1 if create_pipe else 0)
+        self.nb = N_VINE_BODIES + self.vine_body_off
         self.dof_state = torch.zeros(num_envs * 6, 2)
         self.rb_state = torch.zeros(num_envs * self.nb, 13)
-        self.root_state = torch.zeros(num_envs * (2 if create_shelf else 1), 13)
+        self.root_state = torch.zeros(num_envs * (1 + int(create_shelf) + int(create_pipe)), 13)
         self.contact = torch.zeros(num_envs * self.nb, 3)
         self.efforts = torch.zeros(num_envs, 6)
         self.calls = []
@@ -254,8 +260,10 @@ class FakeGym:
         return np.zeros(6, dtype=[("driveMode", np.int32), ("damping", np.float32), ("stiffness", np.float32)])
 
     def find_actor_rigid_body_index(self, env, handle, name, domain):
-        if name in SHELF_BODY and self.shelf and name != "tip" and name not in VINE_BODY:
+        if name in SHELF_BODY and self.shelf and name not in VINE_BODY:
             return SHELF_BODY[name]
+        if name == "base_link":                      # the pipe's only body, created after the shelf
+            return N_SHELF_BODIES if self.shelf else 0
         return self.vine_body_off + VINE_BODY[name]
 
     def create_camera_sensor(self, *a):
@@ -352,6 +360,7 @@ def oracle_cfg_from(cfg, held=True):
         c.reward_weights[i] = e[nme + "_REWARD_WEIGHT"]
     vo.load().vine_config_set_obs_type(c, abi.OBS_TYPE_BY_NAME[e["OBSERVATION_TYPE"]], int(e["SCALE_OBSERVATIONS"]))
     c.set_flag(abi.FLAG_CREATE_SHELF, e["CREATE_SHELF"])
+    c.set_flag(abi.FLAG_CREATE_PIPE, e.get("CREATE_PIPE", False))
     c.set_flag(abi.FLAG_USE_TARGET_REACHED_RESET, e["USE_TARGET_REACHED_RESET"])
     c.set_flag(abi.FLAG_USE_TIP_LIMIT_HIT_RESET, e["USE_TIP_LIMIT_HIT_RESET"])
     c.set_flag(abi.FLAG_USE_NONZERO_CONTACT_FORCE_RESET, e["USE_NONZERO_CONTACT_FORCE_RESET"])
@@ -365,7 +374,7 @@ def oracle_cfg_from(cfg, held=True):
 def make_task(vt, v5, cfg):
     vt.EXISTING_SIM = None
     ocfg = oracle_cfg_from(cfg)
-    FakeGym(cfg["env"]["numEnvs"], cfg["env"]["CREATE_SHELF"], ocfg)
+    FakeGym(cfg["env"]["numEnvs"], cfg["env"]["CREATE_SHELF"], ocfg, cfg["env"].get("CREATE_PIPE", False))
     task = v5.Vine5LinkMovingBase(cfg=cfg, rl_device="cpu", sim_device="cpu", graphics_device_id=-1, headless=True,
                                   virtual_screen_capture=False, force_render=False)
     return task, FakeGym.instance, ocfg
@@ -499,6 +508,17 @@ def f4_reset(vt, v5, out):
 
 def f5_reset_sampling(vt, v5, out):
     N = 1024
+    # CREATE_PIPE (the reference's default obstacle): pose + object_info of V5:841-885
+    for shelf in (False, True):
+        cfg = reference_task_cfg(N, CREATE_SHELF=shelf, CREATE_PIPE=True)
+        task, gym, _ = make_task(vt, v5, cfg)
+        torch.manual_seed(43)
+        task.reset_idx(torch.arange(N))
+        out["f5_reset_pipe_shelf%d" % int(shelf)] = dict(
+            q=npf(task.dof_pos), target=npf(task.target_positions), obj_info=npf(task.object_info),
+            pipe_root=npf(gym.root_state[task.pipe_indices, 0:7]),
+            shelf_root=npf(gym.root_state[task.shelf_indices, 0:3]) if shelf else np.zeros((0, 3), np.float32),
+            pipe_radius=np.float64(v5.PIPE_RADIUS))
     for shelf in (False, True):
         cfg = reference_task_cfg(N, CREATE_SHELF=shelf)
         task, gym, _ = make_task(vt, v5, cfg)

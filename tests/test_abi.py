@@ -60,6 +60,7 @@ def test_field_enum_matches_header():
     text = open(os.path.join(REPO, "include", "vine.h")).read()
     for name, val in re.findall(r"\b(VF_[A-Z_0-9]+)\s*=\s*(\d+)\s*[,/]", text):
         assert getattr(abi, name) == int(val), name
+    assert abi.VF_PIPE_Y == 42 + 2 * abi.MAX_DELAY and abi.VF_COUNT == 44 + 2 * abi.MAX_DELAY
     for name, shift in re.findall(r"\bVINE_(FLAG_[A-Z_]+)\s*=\s*1u << (\d+)", text):
         assert getattr(abi, name) == 1 << int(shift), name
 

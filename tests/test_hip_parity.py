@@ -127,6 +127,48 @@ def test_shelf_contacts_match_oracle(HipEnv):
         hip.close(); orc.close()
 
 
+@pytest.mark.parametrize("with_shelf", [False, True])
+def test_pipe_obstacle_matches_oracle(HipEnv, with_shelf):
+    """CREATE_PIPE (the reference's default obstacle) as its planar cross-section: reset pose/object_info and wall
+    contacts against the oracle; the pipe is placed around each env's tip so that contacts are active."""
+    n = 640
+    cfg = base_cfg(n, 0, True, action_delay=1, seed=5)
+    cfg.set_flag(abi.FLAG_CREATE_PIPE, True)
+    cfg.set_flag(abi.FLAG_CREATE_SHELF, with_shelf)
+    rng = np.random.default_rng(33)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    st = seed_both(hip, orc, rng, n, cfg)
+    tp = rng.uniform(0.4, 1.1, n)
+    th = tp + np.pi / 2
+    # pipe origin such that the tip sits ~5 cm inside the entrance, near the first wall
+    yl, zl = rng.uniform(-0.01, 0.03, n), rng.uniform(0.0, 0.1, n)
+    st[abi.VF_PIPE_Y] = st[abi.VF_TIP_Y] - (yl * np.cos(th) - zl * np.sin(th))
+    st[abi.VF_PIPE_Z] = st[abi.VF_TIP_Z] - (yl * np.sin(th) + zl * np.cos(th))
+    st[abi.VF_OBJ_ANGLE] = tp
+    hip.set_state(st)
+    orc.state[:] = st.astype(orc.real)
+    a = rng.uniform(-1, 1, (n, 2))
+    out = hip.step(a)
+    orc.step(a)
+    hs, os_ = hip.state, orc.state.astype(np.float64)
+    # contacts were active: the free-space oracle from the same state ends elsewhere
+    free_cfg = base_cfg(n, 0, True, action_delay=1, seed=5)
+    free = vo.OracleEnv(free_cfg, "f32")
+    free.state[:abi.VF_PIPE_Y] = st[:abi.VF_PIPE_Y].astype(free.real)
+    free.reset_buf[:] = 0
+    free.progress[:] = 5
+    assert np.isfinite(hs).all()
+    np.testing.assert_array_equal(out[2], orc.reset_buf)
+    ok = np.abs(hs[QVEL] - os_[QVEL]).max(0) < 0.5      # a contact opening/closing within round-off flips an env
+    assert ok.mean() > 0.97
+    np.testing.assert_allclose(hs[QPOS][:, ok], os_[QPOS][:, ok], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(hs[QVEL][:, ok], os_[QVEL][:, ok], rtol=0, atol=5e-2)
+    for f in (abi.VF_PIPE_Y, abi.VF_PIPE_Z, abi.VF_OBJ_ANGLE, abi.VF_OBJ_DEPTH, abi.VF_TARGET_Y, abi.VF_TARGET_Z):
+        np.testing.assert_allclose(hs[f], os_[f], rtol=0, atol=2e-5, err_msg="field %d" % f)
+    np.testing.assert_allclose(out[0][ok], orc.obs[ok], rtol=0, atol=2e-2)
+    hip.close(); orc.close()
+
+
 def test_first_step_resets_everything(HipEnv):
     """reset_buf starts at ones (vec_task.py:275): the first step simulates the zero pose, then resets all envs."""
     n = 512

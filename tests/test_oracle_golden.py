@@ -181,3 +181,37 @@ def test_f6_step_sequencing(golden, tag, delay, obs_type):
         n_resets += int(will_reset.sum())
         n_timeouts += int(to.sum())
     assert n_resets > N and n_timeouts > 0               # the trajectory exercises resets and timeouts
+
+
+@pytest.mark.parametrize("shelf", [0, 1])
+def test_f5_pipe_pose_and_object_info(golden, shelf):
+    """reset_idx with CREATE_PIPE (V5:841-885): given the reference's own draws (injected), the oracle reproduces the
+    pipe root position, its angle theta' (cubic in INIT_Z - target_z, V5:854-857) and object_info exactly."""
+    g = golden("f5_reset_pipe_shelf%d" % shelf)
+    N = g["q"].shape[0]
+    cfg = base_cfg(N)
+    cfg.set_flag(abi.FLAG_CREATE_PIPE, True)
+    cfg.set_flag(abi.FLAG_CREATE_SHELF, shelf)
+    env = vo.OracleEnv(cfg, "f64")
+    vals = np.zeros((N, 10), np.float32)
+    vals[:, 0:5], vals[:, 5] = g["q"][:, 1:6], g["q"][:, 0]
+    vals[:, 6] = g["obj_info"][:, 0]                      # the pipe's entrance depth (overrides the shelf's, V5:884)
+    vals[:, 7:9] = g["target"][:, 1:3]
+    if shelf:
+        vals[:, 9] = g["shelf_root"][:, 1] - g["target"][:, 1] + 0.2
+    env.bind_reset_values(vals)
+    env.reset_idx(np.arange(N))
+    st = env.state
+    np.testing.assert_allclose(st[abi.VF_OBJ_DEPTH], g["obj_info"][:, 0], atol=1e-7)
+    np.testing.assert_allclose(st[abi.VF_OBJ_ANGLE], g["obj_info"][:, 1], rtol=0, atol=2e-4)   # float32 polyval in the reference
+    np.testing.assert_allclose(st[abi.VF_PIPE_Y], g["pipe_root"][:, 1], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(st[abi.VF_PIPE_Z], g["pipe_root"][:, 2], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(g["pipe_root"][:, 0], -float(g["pipe_radius"]), atol=1e-6)     # x offset: axis at x ~ 0
+    # orientation: rotation about x by theta' + 90 deg (V5:858-861), quaternion (x, y, z, w)
+    th = st[abi.VF_OBJ_ANGLE] + np.pi / 2
+    np.testing.assert_allclose(g["pipe_root"][:, 3], np.sin(th / 2), atol=2e-4)
+    np.testing.assert_allclose(g["pipe_root"][:, 6], np.cos(th / 2), atol=2e-4)
+    assert np.abs(g["pipe_root"][:, 4:6]).max() == 0
+    assert 20 < np.degrees(st[abi.VF_OBJ_ANGLE]).min() and np.degrees(st[abi.VF_OBJ_ANGLE]).max() < 70
+    if shelf:
+        np.testing.assert_allclose(st[abi.VF_SHELF_Y], g["shelf_root"][:, 1], atol=2e-6)

@@ -259,3 +259,45 @@ def test_shelf_run_is_stable():
         assert np.abs(env.state[abi.VF_QD0 + 1:abi.VF_QD0 + 6]).max() < 60
         touched += int((env.state[abi.VF_CONTACT_MEAN] > 0).sum())
     assert touched > 0
+
+
+def test_pipe_contact_model():
+    """CREATE_PIPE cross-section (two walls in the pipe frame): no force away from the pipe; a link pressed into a
+    wall is pushed back along the wall normal; the run with the obstacle stays bounded."""
+    import ctypes as C
+    lib = vo.load("f64")
+    cfg = vo.default_config()
+    D = C.POINTER(C.c_double)
+
+    def contact(q, qd, py, pz, tp):
+        q, qd = np.ascontiguousarray(q, np.float64), np.ascontiguousarray(qd, np.float64)
+        Q = np.zeros(6)
+        lib.vine_oracle_pipe_contact(C.byref(cfg), q.ctypes.data_as(D), qd.ctypes.data_as(D), py, pz, tp,
+                                     Q.ctypes.data_as(D))
+        return Q
+
+    q0 = np.zeros(6)
+    assert not contact(q0, np.zeros(6), -2.0, 0.5, 0.8).any()
+    # theta' = -90 deg -> theta = 0: pipe frame == world frame; wall 1 occupies y in [py, py+0.00525], z in [pz, pz+0.34125].
+    # Put it 1.5 mm inside the -y face of the hanging chain (face at y = -0.0719): it must push the chain towards +y
+    # (walls are 5.25 mm thin: beyond half their thickness the nearest exit is the far side).
+    t = vo.tip(cfg, q0, np.zeros(6))
+    py = t[0] - 0.0719 - 0.00525 + 0.0015
+    Q = contact(q0, np.zeros(6), py, 0.55, -np.pi / 2)
+    assert Q[0] > 0 and Q[1] != 0
+    # and the mirror image with the second wall on the +y face (face at y = +0.0381) pushes towards -y
+    py2 = t[0] + 0.0381 - 0.0015 - (0.1554 - 0.00525)
+    Q2 = contact(q0, np.zeros(6), py2, 0.55, -np.pi / 2)
+    assert Q2[0] < 0
+    cfg2 = vo.default_config(num_envs=64)
+    cfg2.set_flag(abi.FLAG_CREATE_PIPE, True)
+    cfg2.set_flag(abi.FLAG_VINE_RANDOMIZE, False)
+    env = vo.OracleEnv(cfg2, "f64")
+    rng = np.random.default_rng(0)
+    a = np.zeros((64, 2))
+    for s in range(300):
+        if s % 8 == 0:
+            a = np.sign(rng.uniform(-1, 1, (64, 2)))
+        env.step(a)
+        assert np.isfinite(env.state).all() and np.abs(env.state[abi.VF_QD0 + 1:abi.VF_QD0 + 6]).max() < 80
+    assert np.abs(env.state[abi.VF_OBJ_ANGLE]).max() < 1.3 and (env.state[abi.VF_OBJ_DEPTH] != 0).all()

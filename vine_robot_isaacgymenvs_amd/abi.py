@@ -40,6 +40,7 @@ FLAG_VINE_RANDOMIZE = 1 << 10
 FLAG_STALE_BODY_STATE_AFTER_RESET = 1 << 11
 FLAG_IMPLICIT_JOINT_DAMPING = 1 << 12
 FLAG_FPAM_DAMPING_HELD = 1 << 13
+FLAG_CREATE_PIPE = 1 << 14
 
 # VineField
 VF_Q0 = 0
@@ -57,7 +58,8 @@ VF_RAIL_FORCE = 33
 VF_PREV_Q0 = 34
 VF_PREV_TIP_Y, VF_PREV_TIP_Z = 40, 41
 VF_FIFO0 = 42
-VF_COUNT = 42 + 2 * MAX_DELAY
+VF_PIPE_Y, VF_PIPE_Z = 42 + 2 * MAX_DELAY, 43 + 2 * MAX_DELAY
+VF_COUNT = 44 + 2 * MAX_DELAY
 
 
 class VineConfig(C.Structure):

@@ -292,6 +292,88 @@ __device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s,
     return sqrtf(strip_fy * strip_fy + strip_fz * strip_fz);
 }
 
+// Planar pipe contact (CREATE_PIPE): the tube of assets/urdf/pipe as two wall rectangles in the pipe frame
+// (oracle/vine_oracle.c pipe_contact).  ADDS its generalised forces to qa.
+#define PIPE_LEN 0.34125f
+#define PIPE_WALL 0.00525f
+#define PIPE_OUTER 0.1554f
+__device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, float pipe_y, float pipe_z, float ct,
+                                             float st, float (&qa)[ND]) {
+    const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
+    float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
+    float Fy[NL], Fz[NL], ny_[NL], nz_[NL], mom_[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const float sp = P.s0 * s.cs[k] + P.c0 * s.sn[k], cp = P.c0 * s.cs[k] - P.s0 * s.sn[k];
+        const float dy = -sp, dz = cp, ly = cp, lz = sp;
+        const float om = s.w[k];
+        const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
+        float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
+        ny_[k] = -cp; nz_[k] = -sp;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const float yl = e ? LINK_Y1 : LINK_Y0;
+                const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+                const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
+                const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
+                    const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
+                    if (ey > 0.0f && ez > 0.0f) {
+                        float fyl = 0.0f, fzl = 0.0f;
+                        if (ey < ez) {
+                            const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                            fyl = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vyl, 0.0f);
+                        } else {
+                            const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                            fzl = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vzl, 0.0f);
+                        }
+                        const float fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;
+                        fy_tot += fy; fz_tot += fz;
+                        mom += -rz * fy + ry * fz;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const float pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0.0f), pzl = (cidx & 2) ? PIPE_LEN : 0.0f;
+                const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
+                const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+                if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                    float dep = zl - z0, ny = -dy, nz = -dz;
+                    if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                    if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                    if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                    const float vy = pvy - om * rz, vz = pvz + om * ry;
+                    const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                    const float fy = -f * ny, fz = -f * nz;
+                    fy_tot += fy; fz_tot += fz;
+                    mom += -rz * fy + ry * fz;
+                }
+            }
+        }
+        Fy[k] = fy_tot; Fz[k] = fz_tot; mom_[k] = mom;
+        py += P.L * dy; pz += P.L * dz;
+        pvy += P.L * om * (-cp); pvz += P.L * om * (-sp);
+    }
+    float sy = 0.0f, sz = 0.0f;
+#pragma unroll
+    for (int i = NL - 1; i >= 0; --i) {
+        qa[i + 1] += mom_[i] + P.L * (ny_[i] * sy + nz_[i] * sz);
+        sy += Fy[i]; sz += Fz[i];
+    }
+    qa[0] += sy;
+}
+
 __device__ __forceinline__ float clampf(float v, float lim) { return fminf(fmaxf(v, -lim), lim); }
 
 #define ST(f) st[(size_t)(f) * n + e]
@@ -302,12 +384,12 @@ __device__ __forceinline__ void reset_env(const DevParams& P, float* __restrict_
                                           unsigned long long step, const float* __restrict__ reset_values,
                                           float (&qn)[ND], float& ty, float& tz) {
     const float ten = 0.17453292519943295f;  // math.radians(10)
-    float depth;
+    float depth, pdepth;
     if (reset_values) {
         const float* v = reset_values + (size_t)e * 10;
 #pragma unroll
         for (int k = 0; k < NL; ++k) qn[k + 1] = v[k];
-        qn[0] = v[5]; ty = v[7]; tz = v[8]; depth = v[9];
+        qn[0] = v[5]; pdepth = v[6]; ty = v[7]; tz = v[8]; depth = v[9];
     } else {
         unsigned r0[4], r1[4], r2[4];
         rng4(P, (unsigned)e, step, RNG_RESET, 0, r0);
@@ -322,6 +404,7 @@ __device__ __forceinline__ void reset_env(const DevParams& P, float* __restrict_
         ty = P.ty_min + P.ty_span * u01(r1[3]);
         tz = P.tz_min + P.tz_span * u01(r2[0]);
         depth = P.depth_min + P.depth_span * u01(r2[1]);
+        pdepth = P.depth_min + P.depth_span * u01(r1[2]);
     }
     if (!(P.flags & VINE_FLAG_RANDOMIZE_DOF_INIT)) {
 #pragma unroll
@@ -340,6 +423,18 @@ __device__ __forceinline__ void reset_env(const DevParams& P, float* __restrict_
         ST(VF_SHELF_Y) = ty + (-0.2f + depth);
         ST(VF_SHELF_Z) = tz - 0.01f;
         ST(VF_OBJ_DEPTH) = depth;
+    }
+    if (P.flags & VINE_FLAG_CREATE_PIPE) {   // V5:841-885
+        const float R = 0.0735f;             // PIPE_RADIUS = 0.07 * 1.05 (V5:88)
+        const float ez = 1.0f - tz;
+        const float deg = ((13199.0f * ez - 12276.0f) * ez + 4045.0f) * ez - 447.0f;
+        const float tp = deg * 0.017453292519943295f;
+        float stp, ctp;
+        sincosf(tp, &stp, &ctp);
+        ST(VF_PIPE_Y) = ty + pdepth * ctp + R * stp;
+        ST(VF_PIPE_Z) = tz + pdepth * stp - R * ctp;
+        ST(VF_OBJ_DEPTH) = pdepth;
+        ST(VF_OBJ_ANGLE) = tp;
     }
 }
 
@@ -369,7 +464,7 @@ __device__ __forceinline__ void tip_fk(const DevParams& P, float y, float vy, co
     tip[0] = ty; tip[1] = tz; tip[2] = tvy; tip[3] = tvz;
 }
 
-template <int OBS_TYPE, bool RANDOMIZE, bool SHELF>
+template <int OBS_TYPE, bool RANDOMIZE, int OBST>   // OBST bit 0: shelf, bit 1: pipe
 __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float* __restrict__ st,
                                                        const float* __restrict__ actions, float* __restrict__ obs,
                                                        float* __restrict__ rew, long long* __restrict__ reset,
@@ -378,6 +473,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
                                                        float* __restrict__ reward_matrix,
                                                        const float* __restrict__ reset_values,
                                                        unsigned long long* __restrict__ counters) {
+    constexpr bool SHELF = (OBST & 1) != 0, PIPE = (OBST & 2) != 0, CONTACT = OBST != 0;
     const int n = P.n;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long step = counters[0];
@@ -426,6 +522,9 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
         float rail_force = 0.0f;
         float contact = SHELF ? ST(VF_CONTACT) : 0.0f, contact_sum = 0.0f;
         const float shelf_y = SHELF ? ST(VF_SHELF_Y) : 0.0f, shelf_z = SHELF ? ST(VF_SHELF_Z) : 0.0f;
+        const float pipe_y = PIPE ? ST(VF_PIPE_Y) : 0.0f, pipe_z = PIPE ? ST(VF_PIPE_Z) : 0.0f;
+        float pipe_ct = 1.0f, pipe_st = 0.0f;
+        if (PIPE) sincosf(ST(VF_OBJ_ANGLE) + 1.5707963267948966f, &pipe_st, &pipe_ct);
         const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
         const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
 
@@ -496,12 +595,22 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             if (P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) {
                 for (int k = 0; k < P.substeps; ++k) {
                     if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);
-                    substep<true, SHELF>(P, s, eff, cj, hc, qa);
+                    if (PIPE && !SHELF) {
+#pragma unroll
+                        for (int i = 0; i < ND; ++i) qa[i] = 0.0f;
+                    }
+                    if (PIPE) pipe_contact(P, s, pipe_y, pipe_z, pipe_ct, pipe_st, qa);
+                    substep<true, CONTACT>(P, s, eff, cj, hc, qa);
                 }
             } else {
                 for (int k = 0; k < P.substeps; ++k) {
                     if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);
-                    substep<false, SHELF>(P, s, eff, cj, hc, qa);
+                    if (PIPE && !SHELF) {
+#pragma unroll
+                        for (int i = 0; i < ND; ++i) qa[i] = 0.0f;
+                    }
+                    if (PIPE) pipe_contact(P, s, pipe_y, pipe_z, pipe_ct, pipe_st, qa);
+                    substep<false, CONTACT>(P, s, eff, cj, hc, qa);
                 }
             }
             if (SHELF) contact = csum / (float)P.substeps;
@@ -717,6 +826,9 @@ __global__ void vine_init_kernel(const DevParams P, float* __restrict__ st) {
     ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1];
     ST(VF_PREV_TIP_Y) = tip[0]; ST(VF_PREV_TIP_Z) = tip[1];
     ST(VF_SHELF_Y) = 0.2f;
+    if (P.flags & VINE_FLAG_CREATE_PIPE) {   // V5:482-484 initial pose, identity orientation
+        ST(VF_PIPE_Y) = -0.4f; ST(VF_PIPE_Z) = 0.5f; ST(VF_OBJ_ANGLE) = -1.5707963267948966f;
+    }
 }
 
 int validate(const VineConfig* c) {
@@ -930,21 +1042,27 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     const int blocks = (h->P.n + threads - 1) / threads;
     hipStream_t s = (hipStream_t)stream;
     const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
-    const bool shelf = (h->P.flags & VINE_FLAG_CREATE_SHELF) != 0;
+    const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
 #define LAUNCH(OT, RND, SH)                                                                                      \
     hipLaunchKernelGGL((vine_step_kernel<OT, RND, SH>), dim3(blocks), dim3(threads), 0, s, h->P, h->state, actions, \
                        obs, rew, (long long*)reset, (long long*)progress, (unsigned char*)timeouts,                 \
                        h->reward_matrix, h->reset_values, h->counters)
-#define LAUNCH_OT(OT)                               \
-    do {                                            \
-        if (rnd && shelf) LAUNCH(OT, true, true);   \
-        else if (rnd) LAUNCH(OT, true, false);      \
-        else if (shelf) LAUNCH(OT, false, true);    \
-        else LAUNCH(OT, false, false);              \
+#define LAUNCH_RND(OT, RND)                  \
+    do {                                     \
+        if (obst == 0) LAUNCH(OT, RND, 0);   \
+        else if (obst == 1) LAUNCH(OT, RND, 1); \
+        else if (obst == 2) LAUNCH(OT, RND, 2); \
+        else LAUNCH(OT, RND, 3);             \
+    } while (0)
+#define LAUNCH_OT(OT)                        \
+    do {                                     \
+        if (rnd) LAUNCH_RND(OT, true);       \
+        else LAUNCH_RND(OT, false);          \
     } while (0)
     if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) LAUNCH_OT(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO);
     else LAUNCH_OT(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
 #undef LAUNCH_OT
+#undef LAUNCH_RND
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return VINE_OK;

@@ -9,7 +9,6 @@ This class keeps the constructor signature, the buffers and the attributes calle
 """
 import ctypes as C
 import logging
-import warnings
 from enum import Enum
 
 import torch
@@ -108,6 +107,7 @@ def vine_config_from_cfg(cfg, lib, seed=None):
                      (abi.FLAG_FORCE_U_FPAM, env.get("FORCE_U_FPAM", False)),
                      (abi.FLAG_FORCE_U_RAIL_VELOCITY, env.get("FORCE_U_RAIL_VELOCITY", False)),
                      (abi.FLAG_CREATE_SHELF, env.get("CREATE_SHELF", False)),
+                     (abi.FLAG_CREATE_PIPE, env.get("CREATE_PIPE", False)),
                      (abi.FLAG_RANDOMIZE_DOF_INIT, env.get("RANDOMIZE_DOF_INIT", True)),
                      (abi.FLAG_RANDOMIZE_TARGETS, env.get("RANDOMIZE_TARGETS", True)),
                      (abi.FLAG_USE_TARGET_REACHED_RESET, env.get("USE_TARGET_REACHED_RESET", True)),
@@ -140,8 +140,7 @@ class Vine5LinkMovingBase(VecTask):
         self.cfg["env"]["numObservations"] = num_observations(observation_type)
         self.cfg["env"]["numActions"] = N_PRESSURE_ACTIONS + N_PRISMATIC_DOFS
         if self.cfg["env"].get("CREATE_PIPE", False):
-            warnings.warn("CREATE_PIPE: the pipe mesh obstacle is not simulated by the MI355X path (mesh collision "
-                          "is out of scope); set CREATE_PIPE=False to silence this warning")
+            self.logger.info("CREATE_PIPE: the pipe mesh is simulated as its planar cross-section (two walls)")
         if self.cfg["env"].get("CAPTURE_VIDEO", False):
             self.logger.info("CAPTURE_VIDEO is accepted and ignored (no renderer on the target)")
 
