@@ -200,6 +200,18 @@ def test_training_runs_and_checkpoint_roundtrip(tmp_path):
     player.restore(path)
     act = player.get_action(torch.zeros(16, 28))
     assert act.shape == (16, 2) and float(act.abs().max()) <= 1.0
+    # deployment loader (vine_robot_test_model.py:143-177): config pickle + .pth -> obs -> action, no simulator
+    import pickle
+    from vine_robot_isaacgymenvs_amd.vine_robot_test_model import VinePolicy
+    pkl = os.path.join(str(tmp_path), "cfg.pkl")
+    with open(pkl, "wb") as f:
+        pickle.dump(cfg["train"], f)
+    pol = VinePolicy.load(pkl, path)
+    a1 = pol.get_action(np.zeros(28, np.float32))
+    assert a1.shape == (2,) and torch.allclose(a1, act[0], atol=1e-6)
+    a2 = pol.get_action(np.zeros(28, np.float32))       # the LSTM state carries over between calls
+    pol.reset()
+    assert torch.allclose(pol.get_action(np.zeros(28, np.float32)), a1, atol=1e-6) and not torch.equal(a1, a2)
 
 
 def test_baseline_config1_cpu_reference_path():

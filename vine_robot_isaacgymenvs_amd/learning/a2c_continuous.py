@@ -241,6 +241,8 @@ class A2CAgent:
             os.makedirs(self.nn_dir, exist_ok=True)
             self.writer = ScalarLog(self.summaries_dir)
         self._rollout_graph = None
+        if self.algo_observer is not None:
+            self.algo_observer.after_init(self)
 
     # ------------------------------------------------------------------ plumbing
     def _setup_flat_grads(self):
@@ -699,6 +701,10 @@ class A2CAgent:
                     print(f"fps step and policy inference: {curr_frames / play_time:.0f} "
                           f"fps total: {curr_frames / sum_time:.0f} epoch: {epoch_num}/{self.max_epochs}")
                 self.write_stats(total_time, epoch_num, play_time, update_time, stats, curr_frames)
+                if self.algo_observer is not None:
+                    env = getattr(self.vec_env, "env", self.vec_env)
+                    self.algo_observer.process_infos({k: v for k, v in getattr(env, "extras", {}).items()}, None)
+                    self.algo_observer.after_print_stats(self.frame, epoch_num, total_time)
                 if float(self.game_rewards.current_size) > 0:
                     mean_rewards = float(self.game_rewards.get_mean()[0])
                     mean_lengths = float(self.game_lengths.get_mean()[0])

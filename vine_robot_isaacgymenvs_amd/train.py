@@ -11,7 +11,7 @@ def launch(cfg):
     from . import make
     from .learning.a2c_continuous import Runner
     from .utils.config import to_yaml
-    from .utils.rlgames_utils import RLGPUEnv, register_env  # noqa: F401
+    from .utils.rlgames_utils import RLGPUAlgoObserver, RLGPUEnv, register_env  # noqa: F401
     from .utils.utils import set_np_formatting, set_seed
 
     time_str = datetime.datetime.now().strftime("%Y-%m-%d_%H-%M-%S")
@@ -37,7 +37,7 @@ def launch(cfg):
     register_env("rlgpu", {"vecenv_type": "RLGPU", "env_creator": create_env_thunk})   # train.py:122-127
 
     rlg_config_dict = cfg["train"]
-    runner = Runner()
+    runner = Runner(RLGPUAlgoObserver())                               # train.py:139-141
     runner.load(rlg_config_dict)
     runner.reset()
 

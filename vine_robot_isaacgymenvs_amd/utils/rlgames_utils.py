@@ -33,6 +33,34 @@ def get_rlgames_env_creator(seed: int, task_config: dict, task_name: str, sim_de
     return create_rlgpu_env
 
 
+class RLGPUAlgoObserver:
+    """rlgames_utils.py:95-148: lets the env log scalars next to the algorithm's statistics.  Scalars found in the
+    ``infos`` dict returned by ``env.step`` are written as ``<key>/frame|iter|time`` to the agent's writer."""
+
+    def __init__(self):
+        self.algo = None
+        self.direct_info = {}
+
+    def after_init(self, algo):
+        self.algo = algo
+        self.writer = getattr(algo, "writer", None)
+
+    def process_infos(self, infos, done_indices=None):
+        assert isinstance(infos, dict), "RLGPUAlgoObserver expects dict info"
+        self.direct_info = {}
+        for k, v in infos.items():
+            if isinstance(v, (float, int)) or (hasattr(v, "shape") and len(v.shape) == 0):
+                self.direct_info[k] = v
+
+    def after_print_stats(self, frame, epoch_num, total_time):
+        if self.writer is None:
+            return
+        for k, v in self.direct_info.items():
+            self.writer.add_scalar(f"{k}/frame", float(v), frame)
+            self.writer.add_scalar(f"{k}/iter", float(v), epoch_num)
+            self.writer.add_scalar(f"{k}/time", float(v), total_time)
+
+
 class RLGPUEnv:
     """rlgames_utils.py:151-180."""
 
