@@ -92,14 +92,20 @@ __device__ __forceinline__ void normal2(unsigned a, unsigned b, float& n0, float
 }
 
 // Articulation state in absolute coordinates: cart (y, vy), link angles th_k = sum_{i<=k} q_i, rates w_k.
-// sn/cs = sin/cos of th, carried along by exact-to-rounding incremental rotations (see substep).
+// sn/cs = sin/cos of the WORLD link angle phi_k = phi0 + th_k, carried along by exact-to-rounding incremental
+// rotations (see substep) and re-synchronised from th once per env step.
 struct Dyn {
     float y, vy, th[NL], w[NL], sn[NL], cs[NL];
 };
 
-__device__ __forceinline__ void dyn_sync_trig(Dyn& s) {
+__device__ __forceinline__ void dyn_sync_trig(const DevParams& P, Dyn& s) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i) sincosf(s.th[i], &s.sn[i], &s.cs[i]);
+    for (int i = 0; i < NL; ++i) {
+        float st, ct;
+        sincosf(s.th[i], &st, &ct);
+        s.sn[i] = P.s0 * ct + P.c0 * st;
+        s.cs[i] = P.c0 * ct - P.s0 * st;
+    }
 }
 
 // One semi-implicit Euler substep.  eff[6] = held efforts (rail force, joint torques), cj[6] = per-DOF
@@ -107,22 +113,23 @@ __device__ __forceinline__ void dyn_sync_trig(Dyn& s) {
 //   row 0:  mtot*ydd - sum_i b_i cos(phi_i) thdd_i = F - cj0*vy - sum_i b_i sin(phi_i) w_i^2
 //   row i: -b_i cos(phi_i) ydd + sum_j a_ij cos(th_i-th_j) thdd_j
 //            = T_i - T_{i+1} - cad*I_i*w_i - sum_j a_ij sin(th_i-th_j) w_j^2 + g b_i sin(phi_i)
-template <bool IMPLICIT, bool CONTACT>
+template <bool IMPLICIT, bool CONTACT, bool EXTRAS>   // EXTRAS: joint stiffness / link angular damping switched on
 __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float (&eff)[ND], const float (&cj)[ND],
                                         const float (&hc)[ND], const float (&qa)[ND]) {
-    float sp[NL], cp[NL], w2[NL];
-    const float (&sn)[NL] = s.sn;
-    const float (&cs)[NL] = s.cs;
+    const float (&sp)[NL] = s.sn;   // sin(phi_i), cos(phi_i)
+    const float (&cp)[NL] = s.cs;
+    float w2[NL];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        sp[i] = P.s0 * cs[i] + P.c0 * sn[i];
-        cp[i] = P.c0 * cs[i] - P.s0 * sn[i];
-        w2[i] = s.w[i] * s.w[i];
-    }
+    for (int i = 0; i < NL; ++i) w2[i] = s.w[i] * s.w[i];
     float T[NL + 1];
-    T[0] = eff[1] - cj[1] * s.w[0] - P.kq * s.th[0];
+    T[0] = eff[1] - cj[1] * s.w[0];
 #pragma unroll
-    for (int i = 1; i < NL; ++i) T[i] = eff[i + 1] - cj[i + 1] * (s.w[i] - s.w[i - 1]) - P.kq * (s.th[i] - s.th[i - 1]);
+    for (int i = 1; i < NL; ++i) T[i] = eff[i + 1] - cj[i + 1] * (s.w[i] - s.w[i - 1]);
+    if (EXTRAS) {
+        T[0] -= P.kq * s.th[0];
+#pragma unroll
+        for (int i = 1; i < NL; ++i) T[i] -= P.kq * (s.th[i] - s.th[i - 1]);
+    }
     T[NL] = 0.0f;
 
     float A[ND][ND];  // lower triangle used
@@ -134,18 +141,19 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
     for (int i = 0; i < NL; ++i) {
         A[i + 1][0] = -P.b[i] * cp[i];
         r[0] -= P.b[i] * sp[i] * w2[i];
-        r[i + 1] = T[i] - T[i + 1] - P.cad * P.I[i] * s.w[i] + P.gb[i] * sp[i];
+        r[i + 1] = T[i] - T[i + 1] + P.gb[i] * sp[i];
+        if (EXTRAS) r[i + 1] -= P.cad * P.I[i] * s.w[i];
         if (CONTACT) r[i + 1] += qa[i + 1];
         A[i + 1][i + 1] = P.a[i][i];
     }
+    // a_ij = L*b_i for every j < i: fold it into row i's sin/cos once, then each pair costs 2+2+2 operations
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
+        const float Ci = P.a[i][0] * cp[i], Si = P.a[i][0] * sp[i];
 #pragma unroll
         for (int j = 0; j < i; ++j) {
-            float cd = cs[i] * cs[j] + sn[i] * sn[j];
-            float sd = sn[i] * cs[j] - cs[i] * sn[j];
-            float asd = P.a[i][j] * sd;
-            A[i + 1][j + 1] = P.a[i][j] * cd;
+            A[i + 1][j + 1] = Ci * cp[j] + Si * sp[j];            // a_ij cos(phi_i - phi_j)
+            const float asd = Si * cp[j] - Ci * sp[j];           // a_ij sin(phi_i - phi_j)
             r[i + 1] -= asd * w2[j];
             r[j + 1] += asd * w2[i];
         }
@@ -155,7 +163,8 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             float cn = (i < NL - 1) ? hc[i + 2] : 0.0f;
-            A[i + 1][i + 1] += hc[i + 1] + cn + P.hsub * P.cad * P.I[i];
+            A[i + 1][i + 1] += hc[i + 1] + cn;
+            if (EXTRAS) A[i + 1][i + 1] += P.hsub * P.cad * P.I[i];
             if (i < NL - 1) A[i + 2][i + 1] -= cn;
         }
     }
@@ -197,11 +206,11 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
         s.w[i] += P.hsub * r[i + 1];
         const float d = P.hsub * s.w[i];
         s.th[i] += d;
-        // rotate (sn, cs) by d: |d| = h*|w| < 0.06 rad even at 64 rad/s, so the degree-5/4 Taylor
-        // polynomials are exact to float rounding (next terms d^7/5040, d^6/720 < 1e-10)
+        // rotate (sn, cs) by d: |d| = h*|w| < 0.06 rad even at 64 rad/s, so the degree-3/4 Taylor polynomials
+        // are exact to float rounding (dropped terms d^5/120 < 7e-9, d^6/720 < 7e-11)
         const float d2 = d * d;
         const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
-        const float sd = d * fmaf(d2, fmaf(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
+        const float sd = d * fmaf(d2, -1.0f / 6.0f, 1.0f);
         const float s_old = s.sn[i], c_old = s.cs[i];
         s.sn[i] = fmaf(s_old, cd, c_old * sd);
         s.cs[i] = fmaf(c_old, cd, -(s_old * sd));
@@ -224,7 +233,7 @@ __device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s,
     float Fy[NL], Fz[NL], ny_[NL], nz_[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-        const float sp = P.s0 * s.cs[k] + P.c0 * s.sn[k], cp = P.c0 * s.cs[k] - P.s0 * s.sn[k];
+        const float sp = s.sn[k], cp = s.cs[k];              // sin/cos of the world link angle
         const float dy = -sp, dz = cp, ly = cp, lz = sp;     // link axis d, lateral l; n = d(d)/d(phi) = (-cp, -sp) = -l
         const float om = s.w[k];
         const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
@@ -304,7 +313,7 @@ __device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, f
     float Fy[NL], Fz[NL], ny_[NL], nz_[NL], mom_[NL];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-        const float sp = P.s0 * s.cs[k] + P.c0 * s.sn[k], cp = P.c0 * s.cs[k] - P.s0 * s.sn[k];
+        const float sp = s.sn[k], cp = s.cs[k];
         const float dy = -sp, dz = cp, ly = cp, lz = sp;
         const float om = s.w[k];
         const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
@@ -444,7 +453,7 @@ __device__ __forceinline__ void tip_fk_sc(const DevParams& P, float y, float vy,
     float ty = y, tz = P.z1, tvy = vy, tvz = 0.0f;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-        float sp = P.s0 * cs[k] + P.c0 * sn[k], cp = P.c0 * cs[k] - P.s0 * sn[k];
+        const float sp = sn[k], cp = cs[k];      // already sin/cos of the world angle
         ty -= P.L * sp; tz += P.L * cp;
         tvy -= P.L * w[k] * cp; tvz -= P.L * w[k] * sp;
     }
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
                 s.w[k] = b;
             }
         }
-        dyn_sync_trig(s);
+        dyn_sync_trig(P, s);
         // ---- control_freq_inv x [refresh, actuation (V5:1028-1106), simulate] (vec_task.py:338-356) ----
         for (int it = 0; it < P.cfi; ++it) {
             float sc[20];
@@ -592,27 +601,22 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             float qa[ND] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             float csum = 0.0f;
             if (SHELF) contact_sum += contact;            // vec_task.py:348-351: force left by the previous simulate
-            if (P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) {
-                for (int k = 0; k < P.substeps; ++k) {
-                    if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);
-                    if (PIPE && !SHELF) {
-#pragma unroll
-                        for (int i = 0; i < ND; ++i) qa[i] = 0.0f;
-                    }
-                    if (PIPE) pipe_contact(P, s, pipe_y, pipe_z, pipe_ct, pipe_st, qa);
-                    substep<true, CONTACT>(P, s, eff, cj, hc, qa);
-                }
-            } else {
-                for (int k = 0; k < P.substeps; ++k) {
-                    if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);
-                    if (PIPE && !SHELF) {
-#pragma unroll
-                        for (int i = 0; i < ND; ++i) qa[i] = 0.0f;
-                    }
-                    if (PIPE) pipe_contact(P, s, pipe_y, pipe_z, pipe_ct, pipe_st, qa);
-                    substep<false, CONTACT>(P, s, eff, cj, hc, qa);
-                }
-            }
+            const bool extras = (P.kq != 0.0f) || (P.cad != 0.0f);
+            const bool implicit = (P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) != 0;
+#define VINE_SUBSTEP_LOOP(IMPL, EXTR)                                                  \
+    for (int k = 0; k < P.substeps; ++k) {                                             \
+        if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);                  \
+        if (PIPE && !SHELF) {                                                          \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) qa[i] = 0.0f;               \
+        }                                                                              \
+        if (PIPE) pipe_contact(P, s, pipe_y, pipe_z, pipe_ct, pipe_st, qa);            \
+        substep<IMPL, CONTACT, EXTR>(P, s, eff, cj, hc, qa);                           \
+    }
+            if (implicit && !extras) { VINE_SUBSTEP_LOOP(true, false) }
+            else if (implicit) { VINE_SUBSTEP_LOOP(true, true) }
+            else if (!extras) { VINE_SUBSTEP_LOOP(false, false) }
+            else { VINE_SUBSTEP_LOOP(false, true) }
+#undef VINE_SUBSTEP_LOOP
             if (SHELF) contact = csum / (float)P.substeps;
             cart_y = s.y;
             cart_vy = s.vy;
