@@ -1064,12 +1064,14 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     for (int it = 0; it < c->control_freq_inv; ++it) {
         real scale[20];
         if (randomize) {                                             /* V5:1053-1055 */
-            for (int g = 0; g < 5; ++g) {
+            /* 20 factors per control iteration from 3 Philox calls: 16-bit uniforms (2 per 32-bit word) */
+            for (int g = 0; g < 3; ++g) {
                 uint32_t r[4];
-                rng4(c->seed, (uint32_t)e, step, RNG_DYN_SCALE, (uint32_t)(it * 5 + g), r);
-                for (int k = 0; k < 4; ++k)
-                    scale[g * 4 + k] = (real)c->dyn_scale_min +
-                                       ((real)c->dyn_scale_max - (real)c->dyn_scale_min) * (real)u01(r[k]);
+                rng4(c->seed, (uint32_t)e, step, RNG_DYN_SCALE, (uint32_t)(it * 3 + g), r);
+                for (int k = 0; k < 8 && g * 8 + k < 20; ++k) {
+                    float u = (float)((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) * (1.0f / 65536.0f);
+                    scale[g * 8 + k] = (real)c->dyn_scale_min + ((real)c->dyn_scale_max - (real)c->dyn_scale_min) * (real)u;
+                }
             }
         } else for (int k = 0; k < 20; ++k) scale[k] = 1;
         real eff[ND], cj[ND];

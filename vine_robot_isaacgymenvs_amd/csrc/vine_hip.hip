@@ -51,7 +51,7 @@ int hip_fail(hipError_t e, const char* what) {
 struct DevParams {
     int n, num_obs, obs_type, cfi, substeps, max_len, delay;
     unsigned flags, seed_lo, seed_hi;
-    float hsub, dt, cdt, clip_obs, clip_act;
+    float hsub, dt, cdt, inv_dt, inv_cdt, clip_obs, clip_act;
     float fpam_min, fpam_span, rail_scale, damping, kq, cad;
     float soft_limit, p_gain, d_gain, rail_acc, alpha_inf, alpha_def, success_dist;
     float cart_min, cart_span, ty_min, ty_span, tz_min, tz_span, depth_min, depth_span, ty_max, tz_fixed;
@@ -61,7 +61,8 @@ struct DevParams {
     float a[NL][NL];
     float K[NL], C[NL], bb[NL], B[NL];
     float rw[VINE_NUM_REWARDS];
-    float obs_scale[VINE_MAX_OBS];
+    float inv_obs_scale[VINE_MAX_OBS];   // reciprocals computed in double on the host: one v_mul instead of a
+                                        // ~10-instruction IEEE division per column (<= 1 ulp from the reference's `/`)
 };
 
 enum { RNG_RESET = 1, RNG_ACTION_NOISE = 2, RNG_DYN_SCALE = 3, RNG_OBS_NOISE = 4 };
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             a1 += P.act_noise * n1;
         }
         float new_rail = a0 * P.rail_scale;
-        float new_fpam = (a1 + 1.0f) / 2.0f * P.fpam_span + P.fpam_min;
+        float new_fpam = (a1 + 1.0f) * 0.5f * P.fpam_span + P.fpam_min;   // /2 == *0.5 exactly
         float u_rail = new_rail, u_fpam = new_fpam;
         if (P.delay > 0) {
             int slot = (int)(step % (unsigned long long)P.delay);
@@ -555,12 +556,18 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
         for (int it = 0; it < P.cfi; ++it) {
             float sc[20];
             if (RANDOMIZE && P.dyn_span != 0.0f) {
+                // 20 factors from 3 Philox calls: 16-bit uniforms, two per 32-bit word
 #pragma unroll
-                for (int g = 0; g < 5; ++g) {
+                for (int g = 0; g < 3; ++g) {
                     unsigned r[4];
-                    rng4(P, (unsigned)e, step, RNG_DYN_SCALE, (unsigned)(it * 5 + g), r);
+                    rng4(P, (unsigned)e, step, RNG_DYN_SCALE, (unsigned)(it * 3 + g), r);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) sc[g * 4 + k] = P.dyn_min + P.dyn_span * u01(r[k]);
+                    for (int k = 0; k < 8; ++k) {
+                        if (g * 8 + k < 20) {
+                            const float u = (float)((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) * (1.0f / 65536.0f);
+                            sc[g * 8 + k] = P.dyn_min + P.dyn_span * u;
+                        }
+                    }
                 }
             } else if (RANDOMIZE) {
 #pragma unroll
@@ -585,9 +592,9 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             }
             {
                 float err = u_rail - cart_vy;
-                float fmax = P.rail_acc / 2.0f;
+                float fmax = P.rail_acc * 0.5f;
                 float minmax = (err > 0.0f) ? fmax : -fmax;
-                float accel = (cart_vy - pcv) / P.dt;
+                float accel = (cart_vy - pcv) * P.inv_dt;
                 float accel_target = (err > 0.0f) ? P.rail_acc : -P.rail_acc;
                 minmax += 0.30f * (accel_target - accel);
                 float pid = P.p_gain * err + P.d_gain * (err - pce);
@@ -684,19 +691,19 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
 #pragma unroll
             for (int i = 0; i < ND; ++i) o[k++] = q[i];
 #pragma unroll
-            for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) / P.cdt;
+            for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) * P.inv_cdt;
         } else {
             o[k++] = q[0];
-            o[k++] = (q[0] - prev_q[0]) / P.cdt;
+            o[k++] = (q[0] - prev_q[0]) * P.inv_cdt;
         }
         o[k++] = 0.0f; o[k++] = tip[0]; o[k++] = tip[1];
-        o[k++] = 0.0f; o[k++] = (tip[0] - prev_tip_y) / P.cdt; o[k++] = (tip[1] - prev_tip_z) / P.cdt;
+        o[k++] = 0.0f; o[k++] = (tip[0] - prev_tip_y) * P.inv_cdt; o[k++] = (tip[1] - prev_tip_z) * P.inv_cdt;
         o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
         o[k++] = 0.0f; o[k++] = 0.0f; o[k++] = 0.0f;
         o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
         constexpr int NOBS = (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) ? 28 : 18;
 #pragma unroll
-        for (int i = 0; i < NOBS; ++i) o[i] = o[i] / P.obs_scale[i];
+        for (int i = 0; i < NOBS; ++i) o[i] = o[i] * P.inv_obs_scale[i];
         if (RANDOMIZE && P.obs_noise != 0.0f) {
 #pragma unroll
             for (int i = 0; i < NOBS; i += 4) {
@@ -853,6 +860,7 @@ void make_params(const VineConfig& c, DevParams& P) {
     P.substeps = c.substeps; P.max_len = c.max_episode_length; P.delay = c.action_delay; P.flags = c.flags;
     P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32);
     P.dt = c.dt; P.hsub = c.dt / (float)c.substeps; P.cdt = c.dt * (float)c.control_freq_inv;
+    P.inv_dt = (float)(1.0 / (double)P.dt); P.inv_cdt = (float)(1.0 / (double)P.cdt);
     P.clip_obs = c.clip_observations; P.clip_act = c.clip_actions;
     P.fpam_min = c.fpam_min; P.fpam_span = (float)((double)c.fpam_max - (double)c.fpam_min);
     P.rail_scale = c.rail_velocity_scale; P.damping = c.damping; P.kq = c.stiffness; P.cad = c.link_angular_damping;
@@ -885,7 +893,7 @@ void make_params(const VineConfig& c, DevParams& P) {
             if (i != j) P.a[i][j] = (float)(L * b[i > j ? i : j]);
     for (int i = 0; i < NL; ++i) { P.K[i] = c.fpam_K[i]; P.C[i] = c.fpam_C[i]; P.bb[i] = c.fpam_b[i]; P.B[i] = c.fpam_B[i]; }
     for (int i = 0; i < VINE_NUM_REWARDS; ++i) P.rw[i] = c.reward_weights[i];
-    for (int i = 0; i < VINE_MAX_OBS; ++i) P.obs_scale[i] = c.obs_scaling[i];
+    for (int i = 0; i < VINE_MAX_OBS; ++i) P.inv_obs_scale[i] = (float)(1.0 / (double)c.obs_scaling[i]);
 }
 
 }  // namespace
