@@ -114,9 +114,32 @@ __device__ __forceinline__ void dyn_sync_trig(const DevParams& P, Dyn& s) {
 //   row 0:  mtot*ydd - sum_i b_i cos(phi_i) thdd_i = F - cj0*vy - sum_i b_i sin(phi_i) w_i^2
 //   row i: -b_i cos(phi_i) ydd + sum_j a_ij cos(th_i-th_j) thdd_j
 //            = T_i - T_{i+1} - cad*I_i*w_i - sum_j a_ij sin(th_i-th_j) w_j^2 + g b_i sin(phi_i)
+// Constants of one `simulate` call (10 substeps): diagonal of the mass matrix with the implicit damping folded in,
+// the negated sub-diagonal damping terms, the pivot of the cart column and the pre-scaled cart-column coefficients.
+struct SimConst {
+    float adiag[NL];   // a_ii + hc[i+1] + hc[i+2] (+ h*cad*I_i)
+    float ncn[NL];     // -hc[i+1]: added to A[i+1][i] (coupling of neighbouring joints through the damping)
+    float a00, p0;     // mtot + hc[0], rsqrt of it
+    float bp[NL];      // -b_i * p0:  L_i0 = bp_i * cos(phi_i)
+};
+
+template <bool IMPLICIT, bool EXTRAS>
+__device__ __forceinline__ void make_sim_const(const DevParams& P, const float (&hc)[ND], SimConst& k) {
+    k.a00 = P.mtot + (IMPLICIT ? hc[0] : 0.0f);
+    k.p0 = __builtin_amdgcn_rsqf(k.a00);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const float cn = (IMPLICIT && i < NL - 1) ? hc[i + 2] : 0.0f;
+        k.adiag[i] = P.a[i][i] + (IMPLICIT ? hc[i + 1] + cn : 0.0f);
+        if (IMPLICIT && EXTRAS) k.adiag[i] += P.hsub * P.cad * P.I[i];
+        k.ncn[i] = IMPLICIT ? -hc[i + 1] : 0.0f;
+        k.bp[i] = -P.b[i] * k.p0;
+    }
+}
+
 template <bool IMPLICIT, bool CONTACT, bool EXTRAS>   // EXTRAS: joint stiffness / link angular damping switched on
 __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float (&eff)[ND], const float (&cj)[ND],
-                                        const float (&hc)[ND], const float (&qa)[ND]) {
+                                        const SimConst& K, const float (&qa)[ND]) {
     const float (&sp)[NL] = s.sn;   // sin(phi_i), cos(phi_i)
     const float (&cp)[NL] = s.cs;
     float w2[NL];
@@ -133,46 +156,39 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
     }
     T[NL] = 0.0f;
 
-    float A[ND][ND];  // lower triangle used
+    float A[ND][ND];  // lower triangle used; column 0 is written already factorised (L_i0)
     float r[ND];
-    A[0][0] = P.mtot;
     r[0] = eff[0] - cj[0] * s.vy;
     if (CONTACT) r[0] += qa[0];
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        A[i + 1][0] = -P.b[i] * cp[i];
+        A[i + 1][0] = K.bp[i] * cp[i];                           // L_i0 = A_i0 * p0 = (-b_i p0) cos(phi_i)
         r[0] -= P.b[i] * sp[i] * w2[i];
         r[i + 1] = T[i] - T[i + 1] + P.gb[i] * sp[i];
         if (EXTRAS) r[i + 1] -= P.cad * P.I[i] * s.w[i];
         if (CONTACT) r[i + 1] += qa[i + 1];
-        A[i + 1][i + 1] = P.a[i][i];
+        A[i + 1][i + 1] = K.adiag[i];
     }
-    // a_ij = L*b_i for every j < i: fold it into row i's sin/cos once, then each pair costs 2+2+2 operations
+    // a_ij = L*b_i for every j < i: fold it into row i's sin/cos once, then each pair costs 2+2+2 operations;
+    // the implicit-damping coupling -hc of neighbouring joints rides in as the accumulator's start value
 #pragma unroll
     for (int i = 1; i < NL; ++i) {
         const float Ci = P.a[i][0] * cp[i], Si = P.a[i][0] * sp[i];
 #pragma unroll
         for (int j = 0; j < i; ++j) {
-            A[i + 1][j + 1] = Ci * cp[j] + Si * sp[j];            // a_ij cos(phi_i - phi_j)
-            const float asd = Si * cp[j] - Ci * sp[j];           // a_ij sin(phi_i - phi_j)
+            const float base = (IMPLICIT && j == i - 1) ? K.ncn[i] : 0.0f;
+            A[i + 1][j + 1] = fmaf(Si, sp[j], fmaf(Ci, cp[j], base));   // a_ij cos(phi_i - phi_j) [- hc]
+            const float asd = Si * cp[j] - Ci * sp[j];                  // a_ij sin(phi_i - phi_j)
             r[i + 1] -= asd * w2[j];
             r[j + 1] += asd * w2[i];
         }
     }
-    if (IMPLICIT) {
-        A[0][0] += hc[0];
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            float cn = (i < NL - 1) ? hc[i + 2] : 0.0f;
-            A[i + 1][i + 1] += hc[i + 1] + cn;
-            if (EXTRAS) A[i + 1][i + 1] += P.hsub * P.cad * P.I[i];
-            if (i < NL - 1) A[i + 2][i + 1] -= cn;
-        }
-    }
-    // Cholesky A = L L^T in place (lower), then forward/back substitution; fully unrolled.
+    // Cholesky A = L L^T in place (lower), then forward/back substitution; fully unrolled.  Column 0 is known in
+    // closed form (constant pivot), so the factorisation starts at column 1.
     float inv[ND];
+    inv[0] = K.p0;
 #pragma unroll
-    for (int j = 0; j < ND; ++j) {
+    for (int j = 1; j < ND; ++j) {
         float d = A[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
@@ -611,13 +627,15 @@ __global__ __launch_bounds__(64) void vine_step_kernel(const DevParams P, float*
             const bool extras = (P.kq != 0.0f) || (P.cad != 0.0f);
             const bool implicit = (P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) != 0;
 #define VINE_SUBSTEP_LOOP(IMPL, EXTR)                                                  \
+    SimConst K;                                                                        \
+    make_sim_const<IMPL, EXTR>(P, hc, K);                                              \
     for (int k = 0; k < P.substeps; ++k) {                                             \
         if (SHELF) csum += shelf_contact(P, s, shelf_y, shelf_z, qa);                  \
         if (PIPE && !SHELF) {                                                          \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) qa[i] = 0.0f;               \
         }                                                                              \
         if (PIPE) pipe_contact(P, s, pipe_y, pipe_z, pipe_ct, pipe_st, qa);            \
-        substep<IMPL, CONTACT, EXTR>(P, s, eff, cj, hc, qa);                           \
+        substep<IMPL, CONTACT, EXTR>(P, s, eff, cj, K, qa);                            \
     }
             if (implicit && !extras) { VINE_SUBSTEP_LOOP(true, false) }
             else if (implicit) { VINE_SUBSTEP_LOOP(true, true) }
