@@ -554,10 +554,15 @@ class A2CAgent:
             self.bounds_loss_coef or 0.0)
         torch.autograd.backward([mu, value], [g_mu, g_val])     # the gradient block was left zeroed by the last Adam step
         self.model.a2c_network.sigma.grad.add_(g_ls)
+        kl = stats[4]
+        if self.multi_gpu and not self.use_grad_scaler:
+            self.optimizer.aux[0:1].copy_(stats[4:5])          # KL rides in the gradient all-reduce
+            self._kl_in_comm = True
+            kl = self.optimizer.aux[0]
         self.truncate_gradients_and_step()
         mu_d = mu.detach()
         sigma_d = torch.exp(logstd.detach()).expand_as(mu_d)
-        return stats[0], stats[1], stats[3], stats[4], stats[2], mu_d, sigma_d
+        return stats[0], stats[1], stats[3], kl, stats[2], mu_d, sigma_d
 
     def calc_gradients(self, mb):
         if self.is_cuda and not self.mixed_precision and self.use_fused:
@@ -583,7 +588,8 @@ class A2CAgent:
 
     def truncate_gradients_and_step(self):
         if self.multi_gpu:
-            dist.all_reduce(self.flat_grads, op=dist.ReduceOp.SUM)     # RCCL over xGMI, in place, 1.63 MB
+            buf = self.optimizer.comm_buffer if not self.use_grad_scaler else self.flat_grads
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)                 # RCCL over xGMI, in place, 1.63 MB
         if not self.use_grad_scaler:
             if self.truncate_grads:
                 if self.multi_gpu:
@@ -603,9 +609,10 @@ class A2CAgent:
 
     def update_lr_from_kl(self, kl):
         """AdaptiveScheduler of rl_games on a device scalar (common_agent.py:217-221 shows the call site)."""
-        if self.multi_gpu:
+        if self.multi_gpu and not getattr(self, "_kl_in_comm", False):
             kl = kl.clone()
             dist.all_reduce(kl, op=dist.ReduceOp.SUM)
+        self._kl_in_comm = False
         if self.is_cuda:
             rc = fused._lib().vine_adaptive_lr(self.lr.data_ptr(), kl.contiguous().data_ptr(), 1.0 / self.rank_size,
                                                self.kl_threshold, self.min_lr, self.max_lr,

@@ -72,8 +72,17 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     # kernel duration inside the timed region when it was launched eagerly; otherwise (launches live inside the
     # replayed hipGraph, where no event can be recorded) the same kernel timed back-to-back just above
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events) if events else env_only_kernel_ms
+    in_sync = None
+    if world > 1:       # replicas must hold identical weights and learning rate after all-reduced updates
+        import torch.distributed as dist
+        chk = torch.stack([torch.cat([p.detach().flatten() for p in agent.model.parameters()]).double().sum(),
+                           agent.lr.double()])
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        in_sync = all(bool(torch.equal(g, gathered[0])) for g in gathered)
     frames = agent.horizon_length * agent.num_actors
     extra = {
+        "replicas_in_sync": in_sync,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
                      "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},
         "ppo_iters_per_sec": steps / elapsed,

@@ -25,7 +25,11 @@ class FlatAdam:
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
         self.flat_params = torch.zeros(self.numel, device=dev, dtype=torch.float32)
-        self.flat_grads = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        # the gradient block carries ALIGN extra floats (`aux`) that ride along in the multi-GPU all-reduce: the
+        # agent puts the minibatch KL there, so gradient and KL averaging cost ONE collective per optimiser step
+        self.comm_buffer = torch.zeros(self.numel + ALIGN, device=dev, dtype=torch.float32)
+        self.flat_grads = self.comm_buffer[:self.numel]
+        self.aux = self.comm_buffer[self.numel:]
         for p, off in zip(self.params, self.offsets):
             n = p.numel()
             self.flat_params[off:off + n].copy_(p.data.reshape(-1))
