@@ -88,31 +88,61 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(args, seconds):
-    """CPU restatement of the reference path (oracle/, float32, OpenMP over envs) on a bounded sample."""
+def cpu_baseline(args, seconds, mode, cfg):
+    """CPU restatement of the reference path on this host's usable cores, on a bounded sample of the same workload.
+    The reference's own sim_device=cpu path needs Isaac Gym/PhysX and cannot run anywhere here (kind = "port"):
+      * env step: oracle/ (float32, OpenMP over envs) through the same step API;
+      * mode=ppo: ONE full PPO iteration (same horizon / minibatch / mini-epoch configuration) with that env and the
+        stock PyTorch-CPU agent -- the same unit as `value` (whole-job env-steps/s)."""
+    import copy
+
     import numpy as np
+    import torch
     from oracle import vine_oracle as vo
     from vine_robot_isaacgymenvs_amd import abi
     lib = vo.load("f32", omp=True)
     cores = lib.vine_oracle_set_threads(usable_cores())
-    cfg = vo.default_config(lib, num_envs=args.num_envs)
-    lib.vine_config_set_obs_type(cfg, abi.OBS_TYPE_BY_NAME[args.obs_type], 1)
-    cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, bool(args.randomize))
-    env = vo.OracleEnv(cfg, "f32", omp=True)
+    ocfg = vo.default_config(lib, num_envs=args.num_envs)
+    lib.vine_config_set_obs_type(ocfg, abi.OBS_TYPE_BY_NAME[args.obs_type], 1)
+    ocfg.set_flag(abi.FLAG_VINE_RANDOMIZE, bool(args.randomize))
+    env = vo.OracleEnv(ocfg, "f32", omp=True)
     rng = np.random.default_rng(42)
     acts = rng.uniform(-1, 1, (4, args.num_envs, 2)).astype(np.float32)
     env.step(acts[0])
+    env_seconds = seconds if mode == "env" else min(3.0, seconds)
     t0 = time.perf_counter()
     n = 0
     while True:
         env.step(acts[n % 4])
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 1000:
+        if dt >= env_seconds or n >= 1000:
             break
-    return {"value": args.num_envs * n / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d VecTask.step calls x %d envs (env step only, random actions), oracle/ float32 + OpenMP, %.1f s"
-                      % (n, args.num_envs, dt)}
+    env_only = args.num_envs * n / dt
+    out = {"value": env_only, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+           "sample": "%d VecTask.step calls x %d envs (env step only, random actions), oracle/ float32 + OpenMP, %.1f s"
+                     % (n, args.num_envs, dt)}
+    if mode == "ppo":
+        from oracle.oracle_vec_task import OracleVecTask
+        from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+        torch.set_num_threads(int(cores))
+        ccfg = copy.deepcopy(cfg)
+        venv = OracleVecTask(ccfg["task"], precision="f32", omp=True)
+        params = ccfg["train"]["params"]
+        params["config"].update(device="cpu", multi_gpu=False, write_files=False, print_stats=False, use_graphs=False)
+        agent = A2CAgent("cpu_baseline", params, vec_env=venv)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        t0 = time.perf_counter()
+        play, upd, _ = agent.train_epoch()
+        dt = time.perf_counter() - t0
+        frames = agent.horizon_length * agent.num_actors
+        out = {"value": frames / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
+               "sample": "1 PPO iteration (%d envs x %d steps rollout with policy inference + %d optimiser steps), oracle/ "
+                         "float32 + OpenMP env, PyTorch-CPU agent, %.1f s (rollout %.1f s, update %.1f s)"
+                         % (args.num_envs, agent.horizon_length, agent.mini_epochs_num * agent.num_minibatches, dt, play, upd),
+               "ppo_iters_per_sec": 1.0 / dt, "env_only_env_steps_per_sec": env_only}
+    return out
 
 
 def main():
@@ -201,7 +231,7 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds, mode, cfg)
         print(json.dumps(out))
     env.close()
     if world > 1:

@@ -15,11 +15,11 @@ from vine_robot_isaacgymenvs_amd.tasks.vine5link_moving_base import num_observat
 
 
 class OracleVecTask:
-    def __init__(self, cfg, precision="f32", seed=42):
-        lib = vo.load(precision)
+    def __init__(self, cfg, precision="f32", seed=42, omp=False):
+        lib = vo.load(precision, omp)
         self.cfg = cfg
         self.vcfg = vine_config_from_cfg(cfg, lib, seed=seed)
-        self.env = vo.OracleEnv(self.vcfg, precision)
+        self.env = vo.OracleEnv(self.vcfg, precision, omp)
         self.num_envs = self.vcfg.num_envs
         self.num_obs = num_observations(ObservationType[cfg["env"]["OBSERVATION_TYPE"]])
         self.num_acts, self.num_states, self.num_agents = 2, 0, 1
