@@ -474,7 +474,8 @@ class A2CAgent:
             torch.cuda.synchronize(self.device)
             self._rollout_graph = torch.cuda.CUDAGraph()
             self._load_live(self._g_in)
-            with torch.cuda.graph(self._rollout_graph):
+            # thread_local: RCCL's watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(self._rollout_graph, capture_error_mode="thread_local"):
                 self._load_live(self._g_in)
                 body()
                 self._g_out = [self.obs, self.dones, self.rnn_states, self.current_rewards, self.current_lengths,
