@@ -423,7 +423,16 @@ class A2CAgent:
     def play_steps_rnn(self):
         body = self._rollout_body_fused if self._can_fuse_rollout() else self._rollout_body
         if self.use_graphs:
-            self._play_graphed(body)
+            try:
+                self._play_graphed(body)
+            except RuntimeError as err:          # capture refused (driver/runtime state): run eagerly from now on
+                if self._rollout_graph is not None and getattr(self, "_graph_replayed", False):
+                    raise
+                print("hipGraph capture of the rollout failed (%s); continuing with eager launches" % str(err)[:200])
+                self.use_graphs = False
+                self._rollout_graph = None
+                torch.cuda.synchronize(self.device)
+                body()
         else:
             body()
         buf = self.buf
@@ -482,6 +491,7 @@ class A2CAgent:
                                self.game_rewards.mean, self.game_rewards.current_size, self.game_lengths.mean,
                                self.game_lengths.current_size]
         self._rollout_graph.replay()
+        self._graph_replayed = True
         # carry the outputs over to the static inputs of the next replay
         o = self._g_out
         pairs = [(self._g_in[0], o[0]), (self._g_in[1], o[1])] + list(zip(self._g_in[2], o[2]))
