@@ -432,6 +432,8 @@ class A2CAgent:
                 self.use_graphs = False
                 self._rollout_graph = None
                 torch.cuda.synchronize(self.device)
+                if getattr(self, "_g_in", None) is not None:
+                    self._load_live(self._g_in)      # the state the capture started from (restored after warm-up)
                 body()
         else:
             body()
