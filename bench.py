@@ -39,6 +39,7 @@ def parse_args():
     p.add_argument("--obs-type", default="POS_AND_FD_VEL_AND_OBJ_INFO")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-saturated", action="store_true", help="skip the 2^20-env run of the step kernel")
     p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
     p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
                    help="ppo mode: autocast dtype of the update (default: the train YAML: mixed_precision fp16)")
@@ -74,6 +75,49 @@ def pmc_traffic():
         return (d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
     except (KeyError, ValueError):
         return None
+
+
+def pmc_valu_per_wave():
+    """VALU instructions one wave issues per env step (SQ_INSTS_VALU / SQ_WAVES of the committed PMC pass)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")))
+    try:
+        d = json.load(open(files[-1]))
+        return d["SQ_INSTS_VALU"]["mean_per_launch"] / d["SQ_WAVES"]["mean_per_launch"]
+    except (IndexError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+def saturated_env_rate(args, device_index, n_sat=1 << 20, steps=40):
+    """The same kernel with enough envs to give every SIMD several waves (16384 envs are 256 waves for 1024 SIMDs):
+    the throughput the kernel itself sustains, priced against HBM and against the fp32 VALU issue rate
+    (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)."""
+    import copy
+    import torch
+    a = copy.copy(args)
+    a.num_envs = n_sat
+    env, _ = make_env(a, 0, device_index)
+    act = torch.rand((n_sat, 2), device=env.device) * 2 - 1
+    for _ in range(5):
+        env._native_step(act, env.obs_buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        env._native_step(act, env.obs_buf)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    rate = n_sat / (ms * 1e-3)
+    gbs = rate * ALGO_BYTES_PER_ENV_STEP[env.num_obs] / 1e9
+    out = {"num_envs": n_sat, "kernel_ms": ms, "env_steps_per_sec": rate, "achieved_GBs": gbs,
+           "hbm_frac": gbs / HBM_PEAK_GBS}
+    per_wave = pmc_valu_per_wave()
+    if per_wave:
+        peak = 1024 * 2.4e9 / 4.0
+        out.update({"valu_insts_per_wave_step": per_wave, "valu_wave_insts_per_sec": rate / 64.0 * per_wave,
+                    "valu_issue_peak": peak, "valu_issue_frac": rate / 64.0 * per_wave / peak})
+    env.close()
+    return out
 
 
 def usable_cores():
@@ -230,6 +274,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
         }
         out.update(extra)
+        if world == 1 and not args.no_saturated:
+            out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds, mode, cfg)
         print(json.dumps(out))

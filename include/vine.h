@@ -49,11 +49,17 @@ typedef enum VineStatus {
     VINE_ERR_ALLOC = -5
 } VineStatus;
 
-/* ObservationType, V5:67-73.  Only the two types the reference can scale
- * (V5:245-268) are supported; the others raise NotImplementedError there too. */
+/* ObservationType, V5:67-73.  The reference can scale only the first two
+ * (V5:245-268); the other four work with SCALE_OBSERVATIONS=False and raise
+ * NotImplementedError otherwise (V5:267-268): vine_config_set_obs_type returns
+ * VINE_ERR_UNSUPPORTED for the same combinations. */
 typedef enum VineObsType {
     VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO = 0,   /* 28 columns, V5:1369-1373 */
-    VINE_OBS_TIP_AND_CART_AND_OBJ_INFO = 1      /* 18 columns, V5:1374-1378 */
+    VINE_OBS_TIP_AND_CART_AND_OBJ_INFO = 1,     /* 18 columns, V5:1374-1378 */
+    VINE_OBS_POS_ONLY = 2,                      /* 14 columns, V5:1354-1356 */
+    VINE_OBS_POS_AND_VEL = 3,                   /* 26 columns, simulator velocities, V5:1357-1360 */
+    VINE_OBS_POS_AND_FD_VEL = 4,                /* 26 columns, finite-difference velocities, V5:1361-1364 */
+    VINE_OBS_POS_AND_PREV_POS = 5               /* 26 columns, previous positions, V5:1365-1368 */
 } VineObsType;
 
 /* Boolean switches (TY keys unless stated). */

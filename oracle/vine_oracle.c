@@ -160,8 +160,11 @@ int vine_config_set_obs_type(VineConfig* c, int obs_type, int scale_observations
                                   0.732f, 2.0f, 0.732f, 0.845f, 0.86f, 0.0385f, 0.5f}; /* V5:246-255 */
     static const float s18[18] = {0.12f, 0.67f, 0.0656f, 0.238f, 0.0656f, 0.732f, 2.0f, 0.732f, 0.02f, 0.0235f, 0.02f,
                                   0.732f, 2.0f, 0.732f, 0.845f, 0.86f, 0.0385f, 0.5f}; /* V5:257-266 */
-    if (obs_type != VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO && obs_type != VINE_OBS_TIP_AND_CART_AND_OBJ_INFO)
-        return fail(VINE_ERR_UNSUPPORTED, "observation type not supported (V5:268)");
+    if (obs_type < VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || obs_type > VINE_OBS_POS_AND_PREV_POS)
+        return fail(VINE_ERR_INVALID_ARG, "unknown observation type (V5:1380)");
+    const int scalable = obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO;
+    if (scale_observations && !scalable)
+        return fail(VINE_ERR_UNSUPPORTED, "observation scaling not implemented for this observation type (V5:267-268)");
     c->obs_type = obs_type;
     for (int i = 0; i < VINE_MAX_OBS; ++i) c->obs_scaling[i] = 1.0f;                     /* V5:241 */
     if (scale_observations) {
@@ -176,7 +179,9 @@ int vine_num_obs(const VineConfig* c) {
     if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
     if (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) return 28; /* V5:164-170 */
     if (c->obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO) return 18;   /* V5:157-162 */
-    return fail(VINE_ERR_UNSUPPORTED, "observation type not supported (V5:268)");
+    if (c->obs_type == VINE_OBS_POS_ONLY) return 14;                    /* V5:153-155 */
+    if (c->obs_type >= VINE_OBS_POS_AND_VEL && c->obs_type <= VINE_OBS_POS_AND_PREV_POS) return 26; /* V5:164-167 */
+    return fail(VINE_ERR_INVALID_ARG, "unknown observation type (V5:1380)");
 }
 
 /* ------------------------------------------------------------------------- */
@@ -757,12 +762,34 @@ static void actuation(const VineConfig* c, const real* q, const real* qd, real c
     *prev_cart_vel = cart_vy;                                      /* V5:1098 */
 }
 /* compute_observations, V5:1339-1385 (before noise and before the VT:374 clamp). Returns the column count. */
-static int observations(const VineConfig* c, const real* q, const real* prev_q, const real* tip, real prev_tip_y,
-                        real prev_tip_z, real ty, real tz, real smoothed, real prev_u_rail, real obj_depth,
-                        real obj_angle, real* o) {
+/* tip = (y, z, vy, vz) of the tip body; qd = simulator joint velocities (used by POS_AND_VEL only). */
+static int observations(const VineConfig* c, const real* q, const real* qd, const real* prev_q, const real* tip,
+                        real prev_tip_y, real prev_tip_z, real ty, real tz, real smoothed, real prev_u_rail,
+                        real obj_depth, real obj_angle, real* o) {
     const real cdt = (real)c->dt * (real)c->control_freq_inv;        /* V5:228 */
     int k = 0;
     real fd_tip_y = (tip[0] - prev_tip_y) / cdt, fd_tip_z = (tip[1] - prev_tip_z) / cdt; /* V5:1348 */
+    if (c->obs_type == VINE_OBS_POS_ONLY) {                          /* V5:1354-1356 */
+        for (int i = 0; i < ND; ++i) o[k++] = q[i];
+        o[k++] = 0; o[k++] = tip[0]; o[k++] = tip[1];
+        o[k++] = 0; o[k++] = ty; o[k++] = tz;
+        o[k++] = smoothed; o[k++] = prev_u_rail;
+        return k;                                                    /* obs_scaling is ones (V5:241, 267-268) */
+    }
+    if (c->obs_type >= VINE_OBS_POS_AND_VEL && c->obs_type <= VINE_OBS_POS_AND_PREV_POS) { /* V5:1357-1368 */
+        const int t = c->obs_type;
+        for (int i = 0; i < ND; ++i) o[k++] = q[i];
+        for (int i = 0; i < ND; ++i)
+            o[k++] = (t == VINE_OBS_POS_AND_VEL) ? qd[i] : (t == VINE_OBS_POS_AND_FD_VEL) ? (q[i] - prev_q[i]) / cdt : prev_q[i];
+        o[k++] = 0; o[k++] = tip[0]; o[k++] = tip[1];
+        o[k++] = 0;
+        o[k++] = (t == VINE_OBS_POS_AND_VEL) ? tip[2] : (t == VINE_OBS_POS_AND_FD_VEL) ? fd_tip_y : prev_tip_y;
+        o[k++] = (t == VINE_OBS_POS_AND_VEL) ? tip[3] : (t == VINE_OBS_POS_AND_FD_VEL) ? fd_tip_z : prev_tip_z;
+        o[k++] = 0; o[k++] = ty; o[k++] = tz;
+        o[k++] = 0; o[k++] = 0; o[k++] = 0;                          /* target_velocities == 0, V5:916-918 */
+        o[k++] = smoothed; o[k++] = prev_u_rail;
+        return k;
+    }
     if (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
         for (int i = 0; i < ND; ++i) o[k++] = q[i];
         for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) / cdt;                  /* V5:1347 */
@@ -778,12 +805,24 @@ static int observations(const VineConfig* c, const real* q, const real* prev_q, 
     for (int i = 0; i < k; ++i) o[i] = o[i] / (real)c->obs_scaling[i];                   /* V5:1385 */
     return k;
 }
+int vine_oracle_observations_ex(const VineConfig* c, const double* q, const double* qd, const double* prev_q,
+                                const double* tip_yz, const double* tip_vel_yz, const double* prev_tip_yz,
+                                const double* target_yz, double smoothed, double prev_u_rail, const double* obj_info,
+                                double* obs) {
+    real rq[ND], rv[ND], rp[ND], o[VINE_MAX_OBS];
+    real t[4] = {(real)tip_yz[0], (real)tip_yz[1], tip_vel_yz ? (real)tip_vel_yz[0] : 0, tip_vel_yz ? (real)tip_vel_yz[1] : 0};
+    for (int i = 0; i < ND; ++i) { rq[i] = (real)q[i]; rp[i] = (real)prev_q[i]; rv[i] = qd ? (real)qd[i] : 0; }
+    int k = observations(c, rq, rv, rp, t, (real)prev_tip_yz[0], (real)prev_tip_yz[1], (real)target_yz[0],
+                         (real)target_yz[1], (real)smoothed, (real)prev_u_rail, (real)obj_info[0], (real)obj_info[1], o);
+    for (int i = 0; i < k; ++i) obs[i] = o[i];
+    return k;
+}
 int vine_oracle_observations(const VineConfig* c, const double* q, const double* prev_q, const double* tip_yz,
                              const double* prev_tip_yz, const double* target_yz, double smoothed, double prev_u_rail,
                              const double* obj_info, double* obs) {
     real rq[ND], rp[ND], t[4] = {(real)tip_yz[0], (real)tip_yz[1], 0, 0}, o[VINE_MAX_OBS];
     for (int i = 0; i < ND; ++i) { rq[i] = (real)q[i]; rp[i] = (real)prev_q[i]; }
-    int k = observations(c, rq, rp, t, (real)prev_tip_yz[0], (real)prev_tip_yz[1], (real)target_yz[0], (real)target_yz[1],
+    int k = observations(c, rq, rq, rp, t, (real)prev_tip_yz[0], (real)prev_tip_yz[1], (real)target_yz[0], (real)target_yz[1],
                          (real)smoothed, (real)prev_u_rail, (real)obj_info[0], (real)obj_info[1], o);
     for (int i = 0; i < k; ++i) obs[i] = o[i];
     return k;
@@ -1116,7 +1155,8 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     real obj_depth = ST(h, VF_OBJ_DEPTH, e), obj_angle = ST(h, VF_OBJ_ANGLE, e);
     /* compute_observations (V5:1339-1390) */
     real o[VINE_MAX_OBS];
-    int k = observations(c, q, prev_q, tip, prev_tip_y, prev_tip_z, ty, tz, smoothed, prev_u_rail, obj_depth, obj_angle, o);
+    int k = observations(c, q, qd, prev_q, tip, prev_tip_y, prev_tip_z, ty, tz, smoothed, prev_u_rail, obj_depth,
+                         obj_angle, o);
     if (randomize) {                                                 /* V5:1388-1390 */
         for (int i = 0; i < k; i += 4) {
             uint32_t r[4]; float nn[4];

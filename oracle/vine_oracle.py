@@ -54,6 +54,8 @@ def load(precision="f64", omp=False):
     lib.vine_oracle_actuation.argtypes = [P, _D, _D, C.c_double, C.c_double, C.c_double, _D, _D, _D, _D]
     lib.vine_oracle_observations.argtypes = [P, _D, _D, _D, _D, _D, C.c_double, C.c_double, _D, _D]
     lib.vine_oracle_observations.restype = C.c_int
+    lib.vine_oracle_observations_ex.argtypes = [P, _D, _D, _D, _D, _D, _D, _D, C.c_double, C.c_double, _D, _D]
+    lib.vine_oracle_observations_ex.restype = C.c_int
     lib.vine_oracle_reward.argtypes = ([P] + [C.c_double, C.c_int] + [C.c_double] * 6 +
                                        [C.c_int, C.c_int, C.c_double, C.c_double, _D])
     lib.vine_oracle_reward.restype = C.c_double

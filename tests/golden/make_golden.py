@@ -435,13 +435,18 @@ def f1_actions_and_actuation(vt, v5, out):
 def f2_observations(vt, v5, out):
     N = 64
     g = torch.Generator().manual_seed(99)
-    for obs_type in ("POS_AND_FD_VEL_AND_OBJ_INFO", "TIP_AND_CART_AND_OBJ_INFO"):
-        cfg = reference_task_cfg(N, OBSERVATION_TYPE=obs_type)
+    unscaled = ("POS_ONLY", "POS_AND_VEL", "POS_AND_FD_VEL", "POS_AND_PREV_POS")   # V5:267-268: no scaling constants
+    for obs_type in ("POS_AND_FD_VEL_AND_OBJ_INFO", "TIP_AND_CART_AND_OBJ_INFO") + unscaled:
+        cfg = reference_task_cfg(N, OBSERVATION_TYPE=obs_type, SCALE_OBSERVATIONS=obs_type not in unscaled)
         task, gym, _ = make_task(vt, v5, cfg)
         ds = gym.dof_state.view(N, 6, 2)
         ds[:, :, 0] = torch.rand(N, 6, generator=g) - 0.5
         rb = gym.rb_state.view(N, gym.nb, 13)
         rb[:, VINE_BODY["tip"], 1:3] = torch.rand(N, 2, generator=g) - 0.5
+        if obs_type in unscaled:
+            ds[:, :, 1] = (torch.rand(N, 6, generator=g) - 0.5) * 4
+            rb[:, VINE_BODY["tip"], 8:10] = (torch.rand(N, 2, generator=g) - 0.5) * 3
+            rb[:8, VINE_BODY["tip"], 2] = 7.0      # unscaled columns need a larger value to reach the clamp
         rb[:8, VINE_BODY["tip"], 1] = 2.0          # forces the +-5 clamp after scaling
         task.prev_dof_pos = ds[:, :, 0] - (torch.rand(N, 6, generator=g) - 0.5) * 0.1
         task.prev_tip_positions = task.tip_positions - (torch.rand(N, 3, generator=g) - 0.5) * 0.05
@@ -454,7 +459,8 @@ def f2_observations(vt, v5, out):
         task.object_info[:, 1] = 0
         obs = task.compute_observations()
         out["f2_obs_" + obs_type] = dict(
-            q=npf(ds[:, :, 0]), prev_q=npf(task.prev_dof_pos), tip=npf(task.tip_positions),
+            q=npf(ds[:, :, 0]), qd=npf(ds[:, :, 1]), tip_vel=npf(task.tip_velocities),
+            prev_q=npf(task.prev_dof_pos), tip=npf(task.tip_positions),
             prev_tip=npf(task.prev_tip_positions), target=npf(task.target_positions),
             smoothed=npf(task.smoothed_u_fpam), prev_u_rail=npf(task.prev_u_rail_velocity),
             obj_info=npf(task.object_info), obs=npf(obs), obs_clamped=npf(torch.clamp(obs, -task.clip_obs, task.clip_obs)),

@@ -10,7 +10,9 @@ from vine_robot_isaacgymenvs_amd import abi
 def base_cfg(num_envs, obs_type=abi.OBS_POS_AND_FD_VEL_AND_OBJ_INFO, randomize=False, **over):
     """TY defaults (reference task YAML) with vine_randomize off unless asked."""
     cfg = vo.default_config(num_envs=num_envs)
-    vo.load().vine_config_set_obs_type(C.byref(cfg), obs_type, 1)
+    # the four non-scalable observation types only exist unscaled (V5:267-268)
+    rc = vo.load().vine_config_set_obs_type(C.byref(cfg), obs_type, int(obs_type in abi.SCALABLE_OBS_TYPES))
+    assert rc == 0, rc
     cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, randomize)
     for k, v in over.items():
         setattr(cfg, k, v)

@@ -53,7 +53,7 @@ def test_struct_layout_and_defaults_match_oracle(hip_lib):
             assert vo.load("f64").vine_config_set_obs_type(C.byref(b), obs_type, scale) == 0
             assert bytes(a) == bytes(b)
             assert hip_lib.vine_num_obs(C.byref(a)) == (28 if obs_type == 0 else 18)
-    assert hip_lib.vine_config_set_obs_type(C.byref(a), 7, 1) == abi.ERR_UNSUPPORTED
+    assert hip_lib.vine_config_set_obs_type(C.byref(a), 7, 1) == abi.ERR_INVALID_ARG
 
 
 def test_field_enum_matches_header():
@@ -78,6 +78,32 @@ def test_invalid_configs_are_rejected(hip_lib):
     c.abi_version = 99
     assert hip_lib.vine_create(C.byref(c), 0, None, C.byref(h)) == abi.ERR_INVALID_ARG
     assert b"abi_version" in hip_lib.vine_last_error()
+
+
+def test_observation_types_and_scaling_rules(hip_lib):
+    """All six ObservationType members (V5:67-73) with their column counts (V5:152-170); scaling exists only for
+    the two *_OBJ_INFO layouts (V5:267-268) -- product library, oracle and the Python front end agree."""
+    from oracle import vine_oracle as vo
+    from vine_robot_isaacgymenvs_amd.tasks.vine5link_moving_base import (ObservationType, num_observations,
+                                                                         vine_config_from_cfg)
+    from vine_robot_isaacgymenvs_amd.utils.config import load_task_config
+    for lib in (hip_lib, vo.load("f64")):
+        for t in ObservationType:
+            code = abi.OBS_TYPE_BY_NAME[t.value]
+            c = abi.VineConfig()
+            lib.vine_config_default(C.byref(c))
+            assert lib.vine_config_set_obs_type(C.byref(c), code, 0) == 0
+            assert lib.vine_num_obs(C.byref(c)) == num_observations(t)
+            assert all(c.obs_scaling[i] == 1.0 for i in range(abi.MAX_OBS))
+            rc = lib.vine_config_set_obs_type(C.byref(c), code, 1)
+            assert rc == (0 if code in abi.SCALABLE_OBS_TYPES else abi.ERR_UNSUPPORTED)
+        assert lib.vine_config_set_obs_type(C.byref(c), 6, 0) == abi.ERR_INVALID_ARG
+    cfg = load_task_config(overrides=["OBSERVATION_TYPE=POS_AND_VEL"])
+    with pytest.raises(NotImplementedError, match="Observation scaling not implemented"):
+        vine_config_from_cfg(cfg, hip_lib)
+    cfg["env"]["SCALE_OBSERVATIONS"] = False
+    c = vine_config_from_cfg(cfg, hip_lib)
+    assert c.obs_type == abi.OBS_POS_AND_VEL and hip_lib.vine_num_obs(C.byref(c)) == 26
 
 
 def test_product_fails_loudly_without_gpu(hip_lib):

@@ -7,6 +7,8 @@ single-step float outputs vs the float32 oracle (same formulation) 2e-5 abs on p
 (the 6x6 mass matrix of a chain of 5 g links carrying a 100 g link has condition number ~1e3-1e4, so float32
 accelerations carry ~1e-4 relative error whatever the instruction order); vs the float64 oracle 1e-4 / 1e-2.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -92,6 +94,37 @@ def test_single_step_matches_oracle(HipEnv, obs_type, randomize, delay):
         assert hip.step_count == 8
         assert orc.reset_buf.sum() > 0 and orc.timeouts.sum() > 0
         hip.close(); orc.close()
+
+
+@pytest.mark.parametrize("obs_type", [abi.OBS_POS_ONLY, abi.OBS_POS_AND_VEL, abi.OBS_POS_AND_FD_VEL,
+                                      abi.OBS_POS_AND_PREV_POS])
+def test_unscaled_observation_types_match_oracle(HipEnv, obs_type):
+    """The four observation layouts the reference only runs with SCALE_OBSERVATIONS=False (V5:1354-1368)."""
+    n = 1000
+    cfg = base_cfg(n, obs_type, True, action_delay=1, seed=77 + obs_type)
+    cfg.obs_noise_std, cfg.action_noise_std = 0.01, 0.02
+    rng = np.random.default_rng(100 + obs_type)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    assert hip.num_obs == orc.num_obs == {abi.OBS_POS_ONLY: 14}.get(obs_type, 26)
+    seed_both(hip, orc, rng, n, cfg)
+    hip.step_count = 3
+    orc.step_count = 3
+    for _ in range(3):
+        actions = rng.uniform(-1.3, 1.3, (n, 2))
+        out = hip.step(actions)
+        orc.step(actions)
+        compare_step(out, orc, hip, 1e-4, 1e-2, 1e-2)
+    assert np.abs(out[0]).max() <= cfg.clip_observations
+    with pytest.raises(RuntimeError):        # scaling these types is NotImplemented in the reference too
+        c2 = base_cfg(8)
+        native_check_set_obs_type(c2, obs_type, 1)
+    hip.close(); orc.close()
+
+
+def native_check_set_obs_type(cfg, obs_type, scale):
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    native.check(lib.vine_config_set_obs_type(C.byref(cfg), obs_type, scale), lib)
 
 
 def test_shelf_contacts_match_oracle(HipEnv):

@@ -60,21 +60,28 @@ def test_f1_actuation(golden, precision, randomize):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("name,obs_type", [("POS_AND_FD_VEL_AND_OBJ_INFO", 0), ("TIP_AND_CART_AND_OBJ_INFO", 1)])
+@pytest.mark.parametrize("name,obs_type", [("POS_AND_FD_VEL_AND_OBJ_INFO", 0), ("TIP_AND_CART_AND_OBJ_INFO", 1),
+                                           ("POS_ONLY", 2), ("POS_AND_VEL", 3), ("POS_AND_FD_VEL", 4),
+                                           ("POS_AND_PREV_POS", 5)])
 def test_f2_observations(golden, precision, name, obs_type):
-    """compute_observations (V5:1339-1385) for both scalable observation types."""
+    """compute_observations (V5:1339-1385): the two scalable observation types with the reference's scaling
+    constants, the other four unscaled (the only way the reference runs them, V5:267-268)."""
     g = golden("f2_obs_" + name)
     lib = vo.load(precision)
     N, nobs = g["obs"].shape
-    cfg = base_cfg(N, obs_type)
+    cfg = base_cfg(N)
+    if obs_type >= 2:
+        assert lib.vine_config_set_obs_type(C.byref(cfg), obs_type, 1) == abi.ERR_UNSUPPORTED
+    assert lib.vine_config_set_obs_type(C.byref(cfg), obs_type, int(obs_type < 2)) == 0
     assert lib.vine_num_obs(C.byref(cfg)) == nobs
     np.testing.assert_allclose(np.array(cfg.obs_scaling[:nobs]), g["obs_scaling"], rtol=1e-7)
     assert abs(cfg.dt * cfg.control_freq_inv - float(g["control_dt"])) < 1e-8
     for e in range(N):
         out = np.zeros(28)
-        k = lib.vine_oracle_observations(
-            C.byref(cfg), dp(g["q"][e].astype(np.float64)), dp(g["prev_q"][e].astype(np.float64)),
-            dp(g["tip"][e, 1:3].astype(np.float64)), dp(g["prev_tip"][e, 1:3].astype(np.float64)),
+        k = lib.vine_oracle_observations_ex(
+            C.byref(cfg), dp(g["q"][e].astype(np.float64)), dp(g["qd"][e].astype(np.float64)),
+            dp(g["prev_q"][e].astype(np.float64)), dp(g["tip"][e, 1:3].astype(np.float64)),
+            dp(g["tip_vel"][e, 1:3].astype(np.float64)), dp(g["prev_tip"][e, 1:3].astype(np.float64)),
             dp(g["target"][e, 1:3].astype(np.float64)), float(g["smoothed"][e, 0]), float(g["prev_u_rail"][e, 0]),
             dp(g["obj_info"][e].astype(np.float64)), dp(out))
         assert k == nobs

@@ -20,10 +20,16 @@ OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_DEVICE, ERR_NO_DEVICE, ERR_ALLOC = 0, 
 # VineObsType (reference ObservationType enum, tasks/Vine5LinkMovingBase.py:67-73)
 OBS_POS_AND_FD_VEL_AND_OBJ_INFO = 0
 OBS_TIP_AND_CART_AND_OBJ_INFO = 1
+OBS_POS_ONLY, OBS_POS_AND_VEL, OBS_POS_AND_FD_VEL, OBS_POS_AND_PREV_POS = 2, 3, 4, 5
 OBS_TYPE_BY_NAME = {
     "POS_AND_FD_VEL_AND_OBJ_INFO": OBS_POS_AND_FD_VEL_AND_OBJ_INFO,
     "TIP_AND_CART_AND_OBJ_INFO": OBS_TIP_AND_CART_AND_OBJ_INFO,
+    "POS_ONLY": OBS_POS_ONLY,
+    "POS_AND_VEL": OBS_POS_AND_VEL,
+    "POS_AND_FD_VEL": OBS_POS_AND_FD_VEL,
+    "POS_AND_PREV_POS": OBS_POS_AND_PREV_POS,
 }
+SCALABLE_OBS_TYPES = (OBS_POS_AND_FD_VEL_AND_OBJ_INFO, OBS_TIP_AND_CART_AND_OBJ_INFO)
 
 # VINE_FLAG_*
 FLAG_USE_SMOOTHED_FPAM = 1 << 0

@@ -707,25 +707,53 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
         const float obj_depth = ST(VF_OBJ_DEPTH), obj_angle = ST(VF_OBJ_ANGLE);
 
         // compute_observations (V5:1339-1390)
+        // OBS_TYPE: the two scalable layouts are specialised; VINE_OBS_POS_ONLY has its own 14-column layout;
+        // VINE_OBS_POS_AND_VEL stands for the 26-column family (V5:1357-1368), whose middle blocks are picked at
+        // run time from P.obs_type (uniform branch).  Those four are unscaled by construction (V5:267-268).
         float o[VINE_MAX_OBS];
         int k = 0;
-        if (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+        constexpr int NOBS = (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) ? 28
+                           : (OBS_TYPE == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO) ? 18
+                           : (OBS_TYPE == VINE_OBS_POS_ONLY) ? 14 : 26;
+        const float fd_tip_y = (tip[0] - prev_tip_y) * P.inv_cdt, fd_tip_z = (tip[1] - prev_tip_z) * P.inv_cdt;
+        if (OBS_TYPE == VINE_OBS_POS_ONLY) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i) o[k++] = q[i];
+            o[k++] = 0.0f; o[k++] = tip[0]; o[k++] = tip[1];
+            o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
+            o[k++] = smoothed; o[k++] = prev_u_rail;
+        } else if (OBS_TYPE == VINE_OBS_POS_AND_VEL) {
+            const bool sim_vel = P.obs_type == VINE_OBS_POS_AND_VEL, fd_vel = P.obs_type == VINE_OBS_POS_AND_FD_VEL;
 #pragma unroll
             for (int i = 0; i < ND; ++i) o[k++] = q[i];
 #pragma unroll
-            for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) * P.inv_cdt;
+            for (int i = 0; i < ND; ++i)
+                o[k++] = sim_vel ? qd[i] : fd_vel ? (q[i] - prev_q[i]) * P.inv_cdt : prev_q[i];
+            o[k++] = 0.0f; o[k++] = tip[0]; o[k++] = tip[1];
+            o[k++] = 0.0f;
+            o[k++] = sim_vel ? tip[2] : fd_vel ? fd_tip_y : prev_tip_y;
+            o[k++] = sim_vel ? tip[3] : fd_vel ? fd_tip_z : prev_tip_z;
+            o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
+            o[k++] = 0.0f; o[k++] = 0.0f; o[k++] = 0.0f;
+            o[k++] = smoothed; o[k++] = prev_u_rail;
         } else {
-            o[k++] = q[0];
-            o[k++] = (q[0] - prev_q[0]) * P.inv_cdt;
-        }
-        o[k++] = 0.0f; o[k++] = tip[0]; o[k++] = tip[1];
-        o[k++] = 0.0f; o[k++] = (tip[0] - prev_tip_y) * P.inv_cdt; o[k++] = (tip[1] - prev_tip_z) * P.inv_cdt;
-        o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
-        o[k++] = 0.0f; o[k++] = 0.0f; o[k++] = 0.0f;
-        o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
-        constexpr int NOBS = (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) ? 28 : 18;
+            if (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
 #pragma unroll
-        for (int i = 0; i < NOBS; ++i) o[i] = o[i] * P.inv_obs_scale[i];
+                for (int i = 0; i < ND; ++i) o[k++] = q[i];
+#pragma unroll
+                for (int i = 0; i < ND; ++i) o[k++] = (q[i] - prev_q[i]) * P.inv_cdt;
+            } else {
+                o[k++] = q[0];
+                o[k++] = (q[0] - prev_q[0]) * P.inv_cdt;
+            }
+            o[k++] = 0.0f; o[k++] = tip[0]; o[k++] = tip[1];
+            o[k++] = 0.0f; o[k++] = fd_tip_y; o[k++] = fd_tip_z;
+            o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
+            o[k++] = 0.0f; o[k++] = 0.0f; o[k++] = 0.0f;
+            o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
+#pragma unroll
+            for (int i = 0; i < NOBS; ++i) o[i] = o[i] * P.inv_obs_scale[i];
+        }
         if (RANDOMIZE && P.obs_noise != 0.0f) {
 #pragma unroll
             for (int i = 0; i < NOBS; i += 4) {
@@ -997,8 +1025,11 @@ int vine_config_set_obs_type(VineConfig* c, int obs_type, int scale_observations
     const float joint_vel[6] = {0.67f, 2.22f, 1.47f, 1.14f, 0.903f, 0.716f};
     const float tail[16] = {0.0656f, 0.238f, 0.0656f, 0.732f, 2.0f, 0.732f, 0.02f, 0.0235f,
                             0.02f, 0.732f, 2.0f, 0.732f, 0.845f, 0.86f, 0.0385f, 0.5f};
-    if (obs_type != VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO && obs_type != VINE_OBS_TIP_AND_CART_AND_OBJ_INFO)
-        return fail(VINE_ERR_UNSUPPORTED, "observation type not supported (only the two scalable types)");
+    if (obs_type < VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || obs_type > VINE_OBS_POS_AND_PREV_POS)
+        return fail(VINE_ERR_INVALID_ARG, "unknown observation type");
+    const bool scalable = obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO;
+    if (scale_observations && !scalable)   // the reference raises NotImplementedError here (V5:267-268)
+        return fail(VINE_ERR_UNSUPPORTED, "observation scaling not implemented for this observation type");
     c->obs_type = obs_type;
     for (int i = 0; i < VINE_MAX_OBS; ++i) c->obs_scaling[i] = 1.0f;
     if (scale_observations) {
@@ -1018,7 +1049,9 @@ int vine_num_obs(const VineConfig* c) {
     if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
     if (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) return 28;
     if (c->obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO) return 18;
-    return fail(VINE_ERR_UNSUPPORTED, "observation type not supported");
+    if (c->obs_type == VINE_OBS_POS_ONLY) return 14;
+    if (c->obs_type >= VINE_OBS_POS_AND_VEL && c->obs_type <= VINE_OBS_POS_AND_PREV_POS) return 26;
+    return fail(VINE_ERR_INVALID_ARG, "unknown observation type");
 }
 
 int vine_create(const VineConfig* cfg, int device_id, float* state_storage, VineHandle** out) {
@@ -1094,7 +1127,9 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
         else LAUNCH_RND(OT, false);          \
     } while (0)
     if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) LAUNCH_OT(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO);
-    else LAUNCH_OT(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
+    else if (h->P.obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO) LAUNCH_OT(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
+    else if (h->P.obs_type == VINE_OBS_POS_ONLY) LAUNCH_OT(VINE_OBS_POS_ONLY);
+    else LAUNCH_OT(VINE_OBS_POS_AND_VEL);    // the 26-column family, resolved inside the kernel
 #undef LAUNCH_OT
 #undef LAUNCH_RND
 #undef LAUNCH

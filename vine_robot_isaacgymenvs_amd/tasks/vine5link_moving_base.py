@@ -62,11 +62,12 @@ def vine_config_from_cfg(cfg, lib, seed=None):
     c = abi.VineConfig()
     native.check(lib.vine_config_default(C.byref(c)), lib)
     observation_type = ObservationType[env["OBSERVATION_TYPE"]]
-    if observation_type.value not in abi.OBS_TYPE_BY_NAME:
+    scale_observations = bool(env.get("SCALE_OBSERVATIONS", True))
+    if scale_observations and abi.OBS_TYPE_BY_NAME[observation_type.value] not in abi.SCALABLE_OBS_TYPES:
         # the reference raises the same for these types whenever SCALE_OBSERVATIONS is on (V5:267-268)
         raise NotImplementedError(f"Observation scaling not implemented for {observation_type}")
     native.check(lib.vine_config_set_obs_type(C.byref(c), abi.OBS_TYPE_BY_NAME[observation_type.value],
-                                              int(bool(env.get("SCALE_OBSERVATIONS", True)))), lib)
+                                              int(scale_observations)), lib)
     if not env.get("USE_MOVING_BASE", True):
         raise NotImplementedError("Not implemented for non-moving base")   # V5:898
     if len(env.get("MAT_FILE", "")) > 0:
