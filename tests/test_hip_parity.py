@@ -408,6 +408,53 @@ def test_task_class_step_contract(HipEnv):
     env.close()
 
 
+def test_mat_file_replay(HipEnv, tmp_path):
+    """MAT_FILE (V5:281-297, 947-982): before every step all envs are put on sample num_steps % T of the recording
+    (joint positions, zero velocities, target, tip state).  Checked against a second env whose state is set by hand."""
+    import scipy.io
+    import torch
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    from vine_robot_isaacgymenvs_amd.utils.config import load_task_config
+    rng = np.random.default_rng(5)
+    T = 7
+    mat = {"cart_pos": rng.uniform(-0.1, 0.1, (1, T)), "Q": rng.uniform(-0.2, 0.2, (5, T)),
+           "moving_target_pos": np.stack([np.zeros(T), rng.uniform(-0.3, -0.1, T), rng.uniform(0.5, 0.6, T)]),
+           "target_vel": np.zeros((3, 1)), "tip_pos": np.stack([np.zeros(T), rng.uniform(-0.2, 0.2, T), rng.uniform(0.5, 0.6, T)]),
+           "tip_vel": rng.uniform(-0.1, 0.1, (3, T))}
+    path = str(tmp_path / "replay.mat")
+    scipy.io.savemat(path, mat)
+    common = ["num_envs=64", "task.env.CREATE_PIPE=False", "vine_randomize=False"]
+
+    def make(extra):
+        cfg = load_task_config("Vine5LinkMovingBase", overrides=common + extra)
+        return isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg, rl_device="cuda:0", sim_device="cuda:0",
+                                                        graphics_device_id=0, headless=True,
+                                                        virtual_screen_capture=False, force_render=False)
+    a, b = make(["task.env.MAT_FILE=" + path]), make([])
+    assert a.graph_capturable is False and b.graph_capturable is True
+    acts = torch.rand(64, 2, device="cuda:0") * 2 - 1
+    for step in range(T + 2):                                  # wraps around the recording
+        i = step % T
+        st = b.state
+        st[abi.VF_Q0] = float(mat["cart_pos"][0, i])
+        for j in range(5):
+            st[abi.VF_Q0 + 1 + j] = float(mat["Q"][j, i])
+        st[abi.VF_QD0:abi.VF_QD0 + 6] = 0.0
+        st[abi.VF_TARGET_Y], st[abi.VF_TARGET_Z] = float(mat["moving_target_pos"][1, i]), float(mat["moving_target_pos"][2, i])
+        st[abi.VF_TIP_Y], st[abi.VF_TIP_Z] = float(mat["tip_pos"][1, i]), float(mat["tip_pos"][2, i])
+        st[abi.VF_TIP_VY], st[abi.VF_TIP_VZ] = float(mat["tip_vel"][1, i]), float(mat["tip_vel"][2, i])
+        oa, ra, da, _ = a.step(acts)
+        ob, rb, db, _ = b.step(acts)
+        if step > 0:      # step 0 resets every env (reset_buf starts at ones) with each env's own draws
+            torch.testing.assert_close(ra, rb, rtol=0, atol=0)
+        assert torch.equal(da, db)
+    mat["target_vel"] = np.ones((3, 1))
+    scipy.io.savemat(path, mat)
+    with pytest.raises(NotImplementedError):
+        make(["task.env.MAT_FILE=" + path])
+    a.close(); b.close()
+
+
 def test_ppo_iteration_on_gpu_eager_and_graphed(HipEnv):
     """The PPO agent on the real task class: one iteration with an eager rollout and one with the rollout
     replayed from a hipGraph start from the same state and must produce the same experience."""

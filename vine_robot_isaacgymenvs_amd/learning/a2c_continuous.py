@@ -422,6 +422,8 @@ class A2CAgent:
 
     def play_steps_rnn(self):
         body = self._rollout_body_fused if self._can_fuse_rollout() else self._rollout_body
+        if self.use_graphs and not getattr(getattr(self.vec_env, "env", self.vec_env), "graph_capturable", True):
+            self.use_graphs = False              # e.g. MAT_FILE replay: host-indexed state writes every step
         if self.use_graphs:
             try:
                 self._play_graphed(body)

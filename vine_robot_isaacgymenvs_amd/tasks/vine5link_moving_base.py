@@ -70,8 +70,6 @@ def vine_config_from_cfg(cfg, lib, seed=None):
                                               int(scale_observations)), lib)
     if not env.get("USE_MOVING_BASE", True):
         raise NotImplementedError("Not implemented for non-moving base")   # V5:898
-    if len(env.get("MAT_FILE", "")) > 0:
-        raise NotImplementedError("MAT_FILE replay is out of scope of the MI355X path")
     c.num_envs = int(env["numEnvs"])
     c.control_freq_inv = int(env.get("controlFrequencyInv", 1))
     c.max_episode_length = int(env["maxEpisodeLength"])
@@ -161,6 +159,40 @@ class Vine5LinkMovingBase(VecTask):
         self.obs_scaling = torch.tensor(list(self._vcfg.obs_scaling[:self.num_obs]), device=self.device)
         self.wandb_dict = {}
         self._reward_matrix = None
+        self.mat = self.read_mat_file(self.cfg["env"]["MAT_FILE"]) if len(self.cfg["env"].get("MAT_FILE", "")) > 0 else None
+        # host-indexed state overwrite every step: cannot live inside a captured hipGraph
+        self.graph_capturable = self.mat is None
+
+    # ------------------------------------------------------------------ MAT_FILE replay (V5:281-297, 947-982)
+    def read_mat_file(self, filename):
+        """Recorded trajectory: cart_pos (1,T), Q (5,T), moving_target_pos (3,T), target_vel, tip_pos (3,T),
+        tip_vel (3,T) -> one [T, 12] device table (q(6), target y/z, tip y/z, tip vy/vz)."""
+        import numpy as np
+        import scipy.io
+        mat = scipy.io.loadmat(filename)
+        cart, Q = np.asarray(mat["cart_pos"], np.float64), np.asarray(mat["Q"], np.float64)
+        T = cart.shape[1]
+        assert cart.shape == (1, T) and Q.shape == (N_REVOLUTE_DOFS, T)
+        if np.any(np.asarray(mat["target_vel"], np.float64) != 0.0):
+            raise NotImplementedError("MAT_FILE with a moving target: target velocities are identically zero in the "
+                                      "step kernel (V5:916-918)")
+        rows = np.concatenate([cart, Q, np.asarray(mat["moving_target_pos"], np.float64)[1:3],
+                               np.asarray(mat["tip_pos"], np.float64)[1:3],
+                               np.asarray(mat["tip_vel"], np.float64)[1:3]], 0).T
+        self._mat_table = torch.as_tensor(rows, dtype=torch.float32, device=self.device).contiguous()
+        return mat
+
+    def overwrite_with_mat(self):
+        """V5:947-982: every env is put on sample ``num_steps % T`` of the recording before the step."""
+        T = self._mat_table.shape[0]
+        index = self.num_steps % T
+        self.logger.info(f"Currently at {index} / {T}")
+        row = self._mat_table[index]
+        st, f = self._state, abi
+        st[f.VF_Q0:f.VF_Q0 + 6] = row[0:6].unsqueeze(-1)
+        st[f.VF_QD0:f.VF_QD0 + 6] = 0.0
+        st[f.VF_TARGET_Y], st[f.VF_TARGET_Z] = row[6], row[7]
+        st[f.VF_TIP_Y], st[f.VF_TIP_Z], st[f.VF_TIP_VY], st[f.VF_TIP_VZ] = row[8], row[9], row[10], row[11]
 
     # ------------------------------------------------------------------ native handle
     def create_sim(self):
@@ -193,6 +225,8 @@ class Vine5LinkMovingBase(VecTask):
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _native_step(self, actions, obs_out):
+        if self.mat is not None:
+            self.overwrite_with_mat()
         native.check(self._lib.vine_step(self._handle, actions.data_ptr(), obs_out.data_ptr(), self.rew_buf.data_ptr(),
                                          self.reset_buf.data_ptr(), self.progress_buf.data_ptr(),
                                          self.timeout_buf.data_ptr(), self._stream()), self._lib)
