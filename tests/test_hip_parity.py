@@ -501,7 +501,9 @@ def test_train_entry_checkpoint_and_play(HipEnv, tmp_path, monkeypatch):
     from vine_robot_isaacgymenvs_amd.train import main
     monkeypatch.chdir(tmp_path)
     ov = ["task=Vine5LinkMovingBase", "num_envs=256", "minibatch_size=1024", "max_iterations=3", "headless=True",
-          "experiment=unit", "train.params.config.save_frequency=1", "train.params.config.save_best_after=0"]
+          "experiment=unit", "train.params.config.save_frequency=1", "train.params.config.save_best_after=0",
+          "train.params.config.env_stats_every=1", "task.env.CREATE_HISTOGRAMS_PERIODICALLY=True",
+          "train.params.config.horizon_length=64"]
     last_mean, epoch = main(ov)
     assert epoch == 3
     run = tmp_path / "runs" / "unit"
@@ -511,11 +513,18 @@ def test_train_entry_checkpoint_and_play(HipEnv, tmp_path, monkeypatch):
     ckpts = glob.glob(str(run / "nn" / "*.pth"))
     assert ckpts, "no checkpoint written"
     scal = (run / "summaries" / "scalars.csv").read_text()
-    for tag in ("performance/step_inference_rl_update_fps", "losses/a_loss", "info/kl", "info/last_lr"):
-        assert tag in scal
+    for tag in ("performance/step_inference_rl_update_fps", "losses/a_loss", "info/kl", "info/last_lr",
+                # the task's dashboard keys (V5:1250-1322) through the observer
+                "env/dist_tip_to_target", "env/Aggregated Reward", "env/Weighted Mean Position Success Reward",
+                "env/tip_pos_z at self.index_to_view"):
+        assert tag in scal, tag
+    hists = glob.glob(str(run / "summaries" / "histograms" / "observation_histograms_*.npz"))
+    assert hists, "CREATE_HISTOGRAMS_PERIODICALLY wrote nothing"
+    h = np.load(hists[0])
+    assert h["rows"].shape == (100, 28) and h["joint_pos_0_counts"].sum() == 100 and "target_angle_edges" in h
     # resume + play
     ck = sorted(ckpts)[-1]
-    main(ov[:-2] + ["checkpoint=" + ck, "max_iterations=4"])
+    main(ov[:-5] + ["checkpoint=" + ck, "max_iterations=4", "train.params.config.horizon_length=64"])
     reward, steps = main(["task=Vine5LinkMovingBase", "num_envs=256", "test=True", "checkpoint=" + ck, "headless=True",
                           "+train.params.config.player={max_steps: 40}"])
     assert np.isfinite(reward) and steps > 0

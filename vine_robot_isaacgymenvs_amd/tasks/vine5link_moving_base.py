@@ -9,6 +9,7 @@ This class keeps the constructor signature, the buffers and the attributes calle
 """
 import ctypes as C
 import logging
+import os
 from enum import Enum
 
 import torch
@@ -328,6 +329,29 @@ class Vine5LinkMovingBase(VecTask):
         host = torch.stack(vals).cpu().tolist()          # the only synchronisation
         self.wandb_dict = dict(zip(names, host))
         return self.wandb_dict
+
+    def observation_names(self):
+        """Column names of the default observation layout (V5:1430-1437); generic names for the other layouts."""
+        xyz = ("x", "y", "z")
+        names = ([f"joint_pos_{i}" for i in range(self.num_dof)] + [f"joint_vel_{i}" for i in range(self.num_dof)]
+                 + [f"tip_pos_{i}" for i in xyz] + [f"tip_vel_{i}" for i in xyz] + [f"target_pos_{i}" for i in xyz]
+                 + [f"target_vel_{i}" for i in xyz] + ["smoothed_u_fpam", "prev_u_rail_vel", "target_depth", "target_angle"])
+        return names if len(names) == self.num_obs else [f"obs_{i}" for i in range(self.num_obs)]
+
+    def write_histograms(self, rows, directory, bins=20):
+        """CREATE_HISTOGRAMS_PERIODICALLY (V5:1392-1452) without wandb: one ``.npz`` per histogram set holding the raw
+        rows, and per observation column the counts and bin edges a ``wandb.plot.histogram`` would draw."""
+        import numpy as np
+        os.makedirs(directory, exist_ok=True)
+        data = np.asarray(rows, dtype=np.float32)
+        out = {"rows": data, "names": np.array(self.observation_names())}
+        for j, name in enumerate(self.observation_names()):
+            counts, edges = np.histogram(data[:, j], bins=bins)
+            out[name + "_counts"], out[name + "_edges"] = counts, edges
+        path = os.path.join(directory, f"observation_histograms_{self.num_steps}.npz")
+        np.savez_compressed(path, **out)
+        self.logger.info(f"Creating histogram at self.num_steps {self.num_steps}: {path}")
+        return path
 
     # ------------------------------------------------------------------ test / tooling hooks
     def bind_reward_matrix(self):

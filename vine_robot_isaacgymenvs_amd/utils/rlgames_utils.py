@@ -4,6 +4,7 @@ rl_games is not a dependency: ``RLGPUEnv`` keeps the ``IVecEnv`` method set rl_g
 (step/reset/reset_done/get_number_of_agents/get_env_info) so that either the built-in PPO
 (``learning/``) or an installed rl_games can drive it.
 """
+import os
 from typing import Callable
 
 from ..tasks import isaacgym_task_map
@@ -37,13 +38,23 @@ class RLGPUAlgoObserver:
     """rlgames_utils.py:95-148: lets the env log scalars next to the algorithm's statistics.  Scalars found in the
     ``infos`` dict returned by ``env.step`` are written as ``<key>/frame|iter|time`` to the agent's writer."""
 
-    def __init__(self):
+    def __init__(self, env_stats_every=10):
         self.algo = None
         self.direct_info = {}
+        self.env_stats_every = env_stats_every      # epochs between dumps of the task's wandb_dict scalars
+        self.histogram_rows = []
 
     def after_init(self, algo):
         self.algo = algo
         self.writer = getattr(algo, "writer", None)
+        self.env_stats_every = int(getattr(algo, "config", {}).get("env_stats_every", self.env_stats_every))
+        env = self._task()
+        if self.writer is not None and self.env_stats_every > 0 and hasattr(env, "bind_reward_matrix"):
+            env.bind_reward_matrix()             # per-term reward entries of the dashboard (V5:1272-1284)
+
+    def _task(self):
+        vec_env = getattr(self.algo, "vec_env", None)
+        return getattr(vec_env, "env", vec_env)
 
     def process_infos(self, infos, done_indices=None):
         assert isinstance(infos, dict), "RLGPUAlgoObserver expects dict info"
@@ -59,6 +70,23 @@ class RLGPUAlgoObserver:
             self.writer.add_scalar(f"{k}/frame", float(v), frame)
             self.writer.add_scalar(f"{k}/iter", float(v), epoch_num)
             self.writer.add_scalar(f"{k}/time", float(v), total_time)
+        env = self._task()
+        if env is None:
+            return
+        # the task's dashboard scalars (the reference wandb.log()s them from the step; here one device pass + one
+        # device->host copy every `env_stats_every` epochs), same key names under "env/"
+        if self.env_stats_every > 0 and epoch_num % self.env_stats_every == 0 and hasattr(env, "collect_stats"):
+            for k, v in env.collect_stats().items():
+                self.writer.add_scalar("env/" + k, v, frame)
+        # CREATE_HISTOGRAMS_PERIODICALLY (V5:1392-1452): observations of env `index_to_view`, 100 consecutive control
+        # steps per histogram set; taken from the rollout buffer so the step path stays free of host work
+        cfg_env = getattr(env, "cfg", {}).get("env", {}) if hasattr(env, "cfg") else {}
+        buf = getattr(self.algo, "buf", None)
+        if cfg_env.get("CREATE_HISTOGRAMS_PERIODICALLY", False) and buf is not None and hasattr(env, "write_histograms"):
+            self.histogram_rows += buf["obses"][:, env.index_to_view].detach().cpu().tolist()
+            if len(self.histogram_rows) >= 100:
+                env.write_histograms(self.histogram_rows[:100], os.path.join(os.path.dirname(self.writer.path), "histograms"))
+                self.histogram_rows = []
 
 
 class RLGPUEnv:
