@@ -25,31 +25,55 @@ extern "C" {
  *   gates = igates[b] + keep_b * hgates[b] + bias;  c' = f * (keep_b * c_prev) + i * g;  h' = o * tanh(c')
  * keep_b = 1 - done[b * done_stride] (done == NULL: keep = 1).
  * igates rows are `ig_stride` floats apart (a [B, T, 4H] tensor viewed at time t), h_out rows `h_stride` apart.
- * gates_act (nullable, [B,4H]) receives the activated gates for the backward pass. */
+ * gates_act (nullable, [B,4H]) receives the activated gates for the backward pass.
+ * hp_next (nullable, rows h_stride apart) receives (1 - done_next[b]) * h': the masked hidden state step t+1
+ * consumes, i.e. the operand of the recurrent weight gradient, so the backward pass need not rebuild it. */
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
-                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* stream);
+                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, float* hp_next,
+                           const uint8_t* done_next, int64_t done_next_stride, void* stream);
 
 /* Backward of the step above.
  *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
  * g_rec / dc_next = gradients w.r.t. the MASKED (h_t, c_t) consumed by step t+1 (NULL at the last step),
  * keep_next = 1 - done_next.  Writes the pre-activation gate gradients (rows dg_stride apart) and the gradient
- * w.r.t. the masked c_{t-1} (dc_prev = dc * f). */
+ * w.r.t. the masked c_{t-1} (dc_prev = dc * f).
+ * bias_partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, 4H]) receives per-workgroup column sums of the gate gradients;
+ * their sum over rows (and over the T steps) is the bias gradient -- deterministic, no atomics. */
+#define VINE_PPO_PARTIAL_BLOCKS 512
 int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
                             const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
-                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev, void* stream);
+                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev,
+                            float* bias_partial, void* stream);
+
+/* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
+ * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.
+ * forward: y = (x - mean) * rstd * gamma + beta; mean/rstd [n] (both nullable) are kept for the backward pass.
+ * backward: dx, and partial [VINE_PPO_PARTIAL_BLOCKS, 2H] whose row sum is {d gamma | d beta}. */
+int vine_layernorm_forward(int64_t n, int64_t H, const float* x, const float* gamma, const float* beta, float eps,
+                           float* y, float* mean, float* rstd, void* stream);
+int vine_layernorm_backward(int64_t n, int64_t H, const float* dy, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, float* dx, float* partial, void* stream);
+
+/* ELU backward from the layer OUTPUT a = elu(z) (PY:19 `activation: elu`): out = g * (a > 0 ? 1 : a + alpha); rows of
+ * g / a / out are *_stride floats apart (so a column block of a wider matrix works); out may alias g.
+ * partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, C]): per-workgroup column sums of out = the bias gradient of the
+ * Linear in front of the activation.  C % 4 == 0 and C/4 divides 256. */
+int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, const float* a, int64_t a_stride,
+                      float alpha, float* out, int64_t out_stride, float* partial, void* stream);
 
 /* PPO loss of one minibatch of n samples with A action dims, forward AND backward in one pass:
  *   loss = mean(a_loss) + 0.5 * critic_coef * mean(c_loss) - entropy_coef * mean(entropy) + bounds_coef * mean(b_loss)
  * Outputs d(loss)/d(mu) [n,A], d(loss)/d(value) [n], d(loss)/d(logstd) [A] and
  * stats[8] = {mean a_loss, mean c_loss, mean b_loss, mean entropy, mean kl(old||new), loss, 0, 0}.
- * grad_logstd and stats are zeroed by the call. */
+ * grad_logstd and stats are zeroed by the call.  Rows of mu / grad_mu are mu_stride floats apart and elements of
+ * value / grad_value value_stride apart (0 = packed: A and 1), so both heads can live in one [n, A+1] GEMM output. */
 int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, const float* value, const float* actions,
                   const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
-                  float* grad_logstd, float* stats, void* stream);
+                  float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, void* stream);
 
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps

@@ -12,8 +12,8 @@ from vine_robot_isaacgymenvs_amd import abi, native
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    text = open(os.path.join(REPO, "include", "vine.h")).read()
+def header_functions(header="vine.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(vine_[a-z_0-9]+)\s*\(", text)))
 
@@ -32,6 +32,16 @@ def test_product_library_exports_every_symbol(hip_lib):
     for name in header_functions():
         assert hasattr(hip_lib, name), name
     assert hip_lib.vine_backend_name() == b"hip-gfx950"
+
+
+def test_ppo_header_symbols_exported_and_mirrored(hip_lib):
+    """include/vine_ppo.h (fused PPO-update ops): every declared function is exported and has a ctypes prototype."""
+    names = header_functions("vine_ppo.h")
+    assert names == sorted(abi.PPO_PROTOTYPES)
+    for name in names:
+        assert hasattr(hip_lib, name), name
+    text = open(os.path.join(REPO, "include", "vine_ppo.h")).read()
+    assert int(re.search(r"#define VINE_PPO_PARTIAL_BLOCKS (\d+)", text).group(1)) == abi.PPO_PARTIAL_BLOCKS
 
 
 def test_oracle_exports_every_symbol():

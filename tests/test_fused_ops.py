@@ -110,6 +110,60 @@ def test_ppo_loss_kernel_matches_autograd(clip_value):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("obs_dim,use_slots", [(28, False), (28, True), (18, True)])
+def test_fused_trunk_matches_float64_composition(obs_dim, use_slots):
+    """The whole network as one hand-written autograd node (fused._Trunk: LayerNorm / ELU-backward / LSTM kernels,
+    merged heads, partial-sum bias gradients) against the stock module composition evaluated in float64 on the CPU:
+    head outputs, final LSTM state and the gradient of every parameter."""
+    import copy
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.network import ModelA2CContinuousLogStd
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    model = ModelA2CContinuousLogStd(load_config()["train"]["params"]["network"], 2, (obs_dim,), True, True)
+    with torch.no_grad():                      # make biases / LayerNorm parameters non-trivial
+        for name, p in model.named_parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    ref = copy.deepcopy(model).double()
+    net = model.a2c_network.to(dev)
+    B, T = 1024, 4
+    n = B * T
+    obs = torch.randn(n, obs_dim).clamp(-5, 5)
+    h0, c0 = torch.randn(1, B, 256) * 0.5, torch.randn(1, B, 256) * 0.5
+    dones = (torch.rand(n) < 0.2).to(torch.uint8)
+    g = torch.randn(n, 3) / n
+    # reference
+    mu, _, value, (hT, cT) = ref.a2c_network(obs.double(), (h0.double(), c0.double()), T, dones)
+    torch.autograd.backward([mu, value], [g[:, :2].double(), g[:, 2:].double()])
+    # fused
+    params = list(net.parameters())
+    if use_slots:                              # the optimiser's flat gradient block: gradients are written in place
+        for p in params:
+            p.grad = torch.zeros_like(p)
+    obs_d = obs.to(dev)
+    assert net.trunk_supported(obs_d, T)
+    heads, (h2, c2) = net.forward_heads(obs_d, (h0.to(dev), c0.to(dev)), T, dones.to(dev))
+    heads.backward(g.to(dev))
+
+    def close(a, b, tol, name):
+        b = b.to(torch.float64)
+        err = float((a.detach().cpu().double() - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err < tol, (name, err)
+
+    close(heads[:, :2], mu, 2e-5, "mu")
+    close(heads[:, 2:], value, 2e-5, "value")
+    close(h2, hT, 2e-5, "hT")
+    close(c2, cT, 2e-5, "cT")
+    ref_params = dict(ref.a2c_network.named_parameters())
+    for name, p in net.named_parameters():
+        if name == "sigma":
+            continue
+        assert p.grad is not None, name
+        close(p.grad, ref_params[name].grad, 2e-4, name)
+
+
+@pytest.mark.gpu
 def test_fused_update_equals_stock_update():
     """One optimiser step of the agent through the fused path and through the stock composition, from the same
     weights and minibatch: same loss statistics, same updated parameters (to fp32 reduction-order noise)."""

@@ -26,7 +26,9 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
                                 const float* __restrict__ hgates, const float* __restrict__ bias,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
                                 long long done_stride, float* __restrict__ h_out, long long h_stride,
-                                float* __restrict__ c_out, float* __restrict__ gates_act) {
+                                float* __restrict__ c_out, float* __restrict__ gates_act,
+                                float* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
+                                long long done_next_stride) {
     const int H4 = H >> 2;
     const long long total = B * H4;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -59,6 +61,10 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
         }
         st4(c_out + b * H + j, make_float4(cn[0], cn[1], cn[2], cn[3]));
         st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        if (hp_next) {   // the masked hidden state step t+1 consumes (operand of the recurrent weight gradient)
+            const float kn = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+            st4(hp_next + b * h_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
+        }
         if (gates_act) {
             float* ga = gates_act + b * 4LL * H;
             st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
@@ -75,9 +81,13 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
                                 const float* __restrict__ gates_act, const float* __restrict__ c_new,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
                                 long long done_stride, float* __restrict__ dgates, long long dg_stride,
-                                float* __restrict__ dc_prev) {
+                                float* __restrict__ dc_prev, float* __restrict__ bias_partial) {
     const int H4 = H >> 2;
     const long long total = B * H4;
+    // bias_partial (nullable, [gridDim.x, 4H]): requires blockDim.x % H4 == 0 so that a thread keeps its column quad
+    float acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.0f;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const long long b = idx / H4;
@@ -119,6 +129,162 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
         st4(dgp + 2 * H + j, make_float4(dg[0], dg[1], dg[2], dg[3]));
         st4(dgp + 3 * H + j, make_float4(dout[0], dout[1], dout[2], dout[3]));
         st4(dc_prev + b * H + j, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+        if (bias_partial) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[u] += di[u]; acc[4 + u] += df[u]; acc[8 + u] += dg[u]; acc[12 + u] += dout[u];
+            }
+        }
+    }
+    if (bias_partial) {
+        // threads tid, tid + H4, tid + 2*H4 ... share a column quad: fold them through LDS, one row per block
+        __shared__ float red[256 * 16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) red[u * 256 + threadIdx.x] = acc[u];
+        __syncthreads();
+        if ((int)threadIdx.x < H4) {
+            float* row = bias_partial + (long long)blockIdx.x * 4 * H;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float sum = 0.0f;
+                for (int t = threadIdx.x; t < (int)blockDim.x; t += H4) sum += red[u * 256 + t];
+                row[(u >> 2) * H + ((int)threadIdx.x << 2) + (u & 3)] = sum;
+            }
+        }
+    }
+}
+
+// ---- LayerNorm over rows of H = 256 * NV floats: one wave per row, lane l owns columns [256 v + 4 l, +4) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(long long n, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ y, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out) {
+    constexpr int H = 256 * NV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 gm[NV], bt[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { gm[v] = ld4(gamma + 256 * v + 4 * lane); bt[v] = ld4(beta + 256 * v + 4 * lane); }
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < n; r += (long long)gridDim.x * 4) {
+        float4 xv[NV];
+        float s = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xv[v] = ld4(x + r * H + 256 * v + 4 * lane);
+            s += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
+        }
+        const float mean = wave_sum(s) * (1.0f / H);
+        float q = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float a = xv[v].x - mean, b = xv[v].y - mean, c = xv[v].z - mean, d = xv[v].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            st4(y + r * H + 256 * v + 4 * lane,
+                make_float4((xv[v].x - mean) * rstd * gm[v].x + bt[v].x, (xv[v].y - mean) * rstd * gm[v].y + bt[v].y,
+                            (xv[v].z - mean) * rstd * gm[v].z + bt[v].z, (xv[v].w - mean) * rstd * gm[v].w + bt[v].w));
+        if (lane == 0 && mean_out) { mean_out[r] = mean; rstd_out[r] = rstd; }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  partial[block] = {sum dy * xhat | sum dy}
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(long long n, const float* __restrict__ dy,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ partial) {
+    constexpr int H = 256 * NV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 gm[NV];
+    float dgm[NV][4], dbt[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        gm[v] = ld4(gamma + 256 * v + 4 * lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { dgm[v][u] = 0.0f; dbt[v][u] = 0.0f; }
+    }
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < n; r += (long long)gridDim.x * 4) {
+        const float mean = mean_in[r], rstd = rstd_in[r];
+        float xh[NV][4], g[NV][4];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 xv = ld4(x + r * H + 256 * v + 4 * lane), dv = ld4(dy + r * H + 256 * v + 4 * lane);
+            const float xa[4] = {xv.x, xv.y, xv.z, xv.w}, da[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float ga[4] = {gm[v].x, gm[v].y, gm[v].z, gm[v].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xh[v][u] = (xa[u] - mean) * rstd;
+                g[v][u] = da[u] * ga[u];
+                s1 += g[v][u];
+                s2 += g[v][u] * xh[v][u];
+                dgm[v][u] += da[u] * xh[v][u];
+                dbt[v][u] += da[u];
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.0f / H), m2 = wave_sum(s2) * (1.0f / H);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            st4(dx + r * H + 256 * v + 4 * lane,
+                make_float4(rstd * (g[v][0] - m1 - xh[v][0] * m2), rstd * (g[v][1] - m1 - xh[v][1] * m2),
+                            rstd * (g[v][2] - m1 - xh[v][2] * m2), rstd * (g[v][3] - m1 - xh[v][3] * m2)));
+    }
+    // the block's 4 waves own the same columns: fold through LDS, then one [2H] row per block
+    __shared__ float red[4][2 * H];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            red[wave][256 * v + 4 * lane + u] = dgm[v][u];
+            red[wave][H + 256 * v + 4 * lane + u] = dbt[v][u];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * H; c += 256)
+        partial[(long long)blockIdx.x * 2 * H + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// ELU backward from the OUTPUT a = elu(z): dz = g * (a > 0 ? 1 : a + alpha), plus per-block column sums of dz
+// (= the bias gradient of the Linear that produced z).  C4 = C/4 threads per row, 256/C4 rows per block pass.
+__global__ __launch_bounds__(256) void elu_bwd_kernel(long long n, int C, const float* __restrict__ g, long long g_stride,
+                                                      const float* __restrict__ a, long long a_stride, float alpha,
+                                                      float* __restrict__ out, long long out_stride,
+                                                      float* __restrict__ partial) {
+    const int C4 = C >> 2;
+    const int rows_per_pass = 256 / C4;
+    const int rq = threadIdx.x / C4, j = (threadIdx.x - rq * C4) << 2;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (long long r = (long long)blockIdx.x * rows_per_pass + rq; r < n; r += (long long)gridDim.x * rows_per_pass) {
+        const float4 gv = ld4(g + r * g_stride + j), av = ld4(a + r * a_stride + j);
+        const float4 d = make_float4(gv.x * (av.x > 0.0f ? 1.0f : av.x + alpha), gv.y * (av.y > 0.0f ? 1.0f : av.y + alpha),
+                                     gv.z * (av.z > 0.0f ? 1.0f : av.z + alpha), gv.w * (av.w > 0.0f ? 1.0f : av.w + alpha));
+        st4(out + r * out_stride + j, d);
+        acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
+    }
+    if (partial) {
+        __shared__ float red[4 * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red[u * 256 + threadIdx.x] = acc[u];
+        __syncthreads();
+        if ((int)threadIdx.x < C4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float sum = 0.0f;
+                for (int t = threadIdx.x; t < 256; t += C4) sum += red[u * 256 + t];
+                partial[(long long)blockIdx.x * C + ((int)threadIdx.x << 2) + u] = sum;
+            }
+        }
     }
 }
 
@@ -132,7 +298,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        float critic_coef, float entropy_coef, float bounds_coef,
                                                        float soft_bound, float* __restrict__ grad_mu,
                                                        float* __restrict__ grad_value, float* __restrict__ grad_logstd,
-                                                       float* __restrict__ stats) {
+                                                       float* __restrict__ stats, long long mu_stride,
+                                                       long long value_stride) {
+    // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
+    // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
     const float inv_n = 1.0f / (float)n;
     float ls[PPO_MAX_A], sg[PPO_MAX_A], isg2[PPO_MAX_A];
     float sum_ls = 0.0f;
@@ -150,7 +319,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         float z2[PPO_MAX_A], dm[PPO_MAX_A], m[PPO_MAX_A];
         float nlp = 0.9189385332046727f * A + sum_ls;
         for (int k = 0; k < A; ++k) {
-            m[k] = mu[i * A + k];
+            m[k] = mu[i * mu_stride + k];
             dm[k] = actions[i * A + k] - m[k];
             z2[k] = dm[k] * dm[k] * isg2[k];
             nlp += 0.5f * z2[k];
@@ -165,7 +334,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         const float dL_dratio = first ? -a : -a * inside;
         const float dL_dnlp = -ratio * dL_dratio * inv_n;    // d ratio / d nlp = -ratio
         // value loss
-        const float v = value[i], vp = old_values[i], R = returns[i];
+        const float v = value[i * value_stride], vp = old_values[i], R = returns[i];
         float c_loss, dL_dv;
         if (clip_value) {
             const float dv = v - vp;
@@ -177,13 +346,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
             c_loss = (R - v) * (R - v);
             dL_dv = 2.0f * (v - R);
         }
-        grad_value[i] = 0.5f * critic_coef * dL_dv * inv_n;
+        grad_value[i * value_stride] = 0.5f * critic_coef * dL_dv * inv_n;
         float b_loss = 0.0f, kl = 0.0f;
         for (int k = 0; k < A; ++k) {
             const float hi = fmaxf(m[k] - soft_bound, 0.0f), lo = fminf(m[k] + soft_bound, 0.0f);
             b_loss += hi * hi + lo * lo;
             // d nlp / d mu = -(a - mu)/sigma^2 ; d nlp / d logstd = 1 - z^2
-            grad_mu[i * A + k] = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
+            grad_mu[i * mu_stride + k] = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
             gls[k] += dL_dnlp * (1.0f - z2[k]);
             const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
             const float c1 = __logf(os / sg[k] + 1e-5f);
@@ -412,29 +581,69 @@ extern "C" {
 
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
-                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* stream) {
+                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, float* hp_next,
+                           const uint8_t* done_next, int64_t done_next_stride, void* stream) {
     if (B <= 0 || H <= 0 || (H & 3) || (ig_stride & 3) || (h_stride & 3) || !igates || !hgates || !bias || !c_prev ||
         !h_out || !c_out)
         return VINE_ERR_INVALID_ARG;
     const int threads = 256;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(grid_for(B * (H / 4), threads)), dim3(threads), 0, (hipStream_t)stream,
                        (long long)B, (int)H, igates, (long long)ig_stride, hgates, bias, c_prev, done,
-                       (long long)done_stride, h_out, (long long)h_stride, c_out, gates_act);
+                       (long long)done_stride, h_out, (long long)h_stride, c_out, gates_act, hp_next, done_next,
+                       (long long)done_next_stride);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
 int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
                             const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
-                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev, void* stream) {
+                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev,
+                            float* bias_partial, void* stream) {
     if (B <= 0 || H <= 0 || (H & 3) || (g_stride & 3) || (dg_stride & 3) || !g_out || !gates_act || !c_new || !c_prev ||
         !dgates || !dc_prev)
         return VINE_ERR_INVALID_ARG;
     const int threads = 256;
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for(B * (H / 4), threads)), dim3(threads), 0, (hipStream_t)stream,
+    if (bias_partial && (H > 1024 || threads % (int)(H / 4) != 0)) return VINE_ERR_UNSUPPORTED;
+    // with partial sums the grid is fixed: the caller's buffer has VINE_PPO_PARTIAL_BLOCKS rows
+    const int blocks = bias_partial ? VINE_PPO_PARTIAL_BLOCKS : grid_for(B * (H / 4), threads);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream,
                        (long long)B, (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next,
                        (long long)done_next_stride, gates_act, c_new, c_prev, done, (long long)done_stride, dgates,
-                       (long long)dg_stride, dc_prev);
+                       (long long)dg_stride, dc_prev, bias_partial);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_layernorm_forward(int64_t n, int64_t H, const float* x, const float* gamma, const float* beta, float eps,
+                           float* y, float* mean, float* rstd, void* stream) {
+    if (n <= 0 || !x || !gamma || !beta || !y || ((mean == nullptr) != (rstd == nullptr))) return VINE_ERR_INVALID_ARG;
+    if (H != 256 && H != 512 && H != 1024) return VINE_ERR_UNSUPPORTED;
+    const int blocks = (int)((n + 3) / 4 < 256 * 8 ? (n + 3) / 4 : 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 256) hipLaunchKernelGGL(layernorm_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, (long long)n, x, gamma, beta, eps, y, mean, rstd);
+    else if (H == 512) hipLaunchKernelGGL(layernorm_fwd_kernel<2>, dim3(blocks), dim3(256), 0, s, (long long)n, x, gamma, beta, eps, y, mean, rstd);
+    else hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, (long long)n, x, gamma, beta, eps, y, mean, rstd);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_layernorm_backward(int64_t n, int64_t H, const float* dy, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, float* dx, float* partial, void* stream) {
+    if (n <= 0 || !dy || !x || !mean || !rstd || !gamma || !dx || !partial) return VINE_ERR_INVALID_ARG;
+    if (H != 256 && H != 512 && H != 1024) return VINE_ERR_UNSUPPORTED;
+    const int blocks = VINE_PPO_PARTIAL_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    if (H == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, (long long)n, dy, x, mean, rstd, gamma, dx, partial);
+    else if (H == 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, (long long)n, dy, x, mean, rstd, gamma, dx, partial);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, (long long)n, dy, x, mean, rstd, gamma, dx, partial);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, const float* a, int64_t a_stride,
+                      float alpha, float* out, int64_t out_stride, float* partial, void* stream) {
+    if (n <= 0 || C <= 0 || !g || !a || !out || (g_stride & 3) || (a_stride & 3) || (out_stride & 3))
+        return VINE_ERR_INVALID_ARG;
+    if ((C & 3) || C > 1024 || 256 % (C / 4) != 0) return VINE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(elu_bwd_kernel, dim3(VINE_PPO_PARTIAL_BLOCKS), dim3(256), 0, (hipStream_t)stream, (long long)n,
+                       (int)C, g, (long long)g_stride, a, (long long)a_stride, alpha, out, (long long)out_stride, partial);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -442,7 +651,7 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
-                  float* grad_logstd, float* stats, void* stream) {
+                  float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, void* stream) {
     if (n <= 0 || A <= 0 || A > PPO_MAX_A || !mu || !logstd || !value || !actions || !old_neglogp || !advantages ||
         !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats)
         return VINE_ERR_INVALID_ARG;
@@ -454,7 +663,8 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(threads), 0, s, (long long)n, (int)A, mu, logstd, value,
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
-                       critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats);
+                       critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats,
+                       (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1));
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

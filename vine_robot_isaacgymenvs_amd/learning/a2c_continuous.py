@@ -562,12 +562,16 @@ class A2CAgent:
         """GPU fp32 path: network forward, then ONE kernel for the whole PPO loss and its gradient w.r.t.
         (mu, value, logstd); autograd carries on from there.  Same arithmetic as ``calc_gradients``."""
         batch_dict = {"obs": mb["obs"], "rnn_states": mb["rnn_states"], "seq_length": self.seq_len, "dones": mb["dones"]}
-        mu, value, logstd, _ = self.model.forward_raw(batch_dict)
+        mu, value, logstd, _, heads = self.model.forward_raw(batch_dict)
         g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(
             mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
             mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef, self.entropy_coef,
-            self.bounds_loss_coef or 0.0)
-        torch.autograd.backward([mu, value], [g_mu, g_val])     # the gradient block was left zeroed by the last Adam step
+            self.bounds_loss_coef or 0.0, heads=heads)
+        # the gradient block was left zeroed by the last Adam step
+        if heads is not None:
+            torch.autograd.backward([heads], [g_mu])            # g_mu is the [n, A+1] gradient of [mu | value]
+        else:
+            torch.autograd.backward([mu, value], [g_mu, g_val])
         self.model.a2c_network.sigma.grad.add_(g_ls)
         kl = stats[4]
         if self.multi_gpu and not self.use_grad_scaler:

@@ -43,7 +43,8 @@ def splitk_tn(dy, x, out=None):
         s *= 2
     if s == 1 or not dy.is_cuda:
         return torch.mm(dy.t(), x, out=out) if out is not None else dy.t().mm(x)
-    part = torch.bmm(dy.view(s, K // s, dy.shape[1]).transpose(1, 2), x.view(s, K // s, x.shape[1]))
+    # unflatten: also valid for operands whose rows are padded (a column block of a wider buffer)
+    part = torch.bmm(dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s)))
     return torch.sum(part, 0, out=out) if out is not None else part.sum(0)
 
 
@@ -103,6 +104,72 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     return torch.stack(outs, 1).reshape(B * T, -1), h, c
 
 
+def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
+    """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
+    hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``)."""
+    BT, H = ig.shape[0], w_hh.shape[1]
+    B = BT // T
+    dev = ig.device
+    out = torch.empty((BT, H), device=dev, dtype=torch.float32)
+    c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
+    c_all[0].copy_(c0)
+    gates = torch.empty((T, B, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
+    hp = torch.empty((B, T, H), device=dev, dtype=torch.float32)
+    if dones is not None:
+        torch.mul(h0, (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)), out=hp[:, 0])
+    else:
+        hp[:, 0].copy_(h0)
+    st = _stream(ig)
+    d_ptr = dones.data_ptr() if dones is not None else None
+    w_hh_t = w_hh.t()
+    for t in range(T):
+        hg = hp[:, t].mm(w_hh_t)
+        last = t == T - 1
+        # hg is already built from the masked state: no second masking inside the kernel (done = NULL), except for c
+        _check(lib.vine_lstm_cell_forward(
+            B, H, ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, hg.data_ptr(), bias.data_ptr(), c_all[t].data_ptr(),
+            (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
+            c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
+            None if last else hp.data_ptr() + 4 * ((t + 1) * H),
+            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, st), "vine_lstm_cell_forward")
+    return out, c_all, gates, hp
+
+
+def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
+    """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials."""
+    from ..abi import PPO_PARTIAL_BLOCKS
+    B, H = c_all.shape[1], c_all.shape[2]
+    dev = g_out.device
+    g_out = g_out.contiguous()
+    dG = torch.empty((B * T, 4 * H), device=dev, dtype=torch.float32)
+    dG3 = dG.view(B, T, 4 * H)
+    dc = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
+    use_partial = H <= 1024 and 256 % (H // 4) == 0
+    bias_partial = torch.empty((T, PPO_PARTIAL_BLOCKS, 4 * H), device=dev, dtype=torch.float32) if use_partial else None
+    st = _stream(g_out)
+    d_ptr = dones.data_ptr() if dones is not None else None
+    g_rec = None
+    dc_next = None
+    for t in reversed(range(T)):
+        dn = (d_ptr + t + 1) if (d_ptr is not None and t < T - 1) else None
+        _check(lib.vine_lstm_cell_backward(
+            B, H, g_out.data_ptr() + 4 * (t * H), T * H, g_rec.data_ptr() if g_rec is not None else None,
+            dc_next.data_ptr() if dc_next is not None else None, dn, T, gates[t].data_ptr(),
+            c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
+            dG.data_ptr() + 4 * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(),
+            bias_partial[t].data_ptr() if use_partial else None, st), "vine_lstm_cell_backward")
+        dc_next = dc[t & 1]
+        if t > 0:
+            g_rec = dG3[:, t].mm(w_hh)
+    return dG, bias_partial
+
+
+def _sum_rows(partial, full, out=None):
+    """Column sums: of the small per-workgroup ``partial`` block when the kernel produced one, else of ``full``."""
+    src = partial.view(-1, partial.shape[-1]) if partial is not None else full
+    return torch.sum(src, 0, out=out) if out is not None else src.sum(0)
+
+
 class _LSTMSeq(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
@@ -113,26 +180,13 @@ class _LSTMSeq(torch.autograd.Function):
         x = x.contiguous()
         ig = x.mm(w_ih.t())                                   # one input projection for every time step
         bias = (b_ih + b_hh).contiguous()
-        out = torch.empty((BT, H), device=x.device, dtype=torch.float32)
-        c_all = torch.empty((T + 1, B, H), device=x.device, dtype=torch.float32)
-        c_all[0].copy_(c0)
-        gates = torch.empty((T, B, 4 * H), device=x.device, dtype=torch.float32) if need_grad else None
-        h0 = h0.contiguous()
-        st = _stream(x)
-        d_ptr = dones.data_ptr() if dones is not None else None
+        out, c_all, gates, hp = _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad)
         out3 = out.view(B, T, H)
-        for t in range(T):
-            h_prev = h0 if t == 0 else out3[:, t - 1]
-            hg = h_prev.mm(w_hh.t())
-            _check(lib.vine_lstm_cell_forward(
-                B, H, ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, hg.data_ptr(), bias.data_ptr(), c_all[t].data_ptr(),
-                (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
-                c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None, st), "vine_lstm_cell_forward")
         ctx.T = T
         ctx.has_dones = dones is not None
         ctx.slots = (_grad_slot(w_ih), _grad_slot(w_hh), _grad_slot(b_ih), _grad_slot(b_hh))
         if need_grad:
-            ctx.save_for_backward(x, w_ih, w_hh, h0, out, c_all, gates, dones if dones is not None else x.new_empty(0))
+            ctx.save_for_backward(x, w_ih, w_hh, hp, out, c_all, gates, dones if dones is not None else x.new_empty(0))
         hT = out3[:, T - 1].contiguous()
         cT = c_all[T].clone()
         ctx.mark_non_differentiable(hT, cT)
@@ -141,43 +195,20 @@ class _LSTMSeq(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, _g_h, _g_c):
         lib = _lib()
-        x, w_ih, w_hh, h0, out, c_all, gates, dones = ctx.saved_tensors
+        x, w_ih, w_hh, hp, out, c_all, gates, dones = ctx.saved_tensors
         T = ctx.T
         BT, H = out.shape
-        B = BT // T
-        g_out = g_out.contiguous()
-        dG = torch.empty((BT, 4 * H), device=x.device, dtype=torch.float32)
-        dG3 = dG.view(B, T, 4 * H)
-        dc = [torch.empty((B, H), device=x.device, dtype=torch.float32) for _ in range(2)]
-        st = _stream(x)
-        d_ptr = dones.data_ptr() if ctx.has_dones else None
-        g_rec = None
-        dc_next = None
-        for t in reversed(range(T)):
-            dn = (d_ptr + t + 1) if (d_ptr is not None and t < T - 1) else None
-            _check(lib.vine_lstm_cell_backward(
-                B, H, g_out.data_ptr() + 4 * (t * H), T * H, g_rec.data_ptr() if g_rec is not None else None,
-                dc_next.data_ptr() if dc_next is not None else None, dn, T, gates[t].data_ptr(),
-                c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
-                dG.data_ptr() + 4 * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(), st), "vine_lstm_cell_backward")
-            dc_next = dc[t & 1]
-            if t > 0:
-                g_rec = dG3[:, t].mm(w_hh)
-        # masked previous hidden state of every step, sequence-major like dG
-        hp = torch.cat([h0.unsqueeze(1), out.view(B, T, H)[:, :-1]], dim=1)
-        if ctx.has_dones:
-            hp = hp * (1.0 - dones.view(B, T, 1).to(hp.dtype))
-        hp = hp.reshape(BT, H)
+        dG, bias_partial = _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones if ctx.has_dones else None, T)
         gx = dG.mm(w_ih) if ctx.needs_input_grad[0] else None
         s_ih, s_hh, s_bi, s_bh = ctx.slots
         g_ih = splitk_tn(dG, x, out=s_ih)
-        g_hh = splitk_tn(dG, hp, out=s_hh)
+        g_hh = splitk_tn(dG, hp.view(BT, H), out=s_hh)
+        gb = _sum_rows(bias_partial, dG, out=s_bi)
         if s_bi is not None and s_bh is not None:
-            torch.sum(dG, 0, out=s_bi)
             s_bh.copy_(s_bi)
             gbi = gbh = None
         else:
-            gbi = gbh = dG.sum(0)
+            gbi = gbh = gb
         return (gx, None if s_ih is not None else g_ih, None if s_hh is not None else g_hh, gbi, gbh,
                 None, None, None, None)
 
@@ -189,6 +220,149 @@ def lstm_sequence(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
             dones = dones.to(torch.uint8).contiguous()
         return _LSTMSeq.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T)
     return _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T)
+
+
+# --------------------------------------------------------------------------- whole actor-critic trunk
+class _Trunk(torch.autograd.Function):
+    """The training forward/backward of the Vine5LinkMovingBasePPO network as ONE autograd node:
+    obs -> [Linear+ELU]*L -> concat obs -> LSTM(T steps) -> LayerNorm -> [mu | value] heads (one GEMM).
+    Every GEMM stays in hipBLASLt; everything between them is a hand-written kernel of csrc/ppo_kernels.hip, and the
+    backward is written out by hand so that
+      * weight gradients are split-K GEMMs written straight into the optimiser's flat gradient block,
+      * bias / LayerNorm-parameter gradients come from per-workgroup partial sums the pointwise backward kernels
+        emit anyway (no extra pass over the activations),
+      * only the MLP columns of the LSTM input gradient are computed (the observation columns need none),
+      * both heads share one forward GEMM, one input-gradient GEMM and one weight-gradient GEMM.
+    Argument order: obs_n, h0, c0, dones, T, concat, n_mlp, then parameters
+    (W_1, b_1, ..., W_L, b_L, w_ih, w_hh, b_ih, b_hh, ln_gamma, ln_beta, ln_eps, mu_w, mu_b, v_w, v_b)."""
+
+    @staticmethod
+    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, *params):
+        lib = _lib()
+        mlp = [(params[2 * i], params[2 * i + 1]) for i in range(n_mlp)]
+        w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, ln_eps, mu_w, mu_b, v_w, v_b = params[2 * n_mlp:]
+        n, F_in = obs_n.shape
+        dev = obs_n.device
+        st = _stream(obs_n)
+        obs_n = obs_n.contiguous()
+        U = mlp[-1][0].shape[0]
+        width = U + (F_in if concat else 0)
+        # rows padded to 64 B so that every row (and the column block the ELU kernel addresses) is float4-aligned
+        xcat = torch.empty((n, (width + 15) // 16 * 16), device=dev, dtype=torch.float32)[:, :width]
+        acts = []
+        x = obs_n
+        for i, (W, b) in enumerate(mlp):
+            z = torch.addmm(b, x, W.t())
+            if i < n_mlp - 1:
+                x = F.elu_(z)
+                acts.append(x)
+            else:
+                torch.ops.aten.elu.out(z, out=xcat[:, :U])
+        if concat:
+            xcat[:, U:].copy_(obs_n)
+        H = w_hh.shape[1]
+        B = n // T
+        ig = xcat.mm(w_ih.t())
+        bias = b_ih + b_hh
+        out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh, bias, h0, c0, dones, T, True)
+        del ig
+        y = torch.empty_like(out)
+        mean = torch.empty(n, device=dev, dtype=torch.float32)
+        rstd = torch.empty(n, device=dev, dtype=torch.float32)
+        _check(lib.vine_layernorm_forward(n, H, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
+                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st), "vine_layernorm_forward")
+        w_heads = torch.cat([mu_w, v_w], 0)
+        heads = torch.addmm(torch.cat([mu_b, v_b], 0), y, w_heads.t())          # [n, A + 1] = [mu | value]
+        ctx.meta = (T, concat, n_mlp, U, float(ln_eps), mu_w.shape[0], dones is not None)
+        ctx.slots = [_grad_slot(p) if isinstance(p, torch.Tensor) else None for p in params]
+        ctx.pshapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in params]
+        ctx.save_for_backward(obs_n, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g,
+                              dones if dones is not None else obs_n.new_empty(0), *acts, *[W for W, _ in mlp])
+        hT = out.view(B, T, H)[:, T - 1].contiguous()
+        cT = c_all[T].clone()
+        ctx.mark_non_differentiable(hT, cT)
+        return heads, hT, cT
+
+    @staticmethod
+    def backward(ctx, g_heads, _gh, _gc):
+        from ..abi import PPO_PARTIAL_BLOCKS
+        lib = _lib()
+        T, concat, n_mlp, U, ln_eps, A, has_dones = ctx.meta
+        saved = ctx.saved_tensors
+        obs_n, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g, dones = saved[:14]
+        acts = list(saved[14:14 + n_mlp - 1])
+        weights = list(saved[14 + n_mlp - 1:])
+        slots = ctx.slots
+        n, H = out.shape
+        dev = out.device
+        st = _stream(out)
+        grads = [None] * len(slots)
+
+        def deliver(idx, write):
+            """Write a parameter gradient into its flat-block slot (autograd then gets None) or hand it back."""
+            if slots[idx] is not None:
+                write(slots[idx])
+            else:
+                grads[idx] = torch.empty(ctx.pshapes[idx], device=dev, dtype=torch.float32)
+                write(grads[idx])
+
+        base = 2 * n_mlp
+        # ---- heads: one weight-gradient GEMM, one input-gradient GEMM
+        g_heads = g_heads.contiguous()
+        gw = splitk_tn(g_heads, y)
+        gb = g_heads.sum(0)
+        deliver(base + 7, lambda o: o.copy_(gw[:A]))
+        deliver(base + 9, lambda o: o.copy_(gw[A:]))
+        deliver(base + 8, lambda o: o.copy_(gb[:A]))
+        deliver(base + 10, lambda o: o.copy_(gb[A:]))
+        dy = g_heads.mm(w_heads)
+        # ---- LayerNorm
+        d_out = torch.empty_like(out)
+        ln_part = torch.empty((PPO_PARTIAL_BLOCKS, 2 * H), device=dev, dtype=torch.float32)
+        _check(lib.vine_layernorm_backward(n, H, dy.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           ln_g.data_ptr(), d_out.data_ptr(), ln_part.data_ptr(), st),
+               "vine_layernorm_backward")
+        deliver(base + 4, lambda o: torch.sum(ln_part[:, :H], 0, out=o))
+        deliver(base + 5, lambda o: torch.sum(ln_part[:, H:], 0, out=o))
+        del dy
+        # ---- LSTM
+        dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T)
+        deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o))
+        deliver(base + 1, lambda o: splitk_tn(dG, hp.view(n, H), out=o))
+        deliver(base + 2, lambda o: _sum_rows(bias_partial, dG, out=o))
+        deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
+        g = dG.mm(w_ih[:, :U]) if concat else dG.mm(w_ih)        # only the MLP columns of the LSTM input need a gradient
+        del dG
+        # ---- MLP, last layer first: ELU' from the stored OUTPUT, bias gradient from the kernel's partial sums
+        for i in reversed(range(n_mlp)):
+            a = xcat if i == n_mlp - 1 else acts[i]
+            C = g.shape[1]
+            part = torch.empty((PPO_PARTIAL_BLOCKS, C), device=dev, dtype=torch.float32)
+            _check(lib.vine_elu_backward(n, C, g.data_ptr(), C, a.data_ptr(), a.stride(0), 1.0, g.data_ptr(), C,
+                                         part.data_ptr(), st), "vine_elu_backward")
+            x_in = acts[i - 1] if i > 0 else obs_n
+            deliver(2 * i, lambda o, g=g, x_in=x_in: splitk_tn(g, x_in, out=o))
+            deliver(2 * i + 1, lambda o, part=part: torch.sum(part, 0, out=o))
+            if i > 0:
+                g = g.mm(weights[i])
+        return (None, None, None, None, None, None, None, *grads)
+
+
+def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
+    """The fused trunk covers the reference's network (PY:10-40) on an MI355X in fp32."""
+    return (obs_n.is_cuda and obs_n.dtype == torch.float32 and torch.is_grad_enabled() and activation_is_elu and has_ln
+            and H in (256, 512, 1024) and all(u % 4 == 0 and 256 % (u // 4) == 0 for u in mlp_units)
+            and obs_n.shape[0] % T == 0 and obs_n.shape[0] >= 256)
+
+
+def trunk(obs_n, h0, c0, dones, T, concat, mlp_params, lstm_params, ln, heads):
+    """-> (heads [n, A+1] = [mu | value], hT, cT).  ``mlp_params`` = [(W, b), ...]; ``lstm_params`` =
+    (w_ih, w_hh, b_ih, b_hh); ``ln`` = (gamma, beta, eps); ``heads`` = (mu_w, mu_b, value_w, value_b)."""
+    if dones is not None:
+        dones = dones.to(torch.uint8).contiguous()
+    flat = [p for wb in mlp_params for p in wb]
+    return _Trunk.apply(obs_n, h0.contiguous(), c0.contiguous(), dones, T, bool(concat), len(mlp_params), *flat,
+                        *lstm_params, ln[0], ln[1], float(ln[2]), *heads)
 
 
 # --------------------------------------------------------------------------- PPO loss
@@ -220,22 +394,36 @@ def ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values,
 
 
 def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip,
-                   clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1):
+                   clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None):
     """One HIP kernel: returns (grad_mu [n,A], grad_value [n,1], grad_logstd [A], stats[8]) where the gradients are
-    d(loss)/d(.) of the same scalar loss as ``ppo_loss_reference``."""
+    d(loss)/d(.) of the same scalar loss as ``ppo_loss_reference``.  With ``heads`` ([n, A+1] = [mu | value], the
+    output of the fused trunk) mu/value are read from it in place and the first return value is the matching
+    [n, A+1] gradient (second is None)."""
     lib = _lib()
-    n, A = mu.shape
+    stats_dev = (heads if heads is not None else mu).device
+    args = [t.detach().contiguous() for t in (actions, old_neglogp, adv, old_values.reshape(-1), returns.reshape(-1),
+                                              old_mu, old_sigma)]
+    ls = logstd.detach().contiguous()
+    A = ls.shape[0]
+    grad_logstd = torch.empty(A, device=stats_dev, dtype=torch.float32)
+    stats = torch.empty(8, device=stats_dev, dtype=torch.float32)
+    scal = (float(e_clip), int(bool(clip_value)), float(critic_coef), float(entropy_coef), float(bounds_coef),
+            float(soft_bound))
+    if heads is not None:
+        hd = heads.detach()
+        assert hd.is_contiguous() and hd.shape[1] == A + 1
+        n = hd.shape[0]
+        g = torch.empty_like(hd)
+        _check(lib.vine_ppo_loss(n, A, hd.data_ptr(), ls.data_ptr(), hd.data_ptr() + 4 * A, *[a.data_ptr() for a in args],
+                                 *scal, g.data_ptr(), g.data_ptr() + 4 * A, grad_logstd.data_ptr(), stats.data_ptr(),
+                                 A + 1, A + 1, _stream(hd)), "vine_ppo_loss")
+        return g, None, grad_logstd, stats
+    n = mu.shape[0]
     mu_c = mu.detach().contiguous()
     val_c = value.detach().reshape(-1).contiguous()
     grad_mu = torch.empty_like(mu_c)
     grad_value = torch.empty_like(val_c)
-    grad_logstd = torch.empty(A, device=mu.device, dtype=torch.float32)
-    stats = torch.empty(8, device=mu.device, dtype=torch.float32)
-    args = [t.detach().contiguous() for t in (actions, old_neglogp, adv, old_values.reshape(-1), returns.reshape(-1),
-                                              old_mu, old_sigma)]
-    ls = logstd.detach().contiguous()
     _check(lib.vine_ppo_loss(n, A, mu_c.data_ptr(), ls.data_ptr(), val_c.data_ptr(), *[a.data_ptr() for a in args],
-                             float(e_clip), int(bool(clip_value)), float(critic_coef), float(entropy_coef),
-                             float(bounds_coef), float(soft_bound), grad_mu.data_ptr(), grad_value.data_ptr(),
-                             grad_logstd.data_ptr(), stats.data_ptr(), _stream(mu)), "vine_ppo_loss")
+                             *scal, grad_mu.data_ptr(), grad_value.data_ptr(), grad_logstd.data_ptr(),
+                             stats.data_ptr(), 0, 0, _stream(mu)), "vine_ppo_loss")
     return grad_mu, grad_value.view_as(value), grad_logstd, stats

@@ -85,6 +85,7 @@ class A2CNetwork(nn.Module):
             layers += [fused.SplitKLinear(in_size, u), act()]
             in_size = u
         self.actor_mlp = nn.Sequential(*layers)
+        self.activation_is_elu = act is nn.ELU
         self.rnn_units = int(rnn["units"])
         self.rnn_concat_input = bool(rnn.get("concat_input", False))
         rnn_in = in_size + (num_inputs if self.rnn_concat_input else 0)
@@ -107,6 +108,20 @@ class A2CNetwork(nn.Module):
     def get_default_rnn_state(self, batch, device=None):
         z = torch.zeros((1, batch, self.rnn_units), device=device)
         return (z, z.clone())
+
+    def forward_heads(self, obs, states, seq_length, dones):
+        """Training forward on the MI355X as one fused autograd node (learning/fused.py:_Trunk):
+        -> (heads [n, A+1] = [mu | value], states).  Caller checks ``fused.trunk_supported`` first."""
+        r = self.rnn.rnn
+        mlp = [(m.weight, m.bias) for m in self.actor_mlp if isinstance(m, nn.Linear)]
+        heads, h, c = fused.trunk(obs, states[0][0], states[1][0], dones, seq_length, self.rnn_concat_input, mlp,
+                                  (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0),
+                                  (self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
+                                  (self.mu.weight, self.mu.bias, self.value.weight, self.value.bias))
+        return heads, (h.unsqueeze(0), c.unsqueeze(0))
+
+    def trunk_supported(self, obs, seq_length):
+        return fused.trunk_supported(obs, self.units, self.activation_is_elu, self.rnn_units, self.rnn_ln, seq_length)
 
     def forward(self, obs, states, seq_length=1, dones=None):
         """obs [B, num_obs] ordered sequence-major (index = seq * seq_length + t)."""
@@ -151,11 +166,17 @@ class ModelA2CContinuousLogStd(nn.Module):
                 + logstd.sum(dim=-1))
 
     def forward_raw(self, input_dict):
-        """Training forward for the fused loss: (mu [n,A], value [n,1], logstd parameter [A], rnn states)."""
+        """Training forward for the fused loss: (mu [n,A], value [n,1], logstd parameter [A], rnn states, heads).
+        ``heads`` is the [n, A+1] = [mu | value] block when the fused trunk ran (mu/value are views of it), else None."""
         obs = self.norm_obs(input_dict["obs"])
-        mu, _logstd, value, states = self.a2c_network(obs, input_dict["rnn_states"], input_dict.get("seq_length", 1),
-                                                     input_dict.get("dones", None))
-        return mu, value, self.a2c_network.sigma, states
+        net = self.a2c_network
+        T = input_dict.get("seq_length", 1)
+        if net.trunk_supported(obs, T):
+            heads, states = net.forward_heads(obs, input_dict["rnn_states"], T, input_dict.get("dones", None))
+            A = net.mu.weight.shape[0]
+            return heads[:, :A], heads[:, A:], net.sigma, states, heads
+        mu, _logstd, value, states = net(obs, input_dict["rnn_states"], T, input_dict.get("dones", None))
+        return mu, value, net.sigma, states, None
 
     def forward(self, input_dict):
         is_train = input_dict.get("is_train", True)

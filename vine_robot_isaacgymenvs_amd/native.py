@@ -4,6 +4,7 @@ There is deliberately no CPU fallback: if the HIP extension is missing or no MI3
 visible, loading/creating fails loudly.
 """
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -15,14 +16,35 @@ SRC_PPO = os.path.join(_HERE, "csrc", "ppo_kernels.hip")
 LIB = os.path.join(_HERE, "libvine_hip.so")
 ARCH = "gfx950"
 
+FINGERPRINT = LIB + ".fingerprint"
+_INC = os.path.join(os.path.dirname(_HERE), "include")
+DEPS = [SRC, SRC_PPO, os.path.join(_INC, "vine.h"), os.path.join(_INC, "vine_ppo.h")]
+
 _lib = None
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources and the two ABI headers: what a built library must correspond to."""
+    h = hashlib.sha256()
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(os.environ.get("VINE_HIPCC_FLAGS", "").encode())
+    return h.hexdigest()
+
+
+def is_fresh():
+    try:
+        return os.path.exists(LIB) and open(FINGERPRINT).read().strip() == source_fingerprint()
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 (works without a GPU); output stays in-tree."""
-    inc = os.path.join(os.path.dirname(_HERE), "include")
-    deps = [SRC, SRC_PPO, os.path.join(inc, "vine.h"), os.path.join(inc, "vine_ppo.h")]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+    """hipcc cross-compiles for gfx950 (works without a GPU); output stays in-tree.  A sidecar fingerprint of the
+    sources is written next to the library: ``load()`` refuses to call into a library built from other sources
+    (a stale binary behind a changed C signature is a wild pointer on the GPU)."""
+    if not force and is_fresh():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-fno-slp-vectorize",
@@ -32,7 +54,11 @@ def build(force=False, verbose=False):
     extra = os.environ.get("VINE_HIPCC_FLAGS")       # experiments only (e.g. "-fslp-vectorize")
     if extra:
         cmd[-4:-4] = extra.split()      # after the default flags (before "-o"), so that they win
+    if os.path.exists(FINGERPRINT):
+        os.remove(FINGERPRINT)
     subprocess.check_call(cmd)
+    with open(FINGERPRINT, "w") as f:
+        f.write(source_fingerprint() + "\n")
     return LIB
 
 
@@ -47,6 +73,18 @@ def load():
             raise RuntimeError(
                 "libvine_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or vine_robot_isaacgymenvs_amd.native.build(); this package has no CPU fallback." % LIB)
+        if not is_fresh():
+            # sources changed since the build (or the sidecar is missing): rebuild in place when a compiler is
+            # here, otherwise stop -- never run a binary whose ABI may not match abi.py
+            if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+                import fcntl
+                with open(LIB + ".lock", "w") as lock:      # ranks of one job: one of them rebuilds, the others wait
+                    fcntl.flock(lock, fcntl.LOCK_EX)
+                    if not is_fresh():
+                        print("libvine_hip.so does not match the sources: rebuilding (hipcc, ~90 s)", flush=True)
+                        build(force=True)
+            else:
+                raise RuntimeError("libvine_hip.so was built from different sources and no hipcc is available")
         _lib = abi.declare_ppo(abi.declare(C.CDLL(LIB)))
     return _lib
 
