@@ -27,11 +27,12 @@ extern "C" {
  * igates rows are `ig_stride` floats apart (a [B, T, 4H] tensor viewed at time t), h_out rows `h_stride` apart.
  * gates_act (nullable, [B,4H]) receives the activated gates for the backward pass.
  * hp_next (nullable, rows h_stride apart) receives (1 - done_next[b]) * h': the masked hidden state step t+1
- * consumes, i.e. the operand of the recurrent weight gradient, so the backward pass need not rebuild it. */
+ * consumes, i.e. the operand of the recurrent weight gradient, so the backward pass need not rebuild it; stored
+ * as bfloat16 when hp_bf16 != 0 (mixed-precision update: GEMM operands in bf16, all arithmetic and state in fp32). */
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
-                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, float* hp_next,
-                           const uint8_t* done_next, int64_t done_next_stride, void* stream);
+                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* hp_next,
+                           const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, void* stream);
 
 /* Backward of the step above.
  *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
@@ -39,13 +40,14 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
  * keep_next = 1 - done_next.  Writes the pre-activation gate gradients (rows dg_stride apart) and the gradient
  * w.r.t. the masked c_{t-1} (dc_prev = dc * f).
  * bias_partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, 4H]) receives per-workgroup column sums of the gate gradients;
- * their sum over rows (and over the T steps) is the bias gradient -- deterministic, no atomics. */
+ * their sum over rows (and over the T steps) is the bias gradient -- deterministic, no atomics.
+ * dgates_bf16 != 0: the gate gradients (only ever GEMM operands) are stored as bfloat16. */
 #define VINE_PPO_PARTIAL_BLOCKS 512
 int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
                             const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
-                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev,
-                            float* bias_partial, void* stream);
+                            int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
+                            float* bias_partial, int32_t dgates_bf16, void* stream);
 
 /* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
  * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.
@@ -59,21 +61,38 @@ int vine_layernorm_backward(int64_t n, int64_t H, const float* dy, const float* 
 /* ELU backward from the layer OUTPUT a = elu(z) (PY:19 `activation: elu`): out = g * (a > 0 ? 1 : a + alpha); rows of
  * g / a / out are *_stride floats apart (so a column block of a wider matrix works); out may alias g.
  * partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, C]): per-workgroup column sums of out = the bias gradient of the
- * Linear in front of the activation.  C % 4 == 0 and C/4 divides 256. */
-int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, const float* a, int64_t a_stride,
-                      float alpha, float* out, int64_t out_stride, float* partial, void* stream);
+ * Linear in front of the activation.  C % 4 == 0 and C/4 divides 256.
+ * a_bf16 / out_bf16: `a` / `out` hold bfloat16 (the mixed-precision update keeps activations only as GEMM operands). */
+int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, const void* a, int64_t a_stride,
+                      float alpha, void* out, int64_t out_stride, float* partial, int32_t a_bf16, int32_t out_bf16,
+                      void* stream);
+
+/* Column sums of src [R, C] (rows row_stride floats apart), deterministic and without scratch memory: finishes the
+ * per-workgroup partial sums of the kernels above and the slices of the split-K weight gradients.
+ * out1 == NULL: out0[0:C] = sums.  out1 != NULL, dup == 0: columns [0, n0) -> out0, [n0, C) -> out1.
+ * dup != 0: all C sums to both out0 and out1 (the two LSTM bias vectors share one gradient). */
+int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride, float* out0, int64_t n0, float* out1,
+                     int32_t dup, void* stream);
+
+/* out = elu(z + bias) for z [n,C] packed fp32 (a GEMM output without epilogue); out rows out_stride apart, fp32 or
+ * bfloat16 (out_bf16). */
+int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float alpha, void* out, int64_t out_stride,
+                  int32_t out_bf16, void* stream);
 
 /* PPO loss of one minibatch of n samples with A action dims, forward AND backward in one pass:
  *   loss = mean(a_loss) + 0.5 * critic_coef * mean(c_loss) - entropy_coef * mean(entropy) + bounds_coef * mean(b_loss)
  * Outputs d(loss)/d(mu) [n,A], d(loss)/d(value) [n], d(loss)/d(logstd) [A] and
  * stats[8] = {mean a_loss, mean c_loss, mean b_loss, mean entropy, mean kl(old||new), loss, 0, 0}.
  * grad_logstd and stats are zeroed by the call.  Rows of mu / grad_mu are mu_stride floats apart and elements of
- * value / grad_value value_stride apart (0 = packed: A and 1), so both heads can live in one [n, A+1] GEMM output. */
+ * value / grad_value value_stride apart (0 = packed: A and 1), so both heads can live in one [n, A+1] GEMM output.
+ * grad_mu_bias [A] / grad_value_bias [1] (both or neither): the column sums of grad_mu / grad_value -- the gradients
+ * of the two head biases -- are ADDED to them (the optimiser leaves its gradient block zeroed after every step). */
 int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, const float* value, const float* actions,
                   const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
-                  float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, void* stream);
+                  float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
+                  float* grad_value_bias, void* stream);
 
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps
@@ -100,9 +119,11 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
  * moments): torch.optim.Adam arithmetic (rl_games: Adam(lr, eps=1e-8), common_agent.py:80) in ONE launch instead of a
  * multi-tensor kernel over 17 small tensors.  `lr` and `step` are device scalars (the adaptive-KL schedule updates lr
  * on the device; `step` is incremented by the kernel).  g is pre-scaled by grad_scale (1/world after the all-reduce)
- * and zeroed after use. */
+ * and zeroed after use.  bf16_shadow (nullable, n bfloat16): receives a bfloat16 copy of the updated parameters -- the
+ * GEMM operands of the mixed-precision update -- so no separate cast pass over the weights is needed. */
 int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
-                   float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+                   float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                   void* bf16_shadow, void* stream);
 
 /* rl_games' AdaptiveScheduler on device scalars (`schedule_type: legacy`, PY:64-66):
  * kl > 2*thr -> lr = max(lr/1.5, min_lr); kl < 0.5*thr -> lr = min(lr*1.5, max_lr).  kl_scale = 1/world. */

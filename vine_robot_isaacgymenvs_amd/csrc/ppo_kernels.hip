@@ -22,12 +22,34 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// bfloat16 storage (GEMM operands of the mixed-precision update; arithmetic stays fp32): round to nearest even
+typedef unsigned short bf16_t;
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+// 4 consecutive elements, fp32 or bf16 storage
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16),
+                       __uint_as_float(r.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 r;
+    r.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    r.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = r;
+}
+
+template <typename HP>
 __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ igates, long long ig_stride,
                                 const float* __restrict__ hgates, const float* __restrict__ bias,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
                                 long long done_stride, float* __restrict__ h_out, long long h_stride,
                                 float* __restrict__ c_out, float* __restrict__ gates_act,
-                                float* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
+                                HP* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
                                 long long done_next_stride) {
     const int H4 = H >> 2;
     const long long total = B * H4;
@@ -75,12 +97,13 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
     }
 }
 
+template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
                                 const unsigned char* __restrict__ done_next, long long done_next_stride,
                                 const float* __restrict__ gates_act, const float* __restrict__ c_new,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
-                                long long done_stride, float* __restrict__ dgates, long long dg_stride,
+                                long long done_stride, DG* __restrict__ dgates, long long dg_stride,
                                 float* __restrict__ dc_prev, float* __restrict__ bias_partial) {
     const int H4 = H >> 2;
     const long long total = B * H4;
@@ -123,7 +146,7 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
             dout[u] = d_o * go[u] * (1.0f - go[u]);
             dcp[u] = d_c * gf[u];
         }
-        float* dgp = dgates + b * dg_stride;
+        DG* dgp = dgates + b * dg_stride;
         st4(dgp + 0 * H + j, make_float4(di[0], di[1], di[2], di[3]));
         st4(dgp + 1 * H + j, make_float4(df[0], df[1], df[2], df[3]));
         st4(dgp + 2 * H + j, make_float4(dg[0], dg[1], dg[2], dg[3]));
@@ -255,11 +278,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long long n, const f
         partial[(long long)blockIdx.x * 2 * H + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// out = elu(z + bias): the activation of a Linear whose GEMM ran without an epilogue (bf16 operands, fp32 output)
+template <typename OT>
+__global__ __launch_bounds__(256) void bias_elu_kernel(long long n, int C, const float* __restrict__ z,
+                                                       const float* __restrict__ bias, float alpha,
+                                                       OT* __restrict__ out, long long out_stride) {
+    const int C4 = C >> 2;
+    const long long total = n * C4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx / C4;
+        const int j = (int)(idx - r * C4) << 2;
+        const float4 zv = ld4(z + r * C + j), bv = ld4(bias + j);
+        const float x[4] = {zv.x + bv.x, zv.y + bv.y, zv.z + bv.z, zv.w + bv.w};
+        float y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[u] = x[u] > 0.0f ? x[u] : alpha * (__expf(x[u]) - 1.0f);
+        st4(out + r * out_stride + j, make_float4(y[0], y[1], y[2], y[3]));
+    }
+}
+
 // ELU backward from the OUTPUT a = elu(z): dz = g * (a > 0 ? 1 : a + alpha), plus per-block column sums of dz
 // (= the bias gradient of the Linear that produced z).  C4 = C/4 threads per row, 256/C4 rows per block pass.
+template <typename AT, typename OT>
 __global__ __launch_bounds__(256) void elu_bwd_kernel(long long n, int C, const float* __restrict__ g, long long g_stride,
-                                                      const float* __restrict__ a, long long a_stride, float alpha,
-                                                      float* __restrict__ out, long long out_stride,
+                                                      const AT* __restrict__ a, long long a_stride, float alpha,
+                                                      OT* __restrict__ out, long long out_stride,
                                                       float* __restrict__ partial) {
     const int C4 = C >> 2;
     const int rows_per_pass = 256 / C4;
@@ -288,6 +332,67 @@ __global__ __launch_bounds__(256) void elu_bwd_kernel(long long n, int C, const 
     }
 }
 
+// Column sums of src [R, C] (rows row_stride apart): 64 columns x 4 row-lanes per workgroup, no atomics, no
+// zero-initialised scratch (ATen's multi-block reductions clear a semaphore buffer with a memset, and memset nodes did
+// not replay reliably inside hipGraphs).  Columns [0, n0) go to out0, columns [n0, C) to out1 (out1 == NULL: all to
+// out0); dup != 0 writes all C columns to both.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ src, long long R, long long C,
+                                                     long long row_stride, float* __restrict__ out0, long long n0,
+                                                     float* __restrict__ out1, int dup) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + cl;
+    float acc = 0.0f;
+    if (c < C)
+        for (long long r = rl; r < R; r += 4) acc += src[r * row_stride + c];
+    __shared__ float red[4][64];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        if (dup) { out0[c] = v; out1[c] = v; }
+        else if (out1 && c >= n0) out1[c - n0] = v;
+        else out0[c] = v;
+    }
+}
+
+// Tall-and-narrow variant (the [512..2048, <= 1024] partial-sum blocks): 16 columns x 64 row-lanes per workgroup so
+// that a few hundred columns still spread over enough CUs; same output conventions, same determinism.
+__global__ __launch_bounds__(1024) void colsum_tall_kernel(const float* __restrict__ src, long long R, long long C,
+                                                           long long row_stride, float* __restrict__ out0,
+                                                           long long n0, float* __restrict__ out1, int dup) {
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const long long c = (long long)blockIdx.x * 16 + cl;
+    float acc = 0.0f;
+    if (c < C)
+        for (long long r = rl; r < R; r += 64) acc += src[r * row_stride + c];
+    __shared__ float red[64][17];
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl < 8) {                                 // 8 partial sums per column, fixed order
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[rl * 8 + k][cl];
+        red[rl * 8][cl] = v;
+    }
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += red[k * 8][cl];
+        if (dup) { out0[c] = v; out1[c] = v; }
+        else if (out1 && c >= n0) out1[c - n0] = v;
+        else out0[c] = v;
+    }
+}
+
+__global__ void zero3_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb, float* __restrict__ c,
+                             int nc) {
+    const int t = threadIdx.x;
+    if (t < na) a[t] = 0.0f;
+    if (t < nb) b[t] = 0.0f;
+    if (c && t < nc) c[t] = 0.0f;
+}
+
 #define PPO_MAX_A 8
 __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const float* __restrict__ mu,
                                                        const float* __restrict__ logstd, const float* __restrict__ value,
@@ -299,7 +404,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        float soft_bound, float* __restrict__ grad_mu,
                                                        float* __restrict__ grad_value, float* __restrict__ grad_logstd,
                                                        float* __restrict__ stats, long long mu_stride,
-                                                       long long value_stride) {
+                                                       long long value_stride, float* __restrict__ grad_mu_bias,
+                                                       float* __restrict__ grad_value_bias) {
     // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
     // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
     const float inv_n = 1.0f / (float)n;
@@ -313,8 +419,9 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
     }
     const float ent = A * (0.5f + 0.9189385332046727f) + sum_ls;   // 0.5 + 0.5*log(2*pi) per dim + logstd
     float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                   // a, c, b, kl, (unused)
-    float gls[PPO_MAX_A];
+    float gls[PPO_MAX_A], gmb[PPO_MAX_A + 1];              // d/d logstd; column sums of the head gradients
     for (int k = 0; k < A; ++k) gls[k] = 0.0f;
+    for (int k = 0; k <= PPO_MAX_A; ++k) gmb[k] = 0.0f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float z2[PPO_MAX_A], dm[PPO_MAX_A], m[PPO_MAX_A];
         float nlp = 0.9189385332046727f * A + sum_ls;
@@ -346,13 +453,17 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
             c_loss = (R - v) * (R - v);
             dL_dv = 2.0f * (v - R);
         }
-        grad_value[i * value_stride] = 0.5f * critic_coef * dL_dv * inv_n;
+        const float gval = 0.5f * critic_coef * dL_dv * inv_n;
+        grad_value[i * value_stride] = gval;
+        gmb[PPO_MAX_A] += gval;
         float b_loss = 0.0f, kl = 0.0f;
         for (int k = 0; k < A; ++k) {
             const float hi = fmaxf(m[k] - soft_bound, 0.0f), lo = fminf(m[k] + soft_bound, 0.0f);
             b_loss += hi * hi + lo * lo;
             // d nlp / d mu = -(a - mu)/sigma^2 ; d nlp / d logstd = 1 - z^2
-            grad_mu[i * mu_stride + k] = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
+            const float gm = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
+            grad_mu[i * mu_stride + k] = gm;
+            gmb[k] += gm;
             gls[k] += dL_dnlp * (1.0f - z2[k]);
             const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
             const float c1 = __logf(os / sg[k] + 1e-5f);
@@ -362,19 +473,21 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         acc[0] += a_loss; acc[1] += c_loss; acc[2] += b_loss; acc[3] += kl;
     }
     // block reduction (wave shuffles, then LDS across the 4 waves), one atomic per block and quantity
-    __shared__ float red[4][5 + PPO_MAX_A];
+    constexpr int NRED = 5 + 2 * PPO_MAX_A + 1;
+    __shared__ float red[4][NRED];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float vals[5 + PPO_MAX_A];
+    float vals[NRED];
     for (int q = 0; q < 4; ++q) vals[q] = acc[q];
     vals[4] = 0.0f;
     for (int k = 0; k < PPO_MAX_A; ++k) vals[5 + k] = (k < A) ? gls[k] : 0.0f;
-    for (int q = 0; q < 5 + PPO_MAX_A; ++q) {
+    for (int k = 0; k <= PPO_MAX_A; ++k) vals[5 + PPO_MAX_A + k] = gmb[k];
+    for (int q = 0; q < NRED; ++q) {
         float x = vals[q];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
         if (lane == 0) red[wave][q] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 5 + PPO_MAX_A) {
+    if (threadIdx.x < NRED) {
         const int q = threadIdx.x;
         const float x = red[0][q] + red[1][q] + red[2][q] + red[3][q];
         if (q < 4) {
@@ -384,6 +497,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
             if (w != 0.0f) atomicAdd(&stats[5], w * mean);
         } else if (q >= 5 && q - 5 < A) {
             atomicAdd(&grad_logstd[q - 5], x);
+        } else if (grad_mu_bias && q >= 5 + PPO_MAX_A) {        // accumulated INTO the two bias gradients
+            const int k = q - 5 - PPO_MAX_A;
+            if (k < A) atomicAdd(&grad_mu_bias[k], x);
+            else if (k == PPO_MAX_A) atomicAdd(&grad_value_bias[0], x);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -395,7 +512,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
 
 __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, const float* __restrict__ lr_p, float* __restrict__ step_p,
-                            float beta1, float beta2, float eps, float wd, float gscale) {
+                            float beta1, float beta2, float eps, float wd, float gscale, bf16_t* __restrict__ shadow) {
     const float step = *step_p + 1.0f;                    // every thread reads the old value; block 0 writes it back
     const float lr = *lr_p;
     const float bc1 = 1.0f - __powf(beta1, step), bc2 = 1.0f - __powf(beta2, step);
@@ -416,6 +533,7 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restric
         st4(m + 4 * i, make_float4(ma[0], ma[1], ma[2], ma[3]));
         st4(v + 4 * i, make_float4(va[0], va[1], va[2], va[3]));
         st4(g + 4 * i, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        if (shadow) st4(shadow + 4 * i, make_float4(pa[0], pa[1], pa[2], pa[3]));   // bf16 copy for the GEMM operands
     }
     // tail (n not a multiple of 4)
     const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -424,6 +542,7 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restric
         float mt = beta1 * m[t] + (1.0f - beta1) * gr, vt = beta2 * v[t] + (1.0f - beta2) * gr * gr;
         p[t] -= step_size * mt / (sqrtf(vt) * inv_sqrt_bc2 + eps);
         m[t] = mt; v[t] = vt; g[t] = 0.0f;
+        if (shadow) shadow[t] = f2bf(p[t]);
     }
 }
 // the step counter is bumped by a separate 1-thread kernel AFTER the update (all blocks above read the old value)
@@ -581,24 +700,29 @@ extern "C" {
 
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
-                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, float* hp_next,
-                           const uint8_t* done_next, int64_t done_next_stride, void* stream) {
+                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* hp_next,
+                           const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, void* stream) {
     if (B <= 0 || H <= 0 || (H & 3) || (ig_stride & 3) || (h_stride & 3) || !igates || !hgates || !bias || !c_prev ||
         !h_out || !c_out)
         return VINE_ERR_INVALID_ARG;
     const int threads = 256;
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(grid_for(B * (H / 4), threads)), dim3(threads), 0, (hipStream_t)stream,
-                       (long long)B, (int)H, igates, (long long)ig_stride, hgates, bias, c_prev, done,
-                       (long long)done_stride, h_out, (long long)h_stride, c_out, gates_act, hp_next, done_next,
-                       (long long)done_next_stride);
+    const dim3 grid(grid_for(B * (H / 4), threads));
+    if (hp_bf16)
+        hipLaunchKernelGGL(lstm_fwd_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
+                           igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
+                           (long long)h_stride, c_out, gates_act, (bf16_t*)hp_next, done_next, (long long)done_next_stride);
+    else
+        hipLaunchKernelGGL(lstm_fwd_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
+                           igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
+                           (long long)h_stride, c_out, gates_act, (float*)hp_next, done_next, (long long)done_next_stride);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
 int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
                             const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
-                            int64_t done_stride, float* dgates, int64_t dg_stride, float* dc_prev,
-                            float* bias_partial, void* stream) {
+                            int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
+                            float* bias_partial, int32_t dgates_bf16, void* stream) {
     if (B <= 0 || H <= 0 || (H & 3) || (g_stride & 3) || (dg_stride & 3) || !g_out || !gates_act || !c_new || !c_prev ||
         !dgates || !dc_prev)
         return VINE_ERR_INVALID_ARG;
@@ -606,10 +730,16 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
     if (bias_partial && (H > 1024 || threads % (int)(H / 4) != 0)) return VINE_ERR_UNSUPPORTED;
     // with partial sums the grid is fixed: the caller's buffer has VINE_PPO_PARTIAL_BLOCKS rows
     const int blocks = bias_partial ? VINE_PPO_PARTIAL_BLOCKS : grid_for(B * (H / 4), threads);
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream,
-                       (long long)B, (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next,
-                       (long long)done_next_stride, gates_act, c_new, c_prev, done, (long long)done_stride, dgates,
-                       (long long)dg_stride, dc_prev, bias_partial);
+    if (dgates_bf16)
+        hipLaunchKernelGGL(lstm_bwd_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
+                           (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
+                           gates_act, c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates, (long long)dg_stride,
+                           dc_prev, bias_partial);
+    else
+        hipLaunchKernelGGL(lstm_bwd_kernel<float>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
+                           (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
+                           gates_act, c_new, c_prev, done, (long long)done_stride, (float*)dgates, (long long)dg_stride,
+                           dc_prev, bias_partial);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -637,13 +767,50 @@ int vine_layernorm_backward(int64_t n, int64_t H, const float* dy, const float* 
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, const float* a, int64_t a_stride,
-                      float alpha, float* out, int64_t out_stride, float* partial, void* stream) {
+int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, const void* a, int64_t a_stride,
+                      float alpha, void* out, int64_t out_stride, float* partial, int32_t a_bf16, int32_t out_bf16,
+                      void* stream) {
     if (n <= 0 || C <= 0 || !g || !a || !out || (g_stride & 3) || (a_stride & 3) || (out_stride & 3))
         return VINE_ERR_INVALID_ARG;
     if ((C & 3) || C > 1024 || 256 % (C / 4) != 0) return VINE_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(elu_bwd_kernel, dim3(VINE_PPO_PARTIAL_BLOCKS), dim3(256), 0, (hipStream_t)stream, (long long)n,
-                       (int)C, g, (long long)g_stride, a, (long long)a_stride, alpha, out, (long long)out_stride, partial);
+    const dim3 grid(VINE_PPO_PARTIAL_BLOCKS), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_ELU_BWD(AT, OT)                                                                                         \
+    hipLaunchKernelGGL((elu_bwd_kernel<AT, OT>), grid, block, 0, s, (long long)n, (int)C, g, (long long)g_stride,    \
+                       (const AT*)a, (long long)a_stride, alpha, (OT*)out, (long long)out_stride, partial)
+    if (a_bf16 && out_bf16) VINE_ELU_BWD(bf16_t, bf16_t);
+    else if (a_bf16) VINE_ELU_BWD(bf16_t, float);
+    else if (out_bf16) VINE_ELU_BWD(float, bf16_t);
+    else VINE_ELU_BWD(float, float);
+#undef VINE_ELU_BWD
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride, float* out0, int64_t n0, float* out1,
+                     int32_t dup, void* stream) {
+    if (R <= 0 || C <= 0 || !src || !out0 || row_stride < C || (dup && !out1) || n0 < 0 || n0 > C)
+        return VINE_ERR_INVALID_ARG;
+    const long long split = out1 && !dup ? n0 : C;
+    if (R >= 128 && C <= 8192)
+        hipLaunchKernelGGL(colsum_tall_kernel, dim3((unsigned)((C + 15) / 16)), dim3(1024), 0, (hipStream_t)stream, src,
+                           (long long)R, (long long)C, (long long)row_stride, out0, split, out1, (int)dup);
+    else
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src,
+                           (long long)R, (long long)C, (long long)row_stride, out0, split, out1, (int)dup);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float alpha, void* out, int64_t out_stride,
+                  int32_t out_bf16, void* stream) {
+    if (n <= 0 || C <= 0 || (C & 3) || (out_stride & 3) || !z || !bias || !out) return VINE_ERR_INVALID_ARG;
+    const int threads = 256;
+    const dim3 grid(grid_for(n * (C / 4), threads));
+    if (out_bf16)
+        hipLaunchKernelGGL(bias_elu_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)C, z,
+                           bias, alpha, (bf16_t*)out, (long long)out_stride);
+    else
+        hipLaunchKernelGGL(bias_elu_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)C, z,
+                           bias, alpha, (float*)out, (long long)out_stride);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -651,20 +818,24 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
-                  float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, void* stream) {
+                  float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
+                  float* grad_value_bias, void* stream) {
     if (n <= 0 || A <= 0 || A > PPO_MAX_A || !mu || !logstd || !value || !actions || !old_neglogp || !advantages ||
-        !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats)
+        !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats ||
+        ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)))
         return VINE_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(stats, 0, 8 * sizeof(float), s) != hipSuccess) return VINE_ERR_DEVICE;
-    if (hipMemsetAsync(grad_logstd, 0, A * sizeof(float), s) != hipSuccess) return VINE_ERR_DEVICE;
+    // accumulators are cleared by a kernel, not hipMemsetAsync: memset nodes of a few bytes did not survive repeated
+    // hipGraph replays intact on ROCm 7.0 (observed: alternate floats of `stats` left with stale data)
+    hipLaunchKernelGGL(zero3_kernel, dim3(1), dim3(64), 0, s, stats, 8, grad_logstd, (int)A, (float*)nullptr, 0);
     const int threads = 256;
     int blocks = (int)((n + threads - 1) / threads);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(threads), 0, s, (long long)n, (int)A, mu, logstd, value,
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats,
-                       (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1));
+                       (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1),
+                       grad_mu_bias, grad_value_bias);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -704,12 +875,13 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
 }
 
 int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
-                   float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+                   float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                   void* bf16_shadow, void* stream) {
     if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step) return VINE_ERR_INVALID_ARG;
     const int threads = 256;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, threads)), dim3(threads), 0, s, (long long)n, params, grads,
-                       exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale);
+                       exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale, (bf16_t*)bf16_shadow);
     hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }

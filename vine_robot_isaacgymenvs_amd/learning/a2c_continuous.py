@@ -177,14 +177,21 @@ class A2CAgent:
         self.value_bootstrap = config.get("value_bootstrap")
         self.reward_scale = config.get("reward_shaper", {}).get("scale_value", 1.0)
         self.reward_shift = config.get("reward_shaper", {}).get("shift_value", 0.0)
-        self.mixed_precision = bool(config.get("mixed_precision", False)) and self.is_cuda
-        self.amp_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[config.get("mixed_precision_dtype", "fp16")]
+        # mixed_precision (PY:53).  On the MI355X with the fused ops this is the hand-written mixed-precision update
+        # (`fused_mixed`): bfloat16 GEMM operands, fp32 accumulation, state, loss and optimiser -- no autocast, no
+        # GradScaler.  `mixed_precision_dtype: fp16` (or use_fused_ops: False) selects torch autocast instead, which is
+        # the reference's literal mechanism and slower than fp32 here.
+        want_mixed = bool(config.get("mixed_precision", False)) and self.is_cuda
+        mp_dtype = config.get("mixed_precision_dtype", "bf16")
+        self.use_fused = bool(config.get("use_fused_ops", True))
+        self.fused_mixed = want_mixed and self.use_fused and mp_dtype == "bf16"
+        self.mixed_precision = want_mixed and not self.fused_mixed          # the torch-autocast path
+        self.amp_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[mp_dtype]
         self.save_freq = config.get("save_frequency", 0)
         self.save_best_after = config.get("save_best_after", 100)
         self.print_stats = config.get("print_stats", True)
         self.games_to_track = config.get("games_to_track", 100)
         self.use_graphs = bool(config.get("use_graphs", False)) and self.is_cuda
-        self.use_fused = bool(config.get("use_fused_ops", True))
         self.schedule_type = config.get("schedule_type", "legacy")
         self.is_adaptive_lr = config["lr_schedule"] == "adaptive"
         self.kl_threshold = config.get("kl_threshold", 0.008)
@@ -222,6 +229,9 @@ class A2CAgent:
                                       weight_decay=config.get("weight_decay", 0.0))
             self.flat_grads = self.optimizer.flat_grads
             self.num_params = self.optimizer.num_params
+            if self.fused_mixed:
+                self.optimizer.enable_bf16_shadow()
+                self.model.a2c_network.op_weight_lookup = self.optimizer.shadow_of
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_grad_scaler)
 
         self.frame = 0
@@ -302,7 +312,7 @@ class A2CAgent:
         self.dones = torch.ones(N, device=dev, dtype=torch.uint8)
         self.game_rewards = DeviceAverageMeter(1, self.games_to_track, dev)
         self.game_lengths = DeviceAverageMeter(1, self.games_to_track, dev)
-        self.fused_rollout = self.is_cuda and self.use_fused and not self.mixed_precision
+        self.fused_rollout = self.is_cuda and self.use_fused and not self.mixed_precision   # fp32 inference
         if self.fused_rollout:
             # {rew_mean, rew_size, len_mean, len_size, tmp...}: written by vine_rollout_post; the meters are views
             self.meter = torch.zeros(8, **f32)
@@ -542,10 +552,27 @@ class A2CAgent:
         advantages = torch.sum(advantages, dim=1)
         if self.normalize_advantage:
             advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
-        self.dataset = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages,
-                        "returns": returns, "actions": batch["actions"], "obs": batch["obses"],
-                        "dones": batch["dones"], "rnn_states": batch["rnn_states"],
-                        "mu": batch["mus"].clone(), "sigma": batch["sigmas"].clone()}
+        ds = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages,
+              "returns": returns, "actions": batch["actions"], "obs": batch["obses"],
+              "dones": batch["dones"], "rnn_states": batch["rnn_states"],
+              "mu": batch["mus"], "sigma": batch["sigmas"]}
+        if self.use_graphs and self.is_cuda:
+            # persistent storage: the captured optimiser steps read their minibatch slices at fixed addresses
+            st = getattr(self, "_ds_static", None)
+            if st is None:
+                st = self._ds_static = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone())
+                                        for k, v in ds.items()}
+            else:
+                for k, v in ds.items():
+                    if isinstance(v, list):
+                        for dst, src in zip(st[k], v):
+                            dst.copy_(src)
+                    else:
+                        st[k].copy_(v)
+            self.dataset = st
+        else:
+            ds["mu"], ds["sigma"] = ds["mu"].clone(), ds["sigma"].clone()
+            self.dataset = ds
 
     def get_minibatch(self, idx):
         """Contiguous slices, no shuffling (rl_games PPODataset._get_item_rnn)."""
@@ -558,29 +585,40 @@ class A2CAgent:
         return mb
 
     # ------------------------------------------------------------------ update (R3, R4, R6)
-    def calc_gradients_fused(self, mb):
-        """GPU fp32 path: network forward, then ONE kernel for the whole PPO loss and its gradient w.r.t.
-        (mu, value, logstd); autograd carries on from there.  Same arithmetic as ``calc_gradients``."""
-        batch_dict = {"obs": mb["obs"], "rnn_states": mb["rnn_states"], "seq_length": self.seq_len, "dones": mb["dones"]}
+    def _fused_grad_half(self, mb, obs_n=None):
+        """Forward, ONE kernel for the whole PPO loss and its gradient w.r.t. the head outputs, hand-written backward
+        into the flat gradient block; the minibatch KL is parked next to the gradients so that one all-reduce
+        averages both.  -> (stats[8], mu, sigma)"""
+        net = self.model.a2c_network
+        hb = (net.mu.bias.grad, net.value.bias.grad)
+        ext = all(g is not None and g.is_cuda for g in hb)     # head-bias gradients straight from the loss kernel
+        batch_dict = {"obs": mb["obs"] if obs_n is None else obs_n, "obs_is_normalized": obs_n is not None,
+                      "rnn_states": mb["rnn_states"], "seq_length": self.seq_len, "dones": mb["dones"],
+                      "head_bias_external": ext}
         mu, value, logstd, _, heads = self.model.forward_raw(batch_dict)
         g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(
             mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
             mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef, self.entropy_coef,
-            self.bounds_loss_coef or 0.0, heads=heads)
+            self.bounds_loss_coef or 0.0, heads=heads, head_bias_grads=hb if (ext and heads is not None) else None)
         # the gradient block was left zeroed by the last Adam step
         if heads is not None:
             torch.autograd.backward([heads], [g_mu])            # g_mu is the [n, A+1] gradient of [mu | value]
         else:
             torch.autograd.backward([mu, value], [g_mu, g_val])
         self.model.a2c_network.sigma.grad.add_(g_ls)
+        self.optimizer.aux[0:1].copy_(stats[4:5])              # KL rides in the gradient all-reduce
+        mu_d = mu.detach()
+        sigma_d = torch.exp(logstd.detach()).expand_as(mu_d)
+        return stats, mu_d, sigma_d
+
+    def calc_gradients_fused(self, mb):
+        """GPU path (fp32 or bf16-operand GEMMs): same arithmetic as ``calc_gradients``."""
+        stats, mu_d, sigma_d = self._fused_grad_half(mb)
         kl = stats[4]
         if self.multi_gpu and not self.use_grad_scaler:
-            self.optimizer.aux[0:1].copy_(stats[4:5])          # KL rides in the gradient all-reduce
             self._kl_in_comm = True
             kl = self.optimizer.aux[0]
         self.truncate_gradients_and_step()
-        mu_d = mu.detach()
-        sigma_d = torch.exp(logstd.detach()).expand_as(mu_d)
         return stats[0], stats[1], stats[3], kl, stats[2], mu_d, sigma_d
 
     def calc_gradients(self, mb):
@@ -646,6 +684,7 @@ class A2CAgent:
         self.lr.copy_(new)
 
     def train_epoch(self):
+        self._epochs_run = getattr(self, "_epochs_run", 0) + 1
         t_play = time.time()
         self.set_eval()
         with torch.no_grad():
@@ -655,33 +694,108 @@ class A2CAgent:
         play_time = time.time() - t_play
         t_upd = time.time()
         self.set_train()
+        if self.fused_mixed:
+            # the Adam kernel keeps the bf16 operand copies current; this catches every other writer of the
+            # parameters (checkpoint restore, broadcast, user code) at the cost of one 0.8 MB copy per iteration
+            self.optimizer.refresh_shadow()
         self.curr_frames = batch.pop("played_frames")
         self.prepare_dataset(batch)
-        a_losses, c_losses, b_losses, entropies, kls = [], [], [], [], []
+        # loss statistics of every optimiser step: rows of [a_loss, c_loss, entropy, kl, b_loss] on the device
+        n_steps = self.mini_epochs_num * self.num_minibatches
+        if getattr(self, "_stat_rows", None) is None or self._stat_rows.shape[0] != n_steps:
+            self._stat_rows = torch.zeros((n_steps, 5), device=self.device, dtype=torch.float32)
+        rows = self._stat_rows
+        graphed = self._update_graphs_usable()
+        kl_global = graphed and self.multi_gpu       # rows hold the all-rank mean KL (it rode in the all-reduce)
         for mini_ep in range(self.mini_epochs_num):
-            ep_kls = []
             for i in range(self.num_minibatches):
+                row = mini_ep * self.num_minibatches + i
+                if graphed and self._update_step_graphed(i, rows[row]):
+                    continue
                 mb = self.get_minibatch(i)
                 a_loss, c_loss, entropy, kl, b_loss, cmu, csigma = self.calc_gradients(mb)
                 start, end = mb["range"]
                 self.dataset["mu"][start:end] = cmu.float()          # dataset.update_mu_sigma
                 self.dataset["sigma"][start:end] = csigma.float()
-                a_losses.append(a_loss); c_losses.append(c_loss); b_losses.append(b_loss)
-                entropies.append(entropy); ep_kls.append(kl)
+                in_comm = getattr(self, "_kl_in_comm", False)
+                kl_global = kl_global or in_comm
+                rows[row].copy_(torch.stack([a_loss, c_loss, entropy, kl / self.rank_size if in_comm else kl, b_loss]))
                 if self.is_adaptive_lr and self.schedule_type == "legacy":
                     self.update_lr_from_kl(kl)
-            av_kls = torch.stack(ep_kls).mean()
             if self.is_adaptive_lr and self.schedule_type == "standard":
-                self.update_lr_from_kl(av_kls)
-            kls.append(av_kls)
+                ep = rows[mini_ep * self.num_minibatches:(mini_ep + 1) * self.num_minibatches, 3].mean()
+                self._kl_in_comm = kl_global
+                self.update_lr_from_kl(ep * self.rank_size if kl_global else ep)
             if self.normalize_input:
                 self.model.running_mean_std.eval()   # statistics are updated during the first mini-epoch only
         if self.is_cuda:
             torch.cuda.synchronize(self.device)
         update_time = time.time() - t_upd
-        stats = {k: torch.stack(v).mean() for k, v in
-                 dict(a_loss=a_losses, c_loss=c_losses, b_loss=b_losses, entropy=entropies, kl=kls).items()}
+        m = rows.mean(0)
+        stats = {"a_loss": m[0], "c_loss": m[1], "entropy": m[2], "kl": m[3], "b_loss": m[4]}
         return play_time, update_time, stats
+
+    # ------------------------------------------------------------------ update as hipGraphs
+    def _update_graphs_usable(self):
+        """The optimiser step is ~105 launches of 5-30 us each: with bf16 GEMM operands (and nearly so in fp32) the
+        host cannot issue them as fast as the GPU retires them.  From the second iteration on (the first one runs
+        eagerly and warms every lazily initialised handle) each step is replayed from two hipGraphs:
+        A = forward + loss + backward, B = Adam + dataset/learning-rate update, with the RCCL all-reduce issued
+        between them outside any capture."""
+        return (self.use_graphs and self.is_cuda and self.use_fused and not self.mixed_precision
+                and not self.truncate_grads and self.is_adaptive_lr and self.schedule_type == "legacy"
+                and getattr(self, "_epochs_run", 0) > 1 and not getattr(self, "_update_graphs_failed", False))
+
+    def _update_step_graphed(self, i, row_out):
+        key = i
+        # observation normalisation (and, in the first mini-epoch, the running-statistics update with its
+        # multi-block reductions) stays outside the capture; the graph reads the result at a fixed address
+        games = self.minibatch_size // self.seq_len
+        obs_mb = self.dataset["obs"][i * games * self.seq_len:(i + 1) * games * self.seq_len]
+        if getattr(self, "_obs_n_static", None) is None:
+            self._obs_n_static = torch.empty_like(obs_mb)
+        self._obs_n_static.copy_(self.model.norm_obs(obs_mb))
+        rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
+        if rec is None:
+            try:
+                rec = self._capture_update_step(i, key)
+            except RuntimeError as err:      # capture refused: nothing has executed, run this and later steps eagerly
+                print("hipGraph capture of the optimiser step failed (%s); continuing with eager launches"
+                      % str(err)[:200])
+                self._update_graphs_failed = True
+                self._kl_in_comm = False
+                torch.cuda.synchronize(self.device)
+                return False
+        rec["A"].replay()
+        if self.multi_gpu:
+            dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)      # gradients + KL, RCCL over xGMI
+        rec["B"].replay()
+        row_out.copy_(rec["row"])
+        return True
+
+    def _capture_update_step(self, i, key):
+        if not hasattr(self, "_upd_graphs"):
+            self._upd_graphs = {}
+            self._upd_pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize(self.device)
+        gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = None if os.environ.get("VINE_UPD_POOL") == "separate" else self._upd_pool
+        with torch.cuda.graph(gA, pool=pool, capture_error_mode="thread_local"):
+            mb = self.get_minibatch(i)
+            stats, mu_d, sigma_d = self._fused_grad_half(mb, obs_n=self._obs_n_static)
+        with torch.cuda.graph(gB, pool=pool, capture_error_mode="thread_local"):
+            self.optimizer.step(grad_scale=1.0 / self.rank_size)
+            start, end = mb["range"]
+            self.dataset["mu"][start:end] = mu_d
+            self.dataset["sigma"][start:end] = sigma_d
+            kl = self.optimizer.aux[0]                          # sum over ranks after the all-reduce
+            self._kl_in_comm = True
+            self.update_lr_from_kl(kl)
+            row = torch.stack([stats[0], stats[1], stats[3], kl / self.rank_size, stats[2]])
+        rec = {"A": gA, "B": gB, "row": row, "keep": (mb, stats, mu_d, sigma_d)}
+        self._upd_graphs[key] = rec
+        return rec
+
 
     # ------------------------------------------------------------------ checkpoint (aux: resume)
     def get_full_state_weights(self):

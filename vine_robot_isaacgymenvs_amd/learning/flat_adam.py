@@ -42,10 +42,28 @@ class FlatAdam:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.param_groups = [{"params": self.params, "lr": self.lr, "betas": betas, "eps": eps,
                               "weight_decay": weight_decay}]
+        self.shadow = None          # bfloat16 copy of flat_params (GEMM operands of the mixed-precision update)
         self._lib = None
         if dev.type == "cuda":
             from .. import native
             self._lib = native.load()
+
+    def enable_bf16_shadow(self):
+        """Keep a bfloat16 copy of the parameter block: written by the Adam kernel itself after every step;
+        ``refresh_shadow`` after anything else touched the parameters (checkpoint load, broadcast)."""
+        self.shadow = self.flat_params.to(torch.bfloat16)
+        return self.shadow
+
+    def refresh_shadow(self):
+        if self.shadow is not None:
+            self.shadow.copy_(self.flat_params)
+
+    def shadow_of(self, p):
+        """The bfloat16 view matching parameter ``p`` (identity lookup)."""
+        for q, off in zip(self.params, self.offsets):
+            if q is p:
+                return self.shadow[off:off + p.numel()].view_as(p)
+        raise KeyError("parameter is not managed by this optimiser")
 
     def zero_grad(self, set_to_none=False):
         self.flat_grads.zero_()
@@ -57,6 +75,7 @@ class FlatAdam:
             rc = self._lib.vine_adam_step(self.numel, self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
                                           self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.lr.data_ptr(),
                                           self.step_t.data_ptr(), b1, b2, self.eps, self.weight_decay, float(grad_scale),
+                                          self.shadow.data_ptr() if self.shadow is not None else None,
                                           torch.cuda.current_stream(self.flat_params.device).cuda_stream)
             if rc != 0:
                 raise RuntimeError("vine_adam_step failed with status %d" % rc)
@@ -72,6 +91,7 @@ class FlatAdam:
         denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
         self.flat_params.sub_(self.exp_avg / denom * (self.lr / bc1))
         self.flat_grads.zero_()
+        self.refresh_shadow()
 
     # ---- torch.optim.Adam-compatible (de)serialisation
     def state_dict(self):

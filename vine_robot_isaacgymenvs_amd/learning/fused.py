@@ -34,6 +34,13 @@ def _check(rc, what):
         raise RuntimeError("%s failed with status %d" % (what, rc))
 
 
+def _mm(a, b):
+    """a @ b with an fp32 result: plain fp32 GEMM, or bf16 operands accumulated and written in fp32."""
+    if a.dtype == torch.bfloat16:
+        return torch.mm(a, b, out_dtype=torch.float32)
+    return a.mm(b)
+
+
 # --------------------------------------------------------------------------- split-K weight gradient
 def splitk_tn(dy, x, out=None):
     """``dy^T @ x`` for tall-skinny operands: dy [K, M], x [K, N] -> [M, N] (written into ``out`` when given)."""
@@ -42,10 +49,25 @@ def splitk_tn(dy, x, out=None):
     while K % (s * 2) == 0 and K // (s * 2) >= 1024 and s < 64:
         s *= 2
     if s == 1 or not dy.is_cuda:
+        if dy.dtype == torch.bfloat16:
+            r = torch.mm(dy.t(), x, out_dtype=torch.float32)
+            return out.copy_(r) if out is not None else r
         return torch.mm(dy.t(), x, out=out) if out is not None else dy.t().mm(x)
     # unflatten: also valid for operands whose rows are padded (a column block of a wider buffer)
-    part = torch.bmm(dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s)))
-    return torch.sum(part, 0, out=out) if out is not None else part.sum(0)
+    a, b = dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s))
+    part = torch.bmm(a, b, out_dtype=torch.float32) if dy.dtype == torch.bfloat16 else torch.bmm(a, b)
+    return column_sums(part, out if out is not None else torch.empty(part.shape[1:], device=part.device))
+
+
+def _splitk_parts(dy, x):
+    """The slices of ``splitk_tn`` before their sum: (s, part [s, M, N]) or (1, dy^T x [M, N])."""
+    K = dy.shape[0]
+    s = 1
+    while K % (s * 2) == 0 and K // (s * 2) >= 1024 and s < 64:
+        s *= 2
+    if s == 1 or not dy.is_cuda:
+        return 1, dy.t().mm(x)
+    return s, torch.bmm(dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s)))
 
 
 def _grad_slot(p):
@@ -106,7 +128,9 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
 
 def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
-    hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``)."""
+    hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
+    ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32."""
+    op = w_hh.dtype
     BT, H = ig.shape[0], w_hh.shape[1]
     B = BT // T
     dev = ig.device
@@ -114,34 +138,36 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
     c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
     c_all[0].copy_(c0)
     gates = torch.empty((T, B, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
-    hp = torch.empty((B, T, H), device=dev, dtype=torch.float32)
+    hp = torch.empty((B, T, H), device=dev, dtype=op)
     if dones is not None:
-        torch.mul(h0, (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)), out=hp[:, 0])
+        hp[:, 0].copy_(h0 * (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)))
     else:
         hp[:, 0].copy_(h0)
     st = _stream(ig)
     d_ptr = dones.data_ptr() if dones is not None else None
     w_hh_t = w_hh.t()
     for t in range(T):
-        hg = hp[:, t].mm(w_hh_t)
+        hg = _mm(hp[:, t], w_hh_t)
         last = t == T - 1
         # hg is already built from the masked state: no second masking inside the kernel (done = NULL), except for c
         _check(lib.vine_lstm_cell_forward(
             B, H, ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, hg.data_ptr(), bias.data_ptr(), c_all[t].data_ptr(),
             (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
             c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
-            None if last else hp.data_ptr() + 4 * ((t + 1) * H),
-            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, st), "vine_lstm_cell_forward")
+            None if last else hp.data_ptr() + hp.element_size() * ((t + 1) * H),
+            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, int(op == torch.bfloat16), st),
+            "vine_lstm_cell_forward")
     return out, c_all, gates, hp
 
 
 def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
-    """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials."""
+    """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials.
+    dG is only ever a GEMM operand: it is stored in ``w_hh``'s dtype (bfloat16 in the mixed-precision update)."""
     from ..abi import PPO_PARTIAL_BLOCKS
     B, H = c_all.shape[1], c_all.shape[2]
     dev = g_out.device
     g_out = g_out.contiguous()
-    dG = torch.empty((B * T, 4 * H), device=dev, dtype=torch.float32)
+    dG = torch.empty((B * T, 4 * H), device=dev, dtype=w_hh.dtype)
     dG3 = dG.view(B, T, 4 * H)
     dc = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
     use_partial = H <= 1024 and 256 % (H // 4) == 0
@@ -156,18 +182,41 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
             B, H, g_out.data_ptr() + 4 * (t * H), T * H, g_rec.data_ptr() if g_rec is not None else None,
             dc_next.data_ptr() if dc_next is not None else None, dn, T, gates[t].data_ptr(),
             c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
-            dG.data_ptr() + 4 * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(),
-            bias_partial[t].data_ptr() if use_partial else None, st), "vine_lstm_cell_backward")
+            dG.data_ptr() + dG.element_size() * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(),
+            bias_partial[t].data_ptr() if use_partial else None, int(dG.dtype == torch.bfloat16), st),
+            "vine_lstm_cell_backward")
         dc_next = dc[t & 1]
         if t > 0:
-            g_rec = dG3[:, t].mm(w_hh)
+            g_rec = _mm(dG3[:, t], w_hh)
     return dG, bias_partial
 
 
 def _sum_rows(partial, full, out=None):
     """Column sums: of the small per-workgroup ``partial`` block when the kernel produced one, else of ``full``."""
     src = partial.view(-1, partial.shape[-1]) if partial is not None else full
+    if src.is_cuda and src.dtype == torch.float32:
+        return column_sums(src, out)
     return torch.sum(src, 0, out=out) if out is not None else src.sum(0)
+
+
+def column_sums(src, out=None, out1=None, n0=0, dup=False):
+    """Sum over dim 0 of a [R, ...] fp32 tensor with the hand-written kernel (deterministic; unlike ATen's
+    multi-block reductions it needs no memset-cleared scratch, so it is safe inside a captured hipGraph).
+    ``out``/``out1``: see vine_column_sums (split at column n0, or ``dup`` to write both)."""
+    R = src.shape[0]
+    C = src.numel() // R
+    if src.dim() == 2:
+        flat = src if src.stride(1) == 1 else src.contiguous()
+    elif src[0].is_contiguous():          # [R, ...] whose slices are dense (possibly a column block): rows of C floats
+        flat = src.as_strided((R, C), (src.stride(0), 1))
+    else:
+        flat = src.reshape(R, C)
+    if out is None:
+        out = torch.empty(src.shape[1:], device=src.device, dtype=torch.float32)
+    _check(_lib().vine_column_sums(R, C, flat.data_ptr(), flat.stride(0), out.data_ptr(), int(n0),
+                                   out1.data_ptr() if out1 is not None else None, int(bool(dup)), _stream(src)),
+           "vine_column_sums")
+    return out
 
 
 class _LSTMSeq(torch.autograd.Function):
@@ -233,39 +282,57 @@ class _Trunk(torch.autograd.Function):
         emit anyway (no extra pass over the activations),
       * only the MLP columns of the LSTM input gradient are computed (the observation columns need none),
       * both heads share one forward GEMM, one input-gradient GEMM and one weight-gradient GEMM.
-    Argument order: obs_n, h0, c0, dones, T, concat, n_mlp, then parameters
+    Argument order: obs_n, h0, c0, dones, T, concat, n_mlp, op_weights (None, or the bfloat16 copies of
+    W_1..W_L, w_ih, w_hh for the mixed-precision update), then the parameters
     (W_1, b_1, ..., W_L, b_L, w_ih, w_hh, b_ih, b_hh, ln_gamma, ln_beta, ln_eps, mu_w, mu_b, v_w, v_b)."""
 
     @staticmethod
-    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, *params):
+    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, op_weights, head_bias_external, *params):
         lib = _lib()
         mlp = [(params[2 * i], params[2 * i + 1]) for i in range(n_mlp)]
         w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, ln_eps, mu_w, mu_b, v_w, v_b = params[2 * n_mlp:]
+        # GEMM operands: the fp32 parameters themselves, or their bfloat16 shadows (W_1..W_L, w_ih, w_hh)
+        mixed = op_weights is not None
+        op = torch.bfloat16 if mixed else torch.float32
+        Wop = list(op_weights[:n_mlp]) if mixed else [W for W, _ in mlp]
+        w_ih_op, w_hh_op = (op_weights[n_mlp], op_weights[n_mlp + 1]) if mixed else (w_ih, w_hh)
         n, F_in = obs_n.shape
         dev = obs_n.device
         st = _stream(obs_n)
-        obs_n = obs_n.contiguous()
+        x0 = obs_n.to(op).contiguous()
         U = mlp[-1][0].shape[0]
         width = U + (F_in if concat else 0)
-        # rows padded to 64 B so that every row (and the column block the ELU kernel addresses) is float4-aligned
-        xcat = torch.empty((n, (width + 15) // 16 * 16), device=dev, dtype=torch.float32)[:, :width]
+        # rows padded to 64 B so that every row (and the column block the ELU kernels address) is 16-B aligned
+        xcat = torch.empty((n, (width + 15) // 16 * 16), device=dev, dtype=op)[:, :width]
         acts = []
-        x = obs_n
+        x = x0
         for i, (W, b) in enumerate(mlp):
-            z = torch.addmm(b, x, W.t())
-            if i < n_mlp - 1:
-                x = F.elu_(z)
-                acts.append(x)
+            last = i == n_mlp - 1
+            if mixed:
+                z = _mm(x, Wop[i].t())
+                C_ = z.shape[1]
+                a = xcat if last else torch.empty((n, C_), device=dev, dtype=op)
+                _check(lib.vine_bias_elu(n, C_, z.data_ptr(), b.data_ptr(), 1.0, a.data_ptr(), a.stride(0), 1, st),
+                       "vine_bias_elu")
             else:
-                torch.ops.aten.elu.out(z, out=xcat[:, :U])
+                z = torch.addmm(b, x, W.t())
+                if last:
+                    torch.ops.aten.elu.out(z, out=xcat[:, :U])
+                else:
+                    a = F.elu_(z)
+            if not last:
+                acts.append(a)
+                x = a
         if concat:
             xcat[:, U:].copy_(obs_n)
         H = w_hh.shape[1]
         B = n // T
-        ig = xcat.mm(w_ih.t())
+        ig = _mm(xcat, w_ih_op.t())
         bias = b_ih + b_hh
-        out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh, bias, h0, c0, dones, T, True)
+        out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True)
         del ig
+        # LayerNorm and the two heads stay in fp32 in both modes (3 output columns: nothing to gain, and mu feeds
+        # the probability ratio directly)
         y = torch.empty_like(out)
         mean = torch.empty(n, device=dev, dtype=torch.float32)
         rstd = torch.empty(n, device=dev, dtype=torch.float32)
@@ -273,11 +340,11 @@ class _Trunk(torch.autograd.Function):
                                           y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st), "vine_layernorm_forward")
         w_heads = torch.cat([mu_w, v_w], 0)
         heads = torch.addmm(torch.cat([mu_b, v_b], 0), y, w_heads.t())          # [n, A + 1] = [mu | value]
-        ctx.meta = (T, concat, n_mlp, U, float(ln_eps), mu_w.shape[0], dones is not None)
+        ctx.meta = (T, concat, n_mlp, U, float(ln_eps), mu_w.shape[0], dones is not None, mixed, head_bias_external)
         ctx.slots = [_grad_slot(p) if isinstance(p, torch.Tensor) else None for p in params]
         ctx.pshapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in params]
-        ctx.save_for_backward(obs_n, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g,
-                              dones if dones is not None else obs_n.new_empty(0), *acts, *[W for W, _ in mlp])
+        ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g,
+                              dones if dones is not None else obs_n.new_empty(0), *acts, *Wop)
         hT = out.view(B, T, H)[:, T - 1].contiguous()
         cT = c_all[T].clone()
         ctx.mark_non_differentiable(hT, cT)
@@ -287,9 +354,9 @@ class _Trunk(torch.autograd.Function):
     def backward(ctx, g_heads, _gh, _gc):
         from ..abi import PPO_PARTIAL_BLOCKS
         lib = _lib()
-        T, concat, n_mlp, U, ln_eps, A, has_dones = ctx.meta
+        T, concat, n_mlp, U, ln_eps, A, has_dones, mixed, head_bias_external = ctx.meta
         saved = ctx.saved_tensors
-        obs_n, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g, dones = saved[:14]
+        x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g, dones = saved[:14]
         acts = list(saved[14:14 + n_mlp - 1])
         weights = list(saved[14 + n_mlp - 1:])
         slots = ctx.slots
@@ -309,12 +376,13 @@ class _Trunk(torch.autograd.Function):
         base = 2 * n_mlp
         # ---- heads: one weight-gradient GEMM, one input-gradient GEMM
         g_heads = g_heads.contiguous()
-        gw = splitk_tn(g_heads, y)
-        gb = g_heads.sum(0)
-        deliver(base + 7, lambda o: o.copy_(gw[:A]))
-        deliver(base + 9, lambda o: o.copy_(gw[A:]))
-        deliver(base + 8, lambda o: o.copy_(gb[:A]))
-        deliver(base + 10, lambda o: o.copy_(gb[A:]))
+        s_heads, part = _splitk_parts(g_heads, y)                 # [s, A+1, H] slices of the weight gradient
+        deliver(base + 7, lambda o: column_sums(part[:, :A], o) if s_heads > 1 else o.copy_(part[:A]))
+        deliver(base + 9, lambda o: column_sums(part[:, A:], o) if s_heads > 1 else o.copy_(part[A:]))
+        if not head_bias_external:      # else: the loss kernel has already added them into the two bias gradients
+            gb = g_heads.sum(0)
+            deliver(base + 8, lambda o: o.copy_(gb[:A]))
+            deliver(base + 10, lambda o: o.copy_(gb[A:]))
         dy = g_heads.mm(w_heads)
         # ---- LayerNorm
         d_out = torch.empty_like(out)
@@ -322,30 +390,37 @@ class _Trunk(torch.autograd.Function):
         _check(lib.vine_layernorm_backward(n, H, dy.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                            ln_g.data_ptr(), d_out.data_ptr(), ln_part.data_ptr(), st),
                "vine_layernorm_backward")
-        deliver(base + 4, lambda o: torch.sum(ln_part[:, :H], 0, out=o))
-        deliver(base + 5, lambda o: torch.sum(ln_part[:, H:], 0, out=o))
+        if slots[base + 4] is not None and slots[base + 5] is not None:
+            column_sums(ln_part, slots[base + 4], out1=slots[base + 5], n0=H)     # {d gamma | d beta} in one launch
+        else:
+            deliver(base + 4, lambda o: column_sums(ln_part[:, :H], o))
+            deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
         del dy
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T)
         deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o))
         deliver(base + 1, lambda o: splitk_tn(dG, hp.view(n, H), out=o))
-        deliver(base + 2, lambda o: _sum_rows(bias_partial, dG, out=o))
-        deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
-        g = dG.mm(w_ih[:, :U]) if concat else dG.mm(w_ih)        # only the MLP columns of the LSTM input need a gradient
+        if bias_partial is not None and slots[base + 2] is not None and slots[base + 3] is not None:
+            column_sums(bias_partial.view(-1, 4 * H), slots[base + 2], out1=slots[base + 3], dup=True)
+        else:
+            deliver(base + 2, lambda o: _sum_rows(bias_partial, dG.float(), out=o))
+            deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
+        g = _mm(dG, w_ih[:, :U] if concat else w_ih)        # only the MLP columns of the LSTM input need a gradient
         del dG
         # ---- MLP, last layer first: ELU' from the stored OUTPUT, bias gradient from the kernel's partial sums
         for i in reversed(range(n_mlp)):
             a = xcat if i == n_mlp - 1 else acts[i]
-            C = g.shape[1]
-            part = torch.empty((PPO_PARTIAL_BLOCKS, C), device=dev, dtype=torch.float32)
-            _check(lib.vine_elu_backward(n, C, g.data_ptr(), C, a.data_ptr(), a.stride(0), 1.0, g.data_ptr(), C,
-                                         part.data_ptr(), st), "vine_elu_backward")
-            x_in = acts[i - 1] if i > 0 else obs_n
-            deliver(2 * i, lambda o, g=g, x_in=x_in: splitk_tn(g, x_in, out=o))
-            deliver(2 * i + 1, lambda o, part=part: torch.sum(part, 0, out=o))
+            C_ = g.shape[1]
+            part = torch.empty((PPO_PARTIAL_BLOCKS, C_), device=dev, dtype=torch.float32)
+            gz = torch.empty((n, C_), device=dev, dtype=torch.bfloat16) if mixed else g     # fp32: in place
+            _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
+                                         part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
+            x_in = acts[i - 1] if i > 0 else x0
+            deliver(2 * i, lambda o, gz=gz, x_in=x_in: splitk_tn(gz, x_in, out=o))
+            deliver(2 * i + 1, lambda o, part=part: column_sums(part, o))
             if i > 0:
-                g = g.mm(weights[i])
-        return (None, None, None, None, None, None, None, *grads)
+                g = _mm(gz, weights[i])
+        return (None, None, None, None, None, None, None, None, None, *grads)
 
 
 def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
@@ -355,13 +430,20 @@ def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
             and obs_n.shape[0] % T == 0 and obs_n.shape[0] >= 256)
 
 
-def trunk(obs_n, h0, c0, dones, T, concat, mlp_params, lstm_params, ln, heads):
+def trunk(obs_n, h0, c0, dones, T, concat, mlp_params, lstm_params, ln, heads, op_weights=None,
+          head_bias_external=False):
     """-> (heads [n, A+1] = [mu | value], hT, cT).  ``mlp_params`` = [(W, b), ...]; ``lstm_params`` =
-    (w_ih, w_hh, b_ih, b_hh); ``ln`` = (gamma, beta, eps); ``heads`` = (mu_w, mu_b, value_w, value_b)."""
+    (w_ih, w_hh, b_ih, b_hh); ``ln`` = (gamma, beta, eps); ``heads`` = (mu_w, mu_b, value_w, value_b).
+    ``op_weights`` = bfloat16 copies of (W_1, ..., W_L, w_ih, w_hh) selects the mixed-precision update: those GEMMs
+    take bf16 operands (fp32 accumulate and output), activations exist only as bf16 GEMM operands; LSTM cell state,
+    gates, LayerNorm, heads, loss, gradients w.r.t. parameters and the optimiser stay fp32.
+    ``head_bias_external``: the caller obtains the two head-bias gradients elsewhere (the PPO loss kernel adds them to
+    the parameters' gradient slots), so the backward skips that column sum over all n rows."""
     if dones is not None:
         dones = dones.to(torch.uint8).contiguous()
     flat = [p for wb in mlp_params for p in wb]
-    return _Trunk.apply(obs_n, h0.contiguous(), c0.contiguous(), dones, T, bool(concat), len(mlp_params), *flat,
+    return _Trunk.apply(obs_n, h0.contiguous(), c0.contiguous(), dones, T, bool(concat), len(mlp_params),
+                        tuple(op_weights) if op_weights is not None else None, bool(head_bias_external), *flat,
                         *lstm_params, ln[0], ln[1], float(ln[2]), *heads)
 
 
@@ -394,11 +476,12 @@ def ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values,
 
 
 def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip,
-                   clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None):
+                   clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None, head_bias_grads=None):
     """One HIP kernel: returns (grad_mu [n,A], grad_value [n,1], grad_logstd [A], stats[8]) where the gradients are
     d(loss)/d(.) of the same scalar loss as ``ppo_loss_reference``.  With ``heads`` ([n, A+1] = [mu | value], the
     output of the fused trunk) mu/value are read from it in place and the first return value is the matching
-    [n, A+1] gradient (second is None)."""
+    [n, A+1] gradient (second is None).  ``head_bias_grads`` = (mu.bias.grad, value.bias.grad): the kernel adds the
+    column sums of the head gradients to them (they must hold zeros, as the optimiser leaves them)."""
     lib = _lib()
     stats_dev = (heads if heads is not None else mu).device
     args = [t.detach().contiguous() for t in (actions, old_neglogp, adv, old_values.reshape(-1), returns.reshape(-1),
@@ -416,7 +499,9 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
         g = torch.empty_like(hd)
         _check(lib.vine_ppo_loss(n, A, hd.data_ptr(), ls.data_ptr(), hd.data_ptr() + 4 * A, *[a.data_ptr() for a in args],
                                  *scal, g.data_ptr(), g.data_ptr() + 4 * A, grad_logstd.data_ptr(), stats.data_ptr(),
-                                 A + 1, A + 1, _stream(hd)), "vine_ppo_loss")
+                                 A + 1, A + 1, head_bias_grads[0].data_ptr() if head_bias_grads else None,
+                                 head_bias_grads[1].data_ptr() if head_bias_grads else None, _stream(hd)),
+               "vine_ppo_loss")
         return g, None, grad_logstd, stats
     n = mu.shape[0]
     mu_c = mu.detach().contiguous()
@@ -425,5 +510,5 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     grad_value = torch.empty_like(val_c)
     _check(lib.vine_ppo_loss(n, A, mu_c.data_ptr(), ls.data_ptr(), val_c.data_ptr(), *[a.data_ptr() for a in args],
                              *scal, grad_mu.data_ptr(), grad_value.data_ptr(), grad_logstd.data_ptr(),
-                             stats.data_ptr(), 0, 0, _stream(mu)), "vine_ppo_loss")
+                             stats.data_ptr(), 0, 0, None, None, _stream(mu)), "vine_ppo_loss")
     return grad_mu, grad_value.view_as(value), grad_logstd, stats

@@ -86,6 +86,8 @@ class A2CNetwork(nn.Module):
             in_size = u
         self.actor_mlp = nn.Sequential(*layers)
         self.activation_is_elu = act is nn.ELU
+        # set by the agent for `mixed_precision: True`: parameter -> its bfloat16 shadow (learning/flat_adam.py)
+        self.op_weight_lookup = None
         self.rnn_units = int(rnn["units"])
         self.rnn_concat_input = bool(rnn.get("concat_input", False))
         rnn_in = in_size + (num_inputs if self.rnn_concat_input else 0)
@@ -109,15 +111,20 @@ class A2CNetwork(nn.Module):
         z = torch.zeros((1, batch, self.rnn_units), device=device)
         return (z, z.clone())
 
-    def forward_heads(self, obs, states, seq_length, dones):
+    def forward_heads(self, obs, states, seq_length, dones, head_bias_external=False):
         """Training forward on the MI355X as one fused autograd node (learning/fused.py:_Trunk):
         -> (heads [n, A+1] = [mu | value], states).  Caller checks ``fused.trunk_supported`` first."""
         r = self.rnn.rnn
         mlp = [(m.weight, m.bias) for m in self.actor_mlp if isinstance(m, nn.Linear)]
+        op_weights = None
+        if self.op_weight_lookup is not None:      # mixed precision: bf16 shadows kept by the optimiser
+            op_weights = [self.op_weight_lookup(w) for w, _ in mlp] + [self.op_weight_lookup(r.weight_ih_l0),
+                                                                       self.op_weight_lookup(r.weight_hh_l0)]
         heads, h, c = fused.trunk(obs, states[0][0], states[1][0], dones, seq_length, self.rnn_concat_input, mlp,
                                   (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0),
                                   (self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
-                                  (self.mu.weight, self.mu.bias, self.value.weight, self.value.bias))
+                                  (self.mu.weight, self.mu.bias, self.value.weight, self.value.bias),
+                                  op_weights=op_weights, head_bias_external=head_bias_external)
         return heads, (h.unsqueeze(0), c.unsqueeze(0))
 
     def trunk_supported(self, obs, seq_length):
@@ -167,12 +174,15 @@ class ModelA2CContinuousLogStd(nn.Module):
 
     def forward_raw(self, input_dict):
         """Training forward for the fused loss: (mu [n,A], value [n,1], logstd parameter [A], rnn states, heads).
-        ``heads`` is the [n, A+1] = [mu | value] block when the fused trunk ran (mu/value are views of it), else None."""
-        obs = self.norm_obs(input_dict["obs"])
+        ``heads`` is the [n, A+1] = [mu | value] block when the fused trunk ran (mu/value are views of it), else None.
+        ``obs_is_normalized``: ``obs`` already went through ``norm_obs`` (the captured optimiser step keeps the
+        running-statistics update outside the hipGraph); ``head_bias_external``: see ``fused.trunk``."""
+        obs = input_dict["obs"] if input_dict.get("obs_is_normalized", False) else self.norm_obs(input_dict["obs"])
         net = self.a2c_network
         T = input_dict.get("seq_length", 1)
         if net.trunk_supported(obs, T):
-            heads, states = net.forward_heads(obs, input_dict["rnn_states"], T, input_dict.get("dones", None))
+            heads, states = net.forward_heads(obs, input_dict["rnn_states"], T, input_dict.get("dones", None),
+                                              input_dict.get("head_bias_external", False))
             A = net.mu.weight.shape[0]
             return heads[:, :A], heads[:, A:], net.sigma, states, heads
         mu, _logstd, value, states = net(obs, input_dict["rnn_states"], T, input_dict.get("dones", None))
