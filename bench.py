@@ -39,10 +39,12 @@ def parse_args():
     p.add_argument("--obs-type", default="POS_AND_FD_VEL_AND_OBJ_INFO")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="ppo mode: skip the run in the other update precision")
     p.add_argument("--no-saturated", action="store_true", help="skip the 2^20-env run of the step kernel")
     p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
     p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
-                   help="ppo mode: autocast dtype of the update (default: the train YAML: mixed_precision fp16)")
+                   help="ppo mode: update precision: off = fp32, bf16 = hand-written mixed precision (the packaged "
+                        "default, mixed_precision: True as in the reference YAML), fp16 = torch autocast + GradScaler")
     return p.parse_args()
 
 
@@ -274,6 +276,11 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
         }
         out.update(extra)
+        if str(extra.get("update_precision", "")).startswith("bf16"):
+            # env step kernel, LSTM/LayerNorm state, loss and optimiser compute in f32; the GEMMs of the PPO update
+            # take bf16 operands with f32 accumulation (the reference YAML's mixed_precision: True; it uses fp16
+            # autocast).  `other_precision` carries the same iteration with an all-f32 update.
+            out["dtype"] = "f32 (env step, state, loss, optimiser) + bf16 GEMM operands / f32 accumulate (PPO update)"
         if world == 1 and not args.no_saturated:
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:

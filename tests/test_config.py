@@ -91,8 +91,7 @@ def test_loader_reads_the_reference_yaml_files_unchanged():
     same resolved value, except the documented deviations."""
     ref = cf.load_config(overrides=["task=Vine5LinkMovingBase"], config_dir=REF_CFG)
     ours = cf.load_config()
-    deviations = {("task", "env", "CAPTURE_VIDEO"),
-                  ("train", "params", "config", "mixed_precision")}
+    deviations = {("task", "env", "CAPTURE_VIDEO")}
 
     def walk(a, b, path):
         for k, v in a.items():

@@ -182,7 +182,7 @@ def test_fused_update_equals_stock_update():
                                                       graphics_device_id=0, headless=True)
         params = cfg["train"]["params"]
         params["config"].update(write_files=False, print_stats=False, use_graphs=False, use_fused_ops=use_fused,
-                                mini_epochs=1)
+                                mini_epochs=1, mixed_precision=False)
         torch.manual_seed(0)
         agent = A2CAgent("t", params, vec_env=env)
         agent.init_tensors()

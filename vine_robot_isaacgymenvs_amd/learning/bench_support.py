@@ -81,7 +81,37 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         dist.all_gather(gathered, chk)
         in_sync = all(bool(torch.equal(g, gathered[0])) for g in gathered)
     frames = agent.horizon_length * agent.num_actors
+    precision = ("bf16 GEMM operands, f32 accumulate/state/loss/optimiser (mixed_precision: True, the reference YAML's "
+                 "value)" if agent.fused_mixed else
+                 "torch autocast %s" % conf.get("mixed_precision_dtype") if agent.mixed_precision else "f32")
+    other = None
+    if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
+        # the same PPO iteration with the update in the OTHER precision (fp32 <-> bf16 operands), same env, same
+        # process: reported beside the headline so that both numbers are always visible
+        conf2 = dict(conf)
+        conf2["mixed_precision"] = not agent.fused_mixed
+        params2 = dict(params)
+        params2["config"] = conf2
+        agent2 = A2CAgent("bench2", params2, vec_env=env)
+        agent2.init_tensors()
+        agent2.obs = agent2.env_reset()["obs"].to(agent2.device)
+        for _ in range(warmup):
+            agent2.train_epoch()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        p2 = u2 = 0.0
+        for _ in range(steps):
+            p, u, _s = agent2.train_epoch()
+            p2 += p
+            u2 += u
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        other = {"update_precision": "bf16 GEMM operands, f32 accumulate/state" if agent2.fused_mixed else "f32",
+                 "value": frames * steps / e2, "unit": "env-steps/s", "ppo_iters_per_sec": steps / e2,
+                 "rollout_ms": p2 / steps * 1e3, "update_ms": u2 / steps * 1e3}
     extra = {
+        "update_precision": precision,
+        "other_precision": other,
         "replicas_in_sync": in_sync,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
                      "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},
@@ -90,7 +120,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         "rollout_ms": play / steps * 1e3, "update_ms": upd / steps * 1e3,
         "ppo": {"horizon": agent.horizon_length, "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs_num,
                 "optimizer_steps_per_iter": agent.mini_epochs_num * agent.num_minibatches,
-                "params": agent.num_params, "mixed_precision": agent.mixed_precision,
-                "rollout_hipgraph": bool(conf["use_graphs"])},
+                "params": agent.num_params, "mixed_precision": bool(agent.fused_mixed or agent.mixed_precision),
+                "hipgraphs": bool(conf["use_graphs"]), "update_hipgraphs": len(getattr(agent, "_upd_graphs", {}))},
     }
     return elapsed, kernel_ms, frames, extra
