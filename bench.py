@@ -67,14 +67,18 @@ def make_env(args, rank, device_index):
 
 def pmc_traffic():
     """HBM bytes per launch of vine_step_kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/: separate FETCH_SIZE and WRITE_SIZE passes, KiB units).  bench.py cannot collect PMC itself."""
+    (profiles/: separate FETCH_SIZE and WRITE_SIZE passes, KiB units), with the gfx950 correction of
+    MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled; WRITE_SIZE
+    is exact.  Both factors were re-measured for this kernel's own access widths (4-B-per-lane SoA loads/stores,
+    float2/float4 row stores) on known byte counts: scripts/ubench/pmc_calib.hip, profiles/r01/pmc_calibration.txt.
+    bench.py cannot collect PMC itself."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")))
     if not files:
         return None
     try:
         d = json.load(open(files[-1]))
-        return (d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+        return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
     except (KeyError, ValueError):
         return None
 

@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--mode env --steps 300 --warmup 30 --no-cpu-baseline $@"
+ARGS="--mode env --steps 300 --warmup 30 --no-cpu-baseline --no-saturated $@"
 # 1) kernel trace + stats (the same command as the bench line)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 # 2) counters, each group in its own pass (no trace domains besides kernel-trace)
