@@ -60,6 +60,76 @@ def test_lstm_sequence_forward_backward(use_dones):
 
 
 @pytest.mark.gpu
+def test_pointwise_kernels_against_torch():
+    """vine_column_sums (wide and tall variants, split / duplicate outputs, padded rows), vine_layernorm_forward/
+    backward, vine_bias_elu and vine_elu_backward (fp32 and bfloat16 storage) against the torch ops they replace."""
+    import ctypes as C
+    from vine_robot_isaacgymenvs_amd.abi import PPO_PARTIAL_BLOCKS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    lib = fused._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    # column sums
+    for R, Cc in ((32, 1024 * 92), (2048, 1024), (512, 64), (7, 130), (300, 5)):
+        src = torch.randn(R, Cc + 6, device=dev)[:, :Cc]                      # padded rows
+        ref = src.double().sum(0)
+        out = fused.column_sums(src)
+        assert float((out.double() - ref).abs().max()) < 1e-4 * (1 + float(ref.abs().max()))
+        a, b = torch.empty(Cc // 2, device=dev), torch.empty(Cc - Cc // 2, device=dev)
+        fused.column_sums(src, a, out1=b, n0=Cc // 2)
+        assert torch.equal(torch.cat([a, b]), out)
+        a2, b2 = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        fused.column_sums(src, a2, out1=b2, dup=True)
+        assert torch.equal(a2, out) and torch.equal(b2, out)
+    part = torch.randn(16, 3, 256, device=dev)
+    assert torch.allclose(fused.column_sums(part[:, :2]), part[:, :2].sum(0), atol=1e-5)
+    # LayerNorm
+    n, H = 4099, 256
+    x = torch.randn(n, H, device=dev) * 2 + 0.5
+    g, b = torch.randn(H, device=dev), torch.randn(H, device=dev)
+    y, mean, rstd = torch.empty_like(x), torch.empty(n, device=dev), torch.empty(n, device=dev)
+    assert lib.vine_layernorm_forward(n, H, x.data_ptr(), g.data_ptr(), b.data_ptr(), 1e-5, y.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), st) == 0
+    xr = x.double().requires_grad_()
+    gr, br = g.double().requires_grad_(), b.double().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-5)
+    assert float((y.double() - yr).abs().max()) < 2e-5
+    dy = torch.randn(n, H, device=dev)
+    yr.backward(dy.double())
+    dx = torch.empty_like(x)
+    part = torch.empty(PPO_PARTIAL_BLOCKS, 2 * H, device=dev)
+    assert lib.vine_layernorm_backward(n, H, dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g.data_ptr(),
+                                       dx.data_ptr(), part.data_ptr(), st) == 0
+    assert float((dx.double() - xr.grad).abs().max()) < 5e-5
+    sums = fused.column_sums(part)
+    assert float((sums[:H].double() - gr.grad).abs().max()) < 1e-3 and float((sums[H:].double() - br.grad).abs().max()) < 1e-3
+    # bias + ELU forward, ELU backward from the output (fp32 and bf16 storage, strided rows)
+    for Cc in (64, 128, 256):
+        z, bias = torch.randn(n, Cc, device=dev), torch.randn(Cc, device=dev)
+        ref = torch.nn.functional.elu(z + bias)
+        wide = torch.zeros(n, Cc + 32, device=dev)
+        assert lib.vine_bias_elu(n, Cc, z.data_ptr(), bias.data_ptr(), 1.0, wide.data_ptr(), Cc + 32, 0, st) == 0
+        assert float((wide[:, :Cc] - ref).abs().max()) < 1e-6 and float(wide[:, Cc:].abs().max()) == 0.0
+        wb = torch.zeros(n, Cc + 32, device=dev, dtype=torch.bfloat16)
+        assert lib.vine_bias_elu(n, Cc, z.data_ptr(), bias.data_ptr(), 1.0, wb.data_ptr(), Cc + 32, 1, st) == 0
+        # round-to-nearest-even like torch; the fast exp may land an element on the other side of a rounding boundary
+        assert float(((wb[:, :Cc].float() - ref).abs() - ref.abs() * 2.0 ** -8).max()) < 1e-6
+        assert float((wb[:, :Cc] != ref.to(torch.bfloat16)).float().mean()) < 1e-3
+        gin = torch.randn(n, Cc, device=dev)
+        ref_g = gin * torch.where(ref > 0, torch.ones_like(ref), ref + 1.0)
+        for a_bf, o_bf in ((0, 0), (1, 1), (1, 0), (0, 1)):
+            a_t = wb if a_bf else wide
+            out = torch.empty(n, Cc, device=dev, dtype=torch.bfloat16 if o_bf else torch.float32)
+            part = torch.empty(PPO_PARTIAL_BLOCKS, Cc, device=dev)
+            assert lib.vine_elu_backward(n, Cc, gin.data_ptr(), Cc, a_t.data_ptr(), Cc + 32, 1.0, out.data_ptr(), Cc,
+                                         part.data_ptr(), a_bf, o_bf, st) == 0
+            tol = 2e-2 if (a_bf or o_bf) else 1e-6
+            assert float((out.float() - ref_g).abs().max()) < tol * (1 + float(ref_g.abs().max()))
+            assert float((fused.column_sums(part) - ref_g.sum(0)).abs().max()) < (0.5 if a_bf else 1e-3)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_splitk_linear_gradients():
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
