@@ -9,8 +9,11 @@ MI355X-first choices (none changes the arithmetic):
     device scalar read by the fused Adam kernel -- no ``.item()`` inside an iteration;
   * gradients live in ONE flat buffer (``param.grad`` are views into it): the multi-GPU step is a single
     in-place RCCL all-reduce of 1.63 MB over xGMI per optimiser step, no concat / scatter copies;
-  * the 16-step rollout can be captured in one hipGraph (``use_graphs``): policy GEMMs + the fused env-step
-    kernel + bookkeeping replay with a single launch.
+  * the 16-step rollout is captured in one hipGraph (``use_graphs``): policy GEMMs + the fused env-step
+    kernel + bookkeeping replay with a single launch; from the second iteration on every optimiser step is two
+    hipGraph replays as well (forward/backward | Adam + schedule) with the all-reduce between them;
+  * ``mixed_precision: True`` (the reference YAML's value) = hand-written mixed precision: bfloat16 GEMM operands,
+    fp32 accumulation, state, loss and optimiser (learning/fused.py ``trunk``), not autocast.
 """
 import copy
 import os

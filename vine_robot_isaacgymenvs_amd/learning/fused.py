@@ -10,7 +10,12 @@ over the whole reduction.  Here:
   * ``lstm_sequence`` : ONE input-projection GEMM for all time steps, per step one recurrent GEMM + one fused
                         pointwise kernel (done-masking folded in); backward mirrors it, weight gradients by split-K;
   * ``ppo_loss``      : the whole PPO loss (surrogate, clipped value loss, bound loss, entropy, KL) forward AND
-                        backward in one kernel.
+                        backward in one kernel;
+  * ``trunk``         : the whole network (MLP -> LSTM -> LayerNorm -> heads) as ONE autograd node with a hand-written
+                        backward, in fp32 or with bfloat16 GEMM operands (``mixed_precision: True``); what the update
+                        actually runs.  The smaller ops above remain as building blocks, for networks the trunk does
+                        not cover, and as stepping stones of the numerics tests;
+  * ``column_sums``   : deterministic reductions over rows that are safe inside a captured hipGraph.
 On a CPU tensor every op falls back to the plain PyTorch composition it replaces (used by the gloo tests and as the
 fp32 reference of the numerics tests); on a GPU tensor the HIP kernels are mandatory.
 """
