@@ -28,11 +28,15 @@ extern "C" {
  * gates_act (nullable, [B,4H]) receives the activated gates for the backward pass.
  * hp_next (nullable, rows h_stride apart) receives (1 - done_next[b]) * h': the masked hidden state step t+1
  * consumes, i.e. the operand of the recurrent weight gradient, so the backward pass need not rebuild it; stored
- * as bfloat16 when hp_bf16 != 0 (mixed-precision update: GEMM operands in bf16, all arithmetic and state in fp32). */
+ * as bfloat16 when hp_bf16 != 0 (mixed-precision update: GEMM operands in bf16, all arithmetic and state in fp32);
+ * its rows are hp_stride elements apart (0 = h_stride).
+ * hgates == NULL: igates already holds x W_ih^T + h W_hh^T (the rollout runs ONE GEMM over a concatenated [x | h]
+ * operand, whose h block is this call's hp_next). */
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
                            float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* hp_next,
-                           const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, void* stream);
+                           const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, int64_t hp_stride,
+                           void* stream);
 
 /* Backward of the step above.
  *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
@@ -74,6 +78,11 @@ int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, co
 int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride, float* out0, int64_t n0, float* out1,
                      int32_t dup, void* stream);
 
+/* RunningMeanStd of rl_games in eval mode: out = clamp((x - mean) / sqrt(var + eps), +-clip) for x [n,F] packed,
+ * float64 statistics; out rows out_stride elements apart (a column block of a wider buffer), fp32 or bfloat16. */
+int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean, const double* var, float eps, float clip,
+                       void* out, int64_t out_stride, int32_t out_bf16, void* stream);
+
 /* out = elu(z + bias) for z [n,C] packed fp32 (a GEMM output without epilogue); out rows out_stride apart, fp32 or
  * bfloat16 (out_bf16). */
 int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float alpha, void* out, int64_t out_stride,
@@ -109,11 +118,14 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
  *   dones_out = reset != 0;  cur_rewards += rew;  cur_lengths += 1
  *   finished episodes feed the two windowed means (rl_games AverageMeter, window max_size), then their
  *   accumulators and the LSTM state rows h,c [N,H] are zeroed;  *counter += 1.
- * meter[8] = {rew_mean, rew_size, len_mean, len_size, tmp_sum_rew, tmp_sum_len, tmp_count, 0}. */
+ * meter[8] = {rew_mean, rew_size, len_mean, len_size, tmp_sum_rew, tmp_sum_len, tmp_count, 0}.
+ * h_op (nullable): a second copy of h used as GEMM operand (rows h_op_stride elements apart, fp32 or bfloat16), zeroed
+ * alongside h_state. */
 int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
                       const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
                       float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
-                      float* c_state, float* meter, float max_size, int64_t* counter, void* stream);
+                      float* c_state, float* meter, float max_size, int64_t* counter, void* h_op, int64_t h_op_stride,
+                      int32_t h_op_bf16, void* stream);
 
 /* Adam step on FLAT buffers (all parameters of the model live in one contiguous block, likewise gradients and
  * moments): torch.optim.Adam arithmetic (rl_games: Adam(lr, eps=1e-8), common_agent.py:80) in ONE launch instead of a

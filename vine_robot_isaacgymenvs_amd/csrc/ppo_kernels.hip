@@ -50,7 +50,7 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
                                 long long done_stride, float* __restrict__ h_out, long long h_stride,
                                 float* __restrict__ c_out, float* __restrict__ gates_act,
                                 HP* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
-                                long long done_next_stride) {
+                                long long done_next_stride, long long hp_stride) {
     const int H4 = H >> 2;
     const long long total = B * H4;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -59,13 +59,21 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
         const int j = (int)(idx - b * H4) << 2;
         const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
         const float* ig = igates + b * ig_stride;
-        const float* hg = hgates + b * 4LL * H;
         float4 g[4];
+        if (hgates) {
+            const float* hg = hgates + b * 4LL * H;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 a = ld4(ig + k * H + j), h = ld4(hg + k * H + j), bb = ld4(bias + k * H + j);
-            g[k] = make_float4(a.x + keep * h.x + bb.x, a.y + keep * h.y + bb.y, a.z + keep * h.z + bb.z,
-                               a.w + keep * h.w + bb.w);
+            for (int k = 0; k < 4; ++k) {
+                const float4 a = ld4(ig + k * H + j), h = ld4(hg + k * H + j), bb = ld4(bias + k * H + j);
+                g[k] = make_float4(a.x + keep * h.x + bb.x, a.y + keep * h.y + bb.y, a.z + keep * h.z + bb.z,
+                                   a.w + keep * h.w + bb.w);
+            }
+        } else {      // igates already holds x W_ih^T + h W_hh^T (one GEMM over the concatenated [x | h] operand)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 a = ld4(ig + k * H + j), bb = ld4(bias + k * H + j);
+                g[k] = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+            }
         }
         const float4 cp = ld4(c_prev + b * H + j);
         float gi[4] = {g[0].x, g[0].y, g[0].z, g[0].w}, gf[4] = {g[1].x, g[1].y, g[1].z, g[1].w};
@@ -85,7 +93,7 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
         st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
         if (hp_next) {   // the masked hidden state step t+1 consumes (operand of the recurrent weight gradient)
             const float kn = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
-            st4(hp_next + b * h_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
+            st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
         }
         if (gates_act) {
             float* ga = gates_act + b * 4LL * H;
@@ -276,6 +284,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(long long n, const f
     __syncthreads();
     for (int c = threadIdx.x; c < 2 * H; c += 256)
         partial[(long long)blockIdx.x * 2 * H + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// RunningMeanStd in eval mode (rl_games: float64 statistics): out = clamp((x - mean) / sqrt(var + eps), +-clip), written
+// into a column block of a wider buffer (rows out_stride apart), fp32 or bfloat16.  One thread per element.
+template <typename OT>
+__global__ void normalize_obs_kernel(long long n, int F, const float* __restrict__ x, const double* __restrict__ mean,
+                                     const double* __restrict__ var, float eps, float clip, OT* __restrict__ out,
+                                     long long out_stride) {
+    const long long total = n * F;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx / F;
+        const int c = (int)(idx - r * F);
+        // same arithmetic as the module: statistics cast to float first, then (x - mean) / sqrt(var + eps)
+        const float m = (float)mean[c], sd = sqrtf((float)var[c] + eps);
+        float y = (x[idx] - m) / sd;
+        y = fminf(fmaxf(y, -clip), clip);
+        if (sizeof(OT) == 2) reinterpret_cast<bf16_t*>(out)[r * out_stride + c] = f2bf(y);
+        else reinterpret_cast<float*>(out)[r * out_stride + c] = y;
+    }
 }
 
 // out = elu(z + bias): the activation of a Linear whose GEMM ran without an epilogue (bf16 operands, fp32 output)
@@ -642,7 +670,8 @@ __global__ void rollout_post_kernel(long long N, int H, const float* __restrict_
                                     const unsigned char* __restrict__ timeouts, const float* __restrict__ values,
                                     float shift, float scale, float gamma_b, float* __restrict__ shaped,
                                     unsigned char* __restrict__ dones, float* __restrict__ cur_r, float* __restrict__ cur_l,
-                                    float* __restrict__ h_state, float* __restrict__ c_state, float* __restrict__ meter) {
+                                    float* __restrict__ h_state, float* __restrict__ c_state, float* __restrict__ meter,
+                                    void* __restrict__ h_op, long long h_op_stride, int h_op_bf16) {
     float sr = 0.0f, sl = 0.0f, cnt = 0.0f;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N; e += (long long)gridDim.x * blockDim.x) {
         const float r = rew[e];
@@ -657,6 +686,10 @@ __global__ void rollout_post_kernel(long long N, int H, const float* __restrict_
             cur_r[e] = 0.0f; cur_l[e] = 0.0f;
             const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             for (int j = 0; j < H; j += 4) { st4(h_state + e * H + j, z); st4(c_state + e * H + j, z); }
+            if (h_op) {   // the GEMM-operand copy of h (column block of the [x | h] buffer of the fused inference)
+                if (h_op_bf16) for (int j = 0; j < H; j += 4) st4((bf16_t*)h_op + e * h_op_stride + j, z);
+                else for (int j = 0; j < H; j += 4) st4((float*)h_op + e * h_op_stride + j, z);
+            }
         } else {
             cur_r[e] = cr; cur_l[e] = cl;
         }
@@ -701,20 +734,24 @@ extern "C" {
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
                            float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* hp_next,
-                           const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, void* stream) {
-    if (B <= 0 || H <= 0 || (H & 3) || (ig_stride & 3) || (h_stride & 3) || !igates || !hgates || !bias || !c_prev ||
-        !h_out || !c_out)
+                           const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, int64_t hp_stride,
+                           void* stream) {
+    if (hp_stride <= 0) hp_stride = h_stride;
+    if (B <= 0 || H <= 0 || (H & 3) || (ig_stride & 3) || (h_stride & 3) || (hp_stride & 3) || !igates || !bias ||
+        !c_prev || !h_out || !c_out)
         return VINE_ERR_INVALID_ARG;
     const int threads = 256;
     const dim3 grid(grid_for(B * (H / 4), threads));
     if (hp_bf16)
         hipLaunchKernelGGL(lstm_fwd_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
                            igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
-                           (long long)h_stride, c_out, gates_act, (bf16_t*)hp_next, done_next, (long long)done_next_stride);
+                           (long long)h_stride, c_out, gates_act, (bf16_t*)hp_next, done_next, (long long)done_next_stride,
+                           (long long)hp_stride);
     else
         hipLaunchKernelGGL(lstm_fwd_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
                            igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
-                           (long long)h_stride, c_out, gates_act, (float*)hp_next, done_next, (long long)done_next_stride);
+                           (long long)h_stride, c_out, gates_act, (float*)hp_next, done_next, (long long)done_next_stride,
+                           (long long)hp_stride);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -800,6 +837,20 @@ int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride,
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean, const double* var, float eps, float clip,
+                       void* out, int64_t out_stride, int32_t out_bf16, void* stream) {
+    if (n <= 0 || F <= 0 || !x || !mean || !var || !out || out_stride < F) return VINE_ERR_INVALID_ARG;
+    const int threads = 256;
+    const dim3 grid(grid_for(n * F, threads));
+    if (out_bf16)
+        hipLaunchKernelGGL(normalize_obs_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)F,
+                           x, mean, var, eps, clip, (bf16_t*)out, (long long)out_stride);
+    else
+        hipLaunchKernelGGL(normalize_obs_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)F,
+                           x, mean, var, eps, clip, (float*)out, (long long)out_stride);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
 int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float alpha, void* out, int64_t out_stride,
                   int32_t out_bf16, void* stream) {
     if (n <= 0 || C <= 0 || (C & 3) || (out_stride & 3) || !z || !bias || !out) return VINE_ERR_INVALID_ARG;
@@ -861,7 +912,8 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
 int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
                       const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
                       float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
-                      float* c_state, float* meter, float max_size, int64_t* counter, void* stream) {
+                      float* c_state, float* meter, float max_size, int64_t* counter, void* h_op, int64_t h_op_stride,
+                      int32_t h_op_bf16, void* stream) {
     if (N <= 0 || H <= 0 || (H & 3) || !rew || !reset || !timeouts || !values || !shaped_out || !dones_out ||
         !cur_rewards || !cur_lengths || !h_state || !c_state || !meter || !counter)
         return VINE_ERR_INVALID_ARG;
@@ -869,7 +921,8 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
     const int threads = 256;
     hipLaunchKernelGGL(rollout_post_kernel, dim3(grid_for(N, threads)), dim3(threads), 0, s, (long long)N, (int)H, rew,
                        (const long long*)reset, timeouts, values, reward_shift, reward_scale, gamma_bootstrap, shaped_out,
-                       dones_out, cur_rewards, cur_lengths, h_state, c_state, meter);
+                       dones_out, cur_rewards, cur_lengths, h_state, c_state, meter, h_op, (long long)h_op_stride,
+                       (int)h_op_bf16);
     hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, s, meter, max_size, (long long*)counter);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }

@@ -281,6 +281,8 @@ class A2CAgent:
             return
         for t in list(self.model.parameters()) + list(self.model.buffers()):
             dist.broadcast(t.data, 0)
+        if self.fused_mixed:
+            self.optimizer.refresh_shadow()
 
     def preprocess_actions(self, actions):
         if self.clip_actions:
@@ -328,12 +330,82 @@ class A2CAgent:
         self.mb_rnn_states = [torch.zeros((n_chunks, 1, N, s.shape[-1]), **f32) for s in self.rnn_states]
         self.last_values = torch.zeros((N, 1), **f32)
         self._head_scratch = [torch.zeros((N, self.actions_num), **f32) for _ in range(3)] + [torch.zeros(N, **f32)]
+        self._setup_fast_inference()
 
     # ------------------------------------------------------------------ rollout (R1)
     def get_action_values(self, obs):
         self.model.eval()
         with torch.no_grad():
             return self.model({"is_train": False, "prev_actions": None, "obs": obs, "rnn_states": self.rnn_states})
+
+    def _setup_fast_inference(self):
+        """Persistent buffers of the hand-written policy inference of the rollout (``_infer``):
+        ``xh`` [N, XW + H] = [MLP output | normalised obs | pad | h] is the operand of ONE gate GEMM against
+        ``wcat`` = [w_ih | 0 | w_hh]; operands are bfloat16 in the mixed-precision mode, fp32 otherwise."""
+        net = self.model.a2c_network
+        self._fast = None
+        if not (self.fused_rollout and self.normalize_input and net.activation_is_elu and net.rnn_ln
+                and net.rnn_units in (256, 512, 1024) and all(u % 4 == 0 for u in net.units)):
+            return
+        dev, N, H = self.device, self.num_actors, net.rnn_units
+        op = torch.bfloat16 if self.fused_mixed else torch.float32
+        U, F_in = net.units[-1], self.obs_shape[0]
+        width = U + (F_in if net.rnn_concat_input else 0)
+        XW = (width + 15) // 16 * 16
+        f = {"op": op, "U": U, "F": F_in, "XW": XW, "H": H,
+             "xh": torch.zeros((N, XW + H), device=dev, dtype=op),
+             "wcat": torch.zeros((4 * H, XW + H), device=dev, dtype=op),
+             "acts": [torch.empty((N, u), device=dev, dtype=op) for u in net.units[:-1]],
+             "y": torch.empty((N, H), device=dev), "h_tmp": torch.empty((N, H), device=dev),
+             "c_tmp": torch.empty((N, H), device=dev)}
+        f["x0"] = f["xh"][:, U:U + F_in] if net.rnn_concat_input else torch.empty((N, F_in), device=dev, dtype=op)
+        self._fast = f
+
+    def _infer_begin(self):
+        """Once per rollout: operand copies of the recurrent weights and of h (the update changed the weights)."""
+        f, net = self._fast, self.model.a2c_network
+        r = net.rnn.rnn
+        src = self.optimizer.shadow_of if self.fused_mixed else (lambda p: p)
+        f["wcat"][:, :r.weight_ih_l0.shape[1]].copy_(src(r.weight_ih_l0))
+        f["wcat"][:, f["XW"]:].copy_(src(r.weight_hh_l0))
+        f["mlp"] = [(src(m.weight), m.bias) for m in net.actor_mlp if isinstance(m, torch.nn.Linear)]
+        f["bias"] = r.bias_ih_l0 + r.bias_hh_l0
+        f["xh"][:, f["XW"]:].copy_(self.rnn_states[0][0])
+
+    def _infer(self, obs, commit=True):
+        """Policy trunk for one step, no autograd: normalise -> [GEMM + bias/ELU kernel] x L -> ONE gate GEMM over
+        [x | h] -> LSTM pointwise kernel (state updated in place) -> LayerNorm kernel.  ~10 launches.
+        ``commit=False`` leaves the LSTM state untouched (the extra forward for the last values)."""
+        lib = fused._lib()
+        f, m = self._fast, self.model
+        net, rms = m.a2c_network, m.running_mean_std
+        N, H, XW = self.num_actors, f["H"], f["XW"]
+        bf = int(f["op"] == torch.bfloat16)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        xh, x0 = f["xh"], f["x0"]
+        fused._check(lib.vine_normalize_obs(N, f["F"], obs.data_ptr(), rms.running_mean.data_ptr(),
+                                            rms.running_var.data_ptr(), float(rms.epsilon), 5.0, x0.data_ptr(),
+                                            x0.stride(0), bf, st), "vine_normalize_obs")
+        x = x0
+        n_mlp = len(f["mlp"])
+        for i, (W, b) in enumerate(f["mlp"]):
+            z = fused._mm(x, W.t())
+            out = xh if i == n_mlp - 1 else f["acts"][i]
+            fused._check(lib.vine_bias_elu(N, z.shape[1], z.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(), out.stride(0),
+                                           bf, st), "vine_bias_elu")
+            x = out
+        gates = fused._mm(xh, f["wcat"].t())
+        h32, c = self.rnn_states[0][0], self.rnn_states[1][0]
+        h_out, c_out = (h32, c) if commit else (f["h_tmp"], f["c_tmp"])
+        fused._check(lib.vine_lstm_cell_forward(
+            N, H, gates.data_ptr(), 4 * H, None, f["bias"].data_ptr(), c.data_ptr(), None, 0, h_out.data_ptr(), H,
+            c_out.data_ptr(), None, (xh.data_ptr() + xh.element_size() * XW) if commit else None, None, 0, bf,
+            XW + H, st), "vine_lstm_cell_forward")
+        y = f["y"]
+        fused._check(lib.vine_layernorm_forward(N, H, h_out.data_ptr(), net.layer_norm.weight.data_ptr(),
+                                                net.layer_norm.bias.data_ptr(), float(net.layer_norm.eps), y.data_ptr(),
+                                                None, None, st), "vine_layernorm_forward")
+        return y
 
     def _rollout_body_fused(self):
         """Same sequence as ``_rollout_body`` with the pointwise work in three hand-written kernels per step:
@@ -372,12 +444,21 @@ class A2CAgent:
                 y = net.layer_norm(y)
             return y.contiguous(), states
 
+        fast = getattr(self, "_fast", None) is not None
+        if fast:
+            self._infer_begin()
+        h_op = self._fast["xh"].data_ptr() + self._fast["xh"].element_size() * self._fast["XW"] if fast else None
+        h_op_stride = self._fast["XW"] + H if fast else 0
+        h_op_bf16 = int(fast and self._fast["op"] == torch.bfloat16)
         for n in range(self.horizon_length):
             if n % self.seq_len == 0:
                 for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
                     mb_s[n // self.seq_len].copy_(s_)
-            y, states = trunk(obs)
-            self.rnn_states = [states[0].contiguous(), states[1].contiguous()]
+            if fast:
+                y = self._infer(obs)
+            else:
+                y, states = trunk(obs)
+                self.rnn_states = [states[0].contiguous(), states[1].contiguous()]
             buf["obses"][n].copy_(obs)
             buf["dones"][n].copy_(self.dones)
             head(y, n, buf["values"][n], buf["mus"][n], buf["sigmas"][n], buf["actions"][n], buf["neglogpacs"][n])
@@ -390,9 +471,10 @@ class A2CAgent:
                 buf["values"][n].data_ptr(), float(self.reward_shift), float(self.reward_scale), gamma_b,
                 buf["rewards"][n].data_ptr(), self.dones.data_ptr(), self.current_rewards.data_ptr(),
                 self.current_lengths.data_ptr(), self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr(),
-                self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(), st), "vine_rollout_post")
+                self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(), h_op, h_op_stride,
+                h_op_bf16, st), "vine_rollout_post")
         self.obs = obs
-        y, _ = trunk(obs)
+        y = self._infer(obs, commit=False) if fast else trunk(obs)[0]
         scratch = self._head_scratch
         head(y, 0, self.last_values, scratch[0], scratch[1], scratch[2], scratch[3])
 
@@ -822,6 +904,8 @@ class A2CAgent:
                 group["lr"] = self.lr
         if "last_lr" in ckpt:
             self.lr.fill_(ckpt["last_lr"])
+        if self.fused_mixed:
+            self.optimizer.refresh_shadow()
 
     # ------------------------------------------------------------------ main loop
     def train(self):

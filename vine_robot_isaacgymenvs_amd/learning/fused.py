@@ -160,7 +160,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
             (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
             c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
             None if last else hp.data_ptr() + hp.element_size() * ((t + 1) * H),
-            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, int(op == torch.bfloat16), st),
+            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, int(op == torch.bfloat16), 0, st),
             "vine_lstm_cell_forward")
     return out, c_all, gates, hp
 
