@@ -29,12 +29,13 @@ extern "C" {
  * hp_next (nullable, rows h_stride apart) receives (1 - done_next[b]) * h': the masked hidden state step t+1
  * consumes, i.e. the operand of the recurrent weight gradient, so the backward pass need not rebuild it; stored
  * as bfloat16 when hp_bf16 != 0 (mixed-precision update: GEMM operands in bf16, all arithmetic and state in fp32);
- * its rows are hp_stride elements apart (0 = h_stride).
+ * its rows are hp_stride elements apart (0 = h_stride).  gates_act uses the same storage type as hp_next (the stored
+ * activations only feed the backward pass).
  * hgates == NULL: igates already holds x W_ih^T + h W_hh^T (the rollout runs ONE GEMM over a concatenated [x | h]
  * operand, whose h block is this call's hp_next). */
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
-                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* hp_next,
+                           float* h_out, int64_t h_stride, float* c_out, void* gates_act, void* hp_next,
                            const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, int64_t hp_stride,
                            void* stream);
 
@@ -45,11 +46,12 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
  * w.r.t. the masked c_{t-1} (dc_prev = dc * f).
  * bias_partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, 4H]) receives per-workgroup column sums of the gate gradients;
  * their sum over rows (and over the T steps) is the bias gradient -- deterministic, no atomics.
- * dgates_bf16 != 0: the gate gradients (only ever GEMM operands) are stored as bfloat16. */
+ * dgates_bf16 != 0: the gate gradients (only ever GEMM operands) are stored as bfloat16, and gates_act is read as
+ * bfloat16 (as the forward call with hp_bf16 != 0 wrote it). */
 #define VINE_PPO_PARTIAL_BLOCKS 512
 int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
-                            const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
+                            const void* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
                             int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
                             float* bias_partial, int32_t dgates_bf16, void* stream);
 

@@ -48,7 +48,7 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
                                 const float* __restrict__ hgates, const float* __restrict__ bias,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
                                 long long done_stride, float* __restrict__ h_out, long long h_stride,
-                                float* __restrict__ c_out, float* __restrict__ gates_act,
+                                float* __restrict__ c_out, HP* __restrict__ gates_act,
                                 HP* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
                                 long long done_next_stride, long long hp_stride) {
     const int H4 = H >> 2;
@@ -96,7 +96,7 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
             st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
         }
         if (gates_act) {
-            float* ga = gates_act + b * 4LL * H;
+            HP* ga = gates_act + b * 4LL * H;
             st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
             st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
             st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
@@ -109,7 +109,7 @@ template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
                                 const unsigned char* __restrict__ done_next, long long done_next_stride,
-                                const float* __restrict__ gates_act, const float* __restrict__ c_new,
+                                const DG* __restrict__ gates_act, const float* __restrict__ c_new,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
                                 long long done_stride, DG* __restrict__ dgates, long long dg_stride,
                                 float* __restrict__ dc_prev, float* __restrict__ bias_partial) {
@@ -136,7 +136,7 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
             const float4 r = ld4(dc_next + b * H + j);
             dc[0] = keep_n * r.x; dc[1] = keep_n * r.y; dc[2] = keep_n * r.z; dc[3] = keep_n * r.w;
         }
-        const float* ga = gates_act + b * 4LL * H;
+        const DG* ga = gates_act + b * 4LL * H;
         const float4 i4 = ld4(ga + j), f4 = ld4(ga + H + j), g4 = ld4(ga + 2 * H + j), o4 = ld4(ga + 3 * H + j);
         const float4 cn4 = ld4(c_new + b * H + j), cp4 = ld4(c_prev + b * H + j);
         const float gi[4] = {i4.x, i4.y, i4.z, i4.w}, gf[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -733,7 +733,7 @@ extern "C" {
 
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
                            const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride,
-                           float* h_out, int64_t h_stride, float* c_out, float* gates_act, void* hp_next,
+                           float* h_out, int64_t h_stride, float* c_out, void* gates_act, void* hp_next,
                            const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, int64_t hp_stride,
                            void* stream) {
     if (hp_stride <= 0) hp_stride = h_stride;
@@ -745,19 +745,21 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
     if (hp_bf16)
         hipLaunchKernelGGL(lstm_fwd_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
                            igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
-                           (long long)h_stride, c_out, gates_act, (bf16_t*)hp_next, done_next, (long long)done_next_stride,
+                           (long long)h_stride, c_out, (bf16_t*)gates_act, (bf16_t*)hp_next, done_next,
+                           (long long)done_next_stride,
                            (long long)hp_stride);
     else
         hipLaunchKernelGGL(lstm_fwd_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
                            igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
-                           (long long)h_stride, c_out, gates_act, (float*)hp_next, done_next, (long long)done_next_stride,
+                           (long long)h_stride, c_out, (float*)gates_act, (float*)hp_next, done_next,
+                           (long long)done_next_stride,
                            (long long)hp_stride);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
 int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const float* g_rec,
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
-                            const float* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
+                            const void* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
                             int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
                             float* bias_partial, int32_t dgates_bf16, void* stream) {
     if (B <= 0 || H <= 0 || (H & 3) || (g_stride & 3) || (dg_stride & 3) || !g_out || !gates_act || !c_new || !c_prev ||
@@ -770,12 +772,14 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
     if (dgates_bf16)
         hipLaunchKernelGGL(lstm_bwd_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
                            (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
-                           gates_act, c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates, (long long)dg_stride,
+                           (const bf16_t*)gates_act, c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates,
+                           (long long)dg_stride,
                            dc_prev, bias_partial);
     else
         hipLaunchKernelGGL(lstm_bwd_kernel<float>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
                            (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
-                           gates_act, c_new, c_prev, done, (long long)done_stride, (float*)dgates, (long long)dg_stride,
+                           (const float*)gates_act, c_new, c_prev, done, (long long)done_stride, (float*)dgates,
+                           (long long)dg_stride,
                            dc_prev, bias_partial);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }

@@ -142,7 +142,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
     out = torch.empty((BT, H), device=dev, dtype=torch.float32)
     c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
     c_all[0].copy_(c0)
-    gates = torch.empty((T, B, 4 * H), device=dev, dtype=torch.float32) if need_grad else None
+    gates = torch.empty((T, B, 4 * H), device=dev, dtype=op) if need_grad else None     # backward-only: operand dtype
     hp = torch.empty((B, T, H), device=dev, dtype=op)
     if dones is not None:
         hp[:, 0].copy_(h0 * (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)))
@@ -350,8 +350,9 @@ class _Trunk(torch.autograd.Function):
         ctx.pshapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in params]
         ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g,
                               dones if dones is not None else obs_n.new_empty(0), *acts, *Wop)
-        hT = out.view(B, T, H)[:, T - 1].contiguous()
-        cT = c_all[T].clone()
+        # final LSTM state as views (no copies): the update discards it, other callers may clone
+        hT = out.view(B, T, H)[:, T - 1]
+        cT = c_all[T]
         ctx.mark_non_differentiable(hT, cT)
         return heads, hT, cT
 
