@@ -64,6 +64,18 @@ int vine_layernorm_forward(int64_t n, int64_t H, const float* x, const float* ga
 int vine_layernorm_backward(int64_t n, int64_t H, const float* dy, const float* x, const float* mean, const float* rstd,
                             const float* gamma, float* dx, float* partial, void* stream);
 
+/* LayerNorm followed by NH output heads (rows of w [NH, H], bias wb [NH]; NH = actions + 1: [mu | value]) in one pass,
+ * H == 256 and 2 <= NH <= 5 (else VINE_ERR_UNSUPPORTED: use the separate kernels and GEMMs):
+ *   forward : heads[r] = w LN(x_r) + wb, LN(x) is never written; mean/rstd [n] kept for the backward pass;
+ *   backward: from g = d loss / d heads [n, NH]: dx [n, H] and partial [VINE_PPO_PARTIAL_BLOCKS, (2 + NH) H] whose
+ *             column sums are { d gamma | d beta | d w[0] | ... | d w[NH-1] }. */
+int vine_layernorm_heads_forward(int64_t n, int64_t H, int64_t NH, const float* x, const float* gamma, const float* beta,
+                                 float eps, const float* w, const float* wb, float* heads, float* mean, float* rstd,
+                                 void* stream);
+int vine_layernorm_heads_backward(int64_t n, int64_t H, int64_t NH, const float* g, const float* x, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, const float* w, float* dx,
+                                  float* partial, void* stream);
+
 /* ELU backward from the layer OUTPUT a = elu(z) (PY:19 `activation: elu`): out = g * (a > 0 ? 1 : a + alpha); rows of
  * g / a / out are *_stride floats apart (so a column block of a wider matrix works); out may alias g.
  * partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, C]): per-workgroup column sums of out = the bias gradient of the

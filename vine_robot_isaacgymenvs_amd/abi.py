@@ -163,6 +163,8 @@ PPO_PROTOTYPES = {
                                           _I64, _VP, _VP, C.c_int32, _VP]),
     "vine_layernorm_forward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP]),
     "vine_layernorm_backward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_layernorm_heads_forward": (C.c_int, [_I64, _I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_layernorm_heads_backward": (C.c_int, [_I64, _I64, _I64] + [_VP] * 10),
     "vine_elu_backward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _I64, _VP, C.c_int32, C.c_int32,
                                     _VP]),
     "vine_bias_elu": (C.c_int, [_I64, _I64, _VP, _VP, C.c_float, _VP, _I64, C.c_int32, _VP]),

@@ -326,6 +326,108 @@ __global__ __launch_bounds__(256) void bias_elu_kernel(long long n, int C, const
     }
 }
 
+// ---- LayerNorm + output heads in one pass (H = 256: one float4 per lane; NH = actions + 1 head rows) ----
+// forward: heads[r] = W (LN(x_r)) + b without materialising LN(x): the heads are 3 GEMV rows, three GEMMs over
+// [n, 256] operands cost more in HBM traffic than the arithmetic is worth.
+template <int NH>
+__global__ __launch_bounds__(256) void ln_heads_fwd_kernel(long long n, const float* __restrict__ x,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           const float* __restrict__ w, const float* __restrict__ wb,
+                                                           float* __restrict__ heads, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out) {
+    constexpr int H = 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 gm = ld4(gamma + 4 * lane), bt = ld4(beta + 4 * lane);
+    float4 wv[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) wv[h] = ld4(w + h * H + 4 * lane);
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < n; r += (long long)gridDim.x * 4) {
+        const float4 xv = ld4(x + r * H + 4 * lane);
+        const float mean = wave_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / H);
+        const float a = xv.x - mean, b = xv.y - mean, c = xv.z - mean, d = xv.w - mean;
+        const float rstd = rsqrtf(wave_sum((a * a + b * b) + (c * c + d * d)) * (1.0f / H) + eps);
+        const float y0 = a * rstd * gm.x + bt.x, y1 = b * rstd * gm.y + bt.y, y2 = c * rstd * gm.z + bt.z,
+                    y3 = d * rstd * gm.w + bt.w;
+        float p[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) p[h] = wave_sum((y0 * wv[h].x + y1 * wv[h].y) + (y2 * wv[h].z + y3 * wv[h].w));
+        if (lane == 0) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) heads[r * NH + h] = p[h] + wb[h];
+            mean_out[r] = mean;
+            rstd_out[r] = rstd;
+        }
+    }
+}
+
+// backward: dy = g W (never stored), LayerNorm backward, and per-workgroup partial sums
+//   partial[block] = { d gamma [H] | d beta [H] | d W [NH, H] }   with  d W[h] = sum_r g[r, h] * LN(x_r)
+template <int NH>
+__global__ __launch_bounds__(256) void ln_heads_bwd_kernel(long long n, const float* __restrict__ g,
+                                                           const float* __restrict__ x,
+                                                           const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ w, float* __restrict__ dx,
+                                                           float* __restrict__ partial) {
+    constexpr int H = 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 gm4 = ld4(gamma + 4 * lane), bt4 = ld4(beta + 4 * lane);
+    const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+    float wv[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float4 t = ld4(w + h * H + 4 * lane);
+        wv[h][0] = t.x; wv[h][1] = t.y; wv[h][2] = t.z; wv[h][3] = t.w;
+    }
+    float dgm[4] = {0, 0, 0, 0}, dbt[4] = {0, 0, 0, 0}, dw[NH][4];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dw[h][u] = 0.0f;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < n; r += (long long)gridDim.x * 4) {
+        const float mean = mean_in[r], rstd = rstd_in[r];
+        float gh[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) gh[h] = g[r * NH + h];
+        const float4 xv = ld4(x + r * H + 4 * lane);
+        const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+        float xh[4], gg[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xh[u] = (xa[u] - mean) * rstd;
+            float dy = 0.0f;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) dy += gh[h] * wv[h][u];
+            const float y = xh[u] * gm[u] + bt[u];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) dw[h][u] += gh[h] * y;
+            gg[u] = dy * gm[u];
+            s1 += gg[u];
+            s2 += gg[u] * xh[u];
+            dgm[u] += dy * xh[u];
+            dbt[u] += dy;
+        }
+        const float m1 = wave_sum(s1) * (1.0f / H), m2 = wave_sum(s2) * (1.0f / H);
+        st4(dx + r * H + 4 * lane, make_float4(rstd * (gg[0] - m1 - xh[0] * m2), rstd * (gg[1] - m1 - xh[1] * m2),
+                                               rstd * (gg[2] - m1 - xh[2] * m2), rstd * (gg[3] - m1 - xh[3] * m2)));
+    }
+    constexpr int W = (2 + NH) * H;
+    __shared__ float red[4][W];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        red[wave][4 * lane + u] = dgm[u];
+        red[wave][H + 4 * lane + u] = dbt[u];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) red[wave][(2 + h) * H + 4 * lane + u] = dw[h][u];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < W; c += 256)
+        partial[(long long)blockIdx.x * W + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 // ELU backward from the OUTPUT a = elu(z): dz = g * (a > 0 ? 1 : a + alpha), plus per-block column sums of dz
 // (= the bias gradient of the Linear that produced z).  C4 = C/4 threads per row, 256/C4 rows per block pass.
 template <typename AT, typename OT>
@@ -805,6 +907,31 @@ int vine_layernorm_backward(int64_t n, int64_t H, const float* dy, const float* 
     if (H == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, (long long)n, dy, x, mean, rstd, gamma, dx, partial);
     else if (H == 512) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, (long long)n, dy, x, mean, rstd, gamma, dx, partial);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, (long long)n, dy, x, mean, rstd, gamma, dx, partial);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_layernorm_heads_forward(int64_t n, int64_t H, int64_t NH, const float* x, const float* gamma, const float* beta,
+                                 float eps, const float* w, const float* wb, float* heads, float* mean, float* rstd,
+                                 void* stream) {
+    if (n <= 0 || !x || !gamma || !beta || !w || !wb || !heads || !mean || !rstd) return VINE_ERR_INVALID_ARG;
+    if (H != 256 || NH < 2 || NH > 5) return VINE_ERR_UNSUPPORTED;
+    const int blocks = (int)((n + 3) / 4 < 256 * 8 ? (n + 3) / 4 : 256 * 8);
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_LNH_FWD(K) hipLaunchKernelGGL(ln_heads_fwd_kernel<K>, dim3(blocks), dim3(256), 0, s, (long long)n, x, gamma, beta, eps, w, wb, heads, mean, rstd)
+    if (NH == 2) VINE_LNH_FWD(2); else if (NH == 3) VINE_LNH_FWD(3); else if (NH == 4) VINE_LNH_FWD(4); else VINE_LNH_FWD(5);
+#undef VINE_LNH_FWD
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_layernorm_heads_backward(int64_t n, int64_t H, int64_t NH, const float* g, const float* x, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, const float* w, float* dx,
+                                  float* partial, void* stream) {
+    if (n <= 0 || !g || !x || !mean || !rstd || !gamma || !beta || !w || !dx || !partial) return VINE_ERR_INVALID_ARG;
+    if (H != 256 || NH < 2 || NH > 5) return VINE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_LNH_BWD(K) hipLaunchKernelGGL(ln_heads_bwd_kernel<K>, dim3(VINE_PPO_PARTIAL_BLOCKS), dim3(256), 0, s, (long long)n, g, x, mean, rstd, gamma, beta, w, dx, partial)
+    if (NH == 2) VINE_LNH_BWD(2); else if (NH == 3) VINE_LNH_BWD(3); else if (NH == 4) VINE_LNH_BWD(4); else VINE_LNH_BWD(5);
+#undef VINE_LNH_BWD
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -338,17 +338,30 @@ class _Trunk(torch.autograd.Function):
         del ig
         # LayerNorm and the two heads stay in fp32 in both modes (3 output columns: nothing to gain, and mu feeds
         # the probability ratio directly)
-        y = torch.empty_like(out)
         mean = torch.empty(n, device=dev, dtype=torch.float32)
         rstd = torch.empty(n, device=dev, dtype=torch.float32)
-        _check(lib.vine_layernorm_forward(n, H, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
-                                          y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st), "vine_layernorm_forward")
         w_heads = torch.cat([mu_w, v_w], 0)
-        heads = torch.addmm(torch.cat([mu_b, v_b], 0), y, w_heads.t())          # [n, A + 1] = [mu | value]
+        b_heads = torch.cat([mu_b, v_b], 0)
+        NH = w_heads.shape[0]
+        fuse_heads = H == 256 and 2 <= NH <= 5
+        if fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
+            y = out.new_empty(0)
+            heads = torch.empty((n, NH), device=dev, dtype=torch.float32)
+            _check(lib.vine_layernorm_heads_forward(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),
+                                                    float(ln_eps), w_heads.data_ptr(), b_heads.data_ptr(),
+                                                    heads.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st),
+                   "vine_layernorm_heads_forward")
+        else:
+            y = torch.empty_like(out)
+            _check(lib.vine_layernorm_forward(n, H, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
+                                              y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), st),
+                   "vine_layernorm_forward")
+            heads = torch.addmm(b_heads, y, w_heads.t())          # [n, A + 1] = [mu | value]
         ctx.meta = (T, concat, n_mlp, U, float(ln_eps), mu_w.shape[0], dones is not None, mixed, head_bias_external)
         ctx.slots = [_grad_slot(p) if isinstance(p, torch.Tensor) else None for p in params]
         ctx.pshapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in params]
-        ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g,
+        ctx.fuse_heads = fuse_heads
+        ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g, ln_b,
                               dones if dones is not None else obs_n.new_empty(0), *acts, *Wop)
         # final LSTM state as views (no copies): the update discards it, other callers may clone
         hT = out.view(B, T, H)[:, T - 1]
@@ -362,9 +375,9 @@ class _Trunk(torch.autograd.Function):
         lib = _lib()
         T, concat, n_mlp, U, ln_eps, A, has_dones, mixed, head_bias_external = ctx.meta
         saved = ctx.saved_tensors
-        x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g, dones = saved[:14]
-        acts = list(saved[14:14 + n_mlp - 1])
-        weights = list(saved[14 + n_mlp - 1:])
+        x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g, ln_b, dones = saved[:15]
+        acts = list(saved[15:15 + n_mlp - 1])
+        weights = list(saved[15 + n_mlp - 1:])
         slots = ctx.slots
         n, H = out.shape
         dev = out.device
@@ -380,28 +393,43 @@ class _Trunk(torch.autograd.Function):
                 write(grads[idx])
 
         base = 2 * n_mlp
-        # ---- heads: one weight-gradient GEMM, one input-gradient GEMM
         g_heads = g_heads.contiguous()
-        s_heads, part = _splitk_parts(g_heads, y)                 # [s, A+1, H] slices of the weight gradient
-        deliver(base + 7, lambda o: column_sums(part[:, :A], o) if s_heads > 1 else o.copy_(part[:A]))
-        deliver(base + 9, lambda o: column_sums(part[:, A:], o) if s_heads > 1 else o.copy_(part[A:]))
+        NH = w_heads.shape[0]
+        d_out = torch.empty_like(out)
         if not head_bias_external:      # else: the loss kernel has already added them into the two bias gradients
             gb = g_heads.sum(0)
             deliver(base + 8, lambda o: o.copy_(gb[:A]))
             deliver(base + 10, lambda o: o.copy_(gb[A:]))
-        dy = g_heads.mm(w_heads)
-        # ---- LayerNorm
-        d_out = torch.empty_like(out)
-        ln_part = torch.empty((PPO_PARTIAL_BLOCKS, 2 * H), device=dev, dtype=torch.float32)
-        _check(lib.vine_layernorm_backward(n, H, dy.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                           ln_g.data_ptr(), d_out.data_ptr(), ln_part.data_ptr(), st),
-               "vine_layernorm_backward")
+        if ctx.fuse_heads:
+            # ---- heads + LayerNorm in one kernel: dy = g W is never stored; partial sums of {d gamma | d beta | d W}
+            part = torch.empty((PPO_PARTIAL_BLOCKS, (2 + NH) * H), device=dev, dtype=torch.float32)
+            _check(lib.vine_layernorm_heads_backward(n, H, NH, g_heads.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                                     rstd.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),
+                                                     w_heads.data_ptr(), d_out.data_ptr(), part.data_ptr(), st),
+                   "vine_layernorm_heads_backward")
+            ln_part, w_part = part[:, :2 * H], part[:, 2 * H:]
+            if slots[base + 7] is not None and slots[base + 9] is not None:
+                column_sums(w_part, slots[base + 7], out1=slots[base + 9], n0=A * H)
+            else:
+                deliver(base + 7, lambda o: column_sums(w_part[:, :A * H], o))
+                deliver(base + 9, lambda o: column_sums(w_part[:, A * H:], o))
+        else:
+            # ---- heads: one weight-gradient GEMM, one input-gradient GEMM
+            s_heads, wpart = _splitk_parts(g_heads, y)                 # [s, A+1, H] slices of the weight gradient
+            deliver(base + 7, lambda o: column_sums(wpart[:, :A], o) if s_heads > 1 else o.copy_(wpart[:A]))
+            deliver(base + 9, lambda o: column_sums(wpart[:, A:], o) if s_heads > 1 else o.copy_(wpart[A:]))
+            dy = g_heads.mm(w_heads)
+            # ---- LayerNorm
+            ln_part = torch.empty((PPO_PARTIAL_BLOCKS, 2 * H), device=dev, dtype=torch.float32)
+            _check(lib.vine_layernorm_backward(n, H, dy.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               ln_g.data_ptr(), d_out.data_ptr(), ln_part.data_ptr(), st),
+                   "vine_layernorm_backward")
+            del dy
         if slots[base + 4] is not None and slots[base + 5] is not None:
             column_sums(ln_part, slots[base + 4], out1=slots[base + 5], n0=H)     # {d gamma | d beta} in one launch
         else:
             deliver(base + 4, lambda o: column_sums(ln_part[:, :H], o))
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
-        del dy
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T)
         deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o))
