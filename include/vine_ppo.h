@@ -97,6 +97,11 @@ int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride,
 int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean, const double* var, float eps, float clip,
                        void* out, int64_t out_stride, int32_t out_bf16, void* stream);
 
+/* Up to 16 vine_column_sums jobs in one launch (arrays of length njobs, host memory, same meaning per entry). */
+int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
+                             const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
+                             const int32_t* dup, void* stream);
+
 /* out = elu(z + bias) for z [n,C] packed fp32 (a GEMM output without epilogue); out rows out_stride apart, fp32 or
  * bfloat16 (out_bf16). */
 int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float alpha, void* out, int64_t out_stride,

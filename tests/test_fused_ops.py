@@ -83,6 +83,18 @@ def test_pointwise_kernels_against_torch():
         assert torch.equal(a2, out) and torch.equal(b2, out)
     part = torch.randn(16, 3, 256, device=dev)
     assert torch.allclose(fused.column_sums(part[:, :2]), part[:, :2].sum(0), atol=1e-5)
+    # the same jobs through the one-launch batched kernel (more than 16 jobs: two launches)
+    batch, expect = fused.ColumnSumBatch(), []
+    for rep in range(3):
+        for R, Cc in ((32, 1024 * 92), (2048, 1024), (512, 64), (7, 130), (300, 5), (512, 1280)):
+            src = torch.randn(R, Cc + 6, device=dev)[:, :Cc]
+            a, b = torch.empty(Cc // 2, device=dev), torch.empty(Cc - Cc // 2, device=dev)
+            batch.add(src, a, out1=b, n0=Cc // 2)
+            expect.append((src.double().sum(0), a, b))
+    batch.flush(part)
+    for ref, a, b in expect:
+        got = torch.cat([a, b]).double()
+        assert float((got - ref).abs().max()) < 1e-4 * (1 + float(ref.abs().max()))
     # LayerNorm
     n, H = 4099, 256
     x = torch.randn(n, H, device=dev) * 2 + 0.5

@@ -515,6 +515,51 @@ __global__ __launch_bounds__(1024) void colsum_tall_kernel(const float* __restri
     }
 }
 
+// Several column-sum jobs in ONE launch (the backward pass of the network ends with ~13 of them, each too small to
+// fill the chip and each paying a launch): workgroup -> job through the block-offset table, then the same two
+// geometries as above (64 columns x 16 row-lanes for short matrices, 16 x 64 for tall ones), 1024 threads.
+struct ColsumJob {
+    const float* src;
+    float* out0;
+    float* out1;
+    long long R, C, row_stride, n0;
+    int dup, first_block;
+};
+#define VINE_COLSUM_MAX_JOBS 16
+struct ColsumBatch {
+    ColsumJob job[VINE_COLSUM_MAX_JOBS];
+    int njobs;
+};
+__global__ __launch_bounds__(1024) void colsum_batched_kernel(ColsumBatch batch) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < batch.njobs; ++k)
+        if ((int)blockIdx.x >= batch.job[k].first_block) j = k;
+    const ColsumJob& J = batch.job[j];
+    const int blk = blockIdx.x - J.first_block;
+    const bool tall = J.R >= 128;
+    const int ct = tall ? 16 : 64, rlanes = tall ? 64 : 16;
+    const int cl = threadIdx.x % ct, rl = threadIdx.x / ct;
+    const long long c = (long long)blk * ct + cl;
+    float acc = 0.0f;
+    if (c < J.C)
+        for (long long r = rl; r < J.R; r += rlanes) acc += J.src[r * J.row_stride + c];
+    __shared__ float red[1024];
+    red[rl * ct + cl] = acc;
+    __syncthreads();
+    // fixed-order tree over the row lanes (power of two)
+    for (int stride = rlanes >> 1; stride > 0; stride >>= 1) {
+        if (rl < stride) red[rl * ct + cl] += red[(rl + stride) * ct + cl];
+        __syncthreads();
+    }
+    if (rl == 0 && c < J.C) {
+        const float v = red[cl];
+        if (J.dup) { J.out0[c] = v; J.out1[c] = v; }
+        else if (J.out1 && c >= J.n0) J.out1[c - J.n0] = v;
+        else J.out0[c] = v;
+    }
+}
+
 __global__ void zero3_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb, float* __restrict__ c,
                              int nc) {
     const int t = threadIdx.x;
@@ -979,6 +1024,27 @@ int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean,
     else
         hipLaunchKernelGGL(normalize_obs_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)F,
                            x, mean, var, eps, clip, (float*)out, (long long)out_stride);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
+                             const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
+                             const int32_t* dup, void* stream) {
+    if (njobs <= 0 || njobs > VINE_COLSUM_MAX_JOBS || !R || !C || !src || !row_stride || !out0 || !n0 || !out1 || !dup)
+        return VINE_ERR_INVALID_ARG;
+    ColsumBatch b;
+    int blocks = 0;
+    for (int k = 0; k < njobs; ++k) {
+        if (R[k] <= 0 || C[k] <= 0 || !src[k] || !out0[k] || row_stride[k] < C[k] || (dup[k] && !out1[k]) || n0[k] < 0 ||
+            n0[k] > C[k])
+            return VINE_ERR_INVALID_ARG;
+        const int ct = R[k] >= 128 ? 16 : 64;
+        b.job[k] = ColsumJob{src[k], out0[k], out1[k], (long long)R[k], (long long)C[k], (long long)row_stride[k],
+                             (long long)(out1[k] && !dup[k] ? n0[k] : C[k]), (int)dup[k], blocks};
+        blocks += (int)((C[k] + ct - 1) / ct);
+    }
+    b.njobs = njobs;
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, b);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

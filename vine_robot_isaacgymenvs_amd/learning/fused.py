@@ -47,8 +47,9 @@ def _mm(a, b):
 
 
 # --------------------------------------------------------------------------- split-K weight gradient
-def splitk_tn(dy, x, out=None):
-    """``dy^T @ x`` for tall-skinny operands: dy [K, M], x [K, N] -> [M, N] (written into ``out`` when given)."""
+def splitk_tn(dy, x, out=None, batch=None):
+    """``dy^T @ x`` for tall-skinny operands: dy [K, M], x [K, N] -> [M, N] (written into ``out`` when given).
+    ``batch``: defer the sum over the slices to a ``ColumnSumBatch`` (the result exists after its ``flush``)."""
     K = dy.shape[0]
     s = 1
     while K % (s * 2) == 0 and K // (s * 2) >= 1024 and s < 64:
@@ -61,7 +62,7 @@ def splitk_tn(dy, x, out=None):
     # unflatten: also valid for operands whose rows are padded (a column block of a wider buffer)
     a, b = dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s))
     part = torch.bmm(a, b, out_dtype=torch.float32) if dy.dtype == torch.bfloat16 else torch.bmm(a, b)
-    return column_sums(part, out if out is not None else torch.empty(part.shape[1:], device=part.device))
+    return column_sums(part, out if out is not None else torch.empty(part.shape[1:], device=part.device), batch=batch)
 
 
 def _splitk_parts(dy, x):
@@ -204,20 +205,56 @@ def _sum_rows(partial, full, out=None):
     return torch.sum(src, 0, out=out) if out is not None else src.sum(0)
 
 
-def column_sums(src, out=None, out1=None, n0=0, dup=False):
-    """Sum over dim 0 of a [R, ...] fp32 tensor with the hand-written kernel (deterministic; unlike ATen's
-    multi-block reductions it needs no memset-cleared scratch, so it is safe inside a captured hipGraph).
-    ``out``/``out1``: see vine_column_sums (split at column n0, or ``dup`` to write both)."""
+def _as_rows(src):
+    """[R, ...] fp32 tensor -> 2-D [R, C] view with unit column stride (rows may be padded / a column block)."""
     R = src.shape[0]
     C = src.numel() // R
     if src.dim() == 2:
-        flat = src if src.stride(1) == 1 else src.contiguous()
-    elif src[0].is_contiguous():          # [R, ...] whose slices are dense (possibly a column block): rows of C floats
-        flat = src.as_strided((R, C), (src.stride(0), 1))
-    else:
-        flat = src.reshape(R, C)
+        return src if src.stride(1) == 1 else src.contiguous()
+    if src[0].is_contiguous():
+        return src.as_strided((R, C), (src.stride(0), 1))
+    return src.reshape(R, C)
+
+
+class ColumnSumBatch:
+    """Collects column-sum jobs and runs them in ONE launch (``vine_column_sums_batched``, 16 jobs per launch): the
+    network's backward pass ends with ~13 of them, each far too small to fill the chip."""
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def add(self, src, out, out1=None, n0=0, dup=False):
+        flat = _as_rows(src)
+        self.keep.append((flat, out, out1))
+        self.jobs.append((flat.shape[0], flat.shape[1], flat.data_ptr(), flat.stride(0), out.data_ptr(), int(n0),
+                          out1.data_ptr() if out1 is not None else 0, int(bool(dup))))
+        return out
+
+    def flush(self, ref):
+        import ctypes as C
+        lib, st = _lib(), _stream(ref)
+        for k in range(0, len(self.jobs), 16):
+            js = self.jobs[k:k + 16]
+            n = len(js)
+            cols = list(zip(*js))
+            i64 = lambda v: (C.c_int64 * n)(*v)
+            ptr = lambda v: (C.c_void_p * n)(*v)
+            _check(lib.vine_column_sums_batched(n, i64(cols[0]), i64(cols[1]), ptr(cols[2]), i64(cols[3]), ptr(cols[4]),
+                                                i64(cols[5]), ptr(cols[6]), (C.c_int32 * n)(*cols[7]), st),
+                   "vine_column_sums_batched")
+        self.jobs, self.keep = [], []
+
+
+def column_sums(src, out=None, out1=None, n0=0, dup=False, batch=None):
+    """Sum over dim 0 of a [R, ...] fp32 tensor with the hand-written kernel (deterministic; unlike ATen's
+    multi-block reductions it needs no memset-cleared scratch, so it is safe inside a captured hipGraph).
+    ``out``/``out1``: see vine_column_sums (split at column n0, or ``dup`` to write both)."""
     if out is None:
         out = torch.empty(src.shape[1:], device=src.device, dtype=torch.float32)
+    if batch is not None:
+        return batch.add(src, out, out1, n0, dup)
+    flat = _as_rows(src)
+    R, C = flat.shape
     _check(_lib().vine_column_sums(R, C, flat.data_ptr(), flat.stride(0), out.data_ptr(), int(n0),
                                    out1.data_ptr() if out1 is not None else None, int(bool(dup)), _stream(src)),
            "vine_column_sums")
@@ -393,6 +430,8 @@ class _Trunk(torch.autograd.Function):
                 write(grads[idx])
 
         base = 2 * n_mlp
+        # with the optimiser's gradient slots in place all column sums are deferred into one launch at the end
+        batch = ColumnSumBatch() if all(sl is not None for k, sl in enumerate(slots) if ctx.pshapes[k] is not None) else None
         g_heads = g_heads.contiguous()
         NH = w_heads.shape[0]
         d_out = torch.empty_like(out)
@@ -409,7 +448,7 @@ class _Trunk(torch.autograd.Function):
                    "vine_layernorm_heads_backward")
             ln_part, w_part = part[:, :2 * H], part[:, 2 * H:]
             if slots[base + 7] is not None and slots[base + 9] is not None:
-                column_sums(w_part, slots[base + 7], out1=slots[base + 9], n0=A * H)
+                column_sums(w_part, slots[base + 7], out1=slots[base + 9], n0=A * H, batch=batch)
             else:
                 deliver(base + 7, lambda o: column_sums(w_part[:, :A * H], o))
                 deliver(base + 9, lambda o: column_sums(w_part[:, A * H:], o))
@@ -426,16 +465,16 @@ class _Trunk(torch.autograd.Function):
                    "vine_layernorm_backward")
             del dy
         if slots[base + 4] is not None and slots[base + 5] is not None:
-            column_sums(ln_part, slots[base + 4], out1=slots[base + 5], n0=H)     # {d gamma | d beta} in one launch
+            column_sums(ln_part, slots[base + 4], out1=slots[base + 5], n0=H, batch=batch)     # {d gamma | d beta}
         else:
             deliver(base + 4, lambda o: column_sums(ln_part[:, :H], o))
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T)
-        deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o))
-        deliver(base + 1, lambda o: splitk_tn(dG, hp.view(n, H), out=o))
+        deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o, batch=batch))
+        deliver(base + 1, lambda o: splitk_tn(dG, hp.view(n, H), out=o, batch=batch))
         if bias_partial is not None and slots[base + 2] is not None and slots[base + 3] is not None:
-            column_sums(bias_partial.view(-1, 4 * H), slots[base + 2], out1=slots[base + 3], dup=True)
+            column_sums(bias_partial.view(-1, 4 * H), slots[base + 2], out1=slots[base + 3], dup=True, batch=batch)
         else:
             deliver(base + 2, lambda o: _sum_rows(bias_partial, dG.float(), out=o))
             deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
@@ -450,10 +489,12 @@ class _Trunk(torch.autograd.Function):
             _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
                                          part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
             x_in = acts[i - 1] if i > 0 else x0
-            deliver(2 * i, lambda o, gz=gz, x_in=x_in: splitk_tn(gz, x_in, out=o))
-            deliver(2 * i + 1, lambda o, part=part: column_sums(part, o))
+            deliver(2 * i, lambda o, gz=gz, x_in=x_in: splitk_tn(gz, x_in, out=o, batch=batch))
+            deliver(2 * i + 1, lambda o, part=part: column_sums(part, o, batch=batch))
             if i > 0:
                 g = _mm(gz, weights[i])
+        if batch is not None:
+            batch.flush(out)
         return (None, None, None, None, None, None, None, None, None, *grads)
 
 
