@@ -111,16 +111,20 @@ int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float
  *   loss = mean(a_loss) + 0.5 * critic_coef * mean(c_loss) - entropy_coef * mean(entropy) + bounds_coef * mean(b_loss)
  * Outputs d(loss)/d(mu) [n,A], d(loss)/d(value) [n], d(loss)/d(logstd) [A] and
  * stats[8] = {mean a_loss, mean c_loss, mean b_loss, mean entropy, mean kl(old||new), loss, 0, 0}.
- * grad_logstd and stats are zeroed by the call.  Rows of mu / grad_mu are mu_stride floats apart and elements of
+ * grad_logstd and stats are overwritten by the call.  Reductions are two-stage through `scratch`
+ * (VINE_PPO_LOSS_SCRATCH_FLOATS floats, contents irrelevant): no float atomics, so gradients and statistics are
+ * bit-reproducible.  Rows of mu / grad_mu are mu_stride floats apart and elements of
  * value / grad_value value_stride apart (0 = packed: A and 1), so both heads can live in one [n, A+1] GEMM output.
  * grad_mu_bias [A] / grad_value_bias [1] (both or neither): the column sums of grad_mu / grad_value -- the gradients
  * of the two head biases -- are ADDED to them (the optimiser leaves its gradient block zeroed after every step). */
+#define VINE_PPO_LOSS_BLOCKS 1024
+#define VINE_PPO_LOSS_SCRATCH_FLOATS (VINE_PPO_LOSS_BLOCKS * 32)
 int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, const float* value, const float* actions,
                   const float* old_neglogp, const float* advantages, const float* old_values, const float* returns,
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
-                  float* grad_value_bias, void* stream);
+                  float* grad_value_bias, float* scratch, void* stream);
 
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps

@@ -316,15 +316,12 @@ def test_graphed_update_equals_eager_update(mixed):
                      {k: float(v) for k, v in stats.items()}, agent.model.running_mean_std.running_mean.clone()))
         env.close()
     (p1, lr1, s1, m1), (p2, lr2, s2, m2) = outs
-    # float atomics (loss statistics, head-bias gradients) make two runs differ in the last bits, and the env
-    # amplifies that over iterations: compare at that level, which still catches any stale/garbled replay
-    # (bf16 operand rounding turns last-bit differences into 2^-8 steps: wider band in mixed mode)
-    f = 5.0 if mixed else 1.0
-    assert max(lr1, lr2) / min(lr1, lr2) < 1.6                 # at most one schedule decision apart
-    assert torch.allclose(m1, m2, rtol=0, atol=1e-3 * f)
-    for k in s1:
-        assert abs(s1[k] - s2[k]) < 2e-2 * f * (1 + abs(s2[k])), (k, s1[k], s2[k])
-    assert float((p1 - p2).abs().max()) < 2e-3 * f
+    # no float atomics anywhere on the training path and the same kernels either way: replayed and eagerly launched
+    # training are bit-identical
+    assert lr1 == lr2
+    assert torch.equal(m1, m2)
+    assert s1 == s2, (s1, s2)
+    assert torch.equal(p1, p2)
 
 
 def _adam_pair(device):

@@ -560,15 +560,8 @@ __global__ __launch_bounds__(1024) void colsum_batched_kernel(ColsumBatch batch)
     }
 }
 
-__global__ void zero3_kernel(float* __restrict__ a, int na, float* __restrict__ b, int nb, float* __restrict__ c,
-                             int nc) {
-    const int t = threadIdx.x;
-    if (t < na) a[t] = 0.0f;
-    if (t < nb) b[t] = 0.0f;
-    if (c && t < nc) c[t] = 0.0f;
-}
-
 #define PPO_MAX_A 8
+#define PPO_LOSS_ROW 32          // floats per workgroup row of the loss kernel's partial sums (22 used)
 __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const float* __restrict__ mu,
                                                        const float* __restrict__ logstd, const float* __restrict__ value,
                                                        const float* __restrict__ actions, const float* __restrict__ old_neglogp,
@@ -579,8 +572,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        float soft_bound, float* __restrict__ grad_mu,
                                                        float* __restrict__ grad_value, float* __restrict__ grad_logstd,
                                                        float* __restrict__ stats, long long mu_stride,
-                                                       long long value_stride, float* __restrict__ grad_mu_bias,
-                                                       float* __restrict__ grad_value_bias) {
+                                                       long long value_stride, float* __restrict__ partial) {
     // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
     // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
     const float inv_n = 1.0f / (float)n;
@@ -592,7 +584,6 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         isg2[k] = 1.0f / (sg[k] * sg[k]);
         sum_ls += ls[k];
     }
-    const float ent = A * (0.5f + 0.9189385332046727f) + sum_ls;   // 0.5 + 0.5*log(2*pi) per dim + logstd
     float acc[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};                   // a, c, b, kl, (unused)
     float gls[PPO_MAX_A], gmb[PPO_MAX_A + 1];              // d/d logstd; column sums of the head gradients
     for (int k = 0; k < A; ++k) gls[k] = 0.0f;
@@ -647,7 +638,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         }
         acc[0] += a_loss; acc[1] += c_loss; acc[2] += b_loss; acc[3] += kl;
     }
-    // block reduction (wave shuffles, then LDS across the 4 waves), one atomic per block and quantity
+    // block reduction (wave shuffles, then LDS across the 4 waves) into one row of `partial` per workgroup; the
+    // finalize kernel adds the rows in a fixed order: no float atomics, results are bit-reproducible
     constexpr int NRED = 5 + 2 * PPO_MAX_A + 1;
     __shared__ float red[4][NRED];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -662,26 +654,48 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         if (lane == 0) red[wave][q] = x;
     }
     __syncthreads();
-    if (threadIdx.x < NRED) {
+    if (threadIdx.x < PPO_LOSS_ROW) {
         const int q = threadIdx.x;
-        const float x = red[0][q] + red[1][q] + red[2][q] + red[3][q];
-        if (q < 4) {
-            const float mean = x * inv_n;
-            atomicAdd(&stats[q == 3 ? 4 : q], mean);
-            const float w = (q == 0) ? 1.0f : (q == 1) ? 0.5f * critic_coef : (q == 2) ? bounds_coef : 0.0f;
-            if (w != 0.0f) atomicAdd(&stats[5], w * mean);
-        } else if (q >= 5 && q - 5 < A) {
-            atomicAdd(&grad_logstd[q - 5], x);
-        } else if (grad_mu_bias && q >= 5 + PPO_MAX_A) {        // accumulated INTO the two bias gradients
-            const int k = q - 5 - PPO_MAX_A;
-            if (k < A) atomicAdd(&grad_mu_bias[k], x);
-            else if (k == PPO_MAX_A) atomicAdd(&grad_value_bias[0], x);
-        }
+        partial[(long long)blockIdx.x * PPO_LOSS_ROW + q] =
+            q < NRED ? (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]) : 0.0f;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&stats[3], ent);
-        atomicAdd(&stats[5], -entropy_coef * ent);
-        for (int k = 0; k < A; ++k) atomicAdd(&grad_logstd[k], -entropy_coef);
+}
+
+// rows of `partial` -> stats[8], grad_logstd[A] and (added into) the two head-bias gradients
+__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(int blocks, int A, long long n,
+                                                                const float* __restrict__ partial,
+                                                                const float* __restrict__ logstd, float critic_coef,
+                                                                float entropy_coef, float bounds_coef,
+                                                                float* __restrict__ stats, float* __restrict__ grad_logstd,
+                                                                float* __restrict__ grad_mu_bias,
+                                                                float* __restrict__ grad_value_bias) {
+    const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
+    float acc = 0.0f;
+    for (int b = rl; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
+    __shared__ float red[8][PPO_LOSS_ROW];
+    __shared__ float tot[PPO_LOSS_ROW];
+    red[rl][q] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        float v = 0.0f;
+        for (int k = 0; k < 8; ++k) v += red[k][q];
+        tot[q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inv_n = 1.0f / (float)n;
+        float sum_ls = 0.0f;
+        for (int k = 0; k < A; ++k) sum_ls += logstd[k];
+        const float ent = A * (0.5f + 0.9189385332046727f) + sum_ls;
+        const float a = tot[0] * inv_n, c = tot[1] * inv_n, b = tot[2] * inv_n, kl = tot[3] * inv_n;
+        stats[0] = a; stats[1] = c; stats[2] = b; stats[3] = ent; stats[4] = kl;
+        stats[5] = a + 0.5f * critic_coef * c + bounds_coef * b - entropy_coef * ent;
+        stats[6] = 0.0f; stats[7] = 0.0f;
+        for (int k = 0; k < A; ++k) grad_logstd[k] = tot[5 + k] - entropy_coef;
+        if (grad_mu_bias) {
+            for (int k = 0; k < A; ++k) grad_mu_bias[k] += tot[5 + PPO_MAX_A + k];
+            grad_value_bias[0] += tot[5 + 2 * PPO_MAX_A];
+        }
     }
 }
 
@@ -1067,23 +1081,24 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
-                  float* grad_value_bias, void* stream) {
+                  float* grad_value_bias, float* scratch, void* stream) {
     if (n <= 0 || A <= 0 || A > PPO_MAX_A || !mu || !logstd || !value || !actions || !old_neglogp || !advantages ||
         !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats ||
-        ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)))
+        ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || !scratch)
         return VINE_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
-    // accumulators are cleared by a kernel, not hipMemsetAsync: memset nodes of a few bytes did not survive repeated
-    // hipGraph replays intact on ROCm 7.0 (observed: alternate floats of `stats` left with stale data)
-    hipLaunchKernelGGL(zero3_kernel, dim3(1), dim3(64), 0, s, stats, 8, grad_logstd, (int)A, (float*)nullptr, 0);
     const int threads = 256;
     int blocks = (int)((n + threads - 1) / threads);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > VINE_PPO_LOSS_BLOCKS) blocks = VINE_PPO_LOSS_BLOCKS;
+    // no hipMemsetAsync and no float atomics: memset nodes of a few bytes did not survive repeated hipGraph replays
+    // intact on ROCm 7.0, and atomics would make the gradients depend on the order workgroups retire in
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(blocks), dim3(threads), 0, s, (long long)n, (int)A, mu, logstd, value,
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats,
                        (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1),
-                       grad_mu_bias, grad_value_bias);
+                       scratch);
+    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, s, blocks, (int)A, (long long)n, scratch, logstd,
+                       critic_coef, entropy_coef, bounds_coef, stats, grad_logstd, grad_mu_bias, grad_value_bias);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

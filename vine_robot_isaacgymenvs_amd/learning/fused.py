@@ -565,6 +565,8 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     A = ls.shape[0]
     grad_logstd = torch.empty(A, device=stats_dev, dtype=torch.float32)
     stats = torch.empty(8, device=stats_dev, dtype=torch.float32)
+    from ..abi import PPO_LOSS_SCRATCH_FLOATS
+    scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=stats_dev, dtype=torch.float32)
     scal = (float(e_clip), int(bool(clip_value)), float(critic_coef), float(entropy_coef), float(bounds_coef),
             float(soft_bound))
     if heads is not None:
@@ -575,7 +577,8 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
         _check(lib.vine_ppo_loss(n, A, hd.data_ptr(), ls.data_ptr(), hd.data_ptr() + 4 * A, *[a.data_ptr() for a in args],
                                  *scal, g.data_ptr(), g.data_ptr() + 4 * A, grad_logstd.data_ptr(), stats.data_ptr(),
                                  A + 1, A + 1, head_bias_grads[0].data_ptr() if head_bias_grads else None,
-                                 head_bias_grads[1].data_ptr() if head_bias_grads else None, _stream(hd)),
+                                 head_bias_grads[1].data_ptr() if head_bias_grads else None, scratch.data_ptr(),
+                                 _stream(hd)),
                "vine_ppo_loss")
         return g, None, grad_logstd, stats
     n = mu.shape[0]
@@ -585,5 +588,5 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     grad_value = torch.empty_like(val_c)
     _check(lib.vine_ppo_loss(n, A, mu_c.data_ptr(), ls.data_ptr(), val_c.data_ptr(), *[a.data_ptr() for a in args],
                              *scal, grad_mu.data_ptr(), grad_value.data_ptr(), grad_logstd.data_ptr(),
-                             stats.data_ptr(), 0, 0, None, None, _stream(mu)), "vine_ppo_loss")
+                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), _stream(mu)), "vine_ppo_loss")
     return grad_mu, grad_value.view_as(value), grad_logstd, stats
