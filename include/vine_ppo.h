@@ -45,7 +45,9 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
  * keep_next = 1 - done_next.  Writes the pre-activation gate gradients (rows dg_stride apart) and the gradient
  * w.r.t. the masked c_{t-1} (dc_prev = dc * f).
  * bias_partial (nullable, [VINE_PPO_PARTIAL_BLOCKS, 4H]) receives per-workgroup column sums of the gate gradients;
- * their sum over rows (and over the T steps) is the bias gradient -- deterministic, no atomics.
+ * bias_partial_prev (nullable, same shape): the rows another time step's call wrote; they are added in, so that after
+ * chaining the T calls the last buffer alone holds the partial sums of the whole sequence.  The column sums of
+ * that buffer are the bias gradient -- deterministic, no atomics.
  * dgates_bf16 != 0: the gate gradients (only ever GEMM operands) are stored as bfloat16, and gates_act is read as
  * bfloat16 (as the forward call with hp_bf16 != 0 wrote it). */
 #define VINE_PPO_PARTIAL_BLOCKS 512
@@ -53,7 +55,7 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
                             const void* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
                             int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
-                            float* bias_partial, int32_t dgates_bf16, void* stream);
+                            float* bias_partial, const float* bias_partial_prev, int32_t dgates_bf16, void* stream);
 
 /* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
  * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.

@@ -112,7 +112,8 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
                                 const DG* __restrict__ gates_act, const float* __restrict__ c_new,
                                 const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
                                 long long done_stride, DG* __restrict__ dgates, long long dg_stride,
-                                float* __restrict__ dc_prev, float* __restrict__ bias_partial) {
+                                float* __restrict__ dc_prev, float* __restrict__ bias_partial,
+                                const float* __restrict__ bias_partial_prev) {
     const int H4 = H >> 2;
     const long long total = B * H4;
     // bias_partial (nullable, [gridDim.x, 4H]): requires blockDim.x % H4 == 0 so that a thread keeps its column quad
@@ -177,9 +178,11 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
             float* row = bias_partial + (long long)blockIdx.x * 4 * H;
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                float sum = 0.0f;
+                const int col = (u >> 2) * H + ((int)threadIdx.x << 2) + (u & 3);
+                // chained over the time steps: this step's row continues the row the previous launch wrote
+                float sum = bias_partial_prev ? bias_partial_prev[(long long)blockIdx.x * 4 * H + col] : 0.0f;
                 for (int t = threadIdx.x; t < (int)blockDim.x; t += H4) sum += red[u * 256 + t];
-                row[(u >> 2) * H + ((int)threadIdx.x << 2) + (u & 3)] = sum;
+                row[col] = sum;
             }
         }
     }
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(1024) void colsum_tall_kernel(const float* __restri
 
 // Several column-sum jobs in ONE launch (the backward pass of the network ends with ~13 of them, each too small to
 // fill the chip and each paying a launch): workgroup -> job through the block-offset table, then the same two
-// geometries as above (64 columns x 16 row-lanes for short matrices, 16 x 64 for tall ones), 1024 threads.
+// geometries (64 columns x 4 row-lanes for short matrices, 16 x 16 for tall ones), 256 threads.
 struct ColsumJob {
     const float* src;
     float* out0;
@@ -530,7 +533,7 @@ struct ColsumBatch {
     ColsumJob job[VINE_COLSUM_MAX_JOBS];
     int njobs;
 };
-__global__ __launch_bounds__(1024) void colsum_batched_kernel(ColsumBatch batch) {
+__global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) {
     int j = 0;
 #pragma unroll 1
     for (int k = 1; k < batch.njobs; ++k)
@@ -538,13 +541,13 @@ __global__ __launch_bounds__(1024) void colsum_batched_kernel(ColsumBatch batch)
     const ColsumJob& J = batch.job[j];
     const int blk = blockIdx.x - J.first_block;
     const bool tall = J.R >= 128;
-    const int ct = tall ? 16 : 64, rlanes = tall ? 64 : 16;
+    const int ct = tall ? 16 : 64, rlanes = tall ? 16 : 4;
     const int cl = threadIdx.x % ct, rl = threadIdx.x / ct;
     const long long c = (long long)blk * ct + cl;
     float acc = 0.0f;
     if (c < J.C)
         for (long long r = rl; r < J.R; r += rlanes) acc += J.src[r * J.row_stride + c];
-    __shared__ float red[1024];
+    __shared__ float red[256];
     red[rl * ct + cl] = acc;
     __syncthreads();
     // fixed-order tree over the row lanes (power of two)
@@ -922,7 +925,7 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
                             const float* dc_next, const uint8_t* done_next, int64_t done_next_stride,
                             const void* gates_act, const float* c_new, const float* c_prev, const uint8_t* done,
                             int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
-                            float* bias_partial, int32_t dgates_bf16, void* stream) {
+                            float* bias_partial, const float* bias_partial_prev, int32_t dgates_bf16, void* stream) {
     if (B <= 0 || H <= 0 || (H & 3) || (g_stride & 3) || (dg_stride & 3) || !g_out || !gates_act || !c_new || !c_prev ||
         !dgates || !dc_prev)
         return VINE_ERR_INVALID_ARG;
@@ -935,13 +938,13 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
                            (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
                            (const bf16_t*)gates_act, c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates,
                            (long long)dg_stride,
-                           dc_prev, bias_partial);
+                           dc_prev, bias_partial, bias_partial_prev);
     else
         hipLaunchKernelGGL(lstm_bwd_kernel<float>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
                            (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
                            (const float*)gates_act, c_new, c_prev, done, (long long)done_stride, (float*)dgates,
                            (long long)dg_stride,
-                           dc_prev, bias_partial);
+                           dc_prev, bias_partial, bias_partial_prev);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -1058,7 +1061,7 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
         blocks += (int)((C[k] + ct - 1) / ct);
     }
     b.njobs = njobs;
-    hipLaunchKernelGGL(colsum_batched_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

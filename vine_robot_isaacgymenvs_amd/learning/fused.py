@@ -177,7 +177,9 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
     dG3 = dG.view(B, T, 4 * H)
     dc = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
     use_partial = H <= 1024 and 256 % (H // 4) == 0
-    bias_partial = torch.empty((T, PPO_PARTIAL_BLOCKS, 4 * H), device=dev, dtype=torch.float32) if use_partial else None
+    # one [PPO_PARTIAL_BLOCKS, 4H] block per step, chained: step t adds the rows of step t+1, the last one (t = 0)
+    # holds the partial sums of the whole sequence
+    bias_partial = torch.empty((2, PPO_PARTIAL_BLOCKS, 4 * H), device=dev, dtype=torch.float32) if use_partial else None
     st = _stream(g_out)
     d_ptr = dones.data_ptr() if dones is not None else None
     g_rec = None
@@ -189,12 +191,13 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
             dc_next.data_ptr() if dc_next is not None else None, dn, T, gates[t].data_ptr(),
             c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
             dG.data_ptr() + dG.element_size() * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(),
-            bias_partial[t].data_ptr() if use_partial else None, int(dG.dtype == torch.bfloat16), st),
-            "vine_lstm_cell_backward")
+            bias_partial[t & 1].data_ptr() if use_partial else None,
+            bias_partial[(t + 1) & 1].data_ptr() if (use_partial and t < T - 1) else None,
+            int(dG.dtype == torch.bfloat16), st), "vine_lstm_cell_backward")
         dc_next = dc[t & 1]
         if t > 0:
             g_rec = _mm(dG3[:, t], w_hh)
-    return dG, bias_partial
+    return dG, (bias_partial[0] if use_partial else None)     # t = 0 ran last
 
 
 def _sum_rows(partial, full, out=None):
