@@ -579,6 +579,13 @@ def f6_trajectory(vt, v5, out):
         d = {k: np.stack(v) for k, v in rec.items()}
         d.update(first_obs=rec_first, env_overrides=np.array(sorted("%s=%r" % kv for kv in env_over.items())))
         out["f6_traj_" + tag] = d
+        if tag == "delay1":
+            # F7: the dashboard scalars the reference puts into wandb_dict every step (V5:1250-1322): key names and,
+            # for the last step of this trajectory, the values computed from the state the fixture already records
+            keys = sorted(task.wandb_dict.keys())
+            out["f7_wandb_keys"] = dict(keys=np.array(keys),
+                                        values=np.array([float(task.wandb_dict[k]) for k in keys], np.float64),
+                                        index_to_view=np.int64(task.index_to_view))
 
 
 def main():
@@ -590,7 +597,7 @@ def main():
     f3_reward(vt, v5, out)
     f4_reset(vt, v5, out)
     f5_reset_sampling(vt, v5, out)
-    f6_trajectory(vt, v5, out)
+    f6_trajectory(vt, v5, out)       # also writes F7 (wandb_dict keys)
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)

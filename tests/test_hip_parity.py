@@ -257,6 +257,38 @@ def test_golden_trajectory_from_reference(HipEnv, golden, tag, delay, obs_type):
         np.testing.assert_allclose(rew, g["rew"][t], rtol=1e-4, atol=1e-3)
 
 
+def test_dashboard_scalars_match_reference(HipEnv, golden):
+    """F7: after replaying the F6 trajectory through the Python task class, ``collect_stats()`` reproduces the ~120
+    scalars the reference's compute_reward left in ``wandb_dict`` at the same step (V5:1250-1322), key for key."""
+    import torch
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    from vine_robot_isaacgymenvs_amd.utils.config import load_task_config
+    g, ref = golden("f6_traj_delay1"), golden("f7_wandb_keys")
+    T, N, _ = g["actions"].shape
+    ov = ["num_envs=%d" % N, "vine_randomize=False", "task.env.CREATE_PIPE=False", "task.env.ACTION_DELAY=1",
+          "task.env.DAMPING=0.08", "task.env.maxEpisodeLength=20", "task.env.SUCCESS_DIST=0.12", "RAIL_SOFT_LIMIT=0.2",
+          "task.env.MIN_TARGET_Y=-0.3", "task.env.MAX_TARGET_Y=-0.1", "task.env.MIN_TARGET_Z=0.53",
+          "task.env.MAX_TARGET_Z=0.6", "task.env.RANDOM_INIT_CART_MIN_Y=-0.02", "task.env.RANDOM_INIT_CART_MAX_Y=0.2",
+          "task.env.physicsModel.fpamDampingHeld=True"]
+    env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=load_task_config("Vine5LinkMovingBase", overrides=ov),
+                                                  rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=0,
+                                                  headless=True)
+    assert env.index_to_view == int(ref["index_to_view"])
+    env.bind_reward_matrix()
+    for t in range(T):
+        env.bind_reset_values(g["reset_values"][t])
+        obs, rew, rst, _ = env.step(torch.as_tensor(g["actions"][t], device="cuda:0"))
+    np.testing.assert_allclose(rew.cpu().numpy(), g["rew"][T - 1], rtol=1e-4, atol=1e-3)
+    stats = env.collect_stats()
+    bad = []
+    for k, v in zip(ref["keys"], ref["values"]):
+        got = stats[str(k)]
+        if not abs(got - v) <= 3e-3 + 2e-3 * abs(v):
+            bad.append((str(k), got, float(v)))
+    assert not bad, bad
+    env.close()
+
+
 def test_reset_idx_outside_step(HipEnv):
     n = 300
     cfg = base_cfg(n)
@@ -372,7 +404,7 @@ def test_envs_are_independent_of_batch_position(HipEnv):
     np.testing.assert_array_equal(rst[sub], rst2)
 
 
-def test_task_class_step_contract(HipEnv):
+def test_task_class_step_contract(HipEnv, golden):
     """The Python drop-in: shapes, dtypes, devices and first-step semantics of VecTask.step/reset."""
     import torch
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
@@ -403,6 +435,9 @@ def test_task_class_step_contract(HipEnv):
                 "tip_pos_z at self.index_to_view", "Mean Position Success Reward", "Weighted Max Contact Force Reward",
                 "Mean Total Reward", "progress_buf"):
         assert key in stats and np.isfinite(stats[key]), key
+    # exactly the key set the reference's compute_reward leaves in wandb_dict (golden F7, from the reference's Python)
+    ref_keys = set(str(k) for k in golden("f7_wandb_keys")["keys"])
+    assert set(stats) == ref_keys, (sorted(ref_keys - set(stats)), sorted(set(stats) - ref_keys))
     assert len(stats) >= 118
     assert abs(stats["Mean Const Negative Reward"] + 1.0) < 1e-6 and 0.0 < stats["progress_buf"] <= 6.0
     env.close()
