@@ -39,6 +39,18 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
                            const uint8_t* done_next, int64_t done_next_stride, int32_t hp_bf16, int64_t hp_stride,
                            void* stream);
 
+/* The same LSTM step with the recurrent GEMM fused in (matrix cores, bfloat16 operands, fp32 accumulation):
+ *   gates = A W^T + igates + bias   with A [B, K] bf16 (rows lda apart) and W [4H, K] bf16 (rows ldw apart),
+ * then the pointwise update exactly as vine_lstm_cell_forward; the [B, 4H] pre-activations never reach HBM.
+ * igates is nullable (the rollout's single GEMM over [x | h] has no separate input projection).  gates_act and
+ * hp_next are bfloat16.  Needs B % 64 == 0, H % 16 == 0, K in {128, 256, 288, 320, 352, 384, 512}; otherwise
+ * VINE_ERR_UNSUPPORTED (callers fall back to GEMM + vine_lstm_cell_forward). */
+int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
+                        const float* igates, int64_t ig_stride, const float* bias, const float* c_prev,
+                        const uint8_t* done, int64_t done_stride, float* h_out, int64_t h_stride, float* c_out,
+                        void* gates_act, void* hp_next, const uint8_t* done_next, int64_t done_next_stride,
+                        int64_t hp_stride, void* stream);
+
 /* Backward of the step above.
  *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
  * g_rec / dc_next = gradients w.r.t. the MASKED (h_t, c_t) consumed by step t+1 (NULL at the last step),

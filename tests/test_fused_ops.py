@@ -142,6 +142,51 @@ def test_pointwise_kernels_against_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,K,with_ig", [(8192, 256, True), (1024, 352, False), (64, 128, True)])
+def test_lstm_step_mfma_matches_gemm_plus_pointwise(B, K, with_ig):
+    """The matrix-core LSTM step (recurrent GEMM fused with the pointwise update, pre-activations never stored) against
+    the unfused pair it replaces: torch GEMM on the same bf16 operands + vine_lstm_cell_forward."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    lib = fused._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    H = 256
+    bf = torch.bfloat16
+    A = (torch.randn(B, K + 16, device=dev) * 0.5).to(bf)[:, :K]                  # padded rows
+    W = (torch.randn(4 * H, K, device=dev) / K ** 0.5).to(bf)
+    ig = torch.randn(B, 4 * H, device=dev) if with_ig else None
+    bias = torch.randn(4 * H, device=dev) * 0.1
+    c0 = torch.randn(B, H, device=dev)
+    done = (torch.rand(B, device=dev) < 0.3).to(torch.uint8)
+    done_n = (torch.rand(B, device=dev) < 0.3).to(torch.uint8)
+
+    def outputs():
+        return (torch.empty(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, 4 * H, device=dev, dtype=bf),
+                torch.empty(B, H, device=dev, dtype=bf))
+    pre = torch.mm(A, W.t(), out_dtype=torch.float32)                 # the GEMM the fused kernel absorbs
+    zero_ig = torch.zeros(B, 4 * H, device=dev)
+    h2, c2, g2, hp2 = outputs()
+    rc = lib.vine_lstm_step_mfma(B, H, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+                                 ig.data_ptr() if with_ig else None, 4 * H, bias.data_ptr(), c0.data_ptr(), done.data_ptr(), 1,
+                                 h2.data_ptr(), H, c2.data_ptr(), g2.data_ptr(), hp2.data_ptr(), done_n.data_ptr(), 1, H, st)
+    assert rc == 0
+    keep = (1.0 - done.float()).unsqueeze(1)
+    # fused kernel: no keep-scaling of the GEMM term (its operand is masked upstream), c is masked by `done`
+    c_masked = c0 * keep
+    h3, c3, g3, hp3 = outputs()
+    assert lib.vine_lstm_cell_forward(B, H, (ig if with_ig else zero_ig).data_ptr(), 4 * H, pre.data_ptr(), bias.data_ptr(),
+                                      c_masked.data_ptr(), None, 0, h3.data_ptr(), H, c3.data_ptr(), g3.data_ptr(),
+                                      hp3.data_ptr(), done_n.data_ptr(), 1, 1, H, st) == 0
+    torch.cuda.synchronize()
+    for name, a, b, tol in (("h", h2, h3, 2e-5), ("c", c2, c3, 2e-5), ("gates", g2.float(), g3.float(), 8e-3),
+                            ("hp", hp2.float(), hp3.float(), 8e-3)):
+        assert float((a - b).abs().max()) < tol, (name, float((a - b).abs().max()))
+    assert lib.vine_lstm_step_mfma(B + 1, H, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), None, 4 * H,
+                                   bias.data_ptr(), c0.data_ptr(), None, 0, h2.data_ptr(), H, c2.data_ptr(), None, None,
+                                   None, 0, H, st) == -2                          # unsupported shape: caller falls back
+
+
+@pytest.mark.gpu
 def test_splitk_linear_gradients():
     dev = torch.device("cuda:0")
     torch.manual_seed(1)

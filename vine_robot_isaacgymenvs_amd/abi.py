@@ -160,6 +160,8 @@ PPO_LOSS_SCRATCH_FLOATS = 1024 * 32   # VINE_PPO_LOSS_SCRATCH_FLOATS
 PPO_PROTOTYPES = {
     "vine_lstm_cell_forward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _VP, _VP,
                                          _VP, _I64, C.c_int32, _I64, _VP]),
+    "vine_lstm_step_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _I64, _VP, _I64,
+                                      _VP, _VP, _VP, _VP, _I64, _I64, _VP]),
     "vine_lstm_cell_backward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP,
                                           _I64, _VP, _VP, _VP, C.c_int32, _VP]),
     "vine_layernorm_forward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP]),

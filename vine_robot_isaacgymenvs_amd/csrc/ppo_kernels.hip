@@ -105,6 +105,103 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
     }
 }
 
+// ---- LSTM step with the recurrent GEMM fused in: gates = A W^T (+ igates) + bias on the matrix cores, pointwise
+// epilogue on the accumulators; the [B, 4H] pre-activations never touch HBM.
+//   A [B, K] bf16 (masked h, or the rollout's [x | h] operand), W [4H, K] bf16 (w_hh, or [w_ih | w_hh]).
+// Tiling: workgroup = 4 waves = 64 batch rows x 16 hidden units (x 4 gates); each wave 16 rows.  Computed transposed
+// (D^T = W A^T) with v_mfma_f32_16x16x32_bf16 so that a lane ends up with 4 CONSECUTIVE hidden units of ONE batch
+// row for each gate (C/D map: col = lane & 15 -> batch row, row = 4 (lane >> 4) + reg -> hidden unit): float4 I/O.
+// W's 64 x K slab is staged once in LDS (row pitch K*2 + 16 B: the 16 lanes of a fragment read hit distinct banks;
+// 33 KB at K = 256: 4 workgroups per CU); the A fragments (16 B per lane and k-step) come straight from global memory.
+// Measured at B = 8192, K = 256: 33 us against 16 us (hipBLASLt GEMM) + 24 us (pointwise kernel) unfused.  Two
+// re-tilings were tried and rejected: 32 units per workgroup with the whole slab in LDS (68 KB, 2 workgroups per CU:
+// 46 us) and 32 units with W streamed through LDS in double-buffered 64-wide k chunks (36 KB: 52 us).
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+#define LSTM_MFMA_MAX_K 512
+
+template <int KSTEPS>      // K = 32 * KSTEPS
+__global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
+    long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W, long long ldw,
+    const float* __restrict__ igates, long long ig_stride, const float* __restrict__ bias,
+    const float* __restrict__ c_prev, const unsigned char* __restrict__ done, long long done_stride,
+    float* __restrict__ h_out, long long h_stride, float* __restrict__ c_out, bf16_t* __restrict__ gates_act,
+    bf16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next, long long done_next_stride,
+    long long hp_stride) {
+    constexpr int K = 32 * KSTEPS;
+    constexpr int PITCH = K + 8;                               // bf16 elements: K*2 + 16 bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(lds_raw);           // [4 gates x 16 units][PITCH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * 16;                            // first hidden unit of this workgroup
+    const long long b0 = (long long)blockIdx.x * 64 + wave * 16;
+    // stage W: LDS row g*16 + i  <-  W[g*H + u0 + i][0:K]   (16-B chunks, coalesced along k)
+    constexpr int CHUNKS = K / 8;
+    for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
+        const int row = c / CHUNKS, ck = c - row * CHUNKS;
+        const int g = row >> 4, i = row & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(W + (long long)(g * H + u0 + i) * ldw + ck * 8);
+        *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
+    }
+    // A fragments of this wave's 16 batch rows: lane holds A[b0 + (lane & 15)][32 kk + 8 (lane >> 4) + 0..7]
+    bf16x8_t af[KSTEPS];
+    const bf16_t* arow = A + (b0 + (lane & 15)) * lda + 8 * (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk);
+    __syncthreads();
+    f32x4_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x8_t wf =
+                *reinterpret_cast<const bf16x8_t*>(&wl[(g * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[g], 0, 0, 0);
+        }
+    }
+    // epilogue: this lane owns batch row b, hidden units j .. j+3
+    const long long b = b0 + (lane & 15);
+    const int j = u0 + 4 * (lane >> 4);
+    const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+    float pre[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bb = ld4(bias + g * H + j);
+        pre[g][0] = acc[g][0] + bb.x; pre[g][1] = acc[g][1] + bb.y; pre[g][2] = acc[g][2] + bb.z; pre[g][3] = acc[g][3] + bb.w;
+        if (igates) {
+            const float4 a = ld4(igates + b * ig_stride + g * H + j);
+            pre[g][0] += a.x; pre[g][1] += a.y; pre[g][2] += a.z; pre[g][3] += a.w;
+        }
+    }
+    const float4 cp = ld4(c_prev + b * H + j);
+    const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+    float gi[4], gf[4], gg[4], go[4], cn[4], hn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        gi[u] = sigmoidf_(pre[0][u]);
+        gf[u] = sigmoidf_(pre[1][u]);
+        gg[u] = tanhf_(pre[2][u]);
+        go[u] = sigmoidf_(pre[3][u]);
+        cn[u] = gf[u] * (keep * cpv[u]) + gi[u] * gg[u];
+        hn[u] = go[u] * tanhf_(cn[u]);
+    }
+    st4(c_out + b * H + j, make_float4(cn[0], cn[1], cn[2], cn[3]));
+    st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
+    if (hp_next) {
+        const float kn = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+        st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
+    }
+    if (gates_act) {
+        bf16_t* ga = gates_act + b * 4LL * H;
+        st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
+        st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
+        st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
+        st4(ga + 3 * H + j, make_float4(go[0], go[1], go[2], go[3]));
+    }
+}
+
 template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
@@ -918,6 +1015,45 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
                            (long long)h_stride, c_out, (float*)gates_act, (float*)hp_next, done_next,
                            (long long)done_next_stride,
                            (long long)hp_stride);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
+                        const float* igates, int64_t ig_stride, const float* bias, const float* c_prev,
+                        const uint8_t* done, int64_t done_stride, float* h_out, int64_t h_stride, float* c_out,
+                        void* gates_act, void* hp_next, const uint8_t* done_next, int64_t done_next_stride,
+                        int64_t hp_stride, void* stream) {
+    if (hp_stride <= 0) hp_stride = h_stride;
+    if (B <= 0 || H <= 0 || K <= 0 || !A || !W || !bias || !c_prev || !h_out || !c_out || (lda & 7) || (ldw & 7) ||
+        (ig_stride & 3) || (h_stride & 3) || (hp_stride & 3))
+        return VINE_ERR_INVALID_ARG;
+    if ((B & 63) || (H & 15) || (K & 31) || K > LSTM_MFMA_MAX_K) return VINE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(B / 64), (unsigned)(H / 16)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);            // 33 KB at K = 256, 45 KB at K = 352
+    static bool lds_raised[LSTM_MFMA_MAX_K / 32 + 1] = {};               // K = 512 needs more than the 64 KB default
+#define VINE_LSTM_MFMA(KS)                                                                                              \
+    if (lds > 65536 && !lds_raised[KS]) {                                                                               \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_step_mfma_kernel<KS>),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                    \
+            return VINE_ERR_DEVICE;                                                                                     \
+        lds_raised[KS] = true;                                                                                          \
+    }                                                                                                                   \
+    hipLaunchKernelGGL(lstm_step_mfma_kernel<KS>, grid, block, lds, s, (long long)B, (int)H, (const bf16_t*)A,          \
+                       (long long)lda, (const bf16_t*)W, (long long)ldw, igates, (long long)ig_stride, bias, c_prev,     \
+                       done, (long long)done_stride, h_out, (long long)h_stride, c_out, (bf16_t*)gates_act,              \
+                       (bf16_t*)hp_next, done_next, (long long)done_next_stride, (long long)hp_stride)
+    switch (K / 32) {
+        case 4: VINE_LSTM_MFMA(4); break;
+        case 8: VINE_LSTM_MFMA(8); break;
+        case 9: VINE_LSTM_MFMA(9); break;
+        case 10: VINE_LSTM_MFMA(10); break;
+        case 11: VINE_LSTM_MFMA(11); break;
+        case 12: VINE_LSTM_MFMA(12); break;
+        case 16: VINE_LSTM_MFMA(16); break;
+        default: return VINE_ERR_UNSUPPORTED;
+    }
+#undef VINE_LSTM_MFMA
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

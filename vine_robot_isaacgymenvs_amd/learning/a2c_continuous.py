@@ -353,12 +353,14 @@ class A2CAgent:
         width = U + (F_in if net.rnn_concat_input else 0)
         XW = (width + 15) // 16 * 16
         f = {"op": op, "U": U, "F": F_in, "XW": XW, "H": H,
-             "xh": torch.zeros((N, XW + H), device=dev, dtype=op),
+             # two copies used alternately: the fused step kernel reads every column of its rows while other
+             # workgroups write the new h block, so the h it produces goes to the OTHER buffer
+             "xh2": [torch.zeros((N, XW + H), device=dev, dtype=op) for _ in range(2)], "cur": 0,
              "wcat": torch.zeros((4 * H, XW + H), device=dev, dtype=op),
              "acts": [torch.empty((N, u), device=dev, dtype=op) for u in net.units[:-1]],
              "y": torch.empty((N, H), device=dev), "h_tmp": torch.empty((N, H), device=dev),
              "c_tmp": torch.empty((N, H), device=dev)}
-        f["x0"] = f["xh"][:, U:U + F_in] if net.rnn_concat_input else torch.empty((N, F_in), device=dev, dtype=op)
+        f["x0_sep"] = None if net.rnn_concat_input else torch.empty((N, F_in), device=dev, dtype=op)
         self._fast = f
 
     def _infer_begin(self):
@@ -370,7 +372,8 @@ class A2CAgent:
         f["wcat"][:, f["XW"]:].copy_(src(r.weight_hh_l0))
         f["mlp"] = [(src(m.weight), m.bias) for m in net.actor_mlp if isinstance(m, torch.nn.Linear)]
         f["bias"] = r.bias_ih_l0 + r.bias_hh_l0
-        f["xh"][:, f["XW"]:].copy_(self.rnn_states[0][0])
+        f["cur"] = 0
+        f["xh2"][0][:, f["XW"]:].copy_(self.rnn_states[0][0])
 
     def _infer(self, obs, commit=True):
         """Policy trunk for one step, no autograd: normalise -> [GEMM + bias/ELU kernel] x L -> ONE gate GEMM over
@@ -382,7 +385,9 @@ class A2CAgent:
         N, H, XW = self.num_actors, f["H"], f["XW"]
         bf = int(f["op"] == torch.bfloat16)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        xh, x0 = f["xh"], f["x0"]
+        xh, xh_next = f["xh2"][f["cur"]], f["xh2"][f["cur"] ^ 1]
+        x0 = f["x0_sep"] if f["x0_sep"] is not None else xh[:, f["U"]:f["U"] + f["F"]]
+        hp_ptr = (xh_next.data_ptr() + xh_next.element_size() * XW) if commit else None
         fused._check(lib.vine_normalize_obs(N, f["F"], obs.data_ptr(), rms.running_mean.data_ptr(),
                                             rms.running_var.data_ptr(), float(rms.epsilon), 5.0, x0.data_ptr(),
                                             x0.stride(0), bf, st), "vine_normalize_obs")
@@ -394,13 +399,24 @@ class A2CAgent:
             fused._check(lib.vine_bias_elu(N, z.shape[1], z.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(), out.stride(0),
                                            bf, st), "vine_bias_elu")
             x = out
-        gates = fused._mm(xh, f["wcat"].t())
         h32, c = self.rnn_states[0][0], self.rnn_states[1][0]
         h_out, c_out = (h32, c) if commit else (f["h_tmp"], f["c_tmp"])
-        fused._check(lib.vine_lstm_cell_forward(
-            N, H, gates.data_ptr(), 4 * H, None, f["bias"].data_ptr(), c.data_ptr(), None, 0, h_out.data_ptr(), H,
-            c_out.data_ptr(), None, (xh.data_ptr() + xh.element_size() * XW) if commit else None, None, 0, bf,
-            XW + H, st), "vine_lstm_cell_forward")
+        Kx = XW + H
+        if bf and N % 64 == 0 and Kx in (128, 256, 288, 320, 352, 384, 512) and H % 16 == 0:
+            # gate GEMM over [x | h] fused with the pointwise update on the matrix cores
+            fused._check(lib.vine_lstm_step_mfma(
+                N, H, Kx, xh.data_ptr(), xh.stride(0), f["wcat"].data_ptr(), f["wcat"].stride(0), None, 4 * H,
+                f["bias"].data_ptr(), c.data_ptr(), None, 0, h_out.data_ptr(), H, c_out.data_ptr(), None,
+                hp_ptr, None, 0, Kx, st), "vine_lstm_step_mfma")
+            gates = None
+        else:
+            gates = fused._mm(xh, f["wcat"].t())
+        if gates is not None:
+            fused._check(lib.vine_lstm_cell_forward(
+                N, H, gates.data_ptr(), 4 * H, None, f["bias"].data_ptr(), c.data_ptr(), None, 0, h_out.data_ptr(), H,
+                c_out.data_ptr(), None, hp_ptr, None, 0, bf, XW + H, st), "vine_lstm_cell_forward")
+        if commit:
+            f["cur"] ^= 1
         y = f["y"]
         fused._check(lib.vine_layernorm_forward(N, H, h_out.data_ptr(), net.layer_norm.weight.data_ptr(),
                                                 net.layer_norm.bias.data_ptr(), float(net.layer_norm.eps), y.data_ptr(),
@@ -447,7 +463,6 @@ class A2CAgent:
         fast = getattr(self, "_fast", None) is not None
         if fast:
             self._infer_begin()
-        h_op = self._fast["xh"].data_ptr() + self._fast["xh"].element_size() * self._fast["XW"] if fast else None
         h_op_stride = self._fast["XW"] + H if fast else 0
         h_op_bf16 = int(fast and self._fast["op"] == torch.bfloat16)
         for n in range(self.horizon_length):
@@ -471,7 +486,10 @@ class A2CAgent:
                 buf["values"][n].data_ptr(), float(self.reward_shift), float(self.reward_scale), gamma_b,
                 buf["rewards"][n].data_ptr(), self.dones.data_ptr(), self.current_rewards.data_ptr(),
                 self.current_lengths.data_ptr(), self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr(),
-                self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(), h_op, h_op_stride,
+                self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(),
+                # the operand copy of h that the NEXT step reads (the buffer _infer just switched to)
+                (self._fast["xh2"][self._fast["cur"]].data_ptr()
+                 + self._fast["xh2"][0].element_size() * self._fast["XW"]) if fast else None, h_op_stride,
                 h_op_bf16, st), "vine_rollout_post")
         self.obs = obs
         y = self._infer(obs, commit=False) if fast else trunk(obs)[0]

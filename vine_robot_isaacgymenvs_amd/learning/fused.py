@@ -152,9 +152,20 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
     st = _stream(ig)
     d_ptr = dones.data_ptr() if dones is not None else None
     w_hh_t = w_hh.t()
+    # mixed precision: the recurrent GEMM runs inside the step kernel on the matrix cores (vine_lstm_step_mfma)
+    mfma = (op == torch.bfloat16 and B % 64 == 0 and H in (128, 256, 512))
     for t in range(T):
-        hg = _mm(hp[:, t], w_hh_t)
         last = t == T - 1
+        if mfma:
+            _check(lib.vine_lstm_step_mfma(
+                B, H, H, hp.data_ptr() + 2 * (t * H), T * H, w_hh.data_ptr(), w_hh.stride(0),
+                ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, bias.data_ptr(), c_all[t].data_ptr(),
+                (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
+                c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
+                None if last else hp.data_ptr() + 2 * ((t + 1) * H),
+                (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, T * H, st), "vine_lstm_step_mfma")
+            continue
+        hg = _mm(hp[:, t], w_hh_t)
         # hg is already built from the masked state: no second masking inside the kernel (done = NULL), except for c
         _check(lib.vine_lstm_cell_forward(
             B, H, ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, hg.data_ptr(), bias.data_ptr(), c_all[t].data_ptr(),
