@@ -135,6 +135,24 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 16;                            // first hidden unit of this workgroup
     const long long b0 = (long long)blockIdx.x * 64 + wave * 16;
+    // Everything this wave will need from HBM is requested up front, so that its latency runs under the weight staging
+    // and the MFMA loop: A fragments (lane holds A[b0 + (lane & 15)][32 kk + 8 (lane >> 4) + 0..7]) and the epilogue's
+    // operands (this lane owns batch row b, hidden units j .. j+3 of every gate).
+    const long long b = b0 + (lane & 15);
+    const int j = u0 + 4 * (lane >> 4);
+    bf16x8_t af[KSTEPS];
+    const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk);
+    float4 igv[4], bbv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bbv[g] = ld4(bias + g * H + j);
+        igv[g] = igates ? ld4(igates + b * ig_stride + g * H + j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    const float4 cp = ld4(c_prev + b * H + j);
+    const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+    const float kn = (hp_next && done_next) ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
     // stage W: LDS row g*16 + i  <-  W[g*H + u0 + i][0:K]   (16-B chunks, coalesced along k)
     constexpr int CHUNKS = K / 8;
     for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
@@ -143,11 +161,6 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
         const uint4 v = *reinterpret_cast<const uint4*>(W + (long long)(g * H + u0 + i) * ldw + ck * 8);
         *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
     }
-    // A fragments of this wave's 16 batch rows: lane holds A[b0 + (lane & 15)][32 kk + 8 (lane >> 4) + 0..7]
-    bf16x8_t af[KSTEPS];
-    const bf16_t* arow = A + (b0 + (lane & 15)) * lda + 8 * (lane >> 4);
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk);
     __syncthreads();
     f32x4_t acc[4];
 #pragma unroll
@@ -161,21 +174,12 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[g], 0, 0, 0);
         }
     }
-    // epilogue: this lane owns batch row b, hidden units j .. j+3
-    const long long b = b0 + (lane & 15);
-    const int j = u0 + 4 * (lane >> 4);
-    const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
     float pre[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const float4 bb = ld4(bias + g * H + j);
-        pre[g][0] = acc[g][0] + bb.x; pre[g][1] = acc[g][1] + bb.y; pre[g][2] = acc[g][2] + bb.z; pre[g][3] = acc[g][3] + bb.w;
-        if (igates) {
-            const float4 a = ld4(igates + b * ig_stride + g * H + j);
-            pre[g][0] += a.x; pre[g][1] += a.y; pre[g][2] += a.z; pre[g][3] += a.w;
-        }
+        pre[g][0] = acc[g][0] + bbv[g].x + igv[g].x; pre[g][1] = acc[g][1] + bbv[g].y + igv[g].y;
+        pre[g][2] = acc[g][2] + bbv[g].z + igv[g].z; pre[g][3] = acc[g][3] + bbv[g].w + igv[g].w;
     }
-    const float4 cp = ld4(c_prev + b * H + j);
     const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
     float gi[4], gf[4], gg[4], go[4], cn[4], hn[4];
 #pragma unroll
@@ -189,10 +193,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     }
     st4(c_out + b * H + j, make_float4(cn[0], cn[1], cn[2], cn[3]));
     st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
-    if (hp_next) {
-        const float kn = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
-        st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
-    }
+    if (hp_next) st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
     if (gates_act) {
         bf16_t* ga = gates_act + b * 4LL * H;
         st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
