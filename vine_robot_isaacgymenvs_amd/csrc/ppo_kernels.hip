@@ -22,12 +22,19 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// bfloat16 storage (GEMM operands of the mixed-precision update; arithmetic stays fp32): round to nearest even
+// bfloat16 storage (GEMM operands of the mixed-precision update; arithmetic stays fp32): round to nearest even, by
+// the hardware conversion of gfx950 (v_cvt_pk_bf16_f32: one instruction per two values)
 typedef unsigned short bf16_t;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_hw;
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2_hw;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return *reinterpret_cast<const bf16_t*>(&h);
+}
+__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {      // two values -> one packed dword
+    const f32x2_hw v = {lo, hi};
+    const bf16x2_hw h = __builtin_convertvector(v, bf16x2_hw);
+    return *reinterpret_cast<const unsigned*>(&h);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 // 4 consecutive elements, fp32 or bf16 storage
@@ -38,8 +45,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 r;
-    r.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-    r.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    r.x = f2bf2(v.x, v.y);
+    r.y = f2bf2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
 }
 
