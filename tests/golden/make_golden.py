@@ -588,6 +588,41 @@ def f6_trajectory(vt, v5, out):
                                         index_to_view=np.int64(task.index_to_view))
 
 
+def f8_ppo_loss_terms(out):
+    """F8: the PPO loss terms as the reference's in-tree text states them (isaacgymenvs/learning/common_agent.py:
+    _actor_loss 482-501, _critic_loss 503-516, bound_loss 427-435).  rl_games (the code that actually runs) is not
+    installed; these three methods are lifted out of the reference file by name and run on a stand-in ``self``."""
+    import ast
+    import types
+    path = os.path.join(REF, "isaacgymenvs/learning/common_agent.py")
+    tree = ast.parse(open(path).read())
+    wanted = {"_actor_loss", "_critic_loss", "bound_loss"}
+    funcs = [n for cls in tree.body if isinstance(cls, ast.ClassDef) for n in cls.body
+             if isinstance(n, ast.FunctionDef) and n.name in wanted]
+    assert {f.name for f in funcs} == wanted
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), path, "exec"), ns)
+    agent = types.SimpleNamespace(ppo=True, bounds_loss_coef=0.0001, ppo_device="cpu")
+    g = torch.Generator().manual_seed(808)
+    n, A = 512, 2
+    old_nlp = torch.randn(n, generator=g) * 0.5 + 2.0
+    nlp = old_nlp + torch.randn(n, generator=g) * 0.3
+    adv = torch.randn(n, generator=g)
+    old_v, v, ret = torch.randn(n, 1, generator=g), torch.randn(n, 1, generator=g), torch.randn(n, 1, generator=g)
+    v[:64] = old_v[:64] + 0.5                      # beyond the clip range
+    mu = torch.randn(n, A, generator=g) * 0.9      # a good share beyond +-1
+    e_clip = 0.2
+    a = ns["_actor_loss"](agent, old_nlp, nlp, adv, e_clip)
+    c = ns["_critic_loss"](agent, old_v, v, e_clip, ret, True)
+    c_noclip = ns["_critic_loss"](agent, old_v, v, e_clip, ret, False)
+    b = ns["bound_loss"](agent, mu)
+    out["f8_ppo_loss_terms"] = dict(old_neglogp=npf(old_nlp), neglogp=npf(nlp), advantage=npf(adv), old_values=npf(old_v),
+                                    values=npf(v), returns=npf(ret), mu=npf(mu), e_clip=np.float64(e_clip),
+                                    a_loss=npf(a["actor_loss"]), clip_frac=npf(a["actor_clip_frac"]),
+                                    c_loss=npf(c["critic_loss"]), c_loss_noclip=npf(c_noclip["critic_loss"]),
+                                    b_loss_soft_bound_1=npf(b))
+
+
 def main():
     install_stubs()
     vt, v5 = load_reference()
@@ -598,6 +633,7 @@ def main():
     f4_reset(vt, v5, out)
     f5_reset_sampling(vt, v5, out)
     f6_trajectory(vt, v5, out)       # also writes F7 (wandb_dict keys)
+    f8_ppo_loss_terms(out)
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)

@@ -295,6 +295,32 @@ def test_fused_trunk_matches_float64_composition(obs_dim, use_slots, mixed):
 
 
 @pytest.mark.gpu
+def test_ppo_loss_kernel_against_reference_text_golden():
+    """Golden F8 through the HIP loss kernel: the means of the actor, clipped-critic and bound (soft bound 1.0) terms the
+    reference's in-tree text computes per sample (isaacgymenvs/learning/common_agent.py:482-516, 427-435)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f8_ppo_loss_terms.npz"))
+    dev = torch.device("cuda:0")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    n, A = g["mu"].shape
+    # the kernel derives neglogp from (mu, sigma, action): sigma = 1, action = mu + sqrt(2 (nlp - const)) on one axis;
+    # only old_neglogp - neglogp enters the loss, so both are shifted to make every target reachable
+    const = 0.5 * np.log(2 * np.pi) * A
+    shift = float(const - g["neglogp"].min() + 0.01)
+    mu = t("mu")
+    actions = mu.clone()
+    actions[:, 0] += torch.sqrt(2.0 * (t("neglogp") + shift - const))
+    logstd = torch.zeros(A, device=dev)
+    _, _, _, stats = fused.ppo_loss_fused(mu, logstd, t("values"), actions, t("old_neglogp") + shift, t("advantage"), t("old_values"),
+                                          t("returns"), mu, torch.ones_like(mu), float(g["e_clip"]), True, 2.0, 0.0, 1e-4,
+                                          soft_bound=1.0)
+    stats = stats.cpu().numpy()
+    assert abs(stats[0] - g["a_loss"].mean()) < 2e-5 * (1 + abs(g["a_loss"].mean()))
+    assert abs(stats[1] - g["c_loss"].mean()) < 2e-5 * (1 + abs(g["c_loss"].mean()))
+    assert abs(stats[2] - g["b_loss_soft_bound_1"].mean()) < 2e-5
+
+
+@pytest.mark.gpu
 def test_fused_update_equals_stock_update():
     """One optimiser step of the agent through the fused path and through the stock composition, from the same
     weights and minibatch: same loss statistics, same updated parameters (to fp32 reduction-order noise)."""

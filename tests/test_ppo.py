@@ -123,6 +123,23 @@ def test_losses_and_kl():
     assert abs(float(a2c.policy_kl(m0, s0, m0, s0))) < 2e-5
 
 
+def test_loss_terms_match_reference_text(golden):
+    """Golden F8: actor / critic / bound loss per sample as the reference's in-tree restatement computes them
+    (isaacgymenvs/learning/common_agent.py:482-516, 427-435; its bound uses 1.0 where rl_games 1.5.2 uses 1.1)."""
+    g = golden("f8_ppo_loss_terms")
+    t = lambda k: torch.from_numpy(g[k])
+    e = float(g["e_clip"])
+    np.testing.assert_allclose(a2c.actor_loss(t("old_neglogp"), t("neglogp"), t("advantage"), e).numpy(), g["a_loss"],
+                               rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(a2c.critic_loss(t("old_values"), t("values"), e, t("returns"), True).numpy(), g["c_loss"],
+                               rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(a2c.critic_loss(t("old_values"), t("values"), e, t("returns"), False).numpy(),
+                               g["c_loss_noclip"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(a2c.bound_loss(t("mu"), soft_bound=1.0).numpy(), g["b_loss_soft_bound_1"], rtol=1e-6,
+                               atol=1e-7)
+    assert (g["b_loss_soft_bound_1"] > 0).mean() > 0.1 and (np.abs(g["values"] - g["old_values"]) > e).any()
+
+
 def test_neglogp_is_gaussian_nll():
     mu, logstd = torch.tensor([[0.3, -0.1]]), torch.tensor([[0.2, -0.4]])
     x = torch.tensor([[0.5, 0.5]])
