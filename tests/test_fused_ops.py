@@ -395,6 +395,69 @@ def test_graphed_update_equals_eager_update(mixed):
     assert torch.equal(p1, p2)
 
 
+@pytest.mark.gpu
+def test_checkpoint_restore_continues_bit_identically(tmp_path):
+    """Save after two iterations, restore into a fresh agent (weights, Adam moments, normaliser statistics, learning
+    rate, bf16 operand shadows) and train one more update on the SAME experience: the restored agent must land on the
+    same parameters bit for bit (default configuration: mixed precision, hipGraph rollout and update)."""
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+
+    def build():
+        cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048"])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        return agent, env
+
+    a, env_a = build()
+    assert a.fused_mixed
+    for _ in range(2):
+        a.train_epoch()
+    path = a.save(str(tmp_path / "ck"))
+    # one more iteration on agent a; capture the experience it used
+    a.set_eval()
+    with torch.no_grad():
+        batch = a.play_steps_rnn()
+    batch_copy = {k: ([t.clone() for t in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v))
+                  for k, v in batch.items()}
+
+    def update_on(agent, b):
+        agent.set_train()
+        if agent.fused_mixed:
+            agent.optimizer.refresh_shadow()
+        agent.curr_frames = b.pop("played_frames")
+        agent.prepare_dataset(b)
+        for _ep in range(agent.mini_epochs_num):
+            for i in range(agent.num_minibatches):
+                mb = agent.get_minibatch(i)
+                _, _, _, kl, _, cmu, csig = agent.calc_gradients(mb)
+                s, e = mb["range"]
+                agent.dataset["mu"][s:e] = cmu
+                agent.dataset["sigma"][s:e] = csig
+                agent.update_lr_from_kl(kl)
+            agent.model.running_mean_std.eval()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone(), float(agent.lr)
+
+    pa, lra = update_on(a, dict(batch_copy))
+    b, env_b = build()
+    b.restore(path)
+    batch_b = {k: ([t.clone() for t in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v))
+               for k, v in batch_copy.items()}
+    pb, lrb = update_on(b, batch_b)
+    assert lra == lrb
+    assert torch.equal(pa, pb)
+    env_a.close(); env_b.close()
+
+
 def _adam_pair(device):
     from vine_robot_isaacgymenvs_amd.learning.flat_adam import FlatAdam
     torch.manual_seed(3)
