@@ -458,6 +458,35 @@ def test_checkpoint_restore_continues_bit_identically(tmp_path):
     env_a.close(); env_b.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("amp", ["fp16", "bf16"])
+def test_torch_autocast_path_still_trains(amp):
+    """``mixed_precision_dtype: fp16`` (the reference's literal mechanism: torch autocast + GradScaler) and autocast bf16
+    with ``use_fused_ops: False`` run the stock composition: the hand-written fp32 kernels must step aside under
+    autocast (they once received half-precision tensors there)."""
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    cfg = load_config(overrides=["num_envs=512", "minibatch_size=4096"])
+    cfg["task"]["seed"] = 42
+    env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                  graphics_device_id=0, headless=True)
+    params = cfg["train"]["params"]
+    params["config"].update(write_files=False, print_stats=False, mixed_precision=True, mixed_precision_dtype=amp,
+                            use_fused_ops=(amp == "fp16"))
+    torch.manual_seed(0)
+    agent = A2CAgent("t", params, vec_env=env)
+    assert agent.mixed_precision and not agent.fused_mixed
+    agent.init_tensors()
+    agent.obs = agent.env_reset()["obs"]
+    for _ in range(2):
+        _, _, stats = agent.train_epoch()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in agent.model.parameters())
+    assert all(np.isfinite(float(v)) for v in stats.values())
+    env.close()
+
+
 def _adam_pair(device):
     from vine_robot_isaacgymenvs_amd.learning.flat_adam import FlatAdam
     torch.manual_seed(3)

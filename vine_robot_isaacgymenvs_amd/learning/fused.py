@@ -61,6 +61,8 @@ def splitk_tn(dy, x, out=None, batch=None):
         return torch.mm(dy.t(), x, out=out) if out is not None else dy.t().mm(x)
     # unflatten: also valid for operands whose rows are padded (a column block of a wider buffer)
     a, b = dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s))
+    if dy.dtype not in (torch.float32, torch.bfloat16) or dy.dtype != x.dtype:
+        raise TypeError("splitk_tn: operands must both be fp32 or both bf16 (got %s, %s)" % (dy.dtype, x.dtype))
     part = torch.bmm(a, b, out_dtype=torch.float32) if dy.dtype == torch.bfloat16 else torch.bmm(a, b)
     return column_sums(part, out if out is not None else torch.empty(part.shape[1:], device=part.device), batch=batch)
 
@@ -103,7 +105,9 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x, weight, bias):
-    if x.is_cuda and torch.is_grad_enabled() and x.shape[0] >= 4096 and x.dtype == torch.float32:
+    # (not under torch.autocast: the hand-written backward passes assume fp32 tensors)
+    if (x.is_cuda and torch.is_grad_enabled() and x.shape[0] >= 4096 and x.dtype == torch.float32
+            and not torch.is_autocast_enabled()):
         return _Linear.apply(x, weight, bias)
     return F.linear(x, weight, bias)
 
@@ -263,6 +267,8 @@ def column_sums(src, out=None, out1=None, n0=0, dup=False, batch=None):
     """Sum over dim 0 of a [R, ...] fp32 tensor with the hand-written kernel (deterministic; unlike ATen's
     multi-block reductions it needs no memset-cleared scratch, so it is safe inside a captured hipGraph).
     ``out``/``out1``: see vine_column_sums (split at column n0, or ``dup`` to write both)."""
+    if src.dtype != torch.float32 or not src.is_cuda or (out is not None and out.dtype != torch.float32):
+        raise TypeError("column_sums: fp32 GPU tensors only (got %s -> %s)" % (src.dtype, None if out is None else out.dtype))
     if out is None:
         out = torch.empty(src.shape[1:], device=src.device, dtype=torch.float32)
     if batch is not None:
@@ -320,7 +326,7 @@ class _LSTMSeq(torch.autograd.Function):
 
 def lstm_sequence(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     """x [B*T, F] (row = seq*T + t), h0/c0 [B, H], dones uint8 [B*T] or None -> (out [B*T, H], hT, cT)."""
-    if x.is_cuda and x.dtype == torch.float32:
+    if x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
         if dones is not None:
             dones = dones.to(torch.uint8).contiguous()
         return _LSTMSeq.apply(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T)

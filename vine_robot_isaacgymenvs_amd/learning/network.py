@@ -128,6 +128,8 @@ class A2CNetwork(nn.Module):
         return heads, (h.unsqueeze(0), c.unsqueeze(0))
 
     def trunk_supported(self, obs, seq_length):
+        if torch.is_autocast_enabled():
+            return False
         return fused.trunk_supported(obs, self.units, self.activation_is_elu, self.rnn_units, self.rnn_ln, seq_length)
 
     def forward(self, obs, states, seq_length=1, dones=None):
