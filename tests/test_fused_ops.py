@@ -487,6 +487,35 @@ def test_torch_autocast_path_still_trains(amp):
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_env,mb,obs_type,mixed", [(100, 400, "POS_AND_FD_VEL_AND_OBJ_INFO", True),
+                                                     (72, 288, "TIP_AND_CART_AND_OBJ_INFO", True),
+                                                     (100, 1600, "POS_AND_FD_VEL_AND_OBJ_INFO", False),
+                                                     (64, 1024, "POS_AND_FD_VEL_AND_OBJ_INFO", True)])
+def test_ragged_sizes_through_the_whole_path(n_env, mb, obs_type, mixed):
+    """Env counts that are not multiples of the kernels' tile sizes (64-row MFMA tiles, 256-thread workgroups, 4-wide
+    vectors), both observation widths: three full PPO iterations incl. graph capture, every shape guard falling back
+    where it must."""
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    cfg = load_config(overrides=["num_envs=%d" % n_env, "minibatch_size=%d" % mb, "OBSERVATION_TYPE=" + obs_type])
+    env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                  graphics_device_id=0, headless=True)
+    params = cfg["train"]["params"]
+    params["config"].update(write_files=False, print_stats=False, mixed_precision=mixed)
+    agent = A2CAgent("t", params, vec_env=env)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()["obs"]
+    for _ in range(3):
+        _, _, stats = agent.train_epoch()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in agent.model.parameters())
+    assert all(np.isfinite(float(v)) for v in stats.values())
+    assert agent._fast is not None and len(agent._upd_graphs) == agent.num_minibatches
+    env.close()
+
+
 def _adam_pair(device):
     from vine_robot_isaacgymenvs_amd.learning.flat_adam import FlatAdam
     torch.manual_seed(3)
