@@ -106,6 +106,13 @@ int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, co
 int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride, float* out0, int64_t n0, float* out1,
                      int32_t dup, void* stream);
 
+/* RunningMeanStd of rl_games in training mode: merge the batch moments of x [n,F] (fp32, packed, F <= 64) into the
+ * float64 running mean / variance / count (Chan et al.; unbiased batch variance like torch's x.var(0)).  Two launches,
+ * fixed summation order, no memsets: safe inside a captured hipGraph.  scratch: VINE_RMS_BLOCKS * 2 * F doubles. */
+#define VINE_RMS_BLOCKS 256
+int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, double* running_var, double* count,
+                    double* scratch, void* stream);
+
 /* RunningMeanStd of rl_games in eval mode: out = clamp((x - mean) / sqrt(var + eps), +-clip) for x [n,F] packed,
  * float64 statistics; out rows out_stride elements apart (a column block of a wider buffer), fp32 or bfloat16. */
 int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean, const double* var, float eps, float clip,

@@ -187,6 +187,31 @@ def test_lstm_step_mfma_matches_gemm_plus_pointwise(B, K, with_ig):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F_", [28, 18, 1])
+def test_running_mean_std_kernels_match_torch_composition(F_):
+    """vine_rms_update + vine_normalize_obs (float64 statistics, two-stage sums) against the module's torch path."""
+    from vine_robot_isaacgymenvs_amd.learning.running_mean_std import RunningMeanStd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    a, b = RunningMeanStd((F_,)).to(dev), RunningMeanStd((F_,)).to(dev)
+    b._use_kernels = lambda x: False                       # reference: the torch composition
+    a.train(); b.train()
+    for n in (32768, 4099, 2):
+        x = torch.randn(n, F_, device=dev) * torch.linspace(0.1, 9.0, F_, device=dev) + 3.0
+        ya, yb = a(x), b(x)
+        assert float((ya - yb).abs().max()) < 2e-5       # fp32 batch mean of the torch path / column std 0.1
+    for name in ("running_mean", "running_var", "count"):
+        u, v = getattr(a, name), getattr(b, name)
+        # the torch path reduces the batch in float32 before the float64 merge; the kernels accumulate in float64
+        assert float(((u - v).abs() / (v.abs() + 1e-30)).max()) < 2e-6, name
+    a.eval(); b.eval()
+    x = torch.randn(1000, F_, device=dev) * 20
+    ya, yb = a(x), b(x)
+    assert float((ya - yb).abs().max()) < 2e-5 and float(ya.abs().max()) == 5.0
+    assert torch.equal(a.count, b.count)                   # eval mode leaves the statistics alone
+
+
+@pytest.mark.gpu
 def test_splitk_linear_gradients():
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
@@ -382,7 +407,7 @@ def test_graphed_update_equals_eager_update(mixed):
             _, _, stats = agent.train_epoch()
         torch.cuda.synchronize()
         if use_graphs:
-            assert len(agent._upd_graphs) == agent.num_minibatches and not getattr(agent, "_update_graphs_failed", False)
+            assert len(agent._upd_graphs) == 2 * agent.num_minibatches and not getattr(agent, "_update_graphs_failed", False)
         outs.append((torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone(), float(agent.lr),
                      {k: float(v) for k, v in stats.items()}, agent.model.running_mean_std.running_mean.clone()))
         env.close()
@@ -512,7 +537,7 @@ def test_ragged_sizes_through_the_whole_path(n_env, mb, obs_type, mixed):
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in agent.model.parameters())
     assert all(np.isfinite(float(v)) for v in stats.values())
-    assert agent._fast is not None and len(agent._upd_graphs) == agent.num_minibatches
+    assert agent._fast is not None and len(agent._upd_graphs) == 2 * agent.num_minibatches
     env.close()
 
 

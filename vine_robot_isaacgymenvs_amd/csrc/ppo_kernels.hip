@@ -414,6 +414,51 @@ __global__ void normalize_obs_kernel(long long n, int F, const float* __restrict
     }
 }
 
+// RunningMeanStd in training mode (rl_games: float64 statistics, Chan et al. merge of the batch moments), two launches:
+//   partial : per-workgroup column sums of x and x^2 in double (64 column lanes x 4 row lanes)
+//   finalize: batch mean / unbiased variance from the partials (fixed order), merged into the running moments
+__global__ __launch_bounds__(256) void rms_partial_kernel(long long n, int F, const float* __restrict__ x,
+                                                          double* __restrict__ partial) {
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double s = 0.0, ss = 0.0;
+    if (c < F)
+        for (long long r = (long long)blockIdx.x * 4 + rl; r < n; r += (long long)gridDim.x * 4) {
+            const double v = (double)x[r * F + c];
+            s += v;
+            ss += v * v;
+        }
+    __shared__ double red[2][4][64];
+    red[0][rl][c] = s;
+    red[1][rl][c] = ss;
+    __syncthreads();
+    if (rl == 0 && c < F) {
+        partial[(long long)blockIdx.x * 2 * F + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        partial[(long long)blockIdx.x * 2 * F + F + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
+__global__ void rms_finalize_kernel(int blocks, int F, long long n, const double* __restrict__ partial,
+                                    double* __restrict__ running_mean, double* __restrict__ running_var,
+                                    double* __restrict__ count) {
+    const int c = threadIdx.x;
+    const double cnt = count[0], nb = (double)n;
+    if (c < F) {
+        double s = 0.0, ss = 0.0;
+        for (int b = 0; b < blocks; ++b) {
+            s += partial[(long long)b * 2 * F + c];
+            ss += partial[(long long)b * 2 * F + F + c];
+        }
+        const double bmean = s / nb;
+        const double bvar = n > 1 ? (ss - nb * bmean * bmean) / (nb - 1.0) : 0.0;      // unbiased, like x.var(0)
+        const double delta = bmean - running_mean[c], tot = cnt + nb;
+        const double m2 = running_var[c] * cnt + bvar * nb + delta * delta * cnt * nb / tot;
+        running_mean[c] += delta * nb / tot;
+        running_var[c] = m2 / tot;
+    }
+    __syncthreads();
+    if (c == 0) count[0] = cnt + nb;
+}
+
 // out = elu(z + bias): the activation of a Linear whose GEMM ran without an epilogue (bf16 operands, fp32 output)
 template <typename OT>
 __global__ __launch_bounds__(256) void bias_elu_kernel(long long n, int C, const float* __restrict__ z,
@@ -1171,6 +1216,19 @@ int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride,
     else
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src,
                            (long long)R, (long long)C, (long long)row_stride, out0, split, out1, (int)dup);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, double* running_var, double* count,
+                    double* scratch, void* stream) {
+    if (n <= 0 || F <= 0 || !x || !running_mean || !running_var || !count || !scratch) return VINE_ERR_INVALID_ARG;
+    if (F > 64) return VINE_ERR_UNSUPPORTED;
+    int blocks = (int)((n + 3) / 4);
+    if (blocks > VINE_RMS_BLOCKS) blocks = VINE_RMS_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(rms_partial_kernel, dim3(blocks), dim3(256), 0, s, (long long)n, (int)F, x, scratch);
+    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(64), 0, s, blocks, (int)F, (long long)n, scratch, running_mean,
+                       running_var, count);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -843,21 +843,16 @@ class A2CAgent:
         """The optimiser step is ~105 launches of 5-30 us each: with bf16 GEMM operands (and nearly so in fp32) the
         host cannot issue them as fast as the GPU retires them.  From the second iteration on (the first one runs
         eagerly and warms every lazily initialised handle) each step is replayed from two hipGraphs:
-        A = forward + loss + backward, B = Adam + dataset/learning-rate update, with the RCCL all-reduce issued
-        between them outside any capture."""
+        A = normalisation (+ running-statistics update in the first mini-epoch) + forward + loss + backward,
+        B = Adam + dataset/learning-rate update, with the RCCL all-reduce issued between them outside any capture."""
         return (self.use_graphs and self.is_cuda and self.use_fused and not self.mixed_precision
                 and not self.truncate_grads and self.is_adaptive_lr and self.schedule_type == "legacy"
                 and getattr(self, "_epochs_run", 0) > 1 and not getattr(self, "_update_graphs_failed", False))
 
     def _update_step_graphed(self, i, row_out):
-        key = i
-        # observation normalisation (and, in the first mini-epoch, the running-statistics update with its
-        # multi-block reductions) stays outside the capture; the graph reads the result at a fixed address
-        games = self.minibatch_size // self.seq_len
-        obs_mb = self.dataset["obs"][i * games * self.seq_len:(i + 1) * games * self.seq_len]
-        if getattr(self, "_obs_n_static", None) is None:
-            self._obs_n_static = torch.empty_like(obs_mb)
-        self._obs_n_static.copy_(self.model.norm_obs(obs_mb))
+        # the running-statistics update of the observation normaliser (first mini-epoch only) is part of graph A:
+        # its kernels use fixed-order two-stage sums and no memsets, so they replay faithfully
+        key = (i, bool(self.normalize_input and self.model.running_mean_std.training))
         rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
         if rec is None:
             try:
@@ -885,7 +880,7 @@ class A2CAgent:
         pool = None if os.environ.get("VINE_UPD_POOL") == "separate" else self._upd_pool
         with torch.cuda.graph(gA, pool=pool, capture_error_mode="thread_local"):
             mb = self.get_minibatch(i)
-            stats, mu_d, sigma_d = self._fused_grad_half(mb, obs_n=self._obs_n_static)
+            stats, mu_d, sigma_d = self._fused_grad_half(mb)
         with torch.cuda.graph(gB, pool=pool, capture_error_mode="thread_local"):
             self.optimizer.step(grad_scale=1.0 / self.rank_size)
             start, end = mb["range"]

@@ -29,7 +29,32 @@ class RunningMeanStd(nn.Module):
         self.running_var.copy_(m2 / tot)
         self.count.copy_(tot)
 
+    def _use_kernels(self, x):
+        """MI355X path: the update is two hand-written launches and the normalisation one (csrc/ppo_kernels.hip),
+        with a fixed summation order and no memsets, so both can live inside a captured hipGraph; same arithmetic as
+        the torch composition below (which stays the CPU path and the reference of the numerics test)."""
+        return (x.is_cuda and x.dtype == torch.float32 and len(self.insize) == 1 and self.insize[0] <= 64
+                and x.dim() == 2 and x.shape[1] == self.insize[0] and not torch.is_autocast_enabled())
+
+    def _forward_kernels(self, x):
+        from .. import native
+        from ..abi import RMS_BLOCKS
+        lib = native.load()
+        x = x.contiguous()
+        n, F = x.shape
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        if self.training:
+            scratch = torch.empty(RMS_BLOCKS * 2 * F, device=x.device, dtype=torch.float64)
+            native.check(lib.vine_rms_update(n, F, x.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
+                                             self.count.data_ptr(), scratch.data_ptr(), st), lib)
+        y = torch.empty_like(x)
+        native.check(lib.vine_normalize_obs(n, F, x.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
+                                            float(self.epsilon), 5.0, y.data_ptr(), F, 0, st), lib)
+        return y
+
     def forward(self, x, unnorm=False):
+        if not unnorm and self._use_kernels(x):
+            return self._forward_kernels(x)
         if self.training and not unnorm:
             self.update(x)
         mean = self.running_mean.float()
