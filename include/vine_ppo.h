@@ -106,6 +106,14 @@ int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, co
 int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride, float* out0, int64_t n0, float* out1,
                      int32_t dup, void* stream);
 
+/* Generalised advantage estimation over a rollout stored [T, N] (row R2; rl_games discount_values, next-nonterminal
+ * form; the in-tree AMP variant is isaacgymenvs/learning/common_agent.py:413-425): one launch instead of T x 6.
+ * dones[t] is the flag stored with step t (the env finished an episode at step t-1), last_dones the flags after the
+ * last step; returns (nullable) = advs + values. */
+int vine_gae(int32_t T, int64_t N, const float* rewards, const float* values, const uint8_t* dones,
+             const float* last_values, const uint8_t* last_dones, float gamma, float tau, float* advs, float* returns,
+             void* stream);
+
 /* RunningMeanStd of rl_games in training mode: merge the batch moments of x [n,F] (fp32, packed, F <= 64) into the
  * float64 running mean / variance / count (Chan et al.; unbiased batch variance like torch's x.var(0)).  Two launches,
  * fixed summation order, no memsets: safe inside a captured hipGraph.  scratch: VINE_RMS_BLOCKS * 2 * F doubles. */

@@ -212,6 +212,24 @@ def test_running_mean_std_kernels_match_torch_composition(F_):
 
 
 @pytest.mark.gpu
+def test_gae_kernel_matches_reference_loop():
+    """vine_gae against the Python loop (rl_games discount_values, next-nonterminal form)."""
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import discount_values
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    T, N = 16, 1000
+    rew, val = torch.randn(T, N, 1, device=dev), torch.randn(T, N, 1, device=dev)
+    dones = (torch.rand(T, N, device=dev) < 0.1).to(torch.uint8)
+    last_d = (torch.rand(N, device=dev) < 0.1).to(torch.uint8)
+    last_v = torch.randn(N, 1, device=dev)
+    ref = discount_values(0.99, 0.95, last_d.float(), last_v, dones.float(), val, rew)
+    adv, ret = torch.empty_like(rew), torch.empty_like(rew)
+    assert fused._lib().vine_gae(T, N, rew.data_ptr(), val.data_ptr(), dones.data_ptr(), last_v.data_ptr(), last_d.data_ptr(),
+                                 0.99, 0.95, adv.data_ptr(), ret.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    assert float((adv - ref).abs().max()) < 1e-5 and float((ret - (ref + val)).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
 def test_splitk_linear_gradients():
     dev = torch.device("cuda:0")
     torch.manual_seed(1)

@@ -414,6 +414,27 @@ __global__ void normalize_obs_kernel(long long n, int F, const float* __restrict
     }
 }
 
+// GAE in rl_games' next-nonterminal form over a [T, N] rollout, one env per lane, reverse scan in registers:
+//   delta_t = r_t + gamma V_{t+1} nt_{t+1} - V_t;  A_t = delta_t + gamma tau nt_{t+1} A_{t+1};  R_t = A_t + V_t
+// (V_T = last_values, nt_T = 1 - dones after the last step; nt_{t+1} = 1 - dones stored at step t+1).
+__global__ void gae_kernel(int T, long long N, const float* __restrict__ rewards, const float* __restrict__ values,
+                           const unsigned char* __restrict__ dones, const float* __restrict__ last_values,
+                           const unsigned char* __restrict__ last_dones, float gamma, float tau,
+                           float* __restrict__ advs, float* __restrict__ returns) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float next_v = last_values[e], nnt = 1.0f - (float)last_dones[e], lam = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float v = values[(long long)t * N + e];
+        const float delta = rewards[(long long)t * N + e] + gamma * next_v * nnt - v;
+        lam = delta + gamma * tau * nnt * lam;
+        advs[(long long)t * N + e] = lam;
+        if (returns) returns[(long long)t * N + e] = lam + v;
+        next_v = v;
+        nnt = 1.0f - (float)dones[(long long)t * N + e];
+    }
+}
+
 // RunningMeanStd in training mode (rl_games: float64 statistics, Chan et al. merge of the batch moments), two launches:
 //   partial : per-workgroup column sums of x and x^2 in double (64 column lanes x 4 row lanes)
 //   finalize: batch mean / unbiased variance from the partials (fixed order), merged into the running moments
@@ -1216,6 +1237,16 @@ int vine_column_sums(int64_t R, int64_t C, const float* src, int64_t row_stride,
     else
         hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src,
                            (long long)R, (long long)C, (long long)row_stride, out0, split, out1, (int)dup);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_gae(int32_t T, int64_t N, const float* rewards, const float* values, const uint8_t* dones,
+             const float* last_values, const uint8_t* last_dones, float gamma, float tau, float* advs, float* returns,
+             void* stream) {
+    if (T <= 0 || N <= 0 || !rewards || !values || !dones || !last_values || !last_dones || !advs)
+        return VINE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)T,
+                       (long long)N, rewards, values, dones, last_values, last_dones, gamma, tau, advs, returns);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -553,10 +553,21 @@ class A2CAgent:
         else:
             body()
         buf = self.buf
-        fdones = self.dones.float()
-        mb_fdones = buf["dones"].float()
-        mb_advs = discount_values(self.gamma, self.tau, fdones, self.last_values, mb_fdones, buf["values"], buf["rewards"])
-        mb_returns = mb_advs + buf["values"]
+        if (self.is_cuda and self.use_fused and buf["dones"].dtype == torch.uint8 and self.dones.dtype == torch.uint8
+                and buf["values"].is_contiguous() and buf["rewards"].is_contiguous()):
+            # GAE as one kernel (one env per lane, reverse scan in registers) instead of 16 x 6 small launches
+            mb_advs, mb_returns = torch.empty_like(buf["rewards"]), torch.empty_like(buf["rewards"])
+            fused._check(fused._lib().vine_gae(
+                self.horizon_length, self.num_actors, buf["rewards"].data_ptr(), buf["values"].data_ptr(),
+                buf["dones"].data_ptr(), self.last_values.data_ptr(), self.dones.data_ptr(), float(self.gamma),
+                float(self.tau), mb_advs.data_ptr(), mb_returns.data_ptr(),
+                torch.cuda.current_stream(self.device).cuda_stream), "vine_gae")
+        else:
+            fdones = self.dones.float()
+            mb_fdones = buf["dones"].float()
+            mb_advs = discount_values(self.gamma, self.tau, fdones, self.last_values, mb_fdones, buf["values"],
+                                      buf["rewards"])
+            mb_returns = mb_advs + buf["values"]
         batch = {k: swap_and_flatten01(buf[k]) for k in ("obses", "actions", "neglogpacs", "values", "mus", "sigmas", "dones")}
         batch["returns"] = swap_and_flatten01(mb_returns)
         batch["played_frames"] = self.batch_size
