@@ -51,6 +51,13 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
                         void* gates_act, void* hp_next, const uint8_t* done_next, int64_t done_next_stride,
                         int64_t hp_stride, void* stream);
 
+/* Linear + bias + ELU on the matrix cores: out = elu(A W^T + bias) with A [n, K] bf16 (rows lda apart), W [N, K] bf16,
+ * out [n, N] bf16 (rows out_stride apart, e.g. a column block of the LSTM operand buffer); the fp32 pre-activation is
+ * never stored.  Needs n % 64 == 0, N % 64 == 0, K in {32, 64, 128, 256}; otherwise VINE_ERR_UNSUPPORTED (callers fall
+ * back to GEMM + vine_bias_elu). */
+int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
+                         const float* bias, float alpha, void* out, int64_t out_stride, void* stream);
+
 /* Backward of the step above.
  *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
  * g_rec / dc_next = gradients w.r.t. the MASKED (h_t, c_t) consumed by step t+1 (NULL at the last step),

@@ -212,6 +212,49 @@ def test_running_mean_std_kernels_match_torch_composition(F_):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,K,N", [(32768, 256, 128), (16384, 128, 64), (64, 32, 64)])
+def test_linear_elu_mfma_matches_gemm_plus_bias_elu(n, K, N):
+    """Matrix-core Linear + bias + ELU against torch GEMM (same bf16 operands, fp32 out) + vine_bias_elu; output
+    into a column block of a wider buffer; timing of both printed for the record."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    lib = fused._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bf = torch.bfloat16
+    A = (torch.randn(n, K + 8, device=dev) * 0.7).to(bf)[:, :K]
+    W = (torch.randn(N, K, device=dev) / K ** 0.5).to(bf)
+    bias = torch.randn(N, device=dev) * 0.2
+    wide = torch.zeros(n, N + 32, device=dev, dtype=bf)
+    ref = torch.zeros(n, N + 32, device=dev, dtype=bf)
+
+    def fusedk():
+        assert lib.vine_linear_elu_mfma(n, N, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), bias.data_ptr(), 1.0,
+                                        wide.data_ptr(), N + 32, st) == 0
+
+    def unfused():
+        z = torch.mm(A, W.t(), out_dtype=torch.float32)
+        assert lib.vine_bias_elu(n, N, z.data_ptr(), bias.data_ptr(), 1.0, ref.data_ptr(), N + 32, 1, st) == 0
+
+    fusedk(); unfused()
+    torch.cuda.synchronize()
+    d = (wide.float() - ref.float()).abs()
+    assert float(d.max()) < 2e-2 and float((d > 0).float().mean()) < 0.02      # bf16 rounding boundaries only
+    assert float(wide[:, N:].float().abs().max()) == 0.0
+    times = []
+    for f in (fusedk, unfused):
+        for _ in range(5):
+            f()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(50):
+            f()
+        e.record()
+        torch.cuda.synchronize()
+        times.append(s.elapsed_time(e) * 20)
+    print("linear_elu n=%d K=%d N=%d: fused %.1f us, gemm+bias_elu %.1f us" % (n, K, N, times[0], times[1]))
+
+
+@pytest.mark.gpu
 def test_gae_kernel_matches_reference_loop():
     """vine_gae against the Python loop (rl_games discount_values, next-nonterminal form)."""
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import discount_values

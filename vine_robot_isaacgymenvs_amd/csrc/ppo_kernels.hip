@@ -210,6 +210,58 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     }
 }
 
+// ---- Linear + bias + ELU on the matrix cores (the MLP layers of the mixed-precision path): out = elu(A W^T + bias),
+// A [n, K] bf16, W [N, K] bf16, out [n, N] bf16.  Same scheme as lstm_step_mfma_kernel: transposed product so that a
+// lane holds 4 consecutive output units of one row per 16-unit tile, W's 64 x K slab in LDS, A fragments from global
+// memory; workgroup = 64 rows x 64 units, so every output row segment is one full 128-B line of bf16.
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N, const bf16_t* __restrict__ A,
+                                                              long long lda, const bf16_t* __restrict__ W, long long ldw,
+                                                              const float* __restrict__ bias, float alpha,
+                                                              bf16_t* __restrict__ out, long long out_stride) {
+    constexpr int K = 32 * KSTEPS;
+    constexpr int PITCH = K + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(lds_raw);           // [64 units][PITCH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * 64;
+    const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    bf16x8_t af[KSTEPS];
+    const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk);
+    float4 bbv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bbv[t] = ld4(bias + u0 + 16 * t + 4 * (lane >> 4));
+    constexpr int CHUNKS = K / 8;
+    for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
+        const int row = c / CHUNKS, ck = c - row * CHUNKS;
+        const uint4 v = *reinterpret_cast<const uint4*>(W + (long long)(u0 + row) * ldw + ck * 8);
+        *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
+    }
+    __syncthreads();
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t wf =
+                *reinterpret_cast<const bf16x8_t*>(&wl[(t * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float x[4] = {acc[t][0] + bbv[t].x, acc[t][1] + bbv[t].y, acc[t][2] + bbv[t].z, acc[t][3] + bbv[t].w};
+        float y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) y[u] = x[u] > 0.0f ? x[u] : alpha * (__expf(x[u]) - 1.0f);
+        st4(out + b * out_stride + u0 + 16 * t + 4 * (lane >> 4), make_float4(y[0], y[1], y[2], y[3]));
+    }
+}
+
 template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
@@ -1128,6 +1180,28 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
         default: return VINE_ERR_UNSUPPORTED;
     }
 #undef VINE_LSTM_MFMA
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
+                         const float* bias, float alpha, void* out, int64_t out_stride, void* stream) {
+    if (n <= 0 || N <= 0 || K <= 0 || !A || !W || !bias || !out || (lda & 7) || (ldw & 7) || (out_stride & 3))
+        return VINE_ERR_INVALID_ARG;
+    if ((n & 63) || (N & 63) || (K & 31) || K > 256) return VINE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(n / 64), (unsigned)(N / 64)), block(256);
+    const size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_LIN_MFMA(KS)                                                                                             \
+    hipLaunchKernelGGL(linear_elu_mfma_kernel<KS>, grid, block, lds, s, (long long)n, (int)N, (const bf16_t*)A,       \
+                       (long long)lda, (const bf16_t*)W, (long long)ldw, bias, alpha, (bf16_t*)out, (long long)out_stride)
+    switch (K / 32) {
+        case 1: VINE_LIN_MFMA(1); break;
+        case 2: VINE_LIN_MFMA(2); break;
+        case 4: VINE_LIN_MFMA(4); break;
+        case 8: VINE_LIN_MFMA(8); break;
+        default: return VINE_ERR_UNSUPPORTED;
+    }
+#undef VINE_LIN_MFMA
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

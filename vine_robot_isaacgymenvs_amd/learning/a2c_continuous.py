@@ -394,10 +394,15 @@ class A2CAgent:
         x = x0
         n_mlp = len(f["mlp"])
         for i, (W, b) in enumerate(f["mlp"]):
-            z = fused._mm(x, W.t())
             out = xh if i == n_mlp - 1 else f["acts"][i]
-            fused._check(lib.vine_bias_elu(N, z.shape[1], z.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(), out.stride(0),
-                                           bf, st), "vine_bias_elu")
+            if bf and fused.linear_elu_mfma_ok(N, W.shape[0], W.shape[1]):
+                fused._check(lib.vine_linear_elu_mfma(N, W.shape[0], W.shape[1], x.data_ptr(), x.stride(0), W.data_ptr(),
+                                                      W.stride(0), b.data_ptr(), 1.0, out.data_ptr(), out.stride(0), st),
+                             "vine_linear_elu_mfma")
+            else:
+                z = fused._mm(x, W.t())
+                fused._check(lib.vine_bias_elu(N, z.shape[1], z.data_ptr(), b.data_ptr(), 1.0, out.data_ptr(),
+                                               out.stride(0), bf, st), "vine_bias_elu")
             x = out
         h32, c = self.rnn_states[0][0], self.rnn_states[1][0]
         h_out, c_out = (h32, c) if commit else (f["h_tmp"], f["c_tmp"])

@@ -371,11 +371,16 @@ class _Trunk(torch.autograd.Function):
         for i, (W, b) in enumerate(mlp):
             last = i == n_mlp - 1
             if mixed:
-                z = _mm(x, Wop[i].t())
-                C_ = z.shape[1]
+                C_, K_ = Wop[i].shape
                 a = xcat if last else torch.empty((n, C_), device=dev, dtype=op)
-                _check(lib.vine_bias_elu(n, C_, z.data_ptr(), b.data_ptr(), 1.0, a.data_ptr(), a.stride(0), 1, st),
-                       "vine_bias_elu")
+                if linear_elu_mfma_ok(n, C_, K_):      # GEMM + bias + ELU in one matrix-core kernel
+                    _check(lib.vine_linear_elu_mfma(n, C_, K_, x.data_ptr(), x.stride(0), Wop[i].data_ptr(),
+                                                    Wop[i].stride(0), b.data_ptr(), 1.0, a.data_ptr(), a.stride(0), st),
+                           "vine_linear_elu_mfma")
+                else:
+                    z = _mm(x, Wop[i].t())
+                    _check(lib.vine_bias_elu(n, C_, z.data_ptr(), b.data_ptr(), 1.0, a.data_ptr(), a.stride(0), 1, st),
+                           "vine_bias_elu")
             else:
                 z = torch.addmm(b, x, W.t())
                 if last:
@@ -516,6 +521,11 @@ class _Trunk(torch.autograd.Function):
         if batch is not None:
             batch.flush(out)
         return (None, None, None, None, None, None, None, None, None, *grads)
+
+
+def linear_elu_mfma_ok(n, N, K):
+    """Shapes vine_linear_elu_mfma covers (else: GEMM + vine_bias_elu)."""
+    return n % 64 == 0 and N % 64 == 0 and K in (32, 64, 128, 256)
 
 
 def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
