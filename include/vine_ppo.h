@@ -42,14 +42,17 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
 /* The same LSTM step with the recurrent GEMM fused in (matrix cores, bfloat16 operands, fp32 accumulation):
  *   gates = A W^T + igates + bias   with A [B, K] bf16 (rows lda apart) and W [4H, K] bf16 (rows ldw apart),
  * then the pointwise update exactly as vine_lstm_cell_forward; the [B, 4H] pre-activations never reach HBM.
- * igates is nullable (the rollout's single GEMM over [x | h] has no separate input projection).  gates_act and
+ * A2 (nullable): second operand source; columns [0, K1) of the product's K come from A, [K1, K) from A2 (the update
+ * keeps the layer input x_t and the masked state h_{t-1} in separate buffers; W is then [w_ih | w_hh] and no input
+ * projection is ever materialised).  Two-source form: K - K1 == 256, K1 in {32, 64, 96, 128}.
+ * igates is nullable (no separate input projection when x is part of the operand).  gates_act and
  * hp_next are bfloat16.  Needs B % 64 == 0, H % 16 == 0, K in {128, 256, 288, 320, 352, 384, 512}; otherwise
  * VINE_ERR_UNSUPPORTED (callers fall back to GEMM + vine_lstm_cell_forward). */
-int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
-                        const float* igates, int64_t ig_stride, const float* bias, const float* c_prev,
-                        const uint8_t* done, int64_t done_stride, float* h_out, int64_t h_stride, float* c_out,
-                        void* gates_act, void* hp_next, const uint8_t* done_next, int64_t done_next_stride,
-                        int64_t hp_stride, void* stream);
+int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t lda, const void* A2, int64_t lda2,
+                        int64_t K1, const void* W, int64_t ldw, const float* igates, int64_t ig_stride,
+                        const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride, float* h_out,
+                        int64_t h_stride, float* c_out, void* gates_act, void* hp_next, const uint8_t* done_next,
+                        int64_t done_next_stride, int64_t hp_stride, void* stream);
 
 /* Linear + bias + ELU on the matrix cores: out = elu(A W^T + bias) with A [n, K] bf16 (rows lda apart), W [N, K] bf16,
  * out [n, N] bf16 (rows out_stride apart, e.g. a column block of the LSTM operand buffer); the fp32 pre-activation is

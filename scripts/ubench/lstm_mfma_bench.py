@@ -21,7 +21,7 @@ gates = torch.empty(B, 4 * H, device=dev, dtype=bf)
 
 
 def fusedk():
-    rc = lib.vine_lstm_step_mfma(B, H, H, hp.data_ptr(), T * H, W.data_ptr(), H, ig.data_ptr(), T * 4 * H, bias.data_ptr(),
+    rc = lib.vine_lstm_step_mfma(B, H, H, hp.data_ptr(), T * H, None, 0, 0, W.data_ptr(), H, ig.data_ptr(), T * 4 * H, bias.data_ptr(),
                                  c0.data_ptr(), None, 0, out.data_ptr(), T * H, c1.data_ptr(), gates.data_ptr(),
                                  hp.data_ptr() + 2 * H, None, 0, T * H, st)
     assert rc == 0

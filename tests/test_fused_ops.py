@@ -166,7 +166,7 @@ def test_lstm_step_mfma_matches_gemm_plus_pointwise(B, K, with_ig):
     pre = torch.mm(A, W.t(), out_dtype=torch.float32)                 # the GEMM the fused kernel absorbs
     zero_ig = torch.zeros(B, 4 * H, device=dev)
     h2, c2, g2, hp2 = outputs()
-    rc = lib.vine_lstm_step_mfma(B, H, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+    rc = lib.vine_lstm_step_mfma(B, H, K, A.data_ptr(), A.stride(0), None, 0, 0, W.data_ptr(), W.stride(0),
                                  ig.data_ptr() if with_ig else None, 4 * H, bias.data_ptr(), c0.data_ptr(), done.data_ptr(), 1,
                                  h2.data_ptr(), H, c2.data_ptr(), g2.data_ptr(), hp2.data_ptr(), done_n.data_ptr(), 1, H, st)
     assert rc == 0
@@ -181,7 +181,15 @@ def test_lstm_step_mfma_matches_gemm_plus_pointwise(B, K, with_ig):
     for name, a, b, tol in (("h", h2, h3, 2e-5), ("c", c2, c3, 2e-5), ("gates", g2.float(), g3.float(), 8e-3),
                             ("hp", hp2.float(), hp3.float(), 8e-3)):
         assert float((a - b).abs().max()) < tol, (name, float((a - b).abs().max()))
-    assert lib.vine_lstm_step_mfma(B + 1, H, K, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), None, 4 * H,
+    if K == 352:      # two-source form: the same product with the operand split into [x (96) | h (256)] buffers
+        A1, A2 = A[:, :96].contiguous(), A[:, 96:].contiguous()
+        h4, c4, g4, hp4 = outputs()
+        assert lib.vine_lstm_step_mfma(B, H, K, A1.data_ptr(), 96, A2.data_ptr(), 256, 96, W.data_ptr(), W.stride(0), None,
+                                       4 * H, bias.data_ptr(), c0.data_ptr(), done.data_ptr(), 1, h4.data_ptr(), H,
+                                       c4.data_ptr(), g4.data_ptr(), hp4.data_ptr(), done_n.data_ptr(), 1, H, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(h4, h2) and torch.equal(c4, c2) and torch.equal(g4, g2) and torch.equal(hp4, hp2)
+    assert lib.vine_lstm_step_mfma(B + 1, H, K, A.data_ptr(), A.stride(0), None, 0, 0, W.data_ptr(), W.stride(0), None, 4 * H,
                                    bias.data_ptr(), c0.data_ptr(), None, 0, h2.data_ptr(), H, c2.data_ptr(), None, None,
                                    None, 0, H, st) == -2                          # unsupported shape: caller falls back
 

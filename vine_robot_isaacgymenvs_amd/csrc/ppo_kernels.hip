@@ -127,9 +127,10 @@ typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 #define LSTM_MFMA_MAX_K 512
 
-template <int KSTEPS>      // K = 32 * KSTEPS
+template <int KSTEPS, int KS1>      // K = 32 * KSTEPS; the first KS1 k-steps of A come from A, the rest from A2
 __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
-    long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ W, long long ldw,
+    long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ A2, long long lda2,
+    const bf16_t* __restrict__ W, long long ldw,
     const float* __restrict__ igates, long long ig_stride, const float* __restrict__ bias,
     const float* __restrict__ c_prev, const unsigned char* __restrict__ done, long long done_stride,
     float* __restrict__ h_out, long long h_stride, float* __restrict__ c_out, bf16_t* __restrict__ gates_act,
@@ -149,8 +150,11 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     const int j = u0 + 4 * (lane >> 4);
     bf16x8_t af[KSTEPS];
     const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
+    const bf16_t* arow2 = KS1 < KSTEPS && KS1 > 0 ? A2 + b * lda2 + 8 * (lane >> 4) : arow;
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk);
+    for (int kk = 0; kk < KSTEPS; ++kk)
+        af[kk] = (KS1 == 0 || kk < KS1) ? *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk)
+                                        : *reinterpret_cast<const bf16x8_t*>(arow2 + 32 * (kk - KS1));
     float4 igv[4], bbv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1144,40 +1148,57 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
-                        const float* igates, int64_t ig_stride, const float* bias, const float* c_prev,
-                        const uint8_t* done, int64_t done_stride, float* h_out, int64_t h_stride, float* c_out,
-                        void* gates_act, void* hp_next, const uint8_t* done_next, int64_t done_next_stride,
-                        int64_t hp_stride, void* stream) {
+int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t lda, const void* A2, int64_t lda2,
+                        int64_t K1, const void* W, int64_t ldw, const float* igates, int64_t ig_stride,
+                        const float* bias, const float* c_prev, const uint8_t* done, int64_t done_stride, float* h_out,
+                        int64_t h_stride, float* c_out, void* gates_act, void* hp_next, const uint8_t* done_next,
+                        int64_t done_next_stride, int64_t hp_stride, void* stream) {
     if (hp_stride <= 0) hp_stride = h_stride;
+    if (!A2) K1 = 0;
     if (B <= 0 || H <= 0 || K <= 0 || !A || !W || !bias || !c_prev || !h_out || !c_out || (lda & 7) || (ldw & 7) ||
-        (ig_stride & 3) || (h_stride & 3) || (hp_stride & 3))
+        (ig_stride & 3) || (h_stride & 3) || (hp_stride & 3) || (A2 && ((lda2 & 7) || K1 <= 0 || K1 >= K)))
         return VINE_ERR_INVALID_ARG;
-    if ((B & 63) || (H & 15) || (K & 31) || K > LSTM_MFMA_MAX_K) return VINE_ERR_UNSUPPORTED;
+    if ((B & 63) || (H & 15) || (K & 31) || (K1 & 31) || K > LSTM_MFMA_MAX_K) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B / 64), (unsigned)(H / 16)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);            // 33 KB at K = 256, 45 KB at K = 352
     static bool lds_raised[LSTM_MFMA_MAX_K / 32 + 1] = {};               // K = 512 needs more than the 64 KB default
-#define VINE_LSTM_MFMA(KS)                                                                                              \
-    if (lds > 65536 && !lds_raised[KS]) {                                                                               \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_step_mfma_kernel<KS>),                              \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                    \
-            return VINE_ERR_DEVICE;                                                                                     \
-        lds_raised[KS] = true;                                                                                          \
-    }                                                                                                                   \
-    hipLaunchKernelGGL(lstm_step_mfma_kernel<KS>, grid, block, lds, s, (long long)B, (int)H, (const bf16_t*)A,          \
-                       (long long)lda, (const bf16_t*)W, (long long)ldw, igates, (long long)ig_stride, bias, c_prev,     \
-                       done, (long long)done_stride, h_out, (long long)h_stride, c_out, (bf16_t*)gates_act,              \
-                       (bf16_t*)hp_next, done_next, (long long)done_next_stride, (long long)hp_stride)
-    switch (K / 32) {
-        case 4: VINE_LSTM_MFMA(4); break;
-        case 8: VINE_LSTM_MFMA(8); break;
-        case 9: VINE_LSTM_MFMA(9); break;
-        case 10: VINE_LSTM_MFMA(10); break;
-        case 11: VINE_LSTM_MFMA(11); break;
-        case 12: VINE_LSTM_MFMA(12); break;
-        case 16: VINE_LSTM_MFMA(16); break;
-        default: return VINE_ERR_UNSUPPORTED;
+#define VINE_LSTM_MFMA(KS, KS1)                                                                                         \
+    do {                                                                                                                \
+        if (lds > 65536 && !lds_raised[KS]) {                                                                           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_step_mfma_kernel<KS, KS1>),                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+                return VINE_ERR_DEVICE;                                                                                 \
+            lds_raised[KS] = true;                                                                                      \
+        }                                                                                                               \
+        hipLaunchKernelGGL((lstm_step_mfma_kernel<KS, KS1>), grid, block, lds, s, (long long)B, (int)H,                 \
+                           (const bf16_t*)A, (long long)lda, (const bf16_t*)A2, (long long)lda2, (const bf16_t*)W,      \
+                           (long long)ldw, igates, (long long)ig_stride, bias, c_prev, done, (long long)done_stride,    \
+                           h_out, (long long)h_stride, c_out, (bf16_t*)gates_act, (bf16_t*)hp_next, done_next,          \
+                           (long long)done_next_stride, (long long)hp_stride);                                          \
+    } while (0)
+    const int ks = (int)(K / 32), ks1 = (int)(K1 / 32);
+    if (ks1 == 0) {
+        switch (ks) {
+            case 4: VINE_LSTM_MFMA(4, 0); break;
+            case 8: VINE_LSTM_MFMA(8, 0); break;
+            case 9: VINE_LSTM_MFMA(9, 0); break;
+            case 10: VINE_LSTM_MFMA(10, 0); break;
+            case 11: VINE_LSTM_MFMA(11, 0); break;
+            case 12: VINE_LSTM_MFMA(12, 0); break;
+            case 16: VINE_LSTM_MFMA(16, 0); break;
+            default: return VINE_ERR_UNSUPPORTED;
+        }
+    } else if (ks - ks1 == 8) {          // [x (32 * ks1 columns) | h (256)]: the update's two-operand form
+        switch (ks1) {
+            case 1: VINE_LSTM_MFMA(9, 1); break;
+            case 2: VINE_LSTM_MFMA(10, 2); break;
+            case 3: VINE_LSTM_MFMA(11, 3); break;
+            case 4: VINE_LSTM_MFMA(12, 4); break;
+            default: return VINE_ERR_UNSUPPORTED;
+        }
+    } else {
+        return VINE_ERR_UNSUPPORTED;
     }
 #undef VINE_LSTM_MFMA
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;

@@ -410,7 +410,7 @@ class A2CAgent:
         if bf and N % 64 == 0 and Kx in (128, 256, 288, 320, 352, 384, 512) and H % 16 == 0:
             # gate GEMM over [x | h] fused with the pointwise update on the matrix cores
             fused._check(lib.vine_lstm_step_mfma(
-                N, H, Kx, xh.data_ptr(), xh.stride(0), f["wcat"].data_ptr(), f["wcat"].stride(0), None, 4 * H,
+                N, H, Kx, xh.data_ptr(), xh.stride(0), None, 0, 0, f["wcat"].data_ptr(), f["wcat"].stride(0), None, 4 * H,
                 f["bias"].data_ptr(), c.data_ptr(), None, 0, h_out.data_ptr(), H, c_out.data_ptr(), None,
                 hp_ptr, None, 0, Kx, st), "vine_lstm_step_mfma")
             gates = None

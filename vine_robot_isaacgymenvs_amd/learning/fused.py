@@ -136,14 +136,16 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     return torch.stack(outs, 1).reshape(B * T, -1), h, c
 
 
-def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
+def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
     hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
-    ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32."""
+    ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32.
+    ``wcat`` = [w_ih | 0 | w_hh] (bf16, K = padded input width + H) with ``ig`` None: no input projection at all; the
+    step kernel multiplies the two operand blocks x_t (rows of ``x``, padded width) and h_{t-1} in one product."""
     op = w_hh.dtype
-    BT, H = ig.shape[0], w_hh.shape[1]
+    BT, H = x.shape[0], w_hh.shape[1]
     B = BT // T
-    dev = ig.device
+    dev = x.device
     out = torch.empty((BT, H), device=dev, dtype=torch.float32)
     c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
     c_all[0].copy_(c0)
@@ -153,16 +155,26 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad):
         hp[:, 0].copy_(h0 * (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)))
     else:
         hp[:, 0].copy_(h0)
-    st = _stream(ig)
+    st = _stream(x)
     d_ptr = dones.data_ptr() if dones is not None else None
     w_hh_t = w_hh.t()
     # mixed precision: the recurrent GEMM runs inside the step kernel on the matrix cores (vine_lstm_step_mfma)
     mfma = (op == torch.bfloat16 and B % 64 == 0 and H in (128, 256, 512))
     for t in range(T):
         last = t == T - 1
+        if mfma and wcat is not None:
+            K1 = wcat.shape[1] - H
+            _check(lib.vine_lstm_step_mfma(
+                B, H, K1 + H, x.data_ptr() + 2 * (t * x.stride(0)), T * x.stride(0), hp.data_ptr() + 2 * (t * H), T * H,
+                K1, wcat.data_ptr(), wcat.stride(0), None, 4 * H, bias.data_ptr(), c_all[t].data_ptr(),
+                (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
+                c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
+                None if last else hp.data_ptr() + 2 * ((t + 1) * H),
+                (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, T * H, st), "vine_lstm_step_mfma")
+            continue
         if mfma:
             _check(lib.vine_lstm_step_mfma(
-                B, H, H, hp.data_ptr() + 2 * (t * H), T * H, w_hh.data_ptr(), w_hh.stride(0),
+                B, H, H, hp.data_ptr() + 2 * (t * H), T * H, None, 0, 0, w_hh.data_ptr(), w_hh.stride(0),
                 ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, bias.data_ptr(), c_all[t].data_ptr(),
                 (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
                 c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
@@ -365,7 +377,9 @@ class _Trunk(torch.autograd.Function):
         U = mlp[-1][0].shape[0]
         width = U + (F_in if concat else 0)
         # rows padded to 64 B so that every row (and the column block the ELU kernels address) is 16-B aligned
-        xcat = torch.empty((n, (width + 15) // 16 * 16), device=dev, dtype=op)[:, :width]
+        wpad = (width + 15) // 16 * 16
+        xfull = torch.empty((n, wpad), device=dev, dtype=op)
+        xcat = xfull[:, :width]
         acts = []
         x = x0
         for i, (W, b) in enumerate(mlp):
@@ -394,10 +408,21 @@ class _Trunk(torch.autograd.Function):
             xcat[:, U:].copy_(obs_n)
         H = w_hh.shape[1]
         B = n // T
-        ig = _mm(xcat, w_ih_op.t())
         bias = b_ih + b_hh
-        out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True)
-        del ig
+        if mixed and B % 64 == 0 and H == 256 and wpad % 32 == 0 and wpad <= 128:
+            # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
+            if wpad > width:
+                xfull[:, width:].fill_(0.0)            # (an elementwise fill, not a memset node)
+            wcat = torch.empty((4 * H, wpad + H), device=dev, dtype=op)
+            wcat[:, :width].copy_(w_ih_op)
+            if wpad > width:
+                wcat[:, width:wpad].fill_(0.0)
+            wcat[:, wpad:].copy_(w_hh_op)
+            out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat)
+        else:
+            ig = _mm(xcat, w_ih_op.t())
+            out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True)
+            del ig
         # LayerNorm and the two heads stay in fp32 in both modes (3 output columns: nothing to gain, and mu feeds
         # the probability ratio directly)
         mean = torch.empty(n, device=dev, dtype=torch.float32)
