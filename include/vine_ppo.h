@@ -61,6 +61,15 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
 int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
                          const float* bias, float alpha, void* out, int64_t out_stride, void* stream);
 
+/* Backward of a Linear through the previous layer's ELU, on the matrix cores:
+ *   gz = (G Wt^T) * elu'(a)   with G [n, K] bf16 (gradient w.r.t. this layer's pre-activation), Wt [N, K] bf16 = the
+ *   layer's weight TRANSPOSED (N = its input width), a [n, N] bf16 = the previous layer's ELU output, gz [n, N] bf16;
+ * partial (nullable, [n / 64, N] fp32): per-workgroup column sums of gz = partial bias gradient of the previous layer.
+ * Needs n % 64 == 0, N % 64 == 0, K in {64, 128, 256}; otherwise VINE_ERR_UNSUPPORTED (GEMM + vine_elu_backward). */
+int vine_linear_bwd_elu_mfma(int64_t n, int64_t N, int64_t K, const void* G, int64_t ldg, const void* Wt, int64_t ldw,
+                             const void* a, int64_t a_stride, float alpha, void* gz, int64_t gz_stride, float* partial,
+                             void* stream);
+
 /* Backward of the step above.
  *   dh = g_out[b] (rows g_stride apart) + keep_next_b * g_rec[b];   dc = keep_next_b * dc_next[b] + dh * o * (1 - tanh(c)^2)
  * g_rec / dc_next = gradients w.r.t. the MASKED (h_t, c_t) consumed by step t+1 (NULL at the last step),

@@ -263,6 +263,34 @@ def test_linear_elu_mfma_matches_gemm_plus_bias_elu(n, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,K,N", [(32768, 128, 256), (16384, 64, 128), (64, 256, 64)])
+def test_linear_bwd_elu_mfma_matches_gemm_plus_elu_backward(n, K, N):
+    """gz = (G W) * elu'(a) and its per-workgroup column sums on the matrix cores against GEMM + vine_elu_backward."""
+    from vine_robot_isaacgymenvs_amd.abi import PPO_PARTIAL_BLOCKS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    lib = fused._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bf = torch.bfloat16
+    G = (torch.randn(n, K, device=dev) / n).to(bf)
+    W = (torch.randn(K, N, device=dev) / K ** 0.5).to(bf)                  # the layer's weight [out, in]
+    a = torch.nn.functional.elu(torch.randn(n, N + 16, device=dev)).to(bf)[:, :N]
+    gz, part = torch.empty(n, N, device=dev, dtype=bf), torch.empty(n // 64, N, device=dev)
+    wt = W.t().contiguous()
+    assert lib.vine_linear_bwd_elu_mfma(n, N, K, G.data_ptr(), K, wt.data_ptr(), K, a.data_ptr(), a.stride(0), 1.0,
+                                        gz.data_ptr(), N, part.data_ptr(), st) == 0
+    g = torch.mm(G, W, out_dtype=torch.float32)
+    ref, rpart = torch.empty(n, N, device=dev, dtype=bf), torch.empty(PPO_PARTIAL_BLOCKS, N, device=dev)
+    assert lib.vine_elu_backward(n, N, g.data_ptr(), N, a.data_ptr(), a.stride(0), 1.0, ref.data_ptr(), N, rpart.data_ptr(),
+                                 1, 1, st) == 0
+    torch.cuda.synchronize()
+    scale = float(ref.float().abs().max())
+    assert float((gz.float() - ref.float()).abs().max()) < 1e-2 * scale
+    s1, s2 = part.sum(0), rpart.sum(0)
+    assert float((s1 - s2).abs().max()) < 1e-3 * (float(s2.abs().max()) + 1e-12) + 1e-7
+
+
+@pytest.mark.gpu
 def test_gae_kernel_matches_reference_loop():
     """vine_gae against the Python loop (rl_games discount_values, next-nonterminal form)."""
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import discount_values

@@ -164,6 +164,8 @@ PPO_PROTOTYPES = {
     "vine_lstm_step_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP,
                                       _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _I64, _VP]),
     "vine_linear_elu_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_float, _VP, _I64, _VP]),
+    "vine_linear_bwd_elu_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _I64, _VP,
+                                           _VP]),
     "vine_lstm_cell_backward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP,
                                           _I64, _VP, _VP, _VP, C.c_int32, _VP]),
     "vine_layernorm_forward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP]),

@@ -266,6 +266,78 @@ __global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N
     }
 }
 
+// ---- backward of a Linear through the previous layer's ELU on the matrix cores:
+//   gz[b, u] = (G W)[b, u] * elu'(a[b, u])      G [n, K] bf16 (gradient w.r.t. this layer's pre-activation),
+//                                               Wt [N, K] bf16 = W^T (N = input width of the layer),
+//                                               a [n, N] bf16 = the previous layer's ELU output
+// plus one row of column sums of gz per workgroup (= partial bias gradient of the previous layer).  Same transposed
+// product scheme as linear_elu_mfma_kernel; the fp32 input gradient is never stored.
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, int N, const bf16_t* __restrict__ G,
+                                                                  long long ldg, const bf16_t* __restrict__ Wt,
+                                                                  long long ldw, const bf16_t* __restrict__ a,
+                                                                  long long a_stride, float alpha,
+                                                                  bf16_t* __restrict__ gz, long long gz_stride,
+                                                                  float* __restrict__ partial) {
+    constexpr int K = 32 * KSTEPS;
+    constexpr int PITCH = K + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16_t* wl = reinterpret_cast<bf16_t*>(lds_raw);           // [64 units][PITCH], later reused for the column sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * 64;
+    const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    bf16x8_t gf[KSTEPS];
+    const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) gf[kk] = *reinterpret_cast<const bf16x8_t*>(grow + 32 * kk);
+    float4 av[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[t] = ld4(a + b * a_stride + u0 + 16 * t + 4 * (lane >> 4));
+    constexpr int CHUNKS = K / 8;
+    for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
+        const int row = c / CHUNKS, ck = c - row * CHUNKS;
+        const uint4 v = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + row) * ldw + ck * 8);
+        *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
+    }
+    __syncthreads();
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8_t wf =
+                *reinterpret_cast<const bf16x8_t*>(&wl[(t * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf[kk], acc[t], 0, 0, 0);
+        }
+    }
+    float d[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float aa[4] = {av[t].x, av[t].y, av[t].z, av[t].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[t][u] = acc[t][u] * (aa[u] > 0.0f ? 1.0f : aa[u] + alpha);
+        st4(gz + b * gz_stride + u0 + 16 * t + 4 * (lane >> 4), make_float4(d[t][0], d[t][1], d[t][2], d[t][3]));
+    }
+    if (partial) {
+        // column sums over the workgroup's 64 rows: [row 0..63][unit 0..63] through LDS, then 64 threads x 64 adds
+        __syncthreads();                                       // everyone is done with the weight slab
+        float* red = reinterpret_cast<float*>(lds_raw);        // 64 x 65 floats (16.6 KB <= slab size for K >= 128)
+        const int r = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) red[r * 65 + 16 * t + 4 * (lane >> 4) + u] = d[t][u];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float sum = 0.0f;
+            for (int rr = 0; rr < 64; ++rr) sum += red[rr * 65 + threadIdx.x];
+            partial[(long long)blockIdx.x * N + u0 + threadIdx.x] = sum;
+        }
+    }
+}
+
 template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
@@ -1223,6 +1295,30 @@ int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t
         default: return VINE_ERR_UNSUPPORTED;
     }
 #undef VINE_LIN_MFMA
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_linear_bwd_elu_mfma(int64_t n, int64_t N, int64_t K, const void* G, int64_t ldg, const void* Wt, int64_t ldw,
+                             const void* a, int64_t a_stride, float alpha, void* gz, int64_t gz_stride, float* partial,
+                             void* stream) {
+    if (n <= 0 || N <= 0 || K <= 0 || !G || !Wt || !a || !gz || (ldg & 7) || (ldw & 7) || (a_stride & 3) || (gz_stride & 3))
+        return VINE_ERR_INVALID_ARG;
+    if ((n & 63) || (N & 63) || (K != 64 && K != 128 && K != 256)) return VINE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(n / 64), (unsigned)(N / 64)), block(256);
+    size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);
+    if (lds < 64 * 65 * sizeof(float)) lds = 64 * 65 * sizeof(float);       // the column-sum stage reuses the slab
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_LINB_MFMA(KS)                                                                                             \
+    hipLaunchKernelGGL(linear_bwd_elu_mfma_kernel<KS>, grid, block, lds, s, (long long)n, (int)N, (const bf16_t*)G,    \
+                       (long long)ldg, (const bf16_t*)Wt, (long long)ldw, (const bf16_t*)a, (long long)a_stride, alpha,  \
+                       (bf16_t*)gz, (long long)gz_stride, partial)
+    switch (K / 32) {
+        case 2: VINE_LINB_MFMA(2); break;
+        case 4: VINE_LINB_MFMA(4); break;
+        case 8: VINE_LINB_MFMA(8); break;
+        default: return VINE_ERR_UNSUPPORTED;
+    }
+#undef VINE_LINB_MFMA
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -530,19 +530,36 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
         g = _mm(dG, w_ih[:, :U] if concat else w_ih)        # only the MLP columns of the LSTM input need a gradient
         del dG
-        # ---- MLP, last layer first: ELU' from the stored OUTPUT, bias gradient from the kernel's partial sums
+        # ---- MLP, last layer first: ELU' from the stored OUTPUT, bias gradient from the kernels' partial sums.
+        # gz = gradient w.r.t. layer i's pre-activation.  In mixed precision the step from layer i to layer i-1
+        # (input-gradient GEMM + ELU backward + bias partial sums) is one matrix-core kernel.
+        gz = part = None
         for i in reversed(range(n_mlp)):
-            a = xcat if i == n_mlp - 1 else acts[i]
-            C_ = g.shape[1]
-            part = torch.empty((PPO_PARTIAL_BLOCKS, C_), device=dev, dtype=torch.float32)
-            gz = torch.empty((n, C_), device=dev, dtype=torch.bfloat16) if mixed else g     # fp32: in place
-            _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
-                                         part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
+            if gz is None:
+                a = xcat if i == n_mlp - 1 else acts[i]
+                C_ = g.shape[1]
+                part = torch.empty((PPO_PARTIAL_BLOCKS, C_), device=dev, dtype=torch.float32)
+                gz = torch.empty((n, C_), device=dev, dtype=torch.bfloat16) if mixed else g     # fp32: in place
+                _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
+                                             part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
             x_in = acts[i - 1] if i > 0 else x0
             deliver(2 * i, lambda o, gz=gz, x_in=x_in: splitk_tn(gz, x_in, out=o, batch=batch))
             deliver(2 * i + 1, lambda o, part=part: column_sums(part, o, batch=batch))
-            if i > 0:
+            if i == 0:
+                break
+            C_in = weights[i].shape[1]
+            if mixed and linear_bwd_mfma_ok(n, C_in, gz.shape[1]):
+                wt = weights[i].t().contiguous()                                   # [C_in, C_i] bf16
+                gz_next = torch.empty((n, C_in), device=dev, dtype=torch.bfloat16)
+                part = torch.empty((n // 64, C_in), device=dev, dtype=torch.float32)
+                _check(lib.vine_linear_bwd_elu_mfma(n, C_in, gz.shape[1], gz.data_ptr(), gz.stride(0), wt.data_ptr(),
+                                                    wt.stride(0), acts[i - 1].data_ptr(), acts[i - 1].stride(0), 1.0,
+                                                    gz_next.data_ptr(), C_in, part.data_ptr(), st),
+                       "vine_linear_bwd_elu_mfma")
+                gz = gz_next
+            else:
                 g = _mm(gz, weights[i])
+                gz = None
         if batch is not None:
             batch.flush(out)
         return (None, None, None, None, None, None, None, None, None, *grads)
@@ -551,6 +568,11 @@ class _Trunk(torch.autograd.Function):
 def linear_elu_mfma_ok(n, N, K):
     """Shapes vine_linear_elu_mfma covers (else: GEMM + vine_bias_elu)."""
     return n % 64 == 0 and N % 64 == 0 and K in (32, 64, 128, 256)
+
+
+def linear_bwd_mfma_ok(n, N, K):
+    """Shapes vine_linear_bwd_elu_mfma covers (else: GEMM + vine_elu_backward)."""
+    return n % 64 == 0 and N % 64 == 0 and K in (64, 128, 256)
 
 
 def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
