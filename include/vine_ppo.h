@@ -136,7 +136,7 @@ int vine_gae(int32_t T, int64_t N, const float* rewards, const float* values, co
 /* RunningMeanStd of rl_games in training mode: merge the batch moments of x [n,F] (fp32, packed, F <= 64) into the
  * float64 running mean / variance / count (Chan et al.; unbiased batch variance like torch's x.var(0)).  Two launches,
  * fixed summation order, no memsets: safe inside a captured hipGraph.  scratch: VINE_RMS_BLOCKS * 2 * F doubles. */
-#define VINE_RMS_BLOCKS 256
+#define VINE_RMS_BLOCKS 128
 int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, double* running_var, double* count,
                     double* scratch, void* stream);
 

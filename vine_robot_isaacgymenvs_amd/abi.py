@@ -156,7 +156,7 @@ _I64 = C.c_int64
 _VP = C.c_void_p
 PPO_PARTIAL_BLOCKS = 512   # VINE_PPO_PARTIAL_BLOCKS
 PPO_LOSS_SCRATCH_FLOATS = 1024 * 32   # VINE_PPO_LOSS_SCRATCH_FLOATS
-RMS_BLOCKS = 256   # VINE_RMS_BLOCKS
+RMS_BLOCKS = 128   # VINE_RMS_BLOCKS
 # include/vine_ppo.h (product library only; the oracle does not implement these)
 PPO_PROTOTYPES = {
     "vine_lstm_cell_forward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _VP, _VP,

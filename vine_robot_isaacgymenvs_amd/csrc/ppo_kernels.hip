@@ -586,17 +586,26 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(long long n, int F, co
     }
 }
 
-__global__ void rms_finalize_kernel(int blocks, int F, long long n, const double* __restrict__ partial,
-                                    double* __restrict__ running_mean, double* __restrict__ running_var,
-                                    double* __restrict__ count) {
-    const int c = threadIdx.x;
-    const double cnt = count[0], nb = (double)n;
-    if (c < F) {
-        double s = 0.0, ss = 0.0;
-        for (int b = 0; b < blocks; ++b) {
+__global__ __launch_bounds__(256) void rms_finalize_kernel(int blocks, int F, long long n,
+                                                           const double* __restrict__ partial,
+                                                           double* __restrict__ running_mean,
+                                                           double* __restrict__ running_var, double* __restrict__ count) {
+    // 64 column lanes x 4 row lanes over the partial rows, folded through LDS in a fixed order
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double s = 0.0, ss = 0.0;
+    if (c < F)
+        for (int b = rl; b < blocks; b += 4) {
             s += partial[(long long)b * 2 * F + c];
             ss += partial[(long long)b * 2 * F + F + c];
         }
+    __shared__ double red[2][4][64];
+    red[0][rl][c] = s;
+    red[1][rl][c] = ss;
+    __syncthreads();
+    const double cnt = count[0], nb = (double)n;
+    if (rl == 0 && c < F) {
+        s = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        ss = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
         const double bmean = s / nb;
         const double bvar = n > 1 ? (ss - nb * bmean * bmean) / (nb - 1.0) : 0.0;      // unbiased, like x.var(0)
         const double delta = bmean - running_mean[c], tot = cnt + nb;
@@ -605,7 +614,7 @@ __global__ void rms_finalize_kernel(int blocks, int F, long long n, const double
         running_var[c] = m2 / tot;
     }
     __syncthreads();
-    if (c == 0) count[0] = cnt + nb;
+    if (threadIdx.x == 0) count[0] = cnt + nb;
 }
 
 // out = elu(z + bias): the activation of a Linear whose GEMM ran without an epilogue (bf16 operands, fp32 output)
@@ -1449,7 +1458,7 @@ int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, 
     if (blocks > VINE_RMS_BLOCKS) blocks = VINE_RMS_BLOCKS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(rms_partial_kernel, dim3(blocks), dim3(256), 0, s, (long long)n, (int)F, x, scratch);
-    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(64), 0, s, blocks, (int)F, (long long)n, scratch, running_mean,
+    hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(256), 0, s, blocks, (int)F, (long long)n, scratch, running_mean,
                        running_var, count);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
