@@ -20,6 +20,17 @@ out = torch.empty(B, T, H, device=dev)
 gates = torch.empty(B, 4 * H, device=dev, dtype=bf)
 
 
+xfull = (torch.randn(B * T, 96, device=dev) * 0.5).to(bf)
+wcat = (torch.randn(4 * H, 96 + H, device=dev) / 16).to(bf)
+
+
+def fused2():      # the update's two-operand form: [x_t (96) | h_{t-1} (256)], no input projection
+    rc = lib.vine_lstm_step_mfma(B, H, 96 + H, xfull.data_ptr(), T * 96, hp.data_ptr(), T * H, 96, wcat.data_ptr(), 96 + H,
+                                 None, 4 * H, bias.data_ptr(), c0.data_ptr(), None, 0, out.data_ptr(), T * H, c1.data_ptr(),
+                                 gates.data_ptr(), hp.data_ptr() + 2 * H, None, 0, T * H, st)
+    assert rc == 0
+
+
 def fusedk():
     rc = lib.vine_lstm_step_mfma(B, H, H, hp.data_ptr(), T * H, None, 0, 0, W.data_ptr(), H, ig.data_ptr(), T * 4 * H, bias.data_ptr(),
                                  c0.data_ptr(), None, 0, out.data_ptr(), T * H, c1.data_ptr(), gates.data_ptr(),
@@ -35,7 +46,7 @@ def unfused():
     assert rc == 0
 
 
-for name, f in (("fused mfma", fusedk), ("gemm + pointwise", unfused)):
+for name, f in (("fused mfma K=352", fused2), ("fused mfma K=256", fusedk), ("gemm + pointwise", unfused)):
     for _ in range(10):
         f()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

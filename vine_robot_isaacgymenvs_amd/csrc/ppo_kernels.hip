@@ -166,11 +166,23 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     const float kn = (hp_next && done_next) ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
     // stage W: LDS row g*16 + i  <-  W[g*H + u0 + i][0:K]   (16-B chunks, coalesced along k)
     constexpr int CHUNKS = K / 8;
-    for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
-        const int row = c / CHUNKS, ck = c - row * CHUNKS;
-        const int g = row >> 4, i = row & 15;
-        const uint4 v = *reinterpret_cast<const uint4*>(W + (long long)(g * H + u0 + i) * ldw + ck * 8);
-        *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
+    // (64 * CHUNKS / 256 = KSTEPS pieces per thread; unrolled with all loads ahead of the LDS stores: left rolled, each
+    //  iteration waited out a full L2 round trip before the next load was issued -- 12 us of a 37 us launch at K = 352)
+    {
+        uint4 stage[KSTEPS];
+#pragma unroll
+        for (int it = 0; it < KSTEPS; ++it) {
+            const int c = threadIdx.x + 256 * it;
+            const int row = c / CHUNKS, ck = c - row * CHUNKS;
+            const int g = row >> 4, i = row & 15;
+            stage[it] = *reinterpret_cast<const uint4*>(W + (long long)(g * H + u0 + i) * ldw + ck * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < KSTEPS; ++it) {
+            const int c = threadIdx.x + 256 * it;
+            const int row = c / CHUNKS, ck = c - row * CHUNKS;
+            *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = stage[it];
+        }
     }
     __syncthreads();
     f32x4_t acc[4];
@@ -238,10 +250,20 @@ __global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N
 #pragma unroll
     for (int t = 0; t < 4; ++t) bbv[t] = ld4(bias + u0 + 16 * t + 4 * (lane >> 4));
     constexpr int CHUNKS = K / 8;
-    for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
-        const int row = c / CHUNKS, ck = c - row * CHUNKS;
-        const uint4 v = *reinterpret_cast<const uint4*>(W + (long long)(u0 + row) * ldw + ck * 8);
-        *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
+    {
+        uint4 stage[KSTEPS];
+#pragma unroll
+        for (int it = 0; it < KSTEPS; ++it) {
+            const int c = threadIdx.x + 256 * it;
+            const int row = c / CHUNKS, ck = c - row * CHUNKS;
+            stage[it] = *reinterpret_cast<const uint4*>(W + (long long)(u0 + row) * ldw + ck * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < KSTEPS; ++it) {
+            const int c = threadIdx.x + 256 * it;
+            const int row = c / CHUNKS, ck = c - row * CHUNKS;
+            *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = stage[it];
+        }
     }
     __syncthreads();
     f32x4_t acc[4];
@@ -294,10 +316,20 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, i
 #pragma unroll
     for (int t = 0; t < 4; ++t) av[t] = ld4(a + b * a_stride + u0 + 16 * t + 4 * (lane >> 4));
     constexpr int CHUNKS = K / 8;
-    for (int c = threadIdx.x; c < 64 * CHUNKS; c += 256) {
-        const int row = c / CHUNKS, ck = c - row * CHUNKS;
-        const uint4 v = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + row) * ldw + ck * 8);
-        *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = v;
+    {
+        uint4 stage[KSTEPS];
+#pragma unroll
+        for (int it = 0; it < KSTEPS; ++it) {
+            const int c = threadIdx.x + 256 * it;
+            const int row = c / CHUNKS, ck = c - row * CHUNKS;
+            stage[it] = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + row) * ldw + ck * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < KSTEPS; ++it) {
+            const int c = threadIdx.x + 256 * it;
+            const int row = c / CHUNKS, ck = c - row * CHUNKS;
+            *reinterpret_cast<uint4*>(&wl[row * PITCH + ck * 8]) = stage[it];
+        }
     }
     __syncthreads();
     f32x4_t acc[4];
