@@ -150,6 +150,15 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
                              const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
                              const int32_t* dup, void* stream);
 
+/* Up to 16 small 2-D element moves in one launch (arrays of length njobs in host memory): dst[r, c] for r < rows,
+ * c < cols, rows of dst / src dst_stride / src_stride ELEMENTS apart.  op: 0 copy, 1 zero, 2 transpose (dst[r, c] =
+ * src[c, r]), 3 float32 -> bfloat16, 4 dst = src + src2 (float32).  elem: element size of dst in bytes (2 or 4).
+ * Used for the per-step operand preparation of the mixed-precision update (concatenated / padded / transposed weight
+ * operands, merged head weights, observation casts). */
+int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
+                      const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
+                      const int64_t* src_stride, const int64_t* dst_stride, void* stream);
+
 /* out = elu(z + bias) for z [n,C] packed fp32 (a GEMM output without epilogue); out rows out_stride apart, fp32 or
  * bfloat16 (out_bf16). */
 int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float alpha, void* out, int64_t out_stride,

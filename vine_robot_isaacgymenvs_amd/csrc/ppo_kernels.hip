@@ -903,6 +903,62 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
     }
 }
 
+// ---- Several small 2-D element moves in ONE launch: the operand preparation of an optimiser step (concatenated /
+// padded / transposed bf16 weight operands, the merged head weights, fp32 -> bf16 casts of the observations) is a
+// dozen strided copies of a few hundred KB each; as separate launches they cost ~5 us apiece.
+// dst[r, c] (rows dst_stride apart) = op(src) for r < rows, c < cols:
+//   op 0 copy        src[r, c]            (elem = 2 or 4 bytes, same type both sides)
+//   op 1 zero
+//   op 2 transpose   src[c, r]            (elem = 2 or 4 bytes)
+//   op 3 f32 -> bf16 src[r, c]
+//   op 4 add (f32)   src[r, c] + src2[r, c]
+struct CopyJob {
+    const void* src;
+    const void* src2;
+    void* dst;
+    long long rows, cols, src_stride, dst_stride;
+    int op, elem, first_block;
+};
+#define VINE_COPY_MAX_JOBS 16
+struct CopyBatchArgs {
+    CopyJob job[VINE_COPY_MAX_JOBS];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < batch.njobs; ++k)
+        if ((int)blockIdx.x >= batch.job[k].first_block) j = k;
+    const CopyJob& J = batch.job[j];
+    const long long total = J.rows * J.cols;
+    const long long base = ((long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long e = base + q;
+        if (e >= total) break;
+        const long long r = e / J.cols, c = e - r * J.cols;
+        const long long d = r * J.dst_stride + c;
+        const long long sidx = (J.op == 2) ? c * J.src_stride + r : r * J.src_stride + c;
+        switch (J.op) {
+            case 0:
+            case 2:
+                if (J.elem == 2) reinterpret_cast<bf16_t*>(J.dst)[d] = reinterpret_cast<const bf16_t*>(J.src)[sidx];
+                else reinterpret_cast<float*>(J.dst)[d] = reinterpret_cast<const float*>(J.src)[sidx];
+                break;
+            case 1:
+                if (J.elem == 2) reinterpret_cast<bf16_t*>(J.dst)[d] = 0;
+                else reinterpret_cast<float*>(J.dst)[d] = 0.0f;
+                break;
+            case 3:
+                reinterpret_cast<bf16_t*>(J.dst)[d] = f2bf(reinterpret_cast<const float*>(J.src)[sidx]);
+                break;
+            default:
+                reinterpret_cast<float*>(J.dst)[d] =
+                    reinterpret_cast<const float*>(J.src)[sidx] + reinterpret_cast<const float*>(J.src2)[sidx];
+        }
+    }
+}
+
 #define PPO_MAX_A 8
 #define PPO_LOSS_ROW 32          // floats per workgroup row of the loss kernel's partial sums (22 used)
 __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const float* __restrict__ mu,
@@ -1527,6 +1583,27 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
     }
     b.njobs = njobs;
     hipLaunchKernelGGL(colsum_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
+                      const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
+                      const int64_t* src_stride, const int64_t* dst_stride, void* stream) {
+    if (njobs <= 0 || njobs > VINE_COPY_MAX_JOBS || !op || !elem || !src || !src2 || !dst || !rows || !cols ||
+        !src_stride || !dst_stride)
+        return VINE_ERR_INVALID_ARG;
+    CopyBatchArgs b;
+    int blocks = 0;
+    for (int k = 0; k < njobs; ++k) {
+        if (op[k] < 0 || op[k] > 4 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
+            (op[k] == 4 && !src2[k]) || (elem[k] != 2 && elem[k] != 4))
+            return VINE_ERR_INVALID_ARG;
+        b.job[k] = CopyJob{src[k], src2[k], dst[k], (long long)rows[k], (long long)cols[k], (long long)src_stride[k],
+                           (long long)dst_stride[k], (int)op[k], (int)elem[k], blocks};
+        blocks += (int)((rows[k] * cols[k] + 1023) / 1024);
+    }
+    b.njobs = njobs;
+    hipLaunchKernelGGL(copy_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

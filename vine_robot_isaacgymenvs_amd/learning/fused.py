@@ -275,6 +275,49 @@ class ColumnSumBatch:
         self.jobs, self.keep = [], []
 
 
+class CopyBatch:
+    """Collects small 2-D element moves (copy / zero / transpose / fp32->bf16 cast / fp32 add) and runs them in ONE
+    launch (``vine_copy_batched``): the operand preparation of an optimiser step is a dozen such moves."""
+    COPY, ZERO, TRANSPOSE, CAST_BF16, ADD = 0, 1, 2, 3, 4
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def add(self, op, dst, src=None, src2=None):
+        """dst: 2-D view with unit column stride (1-D tensors are taken as one row)."""
+        d2 = dst if dst.dim() == 2 else dst.view(1, -1)
+        s2 = None if src is None else (src if src.dim() == 2 else src.view(1, -1))
+        t2 = None if src2 is None else (src2 if src2.dim() == 2 else src2.view(1, -1))
+        assert d2.stride(1) == 1 and (s2 is None or s2.stride(1) == 1) and (t2 is None or t2.stride(1) == 1)
+        rows, cols = d2.shape
+        if op == self.TRANSPOSE:
+            assert tuple(s2.shape) == (cols, rows) and s2.dtype == d2.dtype
+        elif op in (self.COPY, self.ADD):
+            assert tuple(s2.shape) == (rows, cols) and s2.dtype == d2.dtype
+        elif op == self.CAST_BF16:
+            assert tuple(s2.shape) == (rows, cols) and s2.dtype == torch.float32 and d2.dtype == torch.bfloat16
+        if op == self.ADD:
+            assert t2.stride(0) == s2.stride(0) and d2.dtype == torch.float32
+        self.keep.append((d2, s2, t2))
+        self.jobs.append((op, d2.element_size(), 0 if s2 is None else s2.data_ptr(), 0 if t2 is None else t2.data_ptr(),
+                          d2.data_ptr(), rows, cols, 0 if s2 is None else s2.stride(0), d2.stride(0)))
+        return dst
+
+    def flush(self, ref):
+        import ctypes as C
+        lib, st = _lib(), _stream(ref)
+        for k in range(0, len(self.jobs), 16):
+            js = self.jobs[k:k + 16]
+            n = len(js)
+            cols = list(zip(*js))
+            i32 = lambda v: (C.c_int32 * n)(*v)
+            i64 = lambda v: (C.c_int64 * n)(*v)
+            ptr = lambda v: (C.c_void_p * n)(*v)
+            _check(lib.vine_copy_batched(n, i32(cols[0]), i32(cols[1]), ptr(cols[2]), ptr(cols[3]), ptr(cols[4]),
+                                         i64(cols[5]), i64(cols[6]), i64(cols[7]), i64(cols[8]), st), "vine_copy_batched")
+        self.jobs, self.keep = [], []
+
+
 def column_sums(src, out=None, out1=None, n0=0, dup=False, batch=None):
     """Sum over dim 0 of a [R, ...] fp32 tensor with the hand-written kernel (deterministic; unlike ATen's
     multi-block reductions it needs no memset-cleared scratch, so it is safe inside a captured hipGraph).
@@ -373,13 +416,53 @@ class _Trunk(torch.autograd.Function):
         n, F_in = obs_n.shape
         dev = obs_n.device
         st = _stream(obs_n)
-        x0 = obs_n.to(op).contiguous()
         U = mlp[-1][0].shape[0]
+        H = w_hh.shape[1]
+        B = n // T
         width = U + (F_in if concat else 0)
         # rows padded to 64 B so that every row (and the column block the ELU kernels address) is 16-B aligned
         wpad = (width + 15) // 16 * 16
         xfull = torch.empty((n, wpad), device=dev, dtype=op)
         xcat = xfull[:, :width]
+        A_ = mu_w.shape[0]
+        w_heads = torch.empty((A_ + v_w.shape[0], H), device=dev, dtype=torch.float32)
+        b_heads = torch.empty(A_ + v_w.shape[0], device=dev, dtype=torch.float32)
+        bias = torch.empty(4 * H, device=dev, dtype=torch.float32)
+        no_proj = mixed and B % 64 == 0 and H == 256 and wpad % 32 == 0 and wpad <= 128
+        wcat, wts = None, [None] * n_mlp
+        if mixed:
+            # every operand derived from the parameters or the observations, in ONE launch: bf16 cast of the
+            # observations (layer-1 operand and the LSTM operand's obs block), zero pad columns, [w_ih | 0 | w_hh],
+            # transposed MLP weights for the backward kernels, merged head weights, b_ih + b_hh
+            obs_c = obs_n.contiguous()
+            x0 = torch.empty((n, F_in), device=dev, dtype=op)
+            prep = CopyBatch()
+            prep.add(CopyBatch.CAST_BF16, x0, obs_c)
+            if concat:
+                prep.add(CopyBatch.CAST_BF16, xfull[:, U:width], obs_c)
+            if wpad > width:
+                prep.add(CopyBatch.ZERO, xfull[:, width:])
+            if no_proj:
+                wcat = torch.empty((4 * H, wpad + H), device=dev, dtype=op)
+                prep.add(CopyBatch.COPY, wcat[:, :width], w_ih_op)
+                if wpad > width:
+                    prep.add(CopyBatch.ZERO, wcat[:, width:wpad])
+                prep.add(CopyBatch.COPY, wcat[:, wpad:], w_hh_op)
+            for i in range(1, n_mlp):
+                if linear_bwd_mfma_ok(n, Wop[i].shape[1], Wop[i].shape[0]):
+                    wts[i] = torch.empty((Wop[i].shape[1], Wop[i].shape[0]), device=dev, dtype=op)
+                    prep.add(CopyBatch.TRANSPOSE, wts[i], Wop[i])
+            prep.add(CopyBatch.COPY, w_heads[:A_], mu_w)
+            prep.add(CopyBatch.COPY, w_heads[A_:], v_w)
+            prep.add(CopyBatch.COPY, b_heads[:A_], mu_b)
+            prep.add(CopyBatch.COPY, b_heads[A_:], v_b)
+            prep.add(CopyBatch.ADD, bias, b_ih, b_hh)
+            prep.flush(obs_n)
+        else:
+            x0 = obs_n.contiguous()
+            torch.cat([mu_w, v_w], 0, out=w_heads)
+            torch.cat([mu_b, v_b], 0, out=b_heads)
+            torch.add(b_ih, b_hh, out=bias)
         acts = []
         x = x0
         for i, (W, b) in enumerate(mlp):
@@ -404,20 +487,10 @@ class _Trunk(torch.autograd.Function):
             if not last:
                 acts.append(a)
                 x = a
-        if concat:
+        if concat and not mixed:
             xcat[:, U:].copy_(obs_n)
-        H = w_hh.shape[1]
-        B = n // T
-        bias = b_ih + b_hh
-        if mixed and B % 64 == 0 and H == 256 and wpad % 32 == 0 and wpad <= 128:
+        if no_proj:
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
-            if wpad > width:
-                xfull[:, width:].fill_(0.0)            # (an elementwise fill, not a memset node)
-            wcat = torch.empty((4 * H, wpad + H), device=dev, dtype=op)
-            wcat[:, :width].copy_(w_ih_op)
-            if wpad > width:
-                wcat[:, width:wpad].fill_(0.0)
-            wcat[:, wpad:].copy_(w_hh_op)
             out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat)
         else:
             ig = _mm(xcat, w_ih_op.t())
@@ -427,8 +500,6 @@ class _Trunk(torch.autograd.Function):
         # the probability ratio directly)
         mean = torch.empty(n, device=dev, dtype=torch.float32)
         rstd = torch.empty(n, device=dev, dtype=torch.float32)
-        w_heads = torch.cat([mu_w, v_w], 0)
-        b_heads = torch.cat([mu_b, v_b], 0)
         NH = w_heads.shape[0]
         fuse_heads = H == 256 and 2 <= NH <= 5
         if fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
@@ -448,6 +519,7 @@ class _Trunk(torch.autograd.Function):
         ctx.slots = [_grad_slot(p) if isinstance(p, torch.Tensor) else None for p in params]
         ctx.pshapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in params]
         ctx.fuse_heads = fuse_heads
+        ctx.wts = wts
         ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g, ln_b,
                               dones if dones is not None else obs_n.new_empty(0), *acts, *Wop)
         # final LSTM state as views (no copies): the update discards it, other callers may clone
@@ -548,8 +620,8 @@ class _Trunk(torch.autograd.Function):
             if i == 0:
                 break
             C_in = weights[i].shape[1]
-            if mixed and linear_bwd_mfma_ok(n, C_in, gz.shape[1]):
-                wt = weights[i].t().contiguous()                                   # [C_in, C_i] bf16
+            if mixed and ctx.wts[i] is not None:
+                wt = ctx.wts[i]                                                    # [C_in, C_i] bf16, made in forward
                 gz_next = torch.empty((n, C_in), device=dev, dtype=torch.bfloat16)
                 part = torch.empty((n // 64, C_in), device=dev, dtype=torch.float32)
                 _check(lib.vine_linear_bwd_elu_mfma(n, C_in, gz.shape[1], gz.data_ptr(), gz.stride(0), wt.data_ptr(),
