@@ -152,12 +152,13 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
 
 /* Up to 16 small 2-D element moves in one launch (arrays of length njobs in host memory): dst[r, c] for r < rows,
  * c < cols, rows of dst / src dst_stride / src_stride ELEMENTS apart.  op: 0 copy, 1 zero, 2 transpose (dst[r, c] =
- * src[c, r]), 3 float32 -> bfloat16, 4 dst = src + src2 (float32).  elem: element size of dst in bytes (2 or 4).
+ * src[c, r]), 3 float32 -> bfloat16, 4 dst = src + src2 (float32), 5 dst = src * (1 - mask[r * aux]) with src float32,
+ * mask = src2 (uint8, nullable) and dst float32 or bfloat16.  elem: element size of dst in bytes (2 or 4).
  * Used for the per-step operand preparation of the mixed-precision update (concatenated / padded / transposed weight
  * operands, merged head weights, observation casts). */
 int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
                       const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
-                      const int64_t* src_stride, const int64_t* dst_stride, void* stream);
+                      const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux, void* stream);
 
 /* out = elu(z + bias) for z [n,C] packed fp32 (a GEMM output without epilogue); out rows out_stride apart, fp32 or
  * bfloat16 (out_bf16). */

@@ -291,6 +291,45 @@ def test_linear_bwd_elu_mfma_matches_gemm_plus_elu_backward(n, K, N):
 
 
 @pytest.mark.gpu
+def test_copy_batch_ops():
+    """vine_copy_batched: copy / zero / transpose / fp32->bf16 cast / add / masked, strided views, 20 jobs (two launches)."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(13)
+    bf = torch.bfloat16
+    cb, checks = fused.CopyBatch(), []
+    for rep in range(3):
+        src = torch.randn(1024, 92, device=dev).to(bf)
+        wide = torch.full((1024, 352), 7.0, device=dev, dtype=bf)
+        cb.add(cb.COPY, wide[:, :92], src)
+        cb.add(cb.ZERO, wide[:, 92:96])
+        checks.append((wide[:, :92], src)); checks.append((wide[:, 92:96], torch.zeros(1024, 4, device=dev, dtype=bf)))
+        w = torch.randn(128, 256, device=dev).to(bf)
+        wt = torch.empty(256, 128, device=dev, dtype=bf)
+        cb.add(cb.TRANSPOSE, wt, w)
+        checks.append((wt, w.t()))
+        x = torch.randn(4099, 28, device=dev)
+        xb = torch.empty(4099, 96, device=dev, dtype=bf)[:, 64:92]
+        cb.add(cb.CAST_BF16, xb, x)
+        checks.append((xb, x.to(bf)))
+        a, b = torch.randn(1024, device=dev), torch.randn(1024, device=dev)
+        o = torch.empty(1024, device=dev)
+        cb.add(cb.ADD, o, a, b)
+        checks.append((o, a + b))
+        h0 = torch.randn(512, 256, device=dev)
+        dones = (torch.rand(512 * 4, device=dev) < 0.3).to(torch.uint8)
+        hp = torch.empty(512, 4, 256, device=dev, dtype=bf)
+        cb.add(cb.MASKED, hp[:, 0], h0, dones, aux=4)
+        checks.append((hp[:, 0], (h0 * (1.0 - dones.view(512, 4)[:, 0:1].float())).to(bf)))
+        c0, c1 = torch.randn(512, 256, device=dev), torch.empty(512, 256, device=dev)
+        cb.add(cb.MASKED, c1, c0, None)
+        checks.append((c1, c0))
+    cb.flush(src)
+    torch.cuda.synchronize()
+    for got, want in checks:
+        assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
 def test_gae_kernel_matches_reference_loop():
     """vine_gae against the Python loop (rl_games discount_values, next-nonterminal form)."""
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import discount_values

@@ -912,11 +912,12 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
 //   op 2 transpose   src[c, r]            (elem = 2 or 4 bytes)
 //   op 3 f32 -> bf16 src[r, c]
 //   op 4 add (f32)   src[r, c] + src2[r, c]
+//   op 5 masked      src[r, c] * (1 - mask[r * aux])   src f32, mask = src2 (uint8), dst f32 or bf16 by elem
 struct CopyJob {
     const void* src;
     const void* src2;
     void* dst;
-    long long rows, cols, src_stride, dst_stride;
+    long long rows, cols, src_stride, dst_stride, aux;
     int op, elem, first_block;
 };
 #define VINE_COPY_MAX_JOBS 16
@@ -952,9 +953,16 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
             case 3:
                 reinterpret_cast<bf16_t*>(J.dst)[d] = f2bf(reinterpret_cast<const float*>(J.src)[sidx]);
                 break;
-            default:
+            case 4:
                 reinterpret_cast<float*>(J.dst)[d] =
                     reinterpret_cast<const float*>(J.src)[sidx] + reinterpret_cast<const float*>(J.src2)[sidx];
+                break;
+            default: {
+                const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
+                const float v = reinterpret_cast<const float*>(J.src)[sidx] * keep;
+                if (J.elem == 2) reinterpret_cast<bf16_t*>(J.dst)[d] = f2bf(v);
+                else reinterpret_cast<float*>(J.dst)[d] = v;
+            }
         }
     }
 }
@@ -1588,18 +1596,18 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
 
 int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
                       const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
-                      const int64_t* src_stride, const int64_t* dst_stride, void* stream) {
+                      const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux, void* stream) {
     if (njobs <= 0 || njobs > VINE_COPY_MAX_JOBS || !op || !elem || !src || !src2 || !dst || !rows || !cols ||
-        !src_stride || !dst_stride)
+        !src_stride || !dst_stride || !aux)
         return VINE_ERR_INVALID_ARG;
     CopyBatchArgs b;
     int blocks = 0;
     for (int k = 0; k < njobs; ++k) {
-        if (op[k] < 0 || op[k] > 4 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
+        if (op[k] < 0 || op[k] > 5 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
             (op[k] == 4 && !src2[k]) || (elem[k] != 2 && elem[k] != 4))
             return VINE_ERR_INVALID_ARG;
         b.job[k] = CopyJob{src[k], src2[k], dst[k], (long long)rows[k], (long long)cols[k], (long long)src_stride[k],
-                           (long long)dst_stride[k], (int)op[k], (int)elem[k], blocks};
+                           (long long)dst_stride[k], (long long)aux[k], (int)op[k], (int)elem[k], blocks};
         blocks += (int)((rows[k] * cols[k] + 1023) / 1024);
     }
     b.njobs = njobs;

@@ -136,7 +136,30 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     return torch.stack(outs, 1).reshape(B * T, -1), h, c
 
 
-def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None):
+def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None):
+    """out / c_all / gates / hp of ``_lstm_forward_steps`` with the step-0 slots initialised (c_all[0] = c0,
+    hp[:, 0] = masked h0 in the operand dtype): through ``prep`` (a CopyBatch flushed by the caller) or directly."""
+    op = w_hh.dtype
+    BT, H = x.shape[0], w_hh.shape[1]
+    B = BT // T
+    dev = x.device
+    out = torch.empty((BT, H), device=dev, dtype=torch.float32)
+    c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
+    gates = torch.empty((T, B, 4 * H), device=dev, dtype=op) if need_grad else None     # backward-only: operand dtype
+    hp = torch.empty((B, T, H), device=dev, dtype=op)
+    if prep is not None:
+        prep.add(CopyBatch.COPY, c_all[0], c0)
+        prep.add(CopyBatch.MASKED, hp[:, 0], h0, dones, aux=T)
+    else:
+        c_all[0].copy_(c0)
+        if dones is not None:
+            hp[:, 0].copy_(h0 * (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)))
+        else:
+            hp[:, 0].copy_(h0)
+    return out, c_all, gates, hp
+
+
+def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
     hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
     ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32.
@@ -145,16 +168,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
     op = w_hh.dtype
     BT, H = x.shape[0], w_hh.shape[1]
     B = BT // T
-    dev = x.device
-    out = torch.empty((BT, H), device=dev, dtype=torch.float32)
-    c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
-    c_all[0].copy_(c0)
-    gates = torch.empty((T, B, 4 * H), device=dev, dtype=op) if need_grad else None     # backward-only: operand dtype
-    hp = torch.empty((B, T, H), device=dev, dtype=op)
-    if dones is not None:
-        hp[:, 0].copy_(h0 * (1.0 - dones.view(B, T)[:, 0:1].to(torch.float32)))
-    else:
-        hp[:, 0].copy_(h0)
+    out, c_all, gates, hp = buffers if buffers is not None else _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad)
     st = _stream(x)
     d_ptr = dones.data_ptr() if dones is not None else None
     w_hh_t = w_hh.t()
@@ -278,15 +292,23 @@ class ColumnSumBatch:
 class CopyBatch:
     """Collects small 2-D element moves (copy / zero / transpose / fp32->bf16 cast / fp32 add) and runs them in ONE
     launch (``vine_copy_batched``): the operand preparation of an optimiser step is a dozen such moves."""
-    COPY, ZERO, TRANSPOSE, CAST_BF16, ADD = 0, 1, 2, 3, 4
+    COPY, ZERO, TRANSPOSE, CAST_BF16, ADD, MASKED = 0, 1, 2, 3, 4, 5
 
     def __init__(self):
         self.jobs, self.keep = [], []
 
-    def add(self, op, dst, src=None, src2=None):
-        """dst: 2-D view with unit column stride (1-D tensors are taken as one row)."""
+    def add(self, op, dst, src=None, src2=None, aux=0):
+        """dst: 2-D view with unit column stride (1-D tensors are taken as one row).  MASKED: src2 = uint8 mask with
+        one entry per row, ``aux`` elements apart (None: plain copy/cast of an fp32 source)."""
         d2 = dst if dst.dim() == 2 else dst.view(1, -1)
         s2 = None if src is None else (src if src.dim() == 2 else src.view(1, -1))
+        if op == self.MASKED:
+            assert tuple(s2.shape) == tuple(d2.shape) and s2.dtype == torch.float32 and s2.stride(1) == 1 and d2.stride(1) == 1
+            assert src2 is None or src2.dtype == torch.uint8
+            self.keep.append((d2, s2, src2))
+            self.jobs.append((op, d2.element_size(), s2.data_ptr(), 0 if src2 is None else src2.data_ptr(), d2.data_ptr(),
+                              d2.shape[0], d2.shape[1], s2.stride(0), d2.stride(0), int(aux)))
+            return dst
         t2 = None if src2 is None else (src2 if src2.dim() == 2 else src2.view(1, -1))
         assert d2.stride(1) == 1 and (s2 is None or s2.stride(1) == 1) and (t2 is None or t2.stride(1) == 1)
         rows, cols = d2.shape
@@ -300,7 +322,7 @@ class CopyBatch:
             assert t2.stride(0) == s2.stride(0) and d2.dtype == torch.float32
         self.keep.append((d2, s2, t2))
         self.jobs.append((op, d2.element_size(), 0 if s2 is None else s2.data_ptr(), 0 if t2 is None else t2.data_ptr(),
-                          d2.data_ptr(), rows, cols, 0 if s2 is None else s2.stride(0), d2.stride(0)))
+                          d2.data_ptr(), rows, cols, 0 if s2 is None else s2.stride(0), d2.stride(0), 0))
         return dst
 
     def flush(self, ref):
@@ -314,7 +336,8 @@ class CopyBatch:
             i64 = lambda v: (C.c_int64 * n)(*v)
             ptr = lambda v: (C.c_void_p * n)(*v)
             _check(lib.vine_copy_batched(n, i32(cols[0]), i32(cols[1]), ptr(cols[2]), ptr(cols[3]), ptr(cols[4]),
-                                         i64(cols[5]), i64(cols[6]), i64(cols[7]), i64(cols[8]), st), "vine_copy_batched")
+                                         i64(cols[5]), i64(cols[6]), i64(cols[7]), i64(cols[8]), i64(cols[9]), st),
+                   "vine_copy_batched")
         self.jobs, self.keep = [], []
 
 
@@ -457,8 +480,10 @@ class _Trunk(torch.autograd.Function):
             prep.add(CopyBatch.COPY, b_heads[:A_], mu_b)
             prep.add(CopyBatch.COPY, b_heads[A_:], v_b)
             prep.add(CopyBatch.ADD, bias, b_ih, b_hh)
+            lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep)
             prep.flush(obs_n)
         else:
+            lstm_buffers = None
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
             torch.cat([mu_b, v_b], 0, out=b_heads)
@@ -491,10 +516,12 @@ class _Trunk(torch.autograd.Function):
             xcat[:, U:].copy_(obs_n)
         if no_proj:
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
-            out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat)
+            out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat,
+                                                        buffers=lstm_buffers)
         else:
             ig = _mm(xcat, w_ih_op.t())
-            out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True)
+            out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True,
+                                                        buffers=lstm_buffers)
             del ig
         # LayerNorm and the two heads stay in fp32 in both modes (3 output columns: nothing to gain, and mu feeds
         # the probability ratio directly)
