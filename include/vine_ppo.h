@@ -171,7 +171,10 @@ int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float
  * stats[8] = {mean a_loss, mean c_loss, mean b_loss, mean entropy, mean kl(old||new), loss, 0, 0}.
  * grad_logstd and stats are overwritten by the call.  Reductions are two-stage through `scratch`
  * (VINE_PPO_LOSS_SCRATCH_FLOATS floats, contents irrelevant): no float atomics, so gradients and statistics are
- * bit-reproducible.  Rows of mu / grad_mu are mu_stride floats apart and elements of
+ * bit-reproducible.  Optional extra outputs (all nullable) that save the update one small launch each: kl_out[1]
+ * receives the mean KL (the slot next to the gradients that rides in the all-reduce); logstd_grad_accum[A] gets
+ * grad_logstd ADDED (the log-sigma parameter's gradient slot); mu_store / sigma_store [n, A] receive the new mu and
+ * sigma of every sample (rl_games' dataset.update_mu_sigma; they may alias old_mu / old_sigma).  Rows of mu / grad_mu are mu_stride floats apart and elements of
  * value / grad_value value_stride apart (0 = packed: A and 1), so both heads can live in one [n, A+1] GEMM output.
  * grad_mu_bias [A] / grad_value_bias [1] (both or neither): the column sums of grad_mu / grad_value -- the gradients
  * of the two head biases -- are ADDED to them (the optimiser leaves its gradient block zeroed after every step). */
@@ -182,7 +185,8 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
-                  float* grad_value_bias, float* scratch, void* stream);
+                  float* grad_value_bias, float* scratch, float* kl_out, float* logstd_grad_accum, float* mu_store,
+                  float* sigma_store, void* stream);
 
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps

@@ -176,7 +176,7 @@ PPO_PROTOTYPES = {
                                     _VP]),
     "vine_bias_elu": (C.c_int, [_I64, _I64, _VP, _VP, C.c_float, _VP, _I64, C.c_int32, _VP]),
     "vine_ppo_loss": (C.c_int, [_I64, C.c_int32] + [_VP] * 10 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
-                                                                C.c_float] + [_VP] * 4 + [_I64, _I64, _VP, _VP, _VP, _VP]),
+                                                                C.c_float] + [_VP] * 4 + [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_copy_batched": (C.c_int, [C.c_int32] + [_VP] * 10 + [_VP]),
     "vine_column_sums_batched": (C.c_int, [C.c_int32] + [_VP] * 8 + [_VP]),
     "vine_column_sums": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_int32, _VP]),

@@ -979,7 +979,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        float soft_bound, float* __restrict__ grad_mu,
                                                        float* __restrict__ grad_value, float* __restrict__ grad_logstd,
                                                        float* __restrict__ stats, long long mu_stride,
-                                                       long long value_stride, float* __restrict__ partial) {
+                                                       long long value_stride, float* __restrict__ partial,
+                                                       float* __restrict__ mu_store, float* __restrict__ sigma_store) {
     // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
     // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
     const float inv_n = 1.0f / (float)n;
@@ -1042,6 +1043,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
             const float c1 = __logf(os / sg[k] + 1e-5f);
             const float c2 = (sg[k] * sg[k] + (om - m[k]) * (om - m[k])) / (2.0f * (os * os + 1e-5f));
             kl += c1 + c2 - 0.5f;
+            if (mu_store) {      // dataset.update_mu_sigma: may alias old_mu / old_sigma (read above by this thread)
+                mu_store[i * A + k] = m[k];
+                sigma_store[i * A + k] = sg[k];
+            }
         }
         acc[0] += a_loss; acc[1] += c_loss; acc[2] += b_loss; acc[3] += kl;
     }
@@ -1075,7 +1080,9 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(int blocks, int 
                                                                 float entropy_coef, float bounds_coef,
                                                                 float* __restrict__ stats, float* __restrict__ grad_logstd,
                                                                 float* __restrict__ grad_mu_bias,
-                                                                float* __restrict__ grad_value_bias) {
+                                                                float* __restrict__ grad_value_bias,
+                                                                float* __restrict__ kl_out,
+                                                                float* __restrict__ logstd_grad_accum) {
     const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
     float acc = 0.0f;
     for (int b = rl; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
@@ -1098,7 +1105,12 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(int blocks, int 
         stats[0] = a; stats[1] = c; stats[2] = b; stats[3] = ent; stats[4] = kl;
         stats[5] = a + 0.5f * critic_coef * c + bounds_coef * b - entropy_coef * ent;
         stats[6] = 0.0f; stats[7] = 0.0f;
-        for (int k = 0; k < A; ++k) grad_logstd[k] = tot[5 + k] - entropy_coef;
+        for (int k = 0; k < A; ++k) {
+            const float gl = tot[5 + k] - entropy_coef;
+            grad_logstd[k] = gl;
+            if (logstd_grad_accum) logstd_grad_accum[k] += gl;
+        }
+        if (kl_out) kl_out[0] = kl;
         if (grad_mu_bias) {
             for (int k = 0; k < A; ++k) grad_mu_bias[k] += tot[5 + PPO_MAX_A + k];
             grad_value_bias[0] += tot[5 + 2 * PPO_MAX_A];
@@ -1634,10 +1646,12 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   const float* old_mu, const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef,
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
-                  float* grad_value_bias, float* scratch, void* stream) {
+                  float* grad_value_bias, float* scratch, float* kl_out, float* logstd_grad_accum, float* mu_store,
+                  float* sigma_store, void* stream) {
     if (n <= 0 || A <= 0 || A > PPO_MAX_A || !mu || !logstd || !value || !actions || !old_neglogp || !advantages ||
         !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats ||
-        ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || !scratch)
+        ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || !scratch ||
+        ((mu_store == nullptr) != (sigma_store == nullptr)))
         return VINE_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int threads = 256;
@@ -1649,9 +1663,10 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats,
                        (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1),
-                       scratch);
+                       scratch, mu_store, sigma_store);
     hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, s, blocks, (int)A, (long long)n, scratch, logstd,
-                       critic_coef, entropy_coef, bounds_coef, stats, grad_logstd, grad_mu_bias, grad_value_bias);
+                       critic_coef, entropy_coef, bounds_coef, stats, grad_logstd, grad_mu_bias, grad_value_bias, kl_out,
+                       logstd_grad_accum);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -707,7 +707,7 @@ class A2CAgent:
     def _fused_grad_half(self, mb, obs_n=None):
         """Forward, ONE kernel for the whole PPO loss and its gradient w.r.t. the head outputs, hand-written backward
         into the flat gradient block; the minibatch KL is parked next to the gradients so that one all-reduce
-        averages both.  -> (stats[8], mu, sigma)"""
+        averages both.  -> (stats[8], mu, logstd)"""
         net = self.model.a2c_network
         hb = (net.mu.bias.grad, net.value.bias.grad)
         ext = all(g is not None and g.is_cuda for g in hb)     # head-bias gradients straight from the loss kernel
@@ -718,21 +718,21 @@ class A2CAgent:
         g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(
             mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
             mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef, self.entropy_coef,
-            self.bounds_loss_coef or 0.0, heads=heads, head_bias_grads=hb if (ext and heads is not None) else None)
+            self.bounds_loss_coef or 0.0, heads=heads, head_bias_grads=hb if (ext and heads is not None) else None,
+            # KL next to the gradients (it rides in the all-reduce), log-sigma gradient into its slot and the dataset's
+            # mu / sigma refreshed in place: all by the loss kernels themselves
+            kl_out=self.optimizer.aux[0:1], logstd_grad=net.sigma.grad, update_old=True)
         # the gradient block was left zeroed by the last Adam step
         if heads is not None:
             torch.autograd.backward([heads], [g_mu])            # g_mu is the [n, A+1] gradient of [mu | value]
         else:
             torch.autograd.backward([mu, value], [g_mu, g_val])
-        self.model.a2c_network.sigma.grad.add_(g_ls)
-        self.optimizer.aux[0:1].copy_(stats[4:5])              # KL rides in the gradient all-reduce
-        mu_d = mu.detach()
-        sigma_d = torch.exp(logstd.detach()).expand_as(mu_d)
-        return stats, mu_d, sigma_d
+        return stats, mu.detach(), logstd.detach()
 
     def calc_gradients_fused(self, mb):
         """GPU path (fp32 or bf16-operand GEMMs): same arithmetic as ``calc_gradients``."""
-        stats, mu_d, sigma_d = self._fused_grad_half(mb)
+        stats, mu_d, logstd_d = self._fused_grad_half(mb)
+        sigma_d = torch.exp(logstd_d).expand_as(mu_d)
         kl = stats[4]
         if self.multi_gpu and not self.use_grad_scaler:
             self._kl_in_comm = True
@@ -896,17 +896,15 @@ class A2CAgent:
         pool = None if os.environ.get("VINE_UPD_POOL") == "separate" else self._upd_pool
         with torch.cuda.graph(gA, pool=pool, capture_error_mode="thread_local"):
             mb = self.get_minibatch(i)
-            stats, mu_d, sigma_d = self._fused_grad_half(mb)
+            stats, mu_d, _logstd_d = self._fused_grad_half(mb)
         with torch.cuda.graph(gB, pool=pool, capture_error_mode="thread_local"):
             self.optimizer.step(grad_scale=1.0 / self.rank_size)
-            start, end = mb["range"]
-            self.dataset["mu"][start:end] = mu_d
-            self.dataset["sigma"][start:end] = sigma_d
+            # (the dataset's mu / sigma slices were refreshed by the loss kernel in graph A)
             kl = self.optimizer.aux[0]                          # sum over ranks after the all-reduce
             self._kl_in_comm = True
             self.update_lr_from_kl(kl)
             row = torch.stack([stats[0], stats[1], stats[3], kl / self.rank_size, stats[2]])
-        rec = {"A": gA, "B": gB, "row": row, "keep": (mb, stats, mu_d, sigma_d)}
+        rec = {"A": gA, "B": gB, "row": row, "keep": (mb, stats, mu_d)}
         self._upd_graphs[key] = rec
         return rec
 

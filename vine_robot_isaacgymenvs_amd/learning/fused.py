@@ -727,16 +727,25 @@ def ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values,
 
 
 def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip,
-                   clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None, head_bias_grads=None):
+                   clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None, head_bias_grads=None,
+                   kl_out=None, logstd_grad=None, update_old=False):
     """One HIP kernel: returns (grad_mu [n,A], grad_value [n,1], grad_logstd [A], stats[8]) where the gradients are
     d(loss)/d(.) of the same scalar loss as ``ppo_loss_reference``.  With ``heads`` ([n, A+1] = [mu | value], the
     output of the fused trunk) mu/value are read from it in place and the first return value is the matching
     [n, A+1] gradient (second is None).  ``head_bias_grads`` = (mu.bias.grad, value.bias.grad): the kernel adds the
-    column sums of the head gradients to them (they must hold zeros, as the optimiser leaves them)."""
+    column sums of the head gradients to them (they must hold zeros, as the optimiser leaves them).
+    ``kl_out`` (1 float) receives the mean KL, ``logstd_grad`` ([A]) gets the log-sigma gradient added, ``update_old``
+    writes the new mu / sigma of every sample over ``old_mu`` / ``old_sigma`` (dataset.update_mu_sigma) -- each saves
+    the update a small launch."""
     lib = _lib()
     stats_dev = (heads if heads is not None else mu).device
     args = [t.detach().contiguous() for t in (actions, old_neglogp, adv, old_values.reshape(-1), returns.reshape(-1),
                                               old_mu, old_sigma)]
+    if update_old:
+        assert args[5].data_ptr() == old_mu.data_ptr() and args[6].data_ptr() == old_sigma.data_ptr(), \
+            "update_old needs contiguous old_mu / old_sigma (they are written in place)"
+    extra = (kl_out.data_ptr() if kl_out is not None else None, logstd_grad.data_ptr() if logstd_grad is not None else None,
+             args[5].data_ptr() if update_old else None, args[6].data_ptr() if update_old else None)
     ls = logstd.detach().contiguous()
     A = ls.shape[0]
     grad_logstd = torch.empty(A, device=stats_dev, dtype=torch.float32)
@@ -753,7 +762,7 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
         _check(lib.vine_ppo_loss(n, A, hd.data_ptr(), ls.data_ptr(), hd.data_ptr() + 4 * A, *[a.data_ptr() for a in args],
                                  *scal, g.data_ptr(), g.data_ptr() + 4 * A, grad_logstd.data_ptr(), stats.data_ptr(),
                                  A + 1, A + 1, head_bias_grads[0].data_ptr() if head_bias_grads else None,
-                                 head_bias_grads[1].data_ptr() if head_bias_grads else None, scratch.data_ptr(),
+                                 head_bias_grads[1].data_ptr() if head_bias_grads else None, scratch.data_ptr(), *extra,
                                  _stream(hd)),
                "vine_ppo_loss")
         return g, None, grad_logstd, stats
@@ -764,5 +773,6 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     grad_value = torch.empty_like(val_c)
     _check(lib.vine_ppo_loss(n, A, mu_c.data_ptr(), ls.data_ptr(), val_c.data_ptr(), *[a.data_ptr() for a in args],
                              *scal, grad_mu.data_ptr(), grad_value.data_ptr(), grad_logstd.data_ptr(),
-                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), _stream(mu)), "vine_ppo_loss")
+                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), *extra, _stream(mu)),
+           "vine_ppo_loss")
     return grad_mu, grad_value.view_as(value), grad_logstd, stats
