@@ -819,13 +819,14 @@ class A2CAgent:
             self.optimizer.refresh_shadow()
         self.curr_frames = batch.pop("played_frames")
         self.prepare_dataset(batch)
-        # loss statistics of every optimiser step: rows of [a_loss, c_loss, entropy, kl, b_loss] on the device
+        # loss statistics of every optimiser step on the device, in the layout of the loss kernel's statistics:
+        # rows of [a_loss, c_loss, b_loss, entropy, kl, (loss, 0, 0)]
         n_steps = self.mini_epochs_num * self.num_minibatches
         if getattr(self, "_stat_rows", None) is None or self._stat_rows.shape[0] != n_steps:
-            self._stat_rows = torch.zeros((n_steps, 5), device=self.device, dtype=torch.float32)
+            self._stat_rows = torch.zeros((n_steps, 8), device=self.device, dtype=torch.float32)
         rows = self._stat_rows
         graphed = self._update_graphs_usable()
-        kl_global = graphed and self.multi_gpu       # rows hold the all-rank mean KL (it rode in the all-reduce)
+        kl_global = False
         for mini_ep in range(self.mini_epochs_num):
             for i in range(self.num_minibatches):
                 row = mini_ep * self.num_minibatches + i
@@ -838,11 +839,11 @@ class A2CAgent:
                 self.dataset["sigma"][start:end] = csigma.float()
                 in_comm = getattr(self, "_kl_in_comm", False)
                 kl_global = kl_global or in_comm
-                rows[row].copy_(torch.stack([a_loss, c_loss, entropy, kl / self.rank_size if in_comm else kl, b_loss]))
+                rows[row, :5].copy_(torch.stack([a_loss, c_loss, b_loss, entropy, kl / self.rank_size if in_comm else kl]))
                 if self.is_adaptive_lr and self.schedule_type == "legacy":
                     self.update_lr_from_kl(kl)
             if self.is_adaptive_lr and self.schedule_type == "standard":
-                ep = rows[mini_ep * self.num_minibatches:(mini_ep + 1) * self.num_minibatches, 3].mean()
+                ep = rows[mini_ep * self.num_minibatches:(mini_ep + 1) * self.num_minibatches, 4].mean()
                 self._kl_in_comm = kl_global
                 self.update_lr_from_kl(ep * self.rank_size if kl_global else ep)
             if self.normalize_input:
@@ -851,7 +852,7 @@ class A2CAgent:
             torch.cuda.synchronize(self.device)
         update_time = time.time() - t_upd
         m = rows.mean(0)
-        stats = {"a_loss": m[0], "c_loss": m[1], "entropy": m[2], "kl": m[3], "b_loss": m[4]}
+        stats = {"a_loss": m[0], "c_loss": m[1], "entropy": m[3], "kl": m[4], "b_loss": m[2]}
         return play_time, update_time, stats
 
     # ------------------------------------------------------------------ update as hipGraphs
@@ -884,7 +885,7 @@ class A2CAgent:
         if self.multi_gpu:
             dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)      # gradients + KL, RCCL over xGMI
         rec["B"].replay()
-        row_out.copy_(rec["row"])
+        row_out.copy_(rec["stats"])   # this rank's [a_loss, c_loss, b_loss, entropy, kl, loss, 0, 0]
         return True
 
     def _capture_update_step(self, i, key):
@@ -903,8 +904,7 @@ class A2CAgent:
             kl = self.optimizer.aux[0]                          # sum over ranks after the all-reduce
             self._kl_in_comm = True
             self.update_lr_from_kl(kl)
-            row = torch.stack([stats[0], stats[1], stats[3], kl / self.rank_size, stats[2]])
-        rec = {"A": gA, "B": gB, "row": row, "keep": (mb, stats, mu_d)}
+        rec = {"A": gA, "B": gB, "stats": stats, "keep": (mb, stats, mu_d)}
         self._upd_graphs[key] = rec
         return rec
 
