@@ -600,21 +600,25 @@ __global__ void gae_kernel(int T, long long N, const float* __restrict__ rewards
 //   finalize: batch mean / unbiased variance from the partials (fixed order), merged into the running moments
 __global__ __launch_bounds__(256) void rms_partial_kernel(long long n, int F, const float* __restrict__ x,
                                                           double* __restrict__ partial) {
-    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    // 256 / F row lanes x F columns (252 of 256 lanes busy at F = 28); consecutive lanes read consecutive floats
+    const int rlanes = 256 / F;
+    const int rl = threadIdx.x / F, c = threadIdx.x - rl * F;
     double s = 0.0, ss = 0.0;
-    if (c < F)
-        for (long long r = (long long)blockIdx.x * 4 + rl; r < n; r += (long long)gridDim.x * 4) {
+    if (rl < rlanes)
+        for (long long r = (long long)blockIdx.x * rlanes + rl; r < n; r += (long long)gridDim.x * rlanes) {
             const double v = (double)x[r * F + c];
             s += v;
             ss += v * v;
         }
-    __shared__ double red[2][4][64];
-    red[0][rl][c] = s;
-    red[1][rl][c] = ss;
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = rl < rlanes ? s : 0.0;
+    red[1][threadIdx.x] = rl < rlanes ? ss : 0.0;
     __syncthreads();
-    if (rl == 0 && c < F) {
-        partial[(long long)blockIdx.x * 2 * F + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-        partial[(long long)blockIdx.x * 2 * F + F + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    if ((int)threadIdx.x < F) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < rlanes; ++k) { a += red[0][k * F + threadIdx.x]; b += red[1][k * F + threadIdx.x]; }
+        partial[(long long)blockIdx.x * 2 * F + threadIdx.x] = a;
+        partial[(long long)blockIdx.x * 2 * F + F + threadIdx.x] = b;
     }
 }
 
@@ -933,13 +937,16 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
     const CopyJob& J = batch.job[j];
     const long long total = J.rows * J.cols;
     const long long base = ((long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x) * 4;
+    if (base >= total) return;
+    // (row, column) of the first of this thread's 4 consecutive elements, then carried along: one division per thread
+    long long r = base / J.cols;
+    int c = (int)(base - r * J.cols);
+    const int cols = (int)J.cols;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const long long e = base + q;
-        if (e >= total) break;
-        const long long r = e / J.cols, c = e - r * J.cols;
+        if (base + q >= total) break;
         const long long d = r * J.dst_stride + c;
-        const long long sidx = (J.op == 2) ? c * J.src_stride + r : r * J.src_stride + c;
+        const long long sidx = (J.op == 2) ? (long long)c * J.src_stride + r : r * J.src_stride + c;
         switch (J.op) {
             case 0:
             case 2:
@@ -964,6 +971,7 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
                 else reinterpret_cast<float*>(J.dst)[d] = v;
             }
         }
+        if (++c == cols) { c = 0; ++r; }
     }
 }
 

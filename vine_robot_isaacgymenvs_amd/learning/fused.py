@@ -379,6 +379,7 @@ class _LSTMSeq(torch.autograd.Function):
         hT = out3[:, T - 1].contiguous()
         cT = c_all[T].clone()
         ctx.mark_non_differentiable(hT, cT)
+        ctx.set_materialize_grads(False)
         return out, hT, cT
 
     @staticmethod
@@ -553,6 +554,7 @@ class _Trunk(torch.autograd.Function):
         hT = out.view(B, T, H)[:, T - 1]
         cT = c_all[T]
         ctx.mark_non_differentiable(hT, cT)
+        ctx.set_materialize_grads(False)       # no zero-filled [B, H] gradients for the two state outputs
         return heads, hT, cT
 
     @staticmethod
