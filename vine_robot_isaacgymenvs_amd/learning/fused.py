@@ -47,12 +47,14 @@ def _mm(a, b):
 
 
 # --------------------------------------------------------------------------- split-K weight gradient
+import os as _os
+SPLITK_ROWS = int(_os.environ.get("VINE_SPLITK_ROWS", "1024"))      # rows of the reduction per slice (experiments)
 def splitk_tn(dy, x, out=None, batch=None):
     """``dy^T @ x`` for tall-skinny operands: dy [K, M], x [K, N] -> [M, N] (written into ``out`` when given).
     ``batch``: defer the sum over the slices to a ``ColumnSumBatch`` (the result exists after its ``flush``)."""
     K = dy.shape[0]
     s = 1
-    while K % (s * 2) == 0 and K // (s * 2) >= 1024 and s < 64:
+    while K % (s * 2) == 0 and K // (s * 2) >= SPLITK_ROWS and s < 64:
         s *= 2
     if s == 1 or not dy.is_cuda:
         if dy.dtype == torch.bfloat16:
@@ -71,7 +73,7 @@ def _splitk_parts(dy, x):
     """The slices of ``splitk_tn`` before their sum: (s, part [s, M, N]) or (1, dy^T x [M, N])."""
     K = dy.shape[0]
     s = 1
-    while K % (s * 2) == 0 and K // (s * 2) >= 1024 and s < 64:
+    while K % (s * 2) == 0 and K // (s * 2) >= SPLITK_ROWS and s < 64:
         s *= 2
     if s == 1 or not dy.is_cuda:
         return 1, dy.t().mm(x)
