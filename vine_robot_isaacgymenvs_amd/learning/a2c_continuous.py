@@ -361,6 +361,11 @@ class A2CAgent:
              "y": torch.empty((N, H), device=dev), "h_tmp": torch.empty((N, H), device=dev),
              "c_tmp": torch.empty((N, H), device=dev)}
         f["x0_sep"] = None if net.rnn_concat_input else torch.empty((N, F_in), device=dev, dtype=op)
+        # padded layer-1 weight [units, 32] for the matrix-core kernel (mixed precision, concatenated input)
+        f["w1p"] = None
+        if (self.fused_mixed and net.rnn_concat_input and XW - U == 32
+                and fused.linear_elu_mfma_ok(N, net.units[0], 32)):
+            f["w1p"] = torch.zeros((net.units[0], 32), device=dev, dtype=op)
         self._fast = f
 
     def _infer_begin(self):
@@ -371,6 +376,10 @@ class A2CAgent:
         f["wcat"][:, :r.weight_ih_l0.shape[1]].copy_(src(r.weight_ih_l0))
         f["wcat"][:, f["XW"]:].copy_(src(r.weight_hh_l0))
         f["mlp"] = [(src(m.weight), m.bias) for m in net.actor_mlp if isinstance(m, torch.nn.Linear)]
+        # layer 1 through the matrix-core kernel too: operand = the obs block of xh plus the zero columns behind it
+        if f["w1p"] is not None:                      # pad columns stay zero (allocated outside any capture)
+            w1 = f["mlp"][0][0]
+            f["w1p"][:, :w1.shape[1]].copy_(w1)
         f["bias"] = r.bias_ih_l0 + r.bias_hh_l0
         f["cur"] = 0
         f["xh2"][0][:, f["XW"]:].copy_(self.rnn_states[0][0])
@@ -395,7 +404,11 @@ class A2CAgent:
         n_mlp = len(f["mlp"])
         for i, (W, b) in enumerate(f["mlp"]):
             out = xh if i == n_mlp - 1 else f["acts"][i]
-            if bf and fused.linear_elu_mfma_ok(N, W.shape[0], W.shape[1]):
+            if i == 0 and f["w1p"] is not None:
+                fused._check(lib.vine_linear_elu_mfma(N, W.shape[0], 32, xh.data_ptr() + 2 * f["U"], xh.stride(0),
+                                                      f["w1p"].data_ptr(), 32, b.data_ptr(), 1.0, out.data_ptr(),
+                                                      out.stride(0), st), "vine_linear_elu_mfma")
+            elif bf and fused.linear_elu_mfma_ok(N, W.shape[0], W.shape[1]):
                 fused._check(lib.vine_linear_elu_mfma(N, W.shape[0], W.shape[1], x.data_ptr(), x.stride(0), W.data_ptr(),
                                                       W.stride(0), b.data_ptr(), 1.0, out.data_ptr(), out.stride(0), st),
                              "vine_linear_elu_mfma")

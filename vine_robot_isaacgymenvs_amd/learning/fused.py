@@ -461,13 +461,22 @@ class _Trunk(torch.autograd.Function):
             # observations (layer-1 operand and the LSTM operand's obs block), zero pad columns, [w_ih | 0 | w_hh],
             # transposed MLP weights for the backward kernels, merged head weights, b_ih + b_hh
             obs_c = obs_n.contiguous()
-            x0 = torch.empty((n, F_in), device=dev, dtype=op)
             prep = CopyBatch()
-            prep.add(CopyBatch.CAST_BF16, x0, obs_c)
+            # layer 1 on the matrix cores too: its operand is the observation block of the LSTM operand buffer plus
+            # the zero pad columns behind it (K = 32), its weight is padded to match
+            l1_mfma = concat and wpad - U == 32 and linear_elu_mfma_ok(n, Wop[0].shape[0], 32)
             if concat:
                 prep.add(CopyBatch.CAST_BF16, xfull[:, U:width], obs_c)
             if wpad > width:
                 prep.add(CopyBatch.ZERO, xfull[:, width:])
+            if l1_mfma:
+                x0 = xfull[:, U:width]                        # strided view; also the operand of layer 1's weight gradient
+                w1p = torch.empty((Wop[0].shape[0], 32), device=dev, dtype=op)
+                prep.add(CopyBatch.COPY, w1p[:, :F_in], Wop[0])
+                prep.add(CopyBatch.ZERO, w1p[:, F_in:])
+            else:
+                x0 = torch.empty((n, F_in), device=dev, dtype=op)
+                prep.add(CopyBatch.CAST_BF16, x0, obs_c)
             if no_proj:
                 wcat = torch.empty((4 * H, wpad + H), device=dev, dtype=op)
                 prep.add(CopyBatch.COPY, wcat[:, :width], w_ih_op)
@@ -487,6 +496,7 @@ class _Trunk(torch.autograd.Function):
             prep.flush(obs_n)
         else:
             lstm_buffers = None
+            l1_mfma = False
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
             torch.cat([mu_b, v_b], 0, out=b_heads)
@@ -498,7 +508,11 @@ class _Trunk(torch.autograd.Function):
             if mixed:
                 C_, K_ = Wop[i].shape
                 a = xcat if last else torch.empty((n, C_), device=dev, dtype=op)
-                if linear_elu_mfma_ok(n, C_, K_):      # GEMM + bias + ELU in one matrix-core kernel
+                if i == 0 and l1_mfma:
+                    _check(lib.vine_linear_elu_mfma(n, C_, 32, xfull.data_ptr() + 2 * U, xfull.stride(0), w1p.data_ptr(), 32,
+                                                    b.data_ptr(), 1.0, a.data_ptr(), a.stride(0), st),
+                           "vine_linear_elu_mfma")
+                elif linear_elu_mfma_ok(n, C_, K_):      # GEMM + bias + ELU in one matrix-core kernel
                     _check(lib.vine_linear_elu_mfma(n, C_, K_, x.data_ptr(), x.stride(0), Wop[i].data_ptr(),
                                                     Wop[i].stride(0), b.data_ptr(), 1.0, a.data_ptr(), a.stride(0), st),
                            "vine_linear_elu_mfma")
