@@ -5,6 +5,57 @@ import time
 import torch
 
 
+def ppo_kernel_rooflines(device, B=8192, T=4, H=256, XW=96):
+    """Stand-alone HIP-event timings of the two largest hand-written kernels of the mixed-precision update at its
+    shapes (one LSTM time step of a 32768-sample minibatch), priced against HBM with their algorithmic bytes:
+      lstm_step_mfma (forward step, GEMM fused): reads x_t bf16 [B,XW] + h_{t-1} bf16 [B,H] + c fp32 [B,H],
+          writes h, c fp32, masked h bf16, 4 gate activations bf16                     -> B*(2*XW + 2*H + 4*H*3 + 2*H + 8*H) bytes
+      lstm_bwd (backward step): reads dh, g_rec, dc fp32, gates bf16 [B,4H], c_t, c_{t-1} fp32; writes dG bf16, dc fp32."""
+    from . import fused
+    from ..abi import PPO_PARTIAL_BLOCKS
+    lib = fused._lib()
+    st = torch.cuda.current_stream(device).cuda_stream
+    bf = torch.bfloat16
+    x = torch.randn(B * T, XW, device=device).to(bf)
+    hp = torch.randn(B, T, H, device=device).to(bf)
+    wcat = (torch.randn(4 * H, XW + H, device=device) / 16).to(bf)
+    whh = (torch.randn(4 * H, H, device=device) / 16).to(bf)
+    bias = torch.zeros(4 * H, device=device)
+    c = torch.randn(T + 1, B, H, device=device)
+    out = torch.empty(B, T, H, device=device)
+    gates = torch.empty(T, B, 4 * H, device=device, dtype=bf)
+    g_out, g_rec = torch.randn(B, T, H, device=device), torch.randn(B, H, device=device)
+    dc = [torch.randn(B, H, device=device) for _ in range(2)]
+    dG = torch.empty(B, T, 4 * H, device=device, dtype=bf)
+    part = torch.empty(2, PPO_PARTIAL_BLOCKS, 4 * H, device=device)
+
+    def fwd():
+        assert lib.vine_lstm_step_mfma(B, H, XW + H, x.data_ptr(), T * XW, hp.data_ptr(), T * H, XW, wcat.data_ptr(), XW + H,
+                                       None, 4 * H, bias.data_ptr(), c[0].data_ptr(), None, 0, out.data_ptr(), T * H,
+                                       c[1].data_ptr(), gates[0].data_ptr(), hp.data_ptr() + 2 * H, None, 0, T * H, st) == 0
+
+    def bwd():
+        assert lib.vine_lstm_cell_backward(B, H, g_out.data_ptr(), T * H, g_rec.data_ptr(), dc[0].data_ptr(), None, 0,
+                                           gates[0].data_ptr(), c[1].data_ptr(), c[0].data_ptr(), None, 0, dG.data_ptr(),
+                                           T * 4 * H, dc[1].data_ptr(), part[0].data_ptr(), part[1].data_ptr(), 1, st) == 0
+
+    res = []
+    for name, f, nbytes in (("lstm_step_mfma_kernel", fwd, B * (2 * XW + 2 * H + 4 * H + 8 * H + 2 * H + 8 * H)),
+                            ("lstm_bwd_kernel", bwd, B * (3 * 4 * H + 8 * H + 8 * H + 8 * H + 4 * H))):
+        for _ in range(10):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            f()
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 10.0
+        res.append({"kernel": name, "us": us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": nbytes / us / 1e3,
+                    "hbm_frac": nbytes / us / 1e3 / 8000.0, "launches_per_ppo_iteration": 128})
+    return res
+
+
 def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     from .a2c_continuous import A2CAgent
 
@@ -109,8 +160,15 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         other = {"update_precision": "bf16 GEMM operands, f32 accumulate/state" if agent2.fused_mixed else "f32",
                  "value": frames * steps / e2, "unit": "env-steps/s", "ppo_iters_per_sec": steps / e2,
                  "rollout_ms": p2 / steps * 1e3, "update_ms": u2 / steps * 1e3}
+    ppo_kernels = None
+    if world == 1 and agent.fused_mixed and not getattr(args, "no_secondary", False):
+        try:
+            ppo_kernels = ppo_kernel_rooflines(agent.device)
+        except (AssertionError, RuntimeError) as err:
+            ppo_kernels = "unavailable: %s" % str(err)[:100]
     extra = {
         "update_precision": precision,
+        "ppo_kernel_rooflines": ppo_kernels,
         "other_precision": other,
         "replicas_in_sync": in_sync,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
