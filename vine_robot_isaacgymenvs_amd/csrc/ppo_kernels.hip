@@ -122,7 +122,8 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
 // 33 KB at K = 256: 4 workgroups per CU); the A fragments (16 B per lane and k-step) come straight from global memory.
 // Measured at B = 8192, K = 256: 33 us against 16 us (hipBLASLt GEMM) + 24 us (pointwise kernel) unfused.  Two
 // re-tilings were tried and rejected: 32 units per workgroup with the whole slab in LDS (68 KB, 2 workgroups per CU:
-// 46 us) and 32 units with W streamed through LDS in double-buffered 64-wide k chunks (36 KB: 52 us).
+// 46 us), 32 units with W streamed through LDS in double-buffered 64-wide k chunks (36 KB: 52 us), and keeping the
+// slab while one workgroup walks over several 64-row blocks (fewer, longer workgroups: 37 us at K = 352).
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 #define LSTM_MFMA_MAX_K 512
