@@ -65,7 +65,8 @@ int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t
  *   gz = (G Wt^T) * elu'(a)   with G [n, K] bf16 (gradient w.r.t. this layer's pre-activation), Wt [N, K] bf16 = the
  *   layer's weight TRANSPOSED (N = its input width), a [n, N] bf16 = the previous layer's ELU output, gz [n, N] bf16;
  * partial (nullable, [n / 64, N] fp32): per-workgroup column sums of gz = partial bias gradient of the previous layer.
- * Needs n % 64 == 0, N % 64 == 0, K in {64, 128, 256}; otherwise VINE_ERR_UNSUPPORTED (GEMM + vine_elu_backward). */
+ * Needs n % 64 == 0, N % 64 == 0, K in {64, 128, 256} (weight slab resident in LDS) or {512, 1024} (both operands
+ * streamed in 128-wide k chunks); otherwise VINE_ERR_UNSUPPORTED (GEMM + vine_elu_backward). */
 int vine_linear_bwd_elu_mfma(int64_t n, int64_t N, int64_t K, const void* G, int64_t ldg, const void* Wt, int64_t ldw,
                              const void* a, int64_t a_stride, float alpha, void* gz, int64_t gz_stride, float* partial,
                              void* stream);
@@ -150,7 +151,7 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
                              const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
                              const int32_t* dup, void* stream);
 
-/* Up to 16 small 2-D element moves in one launch (arrays of length njobs in host memory): dst[r, c] for r < rows,
+/* Up to 24 small 2-D element moves in one launch (arrays of length njobs in host memory): dst[r, c] for r < rows,
  * c < cols, rows of dst / src dst_stride / src_stride ELEMENTS apart.  op: 0 copy, 1 zero, 2 transpose (dst[r, c] =
  * src[c, r]), 3 float32 -> bfloat16, 4 dst = src + src2 (float32), 5 dst = src * (1 - mask[r * aux]) with src float32,
  * mask = src2 (uint8, nullable) and dst float32 or bfloat16.  elem: element size of dst in bytes (2 or 4).

@@ -263,7 +263,7 @@ def test_linear_elu_mfma_matches_gemm_plus_bias_elu(n, K, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,K,N", [(32768, 128, 256), (16384, 64, 128), (64, 256, 64)])
+@pytest.mark.parametrize("n,K,N", [(32768, 128, 256), (16384, 64, 128), (64, 256, 64), (32768, 1024, 64), (128, 512, 128)])
 def test_linear_bwd_elu_mfma_matches_gemm_plus_elu_backward(n, K, N):
     """gz = (G W) * elu'(a) and its per-workgroup column sums on the matrix cores against GEMM + vine_elu_backward."""
     from vine_robot_isaacgymenvs_amd.abi import PPO_PARTIAL_BLOCKS
@@ -288,6 +288,27 @@ def test_linear_bwd_elu_mfma_matches_gemm_plus_elu_backward(n, K, N):
     assert float((gz.float() - ref.float()).abs().max()) < 1e-2 * scale
     s1, s2 = part.sum(0), rpart.sum(0)
     assert float((s1 - s2).abs().max()) < 1e-3 * (float(s2.abs().max()) + 1e-12) + 1e-7
+    if n >= 16384:
+        def fusedk():
+            lib.vine_linear_bwd_elu_mfma(n, N, K, G.data_ptr(), K, wt.data_ptr(), K, a.data_ptr(), a.stride(0), 1.0,
+                                         gz.data_ptr(), N, part.data_ptr(), st)
+
+        def unfused():
+            g2 = torch.mm(G, W, out_dtype=torch.float32)
+            lib.vine_elu_backward(n, N, g2.data_ptr(), N, a.data_ptr(), a.stride(0), 1.0, ref.data_ptr(), N, rpart.data_ptr(),
+                                  1, 1, st)
+        times = []
+        for f in (fusedk, unfused):
+            for _ in range(5):
+                f()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(50):
+                f()
+            e.record()
+            torch.cuda.synchronize()
+            times.append(s.elapsed_time(e) * 20)
+        print("linear_bwd_elu n=%d K=%d N=%d: fused %.1f us, gemm+elu_bwd %.1f us" % (n, K, N, times[0], times[1]))
 
 
 @pytest.mark.gpu

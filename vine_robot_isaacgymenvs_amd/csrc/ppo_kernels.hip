@@ -371,6 +371,101 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, i
     }
 }
 
+// ---- the same backward product for a LONG reduction (K = 128 * NCH, e.g. the 1024 gate columns of the LSTM): both
+// operands stream in 128-wide k chunks, the weight chunk double-buffered through LDS (2 x 17 KB), the G fragments
+// double-buffered in registers; one barrier per chunk.  Everything is written out unrolled (no index arrays in
+// scratch).  N = 64 output units per workgroup; with N == 64 every G row is read exactly once from HBM.
+template <int NCH>
+__global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
+    long long n, int N, const bf16_t* __restrict__ G, long long ldg, const bf16_t* __restrict__ Wt, long long ldw,
+    const bf16_t* __restrict__ a, long long a_stride, float alpha, bf16_t* __restrict__ gz, long long gz_stride,
+    float* __restrict__ partial) {
+    constexpr int CK = 128;                                    // k per chunk = 4 MFMA k-steps
+    constexpr int PITCH = CK + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t wl[2][64 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * 64;
+    const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
+    // this thread's 4 weight pieces of a chunk: piece p = tid + 256 q -> row p >> 4, 16-B column p & 15
+    const int prow[4] = {(int)threadIdx.x >> 4, ((int)threadIdx.x + 256) >> 4, ((int)threadIdx.x + 512) >> 4,
+                         ((int)threadIdx.x + 768) >> 4};
+    const int pcol = threadIdx.x & 15;
+    uint4 w0, w1, w2, w3;
+    bf16x8_t g0, g1, g2, g3, h0, h1, h2, h3;
+#define LOAD_W(c)                                                                                              \
+    w0 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[0]) * ldw + (c) * CK + pcol * 8);          \
+    w1 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[1]) * ldw + (c) * CK + pcol * 8);          \
+    w2 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[2]) * ldw + (c) * CK + pcol * 8);          \
+    w3 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[3]) * ldw + (c) * CK + pcol * 8)
+#define STORE_W(buf)                                                                                           \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[0] * PITCH + pcol * 8]) = w0;                                      \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[1] * PITCH + pcol * 8]) = w1;                                      \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                                      \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
+#define LOAD_G(c, x0, x1, x2, x3)                                                                              \
+    x0 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK);                                                  \
+    x1 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 32);                                             \
+    x2 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 64);                                             \
+    x3 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 96)
+    LOAD_W(0);
+    LOAD_G(0, g0, g1, g2, g3);
+    float4 av[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) av[t] = ld4(a + b * a_stride + u0 + 16 * t + 4 * (lane >> 4));
+    STORE_W(0);
+    __syncthreads();
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) {
+            LOAD_W(c + 1);
+            LOAD_G(c + 1, h0, h1, h2, h3);
+        }
+        const bf16_t* wb = wl[c & 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16_t* wr = wb + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr), g0, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32), g1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 64), g2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 96), g3, acc[t], 0, 0, 0);
+        }
+        if (c + 1 < NCH) {
+            STORE_W((c + 1) & 1);                              // buffer (c+1)&1 was last read before the previous barrier
+            g0 = h0; g1 = h1; g2 = h2; g3 = h3;
+        }
+        __syncthreads();
+    }
+#undef LOAD_W
+#undef STORE_W
+#undef LOAD_G
+    float d[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float aa[4] = {av[t].x, av[t].y, av[t].z, av[t].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[t][u] = acc[t][u] * (aa[u] > 0.0f ? 1.0f : aa[u] + alpha);
+        st4(gz + b * gz_stride + u0 + 16 * t + 4 * (lane >> 4), make_float4(d[t][0], d[t][1], d[t][2], d[t][3]));
+    }
+    if (partial) {
+        float* red = reinterpret_cast<float*>(&wl[0][0]);      // 64 x 65 floats = 16.6 KB <= one weight buffer (17.4 KB)
+        const int r = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) red[r * 65 + 16 * t + 4 * (lane >> 4) + u] = d[t][u];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float sum = 0.0f;
+            for (int rr = 0; rr < 64; ++rr) sum += red[rr * 65 + threadIdx.x];
+            partial[(long long)blockIdx.x * N + u0 + threadIdx.x] = sum;
+        }
+    }
+}
+
 template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
@@ -925,7 +1020,7 @@ struct CopyJob {
     long long rows, cols, src_stride, dst_stride, aux;
     int op, elem, first_block;
 };
-#define VINE_COPY_MAX_JOBS 16
+#define VINE_COPY_MAX_JOBS 24
 struct CopyBatchArgs {
     CopyJob job[VINE_COPY_MAX_JOBS];
     int njobs;
@@ -1429,8 +1524,20 @@ int vine_linear_bwd_elu_mfma(int64_t n, int64_t N, int64_t K, const void* G, int
                              void* stream) {
     if (n <= 0 || N <= 0 || K <= 0 || !G || !Wt || !a || !gz || (ldg & 7) || (ldw & 7) || (a_stride & 3) || (gz_stride & 3))
         return VINE_ERR_INVALID_ARG;
-    if ((n & 63) || (N & 63) || (K != 64 && K != 128 && K != 256)) return VINE_ERR_UNSUPPORTED;
+    if ((n & 63) || (N & 63) || (K != 64 && K != 128 && K != 256 && K != 512 && K != 1024)) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(n / 64), (unsigned)(N / 64)), block(256);
+    if (K >= 512) {          // long reduction: both operands stream in 128-wide k chunks
+        hipStream_t s2 = (hipStream_t)stream;
+        if (K == 512)
+            hipLaunchKernelGGL(linear_bwd_elu_mfma_chunked_kernel<4>, grid, block, 0, s2, (long long)n, (int)N,
+                               (const bf16_t*)G, (long long)ldg, (const bf16_t*)Wt, (long long)ldw, (const bf16_t*)a,
+                               (long long)a_stride, alpha, (bf16_t*)gz, (long long)gz_stride, partial);
+        else
+            hipLaunchKernelGGL(linear_bwd_elu_mfma_chunked_kernel<8>, grid, block, 0, s2, (long long)n, (int)N,
+                               (const bf16_t*)G, (long long)ldg, (const bf16_t*)Wt, (long long)ldw, (const bf16_t*)a,
+                               (long long)a_stride, alpha, (bf16_t*)gz, (long long)gz_stride, partial);
+        return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    }
     size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);
     if (lds < 64 * 65 * sizeof(float)) lds = 64 * 65 * sizeof(float);       // the column-sum stage reuses the slab
     hipStream_t s = (hipStream_t)stream;

@@ -330,8 +330,8 @@ class CopyBatch:
     def flush(self, ref):
         import ctypes as C
         lib, st = _lib(), _stream(ref)
-        for k in range(0, len(self.jobs), 16):
-            js = self.jobs[k:k + 16]
+        for k in range(0, len(self.jobs), 24):
+            js = self.jobs[k:k + 24]
             n = len(js)
             cols = list(zip(*js))
             i32 = lambda v: (C.c_int32 * n)(*v)
@@ -487,6 +487,10 @@ class _Trunk(torch.autograd.Function):
                 if linear_bwd_mfma_ok(n, Wop[i].shape[1], Wop[i].shape[0]):
                     wts[i] = torch.empty((Wop[i].shape[1], Wop[i].shape[0]), device=dev, dtype=op)
                     prep.add(CopyBatch.TRANSPOSE, wts[i], Wop[i])
+            # transposed MLP block of w_ih: the LSTM's input gradient and the last ELU's backward are one kernel
+            if n % 64 == 0 and U % 64 == 0 and 4 * H in (512, 1024):
+                wts[0] = torch.empty((U, 4 * H), device=dev, dtype=op)
+                prep.add(CopyBatch.TRANSPOSE, wts[0], w_ih_op[:, :U])
             prep.add(CopyBatch.COPY, w_heads[:A_], mu_w)
             prep.add(CopyBatch.COPY, w_heads[A_:], v_w)
             prep.add(CopyBatch.COPY, b_heads[:A_], mu_b)
@@ -645,12 +649,21 @@ class _Trunk(torch.autograd.Function):
         else:
             deliver(base + 2, lambda o: _sum_rows(bias_partial, dG.float(), out=o))
             deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
-        g = _mm(dG, w_ih[:, :U] if concat else w_ih)        # only the MLP columns of the LSTM input need a gradient
+        gz = part = g = None
+        if mixed and ctx.wts[0] is not None:
+            # LSTM input gradient (MLP columns only) x ELU' of the last MLP layer + its bias partial sums: one
+            # matrix-core kernel streaming the 4H-long reduction in k chunks
+            gz = torch.empty((n, U), device=dev, dtype=torch.bfloat16)
+            part = torch.empty((n // 64, U), device=dev, dtype=torch.float32)
+            _check(lib.vine_linear_bwd_elu_mfma(n, U, 4 * H, dG.data_ptr(), dG.stride(0), ctx.wts[0].data_ptr(),
+                                                ctx.wts[0].stride(0), xcat.data_ptr(), xcat.stride(0), 1.0,
+                                                gz.data_ptr(), U, part.data_ptr(), st), "vine_linear_bwd_elu_mfma")
+        else:
+            g = _mm(dG, w_ih[:, :U] if concat else w_ih)    # only the MLP columns of the LSTM input need a gradient
         del dG
         # ---- MLP, last layer first: ELU' from the stored OUTPUT, bias gradient from the kernels' partial sums.
         # gz = gradient w.r.t. layer i's pre-activation.  In mixed precision the step from layer i to layer i-1
         # (input-gradient GEMM + ELU backward + bias partial sums) is one matrix-core kernel.
-        gz = part = None
         for i in reversed(range(n_mlp)):
             if gz is None:
                 a = xcat if i == n_mlp - 1 else acts[i]
