@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/vine.h"
 #include "../../include/vine_ppo.h"
@@ -124,6 +125,8 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
 // re-tilings were tried and rejected: 32 units per workgroup with the whole slab in LDS (68 KB, 2 workgroups per CU:
 // 46 us), 32 units with W streamed through LDS in double-buffered 64-wide k chunks (36 KB: 52 us), and keeping the
 // slab while one workgroup walks over several 64-row blocks (fewer, longer workgroups: 37 us at K = 352).
+// What did pay for the K = 352 [x | h] shapes: lstm_step_mfma64_kernel below (64 units per workgroup, the A fragments
+// are re-read 4 instead of 16 times, W streamed one 32-wide k-step at a time): 28.9 us against 32.3 us.
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
 #define LSTM_MFMA_MAX_K 512
@@ -224,6 +227,120 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
         st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
         st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
         st4(ga + 3 * H + j, make_float4(go[0], go[1], go[2], go[3]));
+    }
+}
+
+// ---- the same LSTM step with 64 hidden units per workgroup and the weights STREAMED through LDS: chunk = one MFMA
+// k-step (32 k) of the 4 x 64 weight rows (20 KB), double-buffered, one barrier per chunk, everything unrolled.
+// Against the resident-slab kernel above this re-reads every A row 4 times instead of 16 and touches 256 contiguous
+// bytes per row and array instead of 64.
+template <int KSTEPS, int KS1>
+__global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
+    long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ A2, long long lda2,
+    const bf16_t* __restrict__ W, long long ldw, const float* __restrict__ igates, long long ig_stride,
+    const float* __restrict__ bias, const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
+    long long done_stride, float* __restrict__ h_out, long long h_stride, float* __restrict__ c_out,
+    bf16_t* __restrict__ gates_act, bf16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
+    long long done_next_stride, long long hp_stride) {
+    constexpr int PITCH = 32 + 8;                              // 80 B rows: 16 fragment rows x 16 B tile the banks
+    __shared__ __attribute__((aligned(16))) bf16_t wl[2][256 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * 64;
+    const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    // A fragments, all k-steps up front
+    bf16x8_t af[KSTEPS];
+    const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
+    const bf16_t* arow2 = KS1 < KSTEPS && KS1 > 0 ? A2 + b * lda2 + 8 * (lane >> 4) : arow;
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk)
+        af[kk] = (KS1 == 0 || kk < KS1) ? *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk)
+                                        : *reinterpret_cast<const bf16x8_t*>(arow2 + 32 * (kk - KS1));
+    // weight chunk kk: LDS row g*64 + i <- W[g*H + u0 + i][32 kk : 32 kk + 32]; 1024 16-B pieces, 4 per thread
+    // (piece p = tid + 256 q: row p >> 2, 16-B column p & 3)
+    const int pcol = threadIdx.x & 3;
+    int prow[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        prow[q] = ((int)threadIdx.x + 256 * q) >> 2;
+        const int g = prow[q] >> 6, i = prow[q] & 63;
+        wsrc[q] = W + (long long)(g * H + u0 + i) * ldw + pcol * 8;
+    }
+    uint4 w0, w1, w2, w3;
+#define LOAD_W(kk)                                                         \
+    w0 = *reinterpret_cast<const uint4*>(wsrc[0] + 32 * (kk));             \
+    w1 = *reinterpret_cast<const uint4*>(wsrc[1] + 32 * (kk));             \
+    w2 = *reinterpret_cast<const uint4*>(wsrc[2] + 32 * (kk));             \
+    w3 = *reinterpret_cast<const uint4*>(wsrc[3] + 32 * (kk))
+#define STORE_W(buf)                                                                        \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[0] * PITCH + pcol * 8]) = w0;                   \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[1] * PITCH + pcol * 8]) = w1;                   \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                   \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
+    LOAD_W(0);
+    const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+    const float kn = (hp_next && done_next) ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+    STORE_W(0);
+    __syncthreads();
+    f32x4_t acc[4][4];                                         // [gate][unit tile]
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[g][t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        if (kk + 1 < KSTEPS) { LOAD_W(kk + 1); }
+        const bf16_t* wb = wl[kk & 1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(
+                    wb + (g * 64 + t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4));
+                acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[g][t], 0, 0, 0);
+            }
+        if (kk + 1 < KSTEPS) { STORE_W((kk + 1) & 1); }
+        __syncthreads();
+    }
+#undef LOAD_W
+#undef STORE_W
+    // epilogue, one 16-unit tile at a time: this lane owns batch row b, hidden units j .. j+3 of the tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = u0 + 16 * t + 4 * (lane >> 4);
+        float pre[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bb = ld4(bias + g * H + j);
+            pre[g][0] = acc[g][t][0] + bb.x; pre[g][1] = acc[g][t][1] + bb.y;
+            pre[g][2] = acc[g][t][2] + bb.z; pre[g][3] = acc[g][t][3] + bb.w;
+            if (igates) {
+                const float4 a = ld4(igates + b * ig_stride + g * H + j);
+                pre[g][0] += a.x; pre[g][1] += a.y; pre[g][2] += a.z; pre[g][3] += a.w;
+            }
+        }
+        const float4 cp = ld4(c_prev + b * H + j);
+        const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
+        float gi[4], gf[4], gg[4], go[4], cn[4], hn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gi[u] = sigmoidf_(pre[0][u]);
+            gf[u] = sigmoidf_(pre[1][u]);
+            gg[u] = tanhf_(pre[2][u]);
+            go[u] = sigmoidf_(pre[3][u]);
+            cn[u] = gf[u] * (keep * cpv[u]) + gi[u] * gg[u];
+            hn[u] = go[u] * tanhf_(cn[u]);
+        }
+        st4(c_out + b * H + j, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        if (hp_next) st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
+        if (gates_act) {
+            bf16_t* ga = gates_act + b * 4LL * H;
+            st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
+            st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
+            st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
+            st4(ga + 3 * H + j, make_float4(go[0], go[1], go[2], go[3]));
+        }
     }
 }
 
@@ -1471,6 +1588,22 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
                            (long long)done_next_stride, (long long)hp_stride);                                          \
     } while (0)
     const int ks = (int)(K / 32), ks1 = (int)(K1 / 32);
+    static const bool use64 = getenv("VINE_LSTM_MFMA_SLAB") == nullptr;       // resident-slab kernel for A/B runs
+    // (measured at B = 8192: K = 352 two-source 28.9 us streamed vs 32.3 us slab; K = 256 + igates 35.5 vs 29.8: the
+    //  streamed kernel only takes the K = 352 shapes the update and the rollout actually use)
+    if (use64 && (H & 63) == 0 && ks == 11 && (ks1 == 0 || ks1 == 3)) {
+        const dim3 grid64((unsigned)(B / 64), (unsigned)(H / 64));
+#define VINE_LSTM_MFMA64(KS, KS1)                                                                                       \
+        hipLaunchKernelGGL((lstm_step_mfma64_kernel<KS, KS1>), grid64, block, 0, s, (long long)B, (int)H,               \
+                           (const bf16_t*)A, (long long)lda, (const bf16_t*)A2, (long long)lda2, (const bf16_t*)W,      \
+                           (long long)ldw, igates, (long long)ig_stride, bias, c_prev, done, (long long)done_stride,    \
+                           h_out, (long long)h_stride, c_out, (bf16_t*)gates_act, (bf16_t*)hp_next, done_next,          \
+                           (long long)done_next_stride, (long long)hp_stride)
+        if (ks1 == 0) VINE_LSTM_MFMA64(11, 0);
+        else VINE_LSTM_MFMA64(11, 3);
+#undef VINE_LSTM_MFMA64
+        return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    }
     if (ks1 == 0) {
         switch (ks) {
             case 4: VINE_LSTM_MFMA(4, 0); break;
