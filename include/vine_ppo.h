@@ -89,6 +89,20 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
                             int64_t done_stride, void* dgates, int64_t dg_stride, float* dc_prev,
                             float* bias_partial, const float* bias_partial_prev, int32_t dgates_bf16, void* stream);
 
+/* The same backward step with the recurrent input gradient computed inside (mixed precision only):
+ *   g_rec[b] = dgates_next[b, :] (bf16, rows dgn_stride apart: the gate gradients the call for step t+1 wrote) times
+ *              w_hh, given TRANSPOSED as w_hh_t [H, 4H] bf16 (rows ldw apart),
+ * on the matrix cores, then exactly the arithmetic above; gates_act / dgates are bfloat16.  dgates_next == w_hh_t ==
+ * NULL at the last time step.  bias_partial / bias_partial_prev: [B / 64, 4H] rows, chained as above.
+ * Requires B % 64 == 0 and H in {128, 256}; VINE_ERR_UNSUPPORTED otherwise (callers then use the two-launch form:
+ * GEMM + vine_lstm_cell_backward). */
+int vine_lstm_step_backward_mfma(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const void* dgates_next,
+                                 int64_t dgn_stride, const void* w_hh_t, int64_t ldw, const float* dc_next,
+                                 const uint8_t* done_next, int64_t done_next_stride, const void* gates_act,
+                                 const float* c_new, const float* c_prev, const uint8_t* done, int64_t done_stride,
+                                 void* dgates, int64_t dg_stride, float* dc_prev, float* bias_partial,
+                                 const float* bias_partial_prev, void* stream);
+
 /* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
  * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.
  * forward: y = (x - mean) * rstd * gamma + beta; mean/rstd [n] (both nullable) are kept for the backward pass.

@@ -195,6 +195,51 @@ def test_lstm_step_mfma_matches_gemm_plus_pointwise(B, K, with_ig):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,use_dones", [(8192, 256, True), (128, 256, False), (64, 128, True)])
+def test_lstm_backward_mfma_matches_gemm_plus_pointwise(B, H, use_dones):
+    """The backward LSTM step with the recurrent input gradient formed on the matrix cores inside the kernel against
+    the two launches it replaces (bf16 GEMM dG_{t+1} w_hh + vine_lstm_cell_backward), over a whole 4-step sequence:
+    gate gradients (bf16), the final cell gradient chain and the chained bias partial sums."""
+    import time
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    lib = fused._lib()
+    T = 4
+    bf = torch.bfloat16
+    w_hh = (torch.randn(4 * H, H, device=dev) / H ** 0.5).to(bf)
+    g_out = torch.randn(B * T, H, device=dev) * 0.1
+    c_all = torch.randn(T + 1, B, H, device=dev)
+    gates = torch.rand(T, B, 4 * H, device=dev)
+    gates[:, :, 2 * H:3 * H] = gates[:, :, 2 * H:3 * H] * 2 - 1                # the tanh gate
+    gates = gates.to(bf)
+    dones = (torch.rand(B * T, device=dev) < 0.2).to(torch.uint8) if use_dones else None
+    dG_a, part_a = fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T)
+    dG_b, part_b = fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=w_hh.t().contiguous())
+    torch.cuda.synchronize()
+    a, b = dG_a.float(), dG_b.float()
+    # same products, different summation order inside the recurrent term, results rounded to bf16
+    assert float((a - b).abs().max()) <= 1e-2 * float(a.abs().max()), float((a - b).abs().max())
+    assert float((a - b).abs().mean()) <= 2e-4 * float(a.abs().mean()) + 1e-9
+    sa, sb = part_a.sum(0), part_b.sum(0)
+    assert float((sa - sb).abs().max()) <= 2e-3 * float(sa.abs().max()), float((sa - sb).abs().max())
+    if B == 8192:
+        wt = w_hh.t().contiguous()
+        for name, kw in (("gemm + pointwise", {}), ("fused mfma", {"w_hh_t": wt})):
+            for _ in range(3):
+                fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, **kw)
+            torch.cuda.synchronize()
+            print("lstm backward, 4 steps, %s: %.1f us per step" % (name, (time.perf_counter() - t0) / 80 * 1e6))
+    assert lib.vine_lstm_step_backward_mfma(B + 1, H, g_out.data_ptr(), T * H, None, 0, None, 0, None, None, 0,
+                                            gates.data_ptr(), c_all[1].data_ptr(), c_all[0].data_ptr(), None, 0,
+                                            dG_b.data_ptr(), T * 4 * H, c_all[2].data_ptr(), None, None,
+                                            torch.cuda.current_stream().cuda_stream) == -2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("F_", [28, 18, 1])
 def test_running_mean_std_kernels_match_torch_composition(F_):
     """vine_rms_update + vine_normalize_obs (float64 statistics, two-stage sums) against the module's torch path."""

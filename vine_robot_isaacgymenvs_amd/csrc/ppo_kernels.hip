@@ -666,6 +666,156 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
     }
 }
 
+// ---- LSTM step backward with the recurrent input gradient fused in (mixed precision): g_rec = dG_{t+1} W_hh is
+// produced on the matrix cores exactly as in linear_bwd_elu_mfma_chunked_kernel (64 rows x 64 hidden units per
+// workgroup, the 4H-long reduction streamed in 128-k chunks), handed over through LDS, and the pointwise backward of
+// lstm_bwd_kernel runs on it with whole 256-B row segments per 16 lanes: g_rec never reaches HBM and the separate
+// [B, 4H] x [4H, H] GEMM launch disappears.  NCH = 0: the last time step (no recurrent gradient).
+// bias_partial: [B / 64, 4H] rows, chained over the time steps like lstm_bwd_kernel's.
+template <int NCH>
+__global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
+    long long B, int H, const float* __restrict__ g_out, long long g_stride, const bf16_t* __restrict__ G, long long ldg,
+    const bf16_t* __restrict__ Wt, long long ldw, const float* __restrict__ dc_next,
+    const unsigned char* __restrict__ done_next, long long done_next_stride, const bf16_t* __restrict__ gates_act,
+    const float* __restrict__ c_new, const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
+    long long done_stride, bf16_t* __restrict__ dgates, long long dg_stride, float* __restrict__ dc_prev,
+    float* __restrict__ bias_partial, const float* __restrict__ bias_partial_prev) {
+    constexpr int CK = 128;
+    constexpr int PITCH = CK + 8;
+    constexpr int GP = 68;                                     // floats per row of the g_rec hand-over tile
+    __shared__ __attribute__((aligned(16))) bf16_t wl[2][64 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.y * 64;
+    float* gt = reinterpret_cast<float*>(&wl[0][0]);           // 64 x 68 floats == one weight buffer
+    if (NCH > 0) {
+        const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
+        const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
+        const int prow[4] = {(int)threadIdx.x >> 4, ((int)threadIdx.x + 256) >> 4, ((int)threadIdx.x + 512) >> 4,
+                             ((int)threadIdx.x + 768) >> 4};
+        const int pcol = threadIdx.x & 15;
+        uint4 w0, w1, w2, w3;
+        bf16x8_t g0, g1, g2, g3, h0, h1, h2, h3;
+#define LOAD_W(c)                                                                                              \
+    w0 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[0]) * ldw + (c) * CK + pcol * 8);          \
+    w1 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[1]) * ldw + (c) * CK + pcol * 8);          \
+    w2 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[2]) * ldw + (c) * CK + pcol * 8);          \
+    w3 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[3]) * ldw + (c) * CK + pcol * 8)
+#define STORE_W(buf)                                                                                           \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[0] * PITCH + pcol * 8]) = w0;                                      \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[1] * PITCH + pcol * 8]) = w1;                                      \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                                      \
+    *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
+#define LOAD_G(c, x0, x1, x2, x3)                                                                              \
+    x0 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK);                                                  \
+    x1 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 32);                                             \
+    x2 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 64);                                             \
+    x3 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 96)
+        LOAD_W(0);
+        LOAD_G(0, g0, g1, g2, g3);
+        STORE_W(0);
+        __syncthreads();
+        f32x4_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) {
+                LOAD_W(c + 1);
+                LOAD_G(c + 1, h0, h1, h2, h3);
+            }
+            const bf16_t* wb = wl[c & 1];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bf16_t* wr = wb + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr), g0, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32), g1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 64), g2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 96), g3, acc[t], 0, 0, 0);
+            }
+            if (c + 1 < NCH) {
+                STORE_W((c + 1) & 1);
+                g0 = h0; g1 = h1; g2 = h2; g3 = h3;
+            }
+            __syncthreads();
+        }
+#undef LOAD_W
+#undef STORE_W
+#undef LOAD_G
+        // accumulators -> [row][unit] tile (a lane holds 4 consecutive units of one row per 16-unit tile)
+        const int r = wave * 16 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<float4*>(&gt[r * GP + 16 * t + 4 * (lane >> 4)]) =
+                make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        __syncthreads();
+    }
+    // ---- pointwise backward: thread -> unit quad q of rows rg, rg + 16, rg + 32, rg + 48
+    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = u0 + 4 * q;
+    float bsum[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bsum[u] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = rg + 16 * p;
+        const long long b = (long long)blockIdx.x * 64 + r;
+        const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+        const float keep_n = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+        const float4 go4 = ld4(g_out + b * g_stride + j);
+        float dh[4] = {go4.x, go4.y, go4.z, go4.w};
+        float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (NCH > 0) {
+            const float4 rr = *reinterpret_cast<const float4*>(&gt[r * GP + 4 * q]);
+            dh[0] += keep_n * rr.x; dh[1] += keep_n * rr.y; dh[2] += keep_n * rr.z; dh[3] += keep_n * rr.w;
+        }
+        if (dc_next) {
+            const float4 rr = ld4(dc_next + b * H + j);
+            dc[0] = keep_n * rr.x; dc[1] = keep_n * rr.y; dc[2] = keep_n * rr.z; dc[3] = keep_n * rr.w;
+        }
+        const bf16_t* ga = gates_act + b * 4LL * H;
+        const float4 i4 = ld4(ga + j), f4 = ld4(ga + H + j), g4 = ld4(ga + 2 * H + j), o4 = ld4(ga + 3 * H + j);
+        const float4 cn4 = ld4(c_new + b * H + j), cp4 = ld4(c_prev + b * H + j);
+        const float gi[4] = {i4.x, i4.y, i4.z, i4.w}, gf[4] = {f4.x, f4.y, f4.z, f4.w};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, go[4] = {o4.x, o4.y, o4.z, o4.w};
+        const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+        float di[4], df[4], dg[4], dout[4], dcp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float tc = tanhf_(cn[u]);
+            const float d_o = dh[u] * tc;
+            const float d_c = dc[u] + dh[u] * go[u] * (1.0f - tc * tc);
+            di[u] = d_c * gg[u] * gi[u] * (1.0f - gi[u]);
+            df[u] = d_c * (keep * cp[u]) * gf[u] * (1.0f - gf[u]);
+            dg[u] = d_c * gi[u] * (1.0f - gg[u] * gg[u]);
+            dout[u] = d_o * go[u] * (1.0f - go[u]);
+            dcp[u] = d_c * gf[u];
+        }
+        bf16_t* dgp = dgates + b * dg_stride;
+        st4(dgp + 0 * H + j, make_float4(di[0], di[1], di[2], di[3]));
+        st4(dgp + 1 * H + j, make_float4(df[0], df[1], df[2], df[3]));
+        st4(dgp + 2 * H + j, make_float4(dg[0], dg[1], dg[2], dg[3]));
+        st4(dgp + 3 * H + j, make_float4(dout[0], dout[1], dout[2], dout[3]));
+        st4(dc_prev + b * H + j, make_float4(dcp[0], dcp[1], dcp[2], dcp[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bsum[u] += di[u]; bsum[4 + u] += df[u]; bsum[8 + u] += dg[u]; bsum[12 + u] += dout[u];
+        }
+    }
+    if (bias_partial) {
+        // 16 row groups x (16 quads x 16 values): fold the row groups through LDS in a fixed order
+        float* red = reinterpret_cast<float*>(&wl[1][0]);      // 16 x 256 floats = 16 KB <= one weight buffer
+#pragma unroll
+        for (int u = 0; u < 16; ++u) red[rg * 256 + u * 16 + q] = bsum[u];
+        __syncthreads();
+        const int u = threadIdx.x >> 4, qq = threadIdx.x & 15;              // value u = 4 gate + unit of quad qq
+        const long long col = (long long)(u >> 2) * H + u0 + 4 * qq + (u & 3);
+        float sum = bias_partial_prev ? bias_partial_prev[(long long)blockIdx.x * 4 * H + col] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) sum += red[g * 256 + threadIdx.x];
+        bias_partial[(long long)blockIdx.x * 4 * H + col] = sum;
+    }
+}
+
 // ---- LayerNorm over rows of H = 256 * NV floats: one wave per row, lane l owns columns [256 v + 4 l, +4) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -1712,6 +1862,32 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
                            (const float*)gates_act, c_new, c_prev, done, (long long)done_stride, (float*)dgates,
                            (long long)dg_stride,
                            dc_prev, bias_partial, bias_partial_prev);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_step_backward_mfma(int64_t B, int64_t H, const float* g_out, int64_t g_stride, const void* dgates_next,
+                                 int64_t dgn_stride, const void* w_hh_t, int64_t ldw, const float* dc_next,
+                                 const uint8_t* done_next, int64_t done_next_stride, const void* gates_act,
+                                 const float* c_new, const float* c_prev, const uint8_t* done, int64_t done_stride,
+                                 void* dgates, int64_t dg_stride, float* dc_prev, float* bias_partial,
+                                 const float* bias_partial_prev, void* stream) {
+    if (B <= 0 || H <= 0 || !g_out || !gates_act || !c_new || !c_prev || !dgates || !dc_prev ||
+        (dgates_next != nullptr) != (w_hh_t != nullptr))
+        return VINE_ERR_INVALID_ARG;
+    if ((B & 63) || (H != 128 && H != 256) || (g_stride & 3) || (dg_stride & 3)) return VINE_ERR_UNSUPPORTED;
+    if (dgates_next && ((dgn_stride & 7) || (ldw & 7) || ldw < 4 * H)) return VINE_ERR_INVALID_ARG;
+    const dim3 grid((unsigned)(B / 64), (unsigned)(H / 64));
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_LSTM_BWD_MFMA(NCH)                                                                                        \
+    hipLaunchKernelGGL(lstm_bwd_mfma_kernel<NCH>, grid, dim3(256), 0, s, (long long)B, (int)H, g_out,                  \
+                       (long long)g_stride, (const bf16_t*)dgates_next, (long long)dgn_stride, (const bf16_t*)w_hh_t,  \
+                       (long long)ldw, dc_next, done_next, (long long)done_next_stride, (const bf16_t*)gates_act,      \
+                       c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates, (long long)dg_stride, dc_prev,    \
+                       bias_partial, bias_partial_prev)
+    if (!dgates_next) VINE_LSTM_BWD_MFMA(0);
+    else if (H == 256) VINE_LSTM_BWD_MFMA(8);
+    else VINE_LSTM_BWD_MFMA(4);
+#undef VINE_LSTM_BWD_MFMA
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

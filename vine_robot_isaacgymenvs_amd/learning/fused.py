@@ -209,9 +209,16 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
     return out, c_all, gates, hp
 
 
-def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
+def lstm_bwd_mfma_ok(B, H):
+    """Shapes vine_lstm_step_backward_mfma covers."""
+    return B % 64 == 0 and H in (128, 256)
+
+
+def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None):
     """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials.
-    dG is only ever a GEMM operand: it is stored in ``w_hh``'s dtype (bfloat16 in the mixed-precision update)."""
+    dG is only ever a GEMM operand: it is stored in ``w_hh``'s dtype (bfloat16 in the mixed-precision update).
+    ``w_hh_t`` ([H, 4H] bf16, the transposed recurrent weight): every step is ONE matrix-core kernel that forms the
+    recurrent input gradient dG_{t+1} w_hh itself (vine_lstm_step_backward_mfma)."""
     from ..abi import PPO_PARTIAL_BLOCKS
     B, H = c_all.shape[1], c_all.shape[2]
     dev = g_out.device
@@ -219,6 +226,23 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T):
     dG = torch.empty((B * T, 4 * H), device=dev, dtype=w_hh.dtype)
     dG3 = dG.view(B, T, 4 * H)
     dc = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
+    if w_hh_t is not None:
+        assert dG.dtype == torch.bfloat16 and lstm_bwd_mfma_ok(B, H)
+        bias_partial = torch.empty((2, B // 64, 4 * H), device=dev, dtype=torch.float32)
+        st = _stream(g_out)
+        d_ptr = dones.data_ptr() if dones is not None else None
+        for t in reversed(range(T)):
+            last = t == T - 1
+            _check(lib.vine_lstm_step_backward_mfma(
+                B, H, g_out.data_ptr() + 4 * (t * H), T * H,
+                None if last else dG.data_ptr() + 2 * ((t + 1) * 4 * H), T * 4 * H,
+                None if last else w_hh_t.data_ptr(), w_hh_t.stride(0),
+                None if last else dc[(t + 1) & 1].data_ptr(),
+                (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, gates[t].data_ptr(),
+                c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
+                dG.data_ptr() + 2 * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(), bias_partial[t & 1].data_ptr(),
+                None if last else bias_partial[(t + 1) & 1].data_ptr(), st), "vine_lstm_step_backward_mfma")
+        return dG, bias_partial[0]
     use_partial = H <= 1024 and 256 % (H // 4) == 0
     # one [PPO_PARTIAL_BLOCKS, 4H] block per step, chained: step t adds the rows of step t+1, the last one (t = 0)
     # holds the partial sums of the whole sequence
@@ -455,7 +479,7 @@ class _Trunk(torch.autograd.Function):
         b_heads = torch.empty(A_ + v_w.shape[0], device=dev, dtype=torch.float32)
         bias = torch.empty(4 * H, device=dev, dtype=torch.float32)
         no_proj = mixed and B % 64 == 0 and H == 256 and wpad % 32 == 0 and wpad <= 128
-        wcat, wts = None, [None] * n_mlp
+        wcat, wts, w_hh_t = None, [None] * n_mlp, None
         if mixed:
             # every operand derived from the parameters or the observations, in ONE launch: bf16 cast of the
             # observations (layer-1 operand and the LSTM operand's obs block), zero pad columns, [w_ih | 0 | w_hh],
@@ -491,6 +515,10 @@ class _Trunk(torch.autograd.Function):
             if n % 64 == 0 and U % 64 == 0 and 4 * H in (512, 1024):
                 wts[0] = torch.empty((U, 4 * H), device=dev, dtype=op)
                 prep.add(CopyBatch.TRANSPOSE, wts[0], w_ih_op[:, :U])
+            # transposed recurrent weight: the backward step forms dG_{t+1} w_hh inside its own kernel
+            if lstm_bwd_mfma_ok(B, H):
+                w_hh_t = torch.empty((H, 4 * H), device=dev, dtype=op)
+                prep.add(CopyBatch.TRANSPOSE, w_hh_t, w_hh_op)
             prep.add(CopyBatch.COPY, w_heads[:A_], mu_w)
             prep.add(CopyBatch.COPY, w_heads[A_:], v_w)
             prep.add(CopyBatch.COPY, b_heads[:A_], mu_b)
@@ -568,6 +596,7 @@ class _Trunk(torch.autograd.Function):
         ctx.pshapes = [tuple(p.shape) if isinstance(p, torch.Tensor) else None for p in params]
         ctx.fuse_heads = fuse_heads
         ctx.wts = wts
+        ctx.w_hh_t = w_hh_t
         ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g, ln_b,
                               dones if dones is not None else obs_n.new_empty(0), *acts, *Wop)
         # final LSTM state as views (no copies): the update discards it, other callers may clone
@@ -641,7 +670,8 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 4, lambda o: column_sums(ln_part[:, :H], o))
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
         # ---- LSTM
-        dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T)
+        dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
+                                                w_hh_t=ctx.w_hh_t)
         deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o, batch=batch))
         deliver(base + 1, lambda o: splitk_tn(dG, hp.view(n, H), out=o, batch=batch))
         if bias_partial is not None and slots[base + 2] is not None and slots[base + 3] is not None:
