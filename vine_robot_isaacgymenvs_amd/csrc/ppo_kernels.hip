@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
 
 // ---- the same LSTM step with 64 hidden units per workgroup and the weights STREAMED through LDS: chunk = one MFMA
 // k-step (32 k) of the 4 x 64 weight rows (20 KB), double-buffered, one barrier per chunk, everything unrolled.
-// Against the resident-slab kernel above this re-reads every A row 4 times instead of 16 and touches 256 contiguous
-// bytes per row and array instead of 64.
+// Against the resident-slab kernel above this re-reads every A row 4 times instead of 16, and its epilogue goes
+// through LDS so that 16 lanes cover one row's 64 units: 256 contiguous bytes per row and array instead of 64.
 template <int KSTEPS, int KS1>
 __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ A2, long long lda2,
@@ -243,7 +243,11 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     bf16_t* __restrict__ gates_act, bf16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
     long long done_next_stride, long long hp_stride) {
     constexpr int PITCH = 32 + 8;                              // 80 B rows: 16 fragment rows x 16 B tile the banks
-    __shared__ __attribute__((aligned(16))) bf16_t wl[2][256 * PITCH];
+    constexpr int GP = 4 * 64 + 4;                             // floats per row of the pre-activation hand-over tile
+    // one LDS block: the two weight buffers (2 x 20 KB) during the product, the [64][GP] fp32 tile (65 KB) after it
+    __shared__ __attribute__((aligned(16))) float smem[64 * GP];
+    bf16_t (*wl)[256 * PITCH] = reinterpret_cast<bf16_t (*)[256 * PITCH]>(smem);
+    float* gt = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
@@ -278,8 +282,6 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                   \
     *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
     LOAD_W(0);
-    const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
-    const float kn = (hp_next && done_next) ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
     STORE_W(0);
     __syncthreads();
     f32x4_t acc[4][4];                                         // [gate][unit tile]
@@ -304,19 +306,40 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     }
 #undef LOAD_W
 #undef STORE_W
-    // epilogue, one 16-unit tile at a time: this lane owns batch row b, hidden units j .. j+3 of the tile
+    // hand-over through LDS: accumulators -> [row][gate][unit] tile, then the pointwise part runs with 16 lanes per
+    // row (whole 256-B fp32 / 128-B bf16 row segments per array) instead of 64-B pieces of 16 different rows
+    {
+        const int r = wave * 16 + (lane & 15);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int j = u0 + 16 * t + 4 * (lane >> 4);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                *reinterpret_cast<float4*>(&gt[r * GP + g * 64 + 16 * t + 4 * (lane >> 4)]) =
+                    make_float4(acc[g][t][0], acc[g][t][1], acc[g][t][2], acc[g][t][3]);
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = u0 + 4 * q;
+    float bv[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 bb = ld4(bias + g * H + j);
+        bv[g][0] = bb.x; bv[g][1] = bb.y; bv[g][2] = bb.z; bv[g][3] = bb.w;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = rg + 16 * p;
+        const long long b = (long long)blockIdx.x * 64 + r;
+        const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
+        const float kn = (hp_next && done_next) ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
         float pre[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 bb = ld4(bias + g * H + j);
-            pre[g][0] = acc[g][t][0] + bb.x; pre[g][1] = acc[g][t][1] + bb.y;
-            pre[g][2] = acc[g][t][2] + bb.z; pre[g][3] = acc[g][t][3] + bb.w;
+            const float4 a = *reinterpret_cast<const float4*>(&gt[r * GP + g * 64 + 4 * q]);
+            pre[g][0] = a.x + bv[g][0]; pre[g][1] = a.y + bv[g][1]; pre[g][2] = a.z + bv[g][2]; pre[g][3] = a.w + bv[g][3];
             if (igates) {
-                const float4 a = ld4(igates + b * ig_stride + g * H + j);
-                pre[g][0] += a.x; pre[g][1] += a.y; pre[g][2] += a.z; pre[g][3] += a.w;
+                const float4 ig = ld4(igates + b * ig_stride + g * H + j);
+                pre[g][0] += ig.x; pre[g][1] += ig.y; pre[g][2] += ig.z; pre[g][3] += ig.w;
             }
         }
         const float4 cp = ld4(c_prev + b * H + j);
