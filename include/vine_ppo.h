@@ -103,6 +103,16 @@ int vine_lstm_step_backward_mfma(int64_t B, int64_t H, const float* g_out, int64
                                  void* dgates, int64_t dg_stride, float* dc_prev, float* bias_partial,
                                  const float* bias_partial_prev, void* stream);
 
+/* Weight gradient of a linear layer on the matrix cores (mixed precision): for each of `slices` equal row slices
+ *   part[s][m][n] = sum over the rows k of slice s of dy[k][m] * x[k][n],   m < M, n < Nv
+ * dy [rows, M] and x [rows, Np] bfloat16 (rows ldy / ldx elements apart, 16-B aligned), part [slices, M, Nv] fp32.
+ * Np = the tile width actually read from x (32, 96 or a multiple of 128; columns Nv .. Np-1 must be readable, their
+ * products are not stored).  The sum over the slices (vine_column_sums over part viewed as [slices, M * Nv]) is the
+ * gradient dy^T x -- fixed summation order, no atomics.  Requires M % 64 == 0 and rows % (32 * slices) == 0;
+ * VINE_ERR_UNSUPPORTED otherwise (callers fall back to a library GEMM). */
+int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const void* dy, int64_t ldy, const void* x,
+                          int64_t ldx, int64_t slices, float* part, void* stream);
+
 /* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
  * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.
  * forward: y = (x - mean) * rstd * gamma + beta; mean/rstd [n] (both nullable) are kept for the backward pass.

@@ -87,7 +87,8 @@ def test_pointwise_kernels_against_torch():
     batch, expect = fused.ColumnSumBatch(), []
     for rep in range(3):
         for R, Cc in ((32, 1024 * 92), (2048, 1024), (512, 64), (7, 130), (300, 5), (512, 1280)):
-            src = torch.randn(R, Cc + 6, device=dev)[:, :Cc]
+            # rep 1: unpadded rows -> the 16-B geometry of the batched kernel for the short, wide jobs
+            src = torch.randn(R, Cc + 6, device=dev)[:, :Cc] if rep != 1 else torch.randn(R, Cc, device=dev)
             a, b = torch.empty(Cc // 2, device=dev), torch.empty(Cc - Cc // 2, device=dev)
             batch.add(src, a, out1=b, n0=Cc // 2)
             expect.append((src.double().sum(0), a, b))
@@ -240,6 +241,55 @@ def test_lstm_backward_mfma_matches_gemm_plus_pointwise(B, H, use_dones):
 
 
 @pytest.mark.gpu
+def test_weight_grad_mfma_matches_float64_product(monkeypatch):
+    """dy^T x on the matrix cores (transposed LDS reads, row slices + deterministic column sums) for every weight of the
+    default network, against the float64 product of the same bf16 operands; operands that are column blocks of a
+    wider padded buffer (the LSTM operand buffer) included."""
+    import time
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    bf = torch.bfloat16
+    n = 32768
+    monkeypatch.setattr(fused, "WGRAD_MAX_OUT", 1 << 30)          # the kernel is opt-in (see fused.WGRAD_MAX_OUT)
+    xfull = (torch.randn(n, 96, device=dev) * 0.5).to(bf)
+    xfull[:, 90:] = float("nan")                       # pad columns are read but must never reach an output
+    cases = [("W1 [256,26]", 256, xfull[:, 64:90]), ("W2 [128,256]", 128, (torch.randn(n, 256, device=dev)).to(bf)),
+             ("W3 [64,128]", 64, torch.randn(n, 128, device=dev).to(bf)), ("w_ih [1024,90]", 1024, xfull[:, :90]),
+             ("w_hh [1024,256]", 1024, torch.randn(n, 256, device=dev).to(bf))]
+    for name, M, x in cases:
+        dy = (torch.randn(n, M, device=dev) * 0.1).to(bf)
+        assert fused._wgrad_plan(dy, x) is not None, name
+        out = fused.weight_grad(dy, x)
+        ref = dy.double().t() @ x.double()
+        err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
+        assert out.shape == ref.shape and err < 2e-5, (name, err)
+        again = fused.weight_grad(dy, x)
+        assert torch.equal(out, again)                 # fixed summation order
+        res = []
+        for f in (lambda: fused.weight_grad(dy, x), lambda: fused.splitk_tn(dy, x)):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                f()
+            torch.cuda.synchronize()
+            res.append((time.perf_counter() - t0) / 30 * 1e6)
+        print("weight gradient %-16s mfma %6.1f us   split-K bmm + column sums %6.1f us" % (name, res[0], res[1]))
+    # small / direct (one slice) and the fallback for unsupported operands
+    dy, x = torch.randn(256, 64, device=dev).to(bf), torch.randn(256, 128, device=dev).to(bf)
+    assert fused._wgrad_plan(dy, x) == (128, 1)
+    assert float((fused.weight_grad(dy, x).double() - dy.double().t() @ x.double()).abs().max()) < 1e-3
+    x26 = torch.randn(256, 26, device=dev).to(bf)                                   # unpadded 26-column rows
+    assert fused._wgrad_plan(dy, x26) is None
+    monkeypatch.setattr(fused, "WGRAD_MAX_OUT", 0)
+    assert fused._wgrad_plan(dy, x) is None                                         # default: off
+    assert float((fused.weight_grad(dy, x26).double() - dy.double().t() @ x26.double()).abs().max()) < 1e-3
+    lib = fused._lib()
+    assert lib.vine_weight_grad_mfma(256, 48, 128, 128, dy.data_ptr(), 64, x.data_ptr(), 128, 1, x.data_ptr(), None) == -2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("F_", [28, 18, 1])
 def test_running_mean_std_kernels_match_torch_composition(F_):
     """vine_rms_update + vine_normalize_obs (float64 statistics, two-stage sums) against the module's torch path."""
@@ -386,6 +436,13 @@ def test_copy_batch_ops():
         hp = torch.empty(512, 4, 256, device=dev, dtype=bf)
         cb.add(cb.MASKED, hp[:, 0], h0, dones, aux=4)
         checks.append((hp[:, 0], (h0 * (1.0 - dones.view(512, 4)[:, 0:1].float())).to(bf)))
+        odd = torch.randn(100, 27, device=dev)                      # 27 columns: the element-wise path
+        odd_dst = torch.empty(100, 31, device=dev)[:, 2:29]
+        cb.add(cb.COPY, odd_dst, odd)
+        checks.append((odd_dst, odd))
+        odd_b = torch.empty(100, 27, device=dev, dtype=bf)
+        cb.add(cb.CAST_BF16, odd_b, odd)
+        checks.append((odd_b, odd.to(bf)))
         c0, c1 = torch.randn(512, 256, device=dev), torch.empty(512, 256, device=dev)
         cb.add(cb.MASKED, c1, c0, None)
         checks.append((c1, c0))

@@ -839,6 +839,103 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
     }
 }
 
+// ---- Weight gradient on the matrix cores: part[s][m][n] = sum over the rows k of slice s of dy[k][m] * x[k][n]
+// (dy [rows, M], x [rows, N] bf16, both with the reduction index as the SLOW dimension -- the layout the backward
+// kernels produce).  Both MFMA operands want 8 consecutive k per lane, i.e. a column of the row-major tiles: the
+// tiles are staged row-major in LDS ([32 rows][cols], pitch = cols * 2 + 32 B) and read with the gfx950 transposed
+// LDS read (ds_read_b64_tr_b16: a 16-lane group fetches a 4-row x 16-column block and gets it column-major).
+// The k <-> lane-group assignment of an MFMA is free as long as both operands agree: group g takes rows 4g .. 4g+3
+// and 16+4g .. 16+4g+3 of the stage, so that a 32-lane half always reads 8 consecutive rows, which the pitch spreads
+// over all 64 banks.  Workgroup = 4 waves along M: (64 MT) x (16 NT) outputs; stages of 32 rows, double-buffered in
+// LDS behind a register prefetch, one barrier per stage.  The slices are summed by the column-sum kernel
+// (deterministic, no atomics).
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
+#define VINE_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ bf16x8_t tr_read8(const bf16_t* p, int second_block_elems) {
+    // two transposed reads: rows (.., +3) at p and the block `second_block_elems` further on
+    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VINE_LDS bf16x4_t*)(p));
+    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VINE_LDS bf16x4_t*)(p + second_block_elems));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_t* __restrict__ dy, long long ldy,
+                                                         const bf16_t* __restrict__ x, long long ldx,
+                                                         float* __restrict__ part, int M, int Nv) {
+    constexpr int MTW = 64 * MT, NTW = 16 * NT;
+    constexpr int PA = MTW + 16, PB = NTW + 16;                 // bf16 elements per LDS row
+    constexpr int AC = MTW / 8, BC = NTW / 8;                   // 16-B pieces per row
+    constexpr int AP = 32 * AC, BP = 32 * BC;
+    constexpr int NA = (AP + 255) / 256, NB = (BP + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16_t al[2][32 * PA];
+    __shared__ __attribute__((aligned(16))) bf16_t bl[2][32 * PB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.x * MTW, n0 = blockIdx.y * NTW;
+    const long long k0 = (long long)blockIdx.z * stages * 32;
+    // up to two 16-B pieces of each tile per thread and stage (named scalars: indexed arrays end up in scratch)
+    const int pa0 = (int)threadIdx.x, pa1 = (int)threadIdx.x + 256;
+    const bool va0 = pa0 < AP, va1 = NA > 1 && pa1 < AP, vb0 = pa0 < BP, vb1 = NB > 1 && pa1 < BP;
+    const bf16_t* asrc0 = dy + (k0 + pa0 / AC) * ldy + m0 + 8 * (pa0 % AC);
+    const bf16_t* asrc1 = dy + (k0 + pa1 / AC) * ldy + m0 + 8 * (pa1 % AC);
+    const bf16_t* bsrc0 = x + (k0 + pa0 / BC) * ldx + n0 + 8 * (pa0 % BC);
+    const bf16_t* bsrc1 = x + (k0 + pa1 / BC) * ldx + n0 + 8 * (pa1 % BC);
+    const int aoff0 = (pa0 / AC) * PA + 8 * (pa0 % AC), aoff1 = (pa1 / AC) * PA + 8 * (pa1 % AC);
+    const int boff0 = (pa0 / BC) * PB + 8 * (pa0 % BC), boff1 = (pa1 / BC) * PB + 8 * (pa1 % BC);
+    uint4 wa0 = make_uint4(0, 0, 0, 0), wa1 = wa0, wb0 = wa0, wb1 = wa0;
+#define WG_LOAD(it)                                                                              \
+    if (va0) wa0 = *reinterpret_cast<const uint4*>(asrc0 + (long long)(it) * 32 * ldy);          \
+    if (va1) wa1 = *reinterpret_cast<const uint4*>(asrc1 + (long long)(it) * 32 * ldy);          \
+    if (vb0) wb0 = *reinterpret_cast<const uint4*>(bsrc0 + (long long)(it) * 32 * ldx);          \
+    if (vb1) wb1 = *reinterpret_cast<const uint4*>(bsrc1 + (long long)(it) * 32 * ldx)
+#define WG_STORE(buf)                                                                            \
+    if (va0) *reinterpret_cast<uint4*>(&al[buf][aoff0]) = wa0;                                   \
+    if (va1) *reinterpret_cast<uint4*>(&al[buf][aoff1]) = wa1;                                   \
+    if (vb0) *reinterpret_cast<uint4*>(&bl[buf][boff0]) = wb0;                                   \
+    if (vb1) *reinterpret_cast<uint4*>(&bl[buf][boff1]) = wb1
+    WG_LOAD(0);
+    WG_STORE(0);
+    __syncthreads();
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    // transposed-read address of this lane inside a 16-column tile: row 4g + q, columns 4p .. 4p+3
+    const int g = lane >> 4, il = lane & 15;
+    const int ra = (4 * g + (il >> 2)) * PA + 4 * (il & 3) + wave * MT * 16;
+    const int rb = (4 * g + (il >> 2)) * PB + 4 * (il & 3);
+    for (int it = 0; it < stages; ++it) {
+        const bool more = it + 1 < stages;
+        if (more) { WG_LOAD(it + 1); }
+        const bf16_t* ab = al[it & 1];
+        const bf16_t* bb = bl[it & 1];
+        bf16x8_t af[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = tr_read8(ab + ra + 16 * mt, 16 * PA);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8_t bf = tr_read8(bb + rb + 16 * nt, 16 * PB);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+        }
+        if (more) { WG_STORE((it + 1) & 1); }
+        __syncthreads();
+    }
+#undef WG_LOAD
+#undef WG_STORE
+    // D[m = 4g + r][n = il] of tile (mt, nt)
+    float* out = part + ((long long)blockIdx.z * M + m0 + (wave * MT) * 16 + 4 * g) * Nv + n0 + il;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (n0 + 16 * nt + il < Nv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(long long)(16 * mt + r) * Nv + 16 * nt] = acc[mt][nt][r];
+            }
+}
+
 // ---- LayerNorm over rows of H = 256 * NV floats: one wave per row, lane l owns columns [256 v + 4 l, +4) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -1226,8 +1323,17 @@ __global__ __launch_bounds__(1024) void colsum_tall_kernel(const float* __restri
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const long long c = (long long)blockIdx.x * 16 + cl;
     float acc = 0.0f;
-    if (c < C)
-        for (long long r = rl; r < R; r += 64) acc += src[r * row_stride + c];
+    if (c < C) {
+        long long r = rl;
+        for (; r + 7 * 64 < R; r += 8 * 64) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(r + 64LL * k) * row_stride + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; r < R; r += 64) acc += src[r * row_stride + c];
+    }
     __shared__ float red[64][17];
     red[rl][cl] = acc;
     __syncthreads();
@@ -1256,7 +1362,7 @@ struct ColsumJob {
     float* out0;
     float* out1;
     long long R, C, row_stride, n0;
-    int dup, first_block;
+    int dup, first_block, quad;
 };
 #define VINE_COLSUM_MAX_JOBS 16
 struct ColsumBatch {
@@ -1270,14 +1376,50 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
         if ((int)blockIdx.x >= batch.job[k].first_block) j = k;
     const ColsumJob& J = batch.job[j];
     const int blk = blockIdx.x - J.first_block;
+    __shared__ __attribute__((aligned(16))) float red[1024];
+    if (J.quad) {
+        // short and wide (the slices of a split-K weight gradient): 64 column QUADS x 4 row-lanes, 16-B loads
+        const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+        const long long c = ((long long)blk * 64 + cl) * 4;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (c < J.C) {
+#pragma unroll 8
+            for (long long r = rl; r < J.R; r += 4) {
+                const float4 v = ld4(J.src + r * J.row_stride + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(red)[rl * 64 + cl] = acc;
+        __syncthreads();
+        if (rl == 0 && c < J.C) {
+            const float4* rq = reinterpret_cast<const float4*>(red);
+            const float4 a = rq[cl], b = rq[64 + cl], cc = rq[128 + cl], d = rq[192 + cl];
+            const float4 v = make_float4((a.x + cc.x) + (b.x + d.x), (a.y + cc.y) + (b.y + d.y), (a.z + cc.z) + (b.z + d.z),
+                                         (a.w + cc.w) + (b.w + d.w));      // the order of the tree below
+            if (J.dup) { st4(J.out0 + c, v); st4(J.out1 + c, v); }
+            else if (J.out1 && c >= J.n0) st4(J.out1 + (c - J.n0), v);
+            else st4(J.out0 + c, v);
+        }
+        return;
+    }
     const bool tall = J.R >= 128;
     const int ct = tall ? 16 : 64, rlanes = tall ? 16 : 4;
     const int cl = threadIdx.x % ct, rl = threadIdx.x / ct;
     const long long c = (long long)blk * ct + cl;
     float acc = 0.0f;
-    if (c < J.C)
-        for (long long r = rl; r < J.R; r += rlanes) acc += J.src[r * J.row_stride + c];
-    __shared__ float red[256];
+    if (c < J.C) {
+        // 8 independent loads in flight per thread: a rolled loop would pay one memory round trip per row
+        const float* sp = J.src + c;
+        long long r = rl;
+        for (; r + 7 * rlanes < J.R; r += 8 * rlanes) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sp[(r + (long long)k * rlanes) * J.row_stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; r < J.R; r += rlanes) acc += sp[r * J.row_stride];
+    }
     red[rl * ct + cl] = acc;
     __syncthreads();
     // fixed-order tree over the row lanes (power of two)
@@ -1308,7 +1450,7 @@ struct CopyJob {
     const void* src2;
     void* dst;
     long long rows, cols, src_stride, dst_stride, aux;
-    int op, elem, first_block;
+    int op, elem, first_block, vec;
 };
 #define VINE_COPY_MAX_JOBS 24
 struct CopyBatchArgs {
@@ -1328,6 +1470,40 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
     long long r = base / J.cols;
     int c = (int)(base - r * J.cols);
     const int cols = (int)J.cols;
+    if (J.vec) {
+        // aligned job (cols, strides multiples of 4, pointers aligned): the 4 elements are one 8- or 16-B access
+        const long long d = r * J.dst_stride + c, sidx = r * J.src_stride + c;
+        switch (J.op) {
+            case 0:
+                if (J.elem == 2)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(J.dst) + d) =
+                        *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(J.src) + sidx);
+                else
+                    st4(reinterpret_cast<float*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
+                break;
+            case 1:
+                if (J.elem == 2) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(J.dst) + d) = make_uint2(0u, 0u);
+                else st4(reinterpret_cast<float*>(J.dst) + d, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                break;
+            case 3:
+                st4(reinterpret_cast<bf16_t*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
+                break;
+            case 4: {
+                const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
+                const float4 b = ld4(reinterpret_cast<const float*>(J.src2) + sidx);
+                st4(reinterpret_cast<float*>(J.dst) + d, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+                break;
+            }
+            default: {
+                const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
+                const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
+                const float4 v = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
+                if (J.elem == 2) st4(reinterpret_cast<bf16_t*>(J.dst) + d, v);
+                else st4(reinterpret_cast<float*>(J.dst) + d, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (base + q >= total) break;
@@ -1914,6 +2090,30 @@ int vine_lstm_step_backward_mfma(int64_t B, int64_t H, const float* g_out, int64
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const void* dy, int64_t ldy, const void* x,
+                          int64_t ldx, int64_t slices, float* part, void* stream) {
+    if (rows <= 0 || M <= 0 || Np <= 0 || Nv <= 0 || Nv > Np || slices <= 0 || !dy || !x || !part || ldy < M || ldx < Np ||
+        (ldy & 7) || (ldx & 7) || ((uintptr_t)dy & 15) || ((uintptr_t)x & 15))
+        return VINE_ERR_INVALID_ARG;
+    if ((M & 63) || rows % (slices * 32) || slices > 65535) return VINE_ERR_UNSUPPORTED;
+    const int mt = (M & 127) ? 1 : 2;
+    int nt;
+    if (Np == 32) nt = 2;
+    else if (Np == 96) nt = 6;
+    else if ((Np & 127) == 0) nt = 8;
+    else return VINE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(M / (64 * mt)), (unsigned)(Np / (16 * nt)), (unsigned)slices);
+    const int stages = (int)(rows / slices / 32);
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_WGRAD(MT_, NT_)                                                                                          \
+    hipLaunchKernelGGL((wgrad_mfma_kernel<MT_, NT_>), grid, dim3(256), 0, s, stages, (const bf16_t*)dy, (long long)ldy, \
+                       (const bf16_t*)x, (long long)ldx, part, (int)M, (int)Nv)
+    if (mt == 2) { if (nt == 2) VINE_WGRAD(2, 2); else if (nt == 6) VINE_WGRAD(2, 6); else VINE_WGRAD(2, 8); }
+    else { if (nt == 2) VINE_WGRAD(1, 2); else if (nt == 6) VINE_WGRAD(1, 6); else VINE_WGRAD(1, 8); }
+#undef VINE_WGRAD
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
 int vine_layernorm_forward(int64_t n, int64_t H, const float* x, const float* gamma, const float* beta, float eps,
                            float* y, float* mean, float* rstd, void* stream) {
     if (n <= 0 || !x || !gamma || !beta || !y || ((mean == nullptr) != (rstd == nullptr))) return VINE_ERR_INVALID_ARG;
@@ -2044,9 +2244,12 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
         if (R[k] <= 0 || C[k] <= 0 || !src[k] || !out0[k] || row_stride[k] < C[k] || (dup[k] && !out1[k]) || n0[k] < 0 ||
             n0[k] > C[k])
             return VINE_ERR_INVALID_ARG;
-        const int ct = R[k] >= 128 ? 16 : 64;
+        // 16-B geometry for short, wide jobs whose rows, split point and outputs are all 16-B aligned
+        const bool quad = R[k] < 128 && C[k] >= 4096 && !(C[k] & 3) && !(row_stride[k] & 3) && !(n0[k] & 3) &&
+                          !((uintptr_t)src[k] & 15) && !((uintptr_t)out0[k] & 15) && !((uintptr_t)out1[k] & 15);
+        const int ct = quad ? 256 : (R[k] >= 128 ? 16 : 64);
         b.job[k] = ColsumJob{src[k], out0[k], out1[k], (long long)R[k], (long long)C[k], (long long)row_stride[k],
-                             (long long)(out1[k] && !dup[k] ? n0[k] : C[k]), (int)dup[k], blocks};
+                             (long long)(out1[k] && !dup[k] ? n0[k] : C[k]), (int)dup[k], blocks, (int)quad};
         blocks += (int)((C[k] + ct - 1) / ct);
     }
     b.njobs = njobs;
@@ -2066,8 +2269,13 @@ int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, con
         if (op[k] < 0 || op[k] > 5 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
             (op[k] == 4 && !src2[k]) || (elem[k] != 2 && elem[k] != 4))
             return VINE_ERR_INVALID_ARG;
+        // vector path: every group of 4 consecutive elements is one aligned 8-/16-B access on both sides
+        const int src_elem = op[k] == 0 ? elem[k] : 4;
+        const bool vec = op[k] != 2 && !(cols[k] & 3) && !(dst_stride[k] & 3) && !((uintptr_t)dst[k] & (4 * elem[k] - 1)) &&
+                         (op[k] == 1 || (!(src_stride[k] & 3) && !((uintptr_t)src[k] & (4 * src_elem - 1)))) &&
+                         (op[k] != 4 || !((uintptr_t)src2[k] & 15));
         b.job[k] = CopyJob{src[k], src2[k], dst[k], (long long)rows[k], (long long)cols[k], (long long)src_stride[k],
-                           (long long)dst_stride[k], (long long)aux[k], (int)op[k], (int)elem[k], blocks};
+                           (long long)dst_stride[k], (long long)aux[k], (int)op[k], (int)elem[k], blocks, (int)vec};
         blocks += (int)((rows[k] * cols[k] + 1023) / 1024);
     }
     b.njobs = njobs;

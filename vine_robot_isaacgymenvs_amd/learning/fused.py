@@ -80,6 +80,60 @@ def _splitk_parts(dy, x):
     return s, torch.bmm(dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s)))
 
 
+WGRAD_WGS = int(_os.environ.get("VINE_WGRAD_WGS", "256"))      # workgroups a weight-gradient launch aims for
+# largest M * Np the matrix-core weight-gradient kernel (vine_weight_grad_mfma) takes.  0 = off, the default: measured
+# inside the whole update (MI355X, n = 32768) the library split-K product + column sums wins at every weight of the
+# default network -- update 15.3 ms without the kernel, 16.0 ms with it for the four small weights, 17.8 ms for all
+# five (w_hh [1024, 256] alone: 93 us against 38 us).  With one workgroup per CU and 32-row stages the kernel is bound
+# by memory latency, not by the matrix cores; it stays as a tested building block (transposed LDS reads) behind this
+# knob.
+WGRAD_MAX_OUT = int(_os.environ.get("VINE_WGRAD_MAX_OUT", "0"))
+
+
+def _wgrad_plan(dy, x):
+    """(Np, slices) when ``vine_weight_grad_mfma`` covers dy^T x for these operands, else None.  Np: x's columns
+    rounded up to a tile width of the kernel; the extra columns must lie inside x's own rows (a column block of a
+    wider, padded buffer) -- they are read, their products are not stored."""
+    if not (dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and x.dim() == 2):
+        return None
+    n, M = dy.shape
+    N = x.shape[1]
+    if x.shape[0] != n or M % 64 or n % 256 or dy.stride(1) != 1 or x.stride(1) != 1:
+        return None
+    Np = 32 if N <= 32 else (96 if 64 < N <= 96 else ((N + 127) // 128 * 128 if N > 96 else 0))
+    if not Np or dy.stride(0) % 8 or x.stride(0) % 8 or dy.data_ptr() % 16 or x.data_ptr() % 16 or dy.stride(0) < M:
+        return None
+    if Np != N and (x.storage_offset() % x.stride(0)) + Np > x.stride(0):
+        return None
+    if x.stride(0) < Np or M * Np > WGRAD_MAX_OUT:
+        return None
+    wgs = (M // (128 if M % 128 == 0 else 64)) * (Np // (Np if Np <= 96 else 128))
+    s = 1
+    while wgs * s < WGRAD_WGS and n // (2 * s) >= 256 and n % (2 * s * 32) == 0:
+        s *= 2
+    return Np, s
+
+
+def weight_grad(dy, x, out=None, batch=None):
+    """``dy^T @ x`` -> [M, N] fp32 (into ``out`` when given): the matrix-core kernel with transposed LDS reads when the
+    operands allow it (bf16, the mixed-precision update), else ``splitk_tn``."""
+    plan = _wgrad_plan(dy, x)
+    if plan is None:
+        return splitk_tn(dy, x, out=out, batch=batch)
+    Np, s = plan
+    n, M = dy.shape
+    N = x.shape[1]
+    if out is None:
+        out = torch.empty((M, N), device=dy.device, dtype=torch.float32)
+    direct = s == 1 and out.is_contiguous()
+    part = out.view(1, M, N) if direct else torch.empty((s, M, N), device=dy.device, dtype=torch.float32)
+    _check(_lib().vine_weight_grad_mfma(n, M, Np, N, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), s,
+                                        part.data_ptr(), _stream(dy)), "vine_weight_grad_mfma")
+    if direct:
+        return out
+    return column_sums(part, out, batch=batch)
+
+
 def _grad_slot(p):
     """The parameter's persistent gradient buffer (a view into the optimiser's flat gradient block) if it can be
     written in place: the custom backward then stores the gradient there directly and returns None, which saves
@@ -138,7 +192,7 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     return torch.stack(outs, 1).reshape(B * T, -1), h, c
 
 
-def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None):
+def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0=True):
     """out / c_all / gates / hp of ``_lstm_forward_steps`` with the step-0 slots initialised (c_all[0] = c0,
     hp[:, 0] = masked h0 in the operand dtype): through ``prep`` (a CopyBatch flushed by the caller) or directly."""
     op = w_hh.dtype
@@ -150,7 +204,8 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None):
     gates = torch.empty((T, B, 4 * H), device=dev, dtype=op) if need_grad else None     # backward-only: operand dtype
     hp = torch.empty((B, T, H), device=dev, dtype=op)
     if prep is not None:
-        prep.add(CopyBatch.COPY, c_all[0], c0)
+        if copy_c0:      # else: the caller hands c0 itself to the step kernels (``c0_direct``), slot 0 stays unused
+            prep.add(CopyBatch.COPY, c_all[0], c0)
         prep.add(CopyBatch.MASKED, hp[:, 0], h0, dones, aux=T)
     else:
         c_all[0].copy_(c0)
@@ -161,7 +216,7 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None):
     return out, c_all, gates, hp
 
 
-def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None):
+def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None, c0_direct=None):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
     hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
     ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32.
@@ -171,6 +226,11 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
     BT, H = x.shape[0], w_hh.shape[1]
     B = BT // T
     out, c_all, gates, hp = buffers if buffers is not None else _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad)
+    # c_{t-1} of step t: c_all[t], except that step 0 may read the caller's c0 in place (saves the 2 x B x H copy)
+    c_prev = [c_all[t] for t in range(T)]
+    if c0_direct is not None:
+        assert c0_direct.dtype == torch.float32 and c0_direct.is_contiguous() and c0_direct.shape == c_all[0].shape
+        c_prev[0] = c0_direct
     st = _stream(x)
     d_ptr = dones.data_ptr() if dones is not None else None
     w_hh_t = w_hh.t()
@@ -182,7 +242,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
             K1 = wcat.shape[1] - H
             _check(lib.vine_lstm_step_mfma(
                 B, H, K1 + H, x.data_ptr() + 2 * (t * x.stride(0)), T * x.stride(0), hp.data_ptr() + 2 * (t * H), T * H,
-                K1, wcat.data_ptr(), wcat.stride(0), None, 4 * H, bias.data_ptr(), c_all[t].data_ptr(),
+                K1, wcat.data_ptr(), wcat.stride(0), None, 4 * H, bias.data_ptr(), c_prev[t].data_ptr(),
                 (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
                 c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
                 None if last else hp.data_ptr() + 2 * ((t + 1) * H),
@@ -191,7 +251,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
         if mfma:
             _check(lib.vine_lstm_step_mfma(
                 B, H, H, hp.data_ptr() + 2 * (t * H), T * H, None, 0, 0, w_hh.data_ptr(), w_hh.stride(0),
-                ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, bias.data_ptr(), c_all[t].data_ptr(),
+                ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, bias.data_ptr(), c_prev[t].data_ptr(),
                 (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
                 c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
                 None if last else hp.data_ptr() + 2 * ((t + 1) * H),
@@ -200,7 +260,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
         hg = _mm(hp[:, t], w_hh_t)
         # hg is already built from the masked state: no second masking inside the kernel (done = NULL), except for c
         _check(lib.vine_lstm_cell_forward(
-            B, H, ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, hg.data_ptr(), bias.data_ptr(), c_all[t].data_ptr(),
+            B, H, ig.data_ptr() + 4 * (t * 4 * H), T * 4 * H, hg.data_ptr(), bias.data_ptr(), c_prev[t].data_ptr(),
             (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
             c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
             None if last else hp.data_ptr() + hp.element_size() * ((t + 1) * H),
@@ -214,7 +274,7 @@ def lstm_bwd_mfma_ok(B, H):
     return B % 64 == 0 and H in (128, 256)
 
 
-def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None):
+def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, c0_direct=None):
     """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials.
     dG is only ever a GEMM operand: it is stored in ``w_hh``'s dtype (bfloat16 in the mixed-precision update).
     ``w_hh_t`` ([H, 4H] bf16, the transposed recurrent weight): every step is ONE matrix-core kernel that forms the
@@ -226,6 +286,9 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None):
     dG = torch.empty((B * T, 4 * H), device=dev, dtype=w_hh.dtype)
     dG3 = dG.view(B, T, 4 * H)
     dc = [torch.empty((B, H), device=dev, dtype=torch.float32) for _ in range(2)]
+    c_prev = [c_all[t] for t in range(T)]
+    if c0_direct is not None:            # the forward pass read c0 in place: c_all[0] was never written
+        c_prev[0] = c0_direct
     if w_hh_t is not None:
         assert dG.dtype == torch.bfloat16 and lstm_bwd_mfma_ok(B, H)
         bias_partial = torch.empty((2, B // 64, 4 * H), device=dev, dtype=torch.float32)
@@ -239,7 +302,7 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None):
                 None if last else w_hh_t.data_ptr(), w_hh_t.stride(0),
                 None if last else dc[(t + 1) & 1].data_ptr(),
                 (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, gates[t].data_ptr(),
-                c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
+                c_all[t + 1].data_ptr(), c_prev[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
                 dG.data_ptr() + 2 * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(), bias_partial[t & 1].data_ptr(),
                 None if last else bias_partial[(t + 1) & 1].data_ptr(), st), "vine_lstm_step_backward_mfma")
         return dG, bias_partial[0]
@@ -256,7 +319,7 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None):
         _check(lib.vine_lstm_cell_backward(
             B, H, g_out.data_ptr() + 4 * (t * H), T * H, g_rec.data_ptr() if g_rec is not None else None,
             dc_next.data_ptr() if dc_next is not None else None, dn, T, gates[t].data_ptr(),
-            c_all[t + 1].data_ptr(), c_all[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
+            c_all[t + 1].data_ptr(), c_prev[t].data_ptr(), (d_ptr + t) if d_ptr is not None else None, T,
             dG.data_ptr() + dG.element_size() * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(),
             bias_partial[t & 1].data_ptr() if use_partial else None,
             bias_partial[(t + 1) & 1].data_ptr() if (use_partial and t < T - 1) else None,
@@ -524,10 +587,13 @@ class _Trunk(torch.autograd.Function):
             prep.add(CopyBatch.COPY, b_heads[:A_], mu_b)
             prep.add(CopyBatch.COPY, b_heads[A_:], v_b)
             prep.add(CopyBatch.ADD, bias, b_ih, b_hh)
-            lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep)
+            c0_direct = c0 if (c0.dtype == torch.float32 and c0.is_contiguous()) else None
+            lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep,
+                                               copy_c0=c0_direct is None)
             prep.flush(obs_n)
         else:
             lstm_buffers = None
+            c0_direct = None
             l1_mfma = False
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
@@ -566,11 +632,11 @@ class _Trunk(torch.autograd.Function):
         if no_proj:
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
             out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat,
-                                                        buffers=lstm_buffers)
+                                                        buffers=lstm_buffers, c0_direct=c0_direct)
         else:
             ig = _mm(xcat, w_ih_op.t())
             out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True,
-                                                        buffers=lstm_buffers)
+                                                        buffers=lstm_buffers, c0_direct=c0_direct)
             del ig
         # LayerNorm and the two heads stay in fp32 in both modes (3 output columns: nothing to gain, and mu feeds
         # the probability ratio directly)
@@ -597,8 +663,10 @@ class _Trunk(torch.autograd.Function):
         ctx.fuse_heads = fuse_heads
         ctx.wts = wts
         ctx.w_hh_t = w_hh_t
+        ctx.has_c0 = c0_direct is not None   # the caller's own c0 buffer is read again in backward (saved below)
         ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g, ln_b,
-                              dones if dones is not None else obs_n.new_empty(0), *acts, *Wop)
+                              dones if dones is not None else obs_n.new_empty(0), *acts, *Wop,
+                              *([c0_direct] if c0_direct is not None else []))
         # final LSTM state as views (no copies): the update discards it, other callers may clone
         hT = out.view(B, T, H)[:, T - 1]
         cT = c_all[T]
@@ -614,7 +682,8 @@ class _Trunk(torch.autograd.Function):
         saved = ctx.saved_tensors
         x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih, w_hh, ln_g, ln_b, dones = saved[:15]
         acts = list(saved[15:15 + n_mlp - 1])
-        weights = list(saved[15 + n_mlp - 1:])
+        weights = list(saved[15 + n_mlp - 1:15 + 2 * n_mlp - 1])
+        c0_direct = saved[-1] if ctx.has_c0 else None
         slots = ctx.slots
         n, H = out.shape
         dev = out.device
@@ -671,9 +740,9 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
-                                                w_hh_t=ctx.w_hh_t)
-        deliver(base + 0, lambda o: splitk_tn(dG, xcat, out=o, batch=batch))
-        deliver(base + 1, lambda o: splitk_tn(dG, hp.view(n, H), out=o, batch=batch))
+                                                w_hh_t=ctx.w_hh_t, c0_direct=c0_direct)
+        deliver(base + 0, lambda o: weight_grad(dG, xcat, out=o, batch=batch))
+        deliver(base + 1, lambda o: weight_grad(dG, hp.view(n, H), out=o, batch=batch))
         if bias_partial is not None and slots[base + 2] is not None and slots[base + 3] is not None:
             column_sums(bias_partial.view(-1, 4 * H), slots[base + 2], out1=slots[base + 3], dup=True, batch=batch)
         else:
@@ -703,7 +772,7 @@ class _Trunk(torch.autograd.Function):
                 _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
                                              part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
             x_in = acts[i - 1] if i > 0 else x0
-            deliver(2 * i, lambda o, gz=gz, x_in=x_in: splitk_tn(gz, x_in, out=o, batch=batch))
+            deliver(2 * i, lambda o, gz=gz, x_in=x_in: weight_grad(gz, x_in, out=o, batch=batch))
             deliver(2 * i + 1, lambda o, part=part: column_sums(part, o, batch=batch))
             if i == 0:
                 break
