@@ -270,40 +270,51 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
         const int g = prow[q] >> 6, i = prow[q] & 63;
         wsrc[q] = W + (long long)(g * H + u0 + i) * ldw + pcol * 8;
     }
-    uint4 w0, w1, w2, w3;
-#define LOAD_W(kk)                                                         \
-    w0 = *reinterpret_cast<const uint4*>(wsrc[0] + 32 * (kk));             \
-    w1 = *reinterpret_cast<const uint4*>(wsrc[1] + 32 * (kk));             \
-    w2 = *reinterpret_cast<const uint4*>(wsrc[2] + 32 * (kk));             \
-    w3 = *reinterpret_cast<const uint4*>(wsrc[3] + 32 * (kk))
-#define STORE_W(buf)                                                                        \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[0] * PITCH + pcol * 8]) = w0;                   \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[1] * PITCH + pcol * 8]) = w1;                   \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                   \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
-    LOAD_W(0);
-    STORE_W(0);
-    __syncthreads();
+    // three register sets for the weight stream (named scalars: an indexed array lands in scratch): chunk kk + 2 is
+    // requested while chunk kk is multiplied, so a request has two whole k-steps of matrix work to hide its L2 round
+    // trip behind instead of one
+    uint4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3, wc0, wc1, wc2, wc3;
+#define LOAD_W(S, kk)                                                       \
+    S##0 = *reinterpret_cast<const uint4*>(wsrc[0] + 32 * (kk));            \
+    S##1 = *reinterpret_cast<const uint4*>(wsrc[1] + 32 * (kk));            \
+    S##2 = *reinterpret_cast<const uint4*>(wsrc[2] + 32 * (kk));            \
+    S##3 = *reinterpret_cast<const uint4*>(wsrc[3] + 32 * (kk))
+#define STORE_W(S, kk)                                                                        \
+    *reinterpret_cast<uint4*>(&wl[(kk) & 1][prow[0] * PITCH + pcol * 8]) = S##0;              \
+    *reinterpret_cast<uint4*>(&wl[(kk) & 1][prow[1] * PITCH + pcol * 8]) = S##1;              \
+    *reinterpret_cast<uint4*>(&wl[(kk) & 1][prow[2] * PITCH + pcol * 8]) = S##2;              \
+    *reinterpret_cast<uint4*>(&wl[(kk) & 1][prow[3] * PITCH + pcol * 8]) = S##3
     f32x4_t acc[4][4];                                         // [gate][unit tile]
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[g][t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-        if (kk + 1 < KSTEPS) { LOAD_W(kk + 1); }
-        const bf16_t* wb = wl[kk & 1];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(
-                    wb + (g * 64 + t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4));
-                acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[g][t], 0, 0, 0);
-            }
-        if (kk + 1 < KSTEPS) { STORE_W((kk + 1) & 1); }
-        __syncthreads();
+    // step kk: request chunk kk + 2 into set SL (stored to LDS one step ago), multiply chunk kk, move chunk kk + 1 from
+    // set SS into the other LDS buffer
+#define LSTM_STEP(kk, SL, SS)                                                                                  \
+    if (KSTEPS > (kk)) {                                                                                       \
+        if ((kk) > 0 && (kk) + 2 < KSTEPS) { LOAD_W(SL, (kk) + 2); }                                           \
+        const bf16_t* wb_ = wl[(kk) & 1];                                                                      \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                          \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(                                        \
+                    wb_ + (g * 64 + t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4));                          \
+                acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[(kk) < KSTEPS ? (kk) : 0], acc[g][t], 0, 0, 0); \
+            }                                                                                                  \
+        if ((kk) + 1 < KSTEPS) { STORE_W(SS, (kk) + 1); }                                                      \
+        __syncthreads();                                                                                       \
     }
+    LOAD_W(wa, 0);
+    if (KSTEPS > 1) { LOAD_W(wb, 1); }
+    if (KSTEPS > 2) { LOAD_W(wc, 2); }
+    STORE_W(wa, 0);
+    __syncthreads();
+    LSTM_STEP(0, wc, wb) LSTM_STEP(1, wa, wc) LSTM_STEP(2, wb, wa) LSTM_STEP(3, wc, wb)
+    LSTM_STEP(4, wa, wc) LSTM_STEP(5, wb, wa) LSTM_STEP(6, wc, wb) LSTM_STEP(7, wa, wc)
+    LSTM_STEP(8, wb, wa) LSTM_STEP(9, wc, wb) LSTM_STEP(10, wa, wc) LSTM_STEP(11, wb, wa)
+    LSTM_STEP(12, wc, wb) LSTM_STEP(13, wa, wc) LSTM_STEP(14, wb, wa) LSTM_STEP(15, wc, wb)
+    static_assert(KSTEPS <= 16, "lstm_step_mfma64_kernel: K <= 512");
+#undef LSTM_STEP
 #undef LOAD_W
 #undef STORE_W
     // hand-over through LDS: accumulators -> [row][gate][unit] tile, then the pointwise part runs with 16 lanes per
@@ -716,54 +727,51 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
         const int prow[4] = {(int)threadIdx.x >> 4, ((int)threadIdx.x + 256) >> 4, ((int)threadIdx.x + 512) >> 4,
                              ((int)threadIdx.x + 768) >> 4};
         const int pcol = threadIdx.x & 15;
-        uint4 w0, w1, w2, w3;
-        bf16x8_t g0, g1, g2, g3, h0, h1, h2, h3;
-#define LOAD_W(c)                                                                                              \
-    w0 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[0]) * ldw + (c) * CK + pcol * 8);          \
-    w1 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[1]) * ldw + (c) * CK + pcol * 8);          \
-    w2 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[2]) * ldw + (c) * CK + pcol * 8);          \
-    w3 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[3]) * ldw + (c) * CK + pcol * 8)
-#define STORE_W(buf)                                                                                           \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[0] * PITCH + pcol * 8]) = w0;                                      \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[1] * PITCH + pcol * 8]) = w1;                                      \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                                      \
-    *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
-#define LOAD_G(c, x0, x1, x2, x3)                                                                              \
-    x0 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK);                                                  \
-    x1 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 32);                                             \
-    x2 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 64);                                             \
-    x3 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 96)
-        LOAD_W(0);
-        LOAD_G(0, g0, g1, g2, g3);
-        STORE_W(0);
-        __syncthreads();
+        // three register sets {weight pieces, G fragments}: chunk c + 2 is requested while chunk c is multiplied
+        uint4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3, wc0, wc1, wc2, wc3;
+        bf16x8_t ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3, gc0, gc1, gc2, gc3;
+#define LOAD_WG(S, c)                                                                                            \
+    w##S##0 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[0]) * ldw + (c) * CK + pcol * 8);       \
+    w##S##1 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[1]) * ldw + (c) * CK + pcol * 8);       \
+    w##S##2 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[2]) * ldw + (c) * CK + pcol * 8);       \
+    w##S##3 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[3]) * ldw + (c) * CK + pcol * 8);       \
+    g##S##0 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK);                                               \
+    g##S##1 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 32);                                          \
+    g##S##2 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 64);                                          \
+    g##S##3 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 96)
+#define STORE_W(S, c)                                                                                            \
+    *reinterpret_cast<uint4*>(&wl[(c) & 1][prow[0] * PITCH + pcol * 8]) = w##S##0;                               \
+    *reinterpret_cast<uint4*>(&wl[(c) & 1][prow[1] * PITCH + pcol * 8]) = w##S##1;                               \
+    *reinterpret_cast<uint4*>(&wl[(c) & 1][prow[2] * PITCH + pcol * 8]) = w##S##2;                               \
+    *reinterpret_cast<uint4*>(&wl[(c) & 1][prow[3] * PITCH + pcol * 8]) = w##S##3
         f32x4_t acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c + 1 < NCH) {
-                LOAD_W(c + 1);
-                LOAD_G(c + 1, h0, h1, h2, h3);
-            }
-            const bf16_t* wb = wl[c & 1];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bf16_t* wr = wb + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr), g0, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32), g1, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 64), g2, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 96), g3, acc[t], 0, 0, 0);
-            }
-            if (c + 1 < NCH) {
-                STORE_W((c + 1) & 1);
-                g0 = h0; g1 = h1; g2 = h2; g3 = h3;
-            }
-            __syncthreads();
-        }
-#undef LOAD_W
+#define BWD_STEP(c, SL, SC, SS)                                                                                  \
+    if (NCH > (c)) {                                                                                             \
+        if ((c) > 0 && (c) + 2 < NCH) { LOAD_WG(SL, (c) + 2); }                                                  \
+        const bf16_t* wb_ = wl[(c) & 1];                                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
+            const bf16_t* wr = wb_ + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);                           \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr), g##SC##0, acc[t], 0, 0, 0);      \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32), g##SC##1, acc[t], 0, 0, 0); \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 64), g##SC##2, acc[t], 0, 0, 0); \
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 96), g##SC##3, acc[t], 0, 0, 0); \
+        }                                                                                                        \
+        if ((c) + 1 < NCH) { STORE_W(SS, (c) + 1); }                                                             \
+        __syncthreads();                                                                                         \
+    }
+        LOAD_WG(a, 0);
+        if (NCH > 1) { LOAD_WG(b, 1); }
+        if (NCH > 2) { LOAD_WG(c, 2); }
+        STORE_W(a, 0);
+        __syncthreads();
+        BWD_STEP(0, c, a, b) BWD_STEP(1, a, b, c) BWD_STEP(2, b, c, a) BWD_STEP(3, c, a, b)
+        BWD_STEP(4, a, b, c) BWD_STEP(5, b, c, a) BWD_STEP(6, c, a, b) BWD_STEP(7, a, b, c)
+        static_assert(NCH <= 8, "lstm_bwd_mfma_kernel: 4H <= 1024");
+#undef BWD_STEP
+#undef LOAD_WG
 #undef STORE_W
-#undef LOAD_G
         // accumulators -> [row][unit] tile (a lane holds 4 consecutive units of one row per 16-unit tile)
         const int r = wave * 16 + (lane & 15);
 #pragma unroll
