@@ -216,26 +216,30 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps
  * (eps ~ N(0,1) from Philox4x32-10 keyed by (seed, env, *counter)), neglogp, value un-normalised
- * (clamp(v, +-5) * value_std + value_mean when normalize_value).  Writes straight into the rollout buffers. */
+ * (clamp(v, +-5) * value_std + value_mean when normalize_value).  Writes straight into the rollout buffers.
+ * ln_gamma / ln_beta (both or neither; H == 256 only, else VINE_ERR_UNSUPPORTED): y is the RAW LSTM output and the
+ * LayerNorm in front of the heads (vine_layernorm_forward's arithmetic, eps = ln_eps) is applied inside. */
 int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
                      const float* w_v, const float* b_v, const float* logstd, const float* value_mean,
                      const float* value_std, int32_t normalize_value, uint64_t seed, const int64_t* counter,
                      float* mu_out, float* sigma_out, float* value_out, float* action_out, float* neglogp_out,
-                     void* stream);
+                     const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
 
-/* Rollout, post-step bookkeeping in two launches (per-env pass + 1-thread finalise):
+/* Rollout, post-step bookkeeping in two launches (per-env pass + one-workgroup finalise):
  *   shaped = (rew + shift) * scale + gamma_bootstrap * value * time_out          (reward_shaper PY:58-59, value_bootstrap PY:56)
  *   dones_out = reset != 0;  cur_rewards += rew;  cur_lengths += 1
  *   finished episodes feed the two windowed means (rl_games AverageMeter, window max_size), then their
  *   accumulators and the LSTM state rows h,c [N,H] are zeroed;  *counter += 1.
- * meter[8] = {rew_mean, rew_size, len_mean, len_size, tmp_sum_rew, tmp_sum_len, tmp_count, 0}.
+ * meter[8] = {rew_mean, rew_size, len_mean, len_size, step_sum_rew, step_sum_len, step_count, 0}.
  * h_op (nullable): a second copy of h used as GEMM operand (rows h_op_stride elements apart, fp32 or bfloat16), zeroed
- * alongside h_state. */
+ * alongside h_state.  scratch: VINE_ROLLOUT_POST_SCRATCH_FLOATS floats (contents irrelevant) for the per-workgroup
+ * episode sums -- fixed summation order, no atomics. */
+#define VINE_ROLLOUT_POST_SCRATCH_FLOATS (1024 * 3)
 int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
                       const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
                       float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
                       float* c_state, float* meter, float max_size, int64_t* counter, void* h_op, int64_t h_op_stride,
-                      int32_t h_op_bf16, void* stream);
+                      int32_t h_op_bf16, float* scratch, void* stream);
 
 /* Adam step on FLAT buffers (all parameters of the model live in one contiguous block, likewise gradients and
  * moments): torch.optim.Adam arithmetic (rl_games: Adam(lr, eps=1e-8), common_agent.py:80) in ONE launch instead of a

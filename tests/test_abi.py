@@ -42,6 +42,8 @@ def test_ppo_header_symbols_exported_and_mirrored(hip_lib):
         assert hasattr(hip_lib, name), name
     text = open(os.path.join(REPO, "include", "vine_ppo.h")).read()
     assert int(re.search(r"#define VINE_PPO_PARTIAL_BLOCKS (\d+)", text).group(1)) == abi.PPO_PARTIAL_BLOCKS
+    m = re.search(r"#define VINE_ROLLOUT_POST_SCRATCH_FLOATS \((\d+) \* (\d+)\)", text)
+    assert int(m.group(1)) * int(m.group(2)) == abi.ROLLOUT_POST_SCRATCH_FLOATS
 
 
 def test_oracle_exports_every_symbol():

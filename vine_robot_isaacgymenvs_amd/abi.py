@@ -156,6 +156,7 @@ _I64 = C.c_int64
 _VP = C.c_void_p
 PPO_PARTIAL_BLOCKS = 512   # VINE_PPO_PARTIAL_BLOCKS
 PPO_LOSS_SCRATCH_FLOATS = 1024 * 32   # VINE_PPO_LOSS_SCRATCH_FLOATS
+ROLLOUT_POST_SCRATCH_FLOATS = 1024 * 3    # VINE_ROLLOUT_POST_SCRATCH_FLOATS
 RMS_BLOCKS = 128   # VINE_RMS_BLOCKS
 # include/vine_ppo.h (product library only; the oracle does not implement these)
 PPO_PROTOTYPES = {
@@ -183,9 +184,10 @@ PPO_PROTOTYPES = {
     "vine_copy_batched": (C.c_int, [C.c_int32] + [_VP] * 10 + [_VP]),
     "vine_column_sums_batched": (C.c_int, [C.c_int32] + [_VP] * 8 + [_VP]),
     "vine_column_sums": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_int32, _VP]),
-    "vine_policy_head": (C.c_int, [_I64, C.c_int32, _I64] + [_VP] * 8 + [C.c_int32, C.c_uint64] + [_VP] * 7),
+    "vine_policy_head": (C.c_int, [_I64, C.c_int32, _I64] + [_VP] * 8 + [C.c_int32, C.c_uint64] + [_VP] * 6 +
+                         [_VP, _VP, C.c_float, _VP]),
     "vine_rollout_post": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 7 + [C.c_float, _VP, _VP, _I64,
-                                                                                                  C.c_int32, _VP]),
+                                                                                                  C.c_int32, _VP, _VP]),
     "vine_gae": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP]),
     "vine_rms_update": (C.c_int, [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_normalize_obs": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _I64, C.c_int32, _VP]),

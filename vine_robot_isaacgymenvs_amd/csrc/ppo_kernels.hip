@@ -1766,7 +1766,9 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
                                                           unsigned seed_lo, unsigned seed_hi,
                                                           const long long* __restrict__ counter, float* __restrict__ mu_out,
                                                           float* __restrict__ sigma_out, float* __restrict__ value_out,
-                                                          float* __restrict__ action_out, float* __restrict__ neglogp_out) {
+                                                          float* __restrict__ action_out, float* __restrict__ neglogp_out,
+                                                          const float* __restrict__ ln_gamma,
+                                                          const float* __restrict__ ln_beta, float ln_eps) {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -1775,8 +1777,22 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
         float acc[HEAD_MAX_A + 1];
 #pragma unroll
         for (int k = 0; k <= HEAD_MAX_A; ++k) acc[k] = 0.0f;
+        // ln_gamma != NULL (H == 256 only): y is the raw LSTM output and the LayerNorm in front of the heads is applied
+        // here (same arithmetic as layernorm_fwd_kernel: two-pass mean / biased variance over the 256 units)
+        float ln_mean = 0.0f, ln_rstd = 1.0f;
+        if (ln_gamma) {
+            const float4 xv = ld4(y + e * H + 4 * lane);
+            ln_mean = wave_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 256.0f);
+            const float a = xv.x - ln_mean, b = xv.y - ln_mean, c = xv.z - ln_mean, d = xv.w - ln_mean;
+            ln_rstd = rsqrtf(wave_sum((a * a + b * b) + (c * c + d * d)) * (1.0f / 256.0f) + ln_eps);
+        }
         for (int j = lane * 4; j < H; j += 256) {
-            const float4 yy = ld4(y + e * H + j);
+            float4 yy = ld4(y + e * H + j);
+            if (ln_gamma) {
+                const float4 gm = ld4(ln_gamma + j), bt = ld4(ln_beta + j);
+                yy = make_float4((yy.x - ln_mean) * ln_rstd * gm.x + bt.x, (yy.y - ln_mean) * ln_rstd * gm.y + bt.y,
+                                 (yy.z - ln_mean) * ln_rstd * gm.z + bt.z, (yy.w - ln_mean) * ln_rstd * gm.w + bt.w);
+            }
 #pragma unroll
             for (int k = 0; k < HEAD_MAX_A; ++k) {
                 if (k < A) {
@@ -1824,49 +1840,85 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
     }
 }
 
-__global__ void rollout_post_kernel(long long N, int H, const float* __restrict__ rew, const long long* __restrict__ reset,
-                                    const unsigned char* __restrict__ timeouts, const float* __restrict__ values,
-                                    float shift, float scale, float gamma_b, float* __restrict__ shaped,
-                                    unsigned char* __restrict__ dones, float* __restrict__ cur_r, float* __restrict__ cur_l,
-                                    float* __restrict__ h_state, float* __restrict__ c_state, float* __restrict__ meter,
-                                    void* __restrict__ h_op, long long h_op_stride, int h_op_bf16) {
+#define ROLLOUT_POST_BLOCKS 1024
+__global__ __launch_bounds__(256) void rollout_post_kernel(
+    long long N, int H, const float* __restrict__ rew, const long long* __restrict__ reset,
+    const unsigned char* __restrict__ timeouts, const float* __restrict__ values, float shift, float scale, float gamma_b,
+    float* __restrict__ shaped, unsigned char* __restrict__ dones, float* __restrict__ cur_r, float* __restrict__ cur_l,
+    float* __restrict__ h_state, float* __restrict__ c_state, float* __restrict__ partial, void* __restrict__ h_op,
+    long long h_op_stride, int h_op_bf16) {
+    // 16 threads per env: thread 0 of the group keeps the books, all 16 clear the LSTM state rows of a finished env
+    // (256 contiguous bytes per group and pass).  The episode statistics leave as ONE {sum r, sum l, count} row per
+    // workgroup (no atomics: with float atomicAdd on three shared words this kernel took 126 us when 30 % of the
+    // envs finished in the same step, and the sum depended on the arrival order).
     float sr = 0.0f, sl = 0.0f, cnt = 0.0f;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < N; e += (long long)gridDim.x * blockDim.x) {
-        const float r = rew[e];
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < N * 16;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long e = idx >> 4;
+        const int k = (int)(idx & 15);
         const bool done = reset[e] != 0;
-        float s = (r + shift) * scale;
-        if (gamma_b != 0.0f && timeouts[e]) s += gamma_b * values[e];
-        shaped[e] = s;
-        dones[e] = done ? 1 : 0;
-        const float cr = cur_r[e] + r, cl = cur_l[e] + 1.0f;
-        if (done) {
-            sr += cr; sl += cl; cnt += 1.0f;
-            cur_r[e] = 0.0f; cur_l[e] = 0.0f;
-            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            for (int j = 0; j < H; j += 4) { st4(h_state + e * H + j, z); st4(c_state + e * H + j, z); }
-            if (h_op) {   // the GEMM-operand copy of h (column block of the [x | h] buffer of the fused inference)
-                if (h_op_bf16) for (int j = 0; j < H; j += 4) st4((bf16_t*)h_op + e * h_op_stride + j, z);
-                else for (int j = 0; j < H; j += 4) st4((float*)h_op + e * h_op_stride + j, z);
+        if (k == 0) {
+            const float r = rew[e];
+            float s = (r + shift) * scale;
+            if (gamma_b != 0.0f && timeouts[e]) s += gamma_b * values[e];
+            shaped[e] = s;
+            dones[e] = done ? 1 : 0;
+            const float cr = cur_r[e] + r, cl = cur_l[e] + 1.0f;
+            if (done) {
+                sr += cr; sl += cl; cnt += 1.0f;
+                cur_r[e] = 0.0f; cur_l[e] = 0.0f;
+            } else {
+                cur_r[e] = cr; cur_l[e] = cl;
             }
-        } else {
-            cur_r[e] = cr; cur_l[e] = cl;
+        }
+        if (done) {
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int j = 4 * k; j < H; j += 64) {
+                st4(h_state + e * H + j, z);
+                st4(c_state + e * H + j, z);
+                if (h_op) {   // the GEMM-operand copy of h (column block of the [x | h] buffer of the fused inference)
+                    if (h_op_bf16) st4((bf16_t*)h_op + e * h_op_stride + j, z);
+                    else st4((float*)h_op + e * h_op_stride + j, z);
+                }
+            }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        sr += __shfl_down(sr, off, 64); sl += __shfl_down(sl, off, 64); cnt += __shfl_down(cnt, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0 && cnt > 0.0f) {
-        atomicAdd(&meter[4], sr); atomicAdd(&meter[5], sl); atomicAdd(&meter[6], cnt);
-    }
+    sr = wave_sum(sr); sl = wave_sum(sl); cnt = wave_sum(cnt);
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave][0] = sr; red[wave][1] = sl; red[wave][2] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        partial[blockIdx.x * 3 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// rl_games AverageMeter.update for both meters from the step's (sum, count); then clear the temporaries.
-__global__ void rollout_finalize_kernel(float* __restrict__ meter, float max_size, long long* __restrict__ counter) {
-    const float size = meter[6];
+// rl_games AverageMeter.update for both meters from the step's (sum, count) -- the per-workgroup rows of the kernel
+// above summed in a fixed order by one 256-thread workgroup.
+__global__ __launch_bounds__(256) void rollout_finalize_kernel(float* __restrict__ meter, float max_size,
+                                                               long long* __restrict__ counter,
+                                                               const float* __restrict__ partial, int blocks) {
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    for (int b = threadIdx.x; b < blocks; b += 256) {
+        v[0] += partial[b * 3]; v[1] += partial[b * 3 + 1]; v[2] += partial[b * 3 + 2];
+    }
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v[k] = wave_sum(v[k]);
+        if (lane == 0) red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float sum_r = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    const float sum_l = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const float size = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
     if (size > 0.0f) {
         const float sc = fminf(size, max_size);
+        const float sums[2] = {sum_r, sum_l};
         for (int m = 0; m < 2; ++m) {
-            const float new_mean = meter[4 + m] / size;
+            const float new_mean = sums[m] / size;
             const float cur = meter[2 * m + 1];
             const float old_size = fminf(max_size - sc, cur);
             const float sum = old_size + sc;
@@ -1874,7 +1926,7 @@ __global__ void rollout_finalize_kernel(float* __restrict__ meter, float max_siz
             meter[2 * m + 1] = sum;
         }
     }
-    meter[4] = 0.0f; meter[5] = 0.0f; meter[6] = 0.0f;
+    meter[4] = sum_r; meter[5] = sum_l; meter[6] = size;      // this step's totals, for introspection
     counter[0] += 1;
 }
 
@@ -2338,18 +2390,19 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
                      const float* w_v, const float* b_v, const float* logstd, const float* value_mean,
                      const float* value_std, int32_t normalize_value, uint64_t seed, const int64_t* counter,
                      float* mu_out, float* sigma_out, float* value_out, float* action_out, float* neglogp_out,
-                     void* stream) {
+                     const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
     if (N <= 0 || A <= 0 || A > HEAD_MAX_A || H <= 0 || (H & 3) || !y || !w_mu || !b_mu || !w_v || !b_v || !logstd ||
         !counter || !mu_out || !sigma_out || !value_out || !action_out || !neglogp_out ||
-        (normalize_value && (!value_mean || !value_std)))
+        (normalize_value && (!value_mean || !value_std)) || ((ln_gamma == nullptr) != (ln_beta == nullptr)))
         return VINE_ERR_INVALID_ARG;
+    if (ln_gamma && H != 256) return VINE_ERR_UNSUPPORTED;
     const int threads = 256;                     // 4 waves per workgroup, one env per wave at a time
     long long blocks = (N + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(policy_head_kernel, dim3((int)blocks), dim3(threads), 0, (hipStream_t)stream, (long long)N, (int)A,
                        (int)H, y, w_mu, b_mu, w_v, b_v, logstd, value_mean, value_std, (int)normalize_value,
                        (unsigned)seed, (unsigned)(seed >> 32), (const long long*)counter, mu_out, sigma_out, value_out,
-                       action_out, neglogp_out);
+                       action_out, neglogp_out, ln_gamma, ln_beta, ln_eps);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -2357,17 +2410,20 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
                       const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
                       float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
                       float* c_state, float* meter, float max_size, int64_t* counter, void* h_op, int64_t h_op_stride,
-                      int32_t h_op_bf16, void* stream) {
+                      int32_t h_op_bf16, float* scratch, void* stream) {
     if (N <= 0 || H <= 0 || (H & 3) || !rew || !reset || !timeouts || !values || !shaped_out || !dones_out ||
-        !cur_rewards || !cur_lengths || !h_state || !c_state || !meter || !counter)
+        !cur_rewards || !cur_lengths || !h_state || !c_state || !meter || !counter || !scratch)
         return VINE_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int threads = 256;
-    hipLaunchKernelGGL(rollout_post_kernel, dim3(grid_for(N, threads)), dim3(threads), 0, s, (long long)N, (int)H, rew,
+    long long blocks = (N * 16 + threads - 1) / threads;
+    if (blocks > ROLLOUT_POST_BLOCKS) blocks = ROLLOUT_POST_BLOCKS;
+    hipLaunchKernelGGL(rollout_post_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, (long long)N, (int)H, rew,
                        (const long long*)reset, timeouts, values, reward_shift, reward_scale, gamma_bootstrap, shaped_out,
-                       dones_out, cur_rewards, cur_lengths, h_state, c_state, meter, h_op, (long long)h_op_stride,
+                       dones_out, cur_rewards, cur_lengths, h_state, c_state, scratch, h_op, (long long)h_op_stride,
                        (int)h_op_bf16);
-    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, s, meter, max_size, (long long*)counter);
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(256), 0, s, meter, max_size, (long long*)counter,
+                       (const float*)scratch, (int)blocks);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

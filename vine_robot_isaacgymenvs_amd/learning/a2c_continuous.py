@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 
 from . import fused
+from ..abi import ROLLOUT_POST_SCRATCH_FLOATS
 from .flat_adam import FlatAdam
 from .network import ModelA2CContinuousLogStd
 
@@ -321,6 +322,7 @@ class A2CAgent:
         if self.fused_rollout:
             # {rew_mean, rew_size, len_mean, len_size, tmp...}: written by vine_rollout_post; the meters are views
             self.meter = torch.zeros(8, **f32)
+            self._post_scratch = torch.empty(ROLLOUT_POST_SCRATCH_FLOATS, **f32)
             self.game_rewards.mean, self.game_rewards.current_size = self.meter[0:1], self.meter[1]
             self.game_lengths.mean, self.game_lengths.current_size = self.meter[2:3], self.meter[3]
             self.roll_counter = torch.zeros(1, device=dev, dtype=torch.int64)
@@ -361,6 +363,7 @@ class A2CAgent:
              "y": torch.empty((N, H), device=dev), "h_tmp": torch.empty((N, H), device=dev),
              "c_tmp": torch.empty((N, H), device=dev)}
         f["x0_sep"] = None if net.rnn_concat_input else torch.empty((N, F_in), device=dev, dtype=op)
+        f["ln_in_head"] = H == 256           # vine_policy_head applies the LayerNorm itself (one launch less per step)
         # padded layer-1 weight [units, 32] for the matrix-core kernel (mixed precision, concatenated input)
         f["w1p"] = None
         if (self.fused_mixed and net.rnn_concat_input and XW - U == 32
@@ -435,6 +438,8 @@ class A2CAgent:
                 c_out.data_ptr(), None, hp_ptr, None, 0, bf, XW + H, st), "vine_lstm_cell_forward")
         if commit:
             f["cur"] ^= 1
+        if f["ln_in_head"]:              # the policy-head kernel normalises (reads the state before rollout_post clears it)
+            return h_out
         y = f["y"]
         fused._check(lib.vine_layernorm_forward(N, H, h_out.data_ptr(), net.layer_norm.weight.data_ptr(),
                                                 net.layer_norm.bias.data_ptr(), float(net.layer_norm.eps), y.data_ptr(),
@@ -461,12 +466,17 @@ class A2CAgent:
         obs = self.obs
 
         def head(x, n_slot, value_out, mu_out, sigma_out, act_out, nlp_out):
+            # x: the LayerNorm output, or (fused inference with H == 256) the raw LSTM output: the head kernel then
+            # applies the LayerNorm itself
+            ln = net.layer_norm if (fast and self._fast["ln_in_head"]) else None
             fused._check(lib.vine_policy_head(
                 N, A, H, x.data_ptr(), net.mu.weight.data_ptr(), net.mu.bias.data_ptr(), net.value.weight.data_ptr(),
                 net.value.bias.data_ptr(), net.sigma.data_ptr(), vmean.data_ptr() if vmean is not None else None,
                 vstd.data_ptr() if vstd is not None else None, int(self.normalize_value), self.head_seed,
                 self.roll_counter.data_ptr(), mu_out.data_ptr(), sigma_out.data_ptr(), value_out.data_ptr(),
-                act_out.data_ptr(), nlp_out.data_ptr(), st), "vine_policy_head")
+                act_out.data_ptr(), nlp_out.data_ptr(), ln.weight.data_ptr() if ln is not None else None,
+                ln.bias.data_ptr() if ln is not None else None, float(ln.eps) if ln is not None else 0.0, st),
+                "vine_policy_head")
 
         def trunk(o):
             x = m.norm_obs(o)
@@ -508,7 +518,7 @@ class A2CAgent:
                 # the operand copy of h that the NEXT step reads (the buffer _infer just switched to)
                 (self._fast["xh2"][self._fast["cur"]].data_ptr()
                  + self._fast["xh2"][0].element_size() * self._fast["XW"]) if fast else None, h_op_stride,
-                h_op_bf16, st), "vine_rollout_post")
+                h_op_bf16, self._post_scratch.data_ptr(), st), "vine_rollout_post")
         self.obs = obs
         y = self._infer(obs, commit=False) if fast else trunk(obs)[0]
         scratch = self._head_scratch
