@@ -10,9 +10,9 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, XW=96):
     shapes (one LSTM time step of a 32768-sample minibatch), priced against HBM with their algorithmic bytes:
       lstm_step_mfma (forward step, GEMM fused): reads x_t bf16 [B,XW] + h_{t-1} bf16 [B,H] + c fp32 [B,H],
           writes h, c fp32, masked h bf16, 4 gate activations bf16                     -> B*(2*XW + 2*H + 4*H*3 + 2*H + 8*H) bytes
-      lstm_bwd (backward step): reads dh, g_rec, dc fp32, gates bf16 [B,4H], c_t, c_{t-1} fp32; writes dG bf16, dc fp32."""
+      lstm_step_backward_mfma (backward step, recurrent-gradient GEMM fused): reads dh, dc fp32, dG_{t+1} bf16 [B,4H],
+          gates bf16 [B,4H], c_t, c_{t-1} fp32; writes dG_t bf16 [B,4H], dc fp32     -> B * 44 H bytes"""
     from . import fused
-    from ..abi import PPO_PARTIAL_BLOCKS
     lib = fused._lib()
     st = torch.cuda.current_stream(device).cuda_stream
     bf = torch.bfloat16
@@ -24,24 +24,28 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, XW=96):
     c = torch.randn(T + 1, B, H, device=device)
     out = torch.empty(B, T, H, device=device)
     gates = torch.empty(T, B, 4 * H, device=device, dtype=bf)
-    g_out, g_rec = torch.randn(B, T, H, device=device), torch.randn(B, H, device=device)
+    g_out = torch.randn(B, T, H, device=device)
     dc = [torch.randn(B, H, device=device) for _ in range(2)]
     dG = torch.empty(B, T, 4 * H, device=device, dtype=bf)
-    part = torch.empty(2, PPO_PARTIAL_BLOCKS, 4 * H, device=device)
+    part = torch.empty(2, B // 64, 4 * H, device=device)
 
     def fwd():
         assert lib.vine_lstm_step_mfma(B, H, XW + H, x.data_ptr(), T * XW, hp.data_ptr(), T * H, XW, wcat.data_ptr(), XW + H,
                                        None, 4 * H, bias.data_ptr(), c[0].data_ptr(), None, 0, out.data_ptr(), T * H,
                                        c[1].data_ptr(), gates[0].data_ptr(), hp.data_ptr() + 2 * H, None, 0, T * H, st) == 0
 
+    whh_t = whh.t().contiguous()
+    dG.normal_()
+
     def bwd():
-        assert lib.vine_lstm_cell_backward(B, H, g_out.data_ptr(), T * H, g_rec.data_ptr(), dc[0].data_ptr(), None, 0,
-                                           gates[0].data_ptr(), c[1].data_ptr(), c[0].data_ptr(), None, 0, dG.data_ptr(),
-                                           T * 4 * H, dc[1].data_ptr(), part[0].data_ptr(), part[1].data_ptr(), 1, st) == 0
+        assert lib.vine_lstm_step_backward_mfma(B, H, g_out.data_ptr(), T * H, dG.data_ptr() + 2 * 4 * H, T * 4 * H,
+                                                whh_t.data_ptr(), 4 * H, dc[0].data_ptr(), None, 0, gates[0].data_ptr(),
+                                                c[1].data_ptr(), c[0].data_ptr(), None, 0, dG.data_ptr(), T * 4 * H,
+                                                dc[1].data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st) == 0
 
     res = []
-    for name, f, nbytes in (("lstm_step_mfma_kernel", fwd, B * (2 * XW + 2 * H + 4 * H + 8 * H + 2 * H + 8 * H)),
-                            ("lstm_bwd_kernel", bwd, B * (3 * 4 * H + 8 * H + 8 * H + 8 * H + 4 * H))):
+    for name, f, nbytes in (("lstm_step_mfma64_kernel", fwd, B * (2 * XW + 2 * H + 4 * H + 8 * H + 2 * H + 8 * H)),
+                            ("lstm_bwd_mfma_kernel", bwd, B * 44 * H)):
         for _ in range(10):
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
