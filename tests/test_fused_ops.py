@@ -640,11 +640,14 @@ def test_fused_update_equals_stock_update():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mixed", [False, True])
-def test_graphed_update_equals_eager_update(mixed):
-    """From the second iteration on every optimiser step is replayed from two hipGraphs (forward/backward | Adam +
-    schedule); five iterations with and without graphs must leave the same parameters, learning rate and loss
+@pytest.mark.parametrize("mixed,scope", [(False, "epoch"), (True, "epoch"), (True, "step")])
+def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
+    """From the second iteration on the update is replayed from hipGraphs: on one rank a whole mini-epoch per graph
+    (scope "epoch": one graph with and one without the running-statistics update), or per optimiser step two graphs
+    (forward/backward | Adam + schedule; scope "step", the form used with several ranks, where the all-reduce runs
+    between the two).  Five iterations with and without graphs must leave the same parameters, learning rate and loss
     statistics (fp32 and mixed-precision update)."""
+    monkeypatch.setenv("VINE_UPD_GRAPH", scope)
     from vine_robot_isaacgymenvs_amd import load_config
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
@@ -666,7 +669,8 @@ def test_graphed_update_equals_eager_update(mixed):
             _, _, stats = agent.train_epoch()
         torch.cuda.synchronize()
         if use_graphs:
-            assert len(agent._upd_graphs) == 2 * agent.num_minibatches and not getattr(agent, "_update_graphs_failed", False)
+            assert len(agent._upd_graphs) == (2 if scope == "epoch" else 2 * agent.num_minibatches)
+            assert not getattr(agent, "_update_graphs_failed", False)
         outs.append((torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone(), float(agent.lr),
                      {k: float(v) for k, v in stats.items()}, agent.model.running_mean_std.running_mean.clone()))
         env.close()
@@ -796,7 +800,7 @@ def test_ragged_sizes_through_the_whole_path(n_env, mb, obs_type, mixed):
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in agent.model.parameters())
     assert all(np.isfinite(float(v)) for v in stats.values())
-    assert agent._fast is not None and len(agent._upd_graphs) == 2 * agent.num_minibatches
+    assert agent._fast is not None and len(agent._upd_graphs) == 2      # mini-epoch graphs: with / without the RMS update
     env.close()
 
 

@@ -850,7 +850,17 @@ class A2CAgent:
         rows = self._stat_rows
         graphed = self._update_graphs_usable()
         kl_global = False
+        # one rank: nothing has to happen between the optimiser steps of a mini-epoch, so all of them replay as ONE
+        # hipGraph (4 graph launches per iteration instead of 64: the launch gaps were ~6 % of the update)
+        whole_epoch = graphed and not self.multi_gpu and os.environ.get("VINE_UPD_GRAPH", "epoch") == "epoch"
         for mini_ep in range(self.mini_epochs_num):
+            nb = self.num_minibatches
+            if whole_epoch and self._update_epoch_graphed(rows[mini_ep * nb:(mini_ep + 1) * nb]):
+                if self.normalize_input:
+                    self.model.running_mean_std.eval()
+                continue
+            whole_epoch = False            # capture refused: the flag set by the failure sends the steps below eager
+            graphed = graphed and not getattr(self, "_update_graphs_failed", False)
             for i in range(self.num_minibatches):
                 row = mini_ep * self.num_minibatches + i
                 if graphed and self._update_step_graphed(i, rows[row]):
@@ -910,6 +920,47 @@ class A2CAgent:
         rec["B"].replay()
         row_out.copy_(rec["stats"])   # this rank's [a_loss, c_loss, b_loss, entropy, kl, loss, 0, 0]
         return True
+
+    def _update_epoch_graphed(self, rows_out):
+        """All optimiser steps of one mini-epoch as one graph replay (single rank only: with more ranks the gradient
+        all-reduce has to run between the two halves of every step, see ``_update_step_graphed``)."""
+        key = ("epoch", bool(self.normalize_input and self.model.running_mean_std.training))
+        rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
+        if rec is None:
+            try:
+                rec = self._capture_update_epoch(key)
+            except RuntimeError as err:
+                print("hipGraph capture of the mini-epoch failed (%s); continuing with eager launches" % str(err)[:200])
+                self._update_graphs_failed = True
+                self._kl_in_comm = False
+                torch.cuda.synchronize(self.device)
+                return False
+        rec["G"].replay()
+        rows_out.copy_(rec["stats"])
+        return True
+
+    def _capture_update_epoch(self, key):
+        if not hasattr(self, "_upd_graphs"):
+            self._upd_graphs = {}
+            self._upd_pool = torch.cuda.graph_pool_handle()
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        pool = None if os.environ.get("VINE_UPD_POOL") == "separate" else self._upd_pool
+        nb = self.num_minibatches
+        stats_all = torch.zeros((nb, 8), device=self.device, dtype=torch.float32)     # (never allocate zeros in capture)
+        keep = []
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            for i in range(nb):
+                mb = self.get_minibatch(i)
+                stats, mu_d, _logstd_d = self._fused_grad_half(mb)
+                self.optimizer.step(grad_scale=1.0 / self.rank_size)
+                self._kl_in_comm = True
+                self.update_lr_from_kl(self.optimizer.aux[0])
+                stats_all[i].copy_(stats)
+                keep.append((mb, stats, mu_d))
+        rec = {"G": g, "stats": stats_all, "keep": keep}
+        self._upd_graphs[key] = rec
+        return rec
 
     def _capture_update_step(self, i, key):
         if not hasattr(self, "_upd_graphs"):
