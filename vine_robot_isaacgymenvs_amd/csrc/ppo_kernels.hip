@@ -11,12 +11,15 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 VALU instructions): the LSTM step kernel spent 800 of
+// its 1800 VALU instructions per wave on the 80 divisions of its gate non-linearities
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-    // tanh via exp of -2|x|: accurate to ~1e-7 relative, no overflow
+    // tanh via exp of -2|x|: accurate to ~2e-7 relative, no overflow
     const float ax = fabsf(x);
     const float e = __expf(-2.0f * ax);
-    const float t = (1.0f - e) / (1.0f + e);
+    const float t = (1.0f - e) * rcpf_(1.0f + e);
     return copysignf(t, x);
 }
 
