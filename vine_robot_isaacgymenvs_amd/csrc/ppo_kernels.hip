@@ -948,10 +948,22 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_
 }
 
 // ---- LayerNorm over rows of H = 256 * NV floats: one wave per row, lane l owns columns [256 v + 4 l, +4) ----
+// Sum over the 64 lanes, returned to every lane: DPP row shifts and row broadcasts (7 VALU adds with a lane-shifted
+// operand, total in lane 63) + one v_readlane, instead of 6 ds_bpermute round trips through the LDS crossbar.
+// Needs all 64 lanes active (every caller runs it from wave-uniform control flow).
+__device__ __forceinline__ float dpp_i2f(int x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ int dpp_f2i(float x) { return __builtin_bit_cast(int, x); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    const int x = dpp_f2i(v);
+    // row_shr:1..3 of the input: lane i of a 16-lane row holds v[i-3 .. i] (lanes shifted in from outside the row: 0)
+    float s = v + dpp_i2f(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, x, 0x113, 0xf, 0xf, true));
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x114, 0xf, 0xe, true));    // row_shr:4 into lanes 4..15
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x118, 0xf, 0xc, true));    // row_shr:8 into lanes 8..15
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x142, 0xa, 0xf, true));    // row_bcast:15 into rows 1, 3
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x143, 0xc, 0xf, true));    // row_bcast:31 into rows 2, 3
+    return dpp_i2f(__builtin_amdgcn_readlane(dpp_f2i(s), 63));
 }
 
 template <int NV>
@@ -1809,9 +1821,7 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
 #pragma unroll
         for (int k = 0; k <= HEAD_MAX_A; ++k) {
             if (k < A || k == HEAD_MAX_A) {
-                float x = acc[k];
-                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-                acc[k] = x;
+                acc[k] = wave_sum(acc[k]);
             }
         }
         if (lane == 0) {
