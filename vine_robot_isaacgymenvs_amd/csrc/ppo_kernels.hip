@@ -1653,9 +1653,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
     vals[4] = 0.0f;
     for (int k = 0; k < PPO_MAX_A; ++k) vals[5 + k] = (k < A) ? gls[k] : 0.0f;
     for (int k = 0; k <= PPO_MAX_A; ++k) vals[5 + PPO_MAX_A + k] = gmb[k];
+#pragma unroll
     for (int q = 0; q < NRED; ++q) {
-        float x = vals[q];
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        // slots of actions k >= A hold zeros: skip their reductions (A is uniform, so is the branch)
+        const bool live = q < 4 || (q >= 5 && q < 5 + A) || (q >= 5 + PPO_MAX_A && q < 5 + PPO_MAX_A + A) ||
+                          q == 5 + 2 * PPO_MAX_A;
+        const float x = live ? wave_sum(vals[q]) : 0.0f;
         if (lane == 0) red[wave][q] = x;
     }
     __syncthreads();
@@ -1678,7 +1681,15 @@ __global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(int blocks, int 
                                                                 float* __restrict__ logstd_grad_accum) {
     const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
     float acc = 0.0f;
-    for (int b = rl; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
+    int b = rl;
+    for (; b + 56 < blocks; b += 64) {                      // 8 rows in flight per thread, same order as one at a time
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partial[(long long)(b + 8 * k) * PPO_LOSS_ROW + q];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
     __shared__ float red[8][PPO_LOSS_ROW];
     __shared__ float tot[PPO_LOSS_ROW];
     red[rl][q] = acc;
