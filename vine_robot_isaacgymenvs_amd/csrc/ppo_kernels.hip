@@ -1110,12 +1110,27 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(long long n, int F, co
     const int rlanes = 256 / F;
     const int rl = threadIdx.x / F, c = threadIdx.x - rl * F;
     double s = 0.0, ss = 0.0;
-    if (rl < rlanes)
-        for (long long r = (long long)blockIdx.x * rlanes + rl; r < n; r += (long long)gridDim.x * rlanes) {
+    if (rl < rlanes) {
+        // 8 rows in flight per thread (a rolled loop pays one memory round trip per row); same summation order
+        const long long step = (long long)gridDim.x * rlanes;
+        long long r = (long long)blockIdx.x * rlanes + rl;
+        for (; r + 7 * step < n; r += 8 * step) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = x[(r + k * step) * F + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double d = (double)v[k];
+                s += d;
+                ss += d * d;
+            }
+        }
+        for (; r < n; r += step) {
             const double v = (double)x[r * F + c];
             s += v;
             ss += v * v;
         }
+    }
     __shared__ double red[2][256];
     red[0][threadIdx.x] = rl < rlanes ? s : 0.0;
     red[1][threadIdx.x] = rl < rlanes ? ss : 0.0;
@@ -1135,11 +1150,23 @@ __global__ __launch_bounds__(256) void rms_finalize_kernel(int blocks, int F, lo
     // 64 column lanes x 4 row lanes over the partial rows, folded through LDS in a fixed order
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     double s = 0.0, ss = 0.0;
-    if (c < F)
-        for (int b = rl; b < blocks; b += 4) {
+    if (c < F) {
+        int b = rl;
+        for (; b + 28 < blocks; b += 32) {                  // 8 partial rows in flight per thread, same order
+            double v[8], w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = partial[(long long)(b + 4 * k) * 2 * F + c];
+                w[k] = partial[(long long)(b + 4 * k) * 2 * F + F + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += v[k]; ss += w[k]; }
+        }
+        for (; b < blocks; b += 4) {
             s += partial[(long long)b * 2 * F + c];
             ss += partial[(long long)b * 2 * F + F + c];
         }
+    }
     __shared__ double red[2][4][64];
     red[0][rl][c] = s;
     red[1][rl][c] = ss;
