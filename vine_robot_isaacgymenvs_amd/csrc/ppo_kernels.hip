@@ -310,6 +310,13 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     LOAD_W(wa, 0);
     if (KSTEPS > 1) { LOAD_W(wb, 1); }
     if (KSTEPS > 2) { LOAD_W(wc, 2); }
+    // operands of the pointwise part (thread -> unit quad pq of rows prg + 16 p), requested now so that their HBM
+    // round trip runs under the matrix work instead of after it
+    const int pq = threadIdx.x & 15, prg = threadIdx.x >> 4;
+    float4 cpre[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        cpre[p] = ld4(c_prev + ((long long)blockIdx.x * 64 + prg + 16 * p) * H + u0 + 4 * pq);
     STORE_W(wa, 0);
     __syncthreads();
     LSTM_STEP(0, wc, wb) LSTM_STEP(1, wa, wc) LSTM_STEP(2, wb, wa) LSTM_STEP(3, wc, wb)
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
                 pre[g][0] += ig.x; pre[g][1] += ig.y; pre[g][2] += ig.z; pre[g][3] += ig.w;
             }
         }
-        const float4 cp = ld4(c_prev + b * H + j);
+        const float4 cp = cpre[p];
         const float cpv[4] = {cp.x, cp.y, cp.z, cp.w};
         float gi[4], gf[4], gg[4], go[4], cn[4], hn[4];
 #pragma unroll
@@ -724,6 +731,17 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     float* gt = reinterpret_cast<float*>(&wl[0][0]);           // 64 x 68 floats == one weight buffer
+    // pointwise part: thread -> unit quad q of rows rg, rg + 16, rg + 32, rg + 48.  The operands of its first pass are
+    // requested here, ahead of the matrix work, so that their HBM round trip is not exposed after the hand-over (the
+    // later passes' loads overlap with the arithmetic of the pass before them)
+    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int j = u0 + 4 * q;
+    const long long b0 = (long long)blockIdx.x * 64 + rg;
+    const float4 pre_go = ld4(g_out + b0 * g_stride + j);
+    const float4 pre_dc = dc_next ? ld4(dc_next + b0 * H + j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 pre_i = ld4(gates_act + b0 * 4LL * H + j), pre_f = ld4(gates_act + b0 * 4LL * H + H + j);
+    const float4 pre_g = ld4(gates_act + b0 * 4LL * H + 2 * H + j), pre_o = ld4(gates_act + b0 * 4LL * H + 3 * H + j);
+    const float4 pre_cn = ld4(c_new + b0 * H + j), pre_cp = ld4(c_prev + b0 * H + j);
     if (NCH > 0) {
         const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
         const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
@@ -783,9 +801,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
                 make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
         __syncthreads();
     }
-    // ---- pointwise backward: thread -> unit quad q of rows rg, rg + 16, rg + 32, rg + 48
-    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int j = u0 + 4 * q;
+    // ---- pointwise backward
     float bsum[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) bsum[u] = 0.0f;
@@ -795,7 +811,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
         const long long b = (long long)blockIdx.x * 64 + r;
         const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
         const float keep_n = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
-        const float4 go4 = ld4(g_out + b * g_stride + j);
+        const float4 go4 = p == 0 ? pre_go : ld4(g_out + b * g_stride + j);
         float dh[4] = {go4.x, go4.y, go4.z, go4.w};
         float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (NCH > 0) {
@@ -803,12 +819,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
             dh[0] += keep_n * rr.x; dh[1] += keep_n * rr.y; dh[2] += keep_n * rr.z; dh[3] += keep_n * rr.w;
         }
         if (dc_next) {
-            const float4 rr = ld4(dc_next + b * H + j);
+            const float4 rr = p == 0 ? pre_dc : ld4(dc_next + b * H + j);
             dc[0] = keep_n * rr.x; dc[1] = keep_n * rr.y; dc[2] = keep_n * rr.z; dc[3] = keep_n * rr.w;
         }
         const bf16_t* ga = gates_act + b * 4LL * H;
-        const float4 i4 = ld4(ga + j), f4 = ld4(ga + H + j), g4 = ld4(ga + 2 * H + j), o4 = ld4(ga + 3 * H + j);
-        const float4 cn4 = ld4(c_new + b * H + j), cp4 = ld4(c_prev + b * H + j);
+        const float4 i4 = p == 0 ? pre_i : ld4(ga + j), f4 = p == 0 ? pre_f : ld4(ga + H + j);
+        const float4 g4 = p == 0 ? pre_g : ld4(ga + 2 * H + j), o4 = p == 0 ? pre_o : ld4(ga + 3 * H + j);
+        const float4 cn4 = p == 0 ? pre_cn : ld4(c_new + b * H + j), cp4 = p == 0 ? pre_cp : ld4(c_prev + b * H + j);
         const float gi[4] = {i4.x, i4.y, i4.z, i4.w}, gf[4] = {f4.x, f4.y, f4.z, f4.w};
         const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, go[4] = {o4.x, o4.y, o4.z, o4.w};
         const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
