@@ -314,9 +314,14 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     // round trip runs under the matrix work instead of after it
     const int pq = threadIdx.x & 15, prg = threadIdx.x >> 4;
     float4 cpre[4];
+    float keep_pre[4], kn_pre[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-        cpre[p] = ld4(c_prev + ((long long)blockIdx.x * 64 + prg + 16 * p) * H + u0 + 4 * pq);
+    for (int p = 0; p < 4; ++p) {
+        const long long bp = (long long)blockIdx.x * 64 + prg + 16 * p;
+        cpre[p] = ld4(c_prev + bp * H + u0 + 4 * pq);
+        keep_pre[p] = done ? 1.0f - (float)done[bp * done_stride] : 1.0f;
+        kn_pre[p] = (hp_next && done_next) ? 1.0f - (float)done_next[bp * done_next_stride] : 1.0f;
+    }
     STORE_W(wa, 0);
     __syncthreads();
     LSTM_STEP(0, wc, wb) LSTM_STEP(1, wa, wc) LSTM_STEP(2, wb, wa) LSTM_STEP(3, wc, wb)
@@ -351,8 +356,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     for (int p = 0; p < 4; ++p) {
         const int r = rg + 16 * p;
         const long long b = (long long)blockIdx.x * 64 + r;
-        const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
-        const float kn = (hp_next && done_next) ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+        const float keep = keep_pre[p], kn = kn_pre[p];
         float pre[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -742,6 +746,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
     const float4 pre_i = ld4(gates_act + b0 * 4LL * H + j), pre_f = ld4(gates_act + b0 * 4LL * H + H + j);
     const float4 pre_g = ld4(gates_act + b0 * 4LL * H + 2 * H + j), pre_o = ld4(gates_act + b0 * 4LL * H + 3 * H + j);
     const float4 pre_cn = ld4(c_new + b0 * H + j), pre_cp = ld4(c_prev + b0 * H + j);
+    float keep_pre[4], keepn_pre[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        keep_pre[p] = done ? 1.0f - (float)done[(b0 + 16 * p) * done_stride] : 1.0f;
+        keepn_pre[p] = done_next ? 1.0f - (float)done_next[(b0 + 16 * p) * done_next_stride] : 1.0f;
+    }
     if (NCH > 0) {
         const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
         const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
@@ -809,8 +819,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
     for (int p = 0; p < 4; ++p) {
         const int r = rg + 16 * p;
         const long long b = (long long)blockIdx.x * 64 + r;
-        const float keep = done ? 1.0f - (float)done[b * done_stride] : 1.0f;
-        const float keep_n = done_next ? 1.0f - (float)done_next[b * done_next_stride] : 1.0f;
+        const float keep = keep_pre[p], keep_n = keepn_pre[p];
         const float4 go4 = p == 0 ? pre_go : ld4(g_out + b * g_stride + j);
         float dh[4] = {go4.x, go4.y, go4.z, go4.w};
         float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
