@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VINE_ABI_VERSION 1
+#define VINE_ABI_VERSION 2         /* 2: VineConfig.env_id_offset, VINE_FLAG_INTROSPECT, vine_set_introspection, vine_stats */
 #define VINE_NUM_LINKS 5          /* N_REVOLUTE_DOFS, V5:54 */
 #define VINE_NUM_DOFS 6           /* 1 prismatic + 5 revolute, V5:83 */
 #define VINE_NUM_ACTIONS 2        /* V5:171 */
@@ -81,8 +81,14 @@ enum {
     VINE_FLAG_FPAM_DAMPING_HELD              = 1u << 13, /* hold the C*qd torque term over the sim step exactly as V5:1062 does
                                                             (unstable with the reference coefficients in this integrator; default off:
                                                             C joins the implicitly integrated DOF damping) */
-    VINE_FLAG_CREATE_PIPE                    = 1u << 14  /* TY:35 CREATE_PIPE: the 13.8 cm-ID tube of assets/urdf/pipe as its planar
+    VINE_FLAG_CREATE_PIPE                    = 1u << 14, /* TY:35 CREATE_PIPE: the 13.8 cm-ID tube of assets/urdf/pipe as its planar
                                                             cross-section (two walls), pose and object_info per V5:841-885 */
+    VINE_FLAG_INTROSPECT                     = 1u << 15  /* also store the fields the step itself never reads back -- the reference
+                                                            exposes them as attributes / dashboard inputs (V5:231-235, 937, 1094,
+                                                            1250-1322): VF_PREV_Q0.., VF_PREV_TIP_*, VF_TIP_VY/VZ, VF_U_FPAM, VF_U_RAIL,
+                                                            VF_PREV_U_RAIL, VF_RAIL_FORCE, VF_CONTACT_MEAN.  Off by default (they are
+                                                            ~70 B of the step's HBM traffic per env); vine_bind_reward_matrix and
+                                                            vine_set_introspection arm it, vine_stats needs it. */
 };
 
 /* Flat POD configuration = TY `env.*`, `sim.*`, `task.*` + URDF constants. */
@@ -135,6 +141,10 @@ typedef struct VineConfig {
     float fpam_b[VINE_NUM_LINKS];    /* V5:1047 */
     float fpam_B[VINE_NUM_LINKS];    /* V5:1048 */
     float obs_scaling[VINE_MAX_OBS]; /* V5:246-266 (ones when SCALE_OBSERVATIONS is off) */
+    int32_t env_id_offset;           /* global id of env 0 of this handle: the counter-based RNG is keyed by
+                                        (seed, env_id_offset + env, step, purpose), so a shard of a larger batch (one rank of a
+                                        strong-scaling run; the reference shards by giving every rank its own seed, TR:78)
+                                        draws exactly what the same envs draw inside the whole batch.  0 by default. */
 } VineConfig;
 
 /* Persistent per-env state, struct-of-arrays: field f of env e lives at
@@ -232,6 +242,38 @@ int vine_set_step_count(VineHandle* h, int64_t step_count);
 /* Per-term reward matrix of the last step, [N,13] row-major (reward_matrix of V5:1272; device/host
  * pointer matching the handle).  Optional: pass NULL to vine_bind_reward_matrix to stop writing it. */
 int vine_bind_reward_matrix(VineHandle* h, float* reward_matrix);
+
+/* Arm / disarm VINE_FLAG_INTROSPECT for the steps launched from now on (a step already captured in a hipGraph keeps the
+ * setting it was captured with).  vine_bind_reward_matrix(non-NULL) arms it too. */
+int vine_set_introspection(VineHandle* h, int on);
+
+/* The dashboard scalars of compute_reward (V5:1250-1322: the ~120 `.mean()/.max()/.item()` the reference evaluates every
+ * step) from the state the LAST vine_step left behind, as one two-stage reduction on the device (no atomics, no
+ * memset: graph-capturable; bit-reproducible).  out[VINE_NUM_STATS] on the handle's device (host memory for the
+ * oracle), layout = VineStat below; the per-term reward entries need a bound reward matrix (else they are 0), the
+ * introspection-only inputs need VINE_FLAG_INTROSPECT (else VINE_ERR_INVALID_ARG).  rew/progress: the step's
+ * rew_buf / progress_buf. */
+#define VINE_NUM_STATS 128
+typedef enum VineStat {
+    VS_DIST_MEAN = 0,          /* dist_tip_to_target                               V5:1250 */
+    VS_TARGET_REACHED,         /* mean(dist < SUCCESS_DIST)                        V5:1251 */
+    VS_LIMIT_HIT,              /* mean(|cart_y| > RAIL_SOFT_LIMIT)                 V5:1252 */
+    VS_TIP_LIMIT_HIT,          /* mean(tip_y < target_y)                           V5:1253 */
+    VS_ABS_TIP_Y, VS_TIP_Z, VS_MAX_ABS_TIP_Y, VS_MAX_TIP_Z,                     /* V5:1254-1257 */
+    VS_TIP_VEL_MEAN, VS_TIP_VEL_MAX,                                            /* V5:1258-1259 */
+    VS_U_RAIL_ABS, VS_PREV_U_RAIL_ABS, VS_RAIL_FORCE_ABS, VS_U_FPAM_ABS, VS_SMOOTHED_ABS,  /* V5:1260-1264 */
+    VS_PROGRESS_MEAN,          /* progress_buf                                     V5:1266 */
+    VS_CONTACT_MEAN, VS_CONTACT_NONZERO,                                        /* V5:1267-1268 */
+    VS_AGG_MEAN, VS_AGG_STD,   /* aggregated_rew_buf mean / unbiased std           V5:1279-1281 */
+    VS_REW_MEAN, VS_REW_MAX,   /* Mean / Max Total Reward                          V5:1285-1286 */
+    VS_VIEW0 = 24,             /* 28 values of env `index_to_view` (V5:1287-1322): q(6), qd(6), prev_q(6), tip y/z/vy/vz,
+                                  prev tip y/z, cart y/vy, target y/z */
+    VS_VIEW_U = VS_VIEW0 + 28, /* u_fpam, smoothed, u_rail, rail_force, contact_mean of that env */
+    VS_TERM0 = 64,             /* per reward term k = 0..12: mean, max, min of the UNWEIGHTED term at VS_TERM0 + 3k, +1, +2
+                                  (V5:1272-1284; the weighted entries follow on the host: w * mean, w >= 0 ? w * max : w * min) */
+    VS_COUNT_USED = VS_TERM0 + 3 * VINE_NUM_REWARDS
+} VineStat;
+int vine_stats(VineHandle* h, const float* rew, const int64_t* progress, int64_t index_to_view, float* out, void* stream);
 
 const char* vine_last_error(void);
 const char* vine_backend_name(void);   /* "hip-gfx950" or "oracle-f64"/"oracle-f32" */

@@ -93,6 +93,7 @@ static inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.
 enum { RNG_RESET = 1, RNG_ACTION_NOISE = 2, RNG_DYN_SCALE = 3, RNG_OBS_NOISE = 4 };
 
 static void rng4(uint64_t seed, uint32_t env, uint64_t step, uint32_t purpose, uint32_t idx, uint32_t out[4]) {
+    /* env = global env id (VineConfig.env_id_offset + local index) */
     philox4x32_10(env, (uint32_t)step, purpose | ((uint32_t)(step >> 32) << 8), idx,
                   (uint32_t)seed, (uint32_t)(seed >> 32), out);
 }
@@ -194,6 +195,12 @@ typedef struct Model {
     real a[NL][NL];    /* a_ij = L b_max(i,j) (i!=j); a_ii = m_i l^2 + L^2 sum_{k>i} m_k + I_i */
     real mtot;
     int implicit_damping;
+    /* probe switches of tests/test_oracle_physics.py (unverifiable Isaac Gym / PhysX defaults); all off
+     * by default and never part of the product: joint armature (added to the joint-space inertia), clamp of the
+     * links' world angular velocity (AssetOptions.max_angular_velocity, 64 rad/s), clamp of the joint velocities
+     * (PhysX maxJointVelocity, 100 rad/s), joint efforts applied during the first substep of a simulate only */
+    real armature, vmax_link, vmax_joint;
+    int effort_first_substep_only;
 } Model;
 
 static void model_init(Model* M, const VineConfig* c) {
@@ -201,6 +208,7 @@ static void model_init(Model* M, const VineConfig* c) {
     M->phi0 = c->phi0; M->g = c->gravity; M->d = c->damping; M->kq = c->stiffness;
     M->cad = c->link_angular_damping;
     M->implicit_damping = (c->flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) != 0;
+    M->armature = 0; M->vmax_link = 0; M->vmax_joint = 0; M->effort_first_substep_only = 0;
     M->mtot = M->mc;
     for (int i = 0; i < NL; ++i) { M->m[i] = c->link_mass[i]; M->I[i] = c->link_inertia[i]; M->mtot += M->m[i]; }
     for (int i = 0; i < NL; ++i) {
@@ -259,8 +267,9 @@ static void passive_forces(const Model* M, const real* cj, const real* q, const 
  * matrix, in relative coordinates: h * d(-Q)/d(qd). */
 static void implicit_matrix(const Model* M, const real* cj, real h, real D[ND][ND]) {
     memset(D, 0, sizeof(real) * ND * ND);
+    for (int i = 1; i < ND; ++i) D[i][i] = M->armature;
     if (!M->implicit_damping) return;
-    for (int i = 0; i < ND; ++i) D[i][i] = h * cj[i];
+    for (int i = 0; i < ND; ++i) D[i][i] += h * cj[i];
     if (M->cad != 0)
         for (int i = 0; i < NL; ++i)
             for (int j = 0; j < NL; ++j) {
@@ -370,7 +379,7 @@ static int fd_aba(const Model* M, const real* cj, const real* q, const real* qd,
         U[i] = v3(Ii[0][0] * S[i].w + Ii[0][1] * S[i].y + Ii[0][2] * S[i].z,
                   Ii[1][0] * S[i].w + Ii[1][1] * S[i].y + Ii[1][2] * S[i].z,
                   Ii[2][0] * S[i].w + Ii[2][1] * S[i].y + Ii[2][2] * S[i].z);
-        Dj[i] = dot3(S[i], U[i]) + (M->implicit_damping ? h * cj[i] : 0);
+        Dj[i] = dot3(S[i], U[i]) + (M->implicit_damping ? h * cj[i] : 0) + (i > 0 ? M->armature : 0);
         u[i] = Q[i] - dot3(S[i], pA[i]);
         if (i > 0) {
             real Ua[3] = {U[i].w, U[i].y, U[i].z};
@@ -443,6 +452,11 @@ static int fd_abs(const Model* M, const real* cj, real ycart, const real* th, re
             if (i < NL - 1) { A[i + 1][i + 2] -= h * cn; A[i + 2][i + 1] -= h * cn; }
         }
     }
+    if (M->armature != 0)      /* T^T diag(armature) T, same tridiagonal pattern */
+        for (int i = 0; i < NL; ++i) {
+            A[i + 1][i + 1] += M->armature * (i < NL - 1 ? 2 : 1);
+            if (i < NL - 1) { A[i + 1][i + 2] -= M->armature; A[i + 2][i + 1] -= M->armature; }
+        }
     for (int i = 0; i < ND; ++i) acc[i] = r[i];
     return chol_solve(ND, A, acc);
 }
@@ -512,7 +526,18 @@ static int substep(const Model* M, int form, const real* cj, real* q, real* qd, 
     real qdd[ND];
     int rc = forward_dynamics(M, form, cj, q, qd, eff, h, qdd);
     if (rc) return rc;
-    for (int i = 0; i < ND; ++i) { qd[i] += h * qdd[i]; q[i] += h * qd[i]; }
+    for (int i = 0; i < ND; ++i) qd[i] += h * qdd[i];
+    if (M->vmax_link > 0) {          /* clamp of the links' world angular velocities */
+        real w = 0, prev = 0;
+        for (int k = 0; k < NL; ++k) {
+            w += qd[k + 1];                       /* world rate of link k before the clamp */
+            real wc = w > M->vmax_link ? M->vmax_link : (w < -M->vmax_link ? -M->vmax_link : w);
+            qd[k + 1] = wc - prev; prev = wc;
+        }
+    }
+    if (M->vmax_joint > 0)
+        for (int i = 1; i < ND; ++i) qd[i] = qd[i] > M->vmax_joint ? M->vmax_joint : (qd[i] < -M->vmax_joint ? -M->vmax_joint : qd[i]);
+    for (int i = 0; i < ND; ++i) q[i] += h * qd[i];
     return 0;
 }
 /* exported for tests: n substeps with constant efforts */
@@ -916,6 +941,11 @@ void vine_oracle_pull_mirror(VineHandle* h) {
     for (size_t i = 0; i < cnt; ++i) h->st[i] = (real)h->st_f32[i];
 }
 void* vine_oracle_state(VineHandle* h) { return h->st; }
+/* probe switches (see Model); oracle-only, used by the physics-assumption sweep in tests/test_oracle_physics.py */
+void vine_oracle_set_probe(VineHandle* h, double armature, double vmax_link, double vmax_joint, int effort_first_substep_only) {
+    h->model.armature = (real)armature; h->model.vmax_link = (real)vmax_link; h->model.vmax_joint = (real)vmax_joint;
+    h->model.effort_first_substep_only = effort_first_substep_only;
+}
 void vine_oracle_set_formulation(VineHandle* h, int form) { h->form = form; }
 
 static int validate(const VineConfig* c) {
@@ -973,6 +1003,59 @@ int64_t vine_get_step_count(VineHandle* h) { return h->step_count; }
 int vine_set_step_count(VineHandle* h, int64_t s) { h->step_count = s; return VINE_OK; }
 int vine_bind_reset_values(VineHandle* h, const float* v) { h->reset_values = v; return VINE_OK; }
 int vine_bind_reward_matrix(VineHandle* h, float* rm) { h->reward_matrix = rm; return VINE_OK; }
+int vine_set_introspection(VineHandle* h, int on) { (void)h; (void)on; return VINE_OK; }   /* the oracle always stores every field */
+
+/* vine_stats: the dashboard scalars of V5:1250-1322 from the state the last step left behind (plain loops, double). */
+int vine_stats(VineHandle* h, const float* rew, const int64_t* progress, int64_t view, float* out, void* stream) {
+    (void)stream;
+    if (!h || !rew || !progress || !out || view < 0 || view >= h->n) return fail(VINE_ERR_INVALID_ARG, "bad argument to vine_stats");
+    const VineConfig* c = &h->cfg;
+    const int n = h->n;
+    double s[VINE_NUM_STATS]; memset(s, 0, sizeof s);
+    double mx_ty = -1e300, mx_tz = -1e300, mx_tv = -1e300, mx_rew = -1e300, agg_sum = 0;
+    for (int e = 0; e < n; ++e) {
+        double ty = ST(h, VF_TIP_Y, e), tz = ST(h, VF_TIP_Z, e), gy = ST(h, VF_TARGET_Y, e), gz = ST(h, VF_TARGET_Z, e);
+        double dist = sqrt((ty - gy) * (ty - gy) + (tz - gz) * (tz - gz));
+        double cy = ST(h, VF_CART_Y, e), tv = sqrt((double)ST(h, VF_TIP_VY, e) * ST(h, VF_TIP_VY, e) + (double)ST(h, VF_TIP_VZ, e) * ST(h, VF_TIP_VZ, e));
+        double cm = ST(h, VF_CONTACT_MEAN, e);
+        s[VS_DIST_MEAN] += dist; s[VS_TARGET_REACHED] += dist < (double)c->success_dist;
+        s[VS_LIMIT_HIT] += (cy > (double)c->rail_soft_limit) || (cy < -(double)c->rail_soft_limit);
+        s[VS_TIP_LIMIT_HIT] += ty < gy; s[VS_ABS_TIP_Y] += fabs(ty); s[VS_TIP_Z] += tz;
+        if (fabs(ty) > mx_ty) mx_ty = fabs(ty);
+        if (tz > mx_tz) mx_tz = tz;
+        if (tv > mx_tv) mx_tv = tv;
+        s[VS_TIP_VEL_MEAN] += tv;
+        s[VS_U_RAIL_ABS] += fabs((double)ST(h, VF_U_RAIL, e)); s[VS_PREV_U_RAIL_ABS] += fabs((double)ST(h, VF_PREV_U_RAIL, e));
+        s[VS_RAIL_FORCE_ABS] += fabs((double)ST(h, VF_RAIL_FORCE, e)); s[VS_U_FPAM_ABS] += fabs((double)ST(h, VF_U_FPAM, e));
+        s[VS_SMOOTHED_ABS] += fabs((double)ST(h, VF_SMOOTHED_U, e)); s[VS_PROGRESS_MEAN] += (double)progress[e];
+        s[VS_CONTACT_MEAN] += cm; s[VS_CONTACT_NONZERO] += cm > 0;
+        agg_sum += ST(h, VF_AGG_REW, e);
+        s[VS_REW_MEAN] += rew[e];
+        if (rew[e] > mx_rew) mx_rew = rew[e];
+    }
+    static const int means[] = {VS_DIST_MEAN, VS_TARGET_REACHED, VS_LIMIT_HIT, VS_TIP_LIMIT_HIT, VS_ABS_TIP_Y, VS_TIP_Z,
+                                VS_TIP_VEL_MEAN, VS_U_RAIL_ABS, VS_PREV_U_RAIL_ABS, VS_RAIL_FORCE_ABS, VS_U_FPAM_ABS,
+                                VS_SMOOTHED_ABS, VS_PROGRESS_MEAN, VS_CONTACT_MEAN, VS_CONTACT_NONZERO, VS_REW_MEAN};
+    for (size_t i = 0; i < sizeof means / sizeof means[0]; ++i) s[means[i]] /= n;
+    s[VS_MAX_ABS_TIP_Y] = mx_ty; s[VS_MAX_TIP_Z] = mx_tz; s[VS_TIP_VEL_MAX] = mx_tv; s[VS_REW_MAX] = mx_rew;
+    double am = agg_sum / n, var = 0;
+    for (int e = 0; e < n; ++e) { double d = ST(h, VF_AGG_REW, e) - am; var += d * d; }
+    s[VS_AGG_MEAN] = am; s[VS_AGG_STD] = n > 1 ? sqrt(var / (n - 1)) : 0;          /* torch.std: unbiased */
+    const int e = (int)view;
+    for (int i = 0; i < 6; ++i) { s[VS_VIEW0 + i] = ST(h, VF_Q0 + i, e); s[VS_VIEW0 + 6 + i] = ST(h, VF_QD0 + i, e); s[VS_VIEW0 + 12 + i] = ST(h, VF_PREV_Q0 + i, e); }
+    static const int vf[10] = {VF_TIP_Y, VF_TIP_Z, VF_TIP_VY, VF_TIP_VZ, VF_PREV_TIP_Y, VF_PREV_TIP_Z, VF_CART_Y, VF_CART_VY, VF_TARGET_Y, VF_TARGET_Z};
+    for (int i = 0; i < 10; ++i) s[VS_VIEW0 + 18 + i] = ST(h, vf[i], e);
+    static const int vu[5] = {VF_U_FPAM, VF_SMOOTHED_U, VF_U_RAIL, VF_RAIL_FORCE, VF_CONTACT_MEAN};
+    for (int i = 0; i < 5; ++i) s[VS_VIEW_U + i] = ST(h, vu[i], e);
+    if (h->reward_matrix)
+        for (int k = 0; k < VINE_NUM_REWARDS; ++k) {
+            double sum = 0, mx = -1e300, mn = 1e300;
+            for (int i = 0; i < n; ++i) { double v = h->reward_matrix[(size_t)i * VINE_NUM_REWARDS + k]; sum += v; if (v > mx) mx = v; if (v < mn) mn = v; }
+            s[VS_TERM0 + 3 * k] = sum / n; s[VS_TERM0 + 3 * k + 1] = mx; s[VS_TERM0 + 3 * k + 2] = mn;
+        }
+    for (int i = 0; i < VINE_NUM_STATS; ++i) out[i] = (float)s[i];
+    return VINE_OK;
+}
 
 /* reset_idx for one env, V5:774-839 + sample_target_positions V5:887-914.
  * Body states (tip, cart) are left untouched when STALE_BODY_STATE_AFTER_RESET (V5:796-797). */
@@ -986,9 +1069,9 @@ static void reset_env(VineHandle* h, int e, uint64_t step) {
         qn[0] = v[5]; pdepth = v[6]; ty = v[7]; tz = v[8]; depth = v[9];
     } else {
         uint32_t r0[4], r1[4], r2[4];
-        rng4(c->seed, (uint32_t)e, step, RNG_RESET, 0, r0);
-        rng4(c->seed, (uint32_t)e, step, RNG_RESET, 1, r1);
-        rng4(c->seed, (uint32_t)e, step, RNG_RESET, 2, r2);
+        rng4(c->seed, (uint32_t)(c->env_id_offset + e), step, RNG_RESET, 0, r0);
+        rng4(c->seed, (uint32_t)(c->env_id_offset + e), step, RNG_RESET, 1, r1);
+        rng4(c->seed, (uint32_t)(c->env_id_offset + e), step, RNG_RESET, 2, r2);
         float u[10] = {u01(r0[0]), u01(r0[1]), u01(r0[2]), u01(r0[3]), u01(r1[0]),
                        u01(r1[1]), u01(r1[2]), u01(r1[3]), u01(r2[0]), u01(r2[1])};
         for (int k = 0; k < NL; ++k) qn[k + 1] = -ten + ((real)2 * ten) * (real)u[k];
@@ -1071,7 +1154,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     /* ---- pre_physics_step (V5:922-945) ---- */
     if (randomize) {                                       /* V5:930-932 */
         uint32_t r[4]; float n0, n1;
-        rng4(c->seed, (uint32_t)e, step, RNG_ACTION_NOISE, 0, r);
+        rng4(c->seed, (uint32_t)(c->env_id_offset + e), step, RNG_ACTION_NOISE, 0, r);
         normal2(r[0], r[1], &n0, &n1);
         a0 += (real)c->action_noise_std * (real)n0;
         a1 += (real)c->action_noise_std * (real)n1;
@@ -1106,7 +1189,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
             /* 20 factors per control iteration from 3 Philox calls: 16-bit uniforms (2 per 32-bit word) */
             for (int g = 0; g < 3; ++g) {
                 uint32_t r[4];
-                rng4(c->seed, (uint32_t)e, step, RNG_DYN_SCALE, (uint32_t)(it * 3 + g), r);
+                rng4(c->seed, (uint32_t)(c->env_id_offset + e), step, RNG_DYN_SCALE, (uint32_t)(it * 3 + g), r);
                 for (int k = 0; k < 8 && g * 8 + k < 20; ++k) {
                     float u = (float)((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) * (1.0f / 65536.0f);
                     scale[g * 8 + k] = (real)c->dyn_scale_min + ((real)c->dyn_scale_max - (real)c->dyn_scale_min) * (real)u;
@@ -1120,7 +1203,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
         real csum = 0;
         for (int s = 0; s < c->substeps; ++s) {                      /* gym.simulate, VT:356 */
             real effc[ND];
-            for (int i = 0; i < ND; ++i) effc[i] = eff[i];
+            for (int i = 0; i < ND; ++i) effc[i] = (i > 0 && s > 0 && M->effort_first_substep_only) ? 0 : eff[i];
             if (shelf) csum += shelf_contact(M, q, qd, shelf_y, shelf_z, effc);
             if (pipe) pipe_contact(M, q, qd, pipe_y, pipe_z, pipe_tp, effc);
             substep(M, h->form, cj, q, qd, effc, hsub);
@@ -1160,7 +1243,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     if (randomize) {                                                 /* V5:1388-1390 */
         for (int i = 0; i < k; i += 4) {
             uint32_t r[4]; float nn[4];
-            rng4(c->seed, (uint32_t)e, step, RNG_OBS_NOISE, (uint32_t)(i / 4), r);
+            rng4(c->seed, (uint32_t)(c->env_id_offset + e), step, RNG_OBS_NOISE, (uint32_t)(i / 4), r);
             normal2(r[0], r[1], &nn[0], &nn[1]); normal2(r[2], r[3], &nn[2], &nn[3]);
             for (int j = 0; j < 4 && i + j < k; ++j) o[i + j] += (real)c->obs_noise_std * (real)nn[j];
         }

@@ -68,6 +68,7 @@ def load(precision="f64", omp=False):
     lib.vine_oracle_state.restype = C.c_void_p
     lib.vine_oracle_set_formulation.argtypes = [C.c_void_p, C.c_int]
     lib.vine_oracle_pull_mirror.argtypes = [C.c_void_p]
+    lib.vine_oracle_set_probe.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
     _cache[key] = lib
     return lib
 
@@ -166,6 +167,19 @@ class OracleEnv:
 
     def set_formulation(self, form):
         self.lib.vine_oracle_set_formulation(self.h, form)
+
+    def set_probe(self, armature=0.0, vmax_link=0.0, vmax_joint=0.0, effort_first_substep_only=False):
+        """Oracle-only physics probe switches (tests/test_oracle_physics.py: sweep of unverifiable PhysX defaults)."""
+        self.lib.vine_oracle_set_probe(self.h, armature, vmax_link, vmax_joint, int(effort_first_substep_only))
+
+    def stats(self, index_to_view=0):
+        """vine_stats: the dashboard vector (abi.VS_*) of the state the last step left behind."""
+        out = np.zeros(abi.NUM_STATS, np.float32)
+        rc = self.lib.vine_stats(self.h, self.rew.ctypes.data, self.progress.ctypes.data, int(index_to_view),
+                                 out.ctypes.data, None)
+        if rc:
+            raise RuntimeError(self.lib.vine_last_error().decode())
+        return out
 
     @property
     def step_count(self):

@@ -302,12 +302,26 @@ class FakeGym:
             rb[e, cart, 1], rb[e, cart, 2], rb[e, cart, 8] = ds[e, 0, 0], 0.975, ds[e, 0, 1]
 
     def simulate(self, sim):
+        """``gym.simulate``: this repo's articulation model.  In the product's default mode (DESIGN.md assumption P4) the
+        velocity term of the efforts the reference has just set, -C_j * qd_j (V5:1062), is not held over the sim step:
+        it is taken back out of the efforts here (qd has not changed since the reference computed them) and C_j joins the
+        implicitly integrated DOF damping -- exactly what vine_step does.  ``VINE_FLAG_FPAM_DAMPING_HELD`` in the
+        oracle config selects the literal held form instead."""
         self.calls.append("simulate")
         ds = self.dof_state.view(self.n, 6, 2)
         h = float(np.float32(self.ocfg.dt) / np.float32(self.ocfg.substeps))
+        held = self.ocfg.has_flag(abi.FLAG_FPAM_DAMPING_HELD)
+        C_ = np.array(list(self.ocfg.fpam_C), np.float32)
         for e in range(self.n):
-            q, qd = vo.simulate(self.ocfg, ds[e, :, 0].numpy(), ds[e, :, 1].numpy(), self.efforts[e].numpy(), h,
-                                self.ocfg.substeps, form=vo.FORM_ABS, precision="f32")
+            qd0 = ds[e, :, 1].numpy().astype(np.float32)
+            eff = self.efforts[e].numpy().astype(np.float32).copy()
+            cj = None
+            if not held:
+                eff[1:] = eff[1:] + C_ * qd0[1:]
+                cj = np.full(6, np.float32(self.ocfg.damping), np.float32)
+                cj[1:] += C_
+            q, qd = vo.simulate(self.ocfg, ds[e, :, 0].numpy(), ds[e, :, 1].numpy(), eff, h,
+                                self.ocfg.substeps, form=vo.FORM_ABS, precision="f32", cj=cj)
             ds[e, :, 0] = torch.from_numpy(q.astype(np.float32))
             ds[e, :, 1] = torch.from_numpy(qd.astype(np.float32))
         self._refresh_bodies()
@@ -339,8 +353,8 @@ def reference_task_cfg(num_envs, **env_overrides):
     return cfg
 
 
-def oracle_cfg_from(cfg, held=True):
-    """VineConfig equivalent of a reference cfg dict (FakeGym physics uses the held-torque mode)."""
+def oracle_cfg_from(cfg, held=False):
+    """VineConfig equivalent of a reference cfg dict (FakeGym physics = the product's default mode unless ``held``)."""
     e, rp = cfg["env"], cfg["task"]["randomization_parameters"]
     c = vo.default_config(num_envs=e["numEnvs"])
     c.max_episode_length = e["maxEpisodeLength"]
@@ -546,7 +560,7 @@ def f6_trajectory(vt, v5, out):
     N, T = 8, 64
     for tag, over in (("delay1", dict(ACTION_DELAY=1)), ("delay0_tipobs", dict(ACTION_DELAY=0, OBSERVATION_TYPE="TIP_AND_CART_AND_OBJ_INFO")),
                       ("delay2", dict(ACTION_DELAY=2))):
-        env_over = dict(DAMPING=0.08, maxEpisodeLength=20, SUCCESS_DIST=0.12, RAIL_SOFT_LIMIT=0.2, MIN_TARGET_Y=-0.3,
+        env_over = dict(maxEpisodeLength=20, SUCCESS_DIST=0.12, RAIL_SOFT_LIMIT=0.2, MIN_TARGET_Y=-0.3,
                         MAX_TARGET_Y=-0.1, MIN_TARGET_Z=0.53, MAX_TARGET_Z=0.6, RANDOM_INIT_CART_MIN_Y=-0.02,
                         RANDOM_INIT_CART_MAX_Y=0.2)
         env_over.update(over)

@@ -20,10 +20,9 @@ def base_cfg(num_envs, obs_type=abi.OBS_POS_AND_FD_VEL_AND_OBJ_INFO, randomize=F
 
 
 def f6_cfg(num_envs, action_delay, obs_type):
-    """The configuration tests/golden/make_golden.py used for the F6 trajectories
-    (env_overrides array inside the fixture) in held-torque mode (reference-literal V5:1062)."""
+    """The configuration tests/golden/make_golden.py used for the F6 trajectories (env_overrides array inside the
+    fixture): the task YAML's own DAMPING (0.02) in the product's default physics mode."""
     cfg = base_cfg(num_envs, obs_type)
-    cfg.damping = 0.08
     cfg.max_episode_length = 20
     cfg.success_dist = 0.12
     cfg.rail_soft_limit = 0.2
@@ -31,7 +30,6 @@ def f6_cfg(num_envs, action_delay, obs_type):
     cfg.min_target_z, cfg.max_target_z = 0.53, 0.6
     cfg.random_init_cart_min_y, cfg.random_init_cart_max_y = -0.02, 0.2
     cfg.action_delay = action_delay
-    cfg.set_flag(abi.FLAG_FPAM_DAMPING_HELD, True)
     return cfg
 
 

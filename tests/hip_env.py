@@ -26,6 +26,18 @@ class HipEnv:
         self.timeouts_t = torch.zeros(self.n, device=self.dev, dtype=torch.bool)
         self.reward_matrix_t = None
         self._rv = None
+        # the parity tests compare every field, also those the step only stores on request
+        native.check(self.lib.vine_set_introspection(self.h, 1), self.lib)
+
+    def set_introspection(self, on):
+        native.check(self.lib.vine_set_introspection(self.h, int(bool(on))), self.lib)
+
+    def stats(self, index_to_view=0):
+        out = torch.zeros(abi.NUM_STATS, device=self.dev)
+        native.check(self.lib.vine_stats(self.h, self.rew_t.data_ptr(), self.progress_t.data_ptr(), int(index_to_view),
+                                         out.data_ptr(), torch.cuda.current_stream(self.dev).cuda_stream), self.lib)
+        torch.cuda.synchronize(self.dev)
+        return out.cpu().numpy()
 
     # numpy views of the device buffers (copies)
     @property

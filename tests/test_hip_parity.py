@@ -266,10 +266,9 @@ def test_dashboard_scalars_match_reference(HipEnv, golden):
     g, ref = golden("f6_traj_delay1"), golden("f7_wandb_keys")
     T, N, _ = g["actions"].shape
     ov = ["num_envs=%d" % N, "vine_randomize=False", "task.env.CREATE_PIPE=False", "task.env.ACTION_DELAY=1",
-          "task.env.DAMPING=0.08", "task.env.maxEpisodeLength=20", "task.env.SUCCESS_DIST=0.12", "RAIL_SOFT_LIMIT=0.2",
+          "task.env.maxEpisodeLength=20", "task.env.SUCCESS_DIST=0.12", "RAIL_SOFT_LIMIT=0.2",
           "task.env.MIN_TARGET_Y=-0.3", "task.env.MAX_TARGET_Y=-0.1", "task.env.MIN_TARGET_Z=0.53",
-          "task.env.MAX_TARGET_Z=0.6", "task.env.RANDOM_INIT_CART_MIN_Y=-0.02", "task.env.RANDOM_INIT_CART_MAX_Y=0.2",
-          "task.env.physicsModel.fpamDampingHeld=True"]
+          "task.env.MAX_TARGET_Z=0.6", "task.env.RANDOM_INIT_CART_MIN_Y=-0.02", "task.env.RANDOM_INIT_CART_MAX_Y=0.2"]
     env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=load_task_config("Vine5LinkMovingBase", overrides=ov),
                                                   rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=0,
                                                   headless=True)

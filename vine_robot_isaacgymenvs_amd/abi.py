@@ -6,7 +6,7 @@ argument/return types to the C-ABI entry points of a loaded shared library and r
 """
 import ctypes as C
 
-VINE_ABI_VERSION = 1
+VINE_ABI_VERSION = 2
 NUM_LINKS = 5
 NUM_DOFS = 6
 NUM_ACTIONS = 2
@@ -47,6 +47,7 @@ FLAG_STALE_BODY_STATE_AFTER_RESET = 1 << 11
 FLAG_IMPLICIT_JOINT_DAMPING = 1 << 12
 FLAG_FPAM_DAMPING_HELD = 1 << 13
 FLAG_CREATE_PIPE = 1 << 14
+FLAG_INTROSPECT = 1 << 15
 
 # VineField
 VF_Q0 = 0
@@ -66,6 +67,16 @@ VF_PREV_TIP_Y, VF_PREV_TIP_Z = 40, 41
 VF_FIFO0 = 42
 VF_PIPE_Y, VF_PIPE_Z = 42 + 2 * MAX_DELAY, 43 + 2 * MAX_DELAY
 VF_COUNT = 44 + 2 * MAX_DELAY
+
+# VineStat (layout of vine_stats' output vector)
+NUM_STATS = 128
+(VS_DIST_MEAN, VS_TARGET_REACHED, VS_LIMIT_HIT, VS_TIP_LIMIT_HIT, VS_ABS_TIP_Y, VS_TIP_Z, VS_MAX_ABS_TIP_Y, VS_MAX_TIP_Z,
+ VS_TIP_VEL_MEAN, VS_TIP_VEL_MAX, VS_U_RAIL_ABS, VS_PREV_U_RAIL_ABS, VS_RAIL_FORCE_ABS, VS_U_FPAM_ABS, VS_SMOOTHED_ABS,
+ VS_PROGRESS_MEAN, VS_CONTACT_MEAN, VS_CONTACT_NONZERO, VS_AGG_MEAN, VS_AGG_STD, VS_REW_MEAN, VS_REW_MAX) = range(22)
+VS_VIEW0 = 24
+VS_VIEW_U = VS_VIEW0 + 28
+VS_TERM0 = 64
+VS_COUNT_USED = VS_TERM0 + 3 * NUM_REWARDS
 
 
 class VineConfig(C.Structure):
@@ -121,6 +132,7 @@ class VineConfig(C.Structure):
         ("fpam_b", C.c_float * NUM_LINKS),
         ("fpam_B", C.c_float * NUM_LINKS),
         ("obs_scaling", C.c_float * MAX_OBS),
+        ("env_id_offset", C.c_int32),
     ]
 
     def set_flag(self, flag, on):
@@ -147,6 +159,8 @@ PROTOTYPES = {
     "vine_get_step_count": (C.c_int64, [_H]),
     "vine_set_step_count": (C.c_int, [_H, C.c_int64]),
     "vine_bind_reward_matrix": (C.c_int, [_H, C.c_void_p]),
+    "vine_set_introspection": (C.c_int, [_H, C.c_int]),
+    "vine_stats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vine_last_error": (C.c_char_p, []),
     "vine_backend_name": (C.c_char_p, []),
 }

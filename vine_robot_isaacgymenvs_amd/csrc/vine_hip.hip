@@ -54,7 +54,7 @@ int hip_fail(hipError_t e, const char* what) {
 // Everything the kernels need, precomputed on the host from VineConfig; passed by value (kernarg).
 struct DevParams {
     int n, num_obs, obs_type, cfi, substeps, max_len, delay;
-    unsigned flags, seed_lo, seed_hi;
+    unsigned flags, seed_lo, seed_hi, env_off;
     float hsub, dt, cdt, inv_dt, inv_cdt, clip_obs, clip_act;
     float fpam_min, fpam_span, rail_scale, damping, kq, cad;
     float soft_limit, p_gain, d_gain, rail_acc, alpha_inf, alpha_def, success_dist;
@@ -85,7 +85,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
 }
 __device__ __forceinline__ void rng4(const DevParams& P, unsigned env, unsigned long long step, unsigned purpose,
                                      unsigned idx, unsigned out[4]) {
-    philox4x32_10(env, (unsigned)step, purpose | ((unsigned)(step >> 32) << 8), idx, P.seed_lo, P.seed_hi, out);
+    // env: local index; the key is the GLOBAL env id (VineConfig.env_id_offset), so a shard draws what the whole batch does
+    philox4x32_10(env + P.env_off, (unsigned)step, purpose | ((unsigned)(step >> 32) << 8), idx, P.seed_lo, P.seed_hi, out);
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ void normal2(unsigned a, unsigned b, float& n0, float& n1) {
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
             qd[i] = ST(VF_QD0 + i);
             prev_q[i] = q[i];
         }
-        float tip[4] = {ST(VF_TIP_Y), ST(VF_TIP_Z), ST(VF_TIP_VY), ST(VF_TIP_VZ)};
+        float tip[4] = {ST(VF_TIP_Y), ST(VF_TIP_Z), 0.0f, 0.0f};   // (the velocities are recomputed before their first use)
         float prev_tip_y = tip[0], prev_tip_z = tip[1];
         float prev_u_rail = u_rail;
         float cart_y = ST(VF_CART_Y), cart_vy = ST(VF_CART_VY);
@@ -557,6 +558,8 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
         if (PIPE) sincosf(ST(VF_OBJ_ANGLE) + 1.5707963267948966f, &pipe_st, &pipe_ct);
         const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
         const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
+        // fields nothing in the step reads back (attributes / dashboard inputs of the reference) are stored on request only
+        const bool introspect = (P.flags & VINE_FLAG_INTROSPECT) != 0;
 
         Dyn s;
         s.y = q[0];
@@ -701,7 +704,10 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
             for (int i = 0; i < ND; ++i) {
                 ST(VF_Q0 + i) = q[i];
                 ST(VF_QD0 + i) = qd[i];
-                ST(VF_PREV_Q0 + i) = prev_q[i];
+            }
+            if (introspect) {
+#pragma unroll
+                for (int i = 0; i < ND; ++i) ST(VF_PREV_Q0 + i) = prev_q[i];
             }
         }
         const float obj_depth = ST(VF_OBJ_DEPTH), obj_angle = ST(VF_OBJ_ANGLE);
@@ -821,14 +827,19 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
             for (int i = 0; i < VINE_NUM_REWARDS; ++i) reward_matrix[(size_t)e * VINE_NUM_REWARDS + i] = rm[i];
         }
         // persistent state
-        ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1]; ST(VF_TIP_VY) = tip[2]; ST(VF_TIP_VZ) = tip[3];
+        ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1];
         ST(VF_CART_Y) = cart_y; ST(VF_CART_VY) = cart_vy;
-        ST(VF_PREV_TIP_Y) = prev_tip_y; ST(VF_PREV_TIP_Z) = prev_tip_z;
-        ST(VF_SMOOTHED_U) = smoothed; ST(VF_U_FPAM) = u_fpam; ST(VF_U_RAIL) = u_rail;
-        ST(VF_PREV_U_RAIL) = prev_u_rail;
+        ST(VF_SMOOTHED_U) = smoothed;
         ST(VF_PREV_CART_VEL) = pcv; ST(VF_PREV_CART_VEL_ERR) = pce;
-        ST(VF_AGG_REW) = agg; ST(VF_RAIL_FORCE) = rail_force;
-        if (SHELF) { ST(VF_CONTACT) = contact; ST(VF_CONTACT_MEAN) = cmean; }
+        ST(VF_AGG_REW) = agg;
+        if (SHELF) ST(VF_CONTACT) = contact;
+        if (introspect) {
+            ST(VF_TIP_VY) = tip[2]; ST(VF_TIP_VZ) = tip[3];
+            ST(VF_PREV_TIP_Y) = prev_tip_y; ST(VF_PREV_TIP_Z) = prev_tip_z;
+            ST(VF_U_FPAM) = u_fpam; ST(VF_U_RAIL) = u_rail; ST(VF_PREV_U_RAIL) = prev_u_rail;
+            ST(VF_RAIL_FORCE) = rail_force;
+            if (SHELF) ST(VF_CONTACT_MEAN) = cmean;
+        }
     }
     // ---- advance the step counter once every workgroup has read it (ticket) ----
     __syncthreads();
@@ -892,6 +903,129 @@ __global__ void vine_init_kernel(const DevParams P, float* __restrict__ st) {
     }
 }
 
+
+// ---- vine_stats: the dashboard scalars of compute_reward (V5:1250-1322) as one two-stage reduction ----
+// Stage 1: STATS_BLOCKS workgroups, each folds its grid-strided share of the envs into one row of partial sums /
+// maxima (double sums: the result does not depend on the launch geometry beyond round-off of doubles, and the same
+// inputs give the same bits every time -- no atomics).  Stage 2: one workgroup folds the rows in a fixed order and
+// writes the VineStat vector.  The variance of aggregated_rew_buf is accumulated about a pilot value (env 0) so
+// that sum / sum-of-squares in double is exact enough for torch.std's unbiased estimate.
+#define STATS_BLOCKS 64
+#define STATS_NSUM (17 + VINE_NUM_REWARDS)        // sums: 16 plain + agg (shifted) + agg^2 (shifted) ... see enum
+#define STATS_NMAX (4 + 2 * VINE_NUM_REWARDS)      // maxima: |tip_y|, tip_z, |v_tip|, rew, then max / -min per term
+enum { SS_DIST = 0, SS_REACHED, SS_LIMIT, SS_TIPLIM, SS_ABSTIPY, SS_TIPZ, SS_TIPV, SS_URAIL, SS_PURAIL, SS_RFORCE, SS_UFPAM,
+       SS_SMOOTH, SS_PROG, SS_CONTACT, SS_NONZERO, SS_REW, SS_AGG, SS_AGG2, SS_TERM0 };
+static_assert(SS_TERM0 + VINE_NUM_REWARDS == STATS_NSUM + 1, "stat slots");
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void vine_stats_partial_kernel(const DevParams P, const float* __restrict__ st,
+                                                                 const float* __restrict__ rew,
+                                                                 const long long* __restrict__ progress,
+                                                                 const float* __restrict__ reward_matrix,
+                                                                 double* __restrict__ psum, float* __restrict__ pmax) {
+    constexpr int NS = STATS_NSUM + 1, NM = STATS_NMAX;
+    const int n = P.n;
+    double s[NS];
+    float m[NM];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) m[i] = -3.0e38f;
+    const float pilot = st[(size_t)VF_AGG_REW * n];        // env 0's value: shift for the variance
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const float ty = ST(VF_TIP_Y), tz = ST(VF_TIP_Z), gy = ST(VF_TARGET_Y), gz = ST(VF_TARGET_Z);
+        const float dy = ty - gy, dz = tz - gz;
+        const float dist = sqrtf(dy * dy + dz * dz);
+        const float cy = ST(VF_CART_Y);
+        const float vy = ST(VF_TIP_VY), vz = ST(VF_TIP_VZ);
+        const float tv = sqrtf(vy * vy + vz * vz);
+        const float cm = ST(VF_CONTACT_MEAN);
+        const float r = rew[e];
+        const float ag = ST(VF_AGG_REW) - pilot;
+        s[SS_DIST] += dist; s[SS_REACHED] += dist < P.success_dist ? 1.0 : 0.0;
+        s[SS_LIMIT] += ((cy > P.soft_limit) || (cy < -P.soft_limit)) ? 1.0 : 0.0;
+        s[SS_TIPLIM] += ty < gy ? 1.0 : 0.0; s[SS_ABSTIPY] += fabsf(ty); s[SS_TIPZ] += tz; s[SS_TIPV] += tv;
+        s[SS_URAIL] += fabsf(ST(VF_U_RAIL)); s[SS_PURAIL] += fabsf(ST(VF_PREV_U_RAIL)); s[SS_RFORCE] += fabsf(ST(VF_RAIL_FORCE));
+        s[SS_UFPAM] += fabsf(ST(VF_U_FPAM)); s[SS_SMOOTH] += fabsf(ST(VF_SMOOTHED_U)); s[SS_PROG] += (double)progress[e];
+        s[SS_CONTACT] += cm; s[SS_NONZERO] += cm > 0.0f ? 1.0 : 0.0; s[SS_REW] += r;
+        s[SS_AGG] += ag; s[SS_AGG2] += (double)ag * (double)ag;
+        m[0] = fmaxf(m[0], fabsf(ty)); m[1] = fmaxf(m[1], tz); m[2] = fmaxf(m[2], tv); m[3] = fmaxf(m[3], r);
+        if (reward_matrix) {
+#pragma unroll
+            for (int k = 0; k < VINE_NUM_REWARDS; ++k) {
+                const float v = reward_matrix[(size_t)e * VINE_NUM_REWARDS + k];
+                s[SS_TERM0 + k] += v;
+                m[4 + 2 * k] = fmaxf(m[4 + 2 * k], v);
+                m[5 + 2 * k] = fmaxf(m[5 + 2 * k], -v);
+            }
+        }
+    }
+    __shared__ double sred[4][NS];
+    __shared__ float mred[4][NM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { const double v = wave_sum_d(s[i]); if (lane == 0) sred[wave][i] = v; }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) { const float v = wave_max_f(m[i]); if (lane == 0) mred[wave][i] = v; }
+    __syncthreads();
+    if (threadIdx.x < NS)
+        psum[(size_t)blockIdx.x * NS + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
+    if (threadIdx.x < NM)
+        pmax[(size_t)blockIdx.x * NM + threadIdx.x] = fmaxf(fmaxf(mred[0][threadIdx.x], mred[1][threadIdx.x]), fmaxf(mred[2][threadIdx.x], mred[3][threadIdx.x]));
+}
+
+__global__ __launch_bounds__(64) void vine_stats_finalize_kernel(const DevParams P, const float* __restrict__ st, int blocks,
+                                                                 const double* __restrict__ psum, const float* __restrict__ pmax,
+                                                                 int has_terms, long long view, float* __restrict__ out) {
+    constexpr int NS = STATS_NSUM + 1, NM = STATS_NMAX;
+    __shared__ double S[NS];
+    __shared__ float M[NM];
+    const int t = threadIdx.x, n = P.n;
+    if (t < NS) { double v = 0.0; for (int b = 0; b < blocks; ++b) v += psum[(size_t)b * NS + t]; S[t] = v; }
+    if (t < NM) { float v = -3.0e38f; for (int b = 0; b < blocks; ++b) v = fmaxf(v, pmax[(size_t)b * NM + t]); M[t] = v; }
+    __syncthreads();
+    for (int i = t; i < VINE_NUM_STATS; i += 64) out[i] = 0.0f;
+    __syncthreads();
+    const double inv = 1.0 / (double)n;
+    if (t == 0) {
+        static const int dst[16] = {VS_DIST_MEAN, VS_TARGET_REACHED, VS_LIMIT_HIT, VS_TIP_LIMIT_HIT, VS_ABS_TIP_Y, VS_TIP_Z, VS_TIP_VEL_MEAN,
+                                    VS_U_RAIL_ABS, VS_PREV_U_RAIL_ABS, VS_RAIL_FORCE_ABS, VS_U_FPAM_ABS, VS_SMOOTHED_ABS,
+                                    VS_PROGRESS_MEAN, VS_CONTACT_MEAN, VS_CONTACT_NONZERO, VS_REW_MEAN};
+        for (int i = 0; i < 16; ++i) out[dst[i]] = (float)(S[i] * inv);
+        out[VS_MAX_ABS_TIP_Y] = M[0]; out[VS_MAX_TIP_Z] = M[1]; out[VS_TIP_VEL_MAX] = M[2]; out[VS_REW_MAX] = M[3];
+        const double pilot = (double)st[(size_t)VF_AGG_REW * n];
+        const double mean_s = S[SS_AGG] * inv;                       // mean of the shifted values
+        double var = n > 1 ? (S[SS_AGG2] - (double)n * mean_s * mean_s) / (double)(n - 1) : 0.0;
+        if (var < 0.0) var = 0.0;
+        out[VS_AGG_MEAN] = (float)(pilot + mean_s);
+        out[VS_AGG_STD] = (float)sqrt(var);
+    }
+    const int e = (int)view;
+    if (t < 6) { out[VS_VIEW0 + t] = ST(VF_Q0 + t); out[VS_VIEW0 + 6 + t] = ST(VF_QD0 + t); out[VS_VIEW0 + 12 + t] = ST(VF_PREV_Q0 + t); }
+    if (t == 6) {
+        const int vf[10] = {VF_TIP_Y, VF_TIP_Z, VF_TIP_VY, VF_TIP_VZ, VF_PREV_TIP_Y, VF_PREV_TIP_Z, VF_CART_Y, VF_CART_VY, VF_TARGET_Y, VF_TARGET_Z};
+        for (int i = 0; i < 10; ++i) out[VS_VIEW0 + 18 + i] = ST(vf[i]);
+        const int vu[5] = {VF_U_FPAM, VF_SMOOTHED_U, VF_U_RAIL, VF_RAIL_FORCE, VF_CONTACT_MEAN};
+        for (int i = 0; i < 5; ++i) out[VS_VIEW_U + i] = ST(vu[i]);
+    }
+    if (has_terms && t >= 16 && t < 16 + VINE_NUM_REWARDS) {
+        const int k = t - 16;
+        out[VS_TERM0 + 3 * k] = (float)(S[SS_TERM0 + k] * inv);
+        out[VS_TERM0 + 3 * k + 1] = M[4 + 2 * k];
+        out[VS_TERM0 + 3 * k + 2] = -M[5 + 2 * k];
+    }
+}
+
 int validate(const VineConfig* c) {
     if (!c) return fail(VINE_ERR_INVALID_ARG, "cfg is NULL");
     if (c->abi_version != VINE_ABI_VERSION) return fail(VINE_ERR_INVALID_ARG, "abi_version mismatch");
@@ -908,7 +1042,7 @@ void make_params(const VineConfig& c, DevParams& P) {
     memset(&P, 0, sizeof P);
     P.n = c.num_envs; P.num_obs = vine_num_obs(&c); P.obs_type = c.obs_type; P.cfi = c.control_freq_inv;
     P.substeps = c.substeps; P.max_len = c.max_episode_length; P.delay = c.action_delay; P.flags = c.flags;
-    P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32);
+    P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32); P.env_off = (unsigned)c.env_id_offset;
     P.dt = c.dt; P.hsub = c.dt / (float)c.substeps; P.cdt = c.dt * (float)c.control_freq_inv;
     P.inv_dt = (float)(1.0 / (double)P.dt); P.inv_cdt = (float)(1.0 / (double)P.cdt);
     P.clip_obs = c.clip_observations; P.clip_act = c.clip_actions;
@@ -957,6 +1091,8 @@ struct VineHandle {
     unsigned long long* counters;  // [0] step count, [1] workgroup ticket
     const float* reset_values;
     float* reward_matrix;
+    double* stats_psum;            // [STATS_BLOCKS][STATS_NSUM + 1] partial sums of vine_stats (allocated on first use)
+    float* stats_pmax;             // [STATS_BLOCKS][STATS_NMAX]
 };
 
 namespace {
@@ -1071,6 +1207,8 @@ int vine_create(const VineConfig* cfg, int device_id, float* state_storage, Vine
     make_params(*cfg, h->P);
     h->reset_values = nullptr;
     h->reward_matrix = nullptr;
+    h->stats_psum = nullptr;
+    h->stats_pmax = nullptr;
     const size_t bytes = (size_t)VF_COUNT * cfg->num_envs * sizeof(float);
     if (state_storage) {
         h->state = state_storage;
@@ -1097,6 +1235,8 @@ void vine_destroy(VineHandle* h) {
     DeviceGuard guard(h->device);
     if (h->owns_state) (void)hipFree(h->state);
     (void)hipFree(h->counters);
+    if (h->stats_psum) (void)hipFree(h->stats_psum);
+    if (h->stats_pmax) (void)hipFree(h->stats_pmax);
     delete h;
 }
 
@@ -1160,6 +1300,36 @@ int vine_bind_reset_values(VineHandle* h, const float* values) {
 int vine_bind_reward_matrix(VineHandle* h, float* reward_matrix) {
     if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
     h->reward_matrix = reward_matrix;
+    if (reward_matrix) h->P.flags |= VINE_FLAG_INTROSPECT;      // whoever asks for the reward matrix reads the dashboard fields too
+    return VINE_OK;
+}
+
+int vine_set_introspection(VineHandle* h, int on) {
+    if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
+    if (on) h->P.flags |= VINE_FLAG_INTROSPECT;
+    else h->P.flags &= ~(unsigned)VINE_FLAG_INTROSPECT;
+    return VINE_OK;
+}
+
+int vine_stats(VineHandle* h, const float* rew, const int64_t* progress, int64_t index_to_view, float* out, void* stream) {
+    if (!h || !rew || !progress || !out || index_to_view < 0 || index_to_view >= h->P.n)
+        return fail(VINE_ERR_INVALID_ARG, "bad argument to vine_stats");
+    if (!(h->P.flags & VINE_FLAG_INTROSPECT))
+        return fail(VINE_ERR_INVALID_ARG, "vine_stats needs VINE_FLAG_INTROSPECT (vine_set_introspection / vine_bind_reward_matrix) "
+                                          "armed before the step whose state it summarises");
+    DeviceGuard guard(h->device);
+    if (!h->stats_psum) {
+        HIP_TRY(hipMalloc(&h->stats_psum, sizeof(double) * STATS_BLOCKS * (STATS_NSUM + 1)));
+        HIP_TRY(hipMalloc(&h->stats_pmax, sizeof(float) * STATS_BLOCKS * STATS_NMAX));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = (h->P.n + 255) / 256;
+    if (blocks > STATS_BLOCKS) blocks = STATS_BLOCKS;
+    hipLaunchKernelGGL(vine_stats_partial_kernel, dim3(blocks), dim3(256), 0, s, h->P, h->state, rew, (const long long*)progress,
+                       h->reward_matrix, h->stats_psum, h->stats_pmax);
+    hipLaunchKernelGGL(vine_stats_finalize_kernel, dim3(1), dim3(64), 0, s, h->P, h->state, blocks, h->stats_psum, h->stats_pmax,
+                       h->reward_matrix ? 1 : 0, (long long)index_to_view, out);
+    HIP_TRY(hipGetLastError());
     return VINE_OK;
 }
 

@@ -121,6 +121,8 @@ def vine_config_from_cfg(cfg, lib, seed=None):
     c.set_flag(abi.FLAG_IMPLICIT_JOINT_DAMPING, bool(model.get("implicitJointDamping", True)))
     c.set_flag(abi.FLAG_FPAM_DAMPING_HELD, bool(model.get("fpamDampingHeld", False)))
     c.link_angular_damping = float(model.get("linkAngularDamping", 0.0))
+    c.set_flag(abi.FLAG_INTROSPECT, bool(env.get("introspection", False)))
+    c.env_id_offset = int(env.get("envIdOffset", 0))
     if seed is not None:
         c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     return c
@@ -160,6 +162,8 @@ class Vine5LinkMovingBase(VecTask):
         self.obs_scaling = torch.tensor(list(self._vcfg.obs_scaling[:self.num_obs]), device=self.device)
         self.wandb_dict = {}
         self._reward_matrix = None
+        self._stats_out = None
+        self._introspection = bool(self._vcfg.flags & abi.FLAG_INTROSPECT)
         self.mat = self.read_mat_file(self.cfg["env"]["MAT_FILE"]) if len(self.cfg["env"].get("MAT_FILE", "")) > 0 else None
         # host-indexed state overwrite every step: cannot live inside a captured hipGraph
         self.graph_capturable = self.mat is None
@@ -245,90 +249,83 @@ class Vine5LinkMovingBase(VecTask):
     # ------------------------------------------------------------------ metrics side channel (V5:1250-1322)
     def collect_stats(self):
         """The ~120 scalars the reference puts into ``wandb_dict`` EVERY step with one ``.item()`` sync each
-        (V5:1250-1322), computed here on demand from the device state in one pass and ONE device->host copy.
-        Same key names, so dashboards carry over.  Needs ``bind_reward_matrix()`` for the per-term entries."""
-        st = self._state
+        (V5:1250-1322): here ONE two-stage reduction on the device (``vine_stats``, include/vine.h) and ONE
+        device->host copy, on demand.  Same key names, so dashboards carry over.  The fields the step only stores on
+        request (VINE_FLAG_INTROSPECT) must have been armed before the step being summarised:
+        ``bind_reward_matrix()`` (also needed for the per-term entries) or ``set_introspection(True)``."""
+        if not self._introspection:
+            raise RuntimeError("collect_stats(): call bind_reward_matrix() or set_introspection(True) before the step "
+                               "whose state is to be summarised (the step stores the dashboard-only fields on request)")
         f = abi
-        tip_y, tip_z = st[f.VF_TIP_Y], st[f.VF_TIP_Z]
-        tip_v = torch.sqrt(st[f.VF_TIP_VY] ** 2 + st[f.VF_TIP_VZ] ** 2)
-        dist = torch.sqrt((tip_y - st[f.VF_TARGET_Y]) ** 2 + (tip_z - st[f.VF_TARGET_Z]) ** 2)
-        cart_y = st[f.VF_CART_Y]
-        lim = float(self.cfg["env"]["RAIL_SOFT_LIMIT"])
-        agg = st[f.VF_AGG_REW]
-        contact = st[f.VF_CONTACT_MEAN]
-        names, vals = [], []
-
-        def put(name, v):
-            names.append(name)
-            vals.append(v.float().reshape(()))
-
-        put("dist_tip_to_target", dist.mean())
-        put("target_reached", (dist < float(self.cfg["env"]["SUCCESS_DIST"])).float().mean())
-        put("limit_hit", ((cart_y > lim) | (cart_y < -lim)).float().mean())
-        put("tip_limit_hit", (tip_y < st[f.VF_TARGET_Y]).float().mean())
-        put("abs_tip_y", tip_y.abs().mean())
-        put("tip_z", tip_z.mean())
-        put("max_abs_tip_y", tip_y.abs().max())
-        put("max_tip_z", tip_z.max())
-        put("tip_velocities", tip_v.mean())
-        put("tip_velocities_max", tip_v.max())
-        put("u_rail_velocity", st[f.VF_U_RAIL].abs().mean())
-        put("prev_u_rail_velocity", st[f.VF_PREV_U_RAIL].abs().mean())
-        put("rail_force", st[f.VF_RAIL_FORCE].abs().mean())
-        put("u_fpam", st[f.VF_U_FPAM].abs().mean())
-        put("smoothed_u_fpam", st[f.VF_SMOOTHED_U].abs().mean())
-        put("tip_target_velocity_difference", tip_v.mean())
-        put("progress_buf", self.progress_buf.float().mean())
-        put("contact_forces", contact.mean())
-        put("nonzero_contact_force", (contact > 0).float().mean())
-        put("Aggregated Reward", agg.mean())
-        put("Aggregated Reward 1 Std Up", agg.mean() + agg.std())
-        put("Aggregated Reward 1 Std Down", agg.mean() - agg.std())
-        i = self.index_to_view
-        fd = (st[f.VF_Q0:f.VF_Q0 + 6, i] - st[f.VF_PREV_Q0:f.VF_PREV_Q0 + 6, i]) / self.control_dt
-        put("prismatic_q0 at self.index_to_view", st[f.VF_Q0, i])
-        put("prismatic_qd0 at self.index_to_view", st[f.VF_QD0, i])
-        put("prismatic_finite_diff_qd0 at self.index_to_view", fd[0])
+        if self._stats_out is None:
+            self._stats_out = torch.zeros(f.NUM_STATS, device=self.device, dtype=torch.float32)
+        native.check(self._lib.vine_stats(self._handle, self.rew_buf.data_ptr(), self.progress_buf.data_ptr(),
+                                          int(self.index_to_view), self._stats_out.data_ptr(), self._stream()), self._lib)
+        v = self._stats_out.cpu().tolist()           # the only synchronisation
+        d = {}
+        for name, k in (("dist_tip_to_target", f.VS_DIST_MEAN), ("target_reached", f.VS_TARGET_REACHED),
+                        ("limit_hit", f.VS_LIMIT_HIT), ("tip_limit_hit", f.VS_TIP_LIMIT_HIT), ("abs_tip_y", f.VS_ABS_TIP_Y),
+                        ("tip_z", f.VS_TIP_Z), ("max_abs_tip_y", f.VS_MAX_ABS_TIP_Y), ("max_tip_z", f.VS_MAX_TIP_Z),
+                        ("tip_velocities", f.VS_TIP_VEL_MEAN), ("tip_velocities_max", f.VS_TIP_VEL_MAX),
+                        ("u_rail_velocity", f.VS_U_RAIL_ABS), ("prev_u_rail_velocity", f.VS_PREV_U_RAIL_ABS),
+                        ("rail_force", f.VS_RAIL_FORCE_ABS), ("u_fpam", f.VS_U_FPAM_ABS),
+                        ("smoothed_u_fpam", f.VS_SMOOTHED_ABS),
+                        ("tip_target_velocity_difference", f.VS_TIP_VEL_MEAN),      # target velocities are zero (V5:916-918)
+                        ("progress_buf", f.VS_PROGRESS_MEAN), ("contact_forces", f.VS_CONTACT_MEAN),
+                        ("nonzero_contact_force", f.VS_CONTACT_NONZERO), ("Aggregated Reward", f.VS_AGG_MEAN)):
+            d[name] = v[k]
+        d["Aggregated Reward 1 Std Up"] = v[f.VS_AGG_MEAN] + v[f.VS_AGG_STD]
+        d["Aggregated Reward 1 Std Down"] = v[f.VS_AGG_MEAN] - v[f.VS_AGG_STD]
+        w0 = f.VS_VIEW0
+        q, qd, pq = v[w0:w0 + 6], v[w0 + 6:w0 + 12], v[w0 + 12:w0 + 18]
+        tip_y, tip_z, tip_vy, tip_vz, ptip_y, ptip_z, cart_y, cart_vy, tgt_y, tgt_z = v[w0 + 18:w0 + 28]
+        u_fpam, smoothed, u_rail, rail_force, contact = v[f.VS_VIEW_U:f.VS_VIEW_U + 5]
+        fd = [(a - b) / self.control_dt for a, b in zip(q, pq)]
+        d["prismatic_q0 at self.index_to_view"] = q[0]
+        d["prismatic_qd0 at self.index_to_view"] = qd[0]
+        d["prismatic_finite_diff_qd0 at self.index_to_view"] = fd[0]
         for j in range(N_REVOLUTE_DOFS):
-            put(f"q{j} at self.index_to_view", st[f.VF_Q0 + 1 + j, i])
-            put(f"qd{j} at self.index_to_view", st[f.VF_QD0 + 1 + j, i])
-            put(f"finite_diff_qd{j} at self.index_to_view", fd[1 + j])
-        zero = torch.zeros((), device=st.device)
-        fd_tip = [(st[f.VF_TIP_Y, i] - st[f.VF_PREV_TIP_Y, i]) / self.control_dt,
-                  (st[f.VF_TIP_Z, i] - st[f.VF_PREV_TIP_Z, i]) / self.control_dt]
-        per_dir = {
-            "x": (zero, zero, zero, zero, zero, zero, zero),
-            "y": (st[f.VF_TIP_VY, i], st[f.VF_CART_VY, i], zero, fd_tip[0], tip_y[i], cart_y[i], st[f.VF_TARGET_Y, i]),
-            "z": (st[f.VF_TIP_VZ, i], zero, zero, fd_tip[1], tip_z[i], torch.full((), CART_Z, device=st.device),
-                  st[f.VF_TARGET_Z, i]),
-        }
-        for d, (tv, cv, gv, ftv, tp, cp, gp) in per_dir.items():
-            put(f"tip_vel_{d} at self.index_to_view", tv)
-            put(f"cart_vel_{d} at self.index_to_view", cv)
-            put(f"target_vel_{d} at self.index_to_view", gv)
-            put(f"finite_diff_tip_vel_{d} at self.index_to_view", ftv)
-            put(f"tip_pos_{d} at self.index_to_view", tp)
-            put(f"cart_pos_{d} at self.index_to_view", cp)
-            put(f"target_pos_{d} at self.index_to_view", gp)
-        put("u_fpam at self.index_to_view", st[f.VF_U_FPAM, i])
-        put("smoothed u_fpam at self.index_to_view", st[f.VF_SMOOTHED_U, i])
-        put("u_rail_velocity at self.index_to_view", st[f.VF_U_RAIL, i])
-        put("rail_force at self.index_to_view", st[f.VF_RAIL_FORCE, i])
-        put("contact_force at self.index_to_view", contact[i])
-        put("nonzero_contact_force at self.index_to_view", (contact[i] > 0).float())
+            d[f"q{j} at self.index_to_view"] = q[1 + j]
+            d[f"qd{j} at self.index_to_view"] = qd[1 + j]
+            d[f"finite_diff_qd{j} at self.index_to_view"] = fd[1 + j]
+        per_dir = {"x": (0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+                   "y": (tip_vy, cart_vy, 0.0, (tip_y - ptip_y) / self.control_dt, tip_y, cart_y, tgt_y),
+                   "z": (tip_vz, 0.0, 0.0, (tip_z - ptip_z) / self.control_dt, tip_z, CART_Z, tgt_z)}
+        for dr, (tv, cv, gv, ftv, tp, cp, gp) in per_dir.items():
+            d[f"tip_vel_{dr} at self.index_to_view"] = tv
+            d[f"cart_vel_{dr} at self.index_to_view"] = cv
+            d[f"target_vel_{dr} at self.index_to_view"] = gv
+            d[f"finite_diff_tip_vel_{dr} at self.index_to_view"] = ftv
+            d[f"tip_pos_{dr} at self.index_to_view"] = tp
+            d[f"cart_pos_{dr} at self.index_to_view"] = cp
+            d[f"target_pos_{dr} at self.index_to_view"] = gp
+        d["u_fpam at self.index_to_view"] = u_fpam
+        d["smoothed u_fpam at self.index_to_view"] = smoothed
+        d["u_rail_velocity at self.index_to_view"] = u_rail
+        d["rail_force at self.index_to_view"] = rail_force
+        d["contact_force at self.index_to_view"] = contact
+        d["nonzero_contact_force at self.index_to_view"] = float(contact > 0)
         if self._reward_matrix is not None:
-            rm = self._reward_matrix
-            wrm = rm * self.reward_weights
             for k, name in enumerate(REWARD_NAMES):
-                put(f"Mean {name} Reward", rm[:, k].mean())
-                put(f"Max {name} Reward", rm[:, k].max())
-                put(f"Weighted Mean {name} Reward", wrm[:, k].mean())
-                put(f"Weighted Max {name} Reward", wrm[:, k].max())
-        put("Mean Total Reward", self.rew_buf.mean())
-        put("Max Total Reward", self.rew_buf.max())
-        host = torch.stack(vals).cpu().tolist()          # the only synchronisation
-        self.wandb_dict = dict(zip(names, host))
-        return self.wandb_dict
+                mean, mx, mn = v[f.VS_TERM0 + 3 * k:f.VS_TERM0 + 3 * k + 3]
+                w = float(self.cfg["env"][_REWARD_KEYS[k] + "_REWARD_WEIGHT"])
+                d[f"Mean {name} Reward"] = mean
+                d[f"Max {name} Reward"] = mx
+                d[f"Weighted Mean {name} Reward"] = w * mean
+                d[f"Weighted Max {name} Reward"] = w * mx if w >= 0 else w * mn
+        d["Mean Total Reward"] = v[f.VS_REW_MEAN]
+        d["Max Total Reward"] = v[f.VS_REW_MAX]
+        self.wandb_dict = d
+        return d
+
+    def set_introspection(self, on=True):
+        """Arm / disarm the stores of the fields nothing in the step reads back (``prev_dof_pos``, ``prev_tip_positions``,
+        ``tip_velocities``, ``u_fpam``, ``u_rail_velocity``, ``prev_u_rail_velocity``, ``rail_force``, the mean contact
+        force): the reference exposes them as attributes and dashboard inputs; they are ~70 B of the step's HBM traffic
+        per env, so the step only stores them on request.  Takes effect with the next step launched outside a captured
+        hipGraph (a captured rollout keeps the setting it was captured with)."""
+        native.check(self._lib.vine_set_introspection(self._handle, int(bool(on))), self._lib)
+        self._introspection = bool(on)
 
     def observation_names(self):
         """Column names of the default observation layout (V5:1430-1437); generic names for the other layouts."""
@@ -358,6 +355,7 @@ class Vine5LinkMovingBase(VecTask):
         """Ask the kernel to also write the [N,13] unweighted reward matrix (V5:1272) each step."""
         self._reward_matrix = torch.zeros((self.num_envs, abi.NUM_REWARDS), device=self.device)
         native.check(self._lib.vine_bind_reward_matrix(self._handle, self._reward_matrix.data_ptr()), self._lib)
+        self._introspection = True           # the library arms VINE_FLAG_INTROSPECT together with the matrix
         return self._reward_matrix
 
     def bind_reset_values(self, values):
