@@ -34,7 +34,12 @@ def parse_args():
     p.add_argument("--steps", type=int, default=None)
     p.add_argument("--warmup", type=int, default=None)
     p.add_argument("--mode", choices=["env", "ppo"], default=None)
-    p.add_argument("--num-envs", type=int, default=16384, help="envs per GPU (BASELINE config 3: 16384)")
+    p.add_argument("--num-envs", type=int, default=16384,
+                   help="envs per GPU with --scaling weak (BASELINE config 3: 16384); TOTAL envs with --scaling strong")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak: every rank owns --num-envs envs and its own 32768-sample minibatches (BASELINE configs "
+                        "3/4); strong: --num-envs envs and every 32768-sample minibatch are split over the ranks "
+                        "(rank r owns envs [r n/W, (r+1) n/W) of the SAME batch: same seed, VineConfig.env_id_offset)")
     p.add_argument("--randomize", type=int, default=1, help="task.vine_randomize (task YAML default: True)")
     p.add_argument("--obs-type", default="POS_AND_FD_VEL_AND_OBJ_INFO")
     p.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
@@ -48,16 +53,27 @@ def parse_args():
     return p.parse_args()
 
 
-def make_env(args, rank, device_index):
+def make_env(args, rank, device_index, world=1):
     from vine_robot_isaacgymenvs_amd import load_config
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
-    ov = ["task=Vine5LinkMovingBase", "num_envs=%d" % args.num_envs, "vine_randomize=%s" % bool(args.randomize),
+    strong = getattr(args, "scaling", "weak") == "strong" and world > 1
+    n_rank = args.num_envs // world if strong else args.num_envs
+    ov = ["task=Vine5LinkMovingBase", "num_envs=%d" % n_rank, "vine_randomize=%s" % bool(args.randomize),
           "OBSERVATION_TYPE=%s" % args.obs_type, "headless=True",
           "task.env.CREATE_PIPE=False",      # default task YAML except CREATE_PIPE / CAPTURE_VIDEO
           "sim_device=cuda:%d" % device_index,
           "rl_device=cuda:%d" % device_index, "multi_gpu=%s" % (args.gpus > 1)]
     cfg = load_config(overrides=ov)
-    cfg["task"]["seed"] = 42 + 2 * rank        # train.py:78 + utils.py:50: the rank is added twice
+    if strong:
+        # one batch of --num-envs envs cut into W shards: same seed everywhere, the RNG keyed by the global env id, and
+        # the global minibatch (PY:80: 32768 samples) split evenly so that the optimiser takes the same number of steps
+        if args.num_envs % world or cfg["train"]["params"]["config"]["minibatch_size"] % world:
+            raise SystemExit("--scaling strong: num_envs and minibatch_size must be divisible by the number of ranks")
+        cfg["task"]["seed"] = 42
+        cfg["task"]["env"]["envIdOffset"] = rank * n_rank
+        cfg["train"]["params"]["config"]["minibatch_size"] //= world
+    else:
+        cfg["task"]["seed"] = 42 + 2 * rank        # train.py:78 + utils.py:50: the rank is added twice
     dev = "cuda:%d" % device_index
     env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device=dev, sim_device=dev,
                                                   graphics_device_id=device_index, headless=True,
@@ -228,7 +244,8 @@ def main():
     steps = args.steps if args.steps is not None else (10 if mode == "ppo" else 2000)
     warmup = args.warmup if args.warmup is not None else (3 if mode == "ppo" else 100)
 
-    env, cfg = make_env(args, rank, local_rank)
+    env, cfg = make_env(args, rank, local_rank, world)
+    strong = args.scaling == "strong" and world > 1
     n = env.num_envs
     extra = {}
 
@@ -267,9 +284,11 @@ def main():
         algo_bytes = ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/sec Vine5LinkMovingBase %d envs per GPU" % n,
+            "metric": ("env-steps/sec Vine5LinkMovingBase %d envs over %d GPUs" % (n * world, world)) if strong
+                      else "env-steps/sec Vine5LinkMovingBase %d envs per GPU" % n,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Vine5LinkMovingBase num_envs=%d per GPU, obs=%d, vine_randomize=%s, mode=%s "
                                    "(BASELINE.json configs[2]; x8 ranks = configs[3])"

@@ -60,3 +60,53 @@ def test_gradient_average_of_identical_shards_equals_single_process():
     one = _run(1, same_data=True)
     assert torch.allclose(two[0][0], one[0][0], rtol=1e-5, atol=1e-6)
     assert two[0][1] == pytest.approx(one[0][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_multi_gpu_code_path_on_one_rank(monkeypatch):
+    """The code every rank of a multi-GPU job executes, on the one GPU a test box has: RCCL world of ONE rank.
+    ``multi_gpu=True`` makes the agent pin its device, ``init_process_group("nccl", device_id=...)``, broadcast the
+    parameters, and run every optimiser step as two hipGraph replays around the EAGER ``all_reduce(comm_buffer)`` with
+    the collective capture decision in front (a 1-rank run without ``multi_gpu`` replays whole mini-epochs instead).
+    The result must equal the plain single-rank run: SUM over one rank / 1."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1").items():
+        monkeypatch.setenv(k, v)
+    results = []
+    try:
+        for multi in (True, False):
+            cfg = load_config(overrides=["num_envs=256", "minibatch_size=1024"])
+            cfg["task"]["seed"] = 42
+            env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                          graphics_device_id=0, headless=True)
+            params = cfg["train"]["params"]
+            params["config"].update(write_files=False, print_stats=False, use_graphs=True, multi_gpu=multi, device="cuda")
+            torch.manual_seed(0)
+            agent = A2CAgent("t", params, vec_env=env)
+            assert torch.cuda.current_device() == agent.device.index == 0
+            assert agent.multi_gpu == multi and (dist.is_initialized() or not multi)
+            if multi:
+                assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+            agent.init_tensors()
+            agent.obs = agent.env_reset()["obs"]
+            agent.broadcast_parameters()
+            torch.manual_seed(123)
+            for _ in range(3):
+                agent.train_epoch()
+            torch.cuda.synchronize()
+            assert agent.graph_status["rollout"] == "graph", agent.graph_status
+            assert agent.graph_status["update"].startswith("graph (2 per" if multi else "graph (1 per"), agent.graph_status
+            flat = torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone()
+            assert torch.isfinite(flat).all()
+            results.append((flat, float(agent.lr)))
+            env.close()
+        assert torch.allclose(results[0][0], results[1][0], rtol=1e-5, atol=1e-6)
+        assert results[0][1] == results[1][1]
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()

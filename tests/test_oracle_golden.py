@@ -222,3 +222,65 @@ def test_f5_pipe_pose_and_object_info(golden, shelf):
     assert 20 < np.degrees(st[abi.VF_OBJ_ANGLE]).min() and np.degrees(st[abi.VF_OBJ_ANGLE]).max() < 70
     if shelf:
         np.testing.assert_allclose(st[abi.VF_SHELF_Y], g["shelf_root"][:, 1], atol=2e-6)
+
+
+def stats_to_wandb(v, cfg, control_dt, with_terms=True):
+    """The reference's wandb_dict keys (V5:1250-1322) from a vine_stats vector: the same mapping the task class's
+    ``collect_stats`` applies (kept separate on purpose: this is the checker's reading of include/vine.h VineStat)."""
+    f = abi
+    names = ["Position", "Const Negative", "Position Success", "Velocity Success", "Velocity", "Rail Velocity Control",
+             "FPAM Control", "Rail Velocity Change", "FPAM Change", "Rail Limit", "Cart Y", "Tip Y", "Contact Force"]
+    d = {"dist_tip_to_target": v[f.VS_DIST_MEAN], "target_reached": v[f.VS_TARGET_REACHED], "limit_hit": v[f.VS_LIMIT_HIT],
+         "tip_limit_hit": v[f.VS_TIP_LIMIT_HIT], "abs_tip_y": v[f.VS_ABS_TIP_Y], "tip_z": v[f.VS_TIP_Z],
+         "max_abs_tip_y": v[f.VS_MAX_ABS_TIP_Y], "max_tip_z": v[f.VS_MAX_TIP_Z], "tip_velocities": v[f.VS_TIP_VEL_MEAN],
+         "tip_velocities_max": v[f.VS_TIP_VEL_MAX], "u_rail_velocity": v[f.VS_U_RAIL_ABS],
+         "prev_u_rail_velocity": v[f.VS_PREV_U_RAIL_ABS], "rail_force": v[f.VS_RAIL_FORCE_ABS], "u_fpam": v[f.VS_U_FPAM_ABS],
+         "smoothed_u_fpam": v[f.VS_SMOOTHED_ABS], "tip_target_velocity_difference": v[f.VS_TIP_VEL_MEAN],
+         "progress_buf": v[f.VS_PROGRESS_MEAN], "contact_forces": v[f.VS_CONTACT_MEAN],
+         "nonzero_contact_force": v[f.VS_CONTACT_NONZERO], "Aggregated Reward": v[f.VS_AGG_MEAN],
+         "Aggregated Reward 1 Std Up": v[f.VS_AGG_MEAN] + v[f.VS_AGG_STD],
+         "Aggregated Reward 1 Std Down": v[f.VS_AGG_MEAN] - v[f.VS_AGG_STD],
+         "Mean Total Reward": v[f.VS_REW_MEAN], "Max Total Reward": v[f.VS_REW_MAX]}
+    w0 = f.VS_VIEW0
+    q, qd, pq = v[w0:w0 + 6], v[w0 + 6:w0 + 12], v[w0 + 12:w0 + 18]
+    tip_y, tip_z, tip_vy, tip_vz, ptip_y, ptip_z, cart_y, cart_vy, tgt_y, tgt_z = v[w0 + 18:w0 + 28]
+    d["prismatic_q0 at self.index_to_view"], d["prismatic_qd0 at self.index_to_view"] = q[0], qd[0]
+    d["prismatic_finite_diff_qd0 at self.index_to_view"] = (q[0] - pq[0]) / control_dt
+    for j in range(5):
+        d["q%d at self.index_to_view" % j], d["qd%d at self.index_to_view" % j] = q[1 + j], qd[1 + j]
+        d["finite_diff_qd%d at self.index_to_view" % j] = (q[1 + j] - pq[1 + j]) / control_dt
+    for dr, vals in (("x", (0, 0, 0, 0, 0, 0, 0)),
+                     ("y", (tip_vy, cart_vy, 0, (tip_y - ptip_y) / control_dt, tip_y, cart_y, tgt_y)),
+                     ("z", (tip_vz, 0, 0, (tip_z - ptip_z) / control_dt, tip_z, 0.975, tgt_z))):
+        for key, val in zip(("tip_vel", "cart_vel", "target_vel", "finite_diff_tip_vel", "tip_pos", "cart_pos", "target_pos"), vals):
+            d["%s_%s at self.index_to_view" % (key, dr)] = val
+    u = v[f.VS_VIEW_U:f.VS_VIEW_U + 5]
+    d["u_fpam at self.index_to_view"], d["smoothed u_fpam at self.index_to_view"] = u[0], u[1]
+    d["u_rail_velocity at self.index_to_view"], d["rail_force at self.index_to_view"] = u[2], u[3]
+    d["contact_force at self.index_to_view"], d["nonzero_contact_force at self.index_to_view"] = u[4], float(u[4] > 0)
+    if with_terms:
+        for k, name in enumerate(names):
+            mean, mx, mn = v[f.VS_TERM0 + 3 * k:f.VS_TERM0 + 3 * k + 3]
+            w = cfg.reward_weights[k]
+            d["Mean %s Reward" % name], d["Max %s Reward" % name] = mean, mx
+            d["Weighted Mean %s Reward" % name] = w * mean
+            d["Weighted Max %s Reward" % name] = w * mx if w >= 0 else w * mn
+    return d
+
+
+def test_f7_dashboard_vector(golden):
+    """F7: the oracle's ``vine_stats`` after replaying F6 reproduces every scalar the reference's compute_reward left in
+    ``wandb_dict`` at the same step (V5:1250-1322) -- names through the VineStat layout of include/vine.h."""
+    g, ref = golden("f6_traj_delay1"), golden("f7_wandb_keys")
+    T, N, _ = g["actions"].shape
+    cfg = f6_cfg(N, 1, 0)
+    env = vo.OracleEnv(cfg, "f32")
+    env.bind_reward_matrix()
+    for t in range(T):
+        env.bind_reset_values(g["reset_values"][t])
+        env.step(g["actions"][t])
+    d = stats_to_wandb(env.stats(int(ref["index_to_view"])).astype(np.float64), cfg, float(cfg.dt) * cfg.control_freq_inv)
+    assert set(d) == set(str(k) for k in ref["keys"])
+    bad = [(str(k), d[str(k)], float(v)) for k, v in zip(ref["keys"], ref["values"])
+           if not abs(d[str(k)] - v) <= 1e-4 + 2e-4 * abs(v)]
+    assert not bad, bad

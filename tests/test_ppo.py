@@ -244,3 +244,52 @@ def test_baseline_config1_cpu_reference_path():
 def test_config_constraints_are_asserted():
     with pytest.raises(AssertionError, match="minibatch_size"):
         make_agent(num_envs=64, minibatch=32768)       # 64*16 = 1024 is not a multiple of 32768 (BASELINE config 1 note)
+
+
+@pytest.mark.parametrize("num_actions", [2, 1])
+def test_robot_side_control_model(tmp_path, num_actions):
+    """N2: the reference's deployment entry point (isaacgymenvs/vine_robot_test_model.py:143-177) -- constructor
+    (config pickle, checkpoint, x_range, u_range), get_action(q, qd, tip_pos, tip_vel, target_pos) on 1-D tensors
+    (N_OBS = 19 there), [-1, 1] -> (rail range, u range) by (x + 1) (high - low) / 2 + low, LSTM state carried
+    between calls -- on a checkpoint + config pickle written the way train.py writes them."""
+    import pickle
+    from vine_robot_isaacgymenvs_amd.vine_robot_test_model import VineRobotControlModel
+    cfg = load_config()
+    params = cfg["train"]["params"]
+    torch.manual_seed(3)
+    net = ModelA2CContinuousLogStd(params["network"], num_actions, (19,), True, True)
+    with torch.no_grad():
+        net.a2c_network.mu.weight.normal_(0, 0.03)         # make the mean depend on the observation visibly
+        net.running_mean_std.running_mean.normal_(0, 0.1)
+    torch.save({"model": net.state_dict(), "epoch": 7}, tmp_path / "p.pth")
+    with open(tmp_path / "cfg.pkl", "wb") as f:
+        pickle.dump({"params": params}, f)
+    x_range, u_range = (-10.0, 10.0), (-0.1, 3.0)
+    m = VineRobotControlModel(str(tmp_path / "cfg.pkl"), str(tmp_path / "p.pth"), x_range, u_range, deterministic=True).to("cpu")
+    g = torch.Generator().manual_seed(0)
+    args = [torch.randn(5, generator=g) * 0.2, torch.randn(5, generator=g), torch.randn(3, generator=g) * 0.3,
+            torch.randn(3, generator=g), torch.tensor([0.0, -0.4, 0.6])]
+    a1 = m.get_action(*args)
+    a2 = m.get_action(*args)                                # the LSTM state moved on: same input, different output
+    assert a1.shape == (num_actions,) and not torch.equal(a1, a2)
+    # against the network driven by hand
+    net.eval()
+    st = [s.clone() for s in net.get_default_rnn_state(1, "cpu")]
+    with torch.no_grad():
+        mu = torch.clamp(net({"is_train": False, "prev_actions": None, "obs": torch.cat(args)[None], "rnn_states": st})["mus"][0], -1, 1)
+    if num_actions == 2:
+        want = torch.stack([(mu[0] + 1) * 20.0 / 2 - 10.0, (mu[1] + 1) * 3.1 / 2 - 0.1])
+        assert x_range[0] <= float(a1[0]) <= x_range[1]
+    else:
+        want = (mu + 1) * 3.1 / 2 - 0.1
+    assert torch.allclose(a1, want, atol=1e-6) and u_range[0] <= float(a1[-1]) <= u_range[1]
+    assert float(m.rescale(torch.tensor(-1.0), 2.0, 6.0)) == 2.0 and float(m.rescale(torch.tensor(1.0), 2.0, 6.0)) == 6.0
+    m.reset()
+    assert torch.equal(m.get_action(*args), a1)             # episode start: state forgotten
+    # sampled actions (the reference player's default) stay inside the ranges
+    s = VineRobotControlModel(str(tmp_path / "cfg.pkl"), str(tmp_path / "p.pth"), x_range, u_range)
+    for _ in range(20):
+        a = s.get_action(*args)
+        assert u_range[0] - 1e-5 <= float(a[-1]) <= u_range[1] + 1e-5
+    with pytest.raises(ValueError):
+        m.get_action(args[0], args[1], args[2], args[3], torch.zeros(5))

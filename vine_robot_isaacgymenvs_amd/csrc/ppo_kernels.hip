@@ -1619,14 +1619,17 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        const float* __restrict__ logstd, const float* __restrict__ value,
                                                        const float* __restrict__ actions, const float* __restrict__ old_neglogp,
                                                        const float* __restrict__ adv, const float* __restrict__ old_values,
-                                                       const float* __restrict__ returns, const float* __restrict__ old_mu,
-                                                       const float* __restrict__ old_sigma, float e_clip, int clip_value,
+                                                       const float* __restrict__ returns,
+                                                       // old_mu / old_sigma may be the SAME buffers as mu_store /
+                                                       // sigma_store (update_old: the dataset refresh in place), so
+                                                       // none of the four is __restrict__
+                                                       const float* old_mu, const float* old_sigma, float e_clip, int clip_value,
                                                        float critic_coef, float entropy_coef, float bounds_coef,
                                                        float soft_bound, float* __restrict__ grad_mu,
                                                        float* __restrict__ grad_value, float* __restrict__ grad_logstd,
                                                        float* __restrict__ stats, long long mu_stride,
                                                        long long value_stride, float* __restrict__ partial,
-                                                       float* __restrict__ mu_store, float* __restrict__ sigma_store) {
+                                                       float* mu_store, float* sigma_store) {
     // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
     // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
     const float inv_n = 1.0f / (float)n;

@@ -150,14 +150,23 @@ class A2CAgent:
         if self.multi_gpu:
             self.rank = int(os.getenv("LOCAL_RANK", "0"))
             self.rank_size = int(os.getenv("WORLD_SIZE", "1"))
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                backend = "nccl" if str(config.get("device", "cuda")).startswith("cuda") else "gloo"
-                dist.init_process_group(backend, rank=int(os.getenv("RANK", self.rank)), world_size=self.rank_size)
             if str(config.get("device", "cuda:0")).startswith("cuda") and not config.get("device_pinned", False):
                 config["device"] = "cuda:" + str(self.rank)
         self.ppo_device = self.device = torch.device(config.get("device", "cuda:0"))
         self.is_cuda = self.device.type == "cuda"
+        if self.is_cuda:
+            # The hand-written kernels are launched through ctypes on `torch.cuda.current_stream(device)`; for the
+            # default stream that handle is 0 = "the null stream of the CURRENT device", and torch.cuda.graph() opens
+            # its capture stream on the current device too: the rank's GPU must be the current device of this process
+            # (train.py:71-75 of the reference relies on rl_games doing the same).
+            torch.cuda.set_device(self.device)
+        if self.multi_gpu and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"device_id": self.device} if self.is_cuda else {}
+            dist.init_process_group("nccl" if self.is_cuda else "gloo", rank=int(os.getenv("RANK", self.rank)),
+                                    world_size=self.rank_size, **kw)
+        # what actually runs, for logs and bench.py: "off" | "graph" | "eager (capture refused)" per phase
+        self.graph_status = {"rollout": "off", "update": "off"}
 
         self.name = base_name
         self.ppo = config.get("ppo", True)
@@ -568,7 +577,9 @@ class A2CAgent:
         if self.use_graphs:
             try:
                 self._play_graphed(body)
+                self.graph_status["rollout"] = "graph"
             except RuntimeError as err:          # capture refused (driver/runtime state): run eagerly from now on
+                self.graph_status["rollout"] = "eager (capture refused)"
                 if self._rollout_graph is not None and getattr(self, "_graph_replayed", False):
                     raise
                 print("hipGraph capture of the rollout failed (%s); continuing with eager launches" % str(err)[:200])
@@ -899,19 +910,39 @@ class A2CAgent:
                 and not self.truncate_grads and self.is_adaptive_lr and self.schedule_type == "legacy"
                 and getattr(self, "_epochs_run", 0) > 1 and not getattr(self, "_update_graphs_failed", False))
 
+    def _capture_agreed(self, ok):
+        """Whether EVERY rank captured its graph: the ranks must take the same path through the optimiser step (graph
+        replays around one eager all-reduce, or eager launches), so a refusal on one rank sends all of them eager.
+        One MIN all-reduce, only at the (rare) moments a capture is attempted -- all ranks attempt it at the same
+        optimiser step, so the collective is matched."""
+        if not self.multi_gpu:
+            return ok
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+
     def _update_step_graphed(self, i, row_out):
         # the running-statistics update of the observation normaliser (first mini-epoch only) is part of graph A:
         # its kernels use fixed-order two-stage sums and no memsets, so they replay faithfully
+        if getattr(self, "_update_graphs_failed", False):
+            return False
         key = (i, bool(self.normalize_input and self.model.running_mean_std.training))
         rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
         if rec is None:
+            err = None
             try:
                 rec = self._capture_update_step(i, key)
-            except RuntimeError as err:      # capture refused: nothing has executed, run this and later steps eagerly
-                print("hipGraph capture of the optimiser step failed (%s); continuing with eager launches"
-                      % str(err)[:200])
+            except RuntimeError as e:        # capture refused: nothing has executed
+                err = e
+            if not self._capture_agreed(rec is not None):
+                # this and every later step run eagerly, on every rank
+                print("hipGraph capture of the optimiser step failed on %s (%s); continuing with eager launches"
+                      % ("this rank" if err is not None else "another rank", str(err)[:200]))
+                if rec is not None:
+                    self._upd_graphs.pop(key, None)
                 self._update_graphs_failed = True
                 self._kl_in_comm = False
+                self.graph_status["update"] = "eager (capture refused)"
                 torch.cuda.synchronize(self.device)
                 return False
         rec["A"].replay()
@@ -919,6 +950,7 @@ class A2CAgent:
             dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)      # gradients + KL, RCCL over xGMI
         rec["B"].replay()
         row_out.copy_(rec["stats"])   # this rank's [a_loss, c_loss, b_loss, entropy, kl, loss, 0, 0]
+        self.graph_status["update"] = "graph (2 per optimiser step, all-reduce between)"
         return True
 
     def _update_epoch_graphed(self, rows_out):
@@ -933,10 +965,12 @@ class A2CAgent:
                 print("hipGraph capture of the mini-epoch failed (%s); continuing with eager launches" % str(err)[:200])
                 self._update_graphs_failed = True
                 self._kl_in_comm = False
+                self.graph_status["update"] = "eager (capture refused)"
                 torch.cuda.synchronize(self.device)
                 return False
         rec["G"].replay()
         rows_out.copy_(rec["stats"])
+        self.graph_status["update"] = "graph (1 per mini-epoch)"
         return True
 
     def _capture_update_epoch(self, key):

@@ -183,6 +183,9 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         "ppo": {"horizon": agent.horizon_length, "minibatch": agent.minibatch_size, "mini_epochs": agent.mini_epochs_num,
                 "optimizer_steps_per_iter": agent.mini_epochs_num * agent.num_minibatches,
                 "params": agent.num_params, "mixed_precision": bool(agent.fused_mixed or agent.mixed_precision),
-                "hipgraphs": bool(conf["use_graphs"]), "update_hipgraphs": len(getattr(agent, "_upd_graphs", {}))},
+                # the OUTCOME, not the request: a refused capture falls back to eager launches
+                "hipgraphs_requested": bool(conf["use_graphs"]), "hipgraphs_active": dict(agent.graph_status),
+                "hipgraphs": agent.graph_status["rollout"] == "graph" and agent.graph_status["update"].startswith("graph"),
+                "update_hipgraphs": len(getattr(agent, "_upd_graphs", {}))},
     }
     return elapsed, kernel_ms, frames, extra

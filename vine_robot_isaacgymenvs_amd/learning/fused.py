@@ -31,6 +31,11 @@ def _lib():
 
 
 def _stream(t):
+    # the kernels of csrc/ppo_kernels.hip launch on the CURRENT device (stream handle 0 = its null stream): the tensor
+    # must live there, else the launch would run on another GPU against this one's pointers
+    if t.device.index != torch.cuda.current_device():
+        raise RuntimeError("fused op on %s while the current device is cuda:%d: call torch.cuda.set_device first "
+                           "(A2CAgent and train.launch do)" % (t.device, torch.cuda.current_device()))
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -25,6 +25,10 @@ def launch(cfg):
         cfg["sim_device"] = f"cuda:{rank}"
         cfg["rl_device"] = f"cuda:{rank}"
         cfg["train"]["params"]["config"]["device"] = cfg["rl_device"]
+    if str(cfg["rl_device"]).startswith("cuda"):
+        import torch
+        if torch.cuda.is_available():        # the rank's GPU is the current device of the process from here on
+            torch.cuda.set_device(torch.device(cfg["rl_device"]))
     cfg["seed"] += rank                                                  # train.py:78 (and set_seed adds it again)
     cfg["seed"] = set_seed(cfg["seed"], torch_deterministic=cfg["torch_deterministic"], rank=rank)
     cfg["train"]["params"]["seed"] = cfg["seed"]
