@@ -54,6 +54,37 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
                         int64_t h_stride, float* c_out, void* gates_act, void* hp_next, const uint8_t* done_next,
                         int64_t done_next_stride, int64_t hp_stride, void* stream);
 
+/* Persistent LSTM forward over a whole (short) sequence, mixed precision, ONE launch for all T steps: a workgroup owns
+ * 32 sequences, keeps h_t (bf16, LDS) and c_t (fp32, registers) on chip between the steps and streams the weights from
+ * a fragment-ordered copy (vine_lstm_tile_weights) straight into the MFMA operand registers.  Same arithmetic, same
+ * accumulation order and same outputs as T calls of vine_lstm_step_mfma with the [x | h] operand.
+ *   x        [B*T, ldx] bf16, row = seq * T + t; its first KX columns are the step's input block (zero-padded to a
+ *            multiple of 32: KX in {32, 64, 96, 128})
+ *   hp       [B, T, H] bf16 (rows hp_stride apart): slot 0 holds the masked initial state (read), slots 1 .. T-1
+ *            receive the masked h_{t-1} each later step consumed (the recurrent weight gradient's operand)
+ *   w_tiled  vine_lstm_tile_weights(H, KX + H, [w_ih | 0 | w_hh], ...) -- [4H, KX + H] bf16 in fragment order
+ *   bias [4H] fp32 (b_ih + b_hh), c0 [B, H] fp32, done [B*T] uint8 (nullable)
+ *   h_out [B*T, H] fp32, c_all [T+1, B, H] fp32 (slots 1 .. T written), gates [T, B, 4H] bf16 (nullable)
+ * Needs B % 32 == 0, H == 256, T <= 8; VINE_ERR_UNSUPPORTED otherwise (callers use the per-step kernels). */
+int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
+                               int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
+                               const uint8_t* done, float* h_out, float* c_all, void* gates, void* stream);
+
+/* Fragment-ordered copy of an LSTM weight for the persistent kernels (H == 256; dst: H * K bf16 elements... K columns
+ * of all 4H rows for the forward form).  transposed = 0: src [4H, ld] row-major with K = 32 * ksteps columns used
+ * (forward operand [w_ih | 0 | w_hh]).  transposed = 1: src = w_hh [4H, ld >= H]; the copy serves the backward
+ * product dG w_hh (reduction over K = 4H, output units H). */
+int vine_lstm_tile_weights(int64_t H, int64_t K, const void* src, int64_t ld, int32_t transposed, void* dst, void* stream);
+
+/* Backward twin of vine_lstm_seq_forward_mfma: all T steps of vine_lstm_step_backward_mfma in ONE launch (dG_{t+1} in
+ * LDS, dc / c in registers).  g_out [B*T, H] fp32 (row = seq * T + t), w_hh_tiled = vine_lstm_tile_weights(H, 4H,
+ * w_hh, ld, 1, ...), gates [T, B, 4H] bf16 and c_all [T+1, B, H] fp32 as the forward pass left them (slot 0 of c_all
+ * is never read: c0 [B, H] is), done [B*T] uint8 (nullable); dgates [B*T, 4H] bf16 out; bias_partial (nullable)
+ * [B / 32, 4H] fp32: its column sums are the bias gradient.  Needs B % 32 == 0, H == 256, T <= 8. */
+int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_out, const void* w_hh_tiled,
+                                const void* gates, const float* c_all, const float* c0, const uint8_t* done,
+                                void* dgates, float* bias_partial, void* stream);
+
 /* Linear + bias + ELU on the matrix cores: out = elu(A W^T + bias) with A [n, K] bf16 (rows lda apart), W [N, K] bf16,
  * out [n, N] bf16 (rows out_stride apart, e.g. a column block of the LSTM operand buffer); the fp32 pre-activation is
  * never stored.  Needs n % 64 == 0, N % 64 == 0, K in {32, 64, 128, 256}; otherwise VINE_ERR_UNSUPPORTED (callers fall

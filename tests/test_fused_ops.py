@@ -241,6 +241,96 @@ def test_lstm_backward_mfma_matches_gemm_plus_pointwise(B, H, use_dones):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,use_dones", [(8192, True), (96, False), (32, True)])
+def test_lstm_sequence_kernels_equal_step_kernels(B, use_dones):
+    """The persistent sequence kernels (ONE launch for all T steps: h_t / dG_t in LDS, c_t / dc_t in registers, weights
+    streamed from the fragment-ordered copy) against the per-step matrix-core kernels they replace.  Same products in
+    the same accumulation order and the same pointwise formulas: every output must be BIT-identical (the bias-gradient
+    partial sums are folded in another order: tolerance)."""
+    import time
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    lib = fused._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    T, H, width, wpad = 4, 256, 92, 96
+    bf = torch.bfloat16
+    xfull = torch.zeros(B * T, wpad, device=dev, dtype=bf)
+    xfull[:, :width] = (torch.randn(B * T, width, device=dev) * 0.7).to(bf)
+    w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
+    w_hh = (torch.randn(4 * H, H, device=dev) / 16).to(bf)
+    bias = torch.randn(4 * H, device=dev) * 0.1
+    h0, c0 = torch.randn(B, H, device=dev) * 0.5, torch.randn(B, H, device=dev) * 0.5
+    dones = (torch.rand(B * T, device=dev) < 0.25).to(torch.uint8) if use_dones else None
+    wcat = torch.zeros(4 * H, wpad + H, device=dev, dtype=bf)
+    wcat[:, :width], wcat[:, wpad:] = w_ih, w_hh
+    # the fragment-ordered copies: through the batched operand-preparation launch and through the stand-alone entry
+    wtile, wtile2 = torch.empty(4 * H * (wpad + H), device=dev, dtype=bf), torch.empty(4 * H * (wpad + H), device=dev, dtype=bf)
+    whh_tiled, whh_tiled2 = torch.empty(4 * H * H, device=dev, dtype=bf), torch.empty(4 * H * H, device=dev, dtype=bf)
+    prep = fused.CopyBatch()
+    prep.add_lstm_tiles(w_ih, w_hh, wpad, wtile, whh_tiled)
+    prep.flush(xfull)
+    assert lib.vine_lstm_tile_weights(H, wpad + H, wcat.data_ptr(), wcat.stride(0), 0, wtile2.data_ptr(), st) == 0
+    assert lib.vine_lstm_tile_weights(H, 4 * H, w_hh.data_ptr(), w_hh.stride(0), 1, whh_tiled2.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(wtile, wtile2) and torch.equal(whh_tiled, whh_tiled2)
+    assert torch.equal(wtile.view(torch.int16).sort().values, wcat.flatten().view(torch.int16).sort().values)     # a permutation
+
+    def forward(**kw):
+        bufs = fused._lstm_state_buffers(xfull, w_hh, h0, c0, dones, T, True)
+        if B % 64 and "wcat" in kw:
+            return None
+        return fused._lstm_forward_steps(lib, xfull, None, w_hh, bias, h0, c0, dones, T, True, buffers=bufs, c0_direct=c0, **kw)
+    seq = forward(wtile=wtile)
+    step = forward(wcat=wcat)
+    torch.cuda.synchronize()
+    if step is None:        # the step kernels need B % 64 == 0: compare with the plain composition instead
+        ref_out, _, ref_c = fused._lstm_reference(xfull[:, :width].float(), w_ih.float(), w_hh.float(), bias, torch.zeros_like(bias),
+                                                  h0, c0, None if dones is None else dones, T)
+        assert float((seq[0] - ref_out).abs().max()) < 3e-2 and float((seq[1][T] - ref_c).abs().max()) < 3e-2
+    else:
+        for name, a, b in zip(("out", "c_all", "gates", "hp"), seq, step):
+            a, b = (a[1:], b[1:]) if name == "c_all" else (a, b)
+            assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+    out, c_all, gates, hp = seq
+    g_out = torch.randn(B * T, H, device=dev) * 0.1
+    dG_s, part_s = fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, c0_direct=c0, w_hh_tiled=whh_tiled)
+    if B % 64 == 0:
+        dG_p, part_p = fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, c0_direct=c0,
+                                                  w_hh_t=w_hh.t().contiguous())
+    else:
+        dG_p, part_p = fused._lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, c0_direct=c0)
+    torch.cuda.synchronize()
+    assert part_s.shape == (B // 32, 4 * H)
+    if B % 64 == 0:
+        assert torch.equal(dG_s, dG_p), float((dG_s.float() - dG_p.float()).abs().max())
+    else:
+        assert float((dG_s.float() - dG_p.float()).abs().max()) <= 1e-2 * float(dG_p.float().abs().max())
+    sa, sb = part_s.sum(0), part_p.view(-1, 4 * H).sum(0)
+    assert float((sa - sb).abs().max()) <= 1e-4 * float(sb.abs().max()) + 1e-5, float((sa - sb).abs().max())
+    # the bias partial sums ARE the column sums of the fp32 gate gradients: against the bf16 result within its rounding
+    assert float((sa - dG_s.float().sum(0)).abs().max()) <= 2e-2 * float(sa.abs().max())
+    if B == 8192:
+        for name, f in (("forward, one launch per step", lambda: forward(wcat=wcat)), ("forward, persistent", lambda: forward(wtile=wtile)),
+                        ("backward, one launch per step", lambda: fused._lstm_backward_steps(
+                            lib, g_out, w_hh, c_all, gates, dones, T, c0_direct=c0, w_hh_t=w_hh.t().contiguous())),
+                        ("backward, persistent", lambda: fused._lstm_backward_steps(
+                            lib, g_out, w_hh, c_all, gates, dones, T, c0_direct=c0, w_hh_tiled=whh_tiled))):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                f()
+            torch.cuda.synchronize()
+            print("lstm %s: %.1f us per 4-step sequence" % (name, (time.perf_counter() - t0) / 20 * 1e6))
+    # unsupported shapes are refused, not mis-run
+    assert lib.vine_lstm_seq_forward_mfma(B + 1, T, H, wpad, xfull.data_ptr(), wpad, hp.data_ptr(), T * H, wtile.data_ptr(),
+                                          bias.data_ptr(), c0.data_ptr(), None, out.data_ptr(), c_all.data_ptr(), None, st) == -2
+    assert lib.vine_lstm_seq_backward_mfma(B, 9, H, g_out.data_ptr(), whh_tiled.data_ptr(), gates.data_ptr(), c_all.data_ptr(),
+                                           c0.data_ptr(), None, dG_s.data_ptr(), None, st) == -2
+
+
+@pytest.mark.gpu
 def test_weight_grad_mfma_matches_float64_product(monkeypatch):
     """dy^T x on the matrix cores (transposed LDS reads, row slices + deterministic column sums) for every weight of the
     default network, against the float64 product of the same bf16 operands; operands that are column blocks of a

@@ -509,9 +509,10 @@ def test_largest_single_gpu_configuration(HipEnv):
             orc.step(a[lo:lo + 64].cpu().numpy())
         np.testing.assert_allclose(hip.obs_t[lo:lo + 64].cpu().numpy(), orc.obs, rtol=0, atol=5e-3)
         np.testing.assert_array_equal(hip.reset_t[lo:lo + 64].cpu().numpy(), orc.reset_buf)
-        # the reset draws of the block (targets: pure RNG outputs) are bit-identical to the shard's
-        np.testing.assert_array_equal(hip.state_t[abi.VF_TARGET_Y, lo:lo + 64].cpu().numpy(),
-                                      orc.state[abi.VF_TARGET_Y].astype(np.float32))
+        # the reset draws of the block (targets: an affine map of pure RNG outputs) agree with the shard's to 1 ulp
+        # (the kernel contracts min + span * u into one fma)
+        np.testing.assert_allclose(hip.state_t[abi.VF_TARGET_Y, lo:lo + 64].cpu().numpy(),
+                                   orc.state[abi.VF_TARGET_Y].astype(np.float32), rtol=0, atol=1e-7)
     hip.close()
 
 

@@ -178,6 +178,9 @@ PPO_PROTOTYPES = {
                                          _VP, _I64, C.c_int32, _I64, _VP]),
     "vine_lstm_step_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP,
                                       _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _I64, _VP]),
+    "vine_lstm_seq_forward_mfma": (C.c_int, [_I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_lstm_seq_backward_mfma": (C.c_int, [_I64, _I64, _I64] + [_VP] * 9),
+    "vine_lstm_tile_weights": (C.c_int, [_I64, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "vine_linear_elu_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_float, _VP, _I64, _VP]),
     "vine_linear_bwd_elu_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _I64, _VP,
                                            _VP]),

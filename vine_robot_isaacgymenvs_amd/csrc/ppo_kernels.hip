@@ -392,6 +392,409 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
     }
 }
 
+// ================================================================================================================
+// Persistent LSTM sequence kernels (mixed precision, H = 256): ONE launch runs all T time steps of a block of 32
+// sequences.  Against one launch per step (lstm_step_mfma64_kernel / lstm_bwd_mfma_kernel, where all 512 workgroups
+// march load -> matrix work -> hand-over -> pointwise -> store in lock-step and the phases add up):
+//   * h_t (forward) / dG_t (backward) stay in LDS as the next step's matrix operand, c_t / dc_t stay in registers:
+//     their HBM round trips and T - 1 kernel boundaries disappear;
+//   * the weights are streamed from L2 straight into MFMA operand registers, from a copy that is PRE-TILED in fragment
+//     order (every load instruction of a wave is one contiguous 1 KiB), through a register ring that keeps ~2.75
+//     k-steps in flight and runs ahead ACROSS the step boundary (the weights do not depend on h): no LDS staging of
+//     weights, no barrier inside the k-loop -- the only workgroup barrier is the one per time step that publishes h_t;
+//   * 8 waves per workgroup (2 per SIMD): while one wave of a SIMD is in its pointwise epilogue / issuing stores the
+//     other one can be in its matrix loop.
+// Workgroup = 512 threads = 8 waves; wave w owns hidden units [32 w, 32 w + 32) for all 32 rows: 2 unit tiles x
+// 4 gates x 2 row tiles of v_mfma_f32_16x16x32_bf16, computed transposed (D^T = W X^T) as in the step kernels so that
+// a lane ends up with consecutive hidden units of ONE batch row.  The weight rows of a tile are permuted -- tile
+// `ut`, row 4 q + j  <->  unit 32 w + 8 q + 4 ut + j -- so that the lane group q holds the 8 CONSECUTIVE units
+// 32 w + 8 q .. + 7 over its two tiles: 32-B fp32 / 16-B bf16 pieces per lane, 128 / 64 contiguous bytes per row.
+// Tiled weight layout (built by lstm_tile_weights_kernel, one 16-B chunk per lane):
+//   chunk(w, kk, j = 2 g + ut, lane)  =  Wsrc[row(g, unit)][32 kk + 8 (lane >> 4) .. + 8],
+//   unit = 32 w + 8 ((lane & 15) >> 2) + 4 ut + (lane & 3),  at chunk index ((w * KSTEPS + kk) * NJ + j) * 64 + lane.
+__device__ __forceinline__ float dpp_i2f(int x);
+__device__ __forceinline__ int dpp_f2i(float x);
+constexpr int SEQ_ROWS = 32;           // sequences per workgroup
+constexpr int SEQ_H = 256;             // hidden units (8 waves x 32)
+
+__device__ __forceinline__ void seq_barrier() {
+    // LDS hand-over between the waves of the workgroup: only the LDS counter has to drain -- the weight ring and
+    // the epilogue's stores stay in flight across the barrier (a __syncthreads() would wait for vmcnt(0) too)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// dst chunk -> source elements.  transposed = 0: Wsrc [rows, ld] row-major, row(g, unit) = g * H + unit, k along the
+// row (forward: [w_ih | 0 | w_hh], K = 32 KSTEPS).  transposed = 1: element (unit, k) = Wsrc[k * ld + unit] (backward:
+// Wsrc = w_hh [4H, H], the product dG W_hh sums over k = gate-major 4H index; NJ = 2, row(g, unit) = unit).
+__global__ __launch_bounds__(256) void lstm_tile_weights_kernel(const bf16_t* __restrict__ src, long long ld, int H, int ksteps,
+                                                                int nj, int transposed, bf16_t* __restrict__ dst) {
+    const long long chunks = (long long)(H / 32) * ksteps * nj * 64;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(c & 63);
+        long long r = c >> 6;
+        const int j = (int)(r % nj); r /= nj;
+        const int kk = (int)(r % ksteps);
+        const int w = (int)(r / ksteps);
+        const int ut = nj == 8 ? (j & 1) : j, g = nj == 8 ? (j >> 1) : 0;
+        const int unit = 32 * w + 8 * ((lane & 15) >> 2) + 4 * ut + (lane & 3);
+        const int k0 = 32 * kk + 8 * (lane >> 4);
+        uint4 v;
+        if (!transposed) {
+            v = *reinterpret_cast<const uint4*>(src + (long long)(g * H + unit) * ld + k0);
+        } else {
+            bf16_t e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) e[i] = src[(long long)(k0 + i) * ld + unit];
+            v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+            v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+        }
+        *reinterpret_cast<uint4*>(dst + c * 8) = v;
+    }
+}
+
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+__device__ __forceinline__ uint4 seq_load_frag(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&v)[8]) {
+    uint4 r;
+    r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
+    return r;
+}
+
+template <int KS1, int RING>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
+__global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
+    int T, long long B, const bf16_t* __restrict__ x, long long ldx, bf16_t* hp, long long hp_stride,
+    const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
+    const unsigned char* __restrict__ done, float* __restrict__ h_out, float* __restrict__ c_all,
+    bf16_t* __restrict__ gates) {
+    constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
+    constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
+    static_assert(NF % RING == 0, "the ring must close on a step boundary");
+    __shared__ __attribute__((aligned(16))) bf16_t xh[2][SEQ_ROWS * PITCH];      // [x_t | masked h_{t-1}] operand rows
+    __shared__ __attribute__((aligned(16))) float bias_l[4 * H];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the stream base below lives in SGPRs
+    const int col = lane & 15, lq = lane >> 4;
+    const long long b0 = (long long)blockIdx.x * SEQ_ROWS;
+    const int U0 = 32 * w + 8 * lq;                              // this lane's 8 consecutive hidden units
+    // ---- weight ring: the wave's own contiguous stream of NF fragments per step, RING of them in flight
+    // (scalar base + one 32-bit lane offset + immediates: 88 per-load 64-bit addresses would not fit the register file)
+    // addressed through a buffer descriptor: scalar base (this wave's stream) + ONE 32-bit lane offset + a scalar
+    // fragment offset per load -- plain pointers made the compiler keep 88 loop-invariant 64-bit addresses in VGPRs
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(Wt) + (long long)w * NF * 1024), 0, NF * 1024, 0x00020000);
+    const int wlane = lane * 16;
+#define SEQ_WFRAG(f) seq_load_frag(wrsrc, wlane, (f) * 1024)
+    uint4 ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = SEQ_WFRAG(i);
+    // ---- operand tile of step 0, bias, cell state, done flags
+    {
+        for (int p = tid; p < SEQ_ROWS * (KX / 8); p += 512) {
+            const int r = p / (KX / 8), c8 = p - r * (KX / 8);
+            *reinterpret_cast<uint4*>(&xh[0][r * PITCH + 8 * c8]) =
+                *reinterpret_cast<const uint4*>(x + ((b0 + r) * T) * ldx + 8 * c8);
+        }
+        for (int p = tid; p < SEQ_ROWS * (H / 8); p += 512) {
+            const int r = p >> 5, c8 = p & 31;
+            *reinterpret_cast<uint4*>(&xh[0][r * PITCH + KX + 8 * c8]) =
+                *reinterpret_cast<const uint4*>(hp + (b0 + r) * hp_stride + 8 * c8);      // slot 0: masked h_{-1}
+        }
+        for (int p = tid; p < H; p += 512) st4(&bias_l[4 * p], ld4(bias + 4 * p));
+    }
+    float c[2][8];
+    unsigned dmask[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const long long b = b0 + 16 * rt + col;
+        const float4 a = ld4(c0 + b * H + U0), bb = ld4(c0 + b * H + U0 + 4);
+        c[rt][0] = a.x; c[rt][1] = a.y; c[rt][2] = a.z; c[rt][3] = a.w;
+        c[rt][4] = bb.x; c[rt][5] = bb.y; c[rt][6] = bb.z; c[rt][7] = bb.w;
+        unsigned m = 0;
+        if (done)
+            for (int t = 0; t < T; ++t) m |= (done[b * T + t] ? 1u : 0u) << t;
+        dmask[rt] = m;
+    }
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        seq_barrier();                                           // xh[t & 1] complete (and bias_l on the first pass)
+        const bf16_t* xb = xh[t & 1];
+        bf16_t* xn = xh[(t + 1) & 1];
+        const bool last = t == T - 1;
+        // x_{t+1}: requested now, moved into the other operand buffer after the matrix loop
+        uint4 xstage = make_uint4(0, 0, 0, 0);
+        const int xr = tid / (KX / 8), xc8 = tid - xr * (KX / 8);
+        const bool xmine = tid < SEQ_ROWS * (KX / 8) && !last;
+        if (xmine) xstage = *reinterpret_cast<const uint4*>(x + ((b0 + xr) * T + t + 1) * ldx + 8 * xc8);
+        f32x4_t acc[4][2][2];                                    // [gate][unit tile][row tile]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) acc[g][ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = kk * 8 + j, slot = f % RING;
+                const uint4 wr = ring[slot];
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wr);
+                acc[j >> 1][j & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[j >> 1][j & 1][0], 0, 0, 0);
+                acc[j >> 1][j & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[j >> 1][j & 1][1], 0, 0, 0);
+                ring[slot] = SEQ_WFRAG((f + RING) % NF);          // the fragment RING places further down the stream
+                // pin the order {2 MFMAs, reload}: left alone, the scheduler sinks every reload down to its use one
+                // step later (to save registers) and the ring degenerates into load -> wait -> use
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (xmine) *reinterpret_cast<uint4*>(&xn[xr * PITCH + 8 * xc8]) = xstage;
+        // ---- pointwise epilogue on the accumulators: lane = batch row 16 rt + col, units U0 .. U0 + 7 (4 per unit tile;
+        // the bf16 outputs of tile 0 wait, packed, for tile 1 so that every bf16 store is one 16-B piece)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const long long b = b0 + 16 * rt + col;
+            const float keep = ((dmask[rt] >> t) & 1u) ? 0.0f : 1.0f;
+            const float kn = ((dmask[rt] >> (t + 1)) & 1u) ? 0.0f : 1.0f;
+            float* cp = c_all + ((long long)(t + 1) * B + b) * H + U0;
+            float* hpo = h_out + (b * T + t) * H + U0;
+            uint2 lo[5];                                         // i, f, g, o, masked h of tile 0
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut) {
+                const float4 bi = *reinterpret_cast<const float4*>(&bias_l[0 * H + U0 + 4 * ut]);
+                const float4 bf_ = *reinterpret_cast<const float4*>(&bias_l[1 * H + U0 + 4 * ut]);
+                const float4 bg = *reinterpret_cast<const float4*>(&bias_l[2 * H + U0 + 4 * ut]);
+                const float4 bo = *reinterpret_cast<const float4*>(&bias_l[3 * H + U0 + 4 * ut]);
+                const float bv[4][4] = {{bi.x, bi.y, bi.z, bi.w}, {bf_.x, bf_.y, bf_.z, bf_.w}, {bg.x, bg.y, bg.z, bg.w},
+                                        {bo.x, bo.y, bo.z, bo.w}};
+                float gi[4], gf[4], gg[4], go[4], hn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gi[u] = sigmoidf_(acc[0][ut][rt][u] + bv[0][u]);
+                    gf[u] = sigmoidf_(acc[1][ut][rt][u] + bv[1][u]);
+                    gg[u] = tanhf_(acc[2][ut][rt][u] + bv[2][u]);
+                    go[u] = sigmoidf_(acc[3][ut][rt][u] + bv[3][u]);
+                    const float cn = gf[u] * (keep * c[rt][4 * ut + u]) + gi[u] * gg[u];
+                    c[rt][4 * ut + u] = cn;
+                    hn[u] = go[u] * tanhf_(cn);
+                }
+                st4(cp + 4 * ut, make_float4(c[rt][4 * ut], c[rt][4 * ut + 1], c[rt][4 * ut + 2], c[rt][4 * ut + 3]));
+                st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
+                uint2 pk[5];
+                pk[0] = make_uint2(f2bf2(gi[0], gi[1]), f2bf2(gi[2], gi[3]));
+                pk[1] = make_uint2(f2bf2(gf[0], gf[1]), f2bf2(gf[2], gf[3]));
+                pk[2] = make_uint2(f2bf2(gg[0], gg[1]), f2bf2(gg[2], gg[3]));
+                pk[3] = make_uint2(f2bf2(go[0], go[1]), f2bf2(go[2], go[3]));
+                pk[4] = make_uint2(f2bf2(kn * hn[0], kn * hn[1]), f2bf2(kn * hn[2], kn * hn[3]));
+                if (ut == 0) {
+#pragma unroll
+                    for (int a = 0; a < 5; ++a) lo[a] = pk[a];
+                } else {
+                    if (gates) {
+                        bf16_t* ga = gates + ((long long)t * B + b) * 4 * H + U0;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<uint4*>(ga + g * H) = make_uint4(lo[g].x, lo[g].y, pk[g].x, pk[g].y);
+                    }
+                    if (!last) {   // the masked state step t + 1 consumes: next operand (LDS) + weight-gradient operand (HBM)
+                        const uint4 hm = make_uint4(lo[4].x, lo[4].y, pk[4].x, pk[4].y);
+                        *reinterpret_cast<uint4*>(&xn[(16 * rt + col) * PITCH + KX + U0]) = hm;
+                        *reinterpret_cast<uint4*>(hp + b * hp_stride + (long long)(t + 1) * H + U0) = hm;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- backward twin: all T steps of lstm_bwd_mfma_kernel for 32 sequences in one launch.  dG_{t+1} [32, 4H] stays in
+// LDS (bf16, the operand of the recurrent product dG_{t+1} W_hh), dc_t and c_t stay in registers, the bias-gradient
+// partial sums are carried in registers over the T steps and folded over the 32 rows once at the end (DPP row sums:
+// the 16 lanes of a DPP row are exactly the 16 batch rows of a unit group).  Wave w owns hidden units [32 w, 32 w + 32):
+// 2 unit tiles x 2 row tiles, K = 4H = 1024 streamed from the fragment-ordered copy of w_hh^T (64 fragments per step).
+__device__ __forceinline__ float dpp_row_sum16(float v) {
+    // sum over the 16 lanes of a DPP row, valid in lane 15 of the row
+    float s = v + dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x111, 0xf, 0xf, true));      // row_shr:1
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x112, 0xf, 0xf, true));                // row_shr:2
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x113, 0xf, 0xf, true));                // row_shr:3
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x114, 0xf, 0xe, true));                // row_shr:4
+    s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x118, 0xf, 0xc, true));                // row_shr:8
+    return s;
+}
+__device__ __forceinline__ void unpack_bf16x8(uint4 r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
+}
+
+template <int RING>
+__global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
+    int T, long long B, const float* __restrict__ g_out, const uint4* __restrict__ Wt, const bf16_t* __restrict__ gates,
+    const float* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
+    bf16_t* __restrict__ dG, float* __restrict__ bias_partial) {
+    constexpr int H = SEQ_H, K = 4 * H, KSTEPS = K / 32, NF = KSTEPS * 2;
+    constexpr int PITCH = K + 8;
+    static_assert(NF % RING == 0, "the ring must close on a step boundary");
+    extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
+    bf16_t (*dgl)[SEQ_ROWS * PITCH] = reinterpret_cast<bf16_t (*)[SEQ_ROWS * PITCH]>(seq_lds);     // [2][32 rows][4H + 8]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, lq = lane >> 4;
+    const long long b0 = (long long)blockIdx.x * SEQ_ROWS;
+    const int U0 = 32 * w + 8 * lq;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(Wt) + (long long)w * NF * 1024), 0, NF * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    uint4 ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = SEQ_WFRAG(i);
+    unsigned dmask[2];
+    float dcarry[2][8], cnew[2][8], bsum[4][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const long long b = b0 + 16 * rt + col;
+        unsigned m = 0;
+        if (done)
+            for (int t = 0; t < T; ++t) m |= (done[b * T + t] ? 1u : 0u) << t;
+        dmask[rt] = m;
+        const float4 a = ld4(c_all + ((long long)T * B + b) * H + U0), bb = ld4(c_all + ((long long)T * B + b) * H + U0 + 4);
+        cnew[rt][0] = a.x; cnew[rt][1] = a.y; cnew[rt][2] = a.z; cnew[rt][3] = a.w;
+        cnew[rt][4] = bb.x; cnew[rt][5] = bb.y; cnew[rt][6] = bb.z; cnew[rt][7] = bb.w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dcarry[rt][e] = 0.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[g][e] = 0.0f;
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; --t) {
+        const bool first = t == T - 1;
+        // operands of the pointwise part: those of row tile 0 are requested ahead of the matrix loop (their HBM round
+        // trip hides under it), those of row tile 1 when tile 0's arithmetic starts (registers: 32 fewer live in the loop)
+        float4 go4[2][2], cp4[2][2];
+        uint4 gpk[2][4];
+#define SEQ_BWD_LOAD(rt)                                                                                   \
+        {                                                                                                  \
+            const long long b_ = b0 + 16 * (rt) + col;                                                     \
+            const float* gp_ = g_out + (b_ * T + t) * H + U0;                                              \
+            go4[rt][0] = ld4(gp_); go4[rt][1] = ld4(gp_ + 4);                                              \
+            const float* cpp_ = (t == 0 ? c0 + b_ * H : c_all + ((long long)t * B + b_) * H) + U0;         \
+            cp4[rt][0] = ld4(cpp_); cp4[rt][1] = ld4(cpp_ + 4);                                            \
+            const bf16_t* ga_ = gates + ((long long)t * B + b_) * 4 * H + U0;                              \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) gpk[rt][g] = *reinterpret_cast<const uint4*>(ga_ + g * H); \
+        }
+        SEQ_BWD_LOAD(0)
+        f32x4_t acc[2][2];                                       // [unit tile][row tile]
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) acc[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        if (!first) {
+            seq_barrier();                                       // dG_{t+1} complete in dgl[(t + 1) & 1]
+            const bf16_t* xb = dgl[(t + 1) & 1];
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
+                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int f = kk * 2 + j, slot = f % RING;
+                    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, ring[slot]);
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[j][1], 0, 0, 0);
+                    ring[slot] = SEQ_WFRAG((f + RING) % NF);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        bf16_t* dgn = dgl[t & 1];
+        SEQ_BWD_LOAD(1)
+#undef SEQ_BWD_LOAD
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const long long b = b0 + 16 * rt + col;
+            const float keep = ((dmask[rt] >> t) & 1u) ? 0.0f : 1.0f;
+            const float keep_n = ((dmask[rt] >> (t + 1)) & 1u) ? 0.0f : 1.0f;
+            bf16_t* dgp = dG + (b * T + t) * 4 * H + U0;
+            uint2 lo[4];                                         // packed dG of unit tile 0 (waits for tile 1: 16-B pieces)
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut) {
+                // the 4 units of this tile: gate activations from the packed loads, the rest from the fp32 quads
+                float gi[4], gf[4], gg[4], go[4];
+                const unsigned ia = ut ? gpk[rt][0].z : gpk[rt][0].x, ib = ut ? gpk[rt][0].w : gpk[rt][0].y;
+                const unsigned fa = ut ? gpk[rt][1].z : gpk[rt][1].x, fb = ut ? gpk[rt][1].w : gpk[rt][1].y;
+                const unsigned ga_ = ut ? gpk[rt][2].z : gpk[rt][2].x, gb_ = ut ? gpk[rt][2].w : gpk[rt][2].y;
+                const unsigned oa = ut ? gpk[rt][3].z : gpk[rt][3].x, ob = ut ? gpk[rt][3].w : gpk[rt][3].y;
+                gi[0] = __uint_as_float(ia << 16); gi[1] = __uint_as_float(ia & 0xFFFF0000u);
+                gi[2] = __uint_as_float(ib << 16); gi[3] = __uint_as_float(ib & 0xFFFF0000u);
+                gf[0] = __uint_as_float(fa << 16); gf[1] = __uint_as_float(fa & 0xFFFF0000u);
+                gf[2] = __uint_as_float(fb << 16); gf[3] = __uint_as_float(fb & 0xFFFF0000u);
+                gg[0] = __uint_as_float(ga_ << 16); gg[1] = __uint_as_float(ga_ & 0xFFFF0000u);
+                gg[2] = __uint_as_float(gb_ << 16); gg[3] = __uint_as_float(gb_ & 0xFFFF0000u);
+                go[0] = __uint_as_float(oa << 16); go[1] = __uint_as_float(oa & 0xFFFF0000u);
+                go[2] = __uint_as_float(ob << 16); go[3] = __uint_as_float(ob & 0xFFFF0000u);
+                const float gout[4] = {go4[rt][ut].x, go4[rt][ut].y, go4[rt][ut].z, go4[rt][ut].w};
+                const float cp[4] = {cp4[rt][ut].x, cp4[rt][ut].y, cp4[rt][ut].z, cp4[rt][ut].w};
+                float di[4], df[4], dg[4], dout[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = 4 * ut + u;
+                    float dh = gout[u];
+                    if (!first) dh += keep_n * acc[ut][rt][u];
+                    const float dc = first ? 0.0f : keep_n * dcarry[rt][e];
+                    const float tc = tanhf_(cnew[rt][e]);
+                    const float d_o = dh * tc;
+                    const float d_c = dc + dh * go[u] * (1.0f - tc * tc);
+                    di[u] = d_c * gg[u] * gi[u] * (1.0f - gi[u]);
+                    df[u] = d_c * (keep * cp[u]) * gf[u] * (1.0f - gf[u]);
+                    dg[u] = d_c * gi[u] * (1.0f - gg[u] * gg[u]);
+                    dout[u] = d_o * go[u] * (1.0f - go[u]);
+                    dcarry[rt][e] = d_c * gf[u];
+                    cnew[rt][e] = cp[u];                          // c_{t-1} is c_new of the next (earlier) step
+                    bsum[0][e] += di[u]; bsum[1][e] += df[u]; bsum[2][e] += dg[u]; bsum[3][e] += dout[u];
+                }
+                uint2 pk[4];
+                pk[0] = make_uint2(f2bf2(di[0], di[1]), f2bf2(di[2], di[3]));
+                pk[1] = make_uint2(f2bf2(df[0], df[1]), f2bf2(df[2], df[3]));
+                pk[2] = make_uint2(f2bf2(dg[0], dg[1]), f2bf2(dg[2], dg[3]));
+                pk[3] = make_uint2(f2bf2(dout[0], dout[1]), f2bf2(dout[2], dout[3]));
+                if (ut == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) lo[g] = pk[g];
+                } else {
+                    bf16_t* row = dgn + (16 * rt + col) * PITCH + U0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint4 v = make_uint4(lo[g].x, lo[g].y, pk[g].x, pk[g].y);
+                        *reinterpret_cast<uint4*>(dgp + g * H) = v;
+                        if (t > 0) *reinterpret_cast<uint4*>(row + g * H) = v;
+                    }
+                }
+            }
+        }
+    }
+    if (bias_partial) {
+        float* outp = bias_partial + (long long)blockIdx.x * 4 * H + U0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = dpp_row_sum16(bsum[g][e]);
+            if (col == 15) {
+                st4(outp + g * H, make_float4(r[0], r[1], r[2], r[3]));
+                st4(outp + g * H + 4, make_float4(r[4], r[5], r[6], r[7]));
+            }
+        }
+    }
+}
+#undef SEQ_WFRAG
+
 // ---- Linear + bias + ELU on the matrix cores (the MLP layers of the mixed-precision path): out = elu(A W^T + bias),
 // A [n, K] bf16, W [N, K] bf16, out [n, N] bf16.  Same scheme as lstm_step_mfma_kernel: transposed product so that a
 // lane holds 4 consecutive output units of one row per 16-unit tile, W's 64 x K slab in LDS, A fragments from global
@@ -1521,6 +1924,7 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
 //   op 3 f32 -> bf16 src[r, c]
 //   op 4 add (f32)   src[r, c] + src2[r, c]
 //   op 5 masked      src[r, c] * (1 - mask[r * aux])   src f32, mask = src2 (uint8), dst f32 or bf16 by elem
+//   op 6 / 7         fragment-ordered LSTM weights for the persistent sequence kernels (see the kernel body)
 struct CopyJob {
     const void* src;
     const void* src2;
@@ -1542,6 +1946,42 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
     const long long total = J.rows * J.cols;
     const long long base = ((long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x) * 4;
     if (base >= total) return;
+    if (J.op >= 6) {
+        // fragment-ordered LSTM weight for the persistent kernels (layout: lstm_tile_weights_kernel).  dst is flat;
+        // element index -> (wave w, k-step kk, fragment j, lane, i) -> (unit, k).
+        //   op 6 (forward operand [w_ih | 0 | w_hh]): src = w_ih [4H, src_stride] with aux & 0xffff valid columns padded
+        //        with zeros to K1 = aux >> 16, src2 = w_hh [4H, dst_stride]; 8 fragments per k-step (j = 2 gate + tile)
+        //   op 7 (backward operand w_hh^T): src = w_hh [4H, src_stride], element (unit, k) = src[k][unit]; 2 fragments
+        const int H = SEQ_H;
+        const int cols1 = (int)(J.aux & 0xffff), K1 = (int)(J.aux >> 16);
+        const int nj = J.op == 6 ? 8 : 2, ksteps = J.op == 6 ? (K1 + H) / 32 : (4 * H) / 32;
+        const bf16_t* s1 = reinterpret_cast<const bf16_t*>(J.src);
+        const bf16_t* s2 = reinterpret_cast<const bf16_t*>(J.src2);
+        bf16_t* d = reinterpret_cast<bf16_t*>(J.dst);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const long long idx = base + q4;
+            if (idx >= total) break;
+            const int i = (int)(idx & 7);
+            long long c = idx >> 3;
+            const int lane = (int)(c & 63); c >>= 6;
+            const int jj = (int)(c % nj); c /= nj;
+            const int kk = (int)(c % ksteps);
+            const int wv = (int)(c / ksteps);
+            const int ut = J.op == 6 ? (jj & 1) : jj, g = J.op == 6 ? (jj >> 1) : 0;
+            const int unit = 32 * wv + 8 * ((lane & 15) >> 2) + 4 * ut + (lane & 3);
+            const int k = 32 * kk + 8 * (lane >> 4) + i;
+            bf16_t v;
+            if (J.op == 6) {
+                const long long row = (long long)g * H + unit;
+                v = k < K1 ? (k < cols1 ? s1[row * J.src_stride + k] : (bf16_t)0) : s2[row * J.dst_stride + (k - K1)];
+            } else {
+                v = s1[(long long)k * J.src_stride + unit];
+            }
+            d[idx] = v;
+        }
+        return;
+    }
     // (row, column) of the first of this thread's 4 consecutive elements, then carried along: one division per thread
     long long r = base / J.cols;
     int c = (int)(base - r * J.cols);
@@ -2119,6 +2559,62 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+int vine_lstm_tile_weights(int64_t H, int64_t K, const void* src, int64_t ld, int32_t transposed, void* dst, void* stream) {
+    if (!src || !dst || H <= 0 || K <= 0 || ld <= 0) return VINE_ERR_INVALID_ARG;
+    if (H != SEQ_H || (K & 31) || (!transposed && (ld < K || (ld & 7))) || (transposed && ld < H)) return VINE_ERR_UNSUPPORTED;
+    const int ksteps = (int)(K / 32), nj = transposed ? 2 : 8;
+    const long long chunks = (long long)(H / 32) * ksteps * nj * 64;
+    hipLaunchKernelGGL(lstm_tile_weights_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (long long)ld, (int)H, ksteps, nj, (int)transposed, (bf16_t*)dst);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
+                               int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
+                               const uint8_t* done, float* h_out, float* c_all, void* gates, void* stream) {
+    if (B <= 0 || T <= 0 || !x || !hp || !w_tiled || !bias || !c0 || !h_out || !c_all || ldx < KX || (ldx & 7) ||
+        hp_stride < T * H || (hp_stride & 7))
+        return VINE_ERR_INVALID_ARG;
+    if ((B % SEQ_ROWS) || H != SEQ_H || T > 8 || (KX != 32 && KX != 64 && KX != 96 && KX != 128)) return VINE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(B / SEQ_ROWS)), block(512);
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_SEQ_FWD(KS1, RING)                                                                                         \
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING>), grid, block, 0, s, (int)T, (long long)B, (const bf16_t*)x,     \
+                       (long long)ldx, (bf16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
+                       c_all, (bf16_t*)gates)
+    switch (KX / 32) {
+        case 1: VINE_SEQ_FWD(1, 24); break;      // 72 fragments per step
+        case 2: VINE_SEQ_FWD(2, 20); break;      // 80
+        case 3: VINE_SEQ_FWD(3, 22); break;      // 88: the update's [x (92 + 4 pad) | h] operand
+        default: VINE_SEQ_FWD(4, 24); break;     // 96
+    }
+#undef VINE_SEQ_FWD
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_out, const void* w_hh_tiled,
+                                const void* gates, const float* c_all, const float* c0, const uint8_t* done,
+                                void* dgates, float* bias_partial, void* stream) {
+    if (B <= 0 || T <= 0 || !g_out || !w_hh_tiled || !gates || !c_all || !c0 || !dgates) return VINE_ERR_INVALID_ARG;
+    if ((B % SEQ_ROWS) || H != SEQ_H || T > 8) return VINE_ERR_UNSUPPORTED;
+#ifndef SEQ_BWD_RING
+#define SEQ_BWD_RING 16
+#endif
+    constexpr int RING = SEQ_BWD_RING;
+    const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(bf16_t);          // 129 KiB: one workgroup per CU
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_bwd_kernel<RING>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VINE_ERR_DEVICE;
+        raised = true;
+    }
+    hipLaunchKernelGGL((lstm_seq_bwd_kernel<RING>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream,
+                       (int)T, (long long)B, g_out, (const uint4*)w_hh_tiled, (const bf16_t*)gates, c_all, c0, done,
+                       (bf16_t*)dgates, bias_partial);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
 int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
                          const float* bias, float alpha, void* out, int64_t out_stride, void* stream) {
     if (n <= 0 || N <= 0 || K <= 0 || !A || !W || !bias || !out || (lda & 7) || (ldw & 7) || (out_stride & 3))
@@ -2406,12 +2902,12 @@ int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, con
     CopyBatchArgs b;
     int blocks = 0;
     for (int k = 0; k < njobs; ++k) {
-        if (op[k] < 0 || op[k] > 5 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
-            (op[k] == 4 && !src2[k]) || (elem[k] != 2 && elem[k] != 4))
+        if (op[k] < 0 || op[k] > 7 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
+            ((op[k] == 4 || op[k] == 6) && !src2[k]) || (elem[k] != 2 && elem[k] != 4) || (op[k] >= 6 && elem[k] != 2))
             return VINE_ERR_INVALID_ARG;
         // vector path: every group of 4 consecutive elements is one aligned 8-/16-B access on both sides
         const int src_elem = op[k] == 0 ? elem[k] : 4;
-        const bool vec = op[k] != 2 && !(cols[k] & 3) && !(dst_stride[k] & 3) && !((uintptr_t)dst[k] & (4 * elem[k] - 1)) &&
+        const bool vec = op[k] != 2 && op[k] < 6 && !(cols[k] & 3) && !(dst_stride[k] & 3) && !((uintptr_t)dst[k] & (4 * elem[k] - 1)) &&
                          (op[k] == 1 || (!(src_stride[k] & 3) && !((uintptr_t)src[k] & (4 * src_elem - 1)))) &&
                          (op[k] != 4 || !((uintptr_t)src2[k] & 15));
         b.job[k] = CopyJob{src[k], src2[k], dst[k], (long long)rows[k], (long long)cols[k], (long long)src_stride[k],

@@ -154,6 +154,8 @@ class A2CAgent:
                 config["device"] = "cuda:" + str(self.rank)
         self.ppo_device = self.device = torch.device(config.get("device", "cuda:0"))
         self.is_cuda = self.device.type == "cuda"
+        if self.is_cuda and self.device.index is None:       # "cuda": the process's current device, made explicit
+            self.ppo_device = self.device = torch.device("cuda", torch.cuda.current_device())
         if self.is_cuda:
             # The hand-written kernels are launched through ctypes on `torch.cuda.current_stream(device)`; for the
             # default stream that handle is 0 = "the null stream of the CURRENT device", and torch.cuda.graph() opens

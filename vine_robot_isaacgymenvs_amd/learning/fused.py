@@ -221,7 +221,16 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0
     return out, c_all, gates, hp
 
 
-def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None, c0_direct=None):
+LSTM_SEQ = _os.environ.get("VINE_LSTM_SEQ", "1") != "0"      # 0: one launch per time step (the round-1 kernels), for A/B runs
+
+
+def lstm_seq_ok(B, H, T, wpad):
+    """Shapes the persistent sequence kernels (vine_lstm_seq_forward_mfma / _backward_mfma) cover."""
+    return LSTM_SEQ and B % 32 == 0 and H == 256 and 1 <= T <= 8 and wpad in (32, 64, 96, 128)
+
+
+def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None, c0_direct=None,
+                        wtile=None):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
     hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
     ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32.
@@ -238,6 +247,16 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
         c_prev[0] = c0_direct
     st = _stream(x)
     d_ptr = dones.data_ptr() if dones is not None else None
+    if wtile is not None:
+        # ONE launch for the whole sequence: h_t stays in LDS, c_t in registers, weights stream from the
+        # fragment-ordered copy (``wtile``); x = the padded operand buffer whose first K1 columns are the step input
+        K1 = wtile.numel() // (4 * H) - H
+        assert op == torch.bfloat16 and lstm_seq_ok(B, H, T, K1) and x.stride(0) >= K1 and hp.is_contiguous()
+        _check(lib.vine_lstm_seq_forward_mfma(B, T, H, K1, x.data_ptr(), x.stride(0), hp.data_ptr(), T * H,
+                                              wtile.data_ptr(), bias.data_ptr(), c_prev[0].data_ptr(), d_ptr,
+                                              out.data_ptr(), c_all.data_ptr(), gates.data_ptr() if need_grad else None,
+                                              st), "vine_lstm_seq_forward_mfma")
+        return out, c_all, gates, hp
     w_hh_t = w_hh.t()
     # mixed precision: the recurrent GEMM runs inside the step kernel on the matrix cores (vine_lstm_step_mfma)
     mfma = (op == torch.bfloat16 and B % 64 == 0 and H in (128, 256, 512))
@@ -279,7 +298,7 @@ def lstm_bwd_mfma_ok(B, H):
     return B % 64 == 0 and H in (128, 256)
 
 
-def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, c0_direct=None):
+def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, c0_direct=None, w_hh_tiled=None):
     """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials.
     dG is only ever a GEMM operand: it is stored in ``w_hh``'s dtype (bfloat16 in the mixed-precision update).
     ``w_hh_t`` ([H, 4H] bf16, the transposed recurrent weight): every step is ONE matrix-core kernel that forms the
@@ -294,6 +313,14 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, 
     c_prev = [c_all[t] for t in range(T)]
     if c0_direct is not None:            # the forward pass read c0 in place: c_all[0] was never written
         c_prev[0] = c0_direct
+    if w_hh_tiled is not None:           # ONE launch for all T steps (dG_{t+1} in LDS, dc / c in registers)
+        assert dG.dtype == torch.bfloat16 and lstm_seq_ok(B, H, T, 32) and gates.is_contiguous() and c_all.is_contiguous()
+        bias_partial = torch.empty((B // 32, 4 * H), device=dev, dtype=torch.float32)
+        _check(lib.vine_lstm_seq_backward_mfma(B, T, H, g_out.data_ptr(), w_hh_tiled.data_ptr(), gates.data_ptr(),
+                                               c_all.data_ptr(), c_prev[0].data_ptr(),
+                                               dones.data_ptr() if dones is not None else None, dG.data_ptr(),
+                                               bias_partial.data_ptr(), _stream(g_out)), "vine_lstm_seq_backward_mfma")
+        return dG, bias_partial
     if w_hh_t is not None:
         assert dG.dtype == torch.bfloat16 and lstm_bwd_mfma_ok(B, H)
         bias_partial = torch.empty((2, B // 64, 4 * H), device=dev, dtype=torch.float32)
@@ -386,7 +413,25 @@ class ColumnSumBatch:
 class CopyBatch:
     """Collects small 2-D element moves (copy / zero / transpose / fp32->bf16 cast / fp32 add) and runs them in ONE
     launch (``vine_copy_batched``): the operand preparation of an optimiser step is a dozen such moves."""
-    COPY, ZERO, TRANSPOSE, CAST_BF16, ADD, MASKED = 0, 1, 2, 3, 4, 5
+    COPY, ZERO, TRANSPOSE, CAST_BF16, ADD, MASKED, LSTM_TILE_FWD, LSTM_TILE_BWD = 0, 1, 2, 3, 4, 5, 6, 7
+
+    def add_lstm_tiles(self, w_ih, w_hh, wpad, fwd_dst, bwd_dst):
+        """Fragment-ordered bf16 copies of the LSTM weights for the persistent sequence kernels (csrc/ppo_kernels.hip,
+        lstm_tile_weights_kernel): ``fwd_dst`` [4H * (wpad + H)] from [w_ih | 0 | w_hh], ``bwd_dst`` [H * 4H] from
+        w_hh^T (either may be None)."""
+        H4, width = w_ih.shape
+        H = w_hh.shape[1]
+        assert w_ih.dtype == w_hh.dtype == torch.bfloat16 and w_ih.stride(1) == 1 and w_hh.stride(1) == 1 and H == 256
+        if fwd_dst is not None:
+            assert fwd_dst.numel() == H4 * (wpad + H) and fwd_dst.is_contiguous() and width <= wpad < 65536
+            self.keep.append((fwd_dst, w_ih, w_hh))
+            self.jobs.append((self.LSTM_TILE_FWD, 2, w_ih.data_ptr(), w_hh.data_ptr(), fwd_dst.data_ptr(), 1, fwd_dst.numel(),
+                              w_ih.stride(0), w_hh.stride(0), width | (wpad << 16)))
+        if bwd_dst is not None:
+            assert bwd_dst.numel() == H4 * H and bwd_dst.is_contiguous()
+            self.keep.append((bwd_dst, w_hh))
+            self.jobs.append((self.LSTM_TILE_BWD, 2, w_hh.data_ptr(), 0, bwd_dst.data_ptr(), 1, bwd_dst.numel(),
+                              w_hh.stride(0), 0, 0))
 
     def __init__(self):
         self.jobs, self.keep = [], []
@@ -546,8 +591,10 @@ class _Trunk(torch.autograd.Function):
         w_heads = torch.empty((A_ + v_w.shape[0], H), device=dev, dtype=torch.float32)
         b_heads = torch.empty(A_ + v_w.shape[0], device=dev, dtype=torch.float32)
         bias = torch.empty(4 * H, device=dev, dtype=torch.float32)
-        no_proj = mixed and B % 64 == 0 and H == 256 and wpad % 32 == 0 and wpad <= 128
+        seq = mixed and lstm_seq_ok(B, H, T, wpad)      # persistent sequence kernels (one launch per direction)
+        no_proj = seq or (mixed and B % 64 == 0 and H == 256 and wpad % 32 == 0 and wpad <= 128)
         wcat, wts, w_hh_t = None, [None] * n_mlp, None
+        wtile = w_hh_tiled = None
         if mixed:
             # every operand derived from the parameters or the observations, in ONE launch: bf16 cast of the
             # observations (layer-1 operand and the LSTM operand's obs block), zero pad columns, [w_ih | 0 | w_hh],
@@ -569,7 +616,12 @@ class _Trunk(torch.autograd.Function):
             else:
                 x0 = torch.empty((n, F_in), device=dev, dtype=op)
                 prep.add(CopyBatch.CAST_BF16, x0, obs_c)
-            if no_proj:
+            if seq:
+                # persistent sequence kernels: fragment-ordered weight copies instead of [w_ih | 0 | w_hh] / w_hh^T
+                wtile = torch.empty(4 * H * (wpad + H), device=dev, dtype=op)
+                w_hh_tiled = torch.empty(4 * H * H, device=dev, dtype=op)
+                prep.add_lstm_tiles(w_ih_op, w_hh_op, wpad, wtile, w_hh_tiled)
+            elif no_proj:
                 wcat = torch.empty((4 * H, wpad + H), device=dev, dtype=op)
                 prep.add(CopyBatch.COPY, wcat[:, :width], w_ih_op)
                 if wpad > width:
@@ -584,7 +636,7 @@ class _Trunk(torch.autograd.Function):
                 wts[0] = torch.empty((U, 4 * H), device=dev, dtype=op)
                 prep.add(CopyBatch.TRANSPOSE, wts[0], w_ih_op[:, :U])
             # transposed recurrent weight: the backward step forms dG_{t+1} w_hh inside its own kernel
-            if lstm_bwd_mfma_ok(B, H):
+            if not seq and lstm_bwd_mfma_ok(B, H):
                 w_hh_t = torch.empty((H, 4 * H), device=dev, dtype=op)
                 prep.add(CopyBatch.TRANSPOSE, w_hh_t, w_hh_op)
             prep.add(CopyBatch.COPY, w_heads[:A_], mu_w)
@@ -637,7 +689,7 @@ class _Trunk(torch.autograd.Function):
         if no_proj:
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
             out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat,
-                                                        buffers=lstm_buffers, c0_direct=c0_direct)
+                                                        buffers=lstm_buffers, c0_direct=c0_direct, wtile=wtile)
         else:
             ig = _mm(xcat, w_ih_op.t())
             out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True,
@@ -668,6 +720,7 @@ class _Trunk(torch.autograd.Function):
         ctx.fuse_heads = fuse_heads
         ctx.wts = wts
         ctx.w_hh_t = w_hh_t
+        ctx.w_hh_tiled = w_hh_tiled
         ctx.has_c0 = c0_direct is not None   # the caller's own c0 buffer is read again in backward (saved below)
         ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g, ln_b,
                               dones if dones is not None else obs_n.new_empty(0), *acts, *Wop,
@@ -745,7 +798,7 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
-                                                w_hh_t=ctx.w_hh_t, c0_direct=c0_direct)
+                                                w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled)
         deliver(base + 0, lambda o: weight_grad(dG, xcat, out=o, batch=batch))
         deliver(base + 1, lambda o: weight_grad(dG, hp.view(n, H), out=o, batch=batch))
         if bias_partial is not None and slots[base + 2] is not None and slots[base + 3] is not None:
