@@ -1,10 +1,8 @@
 #!/bin/bash
-# A/B two builds of the HIP library on the GPU box: scripts/ab_build.sh "<flagsA>" "<flagsB>"
-for v in A B; do
-  if [ $v = A ]; then F="$1"; else F="$2"; fi
-  VINE_HIPCC_FLAGS="$F" python3 -c "from vine_robot_isaacgymenvs_amd import native; native.build(force=True)"
-  for r in 1 2; do
-    python3 bench.py --mode env --steps 1000 --warmup 100 --no-cpu-baseline --randomize 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$v [$F] norand kernel_ms', d['roofline']['kernel_ms'], 'ms/step', d['ms_per_step'])"
-  done
-done
-python3 -c "from vine_robot_isaacgymenvs_amd import native; native.build(force=True)"
+# A/B builds of libvine_hip.so with extra compile flags: scripts/ab_build.sh <name> "<flags>"  -> build/libvine_<name>.so
+# (run with VINE_HIP_LIB=build/libvine_<name>.so; experiments only)
+set -e
+mkdir -p build
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=fast -fno-slp-vectorize -Wall -Wno-unused-function $2 \
+    -o build/libvine_$1.so vine_robot_isaacgymenvs_amd/csrc/vine_hip.hip vine_robot_isaacgymenvs_amd/csrc/ppo_kernels.hip
+echo built build/libvine_$1.so

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     int T, long long B, const bf16_t* __restrict__ x, long long ldx, bf16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
     const unsigned char* __restrict__ done, float* __restrict__ h_out, float* __restrict__ c_all,
-    bf16_t* __restrict__ gates) {
+    bf16_t* __restrict__ gates, int ablate) {
     constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
     constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wr);
                 acc[j >> 1][j & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[j >> 1][j & 1][0], 0, 0, 0);
                 acc[j >> 1][j & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[j >> 1][j & 1][1], 0, 0, 0);
-                ring[slot] = SEQ_WFRAG((f + RING) % NF);          // the fragment RING places further down the stream
+                if (!(ablate & 2)) ring[slot] = SEQ_WFRAG((f + RING) % NF);      // the fragment RING places further down the stream
                 // pin the order {2 MFMAs, reload}: left alone, the scheduler sinks every reload down to its use one
                 // step later (to save registers) and the ring degenerates into load -> wait -> use
                 __builtin_amdgcn_sched_barrier(0);
@@ -582,8 +582,10 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     c[rt][4 * ut + u] = cn;
                     hn[u] = go[u] * tanhf_(cn);
                 }
-                st4(cp + 4 * ut, make_float4(c[rt][4 * ut], c[rt][4 * ut + 1], c[rt][4 * ut + 2], c[rt][4 * ut + 3]));
-                st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
+                if (!(ablate & 1)) {
+                    st4(cp + 4 * ut, make_float4(c[rt][4 * ut], c[rt][4 * ut + 1], c[rt][4 * ut + 2], c[rt][4 * ut + 3]));
+                    st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
+                }
                 uint2 pk[5];
                 pk[0] = make_uint2(f2bf2(gi[0], gi[1]), f2bf2(gi[2], gi[3]));
                 pk[1] = make_uint2(f2bf2(gf[0], gf[1]), f2bf2(gf[2], gf[3]));
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
 #pragma unroll
                     for (int a = 0; a < 5; ++a) lo[a] = pk[a];
                 } else {
-                    if (gates) {
+                    if (gates && !(ablate & 1)) {
                         bf16_t* ga = gates + ((long long)t * B + b) * 4 * H + U0;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     if (!last) {   // the masked state step t + 1 consumes: next operand (LDS) + weight-gradient operand (HBM)
                         const uint4 hm = make_uint4(lo[4].x, lo[4].y, pk[4].x, pk[4].y);
                         *reinterpret_cast<uint4*>(&xn[(16 * rt + col) * PITCH + KX + U0]) = hm;
-                        *reinterpret_cast<uint4*>(hp + b * hp_stride + (long long)(t + 1) * H + U0) = hm;
+                        if (!(ablate & 1)) *reinterpret_cast<uint4*>(hp + b * hp_stride + (long long)(t + 1) * H + U0) = hm;
                     }
                 }
             }
@@ -636,7 +638,7 @@ template <int RING>
 __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
     int T, long long B, const float* __restrict__ g_out, const uint4* __restrict__ Wt, const bf16_t* __restrict__ gates,
     const float* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
-    bf16_t* __restrict__ dG, float* __restrict__ bias_partial) {
+    bf16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate) {
     constexpr int H = SEQ_H, K = 4 * H, KSTEPS = K / 32, NF = KSTEPS * 2;
     constexpr int PITCH = K + 8;
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
                     const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, ring[slot]);
                     acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[j][0], 0, 0, 0);
                     acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[j][1], 0, 0, 0);
-                    ring[slot] = SEQ_WFRAG((f + RING) % NF);
+                    if (!(ablate & 2)) ring[slot] = SEQ_WFRAG((f + RING) % NF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint4 v = make_uint4(lo[g].x, lo[g].y, pk[g].x, pk[g].y);
-                        *reinterpret_cast<uint4*>(dgp + g * H) = v;
+                        if (!(ablate & 1)) *reinterpret_cast<uint4*>(dgp + g * H) = v;
                         if (t > 0) *reinterpret_cast<uint4*>(row + g * H) = v;
                     }
                 }
@@ -2569,6 +2571,14 @@ int vine_lstm_tile_weights(int64_t H, int64_t K, const void* src, int64_t ld, in
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+// experiment knob of the persistent kernels, VINE_SEQ_ABLATE: bit 0 = no global stores, bit 1 = no weight reloads
+// (timing ablations only -- results are wrong; profiles/r02/lstm_seq_ablation.txt)
+static int seq_ablate() {
+    static int ab = -1;
+    if (ab < 0) { const char* e = getenv("VINE_SEQ_ABLATE"); ab = e ? atoi(e) : 0; }
+    return ab;
+}
+
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
                                const uint8_t* done, float* h_out, float* c_all, void* gates, void* stream) {
@@ -2578,10 +2588,11 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8 || (KX != 32 && KX != 64 && KX != 96 && KX != 128)) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B / SEQ_ROWS)), block(512);
     hipStream_t s = (hipStream_t)stream;
+    const int ablate = seq_ablate();
 #define VINE_SEQ_FWD(KS1, RING)                                                                                         \
     hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING>), grid, block, 0, s, (int)T, (long long)B, (const bf16_t*)x,     \
                        (long long)ldx, (bf16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
-                       c_all, (bf16_t*)gates)
+                       c_all, (bf16_t*)gates, ablate)
     switch (KX / 32) {
         case 1: VINE_SEQ_FWD(1, 24); break;      // 72 fragments per step
         case 2: VINE_SEQ_FWD(2, 20); break;      // 80
@@ -2598,7 +2609,7 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_
     if (B <= 0 || T <= 0 || !g_out || !w_hh_tiled || !gates || !c_all || !c0 || !dgates) return VINE_ERR_INVALID_ARG;
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8) return VINE_ERR_UNSUPPORTED;
 #ifndef SEQ_BWD_RING
-#define SEQ_BWD_RING 16
+#define SEQ_BWD_RING 8      // 16 does not fit the register file without spills: 76.7 us against 65.3 us per 4-step sequence
 #endif
     constexpr int RING = SEQ_BWD_RING;
     const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(bf16_t);          // 129 KiB: one workgroup per CU
@@ -2609,9 +2620,10 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_
             return VINE_ERR_DEVICE;
         raised = true;
     }
+    const int ablate = seq_ablate();
     hipLaunchKernelGGL((lstm_seq_bwd_kernel<RING>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream,
                        (int)T, (long long)B, g_out, (const uint4*)w_hh_tiled, (const bf16_t*)gates, c_all, c0, done,
-                       (bf16_t*)dgates, bias_partial);
+                       (bf16_t*)dgates, bias_partial, ablate);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -5,58 +5,69 @@ import time
 import torch
 
 
-def ppo_kernel_rooflines(device, B=8192, T=4, H=256, XW=96):
+def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
     """Stand-alone HIP-event timings of the two largest hand-written kernels of the mixed-precision update at its
-    shapes (one LSTM time step of a 32768-sample minibatch), priced against HBM with their algorithmic bytes:
-      lstm_step_mfma (forward step, GEMM fused): reads x_t bf16 [B,XW] + h_{t-1} bf16 [B,H] + c fp32 [B,H],
-          writes h, c fp32, masked h bf16, 4 gate activations bf16                     -> B*(2*XW + 2*H + 4*H*3 + 2*H + 8*H) bytes
-      lstm_step_backward_mfma (backward step, recurrent-gradient GEMM fused): reads dh, dc fp32, dG_{t+1} bf16 [B,4H],
-          gates bf16 [B,4H], c_t, c_{t-1} fp32; writes dG_t bf16 [B,4H], dc fp32     -> B * 44 H bytes"""
+    shapes (the LSTM over the 4-step sequences of a 32768-sample minibatch, ONE persistent launch per direction),
+    priced against HBM with their algorithmic bytes.  Every launch runs on its own operand / output set, `sets` of them
+    in rotation (> 256 MB in total: more than the Infinity Cache holds), so the figures are cold-cache ones; the
+    in-situ durations of the same kernels are in profiles/r02/ppo_iteration_graphed_kernel_stats.csv.
+      lstm_seq_fwd_kernel: reads x bf16 [B*T, wpad] + masked h0 bf16 [B, H] + c0 fp32 [B, H] + weights (bf16, 4H x
+          (wpad + H)); writes h fp32 [B*T, H], c fp32 [T, B, H], gate activations bf16 [T, B, 4H], masked h bf16 [B, T-1, H]
+      lstm_seq_bwd_kernel: reads dh fp32 [B*T, H], gates bf16 [T, B, 4H], c fp32 [T+1, B, H], w_hh bf16; writes dG bf16 [B*T, 4H]"""
     from . import fused
     lib = fused._lib()
     st = torch.cuda.current_stream(device).cuda_stream
     bf = torch.bfloat16
-    x = torch.randn(B * T, XW, device=device).to(bf)
-    hp = torch.randn(B, T, H, device=device).to(bf)
-    wcat = (torch.randn(4 * H, XW + H, device=device) / 16).to(bf)
-    whh = (torch.randn(4 * H, H, device=device) / 16).to(bf)
+    w_ih = (torch.randn(4 * H, width, device=device) / 10).to(bf)
+    w_hh = (torch.randn(4 * H, H, device=device) / 16).to(bf)
+    wtile = torch.empty(4 * H * (wpad + H), device=device, dtype=bf)
+    whh_tiled = torch.empty(4 * H * H, device=device, dtype=bf)
+    prep = fused.CopyBatch()
+    prep.add_lstm_tiles(w_ih, w_hh, wpad, wtile, whh_tiled)
+    prep.flush(wtile)
     bias = torch.zeros(4 * H, device=device)
-    c = torch.randn(T + 1, B, H, device=device)
-    out = torch.empty(B, T, H, device=device)
-    gates = torch.empty(T, B, 4 * H, device=device, dtype=bf)
-    g_out = torch.randn(B, T, H, device=device)
-    dc = [torch.randn(B, H, device=device) for _ in range(2)]
-    dG = torch.empty(B, T, 4 * H, device=device, dtype=bf)
-    part = torch.empty(2, B // 64, 4 * H, device=device)
+    data = []
+    for _ in range(sets):
+        x = torch.zeros(B * T, wpad, device=device, dtype=bf)
+        x[:, :width] = (torch.randn(B * T, width, device=device) * 0.7).to(bf)
+        c0 = torch.randn(B, H, device=device) * 0.5
+        hp = (torch.randn(B, T, H, device=device) * 0.5).to(bf)
+        dones = (torch.rand(B * T, device=device) < 0.2).to(torch.uint8)
+        data.append(dict(x=x, c0=c0, hp=hp, dones=dones, out=torch.empty(B * T, H, device=device),
+                         c_all=torch.empty(T + 1, B, H, device=device), gates=torch.empty(T, B, 4 * H, device=device, dtype=bf),
+                         g_out=torch.randn(B * T, H, device=device) * 0.1, dG=torch.empty(B * T, 4 * H, device=device, dtype=bf)))
+    part = torch.empty(B // 32, 4 * H, device=device)
 
-    def fwd():
-        assert lib.vine_lstm_step_mfma(B, H, XW + H, x.data_ptr(), T * XW, hp.data_ptr(), T * H, XW, wcat.data_ptr(), XW + H,
-                                       None, 4 * H, bias.data_ptr(), c[0].data_ptr(), None, 0, out.data_ptr(), T * H,
-                                       c[1].data_ptr(), gates[0].data_ptr(), hp.data_ptr() + 2 * H, None, 0, T * H, st) == 0
+    def fwd(i):
+        d = data[i % sets]
+        assert lib.vine_lstm_seq_forward_mfma(B, T, H, wpad, d["x"].data_ptr(), wpad, d["hp"].data_ptr(), T * H,
+                                              wtile.data_ptr(), bias.data_ptr(), d["c0"].data_ptr(), d["dones"].data_ptr(),
+                                              d["out"].data_ptr(), d["c_all"].data_ptr(), d["gates"].data_ptr(), st) == 0
 
-    whh_t = whh.t().contiguous()
-    dG.normal_()
+    def bwd(i):
+        d = data[i % sets]
+        assert lib.vine_lstm_seq_backward_mfma(B, T, H, d["g_out"].data_ptr(), whh_tiled.data_ptr(), d["gates"].data_ptr(),
+                                               d["c_all"].data_ptr(), d["c0"].data_ptr(), d["dones"].data_ptr(),
+                                               d["dG"].data_ptr(), part.data_ptr(), st) == 0
 
-    def bwd():
-        assert lib.vine_lstm_step_backward_mfma(B, H, g_out.data_ptr(), T * H, dG.data_ptr() + 2 * 4 * H, T * 4 * H,
-                                                whh_t.data_ptr(), 4 * H, dc[0].data_ptr(), None, 0, gates[0].data_ptr(),
-                                                c[1].data_ptr(), c[0].data_ptr(), None, 0, dG.data_ptr(), T * 4 * H,
-                                                dc[1].data_ptr(), part[0].data_ptr(), part[1].data_ptr(), st) == 0
-
+    fwd_bytes = (B * T * wpad * 2 + B * H * 2 + B * H * 4 + wtile.numel() * 2 + B * T
+                 + B * T * H * 4 + T * B * H * 4 + T * B * 4 * H * 2 + B * (T - 1) * H * 2)
+    bwd_bytes = (B * T * H * 4 + T * B * 4 * H * 2 + (T + 1) * B * H * 4 + whh_tiled.numel() * 2 + B * T
+                 + B * T * 4 * H * 2 + part.numel() * 4)
     res = []
-    for name, f, nbytes in (("lstm_step_mfma64_kernel", fwd, B * (2 * XW + 2 * H + 4 * H + 8 * H + 2 * H + 8 * H)),
-                            ("lstm_bwd_mfma_kernel", bwd, B * 44 * H)):
-        for _ in range(10):
-            f()
+    for name, f, nbytes in (("lstm_seq_fwd_kernel", fwd, fwd_bytes), ("lstm_seq_bwd_kernel", bwd, bwd_bytes)):
+        for i in range(2 * sets):
+            f(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(100):
-            f()
+        n = 10 * sets
+        for i in range(n):
+            f(i)
         e1.record()
         torch.cuda.synchronize(device)
-        us = e0.elapsed_time(e1) * 10.0
+        us = e0.elapsed_time(e1) * 1e3 / n
         res.append({"kernel": name, "us": us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": nbytes / us / 1e3,
-                    "hbm_frac": nbytes / us / 1e3 / 8000.0, "launches_per_ppo_iteration": 128})
+                    "hbm_frac": nbytes / us / 1e3 / 8000.0, "launches_per_ppo_iteration": 32, "cache_state": "cold (rotating sets)"})
     return res
 
 

@@ -65,6 +65,11 @@ def build(force=False, verbose=False):
 def load():
     """Return the ctypes handle of libvine_hip.so with prototypes attached."""
     global _lib
+    if _lib is None and os.environ.get("VINE_HIP_LIB"):
+        # experiments only (A/B builds of the kernels with other compile flags): load exactly this file
+        import torch  # noqa: F401
+        _lib = abi.declare_ppo(abi.declare(C.CDLL(os.environ["VINE_HIP_LIB"])))
+        return _lib
     if _lib is None:
         # PyTorch-ROCm ships its own libamdhip64.so.7; it must be the HIP runtime of the process, so it is
         # loaded first (two runtimes in one process do not both see the device).
