@@ -185,6 +185,26 @@ def cpu_baseline(args, seconds, mode, cfg):
         if dt >= env_seconds or n >= 1000:
             break
     env_only = args.num_envs * n / dt
+    # (a) of SURVEY 8(d): the same loop on ONE thread (a 2 s sample of a smaller batch: the per-env cost is what counts)
+    lib.vine_oracle_set_threads(1)
+    n1 = min(args.num_envs, 2048)
+    ocfg1 = vo.default_config(lib, num_envs=n1)
+    lib.vine_config_set_obs_type(ocfg1, abi.OBS_TYPE_BY_NAME[args.obs_type], 1)
+    ocfg1.set_flag(abi.FLAG_VINE_RANDOMIZE, bool(args.randomize))
+    env1 = vo.OracleEnv(ocfg1, "f32", omp=True)
+    env1.step(acts[0][:n1])
+    t0 = time.perf_counter()
+    k1 = 0
+    while time.perf_counter() - t0 < 2.0 and k1 < 1000:
+        env1.step(acts[k1 % 4][:n1])
+        k1 += 1
+    single = n1 * k1 / (time.perf_counter() - t0)
+    env1.close()
+    lib.vine_oracle_set_threads(int(cores))
+    try:
+        flops = {k: (float(v) if not isinstance(v, str) else v) for k, v in vo.flop_counts(256, 10, bool(args.randomize)).items()}
+    except Exception as err:      # the counting build is optional
+        flops = "unavailable: %s" % str(err)[:80]
     out = {"value": env_only, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
            "sample": "%d VecTask.step calls x %d envs (env step only, random actions), oracle/ float32 + OpenMP, %.1f s"
                      % (n, args.num_envs, dt)}
@@ -208,6 +228,28 @@ def cpu_baseline(args, seconds, mode, cfg):
                          "float32 + OpenMP env, PyTorch-CPU agent, %.1f s (rollout %.1f s, update %.1f s)"
                          % (args.num_envs, agent.horizon_length, agent.mini_epochs_num * agent.num_minibatches, dt, play, upd),
                "ppo_iters_per_sec": 1.0 / dt, "env_only_env_steps_per_sec": env_only}
+        # config C1 (BASELINE.json configs[0], the reference's own CPU-runnable case): 64 envs, 1 PPO iteration,
+        # minibatch 1024 (the default 32768 does not divide 64 x 16), same oracle env + PyTorch-CPU agent
+        try:
+            c1 = copy.deepcopy(cfg)
+            c1["task"]["env"]["numEnvs"] = 64
+            c1["task"]["env"].pop("envIdOffset", None)
+            p1 = c1["train"]["params"]
+            p1["config"].update(device="cpu", multi_gpu=False, write_files=False, print_stats=False, use_graphs=False,
+                                num_actors=64, minibatch_size=1024)
+            a1 = A2CAgent("cpu_c1", p1, vec_env=OracleVecTask(c1["task"], precision="f32", omp=True))
+            a1.init_tensors()
+            a1.obs = a1.env_reset()["obs"]
+            a1.train_epoch()                                   # warm-up (allocations)
+            t0 = time.perf_counter()
+            a1.train_epoch()
+            d1 = time.perf_counter() - t0
+            out["config_c1"] = {"num_envs": 64, "minibatch": 1024, "env_steps_per_sec": 64 * a1.horizon_length / d1,
+                                "ppo_iters_per_sec": 1.0 / d1}
+        except Exception as err:
+            out["config_c1"] = "unavailable: %s" % str(err)[:120]
+    out["single_thread_env_only_env_steps_per_sec"] = single
+    out["algorithmic_flops"] = flops
     return out
 
 

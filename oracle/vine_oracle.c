@@ -45,6 +45,26 @@ typedef VINE_REAL real;
 #define NL VINE_NUM_LINKS
 #define ND VINE_NUM_DOFS
 
+/* Flop instrumentation (-DVINE_COUNT_FLOPS, oracle/Makefile `flops`): every arithmetic block of the step path adds its
+ * operation count (+, -, *, / and each sin / cos / sqrt / log / exp counted as ONE) to one of three buckets as it runs,
+ * so loops, branches (randomisation, resets) and the solver's triangular loops are counted as executed:
+ *   bucket 0 = one substep (forward dynamics + integration), 1 = one actuation call, 2 = everything else of a step.
+ * vine_oracle_flop_counters() returns the totals and the number of substeps / actuation calls / env steps seen. */
+#ifdef VINE_COUNT_FLOPS
+static double g_flops[3], g_calls[3];
+static int g_bucket = 2;
+#define FLOPS(n) (g_flops[g_bucket] += (n))
+#define FLOP_BUCKET(b) (g_bucket = (b))
+#define FLOP_CALL(b) (g_calls[b] += 1)
+void vine_oracle_flop_counters(double* flops3, double* calls3, int reset) {
+    for (int i = 0; i < 3; ++i) { flops3[i] = g_flops[i]; calls3[i] = g_calls[i]; if (reset) { g_flops[i] = 0; g_calls[i] = 0; } }
+}
+#else
+#define FLOPS(n) ((void)0)
+#define FLOP_BUCKET(b) ((void)0)
+#define FLOP_CALL(b) ((void)0)
+#endif
+
 static __thread char g_err[256];
 static int fail(int code, const char* msg) {
     snprintf(g_err, sizeof g_err, "%s", msg);
@@ -229,22 +249,26 @@ static int chol_solve(int n, real A[ND][ND], real* x) {
         for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
         if (!(s > 0)) return -1;
         real Ljj = (real)sqrt((double)s);
+        FLOPS(2 * j + 1);
         A[j][j] = Ljj;
         for (int i = j + 1; i < n; ++i) {
             real t = A[i][j];
             for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
             A[i][j] = t / Ljj;
+            FLOPS(2 * j + 1);
         }
     }
     for (int i = 0; i < n; ++i) {
         real t = x[i];
         for (int k = 0; k < i; ++k) t -= A[i][k] * x[k];
         x[i] = t / A[i][i];
+        FLOPS(2 * i + 1);
     }
     for (int i = n - 1; i >= 0; --i) {
         real t = x[i];
         for (int k = i + 1; k < n; ++k) t -= A[k][i] * x[k];
         x[i] = t / A[i][i];
+        FLOPS(2 * (n - 1 - i) + 1);
     }
     return 0;
 }
@@ -424,14 +448,17 @@ static int fd_abs(const Model* M, const real* cj, real ycart, const real* th, re
         s[i] = (real)sin((double)th[i]); c[i] = (real)cos((double)th[i]);
         sp[i] = s0 * c[i] + c0 * s[i];   /* sin(phi_i) */
         cp[i] = c0 * c[i] - s0 * s[i];   /* cos(phi_i) */
+        FLOPS(8);
     }
     real T[NL + 1];
     T[0] = eff[1] - cj[1] * w[0] - M->kq * th[0];
     for (int i = 1; i < NL; ++i) T[i] = eff[i + 1] - cj[i + 1] * (w[i] - w[i - 1]) - M->kq * (th[i] - th[i - 1]);
     T[NL] = 0;
+    FLOPS(4 + 6 * (NL - 1));
     real A[ND][ND], r[ND];
     A[0][0] = M->mtot;
     r[0] = eff[0] - cj[0] * vy;
+    FLOPS(2);
     for (int i = 0; i < NL; ++i) {
         A[0][i + 1] = A[i + 1][0] = -M->b[i] * cp[i];
         r[0] -= M->b[i] * sp[i] * w[i] * w[i];
@@ -441,8 +468,10 @@ static int fd_abs(const Model* M, const real* cj, real ycart, const real* th, re
             real sd = s[i] * c[j] - c[i] * s[j];
             A[i + 1][j + 1] = M->a[i][j] * cd;
             ri -= M->a[i][j] * sd * w[j] * w[j];
+            FLOPS(11);
         }
         r[i + 1] = ri;
+        FLOPS(1 + 4 + 8);
     }
     if (M->implicit_damping) { /* h * T^T diag(cj) T with qd = T x_dot: tridiagonal */
         A[0][0] += h * cj[0];
@@ -450,7 +479,9 @@ static int fd_abs(const Model* M, const real* cj, real ycart, const real* th, re
             real cn = (i < NL - 1) ? cj[i + 2] : 0;
             A[i + 1][i + 1] += h * (cj[i + 1] + cn) + h * M->cad * M->I[i];
             if (i < NL - 1) { A[i + 1][i + 2] -= h * cn; A[i + 2][i + 1] -= h * cn; }
+            FLOPS(10);
         }
+        FLOPS(2);
     }
     if (M->armature != 0)      /* T^T diag(armature) T, same tridiagonal pattern */
         for (int i = 0; i < NL; ++i) {
@@ -473,6 +504,7 @@ static int forward_dynamics(const Model* M, int form, const real* cj, const real
     int rc = fd_abs(M, cj, q[0], th, qd[0], w, eff, h, acc);
     qdd[0] = acc[0]; qdd[1] = acc[1];
     for (int k = 1; k < NL; ++k) qdd[k + 1] = acc[k + 1] - acc[k];
+    FLOPS(2 * NL + NL - 1);
     return rc;
 }
 
@@ -495,6 +527,7 @@ static void tip_kinematics(const Model* M, const real* q, const real* qd, real* 
         real s = (real)sin((double)ang), c = (real)cos((double)ang);
         y += M->L * (-s); z += M->L * c;
         vy += M->L * om * (-c); vz += M->L * om * (-s);
+        FLOPS(2 + 2 + 4 + 6);
     }
     tip[0] = y; tip[1] = z; tip[2] = vy; tip[3] = vz;
 }
@@ -527,6 +560,7 @@ static int substep(const Model* M, int form, const real* cj, real* q, real* qd, 
     int rc = forward_dynamics(M, form, cj, q, qd, eff, h, qdd);
     if (rc) return rc;
     for (int i = 0; i < ND; ++i) qd[i] += h * qdd[i];
+    FLOPS(4 * ND);
     if (M->vmax_link > 0) {          /* clamp of the links' world angular velocities */
         real w = 0, prev = 0;
         for (int k = 0; k < NL; ++k) {
@@ -773,7 +807,9 @@ static void actuation(const VineConfig* c, const real* q, const real* qd, real c
         t += (real)c->fpam_B[j] * scale[15 + j] * u_used;
         eff[j + 1] = -t;
         if (cj) cj[j + 1] = (real)c->damping + (held ? 0 : cv);
+        FLOPS(2 + 1 + (held ? 2 : 1) + 2 + 3 + 1);
     }
+    FLOPS(1 + 1 + 2 + 2 + 4 + 1);
     real err = u_rail - cart_vy;                                   /* V5:1070 */
     real acc = (real)c->rail_acceleration;
     real fmax = acc / (real)2.0;                                   /* V5:1075 */
@@ -828,6 +864,7 @@ static int observations(const VineConfig* c, const real* q, const real* qd, cons
     o[k++] = 0; o[k++] = 0; o[k++] = 0;                              /* target_velocities == 0, V5:916-918 */
     o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
     for (int i = 0; i < k; ++i) o[i] = o[i] / (real)c->obs_scaling[i];                   /* V5:1385 */
+    FLOPS(1 + 4 + (c->obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ? 2 * ND : 2) + k);
     return k;
 }
 int vine_oracle_observations_ex(const VineConfig* c, const double* q, const double* qd, const double* prev_q,
@@ -873,6 +910,7 @@ static real reward_terms(const VineConfig* c, real dist, int reached, real tip_v
     rm[12] = -((contact > 0) ? contact : 0);
     real total = 0;
     for (int i = 0; i < VINE_NUM_REWARDS; ++i) total += rm[i] * (real)c->reward_weights[i];
+    FLOPS(4 + 8 + 2 * VINE_NUM_REWARDS);
     return total;
 }
 /* compute_reset_jit, V5:1540-1558 */
@@ -1142,6 +1180,8 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     const VineConfig* c = &h->cfg;
     const Model* M = &h->model;
     const uint64_t step = (uint64_t)h->step_count;
+    FLOP_CALL(2);
+    FLOPS(2 + 6 + 4);      /* clamp, action rescale (V5:1458-1463), smoothing filter (V5:999-1005) */
     const int randomize = (c->flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
     const int shelf = (c->flags & VINE_FLAG_CREATE_SHELF) != 0;
     const int pipe = (c->flags & VINE_FLAG_CREATE_PIPE) != 0;
@@ -1197,7 +1237,9 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
             }
         } else for (int k = 0; k < 20; ++k) scale[k] = 1;
         real eff[ND], cj[ND];
+        FLOP_BUCKET(1); FLOP_CALL(1);
         actuation(c, q, qd, cart_vy, u_rail, u_used, scale, &pcv, &pce, eff, cj);
+        FLOP_BUCKET(2);
         rail_force = eff[0];
         if (shelf) contact_sum += contact;                           /* VT:348-351 */
         real csum = 0;
@@ -1206,7 +1248,9 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
             for (int i = 0; i < ND; ++i) effc[i] = (i > 0 && s > 0 && M->effort_first_substep_only) ? 0 : eff[i];
             if (shelf) csum += shelf_contact(M, q, qd, shelf_y, shelf_z, effc);
             if (pipe) pipe_contact(M, q, qd, pipe_y, pipe_z, pipe_tp, effc);
+            FLOP_BUCKET(0); FLOP_CALL(0);
             substep(M, h->form, cj, q, qd, effc, hsub);
+            FLOP_BUCKET(2);
         }
         contact = shelf ? csum / (real)c->substeps : 0;
         tip_kinematics(M, q, qd, tip);                               /* refreshed rigid-body states */
@@ -1251,6 +1295,7 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
     /* compute_reward (V5:1218-1331) */
     real dy = tip[0] - ty, dz = tip[1] - tz;
     real dist = (real)sqrt((double)(dy * dy + dz * dz));             /* x components are both 0 */
+    FLOPS(6 + 3 + 1);      /* distance, comparisons, aggregated reward */
     int reached = dist < (real)c->success_dist;                      /* V5:1228 */
     int limit_hit = (cart_y > (real)c->rail_soft_limit) || (cart_y < -(real)c->rail_soft_limit); /* V5:1232 */
     int tip_limit_hit = tip[0] < ty;                                 /* V5:1237 */

@@ -28,13 +28,18 @@ _D = C.POINTER(C.c_double)
 
 
 def load(precision="f64", omp=False):
-    key = (precision, omp)
+    key = (precision, omp, "" if omp else os.environ.get("VINE_ORACLE_VARIANT", ""))
     if key in _cache:
         return _cache[key]
-    name = "libvine_oracle_%s%s.so" % (precision, "_omp" if omp else "")
+    # VINE_ORACLE_VARIANT=_asan: the sanitizer build (oracle/Makefile `asan-test`); "_flops": the flop-counting build
+    variant = "" if omp else os.environ.get("VINE_ORACLE_VARIANT", "")
+    name = "libvine_oracle_%s%s%s.so" % (precision, "_omp" if omp else "", variant)
     path = os.path.join(_BUILD, name)
     if not os.path.exists(path):
-        build()
+        if variant == "_asan":
+            subprocess.check_call(["make", "-C", _HERE, "asan"], stdout=subprocess.DEVNULL)
+        else:
+            build()
     lib = abi.declare(C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0)))
     P = C.POINTER(abi.VineConfig)
     lib.vine_oracle_real_bytes.restype = C.c_int
@@ -71,6 +76,42 @@ def load(precision="f64", omp=False):
     lib.vine_oracle_set_probe.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
     _cache[key] = lib
     return lib
+
+
+def flop_counts(num_envs=256, steps=20, randomize=True, seed=0):
+    """Algorithmic flops per env step measured by the counting build of the oracle (``make -C oracle flops``): random
+    actions through the full step; returns {"F_sub", "F_act", "F_post", "per_env_step"} (SURVEY 8d:
+    40 F_sub + 4 F_act + F_post).  RNG draws, the contact tests and the resets are NOT counted (integer / branchy work)."""
+    old = os.environ.get("VINE_ORACLE_VARIANT")
+    os.environ["VINE_ORACLE_VARIANT"] = "_flops"
+    try:
+        lib = load("f32")
+    finally:
+        if old is None:
+            os.environ.pop("VINE_ORACLE_VARIANT", None)
+        else:
+            os.environ["VINE_ORACLE_VARIANT"] = old
+    lib.vine_oracle_flop_counters.argtypes = [_D, _D, C.c_int]
+    cfg = default_config(lib, num_envs=num_envs)
+    cfg.set_flag(abi.FLAG_VINE_RANDOMIZE, randomize)
+    h = C.c_void_p()
+    assert lib.vine_create(C.byref(cfg), -1, None, C.byref(h)) == 0
+    n, nobs = num_envs, lib.vine_num_obs(C.byref(cfg))
+    obs, rew = np.zeros((n, nobs), np.float32), np.zeros(n, np.float32)
+    rst, prog, to = np.ones(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.uint8)
+    rng = np.random.default_rng(seed)
+    fl, calls = np.zeros(3), np.zeros(3)
+    lib.vine_oracle_flop_counters(_dp(fl), _dp(calls), 1)
+    for _ in range(steps):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        lib.vine_step(h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, rst.ctypes.data, prog.ctypes.data, to.ctypes.data, None)
+    lib.vine_oracle_flop_counters(_dp(fl), _dp(calls), 1)
+    lib.vine_destroy(h)
+    f_sub, f_act, f_post = fl[0] / calls[0], fl[1] / calls[1], fl[2] / calls[2]
+    return {"F_sub": f_sub, "F_act": f_act, "F_post": f_post,
+            "per_env_step": cfg.control_freq_inv * cfg.substeps * f_sub + cfg.control_freq_inv * f_act + f_post,
+            "substeps_per_env_step": calls[0] / calls[2], "note": "+, -, *, / and each sin/cos/sqrt counted as one; oracle's "
+            "plain formulation (full mass matrix, sincos per substep); RNG, contacts and resets not counted"}
 
 
 def default_config(lib=None, **overrides):

@@ -29,6 +29,24 @@ from .flat_adam import FlatAdam
 from .network import ModelA2CContinuousLogStd
 
 
+class _Range:
+    """roctx range (torch.cuda.nvtx is roctx on ROCm) around a phase of the iteration -- rollout, update, each graph
+    replay -- so that `rocprofv3 --marker-trace` timelines carry the phase names.  Off unless VINE_ROCTX=1: a push/pop
+    pair is host work inside the launch-bound loop."""
+    enabled = os.environ.get("VINE_ROCTX", "0") == "1"
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _Range.enabled:
+            torch.cuda.nvtx.range_push(self.name)
+
+    def __exit__(self, *a):
+        if _Range.enabled:
+            torch.cuda.nvtx.range_pop()
+
+
 def swap_and_flatten01(arr):
     """[T, N, ...] -> [N*T, ...] with index = env * T + t (each env's steps contiguous)."""
     if arr is None:
@@ -659,7 +677,8 @@ class A2CAgent:
                 self._g_out = [self.obs, self.dones, self.rnn_states, self.current_rewards, self.current_lengths,
                                self.game_rewards.mean, self.game_rewards.current_size, self.game_lengths.mean,
                                self.game_lengths.current_size]
-        self._rollout_graph.replay()
+        with _Range("rollout_graph_replay"):
+            self._rollout_graph.replay()
         self._graph_replayed = True
         # carry the outputs over to the static inputs of the next replay
         o = self._g_out
@@ -842,12 +861,14 @@ class A2CAgent:
         self._epochs_run = getattr(self, "_epochs_run", 0) + 1
         t_play = time.time()
         self.set_eval()
-        with torch.no_grad():
+        with torch.no_grad(), _Range("rollout"):
             batch = self.play_steps_rnn()
         if self.is_cuda:
             torch.cuda.synchronize(self.device)
         play_time = time.time() - t_play
         t_upd = time.time()
+        upd_range = _Range("update")
+        upd_range.__enter__()
         self.set_train()
         if self.fused_mixed:
             # the Adam kernel keeps the bf16 operand copies current; this catches every other writer of the
@@ -896,6 +917,7 @@ class A2CAgent:
                 self.model.running_mean_std.eval()   # statistics are updated during the first mini-epoch only
         if self.is_cuda:
             torch.cuda.synchronize(self.device)
+        upd_range.__exit__()
         update_time = time.time() - t_upd
         m = rows.mean(0)
         stats = {"a_loss": m[0], "c_loss": m[1], "entropy": m[3], "kl": m[4], "b_loss": m[2]}
@@ -947,10 +969,13 @@ class A2CAgent:
                 self.graph_status["update"] = "eager (capture refused)"
                 torch.cuda.synchronize(self.device)
                 return False
-        rec["A"].replay()
+        with _Range("update_graph_A_forward_loss_backward"):
+            rec["A"].replay()
         if self.multi_gpu:
-            dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)      # gradients + KL, RCCL over xGMI
-        rec["B"].replay()
+            with _Range("grad_all_reduce"):
+                dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)      # gradients + KL, RCCL over xGMI
+        with _Range("update_graph_B_adam_lr"):
+            rec["B"].replay()
         row_out.copy_(rec["stats"])   # this rank's [a_loss, c_loss, b_loss, entropy, kl, loss, 0, 0]
         self.graph_status["update"] = "graph (2 per optimiser step, all-reduce between)"
         return True
@@ -970,7 +995,8 @@ class A2CAgent:
                 self.graph_status["update"] = "eager (capture refused)"
                 torch.cuda.synchronize(self.device)
                 return False
-        rec["G"].replay()
+        with _Range("update_graph_mini_epoch"):
+            rec["G"].replay()
         rows_out.copy_(rec["stats"])
         self.graph_status["update"] = "graph (1 per mini-epoch)"
         return True
