@@ -9,7 +9,10 @@ from vine_robot_isaacgymenvs_amd import abi, native
 
 
 class HipEnv:
+    kernel = None        # "lane" / "quad": force the one-lane or the four-lanes-per-env step kernel (None: by size)
+
     def __init__(self, cfg, device_id=0):
+        import os
         self.lib = native.load()
         self.cfg = cfg
         self.n = cfg.num_envs
@@ -17,7 +20,17 @@ class HipEnv:
         self.num_obs = self.lib.vine_num_obs(C.byref(cfg))
         self.state_t = torch.zeros((abi.VF_COUNT, self.n), device=self.dev, dtype=torch.float32)
         h = C.c_void_p()
-        native.check(self.lib.vine_create(C.byref(cfg), device_id, self.state_t.data_ptr(), C.byref(h)), self.lib)
+        old = os.environ.get("VINE_STEP_KERNEL")
+        if self.kernel:
+            os.environ["VINE_STEP_KERNEL"] = self.kernel      # read by vine_create
+        try:
+            native.check(self.lib.vine_create(C.byref(cfg), device_id, self.state_t.data_ptr(), C.byref(h)), self.lib)
+        finally:
+            if self.kernel:
+                if old is None:
+                    os.environ.pop("VINE_STEP_KERNEL", None)
+                else:
+                    os.environ["VINE_STEP_KERNEL"] = old
         self.h = h
         self.obs_t = torch.zeros((self.n, self.num_obs), device=self.dev)
         self.rew_t = torch.zeros(self.n, device=self.dev)

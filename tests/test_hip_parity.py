@@ -19,13 +19,16 @@ from tests.helpers import base_cfg, f6_cfg, random_state
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def HipEnv():
+@pytest.fixture(scope="module", params=["lane", "quad"])
+def HipEnv(request):
+    """The product library through its C ABI, once per step kernel: "lane" = one env per lane (vine_step_kernel),
+    "quad" = four lanes per env (vine_step_quad_kernel) wherever that kernel applies (no obstacle, the two scalable
+    observation layouts; the library silently takes the one-lane kernel elsewhere)."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X (the product has no CPU fallback)")
     from tests.hip_env import HipEnv as H
-    return H
+    return type("HipEnv_" + request.param, (H,), {"kernel": request.param})
 
 
 def pair(HipEnv, cfg, precision="f32"):

@@ -144,7 +144,8 @@ __device__ __forceinline__ void make_sim_const(const DevParams& P, const float (
 
 template <bool IMPLICIT, bool CONTACT, bool EXTRAS>   // EXTRAS: joint stiffness / link angular damping switched on
 __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float (&eff)[ND], const float (&cj)[ND],
-                                        const SimConst& K, const float (&qa)[ND]) {
+                                        const SimConst& K, const float (&qa)[ND]
+                                        ) {
     const float (&sp)[NL] = s.sn;   // sin(phi_i), cos(phi_i)
     const float (&cp)[NL] = s.cs;
     float w2[NL];
@@ -854,6 +855,522 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
     }
 }
 
+// ================================================================================================================
+// Lane-cooperative step kernel: FOUR lanes per env (one DPP quad).  At the metric's 16384 envs per GPU the kernel above
+// fills 256 of the chip's 1024 SIMDs with one wave each and sits on the single-wave VALU issue rate; spread over a
+// quad the same envs are 1024 waves, each executing ~170 instead of ~275 instructions per substep.
+//   * lane t of a quad owns link t (angle, rate, sin / cos of the world angle); link 4 (the 100 g end link) and the
+//     cart are replicated on all four lanes;
+//   * every cross-lane operand is a DPP quad_perm source (broadcast of lane k, rotation by +-1, xor 1 / 2 for the
+//     quad sums): no LDS, no ds_bpermute;
+//   * the 6x6 system is solved by eliminating the two replicated rows first (cart: constant pivot; link 4), which
+//     leaves a 4x4 system with ONE ROW PER LANE, solved by Gauss-Jordan with the pivot row broadcast from lane j;
+//   * the glue is parallelised where it is expensive: lane i draws the dynamics-scaling factors of control iteration i
+//     (3 Philox calls instead of 12), lane t assembles, perturbs and stores observation columns [4t, 4t+4) and
+//     [16+4t, 16+4t+4) (2 Philox calls + 4 Box-Muller pairs instead of 7 + 14), lanes 0..2 draw one reset word each.
+// Same arithmetic model, same RNG keys and draw-to-variable mapping as vine_step_kernel (and the oracle): results
+// differ by round-off only (another elimination order).  Covers the configurations the rollout actually runs at that
+// size -- no obstacle, implicit joint damping, no joint stiffness / link damping, the two scalable observation
+// layouts; everything else takes the one-lane kernel.
+template <int CTRL>
+__device__ __forceinline__ float qperm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int K>
+__device__ __forceinline__ float qbcast(float v) { return qperm<K * 0x55>(v); }            // lane K of the quad
+__device__ __forceinline__ float qprev(float v) { return qperm<0x93>(v); }                 // lane t reads lane t - 1
+__device__ __forceinline__ float qnext(float v) { return qperm<0x39>(v); }                 // lane t reads lane t + 1
+__device__ __forceinline__ float quad_sum(float v) {
+    const float s = v + qperm<0xB1>(v);                                                    // xor 1
+    return s + qperm<0x4E>(s);                                                             // xor 2
+}
+// NOTE on selects: a DPP read must execute with the whole quad active -- a source lane that EXEC has switched off
+// delivers 0 -- and `c ? dpp(x) : y` is a branch around the DPP (C++ evaluates only the chosen operand, and the
+// compiler may not speculate a convergent operation).  Every cross-lane value is therefore produced unconditionally
+// and selected afterwards: pick() / sel4() take their operands by value.
+__device__ __forceinline__ float pick(bool c, float a, float b) { return c ? a : b; }
+__device__ __forceinline__ float sel4(int t, float v0, float v1, float v2, float v3) {
+    return t == 0 ? v0 : (t == 1 ? v1 : (t == 2 ? v2 : v3));
+}
+template <int K>
+__device__ __forceinline__ unsigned qbcast_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, true);
+}
+
+template <int OBS_TYPE, bool RANDOMIZE>
+__global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, float* __restrict__ st,
+                                                             const float* __restrict__ actions, float* __restrict__ obs,
+                                                             float* __restrict__ rew, long long* __restrict__ reset,
+                                                             long long* __restrict__ progress,
+                                                             unsigned char* __restrict__ timeouts,
+                                                             float* __restrict__ reward_matrix,
+                                                             const float* __restrict__ reset_values,
+                                                             unsigned long long* __restrict__ counters) {
+    static_assert(OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || OBS_TYPE == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, "");
+    constexpr int NOBS = OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ? 28 : 18;
+    const int n = P.n;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = gid >> 2, t = threadIdx.x & 3;
+    const unsigned long long step = counters[0];
+    if (e < n) {
+        // ---- per-lane constants of link t / joint t
+        const float b_t = sel4(t, P.b[0], P.b[1], P.b[2], P.b[3]);
+        const float gb_t = sel4(t, P.gb[0], P.gb[1], P.gb[2], P.gb[3]);
+        const float nb_t = -b_t;
+        float a_k[4], as_k[4];                           // a_tk (cos terms; a_tt on the diagonal), the same with 0 on the diagonal
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a_k[k] = sel4(t, P.a[0][k], P.a[1][k], P.a[2][k], P.a[3][k]);
+            as_k[k] = t == k ? 0.0f : a_k[k];
+        }
+        const float a_t4 = sel4(t, P.a[0][4], P.a[1][4], P.a[2][4], P.a[3][4]);
+        const float K_t = sel4(t, P.K[0], P.K[1], P.K[2], P.K[3]), C_t = sel4(t, P.C[0], P.C[1], P.C[2], P.C[3]);
+        const float bb_t = sel4(t, P.bb[0], P.bb[1], P.bb[2], P.bb[3]), B_t = sel4(t, P.B[0], P.B[1], P.B[2], P.B[3]);
+        // ---- VecTask.step: clamp actions (vec_task.py:333); pre_physics_step (V5:922-945), replicated on the quad
+        const float2 act = reinterpret_cast<const float2*>(actions)[e];
+        float a0 = clampf(act.x, P.clip_act), a1 = clampf(act.y, P.clip_act);
+        if (RANDOMIZE && P.act_noise != 0.0f) {
+            unsigned r[4];
+            float n0, n1;
+            rng4(P, (unsigned)e, step, RNG_ACTION_NOISE, 0, r);
+            normal2(r[0], r[1], n0, n1);
+            a0 += P.act_noise * n0;
+            a1 += P.act_noise * n1;
+        }
+        const float new_rail = a0 * P.rail_scale;
+        const float new_fpam = (a1 + 1.0f) * 0.5f * P.fpam_span + P.fpam_min;
+        float u_rail = new_rail, u_fpam = new_fpam;
+        if (P.delay > 0) {
+            const int slot = (int)(step % (unsigned long long)P.delay);
+            u_rail = ST(VF_FIFO0 + 2 * slot);
+            u_fpam = ST(VF_FIFO0 + 2 * slot + 1);
+            if (t == 0) {
+                ST(VF_FIFO0 + 2 * slot) = new_rail;
+                ST(VF_FIFO0 + 2 * slot + 1) = new_fpam;
+            }
+        }
+        if (P.flags & VINE_FLAG_FORCE_U_FPAM) u_fpam = 0.0f;
+        if (P.flags & VINE_FLAG_FORCE_U_RAIL_VELOCITY) u_rail = 0.0f;
+        float smoothed = ST(VF_SMOOTHED_U);
+        {
+            const float alpha = (u_fpam > smoothed) ? P.alpha_inf : P.alpha_def;
+            smoothed = alpha * smoothed + (1.0f - alpha) * u_fpam;
+        }
+        // relative joint coordinates: lane t holds joint t (dof 1 + t), everyone dof 5 and the cart
+        float q_own = ST(VF_Q0 + 1 + t), qd_own = ST(VF_QD0 + 1 + t);
+        float q5 = ST(VF_Q0 + 5), qd5 = ST(VF_QD0 + 5);
+        float y = ST(VF_Q0), vy = ST(VF_QD0);
+        const float prev_q_own = q_own, prev_q5 = q5, prev_y = y;
+        float tip_y = ST(VF_TIP_Y), tip_z = ST(VF_TIP_Z), tip_vy = 0.0f, tip_vz = 0.0f;
+        float prev_tip_y = tip_y, prev_tip_z = tip_z;
+        float prev_u_rail = u_rail;
+        float cart_y = ST(VF_CART_Y), cart_vy = ST(VF_CART_VY);
+        float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
+        float rail_force = 0.0f;
+        const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
+        const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
+        const bool introspect = (P.flags & VINE_FLAG_INTROSPECT) != 0;
+        // absolute angles / rates: inclusive prefix sums over the quad, then link 4 on top of lane 3's
+        float th, w;
+        {
+            float s = q_own + pick(t > 0, qprev(q_own), 0.0f);
+            th = s + pick(t >= 2, qperm<0x4E>(s), 0.0f);
+            float v = qd_own + pick(t > 0, qprev(qd_own), 0.0f);
+            w = v + pick(t >= 2, qperm<0x4E>(v), 0.0f);
+        }
+        float th4 = qbcast<3>(th) + q5, w4 = qbcast<3>(w) + qd5;
+        float sn, cs, sn4, cs4;
+        {
+            float s_, c_;
+            sincosf(th, &s_, &c_);
+            sn = P.s0 * c_ + P.c0 * s_; cs = P.c0 * c_ - P.s0 * s_;
+            sincosf(th4, &s_, &c_);
+            sn4 = P.s0 * c_ + P.c0 * s_; cs4 = P.c0 * c_ - P.s0 * s_;
+        }
+        // ---- dynamics-scaling factors: lane i draws the 20 factors of control iteration i (V5:1053-1055)
+        float scl[20];
+        if (RANDOMIZE && P.dyn_span != 0.0f) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                unsigned r[4];
+                rng4(P, (unsigned)e, step, RNG_DYN_SCALE, (unsigned)(t * 3 + g), r);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (g * 8 + k < 20) {
+                        const float u = (float)((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) * (1.0f / 65536.0f);
+                        scl[g * 8 + k] = P.dyn_min + P.dyn_span * u;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 20; ++k) scl[k] = RANDOMIZE ? P.dyn_min : 1.0f;
+        }
+        const float h = P.hsub;
+        const float gb4 = P.gb[4], b4 = P.b[4], a44 = P.a[4][4];
+        // ---- control_freq_inv x [actuation (V5:1028-1106), simulate]: iterations unrolled by 4 (the broadcasting lane
+        // of the scaling factors is a compile-time constant), any further ones reuse the pattern
+#define VINE_QUAD_ITER(IT)                                                                                               \
+        {                                                                                                                \
+            float sK, sC, sb, sB, sK4, sC4, sb4, sB4;                                                                    \
+            if (RANDOMIZE && P.dyn_span != 0.0f) {                                                                       \
+                sK = sel4(t, qbcast<IT>(scl[0]), qbcast<IT>(scl[1]), qbcast<IT>(scl[2]), qbcast<IT>(scl[3]));            \
+                sC = sel4(t, qbcast<IT>(scl[5]), qbcast<IT>(scl[6]), qbcast<IT>(scl[7]), qbcast<IT>(scl[8]));            \
+                sb = sel4(t, qbcast<IT>(scl[10]), qbcast<IT>(scl[11]), qbcast<IT>(scl[12]), qbcast<IT>(scl[13]));        \
+                sB = sel4(t, qbcast<IT>(scl[15]), qbcast<IT>(scl[16]), qbcast<IT>(scl[17]), qbcast<IT>(scl[18]));        \
+                sK4 = qbcast<IT>(scl[4]); sC4 = qbcast<IT>(scl[9]); sb4 = qbcast<IT>(scl[14]); sB4 = qbcast<IT>(scl[19]); \
+            } else {                                                                                                     \
+                sK = sC = sb = sB = sK4 = sC4 = sb4 = sB4 = scl[0];                                                      \
+            }                                                                                                            \
+            quad_simulate(sK, sC, sb, sB, sK4, sC4, sb4, sB4);                                                           \
+        }
+        auto quad_simulate = [&](float sK, float sC, float sb, float sB, float sK4, float sC4, float sb4, float sB4) {
+            // FPAM torque model of joint t (own) and joint 4 (replicated)
+            const float qj = th - pick(t > 0, qprev(th), 0.0f), qdj = w - pick(t > 0, qprev(w), 0.0f);
+            float tq = K_t * sK * qj;
+            const float cv = C_t * sC;
+            if (held) tq += cv * qdj;
+            tq += bb_t * sb;
+            tq += B_t * sB * u_used;
+            const float eff_t = -tq, cj_t = P.damping + (held ? 0.0f : cv);
+            const float q5r = th4 - qbcast<3>(th), qd5r = w4 - qbcast<3>(w);
+            float tq4 = P.K[4] * sK4 * q5r;
+            const float cv4 = P.C[4] * sC4;
+            if (held) tq4 += cv4 * qd5r;
+            tq4 += P.bb[4] * sb4;
+            tq4 += P.B[4] * sB4 * u_used;
+            const float eff4 = -tq4, cj4 = P.damping + (held ? 0.0f : cv4);
+            float eff0;
+            {   // rail controller (V5:1069-1098), replicated
+                const float err = u_rail - cart_vy;
+                const float fmax = P.rail_acc * 0.5f;
+                float minmax = (err > 0.0f) ? fmax : -fmax;
+                const float accel = (cart_vy - pcv) * P.inv_dt;
+                const float accel_target = (err > 0.0f) ? P.rail_acc : -P.rail_acc;
+                minmax += 0.30f * (accel_target - accel);
+                const float pid = P.p_gain * err + P.d_gain * (err - pce);
+                eff0 = (fabsf(err) > 0.1f) ? minmax : pid;
+                pce = err;
+                pcv = cart_vy;
+                rail_force = eff0;
+            }
+            // constants of this simulate: implicit damping folded into the matrix (tridiagonal in the absolute angles)
+            const float cj0 = P.damping;
+            const float hc_t = h * cj_t, hc4 = h * cj4, hc0 = h * cj0;
+            const float hc_n = pick(t == 3, hc4, qnext(hc_t));                 // damping of the joint BEYOND link t
+            float nbase[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nbase[k] = t == k ? hc_t + hc_n : (t == k + 1 ? -hc_t : (t == k - 1 ? -hc_n : 0.0f));
+            const float nb4 = t == 3 ? -hc4 : 0.0f;
+            const float adiag4 = a44 + hc4;
+            const float a00 = P.mtot + hc0;
+            const float inv_a00 = 1.0f / a00;
+            for (int ss = 0; ss < P.substeps; ++ss) {
+                const float w2 = w * w, w24 = w4 * w4;
+                // right-hand sides
+                const float dwm = w - pick(t > 0, qprev(w), 0.0f);
+                const float T = eff_t - cj_t * dwm;
+                const float T4 = eff4 - cj4 * (w4 - qbcast<3>(w));
+                const float Tn = pick(t == 3, T4, qnext(T));
+                float r = T - Tn + gb_t * sn;
+                float r4 = T4 + gb4 * sn4;
+                const float rc = eff0 - cj0 * vy - quad_sum(b_t * sn * w2) - b4 * sn4 * w24;
+                // cart column
+                const float Ac = nb_t * cs, A4c = -b4 * cs4;
+                // rows of the 4x4 block (absolute column index k), link-4 column
+                float R[4];
+#define VINE_QUAD_COL(KK)                                                                                \
+                {                                                                                        \
+                    const float ck = qbcast<KK>(cs), sk = qbcast<KK>(sn), w2k = qbcast<KK>(w2);          \
+                    const float cosd = fmaf(sn, sk, cs * ck), sind = fmaf(sn, ck, -(cs * sk));           \
+                    R[KK] = fmaf(a_k[KK], cosd, nbase[KK]);                                              \
+                    r = fmaf(-(as_k[KK] * sind), w2k, r);                                                \
+                }
+                VINE_QUAD_COL(0) VINE_QUAD_COL(1) VINE_QUAD_COL(2) VINE_QUAD_COL(3)
+#undef VINE_QUAD_COL
+                const float cos4 = fmaf(sn, sn4, cs * cs4), sin4 = fmaf(sn, cs4, -(cs * sn4));
+                float A4 = fmaf(a_t4, cos4, nb4);
+                const float as4 = a_t4 * sin4;
+                r = fmaf(-as4, w24, r);
+                r4 += quad_sum(as4 * w2);
+                // eliminate the cart (constant pivot a00)
+                const float fc = Ac * inv_a00;
+                R[0] = fmaf(-fc, qbcast<0>(Ac), R[0]); R[1] = fmaf(-fc, qbcast<1>(Ac), R[1]);
+                R[2] = fmaf(-fc, qbcast<2>(Ac), R[2]); R[3] = fmaf(-fc, qbcast<3>(Ac), R[3]);
+                A4 = fmaf(-fc, A4c, A4);
+                r = fmaf(-fc, rc, r);
+                const float f4c = A4c * inv_a00;
+                const float A44 = fmaf(-f4c, A4c, adiag4);
+                r4 = fmaf(-f4c, rc, r4);
+                // eliminate link 4
+                const float i44 = __builtin_amdgcn_rcpf(A44);
+                const float f4 = A4 * i44;
+                R[0] = fmaf(-f4, qbcast<0>(A4), R[0]); R[1] = fmaf(-f4, qbcast<1>(A4), R[1]);
+                R[2] = fmaf(-f4, qbcast<2>(A4), R[2]); R[3] = fmaf(-f4, qbcast<3>(A4), R[3]);
+                r = fmaf(-f4, r4, r);
+                // Gauss-Jordan on the 4x4 system, one row per lane, pivot row broadcast from lane j
+                float pown = 0.0f;
+#define VINE_QUAD_PIVOT(J)                                                                               \
+                {                                                                                        \
+                    const float pinv = __builtin_amdgcn_rcpf(R[J]);                                      \
+                    const float nf = pick(t == J, 0.0f, -(R[J] * qbcast<J>(pinv)));                          \
+                    if (J < 1) R[1] = fmaf(nf, qbcast<J>(R[1]), R[1]);                                   \
+                    if (J < 2) R[2] = fmaf(nf, qbcast<J>(R[2]), R[2]);                                   \
+                    if (J < 3) R[3] = fmaf(nf, qbcast<J>(R[3]), R[3]);                                   \
+                    r = fmaf(nf, qbcast<J>(r), r);                                                       \
+                    pown = t == J ? pinv : pown;                                                         \
+                }
+                VINE_QUAD_PIVOT(0) VINE_QUAD_PIVOT(1) VINE_QUAD_PIVOT(2) VINE_QUAD_PIVOT(3)
+#undef VINE_QUAD_PIVOT
+                const float x = r * pown;                                   // angular acceleration of link t
+                const float x4 = (r4 - quad_sum(A4 * x)) * i44;
+                const float ydd = (rc - A4c * x4 - quad_sum(Ac * x)) * inv_a00;
+                // semi-implicit Euler + incremental rotation of (sin, cos) (see substep() above)
+                vy += h * ydd;
+                y += h * vy;
+                {
+                    w += h * x;
+                    const float d = h * w;
+                    th += d;
+                    const float d2 = d * d;
+                    const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+                    const float sd = d * fmaf(d2, -1.0f / 6.0f, 1.0f);
+                    const float s_old = sn, c_old = cs;
+                    sn = fmaf(s_old, cd, c_old * sd);
+                    cs = fmaf(c_old, cd, -(s_old * sd));
+                }
+                {
+                    w4 += h * x4;
+                    const float d = h * w4;
+                    th4 += d;
+                    const float d2 = d * d;
+                    const float cd = fmaf(d2, fmaf(d2, 1.0f / 24.0f, -0.5f), 1.0f);
+                    const float sd = d * fmaf(d2, -1.0f / 6.0f, 1.0f);
+                    const float s_old = sn4, c_old = cs4;
+                    sn4 = fmaf(s_old, cd, c_old * sd);
+                    cs4 = fmaf(c_old, cd, -(s_old * sd));
+                }
+            }
+            cart_y = y;
+            cart_vy = vy;
+        };
+        {
+            int it = 0;
+            for (; it + 4 <= P.cfi; it += 4) { VINE_QUAD_ITER(0) VINE_QUAD_ITER(1) VINE_QUAD_ITER(2) VINE_QUAD_ITER(3) }
+        }
+#undef VINE_QUAD_ITER
+        // ---- refreshed rigid-body states: tip = joint 1 + L sum d_k (quad sums over links 0..3, link 4 on top)
+        {
+            const float L = P.L;
+            tip_y = y - L * (quad_sum(sn) + sn4);
+            tip_z = P.z1 + L * (quad_sum(cs) + cs4);
+            tip_vy = vy - L * (quad_sum(w * cs) + w4 * cs4);
+            tip_vz = -L * (quad_sum(w * sn) + w4 * sn4);
+        }
+        q_own = th - pick(t > 0, qprev(th), 0.0f);
+        qd_own = w - pick(t > 0, qprev(w), 0.0f);
+        q5 = th4 - qbcast<3>(th);
+        qd5 = w4 - qbcast<3>(w);
+        float q0 = y, qd0 = vy;
+        float prev_q0 = prev_y, prev_qo = prev_q_own, prev_q5v = prev_q5;
+        // ---- post_physics_step (V5:1110-1120)
+        long long prog = progress[e] + 1;
+        long long rst = reset[e];
+        float agg = ST(VF_AGG_REW);
+        float ty = ST(VF_TARGET_Y), tz = ST(VF_TARGET_Z);
+        if (rst != 0) {      // reset_idx (V5:774-839, 887-914): a quad-uniform branch
+            const float ten = 0.17453292519943295f;
+            float qn1_4[4], qn5, qn0, depth, pdepth;
+            if (reset_values) {
+                const float* v = reset_values + (size_t)e * 10;
+                qn1_4[0] = v[0]; qn1_4[1] = v[1]; qn1_4[2] = v[2]; qn1_4[3] = v[3];
+                qn5 = v[4]; qn0 = v[5]; pdepth = v[6]; ty = v[7]; tz = v[8]; depth = v[9];
+            } else {
+                // lanes 0..2 draw one Philox word quadruple each; the ten uniforms are then broadcast
+                unsigned r[4];
+                rng4(P, (unsigned)e, step, RNG_RESET, (unsigned)(t < 3 ? t : 0), r);
+                qn1_4[0] = -ten + (2.0f * ten) * u01(qbcast_u<0>(r[0]));
+                qn1_4[1] = -ten + (2.0f * ten) * u01(qbcast_u<0>(r[1]));
+                qn1_4[2] = -ten + (2.0f * ten) * u01(qbcast_u<0>(r[2]));
+                qn1_4[3] = -ten + (2.0f * ten) * u01(qbcast_u<0>(r[3]));
+                qn5 = -ten + (2.0f * ten) * u01(qbcast_u<1>(r[0]));
+                qn0 = P.cart_min + P.cart_span * u01(qbcast_u<1>(r[1]));
+                pdepth = P.depth_min + P.depth_span * u01(qbcast_u<1>(r[2]));
+                ty = P.ty_min + P.ty_span * u01(qbcast_u<1>(r[3]));
+                tz = P.tz_min + P.tz_span * u01(qbcast_u<2>(r[0]));
+                depth = P.depth_min + P.depth_span * u01(qbcast_u<2>(r[1]));
+            }
+            if (!(P.flags & VINE_FLAG_RANDOMIZE_DOF_INIT)) {
+                qn1_4[0] = qn1_4[1] = qn1_4[2] = qn1_4[3] = 0.0f; qn5 = 0.0f; qn0 = 0.0f;
+            }
+            if (!(P.flags & VINE_FLAG_RANDOMIZE_TARGETS)) { ty = P.ty_max; tz = P.tz_fixed; }
+            (void)depth; (void)pdepth;         // obstacle poses: this kernel runs without obstacles
+            rst = 0;
+            prog = 0;
+            q_own = sel4(t, qn1_4[0], qn1_4[1], qn1_4[2], qn1_4[3]);
+            q5 = qn5; q0 = qn0;
+            qd_own = 0.0f; qd5 = 0.0f; qd0 = 0.0f;
+            prev_qo = q_own; prev_q5v = q5; prev_q0 = q0;
+            ST(VF_Q0 + 1 + t) = q_own; ST(VF_QD0 + 1 + t) = 0.0f; ST(VF_PREV_Q0 + 1 + t) = q_own;
+            if (t == 0) {
+                ST(VF_Q0) = q0; ST(VF_QD0) = 0.0f; ST(VF_PREV_Q0) = q0;
+                ST(VF_Q0 + 5) = q5; ST(VF_QD0 + 5) = 0.0f; ST(VF_PREV_Q0 + 5) = q5;
+                ST(VF_TARGET_Y) = ty; ST(VF_TARGET_Z) = tz;
+            }
+            if (P.flags & VINE_FLAG_STALE_BODY_STATE_AFTER_RESET) {
+                prev_tip_y = tip_y;        // tip/cart rigid-body states keep their pre-reset values (V5:796-797 TODO)
+                prev_tip_z = tip_z;
+            } else {
+                // forward kinematics of the reset pose (zero rates): prefix sums of the new joint angles
+                float s = q_own + pick(t > 0, qprev(q_own), 0.0f);
+                const float thn = s + pick(t >= 2, qperm<0x4E>(s), 0.0f);
+                const float th4n = qbcast<3>(thn) + q5;
+                float s_, c_;
+                sincosf(thn, &s_, &c_);
+                const float snn = P.s0 * c_ + P.c0 * s_, csn = P.c0 * c_ - P.s0 * s_;
+                sincosf(th4n, &s_, &c_);
+                tip_y = q0 - P.L * (quad_sum(snn) + (P.s0 * c_ + P.c0 * s_));
+                tip_z = P.z1 + P.L * (quad_sum(csn) + (P.c0 * c_ - P.s0 * s_));
+                tip_vy = 0.0f; tip_vz = 0.0f;
+                prev_tip_y = tip_y; prev_tip_z = tip_z;
+                cart_y = q0; cart_vy = 0.0f;
+            }
+            prev_u_rail = 0.0f;
+            pce = 0.0f;
+            agg = 0.0f;
+        } else {
+            ST(VF_Q0 + 1 + t) = q_own; ST(VF_QD0 + 1 + t) = qd_own;
+            if (t == 0) { ST(VF_Q0) = q0; ST(VF_QD0) = qd0; ST(VF_Q0 + 5) = q5; ST(VF_QD0 + 5) = qd5; }
+            if (introspect) {
+                ST(VF_PREV_Q0 + 1 + t) = prev_qo;
+                if (t == 0) { ST(VF_PREV_Q0) = prev_q0; ST(VF_PREV_Q0 + 5) = prev_q5v; }
+            }
+        }
+        const float obj_depth = ST(VF_OBJ_DEPTH), obj_angle = ST(VF_OBJ_ANGLE);
+        // ---- compute_observations (V5:1339-1390): the row is assembled replicated, then lane t keeps, perturbs, clamps
+        // and stores columns [4t, 4t+4) and [16+4t, 16+4t+4)
+        float o[32];
+        {
+            const float fd_tip_y = (tip_y - prev_tip_y) * P.inv_cdt, fd_tip_z = (tip_z - prev_tip_z) * P.inv_cdt;
+            int k = 0;
+            if (OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+                const float fd_own = (q_own - prev_qo) * P.inv_cdt;
+                o[k++] = q0;
+                o[k++] = qbcast<0>(q_own); o[k++] = qbcast<1>(q_own); o[k++] = qbcast<2>(q_own); o[k++] = qbcast<3>(q_own);
+                o[k++] = q5;
+                o[k++] = (q0 - prev_q0) * P.inv_cdt;
+                o[k++] = qbcast<0>(fd_own); o[k++] = qbcast<1>(fd_own); o[k++] = qbcast<2>(fd_own); o[k++] = qbcast<3>(fd_own);
+                o[k++] = (q5 - prev_q5v) * P.inv_cdt;
+            } else {
+                o[k++] = q0;
+                o[k++] = (q0 - prev_q0) * P.inv_cdt;
+            }
+            o[k++] = 0.0f; o[k++] = tip_y; o[k++] = tip_z;
+            o[k++] = 0.0f; o[k++] = fd_tip_y; o[k++] = fd_tip_z;
+            o[k++] = 0.0f; o[k++] = ty; o[k++] = tz;
+            o[k++] = 0.0f; o[k++] = 0.0f; o[k++] = 0.0f;
+            o[k++] = smoothed; o[k++] = prev_u_rail; o[k++] = obj_depth; o[k++] = obj_angle;
+#pragma unroll
+            for (int i = 0; i < NOBS; ++i) o[i] = o[i] * P.inv_obs_scale[i];
+#pragma unroll
+            for (int i = NOBS; i < 32; ++i) o[i] = 0.0f;
+        }
+        float mine[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mine[c] = sel4(t, o[c], o[4 + c], o[8 + c], o[12 + c]);
+            mine[4 + c] = sel4(t, o[16 + c], o[20 + c], o[24 + c], o[28 + c]);
+        }
+        if (RANDOMIZE && P.obs_noise != 0.0f) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // Philox call index = first column / 4: t for columns [4t, 4t+4), 4 + t for [16+4t, ...)
+                unsigned r[4];
+                float nn[4];
+                rng4(P, (unsigned)e, step, RNG_OBS_NOISE, (unsigned)(4 * half + t), r);
+                normal2(r[0], r[1], nn[0], nn[1]);
+                normal2(r[2], r[3], nn[2], nn[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[4 * half + j] += P.obs_noise * nn[j];
+            }
+        }
+        {
+            float* orow = obs + (size_t)e * NOBS;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mine[j] = clampf(mine[j], P.clip_obs);
+            if (NOBS % 4 == 0) {
+                reinterpret_cast<float4*>(orow)[t] = make_float4(mine[0], mine[1], mine[2], mine[3]);
+                if (16 + 4 * t < NOBS) reinterpret_cast<float4*>(orow)[4 + t] = make_float4(mine[4], mine[5], mine[6], mine[7]);
+            } else {       // 18 columns: 72-B rows are 8-B aligned only
+                reinterpret_cast<float2*>(orow)[2 * t] = make_float2(mine[0], mine[1]);
+                reinterpret_cast<float2*>(orow)[2 * t + 1] = make_float2(mine[2], mine[3]);
+                if (t == 0) reinterpret_cast<float2*>(orow)[8] = make_float2(mine[4], mine[5]);
+            }
+        }
+        // ---- compute_reward (V5:1218-1331, 1470-1537), compute_reset (V5:1540-1558): replicated, lane 0 stores
+        const float dy = tip_y - ty, dz = tip_z - tz;
+        const float dist = sqrtf(dy * dy + dz * dz);
+        const bool reached = dist < P.success_dist;
+        const bool limit_hit = (cart_y > P.soft_limit) || (cart_y < -P.soft_limit);
+        const bool tip_limit_hit = tip_y < ty;
+        const float vnorm = sqrtf(tip_vy * tip_vy + tip_vz * tip_vz);
+        float rm[VINE_NUM_REWARDS];
+        rm[0] = -dist;
+        rm[1] = -1.0f;
+        rm[2] = reached ? 1000.0f : 0.0f;
+        rm[3] = -(reached ? vnorm : 0.0f);
+        rm[4] = vnorm;
+        rm[5] = -fabsf(u_rail);
+        rm[6] = -fabsf(u_fpam);
+        rm[7] = -fabsf(u_rail - prev_u_rail);
+        rm[8] = -fabsf(u_fpam - smoothed);
+        rm[9] = limit_hit ? -100.0f : 0.0f;
+        rm[10] = -fabsf(cart_y);
+        rm[11] = tip_limit_hit ? -100.0f : 0.0f;
+        rm[12] = -0.0f;
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < VINE_NUM_REWARDS; ++i) total += rm[i] * P.rw[i];
+        agg += total;
+        if (prog >= (long long)P.max_len - 1) rst = 1;
+        if (reached && (P.flags & VINE_FLAG_USE_TARGET_REACHED_RESET)) rst = 1;
+        if (tip_limit_hit && (P.flags & VINE_FLAG_USE_TIP_LIMIT_HIT_RESET)) rst = 1;
+        if (limit_hit) rst = 1;
+        const unsigned char to = (prog >= (long long)P.max_len - 1) && (rst != 0);
+        if (t == 0) {
+            rew[e] = total;
+            reset[e] = rst;
+            progress[e] = prog;
+            timeouts[e] = to;
+            if (reward_matrix) {
+#pragma unroll
+                for (int i = 0; i < VINE_NUM_REWARDS; ++i) reward_matrix[(size_t)e * VINE_NUM_REWARDS + i] = rm[i];
+            }
+            ST(VF_TIP_Y) = tip_y; ST(VF_TIP_Z) = tip_z;
+            ST(VF_CART_Y) = cart_y; ST(VF_CART_VY) = cart_vy;
+            ST(VF_SMOOTHED_U) = smoothed;
+            ST(VF_PREV_CART_VEL) = pcv; ST(VF_PREV_CART_VEL_ERR) = pce;
+            ST(VF_AGG_REW) = agg;
+            if (introspect) {
+                ST(VF_TIP_VY) = tip_vy; ST(VF_TIP_VZ) = tip_vz;
+                ST(VF_PREV_TIP_Y) = prev_tip_y; ST(VF_PREV_TIP_Z) = prev_tip_z;
+                ST(VF_U_FPAM) = u_fpam; ST(VF_U_RAIL) = u_rail; ST(VF_PREV_U_RAIL) = prev_u_rail;
+                ST(VF_RAIL_FORCE) = rail_force;
+            }
+        }
+    }
+    // ---- advance the step counter once every workgroup has read it (ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned long long ticket = atomicAdd(&counters[1], 1ull);
+        if (ticket == (unsigned long long)gridDim.x - 1) {
+            counters[1] = 0ull;
+            counters[0] = step + 1ull;
+            __threadfence();
+        }
+    }
+}
+
 // reset_idx(env_ids) from outside the step (vec_task.py:412-427; V5:715-718).
 __global__ void vine_reset_idx_kernel(const DevParams P, float* __restrict__ st, const long long* __restrict__ env_ids,
                                       long long count, float* __restrict__ rew, long long* __restrict__ reset,
@@ -1091,6 +1608,7 @@ struct VineHandle {
     unsigned long long* counters;  // [0] step count, [1] workgroup ticket
     const float* reset_values;
     float* reward_matrix;
+    int step_kernel;               // 0 = by size, 1 = one lane per env, 2 = four lanes per env where it applies (VINE_STEP_KERNEL)
     double* stats_psum;            // [STATS_BLOCKS][STATS_NSUM + 1] partial sums of vine_stats (allocated on first use)
     float* stats_pmax;             // [STATS_BLOCKS][STATS_NMAX]
 };
@@ -1209,6 +1727,8 @@ int vine_create(const VineConfig* cfg, int device_id, float* state_storage, Vine
     h->reward_matrix = nullptr;
     h->stats_psum = nullptr;
     h->stats_pmax = nullptr;
+    h->step_kernel = 0;
+    if (const char* k = getenv("VINE_STEP_KERNEL")) h->step_kernel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : 0);
     const size_t bytes = (size_t)VF_COUNT * cfg->num_envs * sizeof(float);
     if (state_storage) {
         h->state = state_storage;
@@ -1250,6 +1770,29 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     hipStream_t s = (hipStream_t)stream;
     const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
     const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
+    // four lanes per env (vine_step_quad_kernel) where the chip would otherwise be three quarters empty, for the
+    // configurations that kernel covers.  Measured (profiles/r02/step_kernels.txt): 4096 envs 30.7 -> 23.6 us, 16384 envs
+    // 32.5 -> 30.2 us, 32768 envs 35.3 -> 43.4 us: up to 16384 envs the quad kernel, beyond one lane per env
+    const bool quad_ok = obst == 0 && h->P.cfi == 4 && (h->P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) && h->P.kq == 0.0f &&
+                         h->P.cad == 0.0f && (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ||
+                                              h->P.obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
+    if (quad_ok && (h->step_kernel == 2 || (h->step_kernel == 0 && h->P.n <= 16384))) {
+        const int qblocks = (int)(((long long)h->P.n * 4 + 255) / 256);
+#define LAUNCH_QUAD(OT, RND)                                                                                            \
+    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND>), dim3(qblocks), dim3(256), 0, s, h->P, h->state, actions, obs, rew, \
+                       (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,              \
+                       h->reset_values, h->counters)
+        if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+            if (rnd) LAUNCH_QUAD(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, true);
+            else LAUNCH_QUAD(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, false);
+        } else {
+            if (rnd) LAUNCH_QUAD(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, true);
+            else LAUNCH_QUAD(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, false);
+        }
+#undef LAUNCH_QUAD
+        HIP_TRY(hipGetLastError());
+        return VINE_OK;
+    }
 #define LAUNCH(OT, RND, SH)                                                                                      \
     hipLaunchKernelGGL((vine_step_kernel<OT, RND, SH>), dim3(blocks), dim3(threads), 0, s, h->P, h->state, actions, \
                        obs, rew, (long long*)reset, (long long*)progress, (unsigned char*)timeouts,                 \
