@@ -144,6 +144,20 @@ int vine_lstm_step_backward_mfma(int64_t B, int64_t H, const float* g_out, int64
 int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const void* dy, int64_t ldy, const void* x,
                           int64_t ldx, int64_t slices, float* part, void* stream);
 
+/* Weight gradient(s) dy^T [x1 | x2] in ONE pass over dy on the matrix cores, for each of `slices` equal row slices:
+ *   part1[s][m][n] = sum_k dy[k][m] x1[k][n] (n < Nv1),   part2[s][m][n] = sum_k dy[k][m] x2[k][n] (n < Nv2)
+ * dy [rows, M], x1 [rows, N1p] (N1p columns read, Nv1 <= N1p stored; N1p = 0: no first operand), x2 [rows, N2p] (Nv2 <= N2p
+ * stored), all bfloat16 with 16-B aligned rows (ldy / ldx1 / ldx2 elements apart); part1 [slices, M, Nv1], part2
+ * [slices, M, Nv2] fp32.  The sums over the slices (vine_column_sums) are the gradients: fixed order, no atomics.
+ * The LSTM of the default network: dy = dG [n, 4H], x1 = the 96-column step-input block (92 stored), x2 = the masked hidden
+ * states (256): dW_ih and dW_hh from one read of dG.  NT = output-tile width / 16, one of {11, 8, 2} (64-row tiles);
+ * requires M % 64 == 0, N1p % 16 == 0, (N1p + N2p) % (16 NT) == 0, slices % 8 == 0, rows % (32 slices) == 0.  NT = 22
+ * selects ONE 128 x 352 tile per workgroup for exactly N1p = 96, N2p = 256 (M % 128 == 0, rows % (64 slices) == 0), the
+ * faster choice for the LSTM.  VINE_ERR_UNSUPPORTED otherwise (callers fall back to library GEMMs). */
+int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1, int64_t N1p,
+                              int64_t Nv1, const void* x2, int64_t ldx2, int64_t N2p, int64_t Nv2, int64_t NT, int64_t slices,
+                              float* part1, float* part2, void* stream);
+
 /* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
  * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.
  * forward: y = (x - mean) * rstd * gamma + beta; mean/rstd [n] (both nullable) are kept for the backward pass.

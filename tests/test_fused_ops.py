@@ -380,6 +380,69 @@ def test_weight_grad_mfma_matches_float64_product(monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wide", [True, False])
+@pytest.mark.parametrize("n,width", [(32768, 92), (4096, 82)])
+def test_weight_grad_cat_matches_float64_products(n, width, wide, monkeypatch):
+    """The LSTM's two weight gradients from ONE pass over dG (vine_weight_grad_cat_mfma: one 128 x 352 output tile per
+    workgroup, or 64 x 176 tiles, over the virtual [x | h]; transposed LDS reads, row slices + deterministic column sums)
+    against the float64 products of the same bf16 operands; the x block is a column block of the 96-column operand
+    buffer whose pad columns hold NaN (read, never stored)."""
+    import time
+    monkeypatch.setattr(fused, "WGRAD_CAT_WIDE", wide)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    bf = torch.bfloat16
+    H, M = 256, 1024
+    xfull = (torch.randn(n, 96, device=dev) * 0.5).to(bf)
+    xfull[:, width:] = float("nan")
+    x1 = xfull[:, :width]
+    hp = torch.randn(n, H, device=dev).to(bf)
+    dG = (torch.randn(n, M, device=dev) * 0.1).to(bf)
+    o1, o2 = torch.empty(M, width, device=dev), torch.empty(M, H, device=dev)
+    assert fused.weight_grad_cat(dG, x1, hp, o1, o2)
+    r1, r2 = dG.double().t() @ x1.double(), dG.double().t() @ hp.double()
+    for name, o, r in (("dW_ih", o1, r1), ("dW_hh", o2, r2)):
+        err = float((o.double() - r).abs().max()) / float(r.abs().max())
+        assert torch.isfinite(o).all() and err < 2e-5, (name, err)
+    a1, a2 = torch.empty_like(o1), torch.empty_like(o2)
+    assert fused.weight_grad_cat(dG, x1, hp, a1, a2) and torch.equal(a1, o1) and torch.equal(a2, o2)     # fixed summation order
+    if n == 32768:
+        for name, f in (("one pass over dG, %s tiles" % ("128 x 352" if wide else "64 x 176"), lambda: fused.weight_grad_cat(dG, x1, hp, o1, o2)),
+                        ("two split-K products (hipBLASLt)", lambda: (fused.splitk_tn(dG, x1, out=o1), fused.splitk_tn(dG, hp, out=o2)))):
+            for _ in range(3):
+                f()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                f()
+            torch.cuda.synchronize()
+            print("LSTM weight gradients, %s: %.1f us" % (name, (time.perf_counter() - t0) / 30 * 1e6))
+    # shapes outside the kernel's family are refused: callers fall back to library products
+    assert not fused.weight_grad_cat(dG[:, :992], x1, hp, torch.empty(992, width, device=dev), torch.empty(992, H, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,stride,off", [(128, 256, 256, 0), (64, 128, 128, 0), (256, 28, 96, 64), (256, 18, 32, 0)])
+def test_weight_grad_cat_single_operand(M, N, stride, off):
+    """The MLP's weight gradients through the same kernel (no first operand): [128, 256] and [64, 128] with 128-wide
+    output tiles, the first layer's [256, num_obs] with a 32-wide tile over a column block of the padded operand buffer."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    bf = torch.bfloat16
+    n = 32768
+    full = torch.full((n, stride), float("nan"), device=dev, dtype=bf)
+    full[:, off:off + N] = (torch.randn(n, N, device=dev) * 0.5).to(bf)
+    x = full[:, off:off + N]
+    dy = (torch.randn(n, M, device=dev) * 0.1).to(bf)
+    out = torch.empty(M, N, device=dev)
+    assert fused.weight_grad_cat(dy, None, x, None, out)
+    ref = dy.double().t() @ x.double()
+    err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
+    assert torch.isfinite(out).all() and err < 2e-5, err
+    assert torch.equal(fused.weight_grad(dy, x), out)                  # the default route of bf16 operands
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("F_", [28, 18, 1])
 def test_running_mean_std_kernels_match_torch_composition(F_):
     """vine_rms_update + vine_normalize_obs (float64 statistics, two-stage sums) against the module's torch path."""

@@ -189,6 +189,8 @@ PPO_PROTOTYPES = {
     "vine_lstm_step_backward_mfma": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _VP, _VP, _VP,
                                                _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP]),
     "vine_weight_grad_mfma": (C.c_int, [_I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _VP]),
+    "vine_weight_grad_cat_mfma": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _I64, _I64, _VP, _I64, _I64, _I64, _I64, _I64,
+                                            _VP, _VP, _VP]),
     "vine_layernorm_forward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP]),
     "vine_layernorm_backward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_layernorm_heads_forward": (C.c_int, [_I64, _I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -1378,6 +1378,235 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_
             }
 }
 
+// ---- Weight gradient(s) on the matrix cores, second generation: dy^T [x1 | x2] in ONE pass over dy,
+//   part1[s][m][n] = sum_k dy[k][m] x1[k][n]  (n < Nv1),   part2[s][m][n] = sum_k dy[k][m] x2[k][n]  (n < Nv2)
+// over the rows k of slice s; x1 may be empty (N1p = 0: a plain dy^T x2).  The LSTM's dW_ih and dW_hh come out of one
+// launch -- dy = dG [n, 4H], the largest tensor of the backward pass, x1 = the step-input block of the operand buffer
+// (92 + 4 pad columns), x2 = the masked hidden states -- and the three MLP weights use the same kernel.
+// What the first generation (wgrad_mfma_kernel, and a 128 x 352-tile version of this one) got wrong was the SPLIT: few,
+// large output tiles need many row slices to fill the chip, and every slice writes a full fp32 copy of the output
+// (32 slices x 1.4 MB = 46 MB for the LSTM) that the column-sum kernel reads back -- as much HBM traffic as the
+// operands.  Here the output tile is small, 64 x (16 NT) with NT <= 11, so that ~512 workgroups need only 8-64 slices:
+//   workgroup = 4 waves along M (16 rows each), every wave NT column tiles: NT MFMAs against 2 (1 + NT) transposed LDS
+//   reads per 32-row stage; stages double-buffered in LDS behind a register prefetch (one barrier per stage); 2+
+//   workgroups per CU hide each other's barriers.  Tiles are staged row-major and read column-wise with
+//   ds_read_b64_tr_b16 exactly as in wgrad_mfma_kernel; the LDS pitches are odd multiples of 32 B so that 8 consecutive
+//   rows tile all 64 banks.  Block -> (slice, tile) keeps the tiles of a slice on one XCD (they share the operand rows:
+//   blocks b and b + 8 share an L2).  Slices are summed by the column-sum kernel: fixed order, no atomics.
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_cat_mfma_kernel(int stages, int mtiles, int ntiles, int slices,
+                                                             const bf16_t* __restrict__ dy, long long ldy,
+                                                             const bf16_t* __restrict__ x1, long long ldx1, int N1p,
+                                                             const bf16_t* __restrict__ x2, long long ldx2,
+                                                             float* __restrict__ part1, int Nv1, float* __restrict__ part2,
+                                                             int Nv2, int M) {
+    constexpr int BM = 64, BN = 16 * NT;
+    constexpr int PA = BM + 16;                                  // 160 B: 40 dwords = odd multiple of 8
+    constexpr int PB = BN + (((8 * NT) % 16) == 8 ? 0 : 16);     // dwords per row = odd multiple of 8
+    constexpr int BC = BN / 8, BP = 32 * BC;                     // 16-B pieces per B row / per B stage
+    constexpr int NB = (BP + 255) / 256;
+    static_assert(NB <= 3 && BP % 64 == 0, "at most 3 staging slots for the x tile; its end on a wave boundary");
+    __shared__ __attribute__((aligned(16))) bf16_t al[2][32 * PA];
+    __shared__ __attribute__((aligned(16))) bf16_t bl[2][32 * PB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // blocks b, b + 8, ... share an XCD: give one XCD all tiles of its slices
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, tps = mtiles * ntiles;
+    const int slice = xcd * (slices >> 3) + q / tps, tile = q % tps;
+    const int m0 = (tile / ntiles) * BM, n0 = (tile % ntiles) * BN;      // n0: column of the virtual [x1 | x2]
+    const long long k0 = (long long)slice * stages * 32;
+    // staging: piece p = tid + 256 i; the dy piece is one per thread; x pieces pick their operand by virtual column
+    // (a pointer select, not a branch); named scalars (an indexed array lands in scratch memory); a slot past the last
+    // piece re-reads piece 0 and is never stored
+    const bf16_t* asrc = dy + (k0 + tid / 8) * ldy + m0 + 8 * (tid % 8);
+    const int aoff = (tid / 8) * PA + 8 * (tid % 8);
+    uint4 ra_0, rb_0, rb_1, rb_2;
+    rb_1 = rb_2 = make_uint4(0, 0, 0, 0);
+#define WGC_SRC(i)                                                                                             \
+    const bf16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
+    {                                                                                                          \
+        const int p = tid + 256 * (i);                                                                         \
+        bval##i = p < BP;                                                                                      \
+        const int pp = bval##i ? p : 0, row = pp / BC, c = n0 + 8 * (pp % BC);                                 \
+        const bool first = c < N1p;                                                                            \
+        bsrc##i = first ? x1 + (k0 + row) * ldx1 + c : x2 + (k0 + row) * ldx2 + (c - N1p);                     \
+        bstep##i = 32 * (first ? ldx1 : ldx2);                                                                 \
+        boff##i = row * PB + 8 * (pp % BC);                                                                    \
+    }
+    WGC_SRC(0) WGC_SRC(1) WGC_SRC(2)
+#undef WGC_SRC
+#define WGC_LOAD(it)                                                                                           \
+    ra_0 = *reinterpret_cast<const uint4*>(asrc + (long long)(it) * 32 * ldy);                                 \
+    rb_0 = *reinterpret_cast<const uint4*>(bsrc0 + (long long)(it) * bstep0);                                  \
+    if (NB > 1) rb_1 = *reinterpret_cast<const uint4*>(bsrc1 + (long long)(it) * bstep1);                      \
+    if (NB > 2) rb_2 = *reinterpret_cast<const uint4*>(bsrc2 + (long long)(it) * bstep2);
+#define WGC_STORE(buf)                                                                                         \
+    *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_0;                                                          \
+    if (bval0) *reinterpret_cast<uint4*>(&bl[buf][boff0]) = rb_0;                                              \
+    if (NB > 1 && bval1) *reinterpret_cast<uint4*>(&bl[buf][boff1]) = rb_1;                                    \
+    if (NB > 2 && bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = rb_2;
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    const int g = lane >> 4, il = lane & 15;
+    const int ra = (4 * g + (il >> 2)) * PA + 4 * (il & 3) + wave * 16;
+    const int rb = (4 * g + (il >> 2)) * PB + 4 * (il & 3);
+    WGC_LOAD(0)
+    WGC_STORE(0)
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < stages; ++it) {
+        const bool more = it + 1 < stages;
+        if (more) { WGC_LOAD(it + 1) }
+        const bf16_t* ab = al[it & 1];
+        const bf16_t* bb = bl[it & 1];
+        const bf16x8_t af = tr_read8(ab + ra, 16 * PA);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bf16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[nt], 0, 0, 0);
+        }
+        if (more) { WGC_STORE((it + 1) & 1) }
+        __syncthreads();
+    }
+#undef WGC_LOAD
+#undef WGC_STORE
+    // D[m = 4g + r][n = il] of column tile nt; virtual column -> (part1 | part2)
+    const long long mrow = (long long)slice * M + m0 + wave * 16 + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int vc = n0 + 16 * nt;                            // wave-uniform
+        float* base;
+        int Nv, col;
+        if (vc < N1p) { Nv = Nv1; col = vc + il; base = part1; }
+        else { Nv = Nv2; col = vc - N1p + il; base = part2; }
+        if (col < Nv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) base[(mrow + r) * Nv + col] = acc[nt][r];
+        }
+    }
+}
+
+// ---- The same product on ONE wide output tile per workgroup, for the LSTM ([x 96 | h 256] = 352 columns): 128 x 352
+// outputs, 8 waves as 4 (M) x 2 (N), wave tile = 32 x 176 (2 x 11 MFMA tiles, 88 accumulator registers), one workgroup
+// per CU.  Against the 64 x 176 tiles of wgrad_cat_mfma_kernel<11> this moves a quarter of the operand bytes through L2
+// (245 MB instead of 1 GB per launch, which is what bounds the small tile: 59.9 us in the update) at the price of twice
+// the row slices (32: 46 MB of partial sums).  With one stage of prefetch the kernel is bound by the latency of its
+// own loads (32 stages x 1.4 us); two stages are kept in flight in two named register sets (the loop is unrolled by two
+// so that the set is a compile-time choice; an indexed array lands in scratch memory).
+template <int NT1>
+__global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mtiles, int slices, const bf16_t* __restrict__ dy,
+                                                             long long ldy, const bf16_t* __restrict__ x1, long long ldx1,
+                                                             const bf16_t* __restrict__ x2, long long ldx2,
+                                                             float* __restrict__ part1, int Nv1, float* __restrict__ part2,
+                                                             int Nv2, int M) {
+    constexpr int MT = 2, NT = 11, WM = 4, WN = 2, TH = 64 * WM * WN;
+    constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN, N1 = 16 * NT1, N2 = BN - N1;
+    constexpr int PA = BM + 16, PB = BN + 16;
+    constexpr int APC = BM / 8, AP = 32 * APC;                  // 16-B pieces per A row / per A stage
+    constexpr int B1C = N1 / 8, B1P = 32 * B1C, B2C = N2 / 8, B2P = 32 * B2C;
+    static_assert(AP == TH && B1P + B2P <= 3 * TH && B1P + B2P > 2 * TH && B1P % 64 == 0 && (B1P + B2P) % 64 == 0,
+                  "staging slots: 1 piece of dy and 3 of [x1 | x2] per thread, operand boundaries on wave boundaries");
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
+    bf16_t (*al)[32 * PA] = reinterpret_cast<bf16_t (*)[32 * PA]>(wg_lds);
+    bf16_t (*bl)[32 * PB] = reinterpret_cast<bf16_t (*)[32 * PB]>(wg_lds + 2 * 32 * PA * sizeof(bf16_t));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // blocks b, b + 8, ... share an XCD: give one XCD all m tiles of its slices
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int slice = xcd * (slices >> 3) + q / mtiles, mtile = q % mtiles;
+    const int m0 = mtile * BM;
+    const long long k0 = (long long)slice * stages * 32;
+    // per-thread source of piece p = tid + TH i (the slot past the last piece re-reads piece 0 and is never stored)
+    const bf16_t* asrc = dy + (k0 + tid / APC) * ldy + m0 + 8 * (tid % APC);
+    const int aoff = (tid / APC) * PA + 8 * (tid % APC);
+#define WGW_SRC(i)                                                                                             \
+    const bf16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
+    {                                                                                                          \
+        const int p = tid + TH * (i);                                                                          \
+        bval##i = p < B1P + B2P;                                                                               \
+        if (p < B1P) {                                                                                         \
+            bsrc##i = x1 + (k0 + p / B1C) * ldx1 + 8 * (p % B1C); bstep##i = 32 * ldx1;                        \
+            boff##i = (p / B1C) * PB + 8 * (p % B1C);                                                          \
+        } else {                                                                                               \
+            const int p2 = bval##i ? p - B1P : 0;                                                              \
+            bsrc##i = x2 + (k0 + p2 / B2C) * ldx2 + 8 * (p2 % B2C); bstep##i = 32 * ldx2;                      \
+            boff##i = (p2 / B2C) * PB + N1 + 8 * (p2 % B2C);                                                   \
+        }                                                                                                      \
+    }
+    WGW_SRC(0) WGW_SRC(1) WGW_SRC(2)
+#undef WGW_SRC
+    uint4 ra_e, rb0_e, rb1_e, rb2_e, ra_o, rb0_o, rb1_o, rb2_o;     // stages of even / odd index in flight
+#define WGW_LOAD(S, it)                                                                                        \
+    {                                                                                                          \
+        const long long t_ = (it) < stages ? (it) : stages - 1;   /* past the end: a harmless re-read */        \
+        ra_##S = *reinterpret_cast<const uint4*>(asrc + t_ * 32 * ldy);                                        \
+        rb0_##S = *reinterpret_cast<const uint4*>(bsrc0 + t_ * bstep0);                                        \
+        rb1_##S = *reinterpret_cast<const uint4*>(bsrc1 + t_ * bstep1);                                        \
+        rb2_##S = *reinterpret_cast<const uint4*>(bsrc2 + t_ * bstep2);                                        \
+        __builtin_amdgcn_sched_barrier(0);   /* requests leave before the products, not after them */          \
+    }
+#define WGW_STORE(S, buf)                                                                                      \
+    *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_##S;                                                        \
+    *reinterpret_cast<uint4*>(&bl[buf][boff0]) = rb0_##S;                                                      \
+    *reinterpret_cast<uint4*>(&bl[buf][boff1]) = rb1_##S;                                                      \
+    if (bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = rb2_##S;
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    const int g = lane >> 4, il = lane & 15;
+    const int ra = (4 * g + (il >> 2)) * PA + 4 * (il & 3) + wm * MT * 16;
+    const int rb = (4 * g + (il >> 2)) * PB + 4 * (il & 3) + wn * NT * 16;
+#define WGW_COMPUTE(buf)                                                                                       \
+    {                                                                                                          \
+        const bf16_t* ab = al[buf];                                                                            \
+        const bf16_t* bb = bl[buf];                                                                            \
+        bf16x8_t af[MT];                                                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = tr_read8(ab + ra + 16 * mt, 16 * PA);       \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                    \
+            const bf16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);                                         \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr, acc[mt][nt], 0, 0, 0);      \
+        }                                                                                                      \
+    }
+    // invariant at the top of an even stage `it`: LDS buffer 0 holds stage it, the odd set holds stage it + 1 (in flight)
+    WGW_LOAD(e, 0)
+    WGW_LOAD(o, 1)
+    WGW_STORE(e, 0)
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < stages; it += 2) {                     // stages is even (host check)
+        WGW_LOAD(e, it + 2)
+        WGW_COMPUTE(0)
+        WGW_STORE(o, 1)
+        __syncthreads();
+        WGW_LOAD(o, it + 3)
+        WGW_COMPUTE(1)
+        WGW_STORE(e, 0)
+        __syncthreads();
+    }
+#undef WGW_LOAD
+#undef WGW_STORE
+#undef WGW_COMPUTE
+    // D[m = 4g + r][n = il] of tile (mt, nt); tiles below NT1 (global tile index) belong to part1, the rest to part2
+    const long long mrow = (long long)slice * M + m0 + wm * MT * 16 + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int tg = wn * NT + nt;                            // wave-uniform
+        float* base;
+        int Nv, col;
+        if (tg < NT1) { Nv = Nv1; col = 16 * tg + il; base = part1; }
+        else { Nv = Nv2; col = 16 * (tg - NT1) + il; base = part2; }
+        if (col < Nv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) base[(mrow + 16 * mt + r) * Nv + col] = acc[mt][nt][r];
+        }
+    }
+}
+
 // ---- LayerNorm over rows of H = 256 * NV floats: one wave per row, lane l owns columns [256 v + 4 l, +4) ----
 // Sum over the 64 lanes, returned to every lane: DPP row shifts and row broadcasts (7 VALU adds with a lane-shifted
 // operand, total in lane 63) + one v_readlane, instead of 6 ds_bpermute round trips through the LDS crossbar.
@@ -2759,6 +2988,46 @@ int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const
     if (mt == 2) { if (nt == 2) VINE_WGRAD(2, 2); else if (nt == 6) VINE_WGRAD(2, 6); else VINE_WGRAD(2, 8); }
     else { if (nt == 2) VINE_WGRAD(1, 2); else if (nt == 6) VINE_WGRAD(1, 6); else VINE_WGRAD(1, 8); }
 #undef VINE_WGRAD
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1, int64_t N1p,
+                              int64_t Nv1, const void* x2, int64_t ldx2, int64_t N2p, int64_t Nv2, int64_t NT, int64_t slices,
+                              float* part1, float* part2, void* stream) {
+    if (rows <= 0 || M <= 0 || slices <= 0 || !dy || !x2 || !part2 || ldy < M || ldx2 < N2p || (ldy & 7) || (ldx2 & 7) ||
+        ((uintptr_t)dy & 15) || ((uintptr_t)x2 & 15) || N2p <= 0 || Nv2 <= 0 || Nv2 > N2p || N1p < 0 ||
+        (N1p > 0 && (!x1 || !part1 || ldx1 < N1p || (ldx1 & 7) || ((uintptr_t)x1 & 15) || Nv1 <= 0 || Nv1 > N1p)))
+        return VINE_ERR_INVALID_ARG;
+    if (NT == 22) {      // one 128 x 352 tile per workgroup over [x1 96 | x2 256]
+        if (N1p != 96 || N2p != 256 || (M & 127) || (slices & 7) || rows % (slices * 64) || slices > 8192) return VINE_ERR_UNSUPPORTED;
+        const int mtiles = (int)(M / 128), stages = (int)(rows / slices / 32);
+        const size_t lds = (size_t)2 * 32 * ((128 + 16) + (352 + 16)) * sizeof(bf16_t);      // 64 KiB
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)wgrad_cat_wide_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return VINE_ERR_DEVICE;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((wgrad_cat_wide_kernel<6>), dim3((unsigned)(mtiles * slices)), dim3(512), lds, (hipStream_t)stream,
+                           stages, mtiles, (int)slices, (const bf16_t*)dy, (long long)ldy, (const bf16_t*)x1, (long long)ldx1,
+                           (const bf16_t*)x2, (long long)ldx2, part1, (int)Nv1, part2, (int)Nv2, (int)M);
+        return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    }
+    if ((NT != 11 && NT != 8 && NT != 2) || (M & 63) || (N1p & 15) || ((N1p + N2p) % (16 * NT)) || (slices & 7) ||
+        rows % (slices * 32) || slices > 8192)
+        return VINE_ERR_UNSUPPORTED;
+    const int mtiles = (int)(M / 64), ntiles = (int)((N1p + N2p) / (16 * NT)), stages = (int)(rows / slices / 32);
+    const dim3 grid((unsigned)(mtiles * ntiles * slices));
+    hipStream_t s = (hipStream_t)stream;
+    if (N1p == 0) { x1 = x2; ldx1 = ldx2; part1 = part2; Nv1 = Nv2; }
+#define VINE_WGC(NT_)                                                                                                  \
+    hipLaunchKernelGGL((wgrad_cat_mfma_kernel<NT_>), grid, dim3(256), 0, s, stages, mtiles, ntiles, (int)slices,       \
+                       (const bf16_t*)dy, (long long)ldy, (const bf16_t*)x1, (long long)ldx1, (int)N1p, (const bf16_t*)x2, \
+                       (long long)ldx2, part1, (int)Nv1, part2, (int)Nv2, (int)M)
+    if (NT == 11) VINE_WGC(11);
+    else if (NT == 8) VINE_WGC(8);
+    else VINE_WGC(2);
+#undef VINE_WGC
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

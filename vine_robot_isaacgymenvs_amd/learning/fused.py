@@ -122,6 +122,10 @@ def _wgrad_plan(dy, x):
 def weight_grad(dy, x, out=None, batch=None):
     """``dy^T @ x`` -> [M, N] fp32 (into ``out`` when given): the matrix-core kernel with transposed LDS reads when the
     operands allow it (bf16, the mixed-precision update), else ``splitk_tn``."""
+    if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_cuda:
+        o = out if out is not None else torch.empty((dy.shape[1], x.shape[1]), device=dy.device, dtype=torch.float32)
+        if o.is_contiguous() and weight_grad_cat(dy, None, x, None, o, batch=batch):
+            return o
     plan = _wgrad_plan(dy, x)
     if plan is None:
         return splitk_tn(dy, x, out=out, batch=batch)
@@ -137,6 +141,63 @@ def weight_grad(dy, x, out=None, batch=None):
     if direct:
         return out
     return column_sums(part, out, batch=batch)
+
+
+WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
+WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
+WGRAD_CAT_WIDE = _os.environ.get("VINE_WGRAD_CAT_WIDE", "1") != "0"  # 128 x 352 tiles for the LSTM's [x | h] (A/B knob)
+
+
+def _cat_operand(x, n):
+    """(columns read, columns stored) of a bf16 operand of ``vine_weight_grad_cat_mfma``: the columns are rounded up to
+    a multiple of 16 that must lie inside the rows of the buffer x is a column block of (read, never stored)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] == n and x.stride(1) == 1
+            and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+        return None
+    N = x.shape[1]
+    Np = (N + 15) // 16 * 16
+    if Np != N and (x.storage_offset() % x.stride(0)) + Np > x.stride(0):
+        return None
+    return Np, N
+
+
+def weight_grad_cat(dy, x1, x2, out1, out2, batch=None):
+    """``dy^T @ [x1 | x2]`` in ONE pass over ``dy`` on the matrix cores (``vine_weight_grad_cat_mfma``); ``x1`` / ``out1``
+    may be None (a plain ``dy^T @ x2``).  dy [n, M], x1 [n, N1], x2 [n, N2] bf16; out1 [M, N1], out2 [M, N2] fp32 receive the
+    sums over the row slices (through ``batch`` when given).  Returns False when the shapes are not covered."""
+    if not (WGRAD_CAT and dy.is_cuda and dy.dtype == torch.bfloat16 and dy.dim() == 2 and dy.stride(1) == 1
+            and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and out2.is_contiguous()
+            and (out1 is None or out1.is_contiguous())):
+        return False
+    n, M = dy.shape
+    o2 = _cat_operand(x2, n)
+    o1 = _cat_operand(x1, n) if x1 is not None else (0, 0)
+    if o1 is None or o2 is None or M % 64:
+        return False
+    Nt = o1[0] + o2[0]
+    NT = 11 if Nt % 176 == 0 else (8 if Nt % 128 == 0 else (2 if Nt == 32 else 0))
+    if not NT:
+        return False
+    wide = WGRAD_CAT_WIDE and o1[0] == 96 and o2[0] == 256 and M % 128 == 0
+    if wide:        # one 128 x 352 tile per workgroup, one workgroup per CU (a quarter of the L2 traffic of 64 x 176 tiles)
+        NT, tiles, target = 22, M // 128, 256
+    else:
+        tiles, target = (M // 64) * (Nt // (16 * NT)), WGRAD_CAT_WGS
+    S = 8
+    while tiles * S < target and n % (128 * S) == 0 and n // (64 * S) >= 8:
+        S *= 2
+    if n % (64 * S if wide else 32 * S):
+        return False
+    part2 = torch.empty((S, M, o2[1]), device=dy.device, dtype=torch.float32)
+    part1 = torch.empty((S, M, o1[1]), device=dy.device, dtype=torch.float32) if x1 is not None else None
+    _check(_lib().vine_weight_grad_cat_mfma(n, M, dy.data_ptr(), dy.stride(0), x1.data_ptr() if x1 is not None else None,
+                                            x1.stride(0) if x1 is not None else 0, o1[0], o1[1], x2.data_ptr(), x2.stride(0),
+                                            o2[0], o2[1], NT, S, part1.data_ptr() if part1 is not None else None,
+                                            part2.data_ptr(), _stream(dy)), "vine_weight_grad_cat_mfma")
+    if part1 is not None:
+        column_sums(part1, out1, batch=batch)
+    column_sums(part2, out2, batch=batch)
+    return True
 
 
 def _grad_slot(p):
@@ -799,8 +860,13 @@ class _Trunk(torch.autograd.Function):
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
                                                 w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled)
-        deliver(base + 0, lambda o: weight_grad(dG, xcat, out=o, batch=batch))
-        deliver(base + 1, lambda o: weight_grad(dG, hp.view(n, H), out=o, batch=batch))
+        fused2 = False
+        if mixed and slots[base + 0] is not None and slots[base + 1] is not None:
+            # dW_ih and dW_hh from one pass over dG (the largest tensor of the backward pass)
+            fused2 = weight_grad_cat(dG, xcat, hp.view(n, H), slots[base + 0], slots[base + 1], batch=batch)
+        if not fused2:
+            deliver(base + 0, lambda o: weight_grad(dG, xcat, out=o, batch=batch))
+            deliver(base + 1, lambda o: weight_grad(dG, hp.view(n, H), out=o, batch=batch))
         if bias_partial is not None and slots[base + 2] is not None and slots[base + 3] is not None:
             column_sums(bias_partial.view(-1, 4 * H), slots[base + 2], out1=slots[base + 3], dup=True, batch=batch)
         else:
