@@ -10,8 +10,8 @@ mode=ppo (default once the learner is available): a "step" is one full PPO itera
   inference + env step] + GAE + mini-epoch updates with the RCCL gradient all-reduce; value = env-steps/sec of the
   whole job (N x horizon x ranks / iteration time), ppo_iters_per_sec reported beside it.
 mode=env: a "step" is one VecTask.step over resident random actions (the hand-written HIP kernel alone).
-Rank 0 prints ONE JSON line.  The `roofline` object prices the dominant hand-written kernel (vine_step_kernel) with
-HIP events recorded on the launching stream inside the timed region; `cpu_baseline` times the CPU oracle
+Rank 0 prints ONE JSON line.  The `roofline` object prices the env-step kernel (`roofline.kernel`: four lanes per env up
+to 16384 envs, one lane per env beyond) with HIP events recorded on the launching stream inside the timed region; `cpu_baseline` times the CPU oracle
 (oracle/, OpenMP over envs) on a bounded sample of the same workload on this host's cores.
 """
 import argparse
@@ -81,32 +81,40 @@ def make_env(args, rank, device_index, world=1):
     return env, cfg
 
 
-def pmc_traffic():
-    """HBM bytes per launch of vine_step_kernel from the committed rocprofv3 PMC passes of this same command
+def _pmc_summary(kernel):
+    """Latest committed PMC summary (profiles/rNN/env_step_*_pmc_summary.json, written by scripts/pmc_summary.py) whose
+    kernel-trace row is `kernel` ("vine_step_kernel<": one lane per env; "vine_step_quad_kernel": four lanes per env)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except ValueError:
+            continue
+        if kernel in d.get("kernel_stats", {}).get("name", ""):
+            return f, d
+    return None, None
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/: separate FETCH_SIZE and WRITE_SIZE passes, KiB units), with the gfx950 correction of
     MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled; WRITE_SIZE
     is exact.  Both factors were re-measured for this kernel's own access widths (4-B-per-lane SoA loads/stores,
     float2/float4 row stores) on known byte counts: scripts/ubench/pmc_calib.hip, profiles/r01/pmc_calibration.txt.
-    bench.py cannot collect PMC itself."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")))
-    if not files:
-        return None
+    bench.py cannot collect PMC itself: the figure belongs to the committed profile named in `traffic_source`."""
+    f, d = _pmc_summary(kernel)
     try:
-        d = json.load(open(files[-1]))
-        return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-    except (KeyError, ValueError):
-        return None
+        return (2.0 * d["FETCH_SIZE"]["mean_per_launch"] + d["WRITE_SIZE"]["mean_per_launch"]) * 1024.0, os.path.relpath(f, REPO)
+    except (KeyError, TypeError):
+        return None, None
 
 
-def pmc_valu_per_wave():
+def pmc_valu_per_wave(kernel):
     """VALU instructions one wave issues per env step (SQ_INSTS_VALU / SQ_WAVES of the committed PMC pass)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")))
+    _f, d = _pmc_summary(kernel)
     try:
-        d = json.load(open(files[-1]))
         return d["SQ_INSTS_VALU"]["mean_per_launch"] / d["SQ_WAVES"]["mean_per_launch"]
-    except (IndexError, KeyError, ValueError, ZeroDivisionError):
+    except (KeyError, TypeError, ZeroDivisionError):
         return None
 
 
@@ -133,7 +141,8 @@ def saturated_env_rate(args, device_index, n_sat=1 << 20, steps=40):
     gbs = rate * ALGO_BYTES_PER_ENV_STEP[env.num_obs] / 1e9
     out = {"num_envs": n_sat, "kernel_ms": ms, "env_steps_per_sec": rate, "achieved_GBs": gbs,
            "hbm_frac": gbs / HBM_PEAK_GBS}
-    per_wave = pmc_valu_per_wave()
+    out["kernel"] = env.step_kernel_name
+    per_wave = pmc_valu_per_wave(out["kernel"] + "<")
     if per_wave:
         peak = 1024 * 2.4e9 / 4.0
         out.update({"valu_insts_per_wave_step": per_wave, "valu_wave_insts_per_sec": rate / 64.0 * per_wave,
@@ -325,6 +334,7 @@ def main():
         value = units_per_step * world * steps / elapsed
         algo_bytes = ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(env.step_kernel_name + "<")
         out = {
             "metric": ("env-steps/sec Vine5LinkMovingBase %d envs over %d GPUs" % (n * world, world)) if strong
                       else "env-steps/sec Vine5LinkMovingBase %d envs per GPU" % n,
@@ -336,8 +346,8 @@ def main():
                                    "(BASELINE.json configs[2]; x8 ranks = configs[3])"
                                    % (n, env.num_obs, bool(args.randomize), mode),
                        "mode": mode, "num_envs_per_gpu": n, "parallelism": "env-sharded dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "vine_step_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+            "roofline": {"bound": "hbm", "kernel": env.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
         }
         out.update(extra)

@@ -276,6 +276,10 @@ typedef enum VineStat {
 int vine_stats(VineHandle* h, const float* rew, const int64_t* progress, int64_t index_to_view, float* out, void* stream);
 
 const char* vine_last_error(void);
+/* Which device kernel vine_step launches for this handle's configuration ("vine_step_kernel": one env per lane;
+ * "vine_step_quad_kernel": four lanes per env, chosen up to 16384 envs without obstacles) -- for profiles and bench lines;
+ * results do not depend on it (tests/test_hip_parity.py runs every case through both). */
+const char* vine_step_kernel_name(VineHandle* h);
 const char* vine_backend_name(void);   /* "hip-gfx950" or "oracle-f64"/"oracle-f32" */
 
 #ifdef __cplusplus

@@ -71,6 +71,7 @@ static int fail(int code, const char* msg) {
     return code;
 }
 const char* vine_last_error(void) { return g_err; }
+const char* vine_step_kernel_name(VineHandle* h) { (void)h; return "oracle"; }
 const char* vine_backend_name(void) { return sizeof(real) == 8 ? "oracle-f64" : "oracle-f32"; }
 int vine_oracle_real_bytes(void) { return (int)sizeof(real); }
 /* threads used by vine_step in the -fopenmp build (cpu_baseline leg of bench.py); returns the count in force */

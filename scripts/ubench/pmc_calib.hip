@@ -34,6 +34,21 @@ __global__ void soa_write_kernel(float* __restrict__ base, size_t n_env, int fie
     if (e >= n_env) return;
     for (int f = 0; f < fields; ++f) base[(size_t)f * n_env + e] = (float)f;
 }
+// the four-lanes-per-env kernel's pattern: the 4 lanes of a quad read the SAME word (one wave = 16 envs = a 64-B segment
+// per field), and lane t of the quad stores field 4 j + t (again 64-B segments per wave)
+__global__ void soa_quad_read_kernel(const float* __restrict__ base, size_t n_env, int fields, float* __restrict__ sink) {
+    size_t e = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    if (e >= n_env) return;
+    float acc = 0.0f;
+    for (int f = 0; f < fields; ++f) acc += base[(size_t)f * n_env + e];
+    if (acc == 12345.678f) sink[0] = acc;
+}
+__global__ void soa_quad_write_kernel(float* __restrict__ base, size_t n_env, int fields) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, e = g >> 2;
+    int t = (int)(g & 3);
+    if (e >= n_env) return;
+    for (int f = 0; f < fields / 4; ++f) base[(size_t)(4 * f + t) * n_env + e] = (float)f;
+}
 // row-major 28-float rows written as 7 float4 per lane (the observation row store): 112 B per lane, strided by lane
 __global__ void rows_write_kernel(float4* __restrict__ dst, size_t rows) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,6 +74,8 @@ int main() {
         hipLaunchKernelGGL(soa_write_kernel, dim3(64), dim3(256), 0, 0, (float*)a, (size_t)16384, 60);
         hipLaunchKernelGGL(soa_read_kernel, dim3(4096), dim3(256), 0, 0, (const float*)a, (size_t)1 << 20, 60, (float*)s);
         hipLaunchKernelGGL(soa_write_kernel, dim3(4096), dim3(256), 0, 0, (float*)a, (size_t)1 << 20, 60);
+        hipLaunchKernelGGL(soa_quad_read_kernel, dim3(256), dim3(256), 0, 0, (const float*)a, (size_t)16384, 60, (float*)s);
+        hipLaunchKernelGGL(soa_quad_write_kernel, dim3(256), dim3(256), 0, 0, (float*)a, (size_t)16384, 60);
         hipLaunchKernelGGL(rows_write_kernel, dim3(64), dim3(256), 0, 0, (float4*)a, (size_t)16384);
         hipLaunchKernelGGL(rows_write_kernel, dim3(4096), dim3(256), 0, 0, (float4*)a, (size_t)1 << 20);
     }

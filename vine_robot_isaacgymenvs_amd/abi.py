@@ -162,6 +162,7 @@ PROTOTYPES = {
     "vine_set_introspection": (C.c_int, [_H, C.c_int]),
     "vine_stats": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "vine_last_error": (C.c_char_p, []),
+    "vine_step_kernel_name": (C.c_char_p, [_H]),
     "vine_backend_name": (C.c_char_p, []),
 }
 

@@ -1760,6 +1760,22 @@ void vine_destroy(VineHandle* h) {
     delete h;
 }
 
+// Four lanes per env (vine_step_quad_kernel) where the chip would otherwise be three quarters empty, for the
+// configurations that kernel covers.  Measured (profiles/r02/step_kernels.txt): 4096 envs 30.7 -> 23.6 us, 16384 envs
+// 32.5 -> 30.2 us, 32768 envs 35.3 -> 43.4 us: up to 16384 envs the quad kernel, beyond one lane per env.
+static bool use_quad_kernel(const VineHandle* h) {
+    const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
+    const bool quad_ok = obst == 0 && h->P.cfi == 4 && (h->P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) && h->P.kq == 0.0f &&
+                         h->P.cad == 0.0f && (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ||
+                                              h->P.obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
+    return quad_ok && (h->step_kernel == 2 || (h->step_kernel == 0 && h->P.n <= 16384));
+}
+
+const char* vine_step_kernel_name(VineHandle* h) {
+    if (!h) return "";
+    return use_quad_kernel(h) ? "vine_step_quad_kernel" : "vine_step_kernel";
+}
+
 int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64_t* reset, int64_t* progress,
               uint8_t* timeouts, void* stream) {
     if (!h || !actions || !obs || !rew || !reset || !progress || !timeouts)
@@ -1770,13 +1786,7 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     hipStream_t s = (hipStream_t)stream;
     const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
     const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
-    // four lanes per env (vine_step_quad_kernel) where the chip would otherwise be three quarters empty, for the
-    // configurations that kernel covers.  Measured (profiles/r02/step_kernels.txt): 4096 envs 30.7 -> 23.6 us, 16384 envs
-    // 32.5 -> 30.2 us, 32768 envs 35.3 -> 43.4 us: up to 16384 envs the quad kernel, beyond one lane per env
-    const bool quad_ok = obst == 0 && h->P.cfi == 4 && (h->P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) && h->P.kq == 0.0f &&
-                         h->P.cad == 0.0f && (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ||
-                                              h->P.obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
-    if (quad_ok && (h->step_kernel == 2 || (h->step_kernel == 0 && h->P.n <= 16384))) {
+    if (use_quad_kernel(h)) {
         const int qblocks = (int)(((long long)h->P.n * 4 + 255) / 256);
 #define LAUNCH_QUAD(OT, RND)                                                                                            \
     hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND>), dim3(qblocks), dim3(256), 0, s, h->P, h->state, actions, obs, rew, \

@@ -318,6 +318,11 @@ class Vine5LinkMovingBase(VecTask):
         self.wandb_dict = d
         return d
 
+    @property
+    def step_kernel_name(self):
+        """Device kernel ``vine_step`` launches for this configuration (one lane per env, or four lanes per env)."""
+        return self._lib.vine_step_kernel_name(self._handle).decode()
+
     def set_introspection(self, on=True):
         """Arm / disarm the stores of the fields nothing in the step reads back (``prev_dof_pos``, ``prev_tip_positions``,
         ``tip_velocities``, ``u_fpam``, ``u_rail_velocity``, ``prev_u_rail_velocity``, ``rail_force``, the mean contact
