@@ -296,6 +296,14 @@ int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float
                    float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                    void* bf16_shadow, void* stream);
 
+/* The same step with rl_games' AdaptiveScheduler (`schedule_type: legacy`) folded in: every workgroup reads the OLD
+ * learning rate, the last one to finish writes lr = max(lr/1.5, min_lr) if kl*kl_scale > 2*thr, min(lr*1.5, max_lr) if
+ * kl*kl_scale < 0.5*thr -- i.e. exactly vine_adam_step followed by vine_adaptive_lr, in one launch (kl NULL: no
+ * schedule).  The step counter is bumped the same way.  One Adam launch in flight per device at a time. */
+int vine_adam_step_sched(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow,
+                         const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, void* stream);
+
 /* rl_games' AdaptiveScheduler on device scalars (`schedule_type: legacy`, PY:64-66):
  * kl > 2*thr -> lr = max(lr/1.5, min_lr); kl < 0.5*thr -> lr = min(lr*1.5, max_lr).  kl_scale = 1/world. */
 int vine_adaptive_lr(float* lr, const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr,

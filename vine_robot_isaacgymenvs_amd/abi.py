@@ -213,6 +213,8 @@ PPO_PROTOTYPES = {
     "vine_normalize_obs": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _I64, C.c_int32, _VP]),
     "vine_adam_step": (C.c_int, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, _VP, _VP]),
+    "vine_adam_step_sched": (C.c_int, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
     "vine_adaptive_lr": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
 }
 

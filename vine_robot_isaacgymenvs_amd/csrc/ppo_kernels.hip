@@ -2286,6 +2286,61 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
 
 #define PPO_MAX_A 8
 #define PPO_LOSS_ROW 32          // floats per workgroup row of the loss kernel's partial sums (22 used)
+// rows of `partial` -> stats[8], grad_logstd[A] and (added into) the two head-bias gradients
+// (run by the LAST workgroup of ppo_loss_kernel to finish: 256 threads)
+__device__ __forceinline__ void ppo_loss_finalize(int blocks, int A, long long n, const float* partial,
+                                                  const float* __restrict__ logstd, float critic_coef, float entropy_coef,
+                                                  float bounds_coef, float* __restrict__ stats,
+                                                  float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
+                                                  float* __restrict__ grad_value_bias, float* __restrict__ kl_out,
+                                                  float* __restrict__ logstd_grad_accum) {
+    const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
+    float acc = 0.0f;
+    int b = rl;
+    for (; b + 56 < blocks; b += 64) {                      // 8 rows in flight per thread, same order as one at a time
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = partial[(long long)(b + 8 * k) * PPO_LOSS_ROW + q];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
+    __shared__ float fred[8][PPO_LOSS_ROW];
+    __shared__ float tot[PPO_LOSS_ROW];
+    fred[rl][q] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        float v = 0.0f;
+        for (int k = 0; k < 8; ++k) v += fred[k][q];
+        tot[q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inv_n = 1.0f / (float)n;
+        float sum_ls = 0.0f;
+        for (int k = 0; k < A; ++k) sum_ls += logstd[k];
+        const float ent = A * (0.5f + 0.9189385332046727f) + sum_ls;
+        const float a = tot[0] * inv_n, c = tot[1] * inv_n, b = tot[2] * inv_n, kl = tot[3] * inv_n;
+        stats[0] = a; stats[1] = c; stats[2] = b; stats[3] = ent; stats[4] = kl;
+        stats[5] = a + 0.5f * critic_coef * c + bounds_coef * b - entropy_coef * ent;
+        stats[6] = 0.0f; stats[7] = 0.0f;
+        for (int k = 0; k < A; ++k) {
+            const float gl = tot[5 + k] - entropy_coef;
+            grad_logstd[k] = gl;
+            if (logstd_grad_accum) logstd_grad_accum[k] += gl;
+        }
+        if (kl_out) kl_out[0] = kl;
+        if (grad_mu_bias) {
+            for (int k = 0; k < A; ++k) grad_mu_bias[k] += tot[5 + PPO_MAX_A + k];
+            grad_value_bias[0] += tot[5 + 2 * PPO_MAX_A];
+        }
+    }
+}
+
+// ticket of the loss kernel's workgroups (the last one to finish runs the finalize step and resets it: a launch always
+// finds 0).  One loss kernel in flight per device at a time -- launches on one stream are ordered.
+__device__ unsigned int g_ppo_loss_ticket = 0;
+
 __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const float* __restrict__ mu,
                                                        const float* __restrict__ logstd, const float* __restrict__ value,
                                                        const float* __restrict__ actions, const float* __restrict__ old_neglogp,
@@ -2299,8 +2354,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        float soft_bound, float* __restrict__ grad_mu,
                                                        float* __restrict__ grad_value, float* __restrict__ grad_logstd,
                                                        float* __restrict__ stats, long long mu_stride,
-                                                       long long value_stride, float* __restrict__ partial,
-                                                       float* mu_store, float* sigma_store) {
+                                                       long long value_stride, float* partial,
+                                                       float* mu_store, float* sigma_store,
+                                                       float* __restrict__ grad_mu_bias, float* __restrict__ grad_value_bias,
+                                                       float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum) {
     // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
     // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
     const float inv_n = 1.0f / (float)n;
@@ -2393,67 +2450,34 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         const int q = threadIdx.x;
         partial[(long long)blockIdx.x * PPO_LOSS_ROW + q] =
             q < NRED ? (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]) : 0.0f;
+        __threadfence();                                    // the row is visible device-wide before the ticket is taken
     }
-}
-
-// rows of `partial` -> stats[8], grad_logstd[A] and (added into) the two head-bias gradients
-__global__ __launch_bounds__(256) void ppo_loss_finalize_kernel(int blocks, int A, long long n,
-                                                                const float* __restrict__ partial,
-                                                                const float* __restrict__ logstd, float critic_coef,
-                                                                float entropy_coef, float bounds_coef,
-                                                                float* __restrict__ stats, float* __restrict__ grad_logstd,
-                                                                float* __restrict__ grad_mu_bias,
-                                                                float* __restrict__ grad_value_bias,
-                                                                float* __restrict__ kl_out,
-                                                                float* __restrict__ logstd_grad_accum) {
-    const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
-    float acc = 0.0f;
-    int b = rl;
-    for (; b + 56 < blocks; b += 64) {                      // 8 rows in flight per thread, same order as one at a time
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = partial[(long long)(b + 8 * k) * PPO_LOSS_ROW + q];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc += v[k];
-    }
-    for (; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
-    __shared__ float red[8][PPO_LOSS_ROW];
-    __shared__ float tot[PPO_LOSS_ROW];
-    red[rl][q] = acc;
-    __syncthreads();
-    if (rl == 0) {
-        float v = 0.0f;
-        for (int k = 0; k < 8; ++k) v += red[k][q];
-        tot[q] = v;
-    }
+    // the last workgroup to get here adds the rows in a fixed order (formerly a second 1-workgroup launch)
+    __shared__ bool is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float inv_n = 1.0f / (float)n;
-        float sum_ls = 0.0f;
-        for (int k = 0; k < A; ++k) sum_ls += logstd[k];
-        const float ent = A * (0.5f + 0.9189385332046727f) + sum_ls;
-        const float a = tot[0] * inv_n, c = tot[1] * inv_n, b = tot[2] * inv_n, kl = tot[3] * inv_n;
-        stats[0] = a; stats[1] = c; stats[2] = b; stats[3] = ent; stats[4] = kl;
-        stats[5] = a + 0.5f * critic_coef * c + bounds_coef * b - entropy_coef * ent;
-        stats[6] = 0.0f; stats[7] = 0.0f;
-        for (int k = 0; k < A; ++k) {
-            const float gl = tot[5 + k] - entropy_coef;
-            grad_logstd[k] = gl;
-            if (logstd_grad_accum) logstd_grad_accum[k] += gl;
-        }
-        if (kl_out) kl_out[0] = kl;
-        if (grad_mu_bias) {
-            for (int k = 0; k < A; ++k) grad_mu_bias[k] += tot[5 + PPO_MAX_A + k];
-            grad_value_bias[0] += tot[5 + 2 * PPO_MAX_A];
-        }
+        const unsigned t = atomicAdd(&g_ppo_loss_ticket, 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) g_ppo_loss_ticket = 0;
+    }
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        ppo_loss_finalize((int)gridDim.x, A, n, partial, logstd, critic_coef, entropy_coef, bounds_coef, stats, grad_logstd,
+                          grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
     }
 }
 
+// ticket of the Adam kernel's workgroups: the last one to finish bumps the step counter and applies the learning-rate
+// schedule (every workgroup has read the old step / lr by then); it resets the ticket, so a launch always finds 0
+__device__ unsigned int g_adam_ticket = 0;
+
 __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, const float* __restrict__ lr_p, float* __restrict__ step_p,
-                            float beta1, float beta2, float eps, float wd, float gscale, bf16_t* __restrict__ shadow) {
-    const float step = *step_p + 1.0f;                    // every thread reads the old value; block 0 writes it back
-    const float lr = *lr_p;
+                            float* __restrict__ v, float* lr_p, float* step_p,
+                            float beta1, float beta2, float eps, float wd, float gscale, bf16_t* __restrict__ shadow,
+                            const float* kl, float kl_scale, float kl_thr, float min_lr, float max_lr) {
+    const float step = *step_p + 1.0f;                    // every thread reads the old values; the last workgroup
+    const float lr = *lr_p;                               // to finish writes the new ones
     const float bc1 = 1.0f - __powf(beta1, step), bc2 = 1.0f - __powf(beta2, step);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
     const long long n4 = n >> 2;
@@ -2483,9 +2507,24 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restric
         m[t] = mt; v[t] = vt; g[t] = 0.0f;
         if (shadow) shadow[t] = f2bf(p[t]);
     }
+    // step counter (+ rl_games' AdaptiveScheduler when `kl` is given) by the last workgroup to finish -- formerly two
+    // 1-thread launches behind this one
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned tk = atomicAdd(&g_adam_ticket, 1u);
+        if (tk == gridDim.x - 1) {
+            g_adam_ticket = 0;
+            *step_p = step;
+            if (kl) {
+                const float k = *kl * kl_scale;
+                float out = lr;
+                if (k > 2.0f * kl_thr) out = fmaxf(lr / 1.5f, min_lr);
+                if (k < 0.5f * kl_thr) out = fminf(lr * 1.5f, max_lr);
+                *lr_p = out;
+            }
+        }
+    }
 }
-// the step counter is bumped by a separate 1-thread kernel AFTER the update (all blocks above read the old value)
-__global__ void adam_bump_kernel(float* step_p) { *step_p += 1.0f; }
 
 __global__ void adaptive_lr_kernel(float* lr, const float* kl, float kl_scale, float thr, float min_lr, float max_lr) {
     const float k = *kl * kl_scale, l = *lr;
@@ -3236,10 +3275,7 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats,
                        (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1),
-                       scratch, mu_store, sigma_store);
-    hipLaunchKernelGGL(ppo_loss_finalize_kernel, dim3(1), dim3(256), 0, s, blocks, (int)A, (long long)n, scratch, logstd,
-                       critic_coef, entropy_coef, bounds_coef, stats, grad_logstd, grad_mu_bias, grad_value_bias, kl_out,
-                       logstd_grad_accum);
+                       scratch, mu_store, sigma_store, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -3284,16 +3320,22 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+int vine_adam_step_sched(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow,
+                         const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, void* stream) {
+    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step) return VINE_ERR_INVALID_ARG;
+    const int threads = 256;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, threads)), dim3(threads), 0, (hipStream_t)stream, (long long)n,
+                       params, grads, exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
+                       (bf16_t*)bf16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
 int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                    float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                    void* bf16_shadow, void* stream) {
-    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step) return VINE_ERR_INVALID_ARG;
-    const int threads = 256;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, threads)), dim3(threads), 0, s, (long long)n, params, grads,
-                       exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale, (bf16_t*)bf16_shadow);
-    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step);
-    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    return vine_adam_step_sched(n, params, grads, exp_avg, exp_avg_sq, const_cast<float*>(lr), step, beta1, beta2, eps,
+                                weight_decay, grad_scale, bf16_shadow, nullptr, 0.0f, 0.0f, 0.0f, 0.0f, stream);
 }
 
 int vine_adaptive_lr(float* lr, const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr,

@@ -759,7 +759,7 @@ class A2CAgent:
         return mb
 
     # ------------------------------------------------------------------ update (R3, R4, R6)
-    def _fused_grad_half(self, mb, obs_n=None):
+    def _fused_grad_half(self, mb, obs_n=None, stats_out=None):
         """Forward, ONE kernel for the whole PPO loss and its gradient w.r.t. the head outputs, hand-written backward
         into the flat gradient block; the minibatch KL is parked next to the gradients so that one all-reduce
         averages both.  -> (stats[8], mu, logstd)"""
@@ -776,7 +776,7 @@ class A2CAgent:
             self.bounds_loss_coef or 0.0, heads=heads, head_bias_grads=hb if (ext and heads is not None) else None,
             # KL next to the gradients (it rides in the all-reduce), log-sigma gradient into its slot and the dataset's
             # mu / sigma refreshed in place: all by the loss kernels themselves
-            kl_out=self.optimizer.aux[0:1], logstd_grad=net.sigma.grad, update_old=True)
+            kl_out=self.optimizer.aux[0:1], logstd_grad=net.sigma.grad, update_old=True, stats_out=stats_out)
         # the gradient block was left zeroed by the last Adam step
         if heads is not None:
             torch.autograd.backward([heads], [g_mu])            # g_mu is the [n, A+1] gradient of [mu | value]
@@ -837,6 +837,11 @@ class A2CAgent:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.scaler.step(self.optimizer)
         self.scaler.update()
+
+    def _lr_schedule_args(self):
+        """Arguments of the AdaptiveScheduler folded into the Adam launch (graphed update: `legacy` schedule, KL parked
+        next to the gradients by the loss kernel, summed over the ranks by the gradient all-reduce)."""
+        return (self.optimizer.aux[0:1], 1.0 / self.rank_size, self.kl_threshold, self.min_lr, self.max_lr)
 
     def update_lr_from_kl(self, kl):
         """AdaptiveScheduler of rl_games on a device scalar (common_agent.py:217-221 shows the call site)."""
@@ -1014,11 +1019,9 @@ class A2CAgent:
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
             for i in range(nb):
                 mb = self.get_minibatch(i)
-                stats, mu_d, _logstd_d = self._fused_grad_half(mb)
-                self.optimizer.step(grad_scale=1.0 / self.rank_size)
-                self._kl_in_comm = True
-                self.update_lr_from_kl(self.optimizer.aux[0])
-                stats_all[i].copy_(stats)
+                # statistics straight into their row, step counter and learning-rate schedule inside the Adam launch
+                stats, mu_d, _logstd_d = self._fused_grad_half(mb, stats_out=stats_all[i])
+                self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
                 keep.append((mb, stats, mu_d))
         rec = {"G": g, "stats": stats_all, "keep": keep}
         self._upd_graphs[key] = rec
@@ -1035,11 +1038,9 @@ class A2CAgent:
             mb = self.get_minibatch(i)
             stats, mu_d, _logstd_d = self._fused_grad_half(mb)
         with torch.cuda.graph(gB, pool=pool, capture_error_mode="thread_local"):
-            self.optimizer.step(grad_scale=1.0 / self.rank_size)
-            # (the dataset's mu / sigma slices were refreshed by the loss kernel in graph A)
-            kl = self.optimizer.aux[0]                          # sum over ranks after the all-reduce
-            self._kl_in_comm = True
-            self.update_lr_from_kl(kl)
+            # (the dataset's mu / sigma slices were refreshed by the loss kernel in graph A); the KL next to the
+            # gradients is the sum over ranks after the all-reduce: schedule inside the Adam launch
+            self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
         rec = {"A": gA, "B": gB, "stats": stats, "keep": (mb, stats, mu_d)}
         self._upd_graphs[key] = rec
         return rec

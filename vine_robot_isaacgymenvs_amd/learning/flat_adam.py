@@ -69,17 +69,24 @@ class FlatAdam:
         self.flat_grads.zero_()
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, lr_schedule=None):
+        """``lr_schedule`` = (kl device scalar, kl_scale, kl_threshold, min_lr, max_lr): rl_games' AdaptiveScheduler
+        applied to ``self.lr`` AFTER this step used the old value, by the same launch (GPU path only)."""
         b1, b2 = self.betas
         if self._lib is not None:
-            rc = self._lib.vine_adam_step(self.numel, self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
-                                          self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.lr.data_ptr(),
-                                          self.step_t.data_ptr(), b1, b2, self.eps, self.weight_decay, float(grad_scale),
-                                          self.shadow.data_ptr() if self.shadow is not None else None,
-                                          torch.cuda.current_stream(self.flat_params.device).cuda_stream)
+            kl, kscale, thr, lo, hi = lr_schedule if lr_schedule is not None else (None, 0.0, 0.0, 0.0, 0.0)
+            rc = self._lib.vine_adam_step_sched(self.numel, self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
+                                                self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.lr.data_ptr(),
+                                                self.step_t.data_ptr(), b1, b2, self.eps, self.weight_decay,
+                                                float(grad_scale),
+                                                self.shadow.data_ptr() if self.shadow is not None else None,
+                                                kl.data_ptr() if kl is not None else None, float(kscale), float(thr),
+                                                float(lo), float(hi),
+                                                torch.cuda.current_stream(self.flat_params.device).cuda_stream)
             if rc != 0:
-                raise RuntimeError("vine_adam_step failed with status %d" % rc)
+                raise RuntimeError("vine_adam_step_sched failed with status %d" % rc)
             return
+        assert lr_schedule is None, "the fused learning-rate schedule exists on the GPU path only"
         g = self.flat_grads * grad_scale
         if self.weight_decay:
             g = g + self.weight_decay * self.flat_params

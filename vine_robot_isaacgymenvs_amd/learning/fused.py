@@ -982,7 +982,7 @@ def ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values,
 
 def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip,
                    clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None, head_bias_grads=None,
-                   kl_out=None, logstd_grad=None, update_old=False):
+                   kl_out=None, logstd_grad=None, update_old=False, stats_out=None):
     """One HIP kernel: returns (grad_mu [n,A], grad_value [n,1], grad_logstd [A], stats[8]) where the gradients are
     d(loss)/d(.) of the same scalar loss as ``ppo_loss_reference``.  With ``heads`` ([n, A+1] = [mu | value], the
     output of the fused trunk) mu/value are read from it in place and the first return value is the matching
@@ -990,7 +990,7 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     column sums of the head gradients to them (they must hold zeros, as the optimiser leaves them).
     ``kl_out`` (1 float) receives the mean KL, ``logstd_grad`` ([A]) gets the log-sigma gradient added, ``update_old``
     writes the new mu / sigma of every sample over ``old_mu`` / ``old_sigma`` (dataset.update_mu_sigma) -- each saves
-    the update a small launch."""
+    the update a small launch.  ``stats_out`` (8 floats): where the statistics go (default: a new tensor)."""
     lib = _lib()
     stats_dev = (heads if heads is not None else mu).device
     args = [t.detach().contiguous() for t in (actions, old_neglogp, adv, old_values.reshape(-1), returns.reshape(-1),
@@ -1003,7 +1003,8 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     ls = logstd.detach().contiguous()
     A = ls.shape[0]
     grad_logstd = torch.empty(A, device=stats_dev, dtype=torch.float32)
-    stats = torch.empty(8, device=stats_dev, dtype=torch.float32)
+    stats = stats_out if stats_out is not None else torch.empty(8, device=stats_dev, dtype=torch.float32)
+    assert stats.is_contiguous() and stats.numel() == 8 and stats.dtype == torch.float32
     from ..abi import PPO_LOSS_SCRATCH_FLOATS
     scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=stats_dev, dtype=torch.float32)
     scal = (float(e_clip), int(bool(clip_value)), float(critic_coef), float(entropy_coef), float(bounds_coef),
