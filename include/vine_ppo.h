@@ -158,6 +158,15 @@ int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t l
                               int64_t Nv1, const void* x2, int64_t ldx2, int64_t N2p, int64_t Nv2, int64_t NT, int64_t slices,
                               float* part1, float* part2, void* stream);
 
+/* Up to VINE_WEIGHT_GRAD_MAX_GROUP products of the small-tile family above (NT in {11, 8, 2}) in ONE launch: problem k
+ * takes element k of every array, with the argument meaning of vine_weight_grad_cat_mfma (x1[k] / part1[k] unused when
+ * N1p[k] = 0).  The three MLP weight gradients of the update are ready at the same time and share one launch. */
+#define VINE_WEIGHT_GRAD_MAX_GROUP 6
+int vine_weight_grad_group(int32_t nprob, const int64_t* rows, const int64_t* M, const void* const* dy, const int64_t* ldy,
+                           const void* const* x1, const int64_t* ldx1, const int64_t* N1p, const int64_t* Nv1,
+                           const void* const* x2, const int64_t* ldx2, const int64_t* N2p, const int64_t* Nv2, const int64_t* NT,
+                           const int64_t* slices, float* const* part1, float* const* part2, void* stream);
+
 /* LayerNorm over the last dimension (rl_games `rnn.layer_norm: True`, PY:36; torch.nn.LayerNorm arithmetic: biased
  * variance, eps inside the square root).  H in {256, 512, 1024}; one 64-lane wave per row.
  * forward: y = (x - mean) * rstd * gamma + beta; mean/rstd [n] (both nullable) are kept for the backward pass.

@@ -443,6 +443,35 @@ def test_weight_grad_cat_single_operand(M, N, stride, off):
 
 
 @pytest.mark.gpu
+def test_weight_grad_group_equals_single_launches():
+    """The three MLP weight gradients of the update in ONE launch (vine_weight_grad_group) are bit-identical to three
+    single launches of the same kernel family, and match the float64 products."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    bf = torch.bfloat16
+    n = 32768
+    xfull = torch.full((n, 96), float("nan"), device=dev, dtype=bf)
+    xfull[:, 64:92] = (torch.randn(n, 28, device=dev) * 0.5).to(bf)
+    cases = [((torch.randn(n, 64, device=dev) * 0.1).to(bf), (torch.randn(n, 128, device=dev) * 0.5).to(bf)),
+             ((torch.randn(n, 128, device=dev) * 0.1).to(bf), (torch.randn(n, 256, device=dev) * 0.5).to(bf)),
+             ((torch.randn(n, 256, device=dev) * 0.1).to(bf), xfull[:, 64:92])]
+    batch, group = fused.ColumnSumBatch(), fused.WeightGradGroup()
+    outs = [torch.empty(dy.shape[1], x.shape[1], device=dev) for dy, x in cases]
+    for (dy, x), o in zip(cases, outs):
+        assert group.add(dy, x, o, batch)
+    group.flush()
+    batch.flush(outs[0])
+    for (dy, x), o in zip(cases, outs):
+        single, b1 = torch.empty_like(o), fused.ColumnSumBatch()
+        assert fused.weight_grad_cat(dy, None, x, None, single, batch=b1)
+        b1.flush(single)
+        assert torch.equal(single, o)
+        ref = dy.double().t() @ x.double()
+        assert float((o.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+    assert not fused.WeightGradGroup().add(cases[0][0], cases[0][1], outs[0], None)      # needs the column-sum batch
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("F_", [28, 18, 1])
 def test_running_mean_std_kernels_match_torch_composition(F_):
     """vine_rms_update + vine_normalize_obs (float64 statistics, two-stage sums) against the module's torch path."""

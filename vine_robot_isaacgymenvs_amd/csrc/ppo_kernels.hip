@@ -1393,24 +1393,43 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_
 //   ds_read_b64_tr_b16 exactly as in wgrad_mfma_kernel; the LDS pitches are odd multiples of 32 B so that 8 consecutive
 //   rows tile all 64 banks.  Block -> (slice, tile) keeps the tiles of a slice on one XCD (they share the operand rows:
 //   blocks b and b + 8 share an L2).  Slices are summed by the column-sum kernel: fixed order, no atomics.
+// One problem of a grouped launch (several independent products in ONE kernel: every node of the replayed update graph
+// costs ~4.5 us of dispatch + drain, and the three MLP weight gradients are ready at the same time).
+struct WgProblem {
+    const bf16_t *dy, *x1, *x2;
+    float *part1, *part2;
+    long long ldy, ldx1, ldx2;
+    int stages, mtiles, ntiles, slices, N1p, Nv1, Nv2, M, NT, first_block;
+};
+#define VINE_WGRAD_MAX_PROBLEMS 6
+struct WgGroupArgs {
+    WgProblem p[VINE_WGRAD_MAX_PROBLEMS];
+    int n;
+};
+constexpr int WGC_LDS_BYTES = 2 * 32 * (64 + 16) * 2 + 2 * 32 * 176 * 2;      // dy tiles + the widest x tiles (NT = 11)
+
 template <int NT>
-__global__ __launch_bounds__(256) void wgrad_cat_mfma_kernel(int stages, int mtiles, int ntiles, int slices,
-                                                             const bf16_t* __restrict__ dy, long long ldy,
-                                                             const bf16_t* __restrict__ x1, long long ldx1, int N1p,
-                                                             const bf16_t* __restrict__ x2, long long ldx2,
-                                                             float* __restrict__ part1, int Nv1, float* __restrict__ part2,
-                                                             int Nv2, int M) {
+__device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int block, unsigned char* lds_raw) {
+    const int stages = P.stages, mtiles = P.mtiles, ntiles = P.ntiles, slices = P.slices, N1p = P.N1p, Nv1 = P.Nv1,
+              Nv2 = P.Nv2, M = P.M;
+    const bf16_t* __restrict__ dy = P.dy;
+    const bf16_t* __restrict__ x1 = P.x1;
+    const bf16_t* __restrict__ x2 = P.x2;
+    float* __restrict__ part1 = P.part1;
+    float* __restrict__ part2 = P.part2;
+    const long long ldy = P.ldy, ldx1 = P.ldx1, ldx2 = P.ldx2;
     constexpr int BM = 64, BN = 16 * NT;
     constexpr int PA = BM + 16;                                  // 160 B: 40 dwords = odd multiple of 8
     constexpr int PB = BN + (((8 * NT) % 16) == 8 ? 0 : 16);     // dwords per row = odd multiple of 8
     constexpr int BC = BN / 8, BP = 32 * BC;                     // 16-B pieces per B row / per B stage
     constexpr int NB = (BP + 255) / 256;
     static_assert(NB <= 3 && BP % 64 == 0, "at most 3 staging slots for the x tile; its end on a wave boundary");
-    __shared__ __attribute__((aligned(16))) bf16_t al[2][32 * PA];
-    __shared__ __attribute__((aligned(16))) bf16_t bl[2][32 * PB];
+    static_assert(2 * 32 * (PA + PB) * 2 <= WGC_LDS_BYTES, "LDS of the grouped kernel");
+    bf16_t (*al)[32 * PA] = reinterpret_cast<bf16_t (*)[32 * PA]>(lds_raw);
+    bf16_t (*bl)[32 * PB] = reinterpret_cast<bf16_t (*)[32 * PB]>(lds_raw + 2 * 32 * PA * sizeof(bf16_t));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // blocks b, b + 8, ... share an XCD: give one XCD all tiles of its slices
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, tps = mtiles * ntiles;
+    const int xcd = block & 7, q = block >> 3, tps = mtiles * ntiles;
     const int slice = xcd * (slices >> 3) + q / tps, tile = q % tps;
     const int m0 = (tile / ntiles) * BM, n0 = (tile % ntiles) * BN;      // n0: column of the virtual [x1 | x2]
     const long long k0 = (long long)slice * stages * 32;
@@ -1484,6 +1503,19 @@ __global__ __launch_bounds__(256) void wgrad_cat_mfma_kernel(int stages, int mti
             for (int r = 0; r < 4; ++r) base[(mrow + r) * Nv + col] = acc[nt][r];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroupArgs G) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[WGC_LDS_BYTES];
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < G.n; ++k)
+        if ((int)blockIdx.x >= G.p[k].first_block) j = k;
+    const WgProblem& P = G.p[j];
+    const int block = (int)blockIdx.x - P.first_block;
+    if (P.NT == 11) wgrad_cat_body<11>(P, block, lds_raw);
+    else if (P.NT == 8) wgrad_cat_body<8>(P, block, lds_raw);
+    else wgrad_cat_body<2>(P, block, lds_raw);
 }
 
 // ---- The same product on ONE wide output tile per workgroup, for the LSTM ([x 96 | h 256] = 352 columns): 128 x 352
@@ -3030,6 +3062,42 @@ int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+int vine_weight_grad_group(int32_t nprob, const int64_t* rows, const int64_t* M, const void* const* dy, const int64_t* ldy,
+                           const void* const* x1, const int64_t* ldx1, const int64_t* N1p, const int64_t* Nv1,
+                           const void* const* x2, const int64_t* ldx2, const int64_t* N2p, const int64_t* Nv2, const int64_t* NT,
+                           const int64_t* slices, float* const* part1, float* const* part2, void* stream) {
+    if (nprob <= 0 || nprob > VINE_WGRAD_MAX_PROBLEMS || !rows || !M || !dy || !ldy || !x1 || !ldx1 || !N1p || !Nv1 || !x2 ||
+        !ldx2 || !N2p || !Nv2 || !NT || !slices || !part1 || !part2)
+        return VINE_ERR_INVALID_ARG;
+    WgGroupArgs G;
+    int blocks = 0;
+    for (int k = 0; k < nprob; ++k) {
+        const bool two = N1p[k] > 0;
+        if (rows[k] <= 0 || M[k] <= 0 || slices[k] <= 0 || !dy[k] || !x2[k] || !part2[k] || ldy[k] < M[k] || ldx2[k] < N2p[k] ||
+            (ldy[k] & 7) || (ldx2[k] & 7) || ((uintptr_t)dy[k] & 15) || ((uintptr_t)x2[k] & 15) || N2p[k] <= 0 || Nv2[k] <= 0 ||
+            Nv2[k] > N2p[k] || N1p[k] < 0 ||
+            (two && (!x1[k] || !part1[k] || ldx1[k] < N1p[k] || (ldx1[k] & 7) || ((uintptr_t)x1[k] & 15) || Nv1[k] <= 0 ||
+                     Nv1[k] > N1p[k])))
+            return VINE_ERR_INVALID_ARG;
+        if ((NT[k] != 11 && NT[k] != 8 && NT[k] != 2) || (M[k] & 63) || (N1p[k] & 15) || ((N1p[k] + N2p[k]) % (16 * NT[k])) ||
+            (slices[k] & 7) || rows[k] % (slices[k] * 32) || slices[k] > 8192)
+            return VINE_ERR_UNSUPPORTED;
+        WgProblem& P = G.p[k];
+        P.dy = (const bf16_t*)dy[k]; P.ldy = ldy[k];
+        P.x2 = (const bf16_t*)x2[k]; P.ldx2 = ldx2[k]; P.part2 = part2[k]; P.Nv2 = (int)Nv2[k];
+        P.x1 = two ? (const bf16_t*)x1[k] : P.x2; P.ldx1 = two ? ldx1[k] : ldx2[k];
+        P.part1 = two ? part1[k] : part2[k]; P.Nv1 = two ? (int)Nv1[k] : (int)Nv2[k];
+        P.N1p = (int)N1p[k]; P.M = (int)M[k]; P.NT = (int)NT[k]; P.slices = (int)slices[k];
+        P.mtiles = (int)(M[k] / 64); P.ntiles = (int)((N1p[k] + N2p[k]) / (16 * NT[k]));
+        P.stages = (int)(rows[k] / slices[k] / 32);
+        P.first_block = blocks;
+        blocks += P.mtiles * P.ntiles * P.slices;
+    }
+    G.n = nprob;
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, G);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
 int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1, int64_t N1p,
                               int64_t Nv1, const void* x2, int64_t ldx2, int64_t N2p, int64_t Nv2, int64_t NT, int64_t slices,
                               float* part1, float* part2, void* stream) {
@@ -3055,19 +3123,13 @@ int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t l
     if ((NT != 11 && NT != 8 && NT != 2) || (M & 63) || (N1p & 15) || ((N1p + N2p) % (16 * NT)) || (slices & 7) ||
         rows % (slices * 32) || slices > 8192)
         return VINE_ERR_UNSUPPORTED;
-    const int mtiles = (int)(M / 64), ntiles = (int)((N1p + N2p) / (16 * NT)), stages = (int)(rows / slices / 32);
-    const dim3 grid((unsigned)(mtiles * ntiles * slices));
-    hipStream_t s = (hipStream_t)stream;
-    if (N1p == 0) { x1 = x2; ldx1 = ldx2; part1 = part2; Nv1 = Nv2; }
-#define VINE_WGC(NT_)                                                                                                  \
-    hipLaunchKernelGGL((wgrad_cat_mfma_kernel<NT_>), grid, dim3(256), 0, s, stages, mtiles, ntiles, (int)slices,       \
-                       (const bf16_t*)dy, (long long)ldy, (const bf16_t*)x1, (long long)ldx1, (int)N1p, (const bf16_t*)x2, \
-                       (long long)ldx2, part1, (int)Nv1, part2, (int)Nv2, (int)M)
-    if (NT == 11) VINE_WGC(11);
-    else if (NT == 8) VINE_WGC(8);
-    else VINE_WGC(2);
-#undef VINE_WGC
-    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    const void* dys[1] = {dy};
+    const void* x1s[1] = {x1};
+    const void* x2s[1] = {x2};
+    float* p1s[1] = {part1};
+    float* p2s[1] = {part2};
+    return vine_weight_grad_group(1, &rows, &M, dys, &ldy, x1s, &ldx1, &N1p, &Nv1, x2s, &ldx2, &N2p, &Nv2, &NT, &slices, p1s, p2s,
+                                  stream);
 }
 
 int vine_layernorm_forward(int64_t n, int64_t H, const float* x, const float* gamma, const float* beta, float eps,

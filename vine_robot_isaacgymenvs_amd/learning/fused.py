@@ -161,24 +161,22 @@ def _cat_operand(x, n):
     return Np, N
 
 
-def weight_grad_cat(dy, x1, x2, out1, out2, batch=None):
-    """``dy^T @ [x1 | x2]`` in ONE pass over ``dy`` on the matrix cores (``vine_weight_grad_cat_mfma``); ``x1`` / ``out1``
-    may be None (a plain ``dy^T @ x2``).  dy [n, M], x1 [n, N1], x2 [n, N2] bf16; out1 [M, N1], out2 [M, N2] fp32 receive the
-    sums over the row slices (through ``batch`` when given).  Returns False when the shapes are not covered."""
+def _wgrad_cat_plan(dy, x1, x2, out1, out2, allow_wide=True):
+    """Arguments of ``vine_weight_grad_cat_mfma`` for ``dy^T @ [x1 | x2]`` -> (n, M, N1p, Nv1, N2p, Nv2, NT, S) or None."""
     if not (WGRAD_CAT and dy.is_cuda and dy.dtype == torch.bfloat16 and dy.dim() == 2 and dy.stride(1) == 1
             and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and out2.is_contiguous()
             and (out1 is None or out1.is_contiguous())):
-        return False
+        return None
     n, M = dy.shape
     o2 = _cat_operand(x2, n)
     o1 = _cat_operand(x1, n) if x1 is not None else (0, 0)
     if o1 is None or o2 is None or M % 64:
-        return False
+        return None
     Nt = o1[0] + o2[0]
     NT = 11 if Nt % 176 == 0 else (8 if Nt % 128 == 0 else (2 if Nt == 32 else 0))
     if not NT:
-        return False
-    wide = WGRAD_CAT_WIDE and o1[0] == 96 and o2[0] == 256 and M % 128 == 0
+        return None
+    wide = allow_wide and WGRAD_CAT_WIDE and o1[0] == 96 and o2[0] == 256 and M % 128 == 0
     if wide:        # one 128 x 352 tile per workgroup, one workgroup per CU (a quarter of the L2 traffic of 64 x 176 tiles)
         NT, tiles, target = 22, M // 128, 256
     else:
@@ -187,17 +185,66 @@ def weight_grad_cat(dy, x1, x2, out1, out2, batch=None):
     while tiles * S < target and n % (128 * S) == 0 and n // (64 * S) >= 8:
         S *= 2
     if n % (64 * S if wide else 32 * S):
+        return None
+    return n, M, o1[0], o1[1], o2[0], o2[1], NT, S
+
+
+def weight_grad_cat(dy, x1, x2, out1, out2, batch=None):
+    """``dy^T @ [x1 | x2]`` in ONE pass over ``dy`` on the matrix cores (``vine_weight_grad_cat_mfma``); ``x1`` / ``out1``
+    may be None (a plain ``dy^T @ x2``).  dy [n, M], x1 [n, N1], x2 [n, N2] bf16; out1 [M, N1], out2 [M, N2] fp32 receive the
+    sums over the row slices (through ``batch`` when given).  Returns False when the shapes are not covered."""
+    plan = _wgrad_cat_plan(dy, x1, x2, out1, out2)
+    if plan is None:
         return False
-    part2 = torch.empty((S, M, o2[1]), device=dy.device, dtype=torch.float32)
-    part1 = torch.empty((S, M, o1[1]), device=dy.device, dtype=torch.float32) if x1 is not None else None
+    n, M, N1p, Nv1, N2p, Nv2, NT, S = plan
+    part2 = torch.empty((S, M, Nv2), device=dy.device, dtype=torch.float32)
+    part1 = torch.empty((S, M, Nv1), device=dy.device, dtype=torch.float32) if x1 is not None else None
     _check(_lib().vine_weight_grad_cat_mfma(n, M, dy.data_ptr(), dy.stride(0), x1.data_ptr() if x1 is not None else None,
-                                            x1.stride(0) if x1 is not None else 0, o1[0], o1[1], x2.data_ptr(), x2.stride(0),
-                                            o2[0], o2[1], NT, S, part1.data_ptr() if part1 is not None else None,
+                                            x1.stride(0) if x1 is not None else 0, N1p, Nv1, x2.data_ptr(), x2.stride(0),
+                                            N2p, Nv2, NT, S, part1.data_ptr() if part1 is not None else None,
                                             part2.data_ptr(), _stream(dy)), "vine_weight_grad_cat_mfma")
     if part1 is not None:
         column_sums(part1, out1, batch=batch)
     column_sums(part2, out2, batch=batch)
     return True
+
+
+class WeightGradGroup:
+    """Several small-tile weight-gradient products in ONE launch (``vine_weight_grad_group``): ``add`` plans a product
+    and registers its slice sums with the column-sum batch, ``flush`` launches them all.  The operands must stay alive
+    (and unchanged) until the flush; the group keeps references."""
+    MAX = 6
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, dy, x, out, batch):
+        if len(self.jobs) >= self.MAX or batch is None:
+            return False
+        plan = _wgrad_cat_plan(dy, None, x, None, out, allow_wide=False)
+        if plan is None:
+            return False
+        n, M, _n1p, _nv1, N2p, Nv2, NT, S = plan
+        part = torch.empty((S, M, Nv2), device=dy.device, dtype=torch.float32)
+        self.jobs.append((n, M, dy, x, N2p, Nv2, NT, S, part))
+        column_sums(part, out, batch=batch)
+        return True
+
+    def flush(self):
+        if not self.jobs:
+            return
+        import ctypes as C
+        k = len(self.jobs)
+        I64, VP = C.c_int64 * k, C.c_void_p * k
+        col = lambda f: [f(j) for j in self.jobs]
+        zeros, nulls = I64(*([0] * k)), VP(*([None] * k))
+        _check(_lib().vine_weight_grad_group(
+            k, I64(*col(lambda j: j[0])), I64(*col(lambda j: j[1])), VP(*col(lambda j: j[2].data_ptr())),
+            I64(*col(lambda j: j[2].stride(0))), nulls, zeros, zeros, zeros, VP(*col(lambda j: j[3].data_ptr())),
+            I64(*col(lambda j: j[3].stride(0))), I64(*col(lambda j: j[4])), I64(*col(lambda j: j[5])),
+            I64(*col(lambda j: j[6])), I64(*col(lambda j: j[7])), nulls, VP(*col(lambda j: j[8].data_ptr())),
+            _stream(self.jobs[0][2])), "vine_weight_grad_group")
+        self.jobs = []
 
 
 def _grad_slot(p):
@@ -873,6 +920,7 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 2, lambda o: _sum_rows(bias_partial, dG.float(), out=o))
             deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
         gz = part = g = None
+        wgroup = WeightGradGroup()
         if mixed and ctx.wts[0] is not None:
             # LSTM input gradient (MLP columns only) x ELU' of the last MLP layer + its bias partial sums: one
             # matrix-core kernel streaming the 4H-long reduction in k chunks
@@ -896,7 +944,7 @@ class _Trunk(torch.autograd.Function):
                 _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
                                              part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
             x_in = acts[i - 1] if i > 0 else x0
-            deliver(2 * i, lambda o, gz=gz, x_in=x_in: weight_grad(gz, x_in, out=o, batch=batch))
+            deliver(2 * i, lambda o, gz=gz, x_in=x_in: wgroup.add(gz, x_in, o, batch) or weight_grad(gz, x_in, out=o, batch=batch))
             deliver(2 * i + 1, lambda o, part=part: column_sums(part, o, batch=batch))
             if i == 0:
                 break
@@ -913,6 +961,7 @@ class _Trunk(torch.autograd.Function):
             else:
                 g = _mm(gz, weights[i])
                 gz = None
+        wgroup.flush()                      # the MLP weight gradients: one launch, all operands exist by now
         if batch is not None:
             batch.flush(out)
         return (None, None, None, None, None, None, None, None, None, *grads)
