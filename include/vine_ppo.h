@@ -92,6 +92,18 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_
 int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, int64_t ldw,
                          const float* bias, float alpha, void* out, int64_t out_stride, void* stream);
 
+/* The MLP [32 -> C1 -> C2 -> C3] (+ ELU after every layer) of the default network in ONE launch, activations carried in
+ * registers from layer to layer: x [n, 32] bf16 rows ldx apart (normalised observations + zero pad columns), w1p [C1, 32]
+ * (zero-padded), w2 [C2, C1], w3 [C3, C2] bf16, biases fp32; out [n, C3] bf16 rows out_stride apart; act1 [n, C1] /
+ * act2 [n, C2] bf16 (packed, nullable): the intermediate activations for the backward pass.  With `raw` (fp32
+ * observations [n, F_in], F_in <= 32) the kernel first forms x = clamp((raw - mean) / sqrt(var + eps), +-clip) from the
+ * float64 RunningMeanStd statistics (vine_normalize_obs' arithmetic), zero-pads it to 32 columns and WRITES it to x.
+ * Covers C1 = 256, C2 = 128, C3 = 64, n % 64 == 0 (VINE_ERR_UNSUPPORTED otherwise: use vine_linear_elu_mfma per layer). */
+int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
+                       float eps, float clip, const void* w1p, const float* b1, int64_t C1, const void* w2, int64_t ldw2,
+                       const float* b2, int64_t C2, const void* w3, int64_t ldw3, const float* b3, int64_t C3, float alpha,
+                       void* act1, void* act2, void* out, int64_t out_stride, void* stream);
+
 /* Backward of a Linear through the previous layer's ELU, on the matrix cores:
  *   gz = (G Wt^T) * elu'(a)   with G [n, K] bf16 (gradient w.r.t. this layer's pre-activation), Wt [N, K] bf16 = the
  *   layer's weight TRANSPOSED (N = its input width), a [n, N] bf16 = the previous layer's ELU output, gz [n, N] bf16;

@@ -859,6 +859,158 @@ __global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N
     }
 }
 
+// ---- The whole MLP of the default network in ONE kernel (mixed precision):
+//   x [n, 32] bf16 (the normalised observation block of the LSTM operand buffer + its zero pad; or, with `raw`, built
+//   here from the fp32 observations and the RunningMeanStd statistics and written there) -> Linear(32, C1) + ELU ->
+//   Linear(C1, C2) + ELU -> Linear(C2, C3) + ELU -> out [n, C3] bf16 (the MLP block of the LSTM operand buffer), with
+//   the two intermediate activations stored for the backward pass when asked for (act1 / act2; the rollout passes NULL).
+// Three launches of linear_elu_mfma_kernel (+ one of normalize_obs_kernel) cost ~4.5 us of dispatch and drain each in the
+// replayed graphs; here a wave carries its 16 rows through all three layers IN REGISTERS.  That needs no cross-lane
+// exchange because the tile -> unit mapping of a producing layer is chosen to match the operand layout of the consuming
+// one (as in the LSTM sequence kernels): output tiles (2 kk, 2 kk + 1) of layer L hold, in lane group q, the units
+// 32 kk + 8 q + {0..3} and + {4..7} -- exactly the 8 consecutive k's that lane needs as its B fragment of k-step kk of
+// layer L + 1 (v_mfma_f32_16x16x32_bf16, transposed product D^T = W X^T as in linear_elu_mfma_kernel).  The weights
+// are staged once per workgroup into LDS with their rows permuted into tile order, so fragment reads stay on
+// consecutive LDS rows (16-B skew per row: conflict-free).  Workgroup = 16 rows per wave, 4 or 8 waves; LDS 103 KB.
+__device__ __forceinline__ int mlp3_tile_row(int u) {      // unit -> LDS row: 32 kk + 8 q + 4 ut + j  ->  32 kk + 16 ut + 4 q + j
+    return (u & ~31) | ((u & 4) << 2) | ((u >> 1) & 12) | (u & 3);
+}
+__device__ __forceinline__ float elu1(float x, float alpha) { return x > 0.0f ? x : alpha * (__expf(x) - 1.0f); }
+
+template <int C1, int C2, int C3, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_elu_mfma_kernel(long long n, bf16_t* x, long long ldx,
+                                                            const float* __restrict__ raw, int F_in,
+                                                            const double* __restrict__ mean, const double* __restrict__ var,
+                                                            float eps, float clip, const bf16_t* __restrict__ w1,
+                                                            const float* __restrict__ b1, const bf16_t* __restrict__ w2,
+                                                            long long ldw2, const float* __restrict__ b2,
+                                                            const bf16_t* __restrict__ w3, long long ldw3,
+                                                            const float* __restrict__ b3, float alpha,
+                                                            bf16_t* __restrict__ act1, bf16_t* __restrict__ act2,
+                                                            bf16_t* out, long long out_stride) {
+    constexpr int P1 = 32 + 8, P2 = C1 + 8, P3 = C2 + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16_t* w1l = reinterpret_cast<bf16_t*>(lds_raw);            // [C1][P1], rows in tile order
+    bf16_t* w2l = w1l + C1 * P1;                                 // [C2][P2], rows in tile order
+    bf16_t* w3l = w2l + C2 * P2;                                 // [C3][P3], natural order (its output goes to memory)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const long long b = ((long long)blockIdx.x * NW + wave) * 16 + i;
+    // ---- this lane's B fragment of layer 1: columns 8 q .. 8 q + 7 of its row (requested before the weight staging)
+    bf16x8_t af1;
+    if (raw) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * q + e;
+            float y = 0.0f;
+            if (c < F_in) {
+                // same arithmetic as normalize_obs_kernel: statistics cast to float first
+                const float m = (float)mean[c], sd = sqrtf((float)var[c] + eps);
+                y = (raw[b * F_in + c] - m) / sd;
+                y = fminf(fmaxf(y, -clip), clip);
+            }
+            v[e] = y;
+        }
+        const uint4 pk = pack_bf16x8(v);
+        af1 = __builtin_bit_cast(bf16x8_t, pk);
+        *reinterpret_cast<uint4*>(x + b * ldx + 8 * q) = pk;     // the LSTM operand's observation block (+ zero pad)
+    } else {
+        af1 = *reinterpret_cast<const bf16x8_t*>(x + b * ldx + 8 * q);
+    }
+    // ---- weights -> LDS.  Every request leaves before anything is waited for (compile-time trip counts: the staging is
+    // one L2 round trip, not one per chunk); layer 1 starts as soon as ITS weights are in LDS, the two larger weights
+    // arrive under its arithmetic
+    constexpr int TH = 64 * NW, N1 = C1 * 4 / TH, N2 = C2 * (C1 / 8) / TH, N3 = C3 * (C2 / 8) / TH;
+    static_assert(C1 * 4 % TH == 0 && C2 * (C1 / 8) % TH == 0 && C3 * (C2 / 8) % TH == 0, "whole chunks per thread");
+    u32x4_t s1[N1], s2[N2], s3[N3];      // native vectors: arrays of the HIP uint4 struct stay in scratch memory here
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+        const int c = tid + TH * it;
+        s1[it] = *reinterpret_cast<const u32x4_t*>(w1 + (c >> 2) * 32 + 8 * (c & 3));
+    }
+#pragma unroll
+    for (int it = 0; it < N2; ++it) {
+        const int c = tid + TH * it, row = c / (C1 / 8), ck = c - row * (C1 / 8);
+        s2[it] = *reinterpret_cast<const u32x4_t*>(w2 + (long long)row * ldw2 + 8 * ck);
+    }
+#pragma unroll
+    for (int it = 0; it < N3; ++it) {
+        const int c = tid + TH * it, row = c / (C2 / 8), ck = c - row * (C2 / 8);
+        s3[it] = *reinterpret_cast<const u32x4_t*>(w3 + (long long)row * ldw3 + 8 * ck);
+    }
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+        const int c = tid + TH * it;
+        *reinterpret_cast<u32x4_t*>(&w1l[mlp3_tile_row(c >> 2) * P1 + 8 * (c & 3)]) = s1[it];
+    }
+    __syncthreads();
+    // ---- layer 1: K = 32, C1 / 32 pairs of output tiles; pair kk becomes the B fragment of k-step kk of layer 2
+    bf16x8_t af2[C1 / 32];
+#pragma unroll
+    for (int kk = 0; kk < C1 / 32; ++kk) {
+        float y[8];
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut) {
+            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w1l[(32 * kk + 16 * ut + i) * P1 + 8 * q]);
+            const f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af1, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            const float4 bb = ld4(b1 + 32 * kk + 8 * q + 4 * ut);
+            y[4 * ut + 0] = elu1(a[0] + bb.x, alpha); y[4 * ut + 1] = elu1(a[1] + bb.y, alpha);
+            y[4 * ut + 2] = elu1(a[2] + bb.z, alpha); y[4 * ut + 3] = elu1(a[3] + bb.w, alpha);
+        }
+        const uint4 pk = pack_bf16x8(y);
+        af2[kk] = __builtin_bit_cast(bf16x8_t, pk);
+        if (act1) *reinterpret_cast<uint4*>(act1 + b * C1 + 32 * kk + 8 * q) = pk;
+    }
+#pragma unroll
+    for (int it = 0; it < N2; ++it) {
+        const int c = tid + TH * it, row = c / (C1 / 8), ck = c - row * (C1 / 8);
+        *reinterpret_cast<u32x4_t*>(&w2l[mlp3_tile_row(row) * P2 + 8 * ck]) = s2[it];
+    }
+#pragma unroll
+    for (int it = 0; it < N3; ++it) {
+        const int c = tid + TH * it, row = c / (C2 / 8), ck = c - row * (C2 / 8);
+        *reinterpret_cast<u32x4_t*>(&w3l[row * P3 + 8 * ck]) = s3[it];
+    }
+    __syncthreads();
+    // ---- layer 2: K = C1
+    bf16x8_t af3[C2 / 32];
+#pragma unroll
+    for (int kp = 0; kp < C2 / 32; ++kp) {
+        f32x4_t a[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+        for (int kk = 0; kk < C1 / 32; ++kk)
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w2l[(32 * kp + 16 * ut + i) * P2 + 32 * kk + 8 * q]);
+                a[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af2[kk], a[ut], 0, 0, 0);
+            }
+        float y[8];
+#pragma unroll
+        for (int ut = 0; ut < 2; ++ut) {
+            const float4 bb = ld4(b2 + 32 * kp + 8 * q + 4 * ut);
+            y[4 * ut + 0] = elu1(a[ut][0] + bb.x, alpha); y[4 * ut + 1] = elu1(a[ut][1] + bb.y, alpha);
+            y[4 * ut + 2] = elu1(a[ut][2] + bb.z, alpha); y[4 * ut + 3] = elu1(a[ut][3] + bb.w, alpha);
+        }
+        const uint4 pk = pack_bf16x8(y);
+        af3[kp] = __builtin_bit_cast(bf16x8_t, pk);
+        if (act2) *reinterpret_cast<uint4*>(act2 + b * C2 + 32 * kp + 8 * q) = pk;
+    }
+    // ---- layer 3: K = C2, natural tile order: lane holds units 16 t + 4 q + {0..3} of its row
+#pragma unroll
+    for (int t = 0; t < C3 / 16; ++t) {
+        f32x4_t a = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < C2 / 32; ++kk) {
+            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w3l[(16 * t + i) * P3 + 32 * kk + 8 * q]);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af3[kk], a, 0, 0, 0);
+        }
+        const float4 bb = ld4(b3 + 16 * t + 4 * q);
+        st4(out + b * out_stride + 16 * t + 4 * q,
+            make_float4(elu1(a[0] + bb.x, alpha), elu1(a[1] + bb.y, alpha), elu1(a[2] + bb.z, alpha), elu1(a[3] + bb.w, alpha)));
+    }
+}
+
 // ---- backward of a Linear through the previous layer's ELU on the matrix cores:
 //   gz[b, u] = (G W)[b, u] * elu'(a[b, u])      G [n, K] bf16 (gradient w.r.t. this layer's pre-activation),
 //                                               Wt [N, K] bf16 = W^T (N = input width of the layer),
@@ -2946,6 +3098,37 @@ int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t
         default: return VINE_ERR_UNSUPPORTED;
     }
 #undef VINE_LIN_MFMA
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
+                       float eps, float clip, const void* w1p, const float* b1, int64_t C1, const void* w2, int64_t ldw2,
+                       const float* b2, int64_t C2, const void* w3, int64_t ldw3, const float* b3, int64_t C3, float alpha,
+                       void* act1, void* act2, void* out, int64_t out_stride, void* stream) {
+    if (n <= 0 || !x || !w1p || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (ldx & 7) || (ldw2 & 7) || (ldw3 & 7) ||
+        (out_stride & 3) || ldx < 32 || ldw2 < C1 || ldw3 < C2 || ((uintptr_t)x & 15) || ((uintptr_t)w1p & 15) ||
+        ((uintptr_t)w2 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)out & 7) || (raw && (!mean || !var || F_in <= 0 || F_in > 32)))
+        return VINE_ERR_INVALID_ARG;
+    if (C1 != 256 || C2 != 128 || C3 != 64 || (n & 63)) return VINE_ERR_UNSUPPORTED;
+    const int threads = (n % 128 == 0 && n >= 32768) ? 512 : 256;        // 8 waves per CU when one round covers the chip
+    const size_t lds = ((size_t)256 * 40 + 128 * 264 + 64 * 136) * sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VINE_ERR_DEVICE;
+        attr_set = true;
+    }
+#define VINE_MLP3(NW_)                                                                                                   \
+    hipLaunchKernelGGL((mlp3_elu_mfma_kernel<256, 128, 64, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), lds,  \
+                       (hipStream_t)stream, (long long)n, (bf16_t*)x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip, \
+                       (const bf16_t*)w1p, b1, (const bf16_t*)w2, (long long)ldw2, b2, (const bf16_t*)w3, (long long)ldw3, \
+                       b3, alpha, (bf16_t*)act1, (bf16_t*)act2, (bf16_t*)out, (long long)out_stride)
+    if (threads == 512) VINE_MLP3(8);
+    else VINE_MLP3(4);
+#undef VINE_MLP3
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -429,12 +429,27 @@ class A2CAgent:
         xh, xh_next = f["xh2"][f["cur"]], f["xh2"][f["cur"] ^ 1]
         x0 = f["x0_sep"] if f["x0_sep"] is not None else xh[:, f["U"]:f["U"] + f["F"]]
         hp_ptr = (xh_next.data_ptr() + xh_next.element_size() * XW) if commit else None
-        fused._check(lib.vine_normalize_obs(N, f["F"], obs.data_ptr(), rms.running_mean.data_ptr(),
-                                            rms.running_var.data_ptr(), float(rms.epsilon), 5.0, x0.data_ptr(),
-                                            x0.stride(0), bf, st), "vine_normalize_obs")
-        x = x0
         n_mlp = len(f["mlp"])
-        for i, (W, b) in enumerate(f["mlp"]):
+        mlp3 = (bf and fused.MLP3 and f["w1p"] is not None and f["x0_sep"] is None and n_mlp == 3 and N % 64 == 0
+                and f["U"] == 64 and f["F"] <= 32 and obs.is_contiguous() and obs.dtype == torch.float32
+                and tuple(W.shape for W, _ in f["mlp"][1:]) == ((128, 256), (64, 128)) and f["mlp"][0][0].shape[0] == 256)
+        if mlp3:
+            # observation normalisation and the whole MLP in ONE launch: the kernel normalises the raw observations
+            # itself, writes them (bf16, zero-padded) into the LSTM operand's observation block and carries the
+            # activations through the three layers in registers (the intermediate activations are not needed here)
+            (W1, b1), (W2, b2), (W3, b3) = f["mlp"]
+            fused._check(lib.vine_mlp3_elu_mfma(N, xh.data_ptr() + 2 * f["U"], xh.stride(0), obs.data_ptr(), f["F"],
+                                                rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                                float(rms.epsilon), 5.0, f["w1p"].data_ptr(), b1.data_ptr(), 256,
+                                                W2.data_ptr(), W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(), W3.stride(0),
+                                                b3.data_ptr(), 64, 1.0, None, None, xh.data_ptr(), xh.stride(0), st),
+                         "vine_mlp3_elu_mfma")
+        else:
+            fused._check(lib.vine_normalize_obs(N, f["F"], obs.data_ptr(), rms.running_mean.data_ptr(),
+                                                rms.running_var.data_ptr(), float(rms.epsilon), 5.0, x0.data_ptr(),
+                                                x0.stride(0), bf, st), "vine_normalize_obs")
+        x = x0
+        for i, (W, b) in enumerate(f["mlp"] if not mlp3 else ()):
             out = xh if i == n_mlp - 1 else f["acts"][i]
             if i == 0 and f["w1p"] is not None:
                 fused._check(lib.vine_linear_elu_mfma(N, W.shape[0], 32, xh.data_ptr() + 2 * f["U"], xh.stride(0),

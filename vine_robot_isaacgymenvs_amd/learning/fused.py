@@ -143,6 +143,7 @@ def weight_grad(dy, x, out=None, batch=None):
     return column_sums(part, out, batch=batch)
 
 
+MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
 WGRAD_CAT_WIDE = _os.environ.get("VINE_WGRAD_CAT_WIDE", "1") != "0"  # 128 x 352 tiles for the LSTM's [x | h] (A/B knob)
@@ -675,7 +676,7 @@ class _Trunk(torch.autograd.Function):
     (W_1, b_1, ..., W_L, b_L, w_ih, w_hh, b_ih, b_hh, ln_gamma, ln_beta, ln_eps, mu_w, mu_b, v_w, v_b)."""
 
     @staticmethod
-    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, op_weights, head_bias_external, *params):
+    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, op_weights, head_bias_external, norm, *params):
         lib = _lib()
         mlp = [(params[2 * i], params[2 * i + 1]) for i in range(n_mlp)]
         w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, ln_eps, mu_w, mu_b, v_w, v_b = params[2 * n_mlp:]
@@ -693,6 +694,23 @@ class _Trunk(torch.autograd.Function):
         width = U + (F_in if concat else 0)
         # rows padded to 64 B so that every row (and the column block the ELU kernels address) is 16-B aligned
         wpad = (width + 15) // 16 * 16
+        # layer 1 on the matrix cores: its operand is the observation block of the LSTM operand buffer plus the zero
+        # pad columns behind it (K = 32); all three layers in one launch when the shapes are the default network's
+        l1_mfma = mixed and concat and wpad - U == 32 and linear_elu_mfma_ok(n, Wop[0].shape[0], 32)
+        mlp3 = (mixed and MLP3 and l1_mfma and n_mlp == 3 and n % 64 == 0 and U == 64
+                and tuple(W.shape[0] for W in Wop) == (256, 128, 64) and Wop[1].shape[1] == 256 and Wop[2].shape[1] == 128)
+        # ``norm`` = (running mean, running var, eps): obs_n holds RAW observations and the one-launch MLP normalises
+        # them itself; every other route normalises here first (vine_normalize_obs, same arithmetic)
+        raw = None
+        if norm is not None:
+            obs_c = obs_n.contiguous()
+            if mlp3 and obs_c.dtype == torch.float32 and F_in <= 32:
+                raw = obs_c
+            else:
+                y = torch.empty_like(obs_c)
+                _check(lib.vine_normalize_obs(n, F_in, obs_c.data_ptr(), norm[0].data_ptr(), norm[1].data_ptr(),
+                                              float(norm[2]), 5.0, y.data_ptr(), F_in, 0, st), "vine_normalize_obs")
+                obs_n = y
         xfull = torch.empty((n, wpad), device=dev, dtype=op)
         xcat = xfull[:, :width]
         A_ = mu_w.shape[0]
@@ -709,13 +727,11 @@ class _Trunk(torch.autograd.Function):
             # transposed MLP weights for the backward kernels, merged head weights, b_ih + b_hh
             obs_c = obs_n.contiguous()
             prep = CopyBatch()
-            # layer 1 on the matrix cores too: its operand is the observation block of the LSTM operand buffer plus
-            # the zero pad columns behind it (K = 32), its weight is padded to match
-            l1_mfma = concat and wpad - U == 32 and linear_elu_mfma_ok(n, Wop[0].shape[0], 32)
-            if concat:
-                prep.add(CopyBatch.CAST_BF16, xfull[:, U:width], obs_c)
-            if wpad > width:
-                prep.add(CopyBatch.ZERO, xfull[:, width:])
+            if raw is None:        # (else the MLP kernel writes the normalised observation block and its zero pad)
+                if concat:
+                    prep.add(CopyBatch.CAST_BF16, xfull[:, U:width], obs_c)
+                if wpad > width:
+                    prep.add(CopyBatch.ZERO, xfull[:, width:])
             if l1_mfma:
                 x0 = xfull[:, U:width]                        # strided view; also the operand of layer 1's weight gradient
                 w1p = torch.empty((Wop[0].shape[0], 32), device=dev, dtype=op)
@@ -759,14 +775,25 @@ class _Trunk(torch.autograd.Function):
         else:
             lstm_buffers = None
             c0_direct = None
-            l1_mfma = False
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
             torch.cat([mu_b, v_b], 0, out=b_heads)
             torch.add(b_ih, b_hh, out=bias)
         acts = []
         x = x0
-        for i, (W, b) in enumerate(mlp):
+        if mlp3:
+            # the whole MLP in one launch, activations carried in registers (vine_mlp3_elu_mfma)
+            acts = [torch.empty((n, 256), device=dev, dtype=op), torch.empty((n, 128), device=dev, dtype=op)]
+            _check(lib.vine_mlp3_elu_mfma(n, xfull.data_ptr() + 2 * U, xfull.stride(0),
+                                          raw.data_ptr() if raw is not None else None, F_in,
+                                          norm[0].data_ptr() if raw is not None else None,
+                                          norm[1].data_ptr() if raw is not None else None,
+                                          float(norm[2]) if raw is not None else 0.0, 5.0,
+                                          w1p.data_ptr(), mlp[0][1].data_ptr(), 256, Wop[1].data_ptr(), Wop[1].stride(0),
+                                          mlp[1][1].data_ptr(), 128, Wop[2].data_ptr(), Wop[2].stride(0),
+                                          mlp[2][1].data_ptr(), 64, 1.0, acts[0].data_ptr(), acts[1].data_ptr(),
+                                          xfull.data_ptr(), xfull.stride(0), st), "vine_mlp3_elu_mfma")
+        for i, (W, b) in enumerate(mlp if not mlp3 else ()):
             last = i == n_mlp - 1
             if mixed:
                 C_, K_ = Wop[i].shape
@@ -964,7 +991,7 @@ class _Trunk(torch.autograd.Function):
         wgroup.flush()                      # the MLP weight gradients: one launch, all operands exist by now
         if batch is not None:
             batch.flush(out)
-        return (None, None, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def linear_elu_mfma_ok(n, N, K):
@@ -985,19 +1012,22 @@ def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
 
 
 def trunk(obs_n, h0, c0, dones, T, concat, mlp_params, lstm_params, ln, heads, op_weights=None,
-          head_bias_external=False):
+          head_bias_external=False, norm=None):
     """-> (heads [n, A+1] = [mu | value], hT, cT).  ``mlp_params`` = [(W, b), ...]; ``lstm_params`` =
     (w_ih, w_hh, b_ih, b_hh); ``ln`` = (gamma, beta, eps); ``heads`` = (mu_w, mu_b, value_w, value_b).
     ``op_weights`` = bfloat16 copies of (W_1, ..., W_L, w_ih, w_hh) selects the mixed-precision update: those GEMMs
     take bf16 operands (fp32 accumulate and output), activations exist only as bf16 GEMM operands; LSTM cell state,
     gates, LayerNorm, heads, loss, gradients w.r.t. parameters and the optimiser stay fp32.
     ``head_bias_external``: the caller obtains the two head-bias gradients elsewhere (the PPO loss kernel adds them to
-    the parameters' gradient slots), so the backward skips that column sum over all n rows."""
+    the parameters' gradient slots), so the backward skips that column sum over all n rows.
+    ``norm`` = (running mean, running var, eps) of the observation normaliser: ``obs_n`` then holds the RAW observations
+    and the trunk normalises them itself (inside the one-launch MLP kernel where that applies)."""
     if dones is not None:
         dones = dones.to(torch.uint8).contiguous()
     flat = [p for wb in mlp_params for p in wb]
     return _Trunk.apply(obs_n, h0.contiguous(), c0.contiguous(), dones, T, bool(concat), len(mlp_params),
-                        tuple(op_weights) if op_weights is not None else None, bool(head_bias_external), *flat,
+                        tuple(op_weights) if op_weights is not None else None, bool(head_bias_external),
+                        tuple(norm) if norm is not None else None, *flat,
                         *lstm_params, ln[0], ln[1], float(ln[2]), *heads)
 
 

@@ -111,7 +111,7 @@ class A2CNetwork(nn.Module):
         z = torch.zeros((1, batch, self.rnn_units), device=device)
         return (z, z.clone())
 
-    def forward_heads(self, obs, states, seq_length, dones, head_bias_external=False):
+    def forward_heads(self, obs, states, seq_length, dones, head_bias_external=False, norm=None):
         """Training forward on the MI355X as one fused autograd node (learning/fused.py:_Trunk):
         -> (heads [n, A+1] = [mu | value], states).  Caller checks ``fused.trunk_supported`` first."""
         r = self.rnn.rnn
@@ -124,7 +124,7 @@ class A2CNetwork(nn.Module):
                                   (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0),
                                   (self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
                                   (self.mu.weight, self.mu.bias, self.value.weight, self.value.bias),
-                                  op_weights=op_weights, head_bias_external=head_bias_external)
+                                  op_weights=op_weights, head_bias_external=head_bias_external, norm=norm)
         return heads, (h.unsqueeze(0), c.unsqueeze(0))
 
     def trunk_supported(self, obs, seq_length):
@@ -179,12 +179,21 @@ class ModelA2CContinuousLogStd(nn.Module):
         ``heads`` is the [n, A+1] = [mu | value] block when the fused trunk ran (mu/value are views of it), else None.
         ``obs_is_normalized``: ``obs`` already went through ``norm_obs`` (the captured optimiser step keeps the
         running-statistics update outside the hipGraph); ``head_bias_external``: see ``fused.trunk``."""
-        obs = input_dict["obs"] if input_dict.get("obs_is_normalized", False) else self.norm_obs(input_dict["obs"])
         net = self.a2c_network
         T = input_dict.get("seq_length", 1)
+        raw, norm = input_dict["obs"], None
+        rms = self.running_mean_std if self.normalize_input else None
+        if (rms is not None and not input_dict.get("obs_is_normalized", False) and net.op_weight_lookup is not None
+                and rms._use_kernels(raw) and net.trunk_supported(raw, T)):
+            # mixed-precision trunk: update the running statistics here (training mode), let the trunk normalise the
+            # raw observations itself (one launch for normalisation + MLP)
+            rms.update_kernels(raw)
+            obs, norm = raw, (rms.running_mean, rms.running_var, rms.epsilon)
+        else:
+            obs = raw if input_dict.get("obs_is_normalized", False) else self.norm_obs(raw)
         if net.trunk_supported(obs, T):
             heads, states = net.forward_heads(obs, input_dict["rnn_states"], T, input_dict.get("dones", None),
-                                              input_dict.get("head_bias_external", False))
+                                              input_dict.get("head_bias_external", False), norm=norm)
             A = net.mu.weight.shape[0]
             return heads[:, :A], heads[:, A:], net.sigma, states, heads
         mu, _logstd, value, states = net(obs, input_dict["rnn_states"], T, input_dict.get("dones", None))

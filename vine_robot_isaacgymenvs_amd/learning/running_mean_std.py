@@ -36,17 +36,27 @@ class RunningMeanStd(nn.Module):
         return (x.is_cuda and x.dtype == torch.float32 and len(self.insize) == 1 and self.insize[0] <= 64
                 and x.dim() == 2 and x.shape[1] == self.insize[0] and not torch.is_autocast_enabled())
 
-    def _forward_kernels(self, x):
+    def update_kernels(self, x):
+        """Statistics update only (training mode; nothing in eval mode): for callers that normalise elsewhere."""
+        if not self.training:
+            return
         from .. import native
         from ..abi import RMS_BLOCKS
         lib = native.load()
         x = x.contiguous()
         n, F = x.shape
+        scratch = torch.empty(RMS_BLOCKS * 2 * F, device=x.device, dtype=torch.float64)
+        native.check(lib.vine_rms_update(n, F, x.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
+                                         self.count.data_ptr(), scratch.data_ptr(),
+                                         torch.cuda.current_stream(x.device).cuda_stream), lib)
+
+    def _forward_kernels(self, x):
+        from .. import native
+        lib = native.load()
+        x = x.contiguous()
+        n, F = x.shape
         st = torch.cuda.current_stream(x.device).cuda_stream
-        if self.training:
-            scratch = torch.empty(RMS_BLOCKS * 2 * F, device=x.device, dtype=torch.float64)
-            native.check(lib.vine_rms_update(n, F, x.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
-                                             self.count.data_ptr(), scratch.data_ptr(), st), lib)
+        self.update_kernels(x)
         y = torch.empty_like(x)
         native.check(lib.vine_normalize_obs(n, F, x.data_ptr(), self.running_mean.data_ptr(), self.running_var.data_ptr(),
                                             float(self.epsilon), 5.0, y.data_ptr(), F, 0, st), lib)
