@@ -104,6 +104,18 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
                        const float* b2, int64_t C2, const void* w3, int64_t ldw3, const float* b3, int64_t C3, float alpha,
                        void* act1, void* act2, void* out, int64_t out_stride, void* stream);
 
+/* Backward of that MLP in ONE launch:  gz3 = (dG wt0^T) * elu'(a3),  gz2 = (gz3 wt1^T) * elu'(a2),  gz1 = (gz2 wt2^T) * elu'(a1)
+ * with dG [n, K0] (the LSTM gate gradients), wt0 [C3, K0] = the MLP block of w_ih transposed, wt1 [C2, C3] = W3^T,
+ * wt2 [C1, C2] = W2^T, a3 [n, C3] (rows a3_stride apart) / a2 [n, C2] / a1 [n, C1] the stored ELU outputs, all bf16;
+ * gz3 / gz2 / gz1 packed bf16 (the operands of the three weight gradients); part3 / part2 / part1
+ * [n / rows_per_workgroup, C] fp32: one row of column sums of each gz per workgroup (partial bias gradients;
+ * rows_per_workgroup = 128 when n % 128 == 0 and n >= 32768, else 64).  Covers C3 = 64, C2 = 128, C1 = 256, K0 = 1024,
+ * n % 64 == 0 (VINE_ERR_UNSUPPORTED otherwise: vine_linear_bwd_elu_mfma per layer). */
+int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, const void* wt0, int64_t ldw0, const void* wt1,
+                           int64_t ldw1, const void* wt2, int64_t ldw2, const void* a3, int64_t a3_stride, const void* a2,
+                           const void* a1, int64_t C3, int64_t C2, int64_t C1, float alpha, void* gz3, void* gz2, void* gz1,
+                           float* part3, float* part2, float* part1, void* stream);
+
 /* Backward of a Linear through the previous layer's ELU, on the matrix cores:
  *   gz = (G Wt^T) * elu'(a)   with G [n, K] bf16 (gradient w.r.t. this layer's pre-activation), Wt [N, K] bf16 = the
  *   layer's weight TRANSPOSED (N = its input width), a [n, N] bf16 = the previous layer's ELU output, gz [n, N] bf16;

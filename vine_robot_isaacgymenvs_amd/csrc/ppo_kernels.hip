@@ -1188,6 +1188,177 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
     }
 }
 
+// ---- The backward pass of the whole MLP in ONE kernel (mixed precision), the twin of mlp3_elu_mfma_kernel:
+//   gz3 [n, C3] = (dG [n, K0] Wt0^T) * elu'(a3)     Wt0 [C3, K0] = the MLP block of w_ih, transposed (K0 = 4H, streamed)
+//   gz2 [n, C2] = (gz3 Wt1^T) * elu'(a2)            Wt1 [C2, C3] = W3^T
+//   gz1 [n, C1] = (gz2 Wt2^T) * elu'(a1)            Wt2 [C1, C2] = W2^T
+// plus one row of column sums of each gz per workgroup (the partial bias gradients).  Formerly three launches
+// (linear_bwd_elu_mfma_chunked_kernel<8>, linear_bwd_elu_mfma_kernel<2>, <4>: 15 + 9 + 18 us in the update).  A wave
+// carries its 16 rows through the three products in registers: the output tiles of a product are ordered so that a lane
+// ends up with the 8 consecutive units it needs as its B fragment of the next product (mlp3_tile_row), which also makes
+// every gz store and every activation load one 16-B piece.  Stage 1 streams K0 in 128-wide chunks exactly like the
+// chunked kernel (weight chunk double-buffered in LDS, dG fragments double-buffered in registers); the two small
+// weights are requested at the start and parked in LDS after stage 1.  Column sums: DPP row sums over the 16 rows of
+// a wave (dpp_row_sum16), then across the waves through LDS -- fixed order, no atomics.
+template <int C3, int C2, int C1, int NCH, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_bwd_elu_mfma_kernel(
+    long long n, const bf16_t* __restrict__ G, long long ldg, const bf16_t* __restrict__ Wt0, long long ldw0,
+    const bf16_t* __restrict__ Wt1, long long ldw1, const bf16_t* __restrict__ Wt2, long long ldw2,
+    const bf16_t* __restrict__ a3, long long a3_stride, const bf16_t* __restrict__ a2, const bf16_t* __restrict__ a1,
+    float alpha, bf16_t* __restrict__ gz3, bf16_t* __restrict__ gz2, bf16_t* __restrict__ gz1,
+    float* __restrict__ part3, float* __restrict__ part2, float* __restrict__ part1) {
+    constexpr int CK = 128, PC = CK + 8, P1 = C3 + 8, P2 = C2 + 8, TH = 64 * NW;
+    constexpr int NPC = C3 * (CK / 8) / TH;                     // weight pieces of a chunk per thread
+    constexpr int N1 = C2 * (C3 / 8) / TH, N2 = C1 * (C2 / 8) / TH;
+    static_assert(C3 == 64 && C3 * (CK / 8) % TH == 0 && C2 * (C3 / 8) % TH == 0 && C1 * (C2 / 8) % TH == 0, "shapes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16_t* wc = reinterpret_cast<bf16_t*>(lds_raw);            // [2][C3][PC] chunk buffers of Wt0, rows in tile order
+    bf16_t* w1l = wc + 2 * C3 * PC;                             // [C2][P1], rows in tile order
+    bf16_t* w2l = w1l + C2 * P1;                                // [C1][P2], rows in tile order
+    float* red = reinterpret_cast<float*>(w2l + C1 * P2);       // [NW][C3 + C2 + C1] column sums of the waves
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const long long b = ((long long)blockIdx.x * NW + wave) * 16 + i;
+    const bf16_t* grow = G + b * ldg + 8 * q;
+    // ---- requests: the two small weights, chunk 0 of Wt0, this lane's dG fragments of chunk 0
+    u32x4_t s1[N1], s2[N2], wp[NPC];
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+        const int c = tid + TH * it, row = c / (C3 / 8), ck = c - row * (C3 / 8);
+        s1[it] = *reinterpret_cast<const u32x4_t*>(Wt1 + (long long)row * ldw1 + 8 * ck);
+    }
+#pragma unroll
+    for (int it = 0; it < N2; ++it) {
+        const int c = tid + TH * it, row = c / (C2 / 8), ck = c - row * (C2 / 8);
+        s2[it] = *reinterpret_cast<const u32x4_t*>(Wt2 + (long long)row * ldw2 + 8 * ck);
+    }
+#define MB_LOAD_W(ch)                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < NPC; ++it) {                                                       \
+        const int c_ = tid + TH * it;                                                                          \
+        wp[it] = *reinterpret_cast<const u32x4_t*>(Wt0 + (long long)(c_ >> 4) * ldw0 + (ch) * CK + 8 * (c_ & 15)); \
+    }
+#define MB_STORE_W(buf)                                                                                        \
+    _Pragma("unroll") for (int it = 0; it < NPC; ++it) {                                                       \
+        const int c_ = tid + TH * it;                                                                          \
+        *reinterpret_cast<u32x4_t*>(&wc[((buf) * C3 + mlp3_tile_row(c_ >> 4)) * PC + 8 * (c_ & 15)]) = wp[it]; \
+    }
+    bf16x8_t gq[3][4];                                          // dG fragments of chunks c, c + 1, c + 2 (two in flight)
+#define MB_LOAD_G(ch)                                                                                          \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                           \
+        gq[(ch) % 3][k_] = *reinterpret_cast<const bf16x8_t*>(grow + (ch) * CK + 32 * k_);
+    MB_LOAD_W(0)
+    MB_LOAD_G(0)
+    if (NCH > 1) { MB_LOAD_G(1) }
+    MB_STORE_W(0)
+    __syncthreads();
+    // ---- stage 1: C3 = 64 units = tiles (pair kk, ut), K0 streamed
+    f32x4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) { MB_LOAD_W(c + 1) }
+        if (c + 2 < NCH) { MB_LOAD_G(c + 2) }
+        const bf16_t* wb = wc + (c & 1) * C3 * PC;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16_t* wr = wb + (t * 16 + i) * PC + 8 * q;
+#pragma unroll
+            for (int k_ = 0; k_ < 4; ++k_)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32 * k_), gq[c % 3][k_],
+                                                                 acc[t], 0, 0, 0);
+        }
+        if (c + 1 < NCH) { MB_STORE_W((c + 1) & 1) }            // buffer (c+1)&1 was last read before the previous barrier
+        __syncthreads();
+    }
+#undef MB_LOAD_W
+#undef MB_STORE_W
+#undef MB_LOAD_G
+    // the two small weights -> LDS (their loads have long landed)
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+        const int c = tid + TH * it, row = c / (C3 / 8), ck = c - row * (C3 / 8);
+        *reinterpret_cast<u32x4_t*>(&w1l[mlp3_tile_row(row) * P1 + 8 * ck]) = s1[it];
+    }
+#pragma unroll
+    for (int it = 0; it < N2; ++it) {
+        const int c = tid + TH * it, row = c / (C2 / 8), ck = c - row * (C2 / 8);
+        *reinterpret_cast<u32x4_t*>(&w2l[mlp3_tile_row(row) * P2 + 8 * ck]) = s2[it];
+    }
+    float* myred = red + wave * (C3 + C2 + C1);
+    // gz = acc * elu'(a) for the pair of tiles holding units u0 .. u0 + 7 of this lane; returns the packed bf16 piece,
+    // stores it, and leaves the wave's column sums of the 8 units in LDS (lane 15 of every DPP row)
+#define MB_FINISH(a_lo, a_hi, aptr, gzptr, redoff, pk)                                                         \
+    {                                                                                                          \
+        float av_[8], d_[8];                                                                                   \
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(aptr), av_);                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
+            d_[e] = (a_lo)[e] * (av_[e] > 0.0f ? 1.0f : av_[e] + alpha);                                       \
+            d_[4 + e] = (a_hi)[e] * (av_[4 + e] > 0.0f ? 1.0f : av_[4 + e] + alpha);                           \
+        }                                                                                                      \
+        pk = pack_bf16x8(d_);                                                                                  \
+        *reinterpret_cast<uint4*>(gzptr) = pk;                                                                 \
+        float r_[8];                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = dpp_row_sum16(d_[e]);                            \
+        if (i == 15) {                                                                                         \
+            st4(myred + (redoff), make_float4(r_[0], r_[1], r_[2], r_[3]));                                    \
+            st4(myred + (redoff) + 4, make_float4(r_[4], r_[5], r_[6], r_[7]));                                \
+        }                                                                                                      \
+    }
+    bf16x8_t gf2[C3 / 32];
+#pragma unroll
+    for (int kk = 0; kk < C3 / 32; ++kk) {
+        uint4 pk;
+        MB_FINISH(acc[2 * kk], acc[2 * kk + 1], a3 + b * a3_stride + 32 * kk + 8 * q, gz3 + b * C3 + 32 * kk + 8 * q,
+                  32 * kk + 8 * q, pk)
+        gf2[kk] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+    __syncthreads();                                             // w1l / w2l complete
+    // ---- stage 2: C2 units, K = C3
+    bf16x8_t gf1[C2 / 32];
+#pragma unroll
+    for (int kp = 0; kp < C2 / 32; ++kp) {
+        f32x4_t a[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+        for (int kk = 0; kk < C3 / 32; ++kk)
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w1l[(32 * kp + 16 * ut + i) * P1 + 32 * kk + 8 * q]);
+                a[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf2[kk], a[ut], 0, 0, 0);
+            }
+        uint4 pk;
+        MB_FINISH(a[0], a[1], a2 + b * C2 + 32 * kp + 8 * q, gz2 + b * C2 + 32 * kp + 8 * q, C3 + 32 * kp + 8 * q, pk)
+        gf1[kp] = __builtin_bit_cast(bf16x8_t, pk);
+    }
+    // ---- stage 3: C1 units, K = C2
+#pragma unroll
+    for (int kp = 0; kp < C1 / 32; ++kp) {
+        f32x4_t a[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+        for (int kk = 0; kk < C2 / 32; ++kk)
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut) {
+                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w2l[(32 * kp + 16 * ut + i) * P2 + 32 * kk + 8 * q]);
+                a[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf1[kk], a[ut], 0, 0, 0);
+            }
+        uint4 pk;
+        MB_FINISH(a[0], a[1], a1 + b * C1 + 32 * kp + 8 * q, gz1 + b * C1 + 32 * kp + 8 * q, C3 + C2 + 32 * kp + 8 * q, pk)
+        (void)pk;
+    }
+#undef MB_FINISH
+    // ---- column sums of the workgroup: the waves' rows added in wave order
+    __syncthreads();
+    for (int u = tid; u < C3 + C2 + C1; u += TH) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += red[w * (C3 + C2 + C1) + u];
+        float* dst = u < C3 ? part3 + (long long)blockIdx.x * C3 + u
+                            : (u < C3 + C2 ? part2 + (long long)blockIdx.x * C2 + (u - C3)
+                                           : part1 + (long long)blockIdx.x * C1 + (u - C3 - C2));
+        *dst = sum;
+    }
+}
+
 template <typename DG>
 __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_out, long long g_stride,
                                 const float* __restrict__ g_rec, const float* __restrict__ dc_next,
@@ -3129,6 +3300,40 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
     if (threads == 512) VINE_MLP3(8);
     else VINE_MLP3(4);
 #undef VINE_MLP3
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, const void* wt0, int64_t ldw0, const void* wt1,
+                           int64_t ldw1, const void* wt2, int64_t ldw2, const void* a3, int64_t a3_stride, const void* a2,
+                           const void* a1, int64_t C3, int64_t C2, int64_t C1, float alpha, void* gz3, void* gz2, void* gz1,
+                           float* part3, float* part2, float* part1, void* stream) {
+    if (n <= 0 || !dG || !wt0 || !wt1 || !wt2 || !a3 || !a2 || !a1 || !gz3 || !gz2 || !gz1 || !part3 || !part2 || !part1 ||
+        (lddg & 7) || (ldw0 & 7) || (ldw1 & 7) || (ldw2 & 7) || (a3_stride & 7) || lddg < K0 || ldw0 < K0 || ldw1 < C3 ||
+        ldw2 < C2 || ((uintptr_t)dG & 15) || ((uintptr_t)wt0 & 15) || ((uintptr_t)wt1 & 15) || ((uintptr_t)wt2 & 15) ||
+        ((uintptr_t)a3 & 15) || ((uintptr_t)a2 & 15) || ((uintptr_t)a1 & 15) || ((uintptr_t)gz3 & 15) || ((uintptr_t)gz2 & 15) ||
+        ((uintptr_t)gz1 & 15))
+        return VINE_ERR_INVALID_ARG;
+    if (C3 != 64 || C2 != 128 || C1 != 256 || K0 != 1024 || (n & 63)) return VINE_ERR_UNSUPPORTED;
+    const int nw = (n % 128 == 0 && n >= 32768) ? 8 : 4;
+    const size_t lds = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(bf16_t) + (size_t)nw * (64 + 128 + 256) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return VINE_ERR_DEVICE;
+        attr_set = true;
+    }
+#define VINE_MLP3B(NW_)                                                                                                   \
+    hipLaunchKernelGGL((mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), \
+                       lds, (hipStream_t)stream, (long long)n, (const bf16_t*)dG, (long long)lddg, (const bf16_t*)wt0,     \
+                       (long long)ldw0, (const bf16_t*)wt1, (long long)ldw1, (const bf16_t*)wt2, (long long)ldw2,          \
+                       (const bf16_t*)a3, (long long)a3_stride, (const bf16_t*)a2, (const bf16_t*)a1, alpha, (bf16_t*)gz3, \
+                       (bf16_t*)gz2, (bf16_t*)gz1, part3, part2, part1)
+    if (nw == 8) VINE_MLP3B(8);
+    else VINE_MLP3B(4);
+#undef VINE_MLP3B
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -948,7 +948,33 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
         gz = part = g = None
         wgroup = WeightGradGroup()
-        if mixed and ctx.wts[0] is not None:
+        mlp3b = (mixed and MLP3 and n_mlp == 3 and all(w is not None for w in ctx.wts) and n % 64 == 0 and U == 64
+                 and 4 * H == 1024 and tuple(ctx.wts[i].shape for i in (1, 2)) == ((256, 128), (128, 64))
+                 and acts[0].shape[1] == 256 and acts[1].shape[1] == 128)
+        if mlp3b:
+            # the whole MLP backward in one launch (vine_mlp3_bwd_elu_mfma): LSTM input gradient (MLP columns) x ELU' ->
+            # gz3 -> gz2 -> gz1 carried in registers, bias partial sums per workgroup
+            rows_wg = 128 if (n % 128 == 0 and n >= 32768) else 64
+            gzs = [torch.empty((n, c), device=dev, dtype=torch.bfloat16) for c in (256, 128, 64)]       # layers 1, 2, 3
+            parts = [torch.empty((n // rows_wg, c), device=dev, dtype=torch.float32) for c in (256, 128, 64)]
+            _check(lib.vine_mlp3_bwd_elu_mfma(n, dG.data_ptr(), dG.stride(0), 4 * H, ctx.wts[0].data_ptr(),
+                                              ctx.wts[0].stride(0), ctx.wts[2].data_ptr(), ctx.wts[2].stride(0),
+                                              ctx.wts[1].data_ptr(), ctx.wts[1].stride(0), xcat.data_ptr(), xcat.stride(0),
+                                              acts[1].data_ptr(), acts[0].data_ptr(), 64, 128, 256, 1.0,
+                                              gzs[2].data_ptr(), gzs[1].data_ptr(), gzs[0].data_ptr(),
+                                              parts[2].data_ptr(), parts[1].data_ptr(), parts[0].data_ptr(), st),
+                   "vine_mlp3_bwd_elu_mfma")
+            del dG
+            for i in range(n_mlp):
+                x_in = acts[i - 1] if i > 0 else x0
+                deliver(2 * i, lambda o, gz=gzs[i], x_in=x_in: wgroup.add(gz, x_in, o, batch) or weight_grad(gz, x_in, out=o, batch=batch))
+                deliver(2 * i + 1, lambda o, part=parts[i]: column_sums(part, o, batch=batch))
+            n_mlp_loop = 0
+        else:
+            n_mlp_loop = n_mlp
+        if mlp3b:
+            pass
+        elif mixed and ctx.wts[0] is not None:
             # LSTM input gradient (MLP columns only) x ELU' of the last MLP layer + its bias partial sums: one
             # matrix-core kernel streaming the 4H-long reduction in k chunks
             gz = torch.empty((n, U), device=dev, dtype=torch.bfloat16)
@@ -958,11 +984,12 @@ class _Trunk(torch.autograd.Function):
                                                 gz.data_ptr(), U, part.data_ptr(), st), "vine_linear_bwd_elu_mfma")
         else:
             g = _mm(dG, w_ih[:, :U] if concat else w_ih)    # only the MLP columns of the LSTM input need a gradient
-        del dG
+        if not mlp3b:
+            del dG
         # ---- MLP, last layer first: ELU' from the stored OUTPUT, bias gradient from the kernels' partial sums.
         # gz = gradient w.r.t. layer i's pre-activation.  In mixed precision the step from layer i to layer i-1
         # (input-gradient GEMM + ELU backward + bias partial sums) is one matrix-core kernel.
-        for i in reversed(range(n_mlp)):
+        for i in reversed(range(n_mlp_loop)):
             if gz is None:
                 a = xcat if i == n_mlp - 1 else acts[i]
                 C_ = g.shape[1]
