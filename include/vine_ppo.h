@@ -291,6 +291,21 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   float* grad_value_bias, float* scratch, float* kl_out, float* logstd_grad_accum, float* mu_store,
                   float* sigma_store, void* stream);
 
+/* LayerNorm + heads + PPO loss + their backward in ONE launch (H = 256, NH = A + 1 in 2..5): from the LSTM output x [n, H] it forms heads = W LN(x) + wb ([n, NH], written out),
+ * the loss terms and statistics of vine_ppo_loss on them, and d loss / d x ([n, H], dx) -- what
+ * vine_layernorm_heads_forward + vine_ppo_loss + vine_layernorm_heads_backward produce in three launches, with the
+ * same arithmetic.  ln_partial [n / R, (2 + NH) H] with R = vine_ln_heads_loss_rows() rows per workgroup (128 by default;
+ * n % R == 0, n / R <= VINE_PPO_LOSS_BLOCKS): per-workgroup sums {d gamma | d beta | d W} (finish with vine_column_sums).  stats / grad_logstd / grad_mu_bias / grad_value_bias / scratch / kl_out / logstd_grad_accum /
+ * mu_store / sigma_store: as in vine_ppo_loss. */
+int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const float* gamma, const float* beta, float eps,
+                       const float* w, const float* wb, const float* logstd, const float* actions, const float* old_neglogp,
+                       const float* advantages, const float* old_values, const float* returns, const float* old_mu,
+                       const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
+                       float bounds_coef, float soft_bound, float* heads, float* dx, float* ln_partial, float* stats,
+                       float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch, float* kl_out,
+                       float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream);
+int vine_ln_heads_loss_rows(void);
+
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps
  * (eps ~ N(0,1) from Philox4x32-10 keyed by (seed, env, *counter)), neglogp, value un-normalised

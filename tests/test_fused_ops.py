@@ -761,6 +761,73 @@ def test_fused_trunk_matches_float64_composition(obs_dim, use_slots, mixed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("clip_value", [True, False])
+def test_ln_heads_loss_kernel_matches_float64_autograd(clip_value):
+    """LayerNorm + heads + PPO loss + their backward in ONE launch (vine_ln_heads_loss) against the float64 autograd
+    of the stock composition: heads, d loss / d x, the gradients of gamma, beta, the head weights and biases, log sigma,
+    the loss statistics, the KL slot and the refreshed dataset mu / sigma."""
+    import ctypes
+    from vine_robot_isaacgymenvs_amd.abi import PPO_LOSS_SCRATCH_FLOATS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    n, H, A = 4096, 256, 2
+    NH = A + 1
+    lib = fused._lib()
+    x = torch.randn(n, H, device=dev) * 1.5 + 0.3
+    gamma, beta = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+    w, wb = torch.randn(NH, H, device=dev) * 0.05, torch.randn(NH, device=dev) * 0.1
+    logstd = torch.tensor([-0.3, 0.2], device=dev)
+    actions = torch.randn(n, A, device=dev)
+    old_mu, old_sigma = torch.randn(n, A, device=dev) * 0.5, torch.rand(n, A, device=dev) * 0.5 + 0.5
+    old_nlp = (0.5 * (((actions - old_mu) / old_sigma) ** 2).sum(-1) + 0.9189385 * A + old_sigma.log().sum(-1))
+    adv, old_values, returns = torch.randn(n, device=dev), torch.randn(n, device=dev), torch.randn(n, device=dev)
+    scal = (0.2, int(clip_value), 2.0, 0.01, 0.0001, 1.1)
+    R = lib.vine_ln_heads_loss_rows()
+    heads, dx = torch.empty(n, NH, device=dev), torch.empty(n, H, device=dev)
+    part = torch.empty(n // R, (2 + NH) * H, device=dev)
+    stats, gls = torch.empty(8, device=dev), torch.empty(A, device=dev)
+    gmb, gvb = torch.zeros(A, device=dev), torch.zeros(1, device=dev)
+    scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=dev)
+    kl_out, gls_acc = torch.zeros(1, device=dev), torch.zeros(A, device=dev)
+    mu_st, sg_st = torch.empty(n, A, device=dev), torch.empty(n, A, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):          # twice: the workgroup ticket must be back at zero after a launch
+        gmb.zero_(); gvb.zero_(); gls_acc.zero_()
+        rc = lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
+                                    logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
+                                    old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
+                                    heads.data_ptr(), dx.data_ptr(), part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
+                                    gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
+                                    mu_st.data_ptr(), sg_st.data_ptr(), st)
+        assert rc == 0
+    torch.cuda.synchronize()
+    # float64 reference
+    xd = x.double().requires_grad_(True)
+    gd, bd, wd, wbd, lsd = (t.double().requires_grad_(True) for t in (gamma, beta, w, wb, logstd))
+    y = torch.nn.functional.layer_norm(xd, (H,), gd, bd, 1e-5)
+    hd = y @ wd.t() + wbd
+    loss, ref = fused.ppo_loss_reference(hd[:, :A], lsd, hd[:, A:], actions.double(), old_nlp.double(), adv.double(),
+                                         old_values.double(), returns.double(), old_mu.double(), old_sigma.double(),
+                                         scal[0], bool(scal[1]), scal[2], scal[3], scal[4], scal[5])
+    loss.backward()
+    rel = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(heads, hd.detach()) < 1e-5
+    assert rel(dx, xd.grad) < 2e-4
+    sums = part.double().sum(0)
+    assert rel(sums[:H], gd.grad) < 2e-4 and rel(sums[H:2 * H], bd.grad) < 2e-4
+    assert rel(sums[2 * H:].view(NH, H), wd.grad) < 2e-4
+    assert rel(torch.cat([gmb, gvb]), wbd.grad) < 2e-4
+    assert rel(gls, lsd.grad) < 2e-4 and rel(gls_acc, lsd.grad) < 2e-4
+    for k_, name in enumerate(("a_loss", "c_loss", "b_loss", "entropy", "kl", "loss")):
+        assert abs(float(stats[k_]) - float(ref[name])) < 2e-5 * max(1.0, abs(float(ref[name]))), name
+    assert abs(float(kl_out) - float(ref["kl"])) < 2e-5
+    assert rel(mu_st, hd.detach()[:, :A]) < 1e-5 and rel(sg_st, lsd.detach().exp().expand(n, A)) < 1e-6
+    # shapes outside the family are refused
+    assert lib.vine_ln_heads_loss(n + 8, H, NH, *([x.data_ptr()] * 3), 1e-5, *([x.data_ptr()] * 10), *scal,
+                                  *([x.data_ptr()] * 12), st) == -2
+
+
+@pytest.mark.gpu
 def test_ppo_loss_kernel_against_reference_text_golden():
     """Golden F8 through the HIP loss kernel: the means of the actor, clipped-critic and bound (soft bound 1.0) terms the
     reference's in-tree text computes per sample (isaacgymenvs/learning/common_agent.py:482-516, 427-435)."""

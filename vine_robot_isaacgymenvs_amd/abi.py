@@ -192,6 +192,10 @@ PPO_PROTOTYPES = {
     "vine_weight_grad_mfma": (C.c_int, [_I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _VP]),
     "vine_mlp3_elu_mfma": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I64, _VP, _I64, _VP,
                                      _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _VP, _VP, _I64, _VP]),
+    "vine_ln_heads_loss": (C.c_int, [_I64, _I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                     _VP, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP, _VP,
+                                     _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_ln_heads_loss_rows": (C.c_int, []),
     "vine_mlp3_bwd_elu_mfma": (C.c_int, [_I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _I64,
                                          _I64, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_weight_grad_group": (C.c_int, [C.c_int32] + [_VP] * 16 + [_VP]),

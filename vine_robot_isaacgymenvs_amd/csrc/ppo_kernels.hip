@@ -2649,20 +2649,32 @@ __device__ __forceinline__ void ppo_loss_finalize(int blocks, int A, long long n
                                                   float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
                                                   float* __restrict__ grad_value_bias, float* __restrict__ kl_out,
                                                   float* __restrict__ logstd_grad_accum) {
+    // (called by whole workgroups of 256 or 512 threads: the first 256 do the work, all take part in the barriers)
     const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
-    float acc = 0.0f;
-    int b = rl;
-    for (; b + 56 < blocks; b += 64) {                      // 8 rows in flight per thread, same order as one at a time
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = partial[(long long)(b + 8 * k) * PPO_LOSS_ROW + q];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc += v[k];
-    }
-    for (; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
     __shared__ float fred[8][PPO_LOSS_ROW];
     __shared__ float tot[PPO_LOSS_ROW];
-    fred[rl][q] = acc;
+    if (threadIdx.x < 256) {
+        // this is the serial tail of the launch (one workgroup, every load an L2 round trip): 16 rows in flight per
+        // thread, added in the order of one at a time
+        float acc = 0.0f;
+        int b = rl;
+        for (; b + 120 < blocks; b += 128) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = partial[(long long)(b + 8 * k) * PPO_LOSS_ROW + q];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += v[k];
+        }
+        for (; b + 24 < blocks; b += 32) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = partial[(long long)(b + 8 * k) * PPO_LOSS_ROW + q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += v[k];
+        }
+        for (; b < blocks; b += 8) acc += partial[(long long)b * PPO_LOSS_ROW + q];
+        fred[rl][q] = acc;
+    }
     __syncthreads();
     if (rl == 0) {
         float v = 0.0f;
@@ -2820,6 +2832,287 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
         __threadfence();
         ppo_loss_finalize((int)gridDim.x, A, n, partial, logstd, critic_coef, entropy_coef, bounds_coef, stats, grad_logstd,
                           grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
+    }
+}
+
+// ---- LayerNorm + heads + PPO loss + their backward in ONE kernel (H = 256): ln_heads_fwd_kernel, ppo_loss_kernel and
+// ln_heads_bwd_kernel were three nodes of the update graph (12 + 13 + 15 us) passing [n, NH] head values and gradients
+// and re-reading the LSTM output.  The loss is a sum over samples, so its gradient w.r.t. a row's heads depends on that
+// row alone: a wave takes 16 rows through all three steps with the rows held in registers.
+//   phase 1 (row at a time, 64 lanes x float4): LayerNorm statistics and the NH head dot products; lane rr keeps row rr's
+//   phase 2 (lanes 0..15, one row each): the loss terms and d loss / d heads exactly as ppo_loss_kernel computes them,
+//            mu / sigma refresh of the dataset, heads written out for the caller;
+//   phase 3 (row at a time): d heads -> d LN output -> LayerNorm backward -> dx, with the partial sums of d gamma,
+//            d beta, d W accumulated per lane.
+// Per-workgroup rows of partial sums (LayerNorm / head parameters: ln_partial; loss statistics: loss_partial) are
+// folded by the column-sum kernel and, for the loss, by the last workgroup to finish (ppo_loss_finalize): fixed order,
+// no atomics on floats.  Workgroup = 8 waves x 16 rows.
+// sum over the 16 lanes of a DPP row, result in EVERY lane of the row: four rotate-and-add steps
+__device__ __forceinline__ float row_allsum16(float v) {
+    v += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x128, 0xf, 0xf, true));      // row_ror:8
+    v += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x124, 0xf, 0xf, true));      // row_ror:4
+    v += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x122, 0xf, 0xf, true));      // row_ror:2
+    v += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x121, 0xf, 0xf, true));      // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {
+    return dpp_i2f(__builtin_amdgcn_ds_bpermute(src_lane << 2, dpp_f2i(v)));
+}
+
+// Lane mapping: SIXTEEN lanes per row (a wave works on 4 rows at a time; lane = 16 sub + cl holds the float4 columns
+// cl + 16 j, j = 0..3, of row `sub`), so that a LayerNorm / head reduction is four DPP rotate-adds inside a 16-lane row
+// instead of a wave-wide sum (9 DPP steps + a readlane, one row at a time: that version took 39 us).  NP passes of 4
+// rows per wave; the rows are re-read in phase 3 (L2 hits) rather than kept in 64 registers.
+template <int NH, int NP>
+__global__ __launch_bounds__(512) void ln_heads_loss_kernel(
+    long long n, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const float* __restrict__ w, const float* __restrict__ wb, const float* __restrict__ logstd,
+    const float* __restrict__ actions, const float* __restrict__ old_neglogp, const float* __restrict__ adv,
+    const float* __restrict__ old_values, const float* __restrict__ returns, const float* old_mu, const float* old_sigma,
+    float e_clip, int clip_value, float critic_coef, float entropy_coef, float bounds_coef, float soft_bound,
+    float* __restrict__ heads, float* __restrict__ dx, float* __restrict__ ln_partial, float* loss_partial,
+    float* __restrict__ stats, float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
+    float* __restrict__ grad_value_bias, float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum, float* mu_store,
+    float* sigma_store) {
+    constexpr int H = 256, A = NH - 1, NWV = 8, W = (2 + NH) * H, RW = 4 * NP;
+    constexpr int NRED = 5 + 2 * PPO_MAX_A + 1;
+    __shared__ float red[NWV][W];
+    __shared__ float lred[NWV][PPO_LOSS_ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, cl = lane & 15;
+    const long long r0 = ((long long)blockIdx.x * NWV + wave) * RW;
+    float gm[4][4], bt[4][4], wv[NH][4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 g4 = ld4(gamma + 4 * (cl + 16 * j)), b4 = ld4(beta + 4 * (cl + 16 * j));
+        gm[j][0] = g4.x; gm[j][1] = g4.y; gm[j][2] = g4.z; gm[j][3] = g4.w;
+        bt[j][0] = b4.x; bt[j][1] = b4.y; bt[j][2] = b4.z; bt[j][3] = b4.w;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float4 t = ld4(w + h * H + 4 * (cl + 16 * j));
+            wv[h][j][0] = t.x; wv[h][j][1] = t.y; wv[h][j][2] = t.z; wv[h][j][3] = t.w;
+        }
+    }
+    // ---- phase 1: LayerNorm statistics and heads of 4 rows per pass; lane (sub, cl = p) keeps row 4 p + sub
+    float myp[NH], mymean = 0.0f, myrstd = 0.0f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) myp[h] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const float* xr = x + (r0 + 4 * p + sub) * H;
+        float xa[4][4];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = ld4(xr + 4 * (cl + 16 * j));
+            xa[j][0] = v.x; xa[j][1] = v.y; xa[j][2] = v.z; xa[j][3] = v.w;
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        const float mean = row_allsum16(s) * (1.0f / H);
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xa[j][u] -= mean;
+                q += xa[j][u] * xa[j][u];
+            }
+        const float rstd = rsqrtf(row_allsum16(q) * (1.0f / H) + eps);
+        float ph[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) ph[h] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float y = xa[j][u] * rstd * gm[j][u] + bt[j][u];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) ph[h] += y * wv[h][j][u];
+            }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float t = row_allsum16(ph[h]) + wb[h];
+            if (cl == p) myp[h] = t;
+        }
+        if (cl == p) { mymean = mean; myrstd = rstd; }
+    }
+    // ---- phase 2: lanes with cl < NP hold one row each (row 4 cl + sub): ppo_loss_kernel's arithmetic
+    float gh[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) gh[h] = 0.0f;
+    float vals[NRED];
+#pragma unroll
+    for (int qq = 0; qq < NRED; ++qq) vals[qq] = 0.0f;
+    if (cl < NP) {
+        const long long i = r0 + 4 * cl + sub;
+        const float inv_n = 1.0f / (float)n;
+        float nlp = 0.9189385332046727f * A;
+        float sg[A], isg2[A], z2[A], dm[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float l = logstd[k];
+            sg[k] = __expf(l);
+            isg2[k] = 1.0f / (sg[k] * sg[k]);
+            nlp += l;
+        }
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            dm[k] = actions[i * A + k] - myp[k];
+            z2[k] = dm[k] * dm[k] * isg2[k];
+            nlp += 0.5f * z2[k];
+        }
+        const float a = adv[i];
+        const float ratio = __expf(old_neglogp[i] - nlp);
+        const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
+        const float s1 = -a * ratio, s2 = -a * rc;
+        const bool first = s1 >= s2;                     // torch.max sends the tie's gradient to the first operand
+        const float a_loss = first ? s1 : s2;
+        const float inside = (ratio > 1.0f - e_clip && ratio < 1.0f + e_clip) ? 1.0f : 0.0f;
+        const float dL_dratio = first ? -a : -a * inside;
+        const float dL_dnlp = -ratio * dL_dratio * inv_n;
+        const float v = myp[A], vp = old_values[i], R = returns[i];
+        float c_loss, dL_dv;
+        if (clip_value) {
+            const float dv = v - vp;
+            const float vc = vp + fminf(fmaxf(dv, -e_clip), e_clip);
+            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            if (l1 >= l2) { c_loss = l1; dL_dv = 2.0f * (v - R); }
+            else { c_loss = l2; dL_dv = (dv > -e_clip && dv < e_clip) ? 2.0f * (vc - R) : 0.0f; }
+        } else {
+            c_loss = (R - v) * (R - v);
+            dL_dv = 2.0f * (v - R);
+        }
+        const float gval = 0.5f * critic_coef * dL_dv * inv_n;
+        gh[A] = gval;
+        vals[5 + 2 * PPO_MAX_A] = gval;
+        float b_loss = 0.0f, kl = 0.0f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float m = myp[k];
+            const float hi = fmaxf(m - soft_bound, 0.0f), lo = fminf(m + soft_bound, 0.0f);
+            b_loss += hi * hi + lo * lo;
+            const float gmk = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
+            gh[k] = gmk;
+            vals[5 + PPO_MAX_A + k] = gmk;
+            vals[5 + k] = dL_dnlp * (1.0f - z2[k]);
+            const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
+            const float c1 = __logf(os / sg[k] + 1e-5f);
+            const float c2 = (sg[k] * sg[k] + (om - m) * (om - m)) / (2.0f * (os * os + 1e-5f));
+            kl += c1 + c2 - 0.5f;
+            if (mu_store) {      // dataset.update_mu_sigma: may alias old_mu / old_sigma (read above by this lane)
+                mu_store[i * A + k] = m;
+                sigma_store[i * A + k] = sg[k];
+            }
+        }
+        vals[0] = a_loss; vals[1] = c_loss; vals[2] = b_loss; vals[3] = kl;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) heads[i * NH + h] = myp[h];
+    }
+    // the wave's rows added (inactive lanes hold zeros), one row of partial sums per wave
+#pragma unroll
+    for (int qq = 0; qq < NRED; ++qq) {
+        const bool live = qq < 4 || (qq >= 5 && qq < 5 + A) || (qq >= 5 + PPO_MAX_A && qq < 5 + PPO_MAX_A + A) ||
+                          qq == 5 + 2 * PPO_MAX_A;
+        const float t = live ? wave_sum(vals[qq]) : 0.0f;
+        if (lane == 0) lred[wave][qq] = t;
+    }
+    if (lane >= NRED && lane < PPO_LOSS_ROW) lred[wave][lane] = 0.0f;
+    // ---- phase 3: d heads -> d LN output -> LayerNorm backward -> dx; parameter partial sums per lane
+    float dgm[4][4], dbt[4][4], dw[NH][4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dgm[j][u] = 0.0f; dbt[j][u] = 0.0f;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) dw[h][j][u] = 0.0f;
+        }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int src = (lane & 48) | p;                        // the lane of this row that holds pass p's values
+        float ghr[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) ghr[h] = lane_bcast(gh[h], src);
+        const float mean = lane_bcast(mymean, src), rstd = lane_bcast(myrstd, src);
+        const long long r = r0 + 4 * p + sub;
+        float xh[4][4], gg[4][4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = ld4(x + r * H + 4 * (cl + 16 * j));
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xh[j][u] = (xv[u] - mean) * rstd;
+                float dy = 0.0f;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) dy += ghr[h] * wv[h][j][u];
+                const float y = xh[j][u] * gm[j][u] + bt[j][u];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) dw[h][j][u] += ghr[h] * y;
+                gg[j][u] = dy * gm[j][u];
+                s1 += gg[j][u];
+                s2 += gg[j][u] * xh[j][u];
+                dgm[j][u] += dy * xh[j][u];
+                dbt[j][u] += dy;
+            }
+        }
+        const float m1 = row_allsum16(s1) * (1.0f / H), m2 = row_allsum16(s2) * (1.0f / H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            st4(dx + r * H + 4 * (cl + 16 * j),
+                make_float4(rstd * (gg[j][0] - m1 - xh[j][0] * m2), rstd * (gg[j][1] - m1 - xh[j][1] * m2),
+                            rstd * (gg[j][2] - m1 - xh[j][2] * m2), rstd * (gg[j][3] - m1 - xh[j][3] * m2)));
+    }
+    // the four 16-lane rows of the wave hold sums for the same columns: add them (lane l <- l ^ 16, l ^ 32), then one
+    // row of W sums per wave in LDS, added over the waves in wave order
+#define LHL_FOLD(v) { v += lane_bcast(v, lane ^ 16); v += lane_bcast(v, lane ^ 32); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            LHL_FOLD(dgm[j][u]) LHL_FOLD(dbt[j][u])
+#pragma unroll
+            for (int h = 0; h < NH; ++h) LHL_FOLD(dw[h][j][u])
+        }
+#undef LHL_FOLD
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = 4 * (cl + 16 * j) + u;
+                red[wave][c] = dgm[j][u];
+                red[wave][H + c] = dbt[j][u];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) red[wave][(2 + h) * H + c] = dw[h][j][u];
+            }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < W; c += 512) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int wq = 0; wq < NWV; ++wq) sum += red[wq][c];
+        ln_partial[(long long)blockIdx.x * W + c] = sum;
+    }
+    if (threadIdx.x < PPO_LOSS_ROW) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int wq = 0; wq < NWV; ++wq) sum += lred[wq][threadIdx.x];
+        loss_partial[(long long)blockIdx.x * PPO_LOSS_ROW + threadIdx.x] = sum;
+        __threadfence();
+    }
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(&g_ppo_loss_ticket, 1u);
+        is_last = t == gridDim.x - 1;
+        if (is_last) g_ppo_loss_ticket = 0;
+    }
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        ppo_loss_finalize((int)gridDim.x, A, n, loss_partial, logstd, critic_coef, entropy_coef, bounds_coef, stats,
+                          grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
     }
 }
 
@@ -3727,6 +4020,57 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                        (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1),
                        scratch, mu_store, sigma_store, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const float* gamma, const float* beta, float eps,
+                       const float* w, const float* wb, const float* logstd, const float* actions, const float* old_neglogp,
+                       const float* advantages, const float* old_values, const float* returns, const float* old_mu,
+                       const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
+                       float bounds_coef, float soft_bound, float* heads, float* dx, float* ln_partial, float* stats,
+                       float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch, float* kl_out,
+                       float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream) {
+    if (n <= 0 || !x || !gamma || !beta || !w || !wb || !logstd || !actions || !old_neglogp || !advantages || !old_values ||
+        !returns || !old_mu || !old_sigma || !heads || !dx || !ln_partial || !stats || !grad_logstd || !scratch ||
+        ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || ((mu_store == nullptr) != (sigma_store == nullptr)))
+        return VINE_ERR_INVALID_ARG;
+    // rows per wave (4 per pass): 16 keeps the workgroup count -- and with it the serial tail of the last workgroup,
+    // which folds one row of loss sums per workgroup -- small (VINE_LHL_ROWS = 4 | 8 | 16 for experiments)
+    static int rw = 0;
+    if (!rw) {
+        const char* e = getenv("VINE_LHL_ROWS");
+        rw = e ? atoi(e) : 16;
+        if (rw != 4 && rw != 8 && rw != 16) rw = 16;
+    }
+    const int rows_wg = 8 * rw;
+    if (H != 256 || NH < 2 || NH > 5 || n % rows_wg || n / rows_wg > VINE_PPO_LOSS_BLOCKS) return VINE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(n / rows_wg)), block(512);
+    hipStream_t s = (hipStream_t)stream;
+#define VINE_LHL(K, R)                                                                                                    \
+    hipLaunchKernelGGL((ln_heads_loss_kernel<K, R>), grid, block, 0, s, (long long)n, x, gamma, beta, eps, w, wb, logstd,  \
+                       actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,  \
+                       critic_coef, entropy_coef, bounds_coef, soft_bound, heads, dx, ln_partial, scratch, stats,          \
+                       grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store, sigma_store)
+#define VINE_LHL_R(K)                                                                                                     \
+    do {                                                                                                                  \
+        if (rw == 4) VINE_LHL(K, 1);                                                                                      \
+        else if (rw == 8) VINE_LHL(K, 2);                                                                                 \
+        else VINE_LHL(K, 4);                                                                                              \
+    } while (0)
+    switch (NH) {
+        case 2: VINE_LHL_R(2); break;
+        case 3: VINE_LHL_R(3); break;
+        case 4: VINE_LHL_R(4); break;
+        default: VINE_LHL_R(5); break;
+    }
+#undef VINE_LHL_R
+#undef VINE_LHL
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_ln_heads_loss_rows(void) {
+    const char* e = getenv("VINE_LHL_ROWS");
+    const int rw = e ? atoi(e) : 16;
+    return 8 * ((rw == 8 || rw == 4) ? rw : 16);
 }
 
 int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,

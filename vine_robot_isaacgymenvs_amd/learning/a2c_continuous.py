@@ -784,7 +784,18 @@ class A2CAgent:
         batch_dict = {"obs": mb["obs"] if obs_n is None else obs_n, "obs_is_normalized": obs_n is not None,
                       "rnn_states": mb["rnn_states"], "seq_length": self.seq_len, "dones": mb["dones"],
                       "head_bias_external": ext}
+        pack = None
+        if ext and fused.HEADS_LOSS and self.fused_mixed:
+            # LayerNorm + heads + loss + their backward inside the trunk node (one launch instead of three)
+            pack = fused.ppo_loss_pack(net.sigma, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"],
+                                       mb["returns"], mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef,
+                                       self.entropy_coef, self.bounds_loss_coef or 0.0, hb, kl_out=self.optimizer.aux[0:1],
+                                       logstd_grad=net.sigma.grad, update_old=True, stats_out=stats_out)
+            batch_dict["loss_pack"] = pack
         mu, value, logstd, _, heads = self.model.forward_raw(batch_dict)
+        if pack is not None and heads is not None and heads.grad_fn is not None and getattr(heads.grad_fn, "loss_fused", None):
+            torch.autograd.backward([heads], [heads.detach()])      # the gradient handed over is ignored by the node
+            return pack["stats"], mu.detach(), logstd.detach()
         g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(
             mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
             mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef, self.entropy_coef,

@@ -143,6 +143,7 @@ def weight_grad(dy, x, out=None, batch=None):
     return column_sums(part, out, batch=batch)
 
 
+HEADS_LOSS = _os.environ.get("VINE_HEADS_LOSS", "1") != "0"    # LayerNorm + heads + loss + backward in one launch (A/B knob)
 MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
@@ -676,7 +677,7 @@ class _Trunk(torch.autograd.Function):
     (W_1, b_1, ..., W_L, b_L, w_ih, w_hh, b_ih, b_hh, ln_gamma, ln_beta, ln_eps, mu_w, mu_b, v_w, v_b)."""
 
     @staticmethod
-    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, op_weights, head_bias_external, norm, *params):
+    def forward(ctx, obs_n, h0, c0, dones, T, concat, n_mlp, op_weights, head_bias_external, norm, loss_pack, *params):
         lib = _lib()
         mlp = [(params[2 * i], params[2 * i + 1]) for i in range(n_mlp)]
         w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, ln_eps, mu_w, mu_b, v_w, v_b = params[2 * n_mlp:]
@@ -836,7 +837,26 @@ class _Trunk(torch.autograd.Function):
         rstd = torch.empty(n, device=dev, dtype=torch.float32)
         NH = w_heads.shape[0]
         fuse_heads = H == 256 and 2 <= NH <= 5
-        if fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
+        ctx.loss_fused = None
+        lhl_rows = lib.vine_ln_heads_loss_rows()
+        if (fuse_heads and loss_pack is not None and HEADS_LOSS and n % lhl_rows == 0 and n // lhl_rows <= 1024
+                and head_bias_external):
+            # LayerNorm + heads + PPO loss + their backward in ONE launch: the gradient w.r.t. the LSTM output is
+            # known before this node's backward runs (which ignores the gradient it is handed for `heads`)
+            y = out.new_empty(0)
+            heads = torch.empty((n, NH), device=dev, dtype=torch.float32)
+            d_out = torch.empty_like(out)
+            ln_part = torch.empty((n // lhl_rows, (2 + NH) * H), device=dev, dtype=torch.float32)
+            lp = loss_pack
+            _check(lib.vine_ln_heads_loss(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
+                                          w_heads.data_ptr(), b_heads.data_ptr(), lp["logstd"].data_ptr(),
+                                          *[t.data_ptr() for t in lp["args"]], *lp["scal"], heads.data_ptr(),
+                                          d_out.data_ptr(), ln_part.data_ptr(), lp["stats"].data_ptr(),
+                                          lp["grad_logstd"].data_ptr(), lp["head_bias_grads"][0].data_ptr(),
+                                          lp["head_bias_grads"][1].data_ptr(), lp["scratch"].data_ptr(), *lp["extra"], st),
+                   "vine_ln_heads_loss")
+            ctx.loss_fused = (d_out, ln_part)
+        elif fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
             y = out.new_empty(0)
             heads = torch.empty((n, NH), device=dev, dtype=torch.float32)
             _check(lib.vine_layernorm_heads_forward(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),
@@ -894,20 +914,28 @@ class _Trunk(torch.autograd.Function):
         base = 2 * n_mlp
         # with the optimiser's gradient slots in place all column sums are deferred into one launch at the end
         batch = ColumnSumBatch() if all(sl is not None for k, sl in enumerate(slots) if ctx.pshapes[k] is not None) else None
-        g_heads = g_heads.contiguous()
         NH = w_heads.shape[0]
-        d_out = torch.empty_like(out)
-        if not head_bias_external:      # else: the loss kernel has already added them into the two bias gradients
+        if ctx.loss_fused is not None:
+            d_out, part = ctx.loss_fused             # computed in forward by the fused LayerNorm + heads + loss kernel
+            ctx.loss_fused = None
+        else:
+            g_heads = g_heads.contiguous()
+            d_out = torch.empty_like(out)
+            part = None
+        if part is not None:
+            pass
+        elif not head_bias_external:      # else: the loss kernel has already added them into the two bias gradients
             gb = g_heads.sum(0)
             deliver(base + 8, lambda o: o.copy_(gb[:A]))
             deliver(base + 10, lambda o: o.copy_(gb[A:]))
         if ctx.fuse_heads:
             # ---- heads + LayerNorm in one kernel: dy = g W is never stored; partial sums of {d gamma | d beta | d W}
-            part = torch.empty((PPO_PARTIAL_BLOCKS, (2 + NH) * H), device=dev, dtype=torch.float32)
-            _check(lib.vine_layernorm_heads_backward(n, H, NH, g_heads.data_ptr(), out.data_ptr(), mean.data_ptr(),
-                                                     rstd.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),
-                                                     w_heads.data_ptr(), d_out.data_ptr(), part.data_ptr(), st),
-                   "vine_layernorm_heads_backward")
+            if part is None:
+                part = torch.empty((PPO_PARTIAL_BLOCKS, (2 + NH) * H), device=dev, dtype=torch.float32)
+                _check(lib.vine_layernorm_heads_backward(n, H, NH, g_heads.data_ptr(), out.data_ptr(), mean.data_ptr(),
+                                                         rstd.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),
+                                                         w_heads.data_ptr(), d_out.data_ptr(), part.data_ptr(), st),
+                       "vine_layernorm_heads_backward")
             ln_part, w_part = part[:, :2 * H], part[:, 2 * H:]
             if slots[base + 7] is not None and slots[base + 9] is not None:
                 column_sums(w_part, slots[base + 7], out1=slots[base + 9], n0=A * H, batch=batch)
@@ -1018,7 +1046,7 @@ class _Trunk(torch.autograd.Function):
         wgroup.flush()                      # the MLP weight gradients: one launch, all operands exist by now
         if batch is not None:
             batch.flush(out)
-        return (None, None, None, None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def linear_elu_mfma_ok(n, N, K):
@@ -1039,7 +1067,7 @@ def trunk_supported(obs_n, mlp_units, activation_is_elu, H, has_ln, T):
 
 
 def trunk(obs_n, h0, c0, dones, T, concat, mlp_params, lstm_params, ln, heads, op_weights=None,
-          head_bias_external=False, norm=None):
+          head_bias_external=False, norm=None, loss_pack=None):
     """-> (heads [n, A+1] = [mu | value], hT, cT).  ``mlp_params`` = [(W, b), ...]; ``lstm_params`` =
     (w_ih, w_hh, b_ih, b_hh); ``ln`` = (gamma, beta, eps); ``heads`` = (mu_w, mu_b, value_w, value_b).
     ``op_weights`` = bfloat16 copies of (W_1, ..., W_L, w_ih, w_hh) selects the mixed-precision update: those GEMMs
@@ -1048,13 +1076,16 @@ def trunk(obs_n, h0, c0, dones, T, concat, mlp_params, lstm_params, ln, heads, o
     ``head_bias_external``: the caller obtains the two head-bias gradients elsewhere (the PPO loss kernel adds them to
     the parameters' gradient slots), so the backward skips that column sum over all n rows.
     ``norm`` = (running mean, running var, eps) of the observation normaliser: ``obs_n`` then holds the RAW observations
-    and the trunk normalises them itself (inside the one-launch MLP kernel where that applies)."""
+    and the trunk normalises them itself (inside the one-launch MLP kernel where that applies).
+    ``loss_pack`` (``ppo_loss_pack``): the PPO loss and its gradient are computed inside the node (one launch for
+    LayerNorm + heads + loss + their backward); ``heads`` is still returned, the statistics land in the pack's tensors,
+    and ``torch.autograd.backward([heads], [anything of the same shape])`` runs the rest of the backward pass."""
     if dones is not None:
         dones = dones.to(torch.uint8).contiguous()
     flat = [p for wb in mlp_params for p in wb]
     return _Trunk.apply(obs_n, h0.contiguous(), c0.contiguous(), dones, T, bool(concat), len(mlp_params),
                         tuple(op_weights) if op_weights is not None else None, bool(head_bias_external),
-                        tuple(norm) if norm is not None else None, *flat,
+                        tuple(norm) if norm is not None else None, loss_pack, *flat,
                         *lstm_params, ln[0], ln[1], float(ln[2]), *heads)
 
 
@@ -1084,6 +1115,33 @@ def ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values,
         kl = (c1 + c2 - 0.5).sum(-1).mean()
     return loss, {"a_loss": a_loss.detach(), "c_loss": c_loss.detach(), "b_loss": b_loss.detach(),
                   "entropy": entropy.detach(), "kl": kl, "loss": loss.detach()}
+
+
+def ppo_loss_pack(logstd, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip, clip_value,
+                  critic_coef, entropy_coef, bounds_coef, head_bias_grads, soft_bound=1.1, kl_out=None, logstd_grad=None,
+                  update_old=False, stats_out=None):
+    """Arguments of the PPO loss for the trunk's one-launch LayerNorm + heads + loss kernel (``trunk(loss_pack=...)``):
+    same meaning as ``ppo_loss_fused``; ``pack["stats"]`` / ``pack["grad_logstd"]`` receive the results."""
+    from ..abi import PPO_LOSS_SCRATCH_FLOATS
+    dev = logstd.device
+    args = [t.detach().contiguous() for t in (actions, old_neglogp, adv, old_values.reshape(-1), returns.reshape(-1),
+                                              old_mu, old_sigma)]
+    if update_old:
+        assert args[5].data_ptr() == old_mu.data_ptr() and args[6].data_ptr() == old_sigma.data_ptr(), \
+            "update_old needs contiguous old_mu / old_sigma (they are written in place)"
+    ls = logstd.detach().contiguous()
+    stats = stats_out if stats_out is not None else torch.empty(8, device=dev, dtype=torch.float32)
+    assert stats.is_contiguous() and stats.numel() == 8 and stats.dtype == torch.float32
+    return {"logstd": ls, "args": args,
+            "scal": (float(e_clip), int(bool(clip_value)), float(critic_coef), float(entropy_coef), float(bounds_coef),
+                     float(soft_bound)),
+            "stats": stats, "grad_logstd": torch.empty(ls.shape[0], device=dev, dtype=torch.float32),
+            "head_bias_grads": head_bias_grads,
+            "scratch": torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=dev, dtype=torch.float32),
+            "extra": (kl_out.data_ptr() if kl_out is not None else None,
+                      logstd_grad.data_ptr() if logstd_grad is not None else None,
+                      args[5].data_ptr() if update_old else None, args[6].data_ptr() if update_old else None),
+            "keep": (kl_out, logstd_grad)}
 
 
 def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip,

@@ -111,7 +111,7 @@ class A2CNetwork(nn.Module):
         z = torch.zeros((1, batch, self.rnn_units), device=device)
         return (z, z.clone())
 
-    def forward_heads(self, obs, states, seq_length, dones, head_bias_external=False, norm=None):
+    def forward_heads(self, obs, states, seq_length, dones, head_bias_external=False, norm=None, loss_pack=None):
         """Training forward on the MI355X as one fused autograd node (learning/fused.py:_Trunk):
         -> (heads [n, A+1] = [mu | value], states).  Caller checks ``fused.trunk_supported`` first."""
         r = self.rnn.rnn
@@ -124,7 +124,8 @@ class A2CNetwork(nn.Module):
                                   (r.weight_ih_l0, r.weight_hh_l0, r.bias_ih_l0, r.bias_hh_l0),
                                   (self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
                                   (self.mu.weight, self.mu.bias, self.value.weight, self.value.bias),
-                                  op_weights=op_weights, head_bias_external=head_bias_external, norm=norm)
+                                  op_weights=op_weights, head_bias_external=head_bias_external, norm=norm,
+                                  loss_pack=loss_pack)
         return heads, (h.unsqueeze(0), c.unsqueeze(0))
 
     def trunk_supported(self, obs, seq_length):
@@ -193,7 +194,8 @@ class ModelA2CContinuousLogStd(nn.Module):
             obs = raw if input_dict.get("obs_is_normalized", False) else self.norm_obs(raw)
         if net.trunk_supported(obs, T):
             heads, states = net.forward_heads(obs, input_dict["rnn_states"], T, input_dict.get("dones", None),
-                                              input_dict.get("head_bias_external", False), norm=norm)
+                                              input_dict.get("head_bias_external", False), norm=norm,
+                                              loss_pack=input_dict.get("loss_pack"))
             A = net.mu.weight.shape[0]
             return heads[:, :A], heads[:, A:], net.sigma, states, heads
         mu, _logstd, value, states = net(obs, input_dict["rnn_states"], T, input_dict.get("dones", None))
