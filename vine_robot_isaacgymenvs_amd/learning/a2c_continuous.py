@@ -535,6 +535,13 @@ class A2CAgent:
         fast = getattr(self, "_fast", None) is not None
         if fast:
             self._infer_begin()
+        # the env writes the next observation, and the post-step kernel the next done flags, straight into the rollout
+        # buffers (30 small copy nodes fewer per iteration) when the task offers step_into on this device
+        direct = (hasattr(env, "step_into") and buf["obses"].dtype == torch.float32 and buf["obses"][0].is_contiguous()
+                  and buf["dones"].dtype == torch.uint8 and self.dones.dtype == torch.uint8
+                  and buf["obses"].device == env.rew_buf.device and tuple(buf["obses"].shape[1:]) == tuple(obs.shape))
+        if direct and getattr(self, "_obs_last", None) is None:
+            self._obs_last = torch.empty_like(obs)
         h_op_stride = self._fast["XW"] + H if fast else 0
         h_op_bf16 = int(fast and self._fast["op"] == torch.bfloat16)
         for n in range(self.horizon_length):
@@ -546,17 +553,26 @@ class A2CAgent:
             else:
                 y, states = trunk(obs)
                 self.rnn_states = [states[0].contiguous(), states[1].contiguous()]
-            buf["obses"][n].copy_(obs)
-            buf["dones"][n].copy_(self.dones)
+            if not direct or n == 0:      # (direct: the env and the post-step kernel wrote slot n themselves, one step ago)
+                buf["obses"][n].copy_(obs)
+                buf["dones"][n].copy_(self.dones)
             head(y, n, buf["values"][n], buf["mus"][n], buf["sigmas"][n], buf["actions"][n], buf["neglogpacs"][n])
             # the env kernel clamps to +-clipActions itself (vec_task.py:333); with the [-1, 1] action space
             # rl_games' preprocess_actions (clamp + affine rescale) is the identity on top of that
-            obs_d, rewards, dones, infos = self.vec_env.step(buf["actions"][n])
-            obs = obs_d["obs"]
+            last = n + 1 == self.horizon_length
+            if direct:
+                # next observation and next done flags straight into their rollout-buffer slots (the last ones into
+                # the tensors the next iteration starts from)
+                obs = env.step_into(buf["actions"][n], self._obs_last if last else buf["obses"][n + 1])
+                dones_dst = self.dones if last else buf["dones"][n + 1]
+            else:
+                obs_d, rewards, dones, infos = self.vec_env.step(buf["actions"][n])
+                obs = obs_d["obs"]
+                dones_dst = self.dones
             fused._check(lib.vine_rollout_post(
                 N, H, env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), env.timeout_buf.data_ptr(),
                 buf["values"][n].data_ptr(), float(self.reward_shift), float(self.reward_scale), gamma_b,
-                buf["rewards"][n].data_ptr(), self.dones.data_ptr(), self.current_rewards.data_ptr(),
+                buf["rewards"][n].data_ptr(), dones_dst.data_ptr(), self.current_rewards.data_ptr(),
                 self.current_lengths.data_ptr(), self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr(),
                 self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(),
                 # the operand copy of h that the NEXT step reads (the buffer _infer just switched to)

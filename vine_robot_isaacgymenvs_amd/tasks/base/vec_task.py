@@ -147,6 +147,19 @@ class VecTask(Env):
             self.obs_dict["states"] = self.get_state()
         return self.obs_dict, self.rew_buf.to(self.rl_device), self.reset_buf.to(self.rl_device), self.extras
 
+    def step_into(self, actions: torch.Tensor, obs_out: torch.Tensor):
+        """``step`` with the observation written straight into the caller's buffer (e.g. the next slot of a rollout
+        buffer: saves the copy a trainer would make) -- an extension of the reference API; ``obs_buf`` keeps its
+        previous contents.  obs_out: [num_envs, num_obs] float32, contiguous, on the sim device.  Returns obs_out."""
+        if (obs_out.shape != self.obs_buf.shape or obs_out.dtype != torch.float32 or not obs_out.is_contiguous()
+                or obs_out.device != self.obs_buf.device):
+            raise ValueError("step_into: obs_out must be a contiguous float32 [num_envs, num_obs] tensor on the sim device")
+        a = actions
+        if a.device != self.rew_buf.device or a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.float32).contiguous()
+        self._native_step(a, obs_out)
+        return obs_out
+
     def zero_actions(self) -> torch.Tensor:
         return torch.zeros([self.num_envs, self.num_actions], dtype=torch.float32, device=self.rl_device)
 
