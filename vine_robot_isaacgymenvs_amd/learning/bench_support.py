@@ -54,6 +54,20 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
                  + B * T * H * 4 + T * B * H * 4 + T * B * 4 * H * 2 + B * (T - 1) * H * 2)
     bwd_bytes = (B * T * H * 4 + T * B * 4 * H * 2 + (T + 1) * B * H * 4 + whh_tiled.numel() * 2 + B * T
                  + B * T * 4 * H * 2 + part.numel() * 4)
+    # what the memory system of THIS box sustains for a plain streaming kernel (y = x + 1 over 1 GiB, read + write):
+    # the practical ceiling for mixed read/write traffic, quoted beside the 8 TB/s spec figure
+    xs = torch.empty(1 << 28, device=device)
+    ys = torch.empty_like(xs)
+    for _ in range(3):
+        torch.add(xs, 1.0, out=ys)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        torch.add(xs, 1.0, out=ys)
+    e1.record()
+    torch.cuda.synchronize(device)
+    stream_gbs = 10 * 2 * 4 * xs.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del xs, ys
     res = []
     for name, f, nbytes in (("lstm_seq_fwd_kernel", fwd, fwd_bytes), ("lstm_seq_bwd_kernel", bwd, bwd_bytes)):
         for i in range(2 * sets):
@@ -67,7 +81,8 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
         torch.cuda.synchronize(device)
         us = e0.elapsed_time(e1) * 1e3 / n
         res.append({"kernel": name, "us": us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": nbytes / us / 1e3,
-                    "hbm_frac": nbytes / us / 1e3 / 8000.0, "launches_per_ppo_iteration": 32, "cache_state": "cold (rotating sets)"})
+                    "hbm_frac": nbytes / us / 1e3 / 8000.0, "launches_per_ppo_iteration": 32, "cache_state": "cold (rotating sets)",
+                    "streaming_kernel_GBs": stream_gbs, "frac_of_streaming_kernel": nbytes / us / 1e3 / stream_gbs})
     return res
 
 
