@@ -65,10 +65,14 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
  *   w_tiled  vine_lstm_tile_weights(H, KX + H, [w_ih | 0 | w_hh], ...) -- [4H, KX + H] bf16 in fragment order
  *   bias [4H] fp32 (b_ih + b_hh), c0 [B, H] fp32, done [B*T] uint8 (nullable)
  *   h_out [B*T, H] fp32, c_all [T+1, B, H] fp32 (slots 1 .. T written), gates [T, B, 4H] bf16 (nullable)
+ *   c_bf16 != 0: the saved cell states are only ever read by the backward pass and are stored as bfloat16 (c_all
+ *            [T+1, B, H] bf16, slots 1 .. T-1 written) -- the recurrence itself runs on fp32 registers either way -- and
+ *            the final state c_T goes to c_last [B, H] fp32 (the LSTM state handed back to the caller)
  * Needs B % 32 == 0, H == 256, T <= 8; VINE_ERR_UNSUPPORTED otherwise (callers use the per-step kernels). */
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
-                               const uint8_t* done, float* h_out, float* c_all, void* gates, void* stream);
+                               const uint8_t* done, float* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
+                               void* stream);
 
 /* Fragment-ordered copy of an LSTM weight for the persistent kernels (H == 256; dst: H * K bf16 elements... K columns
  * of all 4H rows for the forward form).  transposed = 0: src [4H, ld] row-major with K = 32 * ksteps columns used
@@ -80,10 +84,13 @@ int vine_lstm_tile_weights(int64_t H, int64_t K, const void* src, int64_t ld, in
  * LDS, dc / c in registers).  g_out [B*T, H] fp32 (row = seq * T + t), w_hh_tiled = vine_lstm_tile_weights(H, 4H,
  * w_hh, ld, 1, ...), gates [T, B, 4H] bf16 and c_all [T+1, B, H] fp32 as the forward pass left them (slot 0 of c_all
  * is never read: c0 [B, H] is), done [B*T] uint8 (nullable); dgates [B*T, 4H] bf16 out; bias_partial (nullable)
- * [B / 32, 4H] fp32: its column sums are the bias gradient.  Needs B % 32 == 0, H == 256, T <= 8. */
-int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_out, const void* w_hh_tiled,
-                                const void* gates, const float* c_all, const float* c0, const uint8_t* done,
-                                void* dgates, float* bias_partial, void* stream);
+ * [B / 32, 4H] fp32: its column sums are the bias gradient.  c_bf16 / c_last: as left by the forward kernel; g_bf16 != 0:
+ * g_out holds bfloat16 (the gradient w.r.t. the hidden states as vine_ln_heads_loss writes it with dx_bf16).
+ * Needs B % 32 == 0, H == 256, T <= 8. */
+int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_out, const void* w_hh_tiled,
+                                const void* gates, const void* c_all, const float* c0, const uint8_t* done,
+                                void* dgates, float* bias_partial, int32_t c_bf16, const float* c_last, int32_t g_bf16,
+                                void* stream);
 
 /* Linear + bias + ELU on the matrix cores: out = elu(A W^T + bias) with A [n, K] bf16 (rows lda apart), W [N, K] bf16,
  * out [n, N] bf16 (rows out_stride apart, e.g. a column block of the LSTM operand buffer); the fp32 pre-activation is
@@ -292,7 +299,8 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   float* sigma_store, void* stream);
 
 /* LayerNorm + heads + PPO loss + their backward in ONE launch (H = 256, NH = A + 1 in 2..5): from the LSTM output x [n, H] it forms heads = W LN(x) + wb ([n, NH], written out),
- * the loss terms and statistics of vine_ppo_loss on them, and d loss / d x ([n, H], dx) -- what
+ * the loss terms and statistics of vine_ppo_loss on them, and d loss / d x ([n, H], dx: fp32, or bfloat16 with dx_bf16 --
+ * the operand type vine_lstm_seq_backward_mfma takes with g_bf16) -- what
  * vine_layernorm_heads_forward + vine_ppo_loss + vine_layernorm_heads_backward produce in three launches, with the
  * same arithmetic.  ln_partial [n / R, (2 + NH) H] with R = vine_ln_heads_loss_rows() rows per workgroup (128 by default;
  * n % R == 0, n / R <= VINE_PPO_LOSS_BLOCKS): per-workgroup sums {d gamma | d beta | d W} (finish with vine_column_sums).  stats / grad_logstd / grad_mu_bias / grad_value_bias / scratch / kl_out / logstd_grad_accum /
@@ -301,9 +309,9 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
                        const float* w, const float* wb, const float* logstd, const float* actions, const float* old_neglogp,
                        const float* advantages, const float* old_values, const float* returns, const float* old_mu,
                        const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
-                       float bounds_coef, float soft_bound, float* heads, float* dx, float* ln_partial, float* stats,
-                       float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch, float* kl_out,
-                       float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream);
+                       float bounds_coef, float soft_bound, float* heads, void* dx, int32_t dx_bf16, float* ln_partial,
+                       float* stats, float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch,
+                       float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream);
 int vine_ln_heads_loss_rows(void);
 
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm

@@ -42,7 +42,7 @@ def one():
         x, h0, c0, dones, (out, c_all, gates, hp), g_out = sets[i % SETS]
         rc = lib.vine_lstm_seq_forward_mfma(B, T, H, wpad, x.data_ptr(), wpad, hp.data_ptr(), T * H, wtile.data_ptr(),
                                             bias.data_ptr(), c0.data_ptr(), dones.data_ptr(), out.data_ptr(), c_all.data_ptr(),
-                                            gates.data_ptr(), st)
+                                            gates.data_ptr(), 0, None, st)
         assert rc == 0
 
     dG = [torch.empty(B * T, 4 * H, device=dev, dtype=bf) for _ in range(SETS)]
@@ -51,7 +51,7 @@ def one():
     def bwd(i):
         x, h0, c0, dones, (out, c_all, gates, hp), g_out = sets[i % SETS]
         rc = lib.vine_lstm_seq_backward_mfma(B, T, H, g_out.data_ptr(), whh_tiled.data_ptr(), gates.data_ptr(), c_all.data_ptr(),
-                                             c0.data_ptr(), dones.data_ptr(), dG[i % SETS].data_ptr(), part.data_ptr(), st)
+                                             c0.data_ptr(), dones.data_ptr(), dG[i % SETS].data_ptr(), part.data_ptr(), 0, None, 0, st)
         assert rc == 0
 
     res = {}

@@ -323,11 +323,27 @@ def test_lstm_sequence_kernels_equal_step_kernels(B, use_dones):
                 f()
             torch.cuda.synchronize()
             print("lstm %s: %.1f us per 4-step sequence" % (name, (time.perf_counter() - t0) / 20 * 1e6))
+    # low-precision store of the backward-only data (the update's default): cell states c_1 .. c_{T-1} as bfloat16 + c_T in
+    # fp32, hidden-state gradient as bfloat16 -- the forward outputs are untouched, dG moves within bf16 rounding
+    bufs_lp = fused._lstm_state_buffers(xfull, w_hh, h0, c0, dones, T, True, c_dtype=bf)
+    c_last = torch.empty(B, H, device=dev)
+    out_lp, c_lp, gates_lp, hp_lp = fused._lstm_forward_steps(lib, xfull, None, w_hh, bias, h0, c0, dones, T, True, buffers=bufs_lp,
+                                                              c0_direct=c0, wtile=wtile, c_last=c_last)
+    torch.cuda.synchronize()
+    assert torch.equal(out_lp, out) and torch.equal(gates_lp, gates) and torch.equal(hp_lp, hp)
+    assert torch.equal(c_last, c_all[T]) and torch.equal(c_lp[1:T], c_all[1:T].to(bf))
+    dG_lp, part_lp = fused._lstm_backward_steps(lib, g_out.to(bf), w_hh, c_lp, gates, dones, T, c0_direct=c0,
+                                                w_hh_tiled=whh_tiled, c_last=c_last)
+    torch.cuda.synchronize()
+    scale = float(dG_s.float().abs().max())
+    assert float((dG_lp.float() - dG_s.float()).abs().max()) <= 2e-2 * scale
+    assert float((dG_lp.float() - dG_s.float()).abs().mean()) <= 2e-3 * scale
     # unsupported shapes are refused, not mis-run
     assert lib.vine_lstm_seq_forward_mfma(B + 1, T, H, wpad, xfull.data_ptr(), wpad, hp.data_ptr(), T * H, wtile.data_ptr(),
-                                          bias.data_ptr(), c0.data_ptr(), None, out.data_ptr(), c_all.data_ptr(), None, st) == -2
+                                          bias.data_ptr(), c0.data_ptr(), None, out.data_ptr(), c_all.data_ptr(), None, 0, None,
+                                          st) == -2
     assert lib.vine_lstm_seq_backward_mfma(B, 9, H, g_out.data_ptr(), whh_tiled.data_ptr(), gates.data_ptr(), c_all.data_ptr(),
-                                           c0.data_ptr(), None, dG_s.data_ptr(), None, st) == -2
+                                           c0.data_ptr(), None, dG_s.data_ptr(), None, 0, None, 0, st) == -2
 
 
 @pytest.mark.gpu
@@ -796,7 +812,7 @@ def test_ln_heads_loss_kernel_matches_float64_autograd(clip_value):
         rc = lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
                                     logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
                                     old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
-                                    heads.data_ptr(), dx.data_ptr(), part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
+                                    heads.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
                                     gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
                                     mu_st.data_ptr(), sg_st.data_ptr(), st)
         assert rc == 0
@@ -822,9 +838,20 @@ def test_ln_heads_loss_kernel_matches_float64_autograd(clip_value):
         assert abs(float(stats[k_]) - float(ref[name])) < 2e-5 * max(1.0, abs(float(ref[name]))), name
     assert abs(float(kl_out) - float(ref["kl"])) < 2e-5
     assert rel(mu_st, hd.detach()[:, :A]) < 1e-5 and rel(sg_st, lsd.detach().exp().expand(n, A)) < 1e-6
+    # the gradient handed to the LSTM backward as bfloat16 (dx_bf16): the fp32 result rounded, everything else unchanged
+    dx16, heads2 = torch.empty(n, H, device=dev, dtype=torch.bfloat16), torch.empty_like(heads)
+    gmb.zero_(); gvb.zero_(); gls_acc.zero_()
+    assert lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
+                                  logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
+                                  old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
+                                  heads2.data_ptr(), dx16.data_ptr(), 1, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
+                                  gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
+                                  mu_st.data_ptr(), sg_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dx16, dx.to(torch.bfloat16)) and torch.equal(heads2, heads)
     # shapes outside the family are refused
     assert lib.vine_ln_heads_loss(n + 8, H, NH, *([x.data_ptr()] * 3), 1e-5, *([x.data_ptr()] * 10), *scal,
-                                  *([x.data_ptr()] * 12), st) == -2
+                                  x.data_ptr(), x.data_ptr(), 0, *([x.data_ptr()] * 10), st) == -2
 
 
 @pytest.mark.gpu

@@ -463,12 +463,14 @@ __device__ __forceinline__ uint4 pack_bf16x8(const float (&v)[8]) {
     return r;
 }
 
-template <int KS1, int RING>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
+// CT: storage type of the saved cell states c_1 .. c_{T-1} (read again by the backward kernel only): float, or bf16_t
+// -- the recurrence itself always runs on the fp32 registers, and c_T then goes to `c_last` in fp32.
+template <int KS1, int RING, typename CT>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
 __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     int T, long long B, const bf16_t* __restrict__ x, long long ldx, bf16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
-    const unsigned char* __restrict__ done, float* __restrict__ h_out, float* __restrict__ c_all,
-    bf16_t* __restrict__ gates, int ablate) {
+    const unsigned char* __restrict__ done, float* __restrict__ h_out, CT* __restrict__ c_all,
+    bf16_t* __restrict__ gates, int ablate, float* __restrict__ c_last) {
     constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
     constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
             const long long b = b0 + 16 * rt + col;
             const float keep = ((dmask[rt] >> t) & 1u) ? 0.0f : 1.0f;
             const float kn = ((dmask[rt] >> (t + 1)) & 1u) ? 0.0f : 1.0f;
-            float* cp = c_all + ((long long)(t + 1) * B + b) * H + U0;
+            CT* cp = c_all + ((long long)(t + 1) * B + b) * H + U0;
+            float* cl = c_last + b * H + U0;                       // (only dereferenced in the low-precision mode)
             float* hpo = h_out + (b * T + t) * H + U0;
             uint2 lo[5];                                         // i, f, g, o, masked h of tile 0
 #pragma unroll
@@ -583,7 +586,9 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     hn[u] = go[u] * tanhf_(cn);
                 }
                 if (!(ablate & 1)) {
-                    st4(cp + 4 * ut, make_float4(c[rt][4 * ut], c[rt][4 * ut + 1], c[rt][4 * ut + 2], c[rt][4 * ut + 3]));
+                    const float4 cv = make_float4(c[rt][4 * ut], c[rt][4 * ut + 1], c[rt][4 * ut + 2], c[rt][4 * ut + 3]);
+                    if (sizeof(CT) == 2 && last) st4(cl + 4 * ut, cv);
+                    else st4(cp + 4 * ut, cv);
                     st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
                 }
                 uint2 pk[5];
@@ -634,11 +639,13 @@ __device__ __forceinline__ void unpack_bf16x8(uint4 r, float (&v)[8]) {
     v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
 }
 
-template <int RING>
+// CT: storage type of the saved cell states (see the forward kernel; with bf16_t, c_T comes from `c_last` in fp32);
+// GT: type of the incoming gradient w.r.t. the hidden states (float, or bf16_t as written by ln_heads_loss_kernel).
+template <int RING, typename CT, typename GT>
 __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
-    int T, long long B, const float* __restrict__ g_out, const uint4* __restrict__ Wt, const bf16_t* __restrict__ gates,
-    const float* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
-    bf16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate) {
+    int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const bf16_t* __restrict__ gates,
+    const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
+    bf16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
     constexpr int H = SEQ_H, K = 4 * H, KSTEPS = K / 32, NF = KSTEPS * 2;
     constexpr int PITCH = K + 8;
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
@@ -664,7 +671,9 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
         if (done)
             for (int t = 0; t < T; ++t) m |= (done[b * T + t] ? 1u : 0u) << t;
         dmask[rt] = m;
-        const float4 a = ld4(c_all + ((long long)T * B + b) * H + U0), bb = ld4(c_all + ((long long)T * B + b) * H + U0 + 4);
+        float4 a, bb;
+        if (sizeof(CT) == 2) { a = ld4(c_last + b * H + U0); bb = ld4(c_last + b * H + U0 + 4); }
+        else { a = ld4(c_all + ((long long)T * B + b) * H + U0); bb = ld4(c_all + ((long long)T * B + b) * H + U0 + 4); }
         cnew[rt][0] = a.x; cnew[rt][1] = a.y; cnew[rt][2] = a.z; cnew[rt][3] = a.w;
         cnew[rt][4] = bb.x; cnew[rt][5] = bb.y; cnew[rt][6] = bb.z; cnew[rt][7] = bb.w;
 #pragma unroll
@@ -684,10 +693,14 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
 #define SEQ_BWD_LOAD(rt)                                                                                   \
         {                                                                                                  \
             const long long b_ = b0 + 16 * (rt) + col;                                                     \
-            const float* gp_ = g_out + (b_ * T + t) * H + U0;                                              \
+            const GT* gp_ = g_out + (b_ * T + t) * H + U0;                                                 \
             go4[rt][0] = ld4(gp_); go4[rt][1] = ld4(gp_ + 4);                                              \
-            const float* cpp_ = (t == 0 ? c0 + b_ * H : c_all + ((long long)t * B + b_) * H) + U0;         \
-            cp4[rt][0] = ld4(cpp_); cp4[rt][1] = ld4(cpp_ + 4);                                            \
+            if (t == 0) {                                                                                  \
+                cp4[rt][0] = ld4(c0 + b_ * H + U0); cp4[rt][1] = ld4(c0 + b_ * H + U0 + 4);                \
+            } else {                                                                                       \
+                const CT* cpp_ = c_all + ((long long)t * B + b_) * H + U0;                                 \
+                cp4[rt][0] = ld4(cpp_); cp4[rt][1] = ld4(cpp_ + 4);                                        \
+            }                                                                                              \
             const bf16_t* ga_ = gates + ((long long)t * B + b_) * 4 * H + U0;                              \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) gpk[rt][g] = *reinterpret_cast<const uint4*>(ga_ + g * H); \
         }
@@ -2863,14 +2876,14 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // cl + 16 j, j = 0..3, of row `sub`), so that a LayerNorm / head reduction is four DPP rotate-adds inside a 16-lane row
 // instead of a wave-wide sum (9 DPP steps + a readlane, one row at a time: that version took 39 us).  NP passes of 4
 // rows per wave; the rows are re-read in phase 3 (L2 hits) rather than kept in 64 registers.
-template <int NH, int NP>
+template <int NH, int NP, typename DXT>      // DXT: type of the gradient handed to the LSTM backward (float or bf16_t)
 __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     long long n, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const float* __restrict__ w, const float* __restrict__ wb, const float* __restrict__ logstd,
     const float* __restrict__ actions, const float* __restrict__ old_neglogp, const float* __restrict__ adv,
     const float* __restrict__ old_values, const float* __restrict__ returns, const float* old_mu, const float* old_sigma,
     float e_clip, int clip_value, float critic_coef, float entropy_coef, float bounds_coef, float soft_bound,
-    float* __restrict__ heads, float* __restrict__ dx, float* __restrict__ ln_partial, float* loss_partial,
+    float* __restrict__ heads, DXT* __restrict__ dx, float* __restrict__ ln_partial, float* loss_partial,
     float* __restrict__ stats, float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
     float* __restrict__ grad_value_bias, float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum, float* mu_store,
     float* sigma_store) {
@@ -3497,49 +3510,67 @@ static int seq_ablate() {
 
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
-                               const uint8_t* done, float* h_out, float* c_all, void* gates, void* stream) {
+                               const uint8_t* done, float* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
+                               void* stream) {
     if (B <= 0 || T <= 0 || !x || !hp || !w_tiled || !bias || !c0 || !h_out || !c_all || ldx < KX || (ldx & 7) ||
-        hp_stride < T * H || (hp_stride & 7))
+        hp_stride < T * H || (hp_stride & 7) || (c_bf16 && !c_last))
         return VINE_ERR_INVALID_ARG;
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8 || (KX != 32 && KX != 64 && KX != 96 && KX != 128)) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B / SEQ_ROWS)), block(512);
     hipStream_t s = (hipStream_t)stream;
     const int ablate = seq_ablate();
-#define VINE_SEQ_FWD(KS1, RING)                                                                                         \
-    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING>), grid, block, 0, s, (int)T, (long long)B, (const bf16_t*)x,     \
+#define VINE_SEQ_FWD_T(KS1, RING, CT)                                                                                   \
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT>), grid, block, 0, s, (int)T, (long long)B, (const bf16_t*)x, \
                        (long long)ldx, (bf16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
-                       c_all, (bf16_t*)gates, ablate)
+                       (CT*)c_all, (bf16_t*)gates, ablate, c_last)
+#define VINE_SEQ_FWD(KS1, RING)                                                                                         \
+    {                                                                                                                   \
+        if (c_bf16) VINE_SEQ_FWD_T(KS1, RING, bf16_t);                                                                  \
+        else VINE_SEQ_FWD_T(KS1, RING, float);                                                                          \
+    }
     switch (KX / 32) {
-        case 1: VINE_SEQ_FWD(1, 24); break;      // 72 fragments per step
-        case 2: VINE_SEQ_FWD(2, 20); break;      // 80
-        case 3: VINE_SEQ_FWD(3, 22); break;      // 88: the update's [x (92 + 4 pad) | h] operand
-        default: VINE_SEQ_FWD(4, 24); break;     // 96
+        case 1: VINE_SEQ_FWD(1, 24) break;      // 72 fragments per step
+        case 2: VINE_SEQ_FWD(2, 20) break;      // 80
+        case 3: VINE_SEQ_FWD(3, 22) break;      // 88: the update's [x (92 + 4 pad) | h] operand
+        default: VINE_SEQ_FWD(4, 24) break;     // 96
     }
 #undef VINE_SEQ_FWD
+#undef VINE_SEQ_FWD_T
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const float* g_out, const void* w_hh_tiled,
-                                const void* gates, const float* c_all, const float* c0, const uint8_t* done,
-                                void* dgates, float* bias_partial, void* stream) {
-    if (B <= 0 || T <= 0 || !g_out || !w_hh_tiled || !gates || !c_all || !c0 || !dgates) return VINE_ERR_INVALID_ARG;
+int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_out, const void* w_hh_tiled,
+                                const void* gates, const void* c_all, const float* c0, const uint8_t* done,
+                                void* dgates, float* bias_partial, int32_t c_bf16, const float* c_last, int32_t g_bf16,
+                                void* stream) {
+    if (B <= 0 || T <= 0 || !g_out || !w_hh_tiled || !gates || !c_all || !c0 || !dgates || (c_bf16 && !c_last))
+        return VINE_ERR_INVALID_ARG;
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8) return VINE_ERR_UNSUPPORTED;
 #ifndef SEQ_BWD_RING
 #define SEQ_BWD_RING 8      // 16 does not fit the register file without spills: 76.7 us against 65.3 us per 4-step sequence
 #endif
     constexpr int RING = SEQ_BWD_RING;
     const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(bf16_t);          // 129 KiB: one workgroup per CU
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_bwd_kernel<RING>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VINE_ERR_DEVICE;
-        raised = true;
-    }
     const int ablate = seq_ablate();
-    hipLaunchKernelGGL((lstm_seq_bwd_kernel<RING>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream,
-                       (int)T, (long long)B, g_out, (const uint4*)w_hh_tiled, (const bf16_t*)gates, c_all, c0, done,
-                       (bf16_t*)dgates, bias_partial, ablate);
+#define VINE_SEQ_BWD(CT, GT)                                                                                              \
+    {                                                                                                                     \
+        static bool raised = false;                                                                                       \
+        if (!raised) {                                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_bwd_kernel<RING, CT, GT>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                  \
+                return VINE_ERR_DEVICE;                                                                                   \
+            raised = true;                                                                                                \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((lstm_seq_bwd_kernel<RING, CT, GT>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds,           \
+                           (hipStream_t)stream, (int)T, (long long)B, (const GT*)g_out, (const uint4*)w_hh_tiled,         \
+                           (const bf16_t*)gates, (const CT*)c_all, c0, done, (bf16_t*)dgates, bias_partial, ablate,       \
+                           c_last);                                                                                       \
+    }
+    if (c_bf16 && g_bf16) VINE_SEQ_BWD(bf16_t, bf16_t)
+    else if (c_bf16) VINE_SEQ_BWD(bf16_t, float)
+    else if (g_bf16) VINE_SEQ_BWD(float, bf16_t)
+    else VINE_SEQ_BWD(float, float)
+#undef VINE_SEQ_BWD
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -4026,9 +4057,9 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
                        const float* w, const float* wb, const float* logstd, const float* actions, const float* old_neglogp,
                        const float* advantages, const float* old_values, const float* returns, const float* old_mu,
                        const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
-                       float bounds_coef, float soft_bound, float* heads, float* dx, float* ln_partial, float* stats,
-                       float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch, float* kl_out,
-                       float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream) {
+                       float bounds_coef, float soft_bound, float* heads, void* dx, int32_t dx_bf16, float* ln_partial,
+                       float* stats, float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch,
+                       float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream) {
     if (n <= 0 || !x || !gamma || !beta || !w || !wb || !logstd || !actions || !old_neglogp || !advantages || !old_values ||
         !returns || !old_mu || !old_sigma || !heads || !dx || !ln_partial || !stats || !grad_logstd || !scratch ||
         ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || ((mu_store == nullptr) != (sigma_store == nullptr)))
@@ -4045,16 +4076,22 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
     if (H != 256 || NH < 2 || NH > 5 || n % rows_wg || n / rows_wg > VINE_PPO_LOSS_BLOCKS) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(n / rows_wg)), block(512);
     hipStream_t s = (hipStream_t)stream;
+#define VINE_LHL_T(K, R, DXT)                                                                                             \
+    hipLaunchKernelGGL((ln_heads_loss_kernel<K, R, DXT>), grid, block, 0, s, (long long)n, x, gamma, beta, eps, w, wb,     \
+                       logstd, actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip,           \
+                       (int)clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound, heads, (DXT*)dx, ln_partial,   \
+                       scratch, stats, grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store,    \
+                       sigma_store)
 #define VINE_LHL(K, R)                                                                                                    \
-    hipLaunchKernelGGL((ln_heads_loss_kernel<K, R>), grid, block, 0, s, (long long)n, x, gamma, beta, eps, w, wb, logstd,  \
-                       actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,  \
-                       critic_coef, entropy_coef, bounds_coef, soft_bound, heads, dx, ln_partial, scratch, stats,          \
-                       grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store, sigma_store)
+    {                                                                                                                     \
+        if (dx_bf16) VINE_LHL_T(K, R, bf16_t);                                                                            \
+        else VINE_LHL_T(K, R, float);                                                                                     \
+    }
 #define VINE_LHL_R(K)                                                                                                     \
     do {                                                                                                                  \
-        if (rw == 4) VINE_LHL(K, 1);                                                                                      \
-        else if (rw == 8) VINE_LHL(K, 2);                                                                                 \
-        else VINE_LHL(K, 4);                                                                                              \
+        if (rw == 4) VINE_LHL(K, 1)                                                                                       \
+        else if (rw == 8) VINE_LHL(K, 2)                                                                                  \
+        else VINE_LHL(K, 4)                                                                                               \
     } while (0)
     switch (NH) {
         case 2: VINE_LHL_R(2); break;
@@ -4064,6 +4101,7 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
     }
 #undef VINE_LHL_R
 #undef VINE_LHL
+#undef VINE_LHL_T
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

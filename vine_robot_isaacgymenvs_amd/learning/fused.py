@@ -307,7 +307,7 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     return torch.stack(outs, 1).reshape(B * T, -1), h, c
 
 
-def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0=True):
+def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0=True, c_dtype=torch.float32):
     """out / c_all / gates / hp of ``_lstm_forward_steps`` with the step-0 slots initialised (c_all[0] = c0,
     hp[:, 0] = masked h0 in the operand dtype): through ``prep`` (a CopyBatch flushed by the caller) or directly."""
     op = w_hh.dtype
@@ -315,7 +315,8 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0
     B = BT // T
     dev = x.device
     out = torch.empty((BT, H), device=dev, dtype=torch.float32)
-    c_all = torch.empty((T + 1, B, H), device=dev, dtype=torch.float32)
+    # (c_dtype bfloat16: the persistent sequence kernels' low-precision store of the cell states the backward pass re-reads)
+    c_all = torch.empty((T + 1, B, H), device=dev, dtype=c_dtype)
     gates = torch.empty((T, B, 4 * H), device=dev, dtype=op) if need_grad else None     # backward-only: operand dtype
     hp = torch.empty((B, T, H), device=dev, dtype=op)
     if prep is not None:
@@ -331,6 +332,9 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0
     return out, c_all, gates, hp
 
 
+# saved cell states and the hidden-state gradient of the persistent LSTM kernels as bfloat16 (backward-only data; the
+# recurrence, the returned state and every parameter gradient stay fp32); 0: fp32 (A/B knob)
+LSTM_LP = _os.environ.get("VINE_LSTM_LP", "1") != "0"
 LSTM_SEQ = _os.environ.get("VINE_LSTM_SEQ", "1") != "0"      # 0: one launch per time step (the round-1 kernels), for A/B runs
 
 
@@ -340,7 +344,7 @@ def lstm_seq_ok(B, H, T, wpad):
 
 
 def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None, c0_direct=None,
-                        wtile=None):
+                        wtile=None, c_last=None):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
     hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
     ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32.
@@ -365,7 +369,9 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
         _check(lib.vine_lstm_seq_forward_mfma(B, T, H, K1, x.data_ptr(), x.stride(0), hp.data_ptr(), T * H,
                                               wtile.data_ptr(), bias.data_ptr(), c_prev[0].data_ptr(), d_ptr,
                                               out.data_ptr(), c_all.data_ptr(), gates.data_ptr() if need_grad else None,
-                                              st), "vine_lstm_seq_forward_mfma")
+                                              int(c_all.dtype == torch.bfloat16),
+                                              c_last.data_ptr() if c_last is not None else None, st),
+               "vine_lstm_seq_forward_mfma")
         return out, c_all, gates, hp
     w_hh_t = w_hh.t()
     # mixed precision: the recurrent GEMM runs inside the step kernel on the matrix cores (vine_lstm_step_mfma)
@@ -408,7 +414,8 @@ def lstm_bwd_mfma_ok(B, H):
     return B % 64 == 0 and H in (128, 256)
 
 
-def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, c0_direct=None, w_hh_tiled=None):
+def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, c0_direct=None, w_hh_tiled=None,
+                         c_last=None):
     """Gate gradients dG [B*T, 4H] of the T steps (reverse order) and the per-workgroup bias-gradient partials.
     dG is only ever a GEMM operand: it is stored in ``w_hh``'s dtype (bfloat16 in the mixed-precision update).
     ``w_hh_t`` ([H, 4H] bf16, the transposed recurrent weight): every step is ONE matrix-core kernel that forms the
@@ -423,13 +430,17 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, 
     c_prev = [c_all[t] for t in range(T)]
     if c0_direct is not None:            # the forward pass read c0 in place: c_all[0] was never written
         c_prev[0] = c0_direct
+    assert w_hh_tiled is not None or (g_out.dtype == torch.float32 and c_all.dtype == torch.float32)
     if w_hh_tiled is not None:           # ONE launch for all T steps (dG_{t+1} in LDS, dc / c in registers)
         assert dG.dtype == torch.bfloat16 and lstm_seq_ok(B, H, T, 32) and gates.is_contiguous() and c_all.is_contiguous()
         bias_partial = torch.empty((B // 32, 4 * H), device=dev, dtype=torch.float32)
         _check(lib.vine_lstm_seq_backward_mfma(B, T, H, g_out.data_ptr(), w_hh_tiled.data_ptr(), gates.data_ptr(),
                                                c_all.data_ptr(), c_prev[0].data_ptr(),
                                                dones.data_ptr() if dones is not None else None, dG.data_ptr(),
-                                               bias_partial.data_ptr(), _stream(g_out)), "vine_lstm_seq_backward_mfma")
+                                               bias_partial.data_ptr(), int(c_all.dtype == torch.bfloat16),
+                                               c_last.data_ptr() if c_last is not None else None,
+                                               int(g_out.dtype == torch.bfloat16), _stream(g_out)),
+               "vine_lstm_seq_backward_mfma")
         return dG, bias_partial
     if w_hh_t is not None:
         assert dG.dtype == torch.bfloat16 and lstm_bwd_mfma_ok(B, H)
@@ -770,12 +781,17 @@ class _Trunk(torch.autograd.Function):
             prep.add(CopyBatch.COPY, b_heads[A_:], v_b)
             prep.add(CopyBatch.ADD, bias, b_ih, b_hh)
             c0_direct = c0 if (c0.dtype == torch.float32 and c0.is_contiguous()) else None
+            # persistent kernels: the saved cell states (backward-only) and the gradient w.r.t. the hidden states travel
+            # as bfloat16 (LSTM_LP); c_T, the state handed back, stays fp32 in its own buffer
+            lp = seq and LSTM_LP and c0_direct is not None
+            c_last = torch.empty((B, H), device=dev, dtype=torch.float32) if lp else None
             lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep,
-                                               copy_c0=c0_direct is None)
+                                               copy_c0=c0_direct is None, c_dtype=torch.bfloat16 if lp else torch.float32)
             prep.flush(obs_n)
         else:
             lstm_buffers = None
             c0_direct = None
+            lp, c_last = False, None
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
             torch.cat([mu_b, v_b], 0, out=b_heads)
@@ -825,7 +841,8 @@ class _Trunk(torch.autograd.Function):
         if no_proj:
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
             out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat,
-                                                        buffers=lstm_buffers, c0_direct=c0_direct, wtile=wtile)
+                                                        buffers=lstm_buffers, c0_direct=c0_direct, wtile=wtile,
+                                                        c_last=c_last)
         else:
             ig = _mm(xcat, w_ih_op.t())
             out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True,
@@ -845,15 +862,15 @@ class _Trunk(torch.autograd.Function):
             # known before this node's backward runs (which ignores the gradient it is handed for `heads`)
             y = out.new_empty(0)
             heads = torch.empty((n, NH), device=dev, dtype=torch.float32)
-            d_out = torch.empty_like(out)
+            d_out = torch.empty((n, H), device=dev, dtype=torch.bfloat16 if lp else torch.float32)
             ln_part = torch.empty((n // lhl_rows, (2 + NH) * H), device=dev, dtype=torch.float32)
-            lp = loss_pack
+            lpk = loss_pack
             _check(lib.vine_ln_heads_loss(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
-                                          w_heads.data_ptr(), b_heads.data_ptr(), lp["logstd"].data_ptr(),
-                                          *[t.data_ptr() for t in lp["args"]], *lp["scal"], heads.data_ptr(),
-                                          d_out.data_ptr(), ln_part.data_ptr(), lp["stats"].data_ptr(),
-                                          lp["grad_logstd"].data_ptr(), lp["head_bias_grads"][0].data_ptr(),
-                                          lp["head_bias_grads"][1].data_ptr(), lp["scratch"].data_ptr(), *lp["extra"], st),
+                                          w_heads.data_ptr(), b_heads.data_ptr(), lpk["logstd"].data_ptr(),
+                                          *[t.data_ptr() for t in lpk["args"]], *lpk["scal"], heads.data_ptr(),
+                                          d_out.data_ptr(), int(lp), ln_part.data_ptr(), lpk["stats"].data_ptr(),
+                                          lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
+                                          lpk["head_bias_grads"][1].data_ptr(), lpk["scratch"].data_ptr(), *lpk["extra"], st),
                    "vine_ln_heads_loss")
             ctx.loss_fused = (d_out, ln_part)
         elif fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
@@ -877,12 +894,14 @@ class _Trunk(torch.autograd.Function):
         ctx.w_hh_t = w_hh_t
         ctx.w_hh_tiled = w_hh_tiled
         ctx.has_c0 = c0_direct is not None   # the caller's own c0 buffer is read again in backward (saved below)
+        ctx.has_clast = c_last is not None
         ctx.save_for_backward(x0, xcat, hp, out, c_all, gates, y, mean, rstd, w_heads, w_ih_op, w_hh_op, ln_g, ln_b,
                               dones if dones is not None else obs_n.new_empty(0), *acts, *Wop,
+                              *([c_last] if c_last is not None else []),
                               *([c0_direct] if c0_direct is not None else []))
         # final LSTM state as views (no copies): the update discards it, other callers may clone
         hT = out.view(B, T, H)[:, T - 1]
-        cT = c_all[T]
+        cT = c_last if c_last is not None else c_all[T]
         ctx.mark_non_differentiable(hT, cT)
         ctx.set_materialize_grads(False)       # no zero-filled [B, H] gradients for the two state outputs
         return heads, hT, cT
@@ -897,6 +916,7 @@ class _Trunk(torch.autograd.Function):
         acts = list(saved[15:15 + n_mlp - 1])
         weights = list(saved[15 + n_mlp - 1:15 + 2 * n_mlp - 1])
         c0_direct = saved[-1] if ctx.has_c0 else None
+        c_last = saved[-2 if ctx.has_c0 else -1] if ctx.has_clast else None
         slots = ctx.slots
         n, H = out.shape
         dev = out.device
@@ -961,7 +981,8 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
         # ---- LSTM
         dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
-                                                w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled)
+                                                w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled,
+                                                c_last=c_last)
         fused2 = False
         if mixed and slots[base + 0] is not None and slots[base + 1] is not None:
             # dW_ih and dW_hh from one pass over dG (the largest tensor of the backward pass)
