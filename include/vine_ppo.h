@@ -68,11 +68,13 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
  *   c_bf16 != 0: the saved cell states are only ever read by the backward pass and are stored as bfloat16 (c_all
  *            [T+1, B, H] bf16, slots 1 .. T-1 written) -- the recurrence itself runs on fp32 registers either way -- and
  *            the final state c_T goes to c_last [B, H] fp32 (the LSTM state handed back to the caller)
+ *   h0 (nullable) [B, H] fp32: the initial hidden state; the kernel then forms the masked bf16 copy itself
+ *            (h0 * (1 - done[b, 0])) and WRITES it to slot 0 of hp instead of reading it from there
  * Needs B % 32 == 0, H == 256, T <= 8; VINE_ERR_UNSUPPORTED otherwise (callers use the per-step kernels). */
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
                                const uint8_t* done, float* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
-                               void* stream);
+                               const float* h0, void* stream);
 
 /* Fragment-ordered copy of an LSTM weight for the persistent kernels (H == 256; dst: H * K bf16 elements... K columns
  * of all 4H rows for the forward form).  transposed = 0: src [4H, ld] row-major with K = 32 * ksteps columns used

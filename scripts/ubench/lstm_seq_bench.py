@@ -42,7 +42,7 @@ def one():
         x, h0, c0, dones, (out, c_all, gates, hp), g_out = sets[i % SETS]
         rc = lib.vine_lstm_seq_forward_mfma(B, T, H, wpad, x.data_ptr(), wpad, hp.data_ptr(), T * H, wtile.data_ptr(),
                                             bias.data_ptr(), c0.data_ptr(), dones.data_ptr(), out.data_ptr(), c_all.data_ptr(),
-                                            gates.data_ptr(), 0, None, st)
+                                            gates.data_ptr(), 0, None, None, st)
         assert rc == 0
 
     dG = [torch.empty(B * T, 4 * H, device=dev, dtype=bf) for _ in range(SETS)]

@@ -332,6 +332,13 @@ def test_lstm_sequence_kernels_equal_step_kernels(B, use_dones):
     torch.cuda.synchronize()
     assert torch.equal(out_lp, out) and torch.equal(gates_lp, gates) and torch.equal(hp_lp, hp)
     assert torch.equal(c_last, c_all[T]) and torch.equal(c_lp[1:T], c_all[1:T].to(bf))
+    # ... and with the masked initial state formed by the kernel itself from the fp32 state (hp slot 0 is then an OUTPUT)
+    bufs_h = fused._lstm_state_buffers(xfull, w_hh, h0, c0, dones, T, True, c_dtype=bf)
+    bufs_h[3][:, 0] = float("nan")
+    out_h, c_h, gates_h, hp_h = fused._lstm_forward_steps(lib, xfull, None, w_hh, bias, h0, c0, dones, T, True, buffers=bufs_h,
+                                                          c0_direct=c0, wtile=wtile, c_last=c_last, h0_direct=h0)
+    torch.cuda.synchronize()
+    assert torch.equal(out_h, out) and torch.equal(gates_h, gates) and torch.equal(hp_h, hp)
     dG_lp, part_lp = fused._lstm_backward_steps(lib, g_out.to(bf), w_hh, c_lp, gates, dones, T, c0_direct=c0,
                                                 w_hh_tiled=whh_tiled, c_last=c_last)
     torch.cuda.synchronize()
@@ -341,7 +348,7 @@ def test_lstm_sequence_kernels_equal_step_kernels(B, use_dones):
     # unsupported shapes are refused, not mis-run
     assert lib.vine_lstm_seq_forward_mfma(B + 1, T, H, wpad, xfull.data_ptr(), wpad, hp.data_ptr(), T * H, wtile.data_ptr(),
                                           bias.data_ptr(), c0.data_ptr(), None, out.data_ptr(), c_all.data_ptr(), None, 0, None,
-                                          st) == -2
+                                          None, st) == -2
     assert lib.vine_lstm_seq_backward_mfma(B, 9, H, g_out.data_ptr(), whh_tiled.data_ptr(), gates.data_ptr(), c_all.data_ptr(),
                                            c0.data_ptr(), None, dG_s.data_ptr(), None, 0, None, 0, st) == -2
 

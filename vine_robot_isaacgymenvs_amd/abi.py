@@ -180,7 +180,7 @@ PPO_PROTOTYPES = {
     "vine_lstm_step_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP,
                                       _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _I64, _VP]),
     "vine_lstm_seq_forward_mfma": (C.c_int, [_I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
-                                             C.c_int32, _VP, _VP]),
+                                             C.c_int32, _VP, _VP, _VP]),
     "vine_lstm_seq_backward_mfma": (C.c_int, [_I64, _I64, _I64] + [_VP] * 8 + [C.c_int32, _VP, C.c_int32, _VP]),
     "vine_lstm_tile_weights": (C.c_int, [_I64, _I64, _VP, _I64, C.c_int32, _VP, _VP]),
     "vine_linear_elu_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_float, _VP, _I64, _VP]),

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     int T, long long B, const bf16_t* __restrict__ x, long long ldx, bf16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
     const unsigned char* __restrict__ done, float* __restrict__ h_out, CT* __restrict__ c_all,
-    bf16_t* __restrict__ gates, int ablate, float* __restrict__ c_last) {
+    bf16_t* __restrict__ gates, int ablate, float* __restrict__ c_last, const float* __restrict__ h0) {
     constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
     constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
@@ -501,8 +501,20 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
         }
         for (int p = tid; p < SEQ_ROWS * (H / 8); p += 512) {
             const int r = p >> 5, c8 = p & 31;
-            *reinterpret_cast<uint4*>(&xh[0][r * PITCH + KX + 8 * c8]) =
-                *reinterpret_cast<const uint4*>(hp + (b0 + r) * hp_stride + 8 * c8);      // slot 0: masked h_{-1}
+            uint4 hv;
+            if (h0) {
+                // the masked initial state is formed here from the fp32 state and the first done flag (formerly a job
+                // of the batched operand-copy launch: three quarters of its threads), and written to slot 0 of hp for
+                // the weight-gradient kernel
+                const float keep0 = (done && done[(b0 + r) * T]) ? 0.0f : 1.0f;
+                const float4 a = ld4(h0 + (b0 + r) * H + 8 * c8), b = ld4(h0 + (b0 + r) * H + 8 * c8 + 4);
+                const float v[8] = {keep0 * a.x, keep0 * a.y, keep0 * a.z, keep0 * a.w, keep0 * b.x, keep0 * b.y, keep0 * b.z, keep0 * b.w};
+                hv = pack_bf16x8(v);
+                *reinterpret_cast<uint4*>(hp + (b0 + r) * hp_stride + 8 * c8) = hv;
+            } else {
+                hv = *reinterpret_cast<const uint4*>(hp + (b0 + r) * hp_stride + 8 * c8);      // slot 0: masked h_{-1}
+            }
+            *reinterpret_cast<uint4*>(&xh[0][r * PITCH + KX + 8 * c8]) = hv;
         }
         for (int p = tid; p < H; p += 512) st4(&bias_l[4 * p], ld4(bias + 4 * p));
     }
@@ -3511,7 +3523,7 @@ static int seq_ablate() {
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
                                const uint8_t* done, float* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
-                               void* stream) {
+                               const float* h0, void* stream) {
     if (B <= 0 || T <= 0 || !x || !hp || !w_tiled || !bias || !c0 || !h_out || !c_all || ldx < KX || (ldx & 7) ||
         hp_stride < T * H || (hp_stride & 7) || (c_bf16 && !c_last))
         return VINE_ERR_INVALID_ARG;
@@ -3522,7 +3534,7 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
 #define VINE_SEQ_FWD_T(KS1, RING, CT)                                                                                   \
     hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT>), grid, block, 0, s, (int)T, (long long)B, (const bf16_t*)x, \
                        (long long)ldx, (bf16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
-                       (CT*)c_all, (bf16_t*)gates, ablate, c_last)
+                       (CT*)c_all, (bf16_t*)gates, ablate, c_last, h0)
 #define VINE_SEQ_FWD(KS1, RING)                                                                                         \
     {                                                                                                                   \
         if (c_bf16) VINE_SEQ_FWD_T(KS1, RING, bf16_t);                                                                  \

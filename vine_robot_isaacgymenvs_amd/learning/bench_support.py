@@ -47,7 +47,7 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
         assert lib.vine_lstm_seq_forward_mfma(B, T, H, wpad, d["x"].data_ptr(), wpad, d["hp"].data_ptr(), T * H,
                                               wtile.data_ptr(), bias.data_ptr(), d["c0"].data_ptr(), d["dones"].data_ptr(),
                                               d["out"].data_ptr(), d["c_all"].data_ptr(), d["gates"].data_ptr(), 1,
-                                              d["c_last"].data_ptr(), st) == 0
+                                              d["c_last"].data_ptr(), None, st) == 0
 
     def bwd(i):
         d = data[i % sets]

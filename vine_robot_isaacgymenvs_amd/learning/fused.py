@@ -307,7 +307,8 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
     return torch.stack(outs, 1).reshape(B * T, -1), h, c
 
 
-def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0=True, c_dtype=torch.float32):
+def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0=True, c_dtype=torch.float32,
+                        mask_h0=True):
     """out / c_all / gates / hp of ``_lstm_forward_steps`` with the step-0 slots initialised (c_all[0] = c0,
     hp[:, 0] = masked h0 in the operand dtype): through ``prep`` (a CopyBatch flushed by the caller) or directly."""
     op = w_hh.dtype
@@ -322,7 +323,8 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0
     if prep is not None:
         if copy_c0:      # else: the caller hands c0 itself to the step kernels (``c0_direct``), slot 0 stays unused
             prep.add(CopyBatch.COPY, c_all[0], c0)
-        prep.add(CopyBatch.MASKED, hp[:, 0], h0, dones, aux=T)
+        if mask_h0:      # else: the persistent forward kernel forms the masked bf16 state itself (h0 handed to it)
+            prep.add(CopyBatch.MASKED, hp[:, 0], h0, dones, aux=T)
     else:
         c_all[0].copy_(c0)
         if dones is not None:
@@ -344,7 +346,7 @@ def lstm_seq_ok(B, H, T, wpad):
 
 
 def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wcat=None, buffers=None, c0_direct=None,
-                        wtile=None, c_last=None):
+                        wtile=None, c_last=None, h0_direct=None):
     """T LSTM steps from the input projection ``ig`` [B*T, 4H]: per step one recurrent GEMM on the MASKED previous
     hidden state + the fused pointwise kernel, which also emits the masked state for the next step (``hp``).
     ``w_hh`` in bfloat16 selects bf16 GEMM operands (``hp`` is then stored in bfloat16); everything else is fp32.
@@ -370,7 +372,8 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
                                               wtile.data_ptr(), bias.data_ptr(), c_prev[0].data_ptr(), d_ptr,
                                               out.data_ptr(), c_all.data_ptr(), gates.data_ptr() if need_grad else None,
                                               int(c_all.dtype == torch.bfloat16),
-                                              c_last.data_ptr() if c_last is not None else None, st),
+                                              c_last.data_ptr() if c_last is not None else None,
+                                              h0_direct.data_ptr() if h0_direct is not None else None, st),
                "vine_lstm_seq_forward_mfma")
         return out, c_all, gates, hp
     w_hh_t = w_hh.t()
@@ -785,13 +788,15 @@ class _Trunk(torch.autograd.Function):
             # as bfloat16 (LSTM_LP); c_T, the state handed back, stays fp32 in its own buffer
             lp = seq and LSTM_LP and c0_direct is not None
             c_last = torch.empty((B, H), device=dev, dtype=torch.float32) if lp else None
+            h0_direct = h0 if (seq and h0.dtype == torch.float32 and h0.is_contiguous()) else None
             lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep,
-                                               copy_c0=c0_direct is None, c_dtype=torch.bfloat16 if lp else torch.float32)
+                                               copy_c0=c0_direct is None, c_dtype=torch.bfloat16 if lp else torch.float32,
+                                               mask_h0=h0_direct is None)
             prep.flush(obs_n)
         else:
             lstm_buffers = None
             c0_direct = None
-            lp, c_last = False, None
+            lp, c_last, h0_direct = False, None, None
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
             torch.cat([mu_b, v_b], 0, out=b_heads)
@@ -842,7 +847,7 @@ class _Trunk(torch.autograd.Function):
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
             out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat,
                                                         buffers=lstm_buffers, c0_direct=c0_direct, wtile=wtile,
-                                                        c_last=c_last)
+                                                        c_last=c_last, h0_direct=h0_direct if mixed else None)
         else:
             ig = _mm(xcat, w_ih_op.t())
             out, c_all, gates, hp = _lstm_forward_steps(lib, xcat, ig, w_hh_op, bias, h0, c0, dones, T, True,
