@@ -264,6 +264,10 @@ def cpu_baseline(args, seconds, mode, cfg):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON result: anything the libraries print on the way (e.g. the action /
+    # observation spaces RLGPUEnv.get_env_info echoes, as the reference's does) goes to stderr
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
     import torch
     import torch.distributed as dist
 
@@ -360,7 +364,7 @@ def main():
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds, mode, cfg)
-        print(json.dumps(out))
+        print(json.dumps(out), file=real_stdout, flush=True)
     env.close()
     if world > 1:
         dist.destroy_process_group()
