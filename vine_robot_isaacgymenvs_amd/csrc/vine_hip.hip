@@ -961,15 +961,26 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         float q5 = ST(VF_Q0 + 5), qd5 = ST(VF_QD0 + 5);
         float y = ST(VF_Q0), vy = ST(VF_QD0);
         const float prev_q_own = q_own, prev_q5 = q5, prev_y = y;
-        float tip_y = ST(VF_TIP_Y), tip_z = ST(VF_TIP_Z), tip_vy = 0.0f, tip_vz = 0.0f;
-        float prev_tip_y = tip_y, prev_tip_z = tip_z;
+        // Rigid-body states of the tip and the cart at the start of the step.  They equal the forward kinematics of the
+        // DOF state EXCEPT in the step after a reset (P5: reset_idx does not move bodies, so they are stale), and they are
+        // then the only copy; progress == 0 marks exactly those envs (and freshly initialised ones, whose body states
+        // vine_init / vine_reset_idx stored).  Everyone else re-derives them (below, once sin / cos exist) instead of
+        // loading four words -- and, at the end, stores them only when the env was reset in this step: 32 B of HBM
+        // traffic per env step less.  With introspection on they are loaded and stored as before (attribute views).
+        const bool introspect = (P.flags & VINE_FLAG_INTROSPECT) != 0;
+        const long long prog_in = progress[e];
+        const bool body_from_mem = introspect || prog_in == 0;
+        float tip_y = 0.0f, tip_z = 0.0f, tip_vy = 0.0f, tip_vz = 0.0f;
+        float cart_y = y, cart_vy = vy;
+        if (body_from_mem) {
+            tip_y = ST(VF_TIP_Y); tip_z = ST(VF_TIP_Z);
+            cart_y = ST(VF_CART_Y); cart_vy = ST(VF_CART_VY);
+        }
         float prev_u_rail = u_rail;
-        float cart_y = ST(VF_CART_Y), cart_vy = ST(VF_CART_VY);
         float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
         float rail_force = 0.0f;
         const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
         const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
-        const bool introspect = (P.flags & VINE_FLAG_INTROSPECT) != 0;
         // absolute angles / rates: inclusive prefix sums over the quad, then link 4 on top of lane 3's
         float th, w;
         {
@@ -987,6 +998,12 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             sincosf(th4, &s_, &c_);
             sn4 = P.s0 * c_ + P.c0 * s_; cs4 = P.c0 * c_ - P.s0 * s_;
         }
+        {   // forward kinematics of the start pose (quad sums outside any branch), used unless the body states are stale
+            const float fk_y = y - P.L * (quad_sum(sn) + sn4), fk_z = P.z1 + P.L * (quad_sum(cs) + cs4);
+            tip_y = body_from_mem ? tip_y : fk_y;
+            tip_z = body_from_mem ? tip_z : fk_z;
+        }
+        float prev_tip_y = tip_y, prev_tip_z = tip_z;
         // ---- dynamics-scaling factors: lane i draws the 20 factors of control iteration i (V5:1053-1055)
         float scl[20];
         if (RANDOMIZE && P.dyn_span != 0.0f) {
@@ -1173,8 +1190,9 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         float q0 = y, qd0 = vy;
         float prev_q0 = prev_y, prev_qo = prev_q_own, prev_q5v = prev_q5;
         // ---- post_physics_step (V5:1110-1120)
-        long long prog = progress[e] + 1;
+        long long prog = prog_in + 1;
         long long rst = reset[e];
+        const bool was_reset = rst != 0;
         float agg = ST(VF_AGG_REW);
         float ty = ST(VF_TARGET_Y), tz = ST(VF_TARGET_Z);
         if (rst != 0) {      // reset_idx (V5:774-839, 887-914): a quad-uniform branch
@@ -1345,8 +1363,10 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
 #pragma unroll
                 for (int i = 0; i < VINE_NUM_REWARDS; ++i) reward_matrix[(size_t)e * VINE_NUM_REWARDS + i] = rm[i];
             }
-            ST(VF_TIP_Y) = tip_y; ST(VF_TIP_Z) = tip_z;
-            ST(VF_CART_Y) = cart_y; ST(VF_CART_VY) = cart_vy;
+            if (introspect || was_reset) {      // (else: re-derived by the next step, see the top of the kernel)
+                ST(VF_TIP_Y) = tip_y; ST(VF_TIP_Z) = tip_z;
+                ST(VF_CART_Y) = cart_y; ST(VF_CART_VY) = cart_vy;
+            }
             ST(VF_SMOOTHED_U) = smoothed;
             ST(VF_PREV_CART_VEL) = pcv; ST(VF_PREV_CART_VEL_ERR) = pce;
             ST(VF_AGG_REW) = agg;

@@ -167,6 +167,10 @@ class Vine5LinkMovingBase(VecTask):
         self.mat = self.read_mat_file(self.cfg["env"]["MAT_FILE"]) if len(self.cfg["env"].get("MAT_FILE", "")) > 0 else None
         # host-indexed state overwrite every step: cannot live inside a captured hipGraph
         self.graph_capturable = self.mat is None
+        if self.mat is not None:
+            # replay overwrites the DOF state before every step without moving the bodies: the step kernel must keep
+            # reading the tip / cart rigid-body states from memory, which it does with introspection on
+            self.set_introspection(True)
 
     # ------------------------------------------------------------------ MAT_FILE replay (V5:281-297, 947-982)
     def read_mat_file(self, filename):
