@@ -466,7 +466,7 @@ def test_weight_grad_cat_single_operand(M, N, stride, off):
 
 
 @pytest.mark.gpu
-def test_weight_grad_group_equals_single_launches():
+def test_weight_grad_group_equals_single_launches(monkeypatch):
     """The three MLP weight gradients of the update in ONE launch (vine_weight_grad_group) are bit-identical to three
     single launches of the same kernel family, and match the float64 products."""
     dev = torch.device("cuda:0")
@@ -478,6 +478,7 @@ def test_weight_grad_group_equals_single_launches():
     cases = [((torch.randn(n, 64, device=dev) * 0.1).to(bf), (torch.randn(n, 128, device=dev) * 0.5).to(bf)),
              ((torch.randn(n, 128, device=dev) * 0.1).to(bf), (torch.randn(n, 256, device=dev) * 0.5).to(bf)),
              ((torch.randn(n, 256, device=dev) * 0.1).to(bf), xfull[:, 64:92])]
+    monkeypatch.setattr(fused, "WGRAD_GROUP_WGS", fused.WGRAD_CAT_WGS)      # same row slices as a launch of its own
     batch, group = fused.ColumnSumBatch(), fused.WeightGradGroup()
     outs = [torch.empty(dy.shape[1], x.shape[1], device=dev) for dy, x in cases]
     for (dy, x), o in zip(cases, outs):
