@@ -1873,19 +1873,20 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroupArgs G) {
 // the row slices (32: 46 MB of partial sums).  With one stage of prefetch the kernel is bound by the latency of its
 // own loads (32 stages x 1.4 us); two stages are kept in flight in two named register sets (the loop is unrolled by two
 // so that the set is a compile-time choice; an indexed array lands in scratch memory).
-template <int NT1>
+template <int NT1, int MT>      // MT = 16-row MFMA tiles per wave along M: workgroup tile = (64 MT) x 352
 __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mtiles, int slices, const bf16_t* __restrict__ dy,
                                                              long long ldy, const bf16_t* __restrict__ x1, long long ldx1,
                                                              const bf16_t* __restrict__ x2, long long ldx2,
                                                              float* __restrict__ part1, int Nv1, float* __restrict__ part2,
                                                              int Nv2, int M) {
-    constexpr int MT = 2, NT = 11, WM = 4, WN = 2, TH = 64 * WM * WN;
+    constexpr int NT = 11, WM = 4, WN = 2, TH = 64 * WM * WN;
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN, N1 = 16 * NT1, N2 = BN - N1;
     constexpr int PA = BM + 16, PB = BN + 16;
     constexpr int APC = BM / 8, AP = 32 * APC;                  // 16-B pieces per A row / per A stage
     constexpr int B1C = N1 / 8, B1P = 32 * B1C, B2C = N2 / 8, B2P = 32 * B2C;
-    static_assert(AP == TH && B1P + B2P <= 3 * TH && B1P + B2P > 2 * TH && B1P % 64 == 0 && (B1P + B2P) % 64 == 0,
-                  "staging slots: 1 piece of dy and 3 of [x1 | x2] per thread, operand boundaries on wave boundaries");
+    static_assert(AP <= TH && AP % 64 == 0 && B1P + B2P <= 3 * TH && B1P + B2P > 2 * TH && B1P % 64 == 0 &&
+                      (B1P + B2P) % 64 == 0,
+                  "staging slots: <= 1 piece of dy and 3 of [x1 | x2] per thread, operand boundaries on wave boundaries");
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     bf16_t (*al)[32 * PA] = reinterpret_cast<bf16_t (*)[32 * PA]>(wg_lds);
     bf16_t (*bl)[32 * PB] = reinterpret_cast<bf16_t (*)[32 * PB]>(wg_lds + 2 * 32 * PA * sizeof(bf16_t));
@@ -1897,8 +1898,10 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
     const int m0 = mtile * BM;
     const long long k0 = (long long)slice * stages * 32;
     // per-thread source of piece p = tid + TH i (the slot past the last piece re-reads piece 0 and is never stored)
-    const bf16_t* asrc = dy + (k0 + tid / APC) * ldy + m0 + 8 * (tid % APC);
-    const int aoff = (tid / APC) * PA + 8 * (tid % APC);
+    const bool aval = tid < AP;                                  // (wave-uniform; the other waves re-read piece 0)
+    const int ap = aval ? tid : 0;
+    const bf16_t* asrc = dy + (k0 + ap / APC) * ldy + m0 + 8 * (ap % APC);
+    const int aoff = (ap / APC) * PA + 8 * (ap % APC);
 #define WGW_SRC(i)                                                                                             \
     const bf16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
     {                                                                                                          \
@@ -1926,7 +1929,7 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
         __builtin_amdgcn_sched_barrier(0);   /* requests leave before the products, not after them */          \
     }
 #define WGW_STORE(S, buf)                                                                                      \
-    *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_##S;                                                        \
+    if (aval) *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_##S;                                              \
     *reinterpret_cast<uint4*>(&bl[buf][boff0]) = rb0_##S;                                                      \
     *reinterpret_cast<uint4*>(&bl[buf][boff1]) = rb1_##S;                                                      \
     if (bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = rb2_##S;
@@ -3829,19 +3832,28 @@ int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t l
         ((uintptr_t)dy & 15) || ((uintptr_t)x2 & 15) || N2p <= 0 || Nv2 <= 0 || Nv2 > N2p || N1p < 0 ||
         (N1p > 0 && (!x1 || !part1 || ldx1 < N1p || (ldx1 & 7) || ((uintptr_t)x1 & 15) || Nv1 <= 0 || Nv1 > N1p)))
         return VINE_ERR_INVALID_ARG;
-    if (NT == 22) {      // one 128 x 352 tile per workgroup over [x1 96 | x2 256]
-        if (N1p != 96 || N2p != 256 || (M & 127) || (slices & 7) || rows % (slices * 64) || slices > 8192) return VINE_ERR_UNSUPPORTED;
-        const int mtiles = (int)(M / 128), stages = (int)(rows / slices / 32);
-        const size_t lds = (size_t)2 * 32 * ((128 + 16) + (352 + 16)) * sizeof(bf16_t);      // 64 KiB
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)wgrad_cat_wide_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return VINE_ERR_DEVICE;
-            attr_set = true;
+    if (NT == 22 || NT == 21) {      // one (128 | 64) x 352 tile per workgroup over [x1 96 | x2 256]
+        const int bm = NT == 22 ? 128 : 64;
+        if (N1p != 96 || N2p != 256 || (M % bm) || (slices & 7) || rows % (slices * 64) || slices > 8192) return VINE_ERR_UNSUPPORTED;
+        const int mtiles = (int)(M / bm), stages = (int)(rows / slices / 32);
+        const size_t lds = (size_t)2 * 32 * ((bm + 16) + (352 + 16)) * sizeof(bf16_t);      // 64 / 56 KiB
+#define VINE_WGW(MT_)                                                                                                     \
+        {                                                                                                                 \
+            static bool attr_set = false;                                                                                 \
+            if (!attr_set) {                                                                                              \
+                if (hipFuncSetAttribute((const void*)wgrad_cat_wide_kernel<6, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        (int)lds) != hipSuccess)                                                          \
+                    return VINE_ERR_DEVICE;                                                                               \
+                attr_set = true;                                                                                          \
+            }                                                                                                             \
+            hipLaunchKernelGGL((wgrad_cat_wide_kernel<6, MT_>), dim3((unsigned)(mtiles * slices)), dim3(512), lds,        \
+                               (hipStream_t)stream, stages, mtiles, (int)slices, (const bf16_t*)dy, (long long)ldy,       \
+                               (const bf16_t*)x1, (long long)ldx1, (const bf16_t*)x2, (long long)ldx2, part1, (int)Nv1,   \
+                               part2, (int)Nv2, (int)M);                                                                  \
         }
-        hipLaunchKernelGGL((wgrad_cat_wide_kernel<6>), dim3((unsigned)(mtiles * slices)), dim3(512), lds, (hipStream_t)stream,
-                           stages, mtiles, (int)slices, (const bf16_t*)dy, (long long)ldy, (const bf16_t*)x1, (long long)ldx1,
-                           (const bf16_t*)x2, (long long)ldx2, part1, (int)Nv1, part2, (int)Nv2, (int)M);
+        if (NT == 22) VINE_WGW(2)
+        else VINE_WGW(1)
+#undef VINE_WGW
         return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
     }
     if ((NT != 11 && NT != 8 && NT != 2) || (M & 63) || (N1p & 15) || ((N1p + N2p) % (16 * NT)) || (slices & 7) ||

@@ -147,6 +147,7 @@ HEADS_LOSS = _os.environ.get("VINE_HEADS_LOSS", "1") != "0"    # LayerNorm + hea
 MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
+WGRAD_WIDE_BM = int(_os.environ.get("VINE_WGRAD_WIDE_BM", "128"))   # 128 | 64 rows of dy^T per workgroup tile (A/B knob)
 WGRAD_GROUP_WGS = int(_os.environ.get("VINE_WGRAD_GROUP_WGS", "256"))   # per problem of a grouped launch
 WGRAD_CAT_WIDE = _os.environ.get("VINE_WGRAD_CAT_WIDE", "1") != "0"  # 128 x 352 tiles for the LSTM's [x | h] (A/B knob)
 
@@ -180,8 +181,8 @@ def _wgrad_cat_plan(dy, x1, x2, out1, out2, allow_wide=True, wgs=None):
     if not NT:
         return None
     wide = allow_wide and WGRAD_CAT_WIDE and o1[0] == 96 and o2[0] == 256 and M % 128 == 0
-    if wide:        # one 128 x 352 tile per workgroup, one workgroup per CU (a quarter of the L2 traffic of 64 x 176 tiles)
-        NT, tiles, target = 22, M // 128, 256
+    if wide:        # one 128 x 352 (or 64 x 352) tile per workgroup, one workgroup per CU
+        NT, tiles, target = (22, M // 128, 256) if WGRAD_WIDE_BM == 128 else (21, M // 64, 256)
     else:
         tiles, target = (M // 64) * (Nt // (16 * NT)), (wgs or WGRAD_CAT_WGS)
     S = 8
