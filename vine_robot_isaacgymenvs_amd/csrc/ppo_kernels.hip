@@ -3306,6 +3306,91 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
     }
 }
 
+// The same head for the rollout's default shape (H == 256, LayerNorm applied here): SIXTEEN lanes per env row, four rows
+// per wave -- the reductions are DPP rotate-adds inside a 16-lane row (row_allsum16) instead of wave-wide sums, and four
+// lanes per wave (one per row) sample in parallel where lane 0 sampled alone.  Same Philox keys, same formulas.
+__global__ __launch_bounds__(256) void policy_head16_kernel(long long N, int A, const float* __restrict__ y,
+                                                            const float* __restrict__ w_mu, const float* __restrict__ b_mu,
+                                                            const float* __restrict__ w_v, const float* __restrict__ b_v,
+                                                            const float* __restrict__ logstd, const float* __restrict__ vmean,
+                                                            const float* __restrict__ vstd, int normalize_value,
+                                                            unsigned seed_lo, unsigned seed_hi,
+                                                            const long long* __restrict__ counter, float* __restrict__ mu_out,
+                                                            float* __restrict__ sigma_out, float* __restrict__ value_out,
+                                                            float* __restrict__ action_out, float* __restrict__ neglogp_out,
+                                                            const float* __restrict__ ln_gamma,
+                                                            const float* __restrict__ ln_beta, float ln_eps) {
+    constexpr int H = 256;
+    const int lane = threadIdx.x & 63, sub = lane >> 4, cl = lane & 15;
+    const long long e = ((((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 2) + sub;      // N % 4 == 0 (host check)
+    const unsigned long long ctr = (unsigned long long)counter[0];
+    float xa[4][4], s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 v = ld4(y + e * H + 4 * (cl + 16 * j));
+        xa[j][0] = v.x; xa[j][1] = v.y; xa[j][2] = v.z; xa[j][3] = v.w;
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = row_allsum16(s) * (1.0f / H);
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xa[j][u] -= mean;
+            q += xa[j][u] * xa[j][u];
+        }
+    const float rstd = rsqrtf(row_allsum16(q) * (1.0f / H) + ln_eps);
+    float acc[HEAD_MAX_A + 1];
+#pragma unroll
+    for (int k = 0; k <= HEAD_MAX_A; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * (cl + 16 * j);
+        const float4 gm = ld4(ln_gamma + c), bt = ld4(ln_beta + c);
+        const float yy[4] = {xa[j][0] * rstd * gm.x + bt.x, xa[j][1] * rstd * gm.y + bt.y, xa[j][2] * rstd * gm.z + bt.z,
+                             xa[j][3] * rstd * gm.w + bt.w};
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_A; ++k) {
+            if (k < A) {
+                const float4 w = ld4(w_mu + (long long)k * H + c);
+                acc[k] += yy[0] * w.x + yy[1] * w.y + yy[2] * w.z + yy[3] * w.w;
+            }
+        }
+        const float4 w = ld4(w_v + c);
+        acc[HEAD_MAX_A] += yy[0] * w.x + yy[1] * w.y + yy[2] * w.z + yy[3] * w.w;
+    }
+#pragma unroll
+    for (int k = 0; k <= HEAD_MAX_A; ++k)
+        if (k < A || k == HEAD_MAX_A) acc[k] = row_allsum16(acc[k]);
+    if (cl == 0) {
+        float v = acc[HEAD_MAX_A] + b_v[0];
+        if (normalize_value) v = fminf(fmaxf(v, -5.0f), 5.0f) * vstd[0] + vmean[0];
+        value_out[e] = v;
+        float nlp = 0.9189385332046727f * A;
+        unsigned r[4];
+        for (int k = 0; k < A; k += 2) {
+            philox4((unsigned)e, (unsigned)ctr, 0x504f4c59u | 0u, (unsigned)(k >> 1), seed_lo, seed_hi, r);
+            const float u1 = 1.0f - (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+            const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * __logf(u1));
+            float sn, cs;
+            __sincosf(6.283185307179586f * u2, &sn, &cs);
+            const float eps2[2] = {rad * cs, rad * sn};
+            for (int qq = 0; qq < 2 && k + qq < A; ++qq) {
+                const int kk = k + qq;
+                const float m = acc[kk] + b_mu[kk], ls = logstd[kk], sg = __expf(ls);
+                const float a = m + sg * eps2[qq];
+                mu_out[e * A + kk] = m;
+                sigma_out[e * A + kk] = sg;
+                action_out[e * A + kk] = a;
+                nlp += 0.5f * eps2[qq] * eps2[qq] + ls;
+            }
+        }
+        neglogp_out[e] = nlp;
+    }
+}
+
 #define ROLLOUT_POST_BLOCKS 1024
 __global__ __launch_bounds__(256) void rollout_post_kernel(
     long long N, int H, const float* __restrict__ rew, const long long* __restrict__ reset,
@@ -4145,6 +4230,13 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
         (normalize_value && (!value_mean || !value_std)) || ((ln_gamma == nullptr) != (ln_beta == nullptr)))
         return VINE_ERR_INVALID_ARG;
     if (ln_gamma && H != 256) return VINE_ERR_UNSUPPORTED;
+    if (ln_gamma && (N & 15) == 0) {             // 16 lanes per env row: 16 rows per 256-thread workgroup
+        hipLaunchKernelGGL(policy_head16_kernel, dim3((unsigned)(N / 16)), dim3(256), 0, (hipStream_t)stream, (long long)N,
+                           (int)A, y, w_mu, b_mu, w_v, b_v, logstd, value_mean, value_std, (int)normalize_value,
+                           (unsigned)seed, (unsigned)(seed >> 32), (const long long*)counter, mu_out, sigma_out, value_out,
+                           action_out, neglogp_out, ln_gamma, ln_beta, ln_eps);
+        return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    }
     const int threads = 256;                     // 4 waves per workgroup, one env per wave at a time
     long long blocks = (N + 3) / 4;
     if (blocks > 2048) blocks = 2048;
