@@ -241,6 +241,88 @@ def test_lstm_backward_mfma_matches_gemm_plus_pointwise(B, H, use_dones):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("low_precision", [False, True])
+def test_lstm_sequence_kernels_match_float64_autograd(low_precision):
+    """The persistent LSTM kernels against an INDEPENDENT reference: the dones-masked LSTM recurrence written out in
+    float64 torch on the same bf16-rounded operands, its autograd giving the gradients w.r.t. the gate pre-activations
+    (= dG) -- not against this repo's own step kernels.  Tolerances = bf16 rounding of the stored activations / dG."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    lib = fused._lib()
+    B, T, H, width, wpad = 256, 4, 256, 92, 96
+    bf = torch.bfloat16
+    xfull = torch.zeros(B * T, wpad, device=dev, dtype=bf)
+    xfull[:, :width] = (torch.randn(B * T, width, device=dev) * 0.7).to(bf)
+    w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
+    w_hh = (torch.randn(4 * H, H, device=dev) / 16).to(bf)
+    bias = torch.randn(4 * H, device=dev) * 0.1
+    h0, c0 = torch.randn(B, H, device=dev) * 0.5, torch.randn(B, H, device=dev) * 0.5
+    dones = (torch.rand(B * T, device=dev) < 0.25).to(torch.uint8)
+    wtile, whh_tiled = torch.empty(4 * H * (wpad + H), device=dev, dtype=bf), torch.empty(4 * H * H, device=dev, dtype=bf)
+    prep = fused.CopyBatch()
+    prep.add_lstm_tiles(w_ih, w_hh, wpad, wtile, whh_tiled)
+    prep.flush(xfull)
+    cdt = bf if low_precision else torch.float32
+    bufs = fused._lstm_state_buffers(xfull, w_hh, h0, c0, dones, T, True, c_dtype=cdt)
+    c_last = torch.empty(B, H, device=dev) if low_precision else None
+    out, c_all, gates, hp = fused._lstm_forward_steps(lib, xfull, None, w_hh, bias, h0, c0, dones, T, True, buffers=bufs,
+                                                      c0_direct=c0, wtile=wtile, c_last=c_last)
+    g_out = torch.randn(B * T, H, device=dev) * 0.1
+    g_in = g_out.to(bf) if low_precision else g_out
+    dG, part = fused._lstm_backward_steps(lib, g_in, w_hh, c_all, gates, dones, T, c0_direct=c0, w_hh_tiled=whh_tiled,
+                                          c_last=c_last)
+    torch.cuda.synchronize()
+    # float64 reference (rl_games' LSTMWithDones: the state is zeroed where the PREVIOUS step was terminal)
+    xd = xfull[:, :width].double().view(B, T, width)
+    Wi, Wh, bd = w_ih.double(), w_hh.double(), bias.double()
+    keep = 1.0 - dones.view(B, T).double()
+    h, c = h0.double(), c0.double()
+    zs, hs = [], []
+    for t in range(T):
+        h, c = h * keep[:, t:t + 1], c * keep[:, t:t + 1]
+        # the kernels feed the recurrent product with the bf16-rounded masked state
+        z = xd[:, t] @ Wi.t() + h.to(bf).double() @ Wh.t() + bd
+        z.requires_grad_(True)
+        z.retain_grad()
+        i, f, g, o = z.chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        zs.append(z); hs.append(h)
+    ref_out = torch.stack(hs, 1).reshape(B * T, H)
+    assert float((out.double() - ref_out.detach()).abs().max()) < 2e-5 * 50      # fp32 arithmetic on identical operands
+    assert float(((c_last if low_precision else c_all[T]).double() - c.detach()).abs().max()) < 1e-3
+    # backward: cut the graph at the pre-activations (h_{t-1} enters the next product detached-and-rounded, so the
+    # recurrent path is propagated by hand exactly as the kernel does: dh_{t-1} += keep_t * (dG_t @ w_hh))
+    dGs = [None] * T
+    dh_next = torch.zeros(B, H, device=dev, dtype=torch.float64)
+    dc_next = torch.zeros(B, H, device=dev, dtype=torch.float64)
+    go = (g_in.double() if low_precision else g_out.double()).view(B, T, H)
+    hcs = []
+    h, c = h0.double(), c0.double()
+    for t in range(T):          # recompute with leaves per step
+        hm, cm = (h * keep[:, t:t + 1]).detach(), (c * keep[:, t:t + 1]).detach().requires_grad_(True)
+        z = (xd[:, t] @ Wi.t() + hm.to(bf).double() @ Wh.t() + bd).detach().requires_grad_(True)
+        i, f, g, o = z.chunk(4, 1)
+        c = torch.sigmoid(f) * cm + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        hcs.append((z, cm, h, c))
+    for t in reversed(range(T)):
+        z, cm, h, c = hcs[t]
+        gz, gc = torch.autograd.grad([h, c], [z, cm], [go[:, t] + dh_next, dc_next])
+        dGs[t] = gz
+        dc_next = gc * keep[:, t:t + 1]
+        # the kernel multiplies the bf16-rounded dG by w_hh
+        dh_next = (gz.to(bf).double() @ Wh) * keep[:, t:t + 1]
+    ref_dG = torch.stack(dGs, 1).reshape(B * T, 4 * H)
+    scale = float(ref_dG.abs().max())
+    err = (dG.double() - ref_dG).abs()
+    tol_max, tol_mean = (3e-2, 2e-3) if low_precision else (1.5e-2, 1e-3)
+    assert float(err.max()) < tol_max * scale and float(err.mean()) < tol_mean * scale, (float(err.max()) / scale, float(err.mean()) / scale)
+    sb = part.double().sum(0)
+    assert float((sb - ref_dG.sum(0)).abs().max()) < 2e-2 * float(ref_dG.sum(0).abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,use_dones", [(8192, True), (96, False), (32, True)])
 def test_lstm_sequence_kernels_equal_step_kernels(B, use_dones):
     """The persistent sequence kernels (ONE launch for all T steps: h_t / dG_t in LDS, c_t / dc_t in registers, weights
