@@ -548,6 +548,71 @@ def test_weight_grad_cat_single_operand(M, N, stride, off):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,raw", [(32768, True), (4096, True), (4096, False)])
+def test_mlp3_kernels_match_float64_autograd(n, raw):
+    """The one-launch MLP (vine_mlp3_elu_mfma: observation normalisation + three Linear+ELU layers, activations carried
+    in registers) and its one-launch backward (vine_mlp3_bwd_elu_mfma) against float64 torch on the same bf16-rounded
+    operands: activations, the normalised observation block, the three pre-activation gradients and the per-workgroup
+    bias partial sums."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(21)
+    lib = fused._lib()
+    st = torch.cuda.current_stream().cuda_stream
+    bf = torch.bfloat16
+    F_in, U, K0 = 28, 64, 1024
+    obs = torch.randn(n, F_in, device=dev) * 3.0 + 0.5
+    mean, var = torch.randn(F_in, device=dev, dtype=torch.float64) * 0.3, torch.rand(F_in, device=dev, dtype=torch.float64) + 0.5
+    xn = ((obs - mean.float()) / torch.sqrt(var.float() + 1e-5)).clamp(-5, 5)
+    xfull = torch.full((n, 96), float("nan"), device=dev, dtype=bf)
+    if not raw:
+        xfull[:, U:U + F_in] = xn.to(bf)
+        xfull[:, U + F_in:] = 0
+    W1, W2, W3 = ((torch.randn(o, i, device=dev) / i ** 0.5).to(bf) for o, i in ((256, F_in), (128, 256), (64, 128)))
+    b1, b2, b3 = (torch.randn(o, device=dev) * 0.1 for o in (256, 128, 64))
+    w1p = torch.zeros(256, 32, device=dev, dtype=bf)
+    w1p[:, :F_in] = W1
+    act1, act2 = torch.empty(n, 256, device=dev, dtype=bf), torch.empty(n, 128, device=dev, dtype=bf)
+    assert lib.vine_mlp3_elu_mfma(n, xfull.data_ptr() + 2 * U, 96, obs.data_ptr() if raw else None, F_in,
+                                  mean.data_ptr() if raw else None, var.data_ptr() if raw else None, 1e-5, 5.0, w1p.data_ptr(),
+                                  b1.data_ptr(), 256, W2.data_ptr(), 256, b2.data_ptr(), 128, W3.data_ptr(), 128, b3.data_ptr(), 64,
+                                  1.0, act1.data_ptr(), act2.data_ptr(), xfull.data_ptr(), 96, st) == 0
+    torch.cuda.synchronize()
+    x0 = xfull[:, U:U + F_in]
+    assert torch.equal(x0, xn.to(bf)) and (xfull[:, U + F_in:].float() == 0).all()
+    elu = torch.nn.functional.elu
+    a1 = elu(x0.double() @ W1.double().t() + b1.double())
+    a2 = elu(act1.double() @ W2.double().t() + b2.double())            # each layer from the kernel's own (rounded) input
+    a3 = elu(act2.double() @ W3.double().t() + b3.double())
+    for name, got, ref in (("act1", act1, a1), ("act2", act2, a2), ("act3", xfull[:, :U], a3)):
+        err = (got.double() - ref).abs() / (ref.abs() + 1.0)
+        assert float(err.max()) < 6e-3, (name, float(err.max()))            # one bf16 rounding of the output
+    # ---- backward
+    dG = (torch.randn(n, K0, device=dev) * 0.05).to(bf)
+    Wt0 = (torch.randn(U, K0, device=dev) / K0 ** 0.5).to(bf)               # the MLP block of w_ih, transposed
+    Wt1, Wt2 = W3.t().contiguous(), W2.t().contiguous()                      # [128, 64], [256, 128]
+    gz3, gz2, gz1 = (torch.empty(n, c, device=dev, dtype=bf) for c in (64, 128, 256))
+    R = 128 if (n % 128 == 0 and n >= 32768) else 64
+    p3, p2, p1 = (torch.empty(n // R, c, device=dev) for c in (64, 128, 256))
+    assert lib.vine_mlp3_bwd_elu_mfma(n, dG.data_ptr(), K0, K0, Wt0.data_ptr(), K0, Wt1.data_ptr(), 64, Wt2.data_ptr(), 128,
+                                      xfull.data_ptr(), 96, act2.data_ptr(), act1.data_ptr(), 64, 128, 256, 1.0,
+                                      gz3.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), p3.data_ptr(), p2.data_ptr(),
+                                      p1.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    dact = lambda a: torch.where(a.double() > 0, torch.ones_like(a, dtype=torch.float64), a.double() + 1.0)      # ELU' from the output
+    r3 = (dG.double() @ Wt0.double().t()) * dact(xfull[:, :U])
+    r2 = (gz3.double() @ Wt1.double().t()) * dact(act2)
+    r1 = (gz2.double() @ Wt2.double().t()) * dact(act1)
+    for name, got, ref, part in (("gz3", gz3, r3, p3), ("gz2", gz2, r2, p2), ("gz1", gz1, r1, p1)):
+        scale = float(ref.abs().max())
+        assert float((got.double() - ref).abs().max()) < 6e-3 * scale, name
+        sums, rs = part.double().sum(0), ref.sum(0)
+        assert float((sums - rs).abs().max()) < 1e-3 * float(rs.abs().max()) + 1e-4 * scale, name
+    assert lib.vine_mlp3_elu_mfma(n + 8, xfull.data_ptr() + 2 * U, 96, None, 0, None, None, 0.0, 0.0, w1p.data_ptr(), b1.data_ptr(),
+                                  256, W2.data_ptr(), 256, b2.data_ptr(), 128, W3.data_ptr(), 128, b3.data_ptr(), 64, 1.0, None,
+                                  None, xfull.data_ptr(), 96, st) == -2
+
+
+@pytest.mark.gpu
 def test_weight_grad_group_equals_single_launches(monkeypatch):
     """The three MLP weight gradients of the update in ONE launch (vine_weight_grad_group) are bit-identical to three
     single launches of the same kernel family, and match the float64 products."""
