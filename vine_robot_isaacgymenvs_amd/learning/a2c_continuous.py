@@ -658,13 +658,35 @@ class A2CAgent:
             mb_advs = discount_values(self.gamma, self.tau, fdones, self.last_values, mb_fdones, buf["values"],
                                       buf["rewards"])
             mb_returns = mb_advs + buf["values"]
-        batch = {k: swap_and_flatten01(buf[k]) for k in ("obses", "actions", "neglogpacs", "values", "mus", "sigmas", "dones")}
+        # [T, N, ...] -> [N * T, ...]: straight into the update graphs' static dataset tensors when they exist (one
+        # transposing copy per tensor instead of a transposing copy + a copy into the static storage)
+        st = getattr(self, "_ds_static", None) if (self.use_graphs and self.is_cuda) else None
+        ds_key = {"obses": "obs", "actions": "actions", "neglogpacs": "old_logp_actions", "mus": "mu", "sigmas": "sigma",
+                  "dones": "dones"}
+
+        def flat(k):
+            src = buf[k]
+            dst = st.get(ds_key.get(k)) if st is not None else None
+            sz = src.size()
+            if dst is not None and dst.is_contiguous() and dst.dtype == src.dtype and \
+                    tuple(dst.shape) == (sz[0] * sz[1], *sz[2:]):
+                dst.view(sz[1], sz[0], *sz[2:]).copy_(src.transpose(0, 1))
+                return dst
+            return swap_and_flatten01(src)
+        batch = {k: flat(k) for k in ("obses", "actions", "neglogpacs", "values", "mus", "sigmas", "dones")}
         batch["returns"] = swap_and_flatten01(mb_returns)
         batch["played_frames"] = self.batch_size
         states = []
-        for mb_s in self.mb_rnn_states:
+        for i, mb_s in enumerate(self.mb_rnn_states):
             t_size = mb_s.size()[0] * mb_s.size()[2]
-            states.append(mb_s.permute(1, 2, 0, 3).reshape(-1, t_size, mb_s.size()[3]))
+            src = mb_s.permute(1, 2, 0, 3)
+            dst = st["rnn_states"][i] if st is not None else None
+            if dst is not None and dst.is_contiguous() and dst.dtype == mb_s.dtype and \
+                    tuple(dst.shape) == (mb_s.size()[1], t_size, mb_s.size()[3]):
+                dst.view(src.shape).copy_(src)
+                states.append(dst)
+            else:
+                states.append(src.reshape(-1, t_size, mb_s.size()[3]))
         batch["rnn_states"] = states
         return batch
 
@@ -771,8 +793,9 @@ class A2CAgent:
                 for k, v in ds.items():
                     if isinstance(v, list):
                         for dst, src in zip(st[k], v):
-                            dst.copy_(src)
-                    else:
+                            if dst.data_ptr() != src.data_ptr():     # (else: written in place by play_steps_rnn)
+                                dst.copy_(src)
+                    elif st[k].data_ptr() != v.data_ptr():
                         st[k].copy_(v)
             self.dataset = st
         else:
