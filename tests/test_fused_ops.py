@@ -1320,7 +1320,7 @@ def test_fused_rollout_matches_stock_and_graph_replay(mixed):
             buf = agent.buf
             nlp = ModelA2CContinuousLogStd.neglogp(buf["actions"], buf["mus"], buf["sigmas"], torch.log(buf["sigmas"]))
             assert torch.allclose(nlp, buf["neglogpacs"], atol=2e-4)
-            states = [agent.mb_rnn_states[0][2], agent.mb_rnn_states[1][2]]       # LSTM state stored before step 8
+            states = [agent.mb_rnn_states[0][:, :, 2].contiguous(), agent.mb_rnn_states[1][:, :, 2].contiguous()]   # LSTM state stored before step 8
             res = agent.model({"is_train": False, "obs": buf["obses"][8], "rnn_states": states})
             assert torch.allclose(res["mus"], buf["mus"][8], atol=tol)
             assert torch.allclose(res["values"], buf["values"][8], atol=tol * 5)       # un-normalised value scale

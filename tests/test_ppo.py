@@ -176,7 +176,9 @@ def test_rollout_buffers_and_dataset_layout():
     assert torch.equal(batch["obses"][3 * T + 5], agent.buf["obses"][5, 3])
     assert batch["rnn_states"][0].shape == (1, N * T // agent.seq_len, 256)
     # stored LSTM state of chunk c of env e sits at sequence index e*(T/seq)+c
-    assert torch.equal(batch["rnn_states"][1][0, 3 * (T // 4) + 2], agent.mb_rnn_states[1][2, 0, 3])
+    # (the rollout stores them as [layer, env, chunk, H], i.e. in dataset order already: the dataset tensor is a view)
+    assert torch.equal(batch["rnn_states"][1][0, 3 * (T // 4) + 2], agent.mb_rnn_states[1][0, 3, 2])
+    assert batch["rnn_states"][1].data_ptr() == agent.mb_rnn_states[1].data_ptr()
     # first stored dones are the initial ones (rl_games starts with dones = 1)
     assert bool((agent.buf["dones"][0] == 1).all())
     # reward shaper (scale 0.01) applied; bootstrap only where time_outs

@@ -358,7 +358,9 @@ class A2CAgent:
             self.head_seed = (int(self.params.get("seed", 0) or 0) + 7919 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF
         self.rnn_states = [s.clone() for s in self.model.get_default_rnn_state(N, dev)]
         n_chunks = T // self.seq_len
-        self.mb_rnn_states = [torch.zeros((n_chunks, 1, N, s.shape[-1]), **f32) for s in self.rnn_states]
+        # initial LSTM state of every sequence, stored in the DATASET's order ([layer, env, chunk, H] = [1, N * chunks, H]
+        # with index env * chunks + chunk): the rollout writes each state once, no permuting copy afterwards
+        self.mb_rnn_states = [torch.zeros((1, N, n_chunks, s.shape[-1]), **f32) for s in self.rnn_states]
         self.last_values = torch.zeros((N, 1), **f32)
         self._head_scratch = [torch.zeros((N, self.actions_num), **f32) for _ in range(3)] + [torch.zeros(N, **f32)]
         self._setup_fast_inference()
@@ -547,7 +549,7 @@ class A2CAgent:
         for n in range(self.horizon_length):
             if n % self.seq_len == 0:
                 for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
-                    mb_s[n // self.seq_len].copy_(s_)
+                    mb_s[:, :, n // self.seq_len].copy_(s_)
             if fast:
                 y = self._infer(obs)
             else:
@@ -592,7 +594,7 @@ class A2CAgent:
         for n in range(self.horizon_length):
             if n % self.seq_len == 0:
                 for s, mb_s in zip(self.rnn_states, self.mb_rnn_states):
-                    mb_s[n // self.seq_len].copy_(s)
+                    mb_s[:, :, n // self.seq_len].copy_(s)
             res = self.get_action_values(obs)
             self.rnn_states = list(res["rnn_states"])
             buf["obses"][n].copy_(obs)
@@ -677,16 +679,8 @@ class A2CAgent:
         batch["returns"] = swap_and_flatten01(mb_returns)
         batch["played_frames"] = self.batch_size
         states = []
-        for i, mb_s in enumerate(self.mb_rnn_states):
-            t_size = mb_s.size()[0] * mb_s.size()[2]
-            src = mb_s.permute(1, 2, 0, 3)
-            dst = st["rnn_states"][i] if st is not None else None
-            if dst is not None and dst.is_contiguous() and dst.dtype == mb_s.dtype and \
-                    tuple(dst.shape) == (mb_s.size()[1], t_size, mb_s.size()[3]):
-                dst.view(src.shape).copy_(src)
-                states.append(dst)
-            else:
-                states.append(src.reshape(-1, t_size, mb_s.size()[3]))
+        for mb_s in self.mb_rnn_states:          # already in dataset order: a view, no copy
+            states.append(mb_s.view(mb_s.size()[0], mb_s.size()[1] * mb_s.size()[2], mb_s.size()[3]))
         batch["rnn_states"] = states
         return batch
 
@@ -787,8 +781,8 @@ class A2CAgent:
             # persistent storage: the captured optimiser steps read their minibatch slices at fixed addresses
             st = getattr(self, "_ds_static", None)
             if st is None:
-                st = self._ds_static = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone())
-                                        for k, v in ds.items()}
+                # (the per-sequence LSTM states are persistent rollout buffers in dataset order already: used in place)
+                st = self._ds_static = {k: (list(v) if isinstance(v, list) else v.clone()) for k, v in ds.items()}
             else:
                 for k, v in ds.items():
                     if isinstance(v, list):
