@@ -359,7 +359,8 @@ def main():
             # env step kernel, LSTM/LayerNorm state, loss and optimiser compute in f32; the GEMMs of the PPO update
             # take bf16 operands with f32 accumulation (the reference YAML's mixed_precision: True; it uses fp16
             # autocast).  `other_precision` carries the same iteration with an all-f32 update.
-            out["dtype"] = "f32 (env step, state, loss, optimiser) + bf16 GEMM operands / f32 accumulate (PPO update)"
+            out["dtype"] = ("f32 (env step, recurrent state, LayerNorm/heads, loss, parameter gradients, optimiser) + bf16 GEMM "
+                            "operands and backward-only saved activations / f32 accumulate (PPO update)")
         if world == 1 and not args.no_saturated:
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:

@@ -168,8 +168,9 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         dist.all_gather(gathered, chk)
         in_sync = all(bool(torch.equal(g, gathered[0])) for g in gathered)
     frames = agent.horizon_length * agent.num_actors
-    precision = ("bf16 GEMM operands, f32 accumulate/state/loss/optimiser (mixed_precision: True, the reference YAML's "
-                 "value)" if agent.fused_mixed else
+    precision = ("bf16 GEMM operands and backward-only saved activations (gates, saved cell states, dG, dh), f32 "
+                 "accumulate/recurrent state/heads/loss/optimiser (mixed_precision: True, the reference YAML's value)"
+                 if agent.fused_mixed else
                  "torch autocast %s" % conf.get("mixed_precision_dtype") if agent.mixed_precision else "f32")
     other = None
     if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
