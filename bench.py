@@ -26,6 +26,11 @@ if REPO not in sys.path:
 
 ALGO_BYTES_PER_ENV_STEP = {28: 320, 18: 280}   # reads 112 B + writes 205 B (obs 28) -> 320 B
 HBM_PEAK_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# MI355X_MICROARCH.md cycle table: `v_fma_f32` (wave64) occupies a SIMD-32 for 2 cycles (4 only for a lone wave's own stream):
+# 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1.2288e12 wave-instructions/s; = 64 FLOP/clk/SIMD = 157.3 TFLOP/s of fp32 FMA.
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 2.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+ALGO_FLOPS_PER_ENV_STEP = 27149.0               # oracle counting build: 40 F_sub (663) + 4 F_act (61) + F_post (385); DESIGN.md section 7
 
 
 def parse_args():
@@ -46,6 +51,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="ppo mode: skip the run in the other update precision")
     p.add_argument("--no-saturated", action="store_true", help="skip the 2^20-env run of the step kernel")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip the env-step timings of the other BASELINE configs (4096 free-space, shelf, default pipe)")
     p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
     p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
                    help="ppo mode: update precision: off = fp32, bf16 = hand-written mixed precision (the packaged "
@@ -53,7 +60,7 @@ def parse_args():
     return p.parse_args()
 
 
-def make_env(args, rank, device_index, world=1):
+def make_env(args, rank, device_index, world=1, extra_overrides=()):
     from vine_robot_isaacgymenvs_amd import load_config
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
     strong = getattr(args, "scaling", "weak") == "strong" and world > 1
@@ -63,7 +70,7 @@ def make_env(args, rank, device_index, world=1):
           "task.env.CREATE_PIPE=False",      # default task YAML except CREATE_PIPE / CAPTURE_VIDEO
           "sim_device=cuda:%d" % device_index,
           "rl_device=cuda:%d" % device_index, "multi_gpu=%s" % (args.gpus > 1)]
-    cfg = load_config(overrides=ov)
+    cfg = load_config(overrides=ov + list(extra_overrides))
     if strong:
         # one batch of --num-envs envs cut into W shards: same seed everywhere, the RNG keyed by the global env id, and
         # the global minibatch (PY:80: 32768 samples) split evenly so that the optimiser takes the same number of steps
@@ -121,7 +128,7 @@ def pmc_valu_per_wave(kernel):
 def saturated_env_rate(args, device_index, n_sat=1 << 20, steps=40):
     """The same kernel with enough envs to give every SIMD several waves (16384 envs are 256 waves for 1024 SIMDs):
     the throughput the kernel itself sustains, priced against HBM and against the fp32 VALU issue rate
-    (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)."""
+    (VALU_ISSUE_PEAK: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction)."""
     import copy
     import torch
     a = copy.copy(args)
@@ -144,11 +151,74 @@ def saturated_env_rate(args, device_index, n_sat=1 << 20, steps=40):
     out["kernel"] = env.step_kernel_name
     per_wave = pmc_valu_per_wave(out["kernel"] + "<")
     if per_wave:
-        peak = 1024 * 2.4e9 / 4.0
+        peak = VALU_ISSUE_PEAK
         out.update({"valu_insts_per_wave_step": per_wave, "valu_wave_insts_per_sec": rate / 64.0 * per_wave,
                     "valu_issue_peak": peak, "valu_issue_frac": rate / 64.0 * per_wave / peak})
     env.close()
     return out
+
+
+def compute_roofline(kernel_name, n_envs, kernel_ms):
+    """What actually binds the env-step kernel (~85 flop per algorithmic byte, state resident in L2): the
+    fp32 VALU.  Two fractions at the metric's own env count: VALU ISSUE (instructions per wave from the committed PMC
+    pass of this kernel x waves per launch / kernel time, against VALU_ISSUE_PEAK) and fp32 FLOPs (the oracle's
+    instrumented algorithmic flop count per env step, against the 157.3 TFLOP/s vector peak)."""
+    lanes_per_env = 4 if "quad" in kernel_name else 1
+    waves = (n_envs * lanes_per_env + 63) // 64
+    per_wave = pmc_valu_per_wave(kernel_name + "<")
+    out = {"waves_per_launch": waves, "valu_issue_peak_wave_insts_per_sec": VALU_ISSUE_PEAK,
+           "algorithmic_flops_per_env_step": ALGO_FLOPS_PER_ENV_STEP,
+           "achieved_TFLOPs": ALGO_FLOPS_PER_ENV_STEP * n_envs / (kernel_ms * 1e-3) / 1e12,
+           "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS}
+    out["flop_frac"] = out["achieved_TFLOPs"] / FP32_VECTOR_PEAK_TFLOPS
+    if per_wave:
+        rate = per_wave * waves / (kernel_ms * 1e-3)
+        out.update({"valu_insts_per_wave_step": per_wave, "valu_wave_insts_per_sec": rate,
+                    "valu_issue_frac": rate / VALU_ISSUE_PEAK})
+    return out
+
+
+# The other single-GPU BASELINE.json configurations and the reference's default obstacle, env step kernel only (HIP events
+# around the C-ABI launch, resident random actions): configs[1] = 4096 envs with the README.md:63 free-space overrides,
+# configs[4]'s per-GPU share = vine_randomize + CREATE_SHELF + ACTION_DELAY=1 at 16384 envs, and the task YAML's own default
+# (CREATE_PIPE: True, TY:35).
+OTHER_CONFIGS = [
+    ("configs[1]: 4096 envs free-space reaching (README.md:63 overrides), fp32", 4096,
+     ["task.env.CREATE_SHELF=False", "task.env.CREATE_PIPE=False", "OBSERVATION_TYPE=TIP_AND_CART_AND_OBJ_INFO",
+      "task.env.maxEpisodeLength=100", "task.env.SUCCESS_DIST=0.04", "task.env.MIN_TARGET_Y=-0.4", "task.env.MAX_TARGET_Y=0.4",
+      "task.env.MIN_TARGET_Z=0.55", "task.env.MAX_TARGET_Z=0.7", "RAIL_SOFT_LIMIT=0.25", "RAIL_P_GAIN=30", "RAIL_ACCELERATION=6"]),
+    ("configs[4] per-GPU share: 16384 envs, vine_randomize + CREATE_SHELF + ACTION_DELAY=1", 16384,
+     ["vine_randomize=True", "task.env.CREATE_SHELF=True", "task.env.CREATE_PIPE=False", "task.env.ACTION_DELAY=1"]),
+    ("task YAML default obstacle: 16384 envs, CREATE_PIPE=True (TY:35)", 16384, ["task.env.CREATE_PIPE=True"]),
+]
+
+
+def other_config_rates(args, device_index, steps=200):
+    import copy
+    import torch
+    rows = []
+    for name, n, ov in OTHER_CONFIGS:
+        a = copy.copy(args)
+        a.num_envs = n
+        if any(o.startswith("OBSERVATION_TYPE=") for o in ov):
+            a.obs_type = [o for o in ov if o.startswith("OBSERVATION_TYPE=")][0].split("=")[1]
+        env, _ = make_env(a, 0, device_index, extra_overrides=ov)
+        g = torch.Generator(device=env.device).manual_seed(7)
+        pool = [torch.rand((n, 2), device=env.device, generator=g) * 2 - 1 for _ in range(16)]
+        for i in range(60):                  # past the all-env reset of the first step; episodes de-synchronise
+            env._native_step(pool[i % 16], env.obs_buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            env._native_step(pool[i % 16], env.obs_buf)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        rows.append({"config": name, "num_envs": n, "kernel": env.step_kernel_name, "kernel_us": ms * 1e3,
+                     "env_steps_per_sec": n / (ms * 1e-3),
+                     "hbm_frac": ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        env.close()
+    return rows
 
 
 def usable_cores():
@@ -350,9 +420,12 @@ def main():
                                    "(BASELINE.json configs[2]; x8 ranks = configs[3])"
                                    % (n, env.num_obs, bool(args.randomize), mode),
                        "mode": mode, "num_envs_per_gpu": n, "parallelism": "env-sharded dp%d" % world},
-            "roofline": {"bound": "hbm", "kernel": env.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            # achieved / peak / frac: the mandated HBM pricing of the algorithmic bytes.  `bound` names what really limits the
+            # kernel (fp32 VALU issue: ~85 flop per algorithmic byte, working set resident in L2) and `compute` prices it.
+            "roofline": {"bound": "valu", "kernel": env.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
+                         "compute": compute_roofline(env.step_kernel_name, n, kernel_ms)},
         }
         out.update(extra)
         if str(extra.get("update_precision", "")).startswith("bf16"):
@@ -363,6 +436,8 @@ def main():
                             "operands and backward-only saved activations / f32 accumulate (PPO update)")
         if world == 1 and not args.no_saturated:
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
+        if world == 1 and not args.no_other_configs:
+            out["configs"] = other_config_rates(args, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds, mode, cfg)
         print(json.dumps(out), file=real_stdout, flush=True)

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define VINE_ABI_VERSION 2         /* 2: VineConfig.env_id_offset, VINE_FLAG_INTROSPECT, vine_set_introspection, vine_stats */
+#define VINE_ABI_VERSION 3         /* 2: VineConfig.env_id_offset, VINE_FLAG_INTROSPECT, vine_set_introspection, vine_stats;
+                                      3: VineConfig.effort_limit */
 #define VINE_NUM_LINKS 5          /* N_REVOLUTE_DOFS, V5:54 */
 #define VINE_NUM_DOFS 6           /* 1 prismatic + 5 revolute, V5:83 */
 #define VINE_NUM_ACTIONS 2        /* V5:171 */
@@ -145,6 +146,10 @@ typedef struct VineConfig {
                                         (seed, env_id_offset + env, step, purpose), so a shard of a larger batch (one rank of a
                                         strong-scaling run; the reference shards by giving every rank its own seed, TR:78)
                                         draws exactly what the same envs draw inside the whole batch.  0 by default. */
+    float effort_limit;              /* clamp of the five joint efforts handed to the simulator (Isaac Gym clamps
+                                        set_dof_actuation_force_tensor to the DOF `effort` property; the URDF has no
+                                        <limit effort>: Vine5LinkMovingBase.urdf:278,292).  Applied to the held efforts of
+                                        V5:1101-1106, revolute DOFs only; 0 = no clamp (default; assumption switch) */
 } VineConfig;
 
 /* Persistent per-env state, struct-of-arrays: field f of env e lives at
@@ -244,7 +249,11 @@ int vine_set_step_count(VineHandle* h, int64_t step_count);
 int vine_bind_reward_matrix(VineHandle* h, float* reward_matrix);
 
 /* Arm / disarm VINE_FLAG_INTROSPECT for the steps launched from now on (a step already captured in a hipGraph keeps the
- * setting it was captured with).  vine_bind_reward_matrix(non-NULL) arms it too. */
+ * setting it was captured with).  vine_bind_reward_matrix(non-NULL) arms it too.  Without it the tip / cart rigid-body
+ * fields (VF_TIP_*, VF_CART_*) are stored only by envs reset in the step (the step re-derives them from the DOF state):
+ * hosts that READ them between steps must arm it.  Switching it ON mid-run makes the NEXT vine_step refresh those fields
+ * from the DOF state first (one extra small launch on that step's stream; do the switch outside a graph capture), so the
+ * switch does not perturb the trajectory. */
 int vine_set_introspection(VineHandle* h, int on);
 
 /* The dashboard scalars of compute_reward (V5:1250-1322: the ~120 `.mean()/.max()/.item()` the reference evaluates every

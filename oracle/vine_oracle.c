@@ -1242,6 +1242,10 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
         actuation(c, q, qd, cart_vy, u_rail, u_used, scale, &pcv, &pce, eff, cj);
         FLOP_BUCKET(2);
         rail_force = eff[0];
+        if (c->effort_limit > 0) {   /* DOF effort clamp of the simulator (assumption switch, include/vine.h) */
+            const real lim = (real)c->effort_limit;
+            for (int i = 1; i < ND; ++i) eff[i] = eff[i] > lim ? lim : (eff[i] < -lim ? -lim : eff[i]);
+        }
         if (shelf) contact_sum += contact;                           /* VT:348-351 */
         real csum = 0;
         for (int s = 0; s < c->substeps; ++s) {                      /* gym.simulate, VT:356 */

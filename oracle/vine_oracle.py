@@ -35,11 +35,10 @@ def load(precision="f64", omp=False):
     variant = "" if omp else os.environ.get("VINE_ORACLE_VARIANT", "")
     name = "libvine_oracle_%s%s%s.so" % (precision, "_omp" if omp else "", variant)
     path = os.path.join(_BUILD, name)
-    if not os.path.exists(path):
-        if variant == "_asan":
-            subprocess.check_call(["make", "-C", _HERE, "asan"], stdout=subprocess.DEVNULL)
-        else:
-            build()
+    if variant == "_asan":
+        subprocess.check_call(["make", "-C", _HERE, "asan"], stdout=subprocess.DEVNULL)
+    else:
+        build()          # make: a no-op unless vine_oracle.c / include/vine.h changed (never run a stale checker)
     lib = abi.declare(C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0)))
     P = C.POINTER(abi.VineConfig)
     lib.vine_oracle_real_bytes.restype = C.c_int

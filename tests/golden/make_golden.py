@@ -316,6 +316,10 @@ class FakeGym:
             qd0 = ds[e, :, 1].numpy().astype(np.float32)
             eff = self.efforts[e].numpy().astype(np.float32).copy()
             cj = None
+            if self.ocfg.effort_limit > 0:     # the simulator's DOF effort clamp (assumption switch, include/vine.h)
+                lim = np.float32(self.ocfg.effort_limit)
+                assert held, "effort clamp fixture: literal mode only"
+                eff[1:] = np.clip(eff[1:], -lim, lim)
             if not held:
                 eff[1:] = eff[1:] + C_ * qd0[1:]
                 cj = np.full(6, np.float32(self.ocfg.damping), np.float32)
@@ -353,7 +357,7 @@ def reference_task_cfg(num_envs, **env_overrides):
     return cfg
 
 
-def oracle_cfg_from(cfg, held=False):
+def oracle_cfg_from(cfg, held=False, effort_limit=0.0):
     """VineConfig equivalent of a reference cfg dict (FakeGym physics = the product's default mode unless ``held``)."""
     e, rp = cfg["env"], cfg["task"]["randomization_parameters"]
     c = vo.default_config(num_envs=e["numEnvs"])
@@ -381,13 +385,14 @@ def oracle_cfg_from(cfg, held=False):
     c.set_flag(abi.FLAG_USE_SMOOTHED_FPAM, e["USE_SMOOTHED_FPAM"])
     c.set_flag(abi.FLAG_VINE_RANDOMIZE, cfg["task"]["vine_randomize"])
     c.set_flag(abi.FLAG_FPAM_DAMPING_HELD, held)
+    c.effort_limit = effort_limit
     c.dyn_scale_min, c.dyn_scale_max = rp["DYNAMICS_SCALING_MIN"], rp["DYNAMICS_SCALING_MAX"]
     return c
 
 
-def make_task(vt, v5, cfg):
+def make_task(vt, v5, cfg, held=False, effort_limit=0.0):
     vt.EXISTING_SIM = None
-    ocfg = oracle_cfg_from(cfg)
+    ocfg = oracle_cfg_from(cfg, held=held, effort_limit=effort_limit)
     FakeGym(cfg["env"]["numEnvs"], cfg["env"]["CREATE_SHELF"], ocfg, cfg["env"].get("CREATE_PIPE", False))
     task = v5.Vine5LinkMovingBase(cfg=cfg, rl_device="cpu", sim_device="cpu", graphics_device_id=-1, headless=True,
                                   virtual_screen_capture=False, force_render=False)
@@ -558,14 +563,19 @@ def f5_reset_sampling(vt, v5, out):
 def f6_trajectory(vt, v5, out):
     """The real VecTask.step driven for T steps; every reset's drawn values are recorded."""
     N, T = 8, 64
+    # "held_damping008": the reference's LITERAL actuation semantics -- the efforts of V5:1062, velocity term C_j*qd_j
+    # included, held over the whole sim step -- at the DAMPING for which this articulation model is stable under them
+    # (0.08; DESIGN.md section 3); "held_efflim03": the same literal semantics at the YAML's own DAMPING (0.02), bounded by
+    # a simulator-side joint effort clamp of 0.3 N m.  The other three run the product's default mode at the YAML's DAMPING.
     for tag, over in (("delay1", dict(ACTION_DELAY=1)), ("delay0_tipobs", dict(ACTION_DELAY=0, OBSERVATION_TYPE="TIP_AND_CART_AND_OBJ_INFO")),
-                      ("delay2", dict(ACTION_DELAY=2))):
+                      ("delay2", dict(ACTION_DELAY=2)), ("held_damping008", dict(ACTION_DELAY=1, DAMPING=0.08)),
+                      ("held_efflim03", dict(ACTION_DELAY=1))):
         env_over = dict(maxEpisodeLength=20, SUCCESS_DIST=0.12, RAIL_SOFT_LIMIT=0.2, MIN_TARGET_Y=-0.3,
                         MAX_TARGET_Y=-0.1, MIN_TARGET_Z=0.53, MAX_TARGET_Z=0.6, RANDOM_INIT_CART_MIN_Y=-0.02,
                         RANDOM_INIT_CART_MAX_Y=0.2)
         env_over.update(over)
         cfg = reference_task_cfg(N, **env_over)
-        task, gym, ocfg = make_task(vt, v5, cfg)
+        task, gym, ocfg = make_task(vt, v5, cfg, held=tag.startswith("held"), effort_limit=0.3 if "efflim03" in tag else 0.0)
         torch.manual_seed(42)
         g = torch.Generator().manual_seed(2024)
         first = task.reset()

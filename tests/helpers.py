@@ -19,10 +19,22 @@ def base_cfg(num_envs, obs_type=abi.OBS_POS_AND_FD_VEL_AND_OBJ_INFO, randomize=F
     return cfg
 
 
-def f6_cfg(num_envs, action_delay, obs_type):
+F6_CASES = [("delay1", 1, 0, False), ("delay0_tipobs", 0, 1, False), ("delay2", 2, 0, False),
+            ("held_damping008", 1, 0, "damping008"), ("held_efflim03", 1, 0, "efflim03")]
+
+
+def f6_cfg(num_envs, action_delay, obs_type, held=False):
     """The configuration tests/golden/make_golden.py used for the F6 trajectories (env_overrides array inside the
-    fixture): the task YAML's own DAMPING (0.02) in the product's default physics mode."""
+    fixture): the task YAML's own DAMPING (0.02) in the product's default physics mode, or -- ``held`` -- the reference's
+    literal actuation (efforts of V5:1062 incl. C_j*qd_j held over the sim step) at DAMPING 0.08 ("damping008") or at the
+    YAML's DAMPING with a 0.3 N m joint effort clamp ("efflim03")."""
     cfg = base_cfg(num_envs, obs_type)
+    if held:
+        cfg.set_flag(abi.FLAG_FPAM_DAMPING_HELD, True)
+        if held == "efflim03":
+            cfg.effort_limit = 0.3            # at the YAML's own DAMPING (0.02)
+        else:
+            cfg.damping = 0.08
     cfg.max_episode_length = 20
     cfg.success_dist = 0.12
     cfg.rail_soft_limit = 0.2

@@ -1036,6 +1036,64 @@ def test_ppo_loss_kernel_against_reference_text_golden():
 
 
 @pytest.mark.gpu
+def test_default_loss_kernel_against_reference_text_golden_per_sample():
+    """Golden F8 through the kernel the default update actually runs (`ln_heads_loss_kernel`, vine_ln_heads_loss), PER
+    SAMPLE: the kernel reports means over its rows, so every one of the 512 fixture samples is launched as its own batch
+    of identical rows (one workgroup's worth) -- its three statistics are then that sample's actor, clipped-critic and
+    bound terms as the reference's text computes them (common_agent.py:482-516, 427-435).  The heads are injected through
+    the head biases (zero head weights), the sample's neglogp through the action (sigma = 1)."""
+    import os
+    from vine_robot_isaacgymenvs_amd import native
+    from vine_robot_isaacgymenvs_amd.abi import PPO_LOSS_SCRATCH_FLOATS, PPO_PARTIAL_BLOCKS
+    lib = native.load()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f8_ppo_loss_terms.npz"))
+    dev = torch.device("cuda:0")
+    S, A = g["mu"].shape
+    H, NH = 256, A + 1
+    n = lib.vine_ln_heads_loss_rows()
+    const = 0.5 * np.log(2 * np.pi) * A
+    shift = float(const - g["neglogp"].min() + 0.01)          # only old_neglogp - neglogp enters the loss
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(n, H, device=dev, generator=gen)
+    gamma, beta = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+    w = torch.zeros(NH, H, device=dev)
+    logstd = torch.zeros(A, device=dev)
+    heads, dx = torch.empty(n, NH, device=dev), torch.empty(n, H, device=dev)
+    part = torch.empty(PPO_PARTIAL_BLOCKS, 2 * H + NH * H, device=dev)
+    stats, gls = torch.zeros(8, device=dev), torch.zeros(A, device=dev)
+    gmb, gvb = torch.zeros(A, device=dev), torch.zeros(1, device=dev)
+    scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=dev)
+    kl_out, gls_acc = torch.zeros(1, device=dev), torch.zeros(A, device=dev)
+    mu_st, sg_st = torch.empty(n, A, device=dev), torch.empty(n, A, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    full = lambda v, cols=None: (torch.full((n,), float(v), device=dev) if cols is None
+                                 else torch.tensor(np.asarray(v, np.float32), device=dev).expand(n, cols).contiguous())
+    got = np.zeros((S, 3))
+    for i in range(S):
+        mu_i = g["mu"][i]
+        wb = torch.tensor(np.concatenate([mu_i, g["values"][i]]).astype(np.float32), device=dev)
+        act = mu_i.astype(np.float64).copy()
+        act[0] += np.sqrt(2.0 * (float(g["neglogp"][i]) + shift - const))
+        actions = full(act, A)
+        old_mu, old_sigma = full(mu_i, A), torch.ones(n, A, device=dev)
+        rc = lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
+                                    logstd.data_ptr(), actions.data_ptr(), full(g["old_neglogp"][i] + shift).data_ptr(),
+                                    full(g["advantage"][i]).data_ptr(), full(g["old_values"][i, 0]).data_ptr(),
+                                    full(g["returns"][i, 0]).data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(),
+                                    float(g["e_clip"]), 1, 2.0, 0.0, 1e-4, 1.0,
+                                    heads.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
+                                    gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
+                                    mu_st.data_ptr(), sg_st.data_ptr(), st)
+        assert rc == 0
+        got[i] = stats[:3].cpu().numpy()
+    tol = lambda ref: 3e-5 * (1.0 + np.abs(ref))
+    assert (np.abs(got[:, 0] - g["a_loss"]) < tol(g["a_loss"])).all()
+    assert (np.abs(got[:, 1] - g["c_loss"][:, 0]) < tol(g["c_loss"][:, 0])).all()
+    assert (np.abs(got[:, 2] - g["b_loss_soft_bound_1"]) < tol(g["b_loss_soft_bound_1"])).all()
+    assert (g["c_loss"] != g["c_loss_noclip"]).any()          # the clipped branch of the critic term is exercised
+
+
+@pytest.mark.gpu
 def test_fused_update_equals_stock_update():
     """One optimiser step of the agent through the fused path and through the stock composition, from the same
     weights and minibatch: same loss statistics, same updated parameters (to fp32 reduction-order noise)."""

@@ -14,7 +14,7 @@ import pytest
 
 from oracle import vine_oracle as vo
 from vine_robot_isaacgymenvs_amd import abi
-from tests.helpers import base_cfg, f6_cfg, random_state
+from tests.helpers import F6_CASES, base_cfg, f6_cfg, random_state
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,56 @@ def HipEnv(request):
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X (the product has no CPU fallback)")
     from tests.hip_env import HipEnv as H
-    return type("HipEnv_" + request.param, (H,), {"kernel": request.param})
+
+    def init(self, cfg, device_id=0):
+        # the kernel the library REALLY dispatches for this configuration: a "quad" case the four-lanes-per-env kernel
+        # does not cover is skipped (it would silently repeat the "lane" case), a "lane" case must be the one-lane kernel
+        H.__init__(self, cfg, device_id)
+        name = self.lib.vine_step_kernel_name(self.h).decode()
+        if request.param == "quad" and name != "vine_step_quad_kernel":
+            self.close()
+            pytest.skip("vine_step_quad_kernel does not cover this configuration (runs as the 'lane' case)")
+        assert name == {"lane": "vine_step_kernel", "quad": "vine_step_quad_kernel"}[request.param], name
+
+    return type("HipEnv_" + request.param, (H,), {"kernel": request.param, "__init__": init})
+
+
+# Physics-model switches of the step kernel: every instantiation of the substep loop
+# (vine_hip.hip VINE_SUBSTEP_LOOP: implicit x extras) and the literal held-torque actuation of V5:1043-1062.
+# The explicit-damping modes are only stable for weak joint damping / torque feedback (that is assumption P2), hence the
+# scaled-down FPAM coefficients there: the point is HIP-vs-oracle parity of the code path, not the reference's tuning.
+def _explicit(cfg):
+    cfg.set_flag(abi.FLAG_IMPLICIT_JOINT_DAMPING, False)
+    cfg.damping = 0.003
+    for i in range(5):
+        cfg.fpam_C[i] = 0.0
+        cfg.fpam_K[i] *= 0.1
+
+
+def _held(cfg):
+    cfg.damping = 0.08
+    cfg.set_flag(abi.FLAG_FPAM_DAMPING_HELD, True)
+
+
+def _stiff(cfg):
+    cfg.stiffness = 0.5
+
+
+def _linkdamp(cfg):
+    cfg.link_angular_damping = 0.5
+
+
+def _explicit_extras(cfg):
+    _explicit(cfg)
+    cfg.stiffness, cfg.link_angular_damping = 0.05, 0.5
+
+
+def _effort_limit(cfg):
+    cfg.effort_limit = 0.05
+
+
+PHYSICS_MODES = {"default": lambda cfg: None, "held": _held, "explicit": _explicit, "stiffness": _stiff,
+                 "linkdamp": _linkdamp, "explicit_extras": _explicit_extras, "effort_limit": _effort_limit}
 
 
 def pair(HipEnv, cfg, precision="f32"):
@@ -76,11 +125,25 @@ def compare_step(hip_out, orc, hip, pos_tol, vel_tol, obs_tol):
 @pytest.mark.parametrize("delay", [0, 1, 3])
 def test_single_step_matches_oracle(HipEnv, obs_type, randomize, delay):
     """One VecTask.step from identical random mid-episode states, incl. resets, time-outs, RNG draws."""
+    single_step_case(HipEnv, obs_type, randomize, delay, "default")
+
+
+@pytest.mark.parametrize("mode", [m for m in PHYSICS_MODES if m != "default"])
+@pytest.mark.parametrize("randomize", [False, True])
+def test_single_step_physics_modes_match_oracle(HipEnv, mode, randomize):
+    """The same single-step comparison in every physics-model mode the task YAML can select (``physicsModel.*``,
+    ``STIFFNESS``): the literal held-torque actuation of V5:1043-1062 (`held`: both kernels), explicit joint damping,
+    joint stiffness, link angular damping, an effort clamp -- all four instantiations of the substep loop."""
+    single_step_case(HipEnv, 0, randomize, 1, mode)
+
+
+def single_step_case(HipEnv, obs_type, randomize, delay, mode):
     n = 1000   # ragged: not a multiple of the 64-wide workgroup
     cfg = base_cfg(n, obs_type, randomize, action_delay=delay, seed=1234 + delay)
     if randomize:
         cfg.obs_noise_std, cfg.action_noise_std = 0.01, 0.02
         cfg.dyn_scale_min, cfg.dyn_scale_max = 0.9, 1.1
+    PHYSICS_MODES[mode](cfg)
     rng = np.random.default_rng(10 * obs_type + delay)
     for precision, tol in (("f32", (2e-5, 2e-3, 2e-3)), ("f64", (1e-4, 1e-2, 1e-2))):
         hip, orc = pair(HipEnv, cfg, precision)
@@ -366,12 +429,18 @@ def test_first_step_resets_everything(HipEnv):
     assert (st[QVEL] == 0).all()
 
 
-def test_trajectory_tracks_oracle(HipEnv):
+@pytest.mark.parametrize("introspect", [True, False])
+@pytest.mark.parametrize("mode", list(PHYSICS_MODES))
+def test_trajectory_tracks_oracle(HipEnv, mode, introspect):
     """40 consecutive steps (1600 substeps) with resets: float32 round-off may grow, flags must stay identical
-    for every env whose decision margins are not within round-off."""
+    for every env whose decision margins are not within round-off.  Every physics mode; with introspection OFF (the
+    branch training and bench run: body states re-derived by forward kinematics, dashboard fields not stored) the
+    algorithmic outputs and the DOF state are compared, the gated fields are skipped."""
     n, T = 256, 40
-    cfg = base_cfg(n, max_episode_length=25)
+    cfg = base_cfg(n, randomize=True, max_episode_length=25)
+    PHYSICS_MODES[mode](cfg)
     hip, orc = pair(HipEnv, cfg, "f32")
+    hip.set_introspection(introspect)
     rng = np.random.default_rng(5)
     worst_q = 0.0
     mismatched = np.zeros(n, bool)
@@ -382,16 +451,21 @@ def test_trajectory_tracks_oracle(HipEnv):
         mismatched |= (rst != orc.reset_buf)
         ok = ~mismatched
         worst_q = max(worst_q, np.abs(hip.state[QPOS][:, ok] - orc.state[QPOS][:, ok]).max())
+        np.testing.assert_allclose(obs[ok], orc.obs[ok], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(rew[ok], orc.rew[ok], rtol=1e-4, atol=5e-3)
+        np.testing.assert_array_equal(hip.progress[ok], orc.progress[ok])
     assert mismatched.mean() < 0.02          # threshold decisions flipped by round-off only
     assert worst_q < 5e-3
+    hip.close(); orc.close()
 
 
-@pytest.mark.parametrize("tag,delay,obs_type", [("delay1", 1, 0), ("delay0_tipobs", 0, 1), ("delay2", 2, 0)])
-def test_golden_trajectory_from_reference(HipEnv, golden, tag, delay, obs_type):
-    """F6: the reference's real VecTask.step over 64 steps (fixture), replayed on the GPU."""
+@pytest.mark.parametrize("tag,delay,obs_type,held", F6_CASES)
+def test_golden_trajectory_from_reference(HipEnv, golden, tag, delay, obs_type, held):
+    """F6: the reference's real VecTask.step over 64 steps (fixture), replayed on the GPU.  ``held`` = the literal
+    actuation semantics of V5:1043-1062 (efforts incl. C_j*qd_j held over the sim step) at DAMPING 0.08."""
     g = golden("f6_traj_" + tag)
     T, N, _ = g["actions"].shape
-    cfg = f6_cfg(N, delay, obs_type)
+    cfg = f6_cfg(N, delay, obs_type, held)
     hip = HipEnv(cfg)
     for t in range(T):
         hip.bind_reset_values(g["reset_values"][t])
@@ -446,6 +520,68 @@ def test_reset_idx_outside_step(HipEnv):
     np.testing.assert_allclose(hip.state, orc.state, rtol=0, atol=1e-6)
     assert (hip.reset_buf[ids] == 0).all() and (hip.reset_buf[1::3] == 1).all()
     hip.reset_idx(np.zeros(0, np.int64))    # empty id list is a no-op
+
+
+@pytest.mark.parametrize("how", ["reset_idx", "set_introspection", "bind_reward_matrix"])
+def test_lazy_body_states_stay_consistent(HipEnv, how):
+    """With introspection off the four-lanes-per-env kernel does not store the tip / cart rigid-body states every step
+    (they are re-derived from the DOF state).  Whoever CONSUMES the memory copies must still see current values:
+    reset_idx from outside the step (the stale-body rule P5 keeps the pre-reset tip as prev_tip: it must be the tip of the
+    LAST step, not of the env's last in-step reset) and switching introspection on mid-run (directly or through
+    vine_bind_reward_matrix).  Twin run with introspection always on; after the event the two must agree."""
+    n = 512
+    cfg = base_cfg(n, 0, True, action_delay=1, seed=21, max_episode_length=40)
+    rng = np.random.default_rng(9)
+    a, b = HipEnv(cfg), HipEnv(cfg)
+    b.set_introspection(False)
+    for t in range(7):
+        acts = rng.uniform(-1, 1, (n, 2))
+        a.step(acts); b.step(acts)
+    ids = np.arange(1, n, 3)
+    if how == "reset_idx":
+        a.reset_idx(ids); b.reset_idx(ids)
+    elif how == "set_introspection":
+        b.set_introspection(True)
+    else:
+        a.bind_reward_matrix(); b.bind_reward_matrix()
+    for t in range(2):
+        acts = rng.uniform(-1, 1, (n, 2))
+        oa, ob = a.step(acts), b.step(acts)
+        np.testing.assert_allclose(oa[0], ob[0], rtol=0, atol=2e-4)       # fd_tip columns are (tip - prev_tip) * 30
+        np.testing.assert_allclose(oa[1], ob[1], rtol=1e-5, atol=1e-4)
+        np.testing.assert_array_equal(oa[2], ob[2])
+    sa, sb = a.state, b.state
+    np.testing.assert_allclose(sa[QPOS], sb[QPOS], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(sa[QVEL], sb[QVEL], rtol=0, atol=2e-4)
+    if how != "reset_idx":
+        for f in (abi.VF_TIP_Y, abi.VF_TIP_Z, abi.VF_CART_Y, abi.VF_CART_VY, abi.VF_PREV_TIP_Y, abi.VF_PREV_TIP_Z):
+            np.testing.assert_allclose(sa[f], sb[f], rtol=0, atol=2e-5, err_msg="field %d" % f)
+    a.close(); b.close()
+
+
+def test_reset_idx_after_steps_matches_oracle(HipEnv):
+    """reset_idx from outside the step AFTER several steps (the production branch: introspection off), against the
+    oracle: the next step's observation carries the stale tip of the last step (P5), not an older one."""
+    n = 300
+    cfg = base_cfg(n, 0, False, action_delay=1, seed=4, max_episode_length=60)
+    hip, orc = pair(HipEnv, cfg, "f32")
+    hip.set_introspection(False)
+    rng = np.random.default_rng(12)
+    for t in range(6):
+        acts = rng.uniform(-1, 1, (n, 2))
+        hip.step(acts); orc.step(acts)
+    ids = np.arange(0, n, 2)
+    hip.reset_idx(ids); orc.reset_idx(ids)
+    bad = np.zeros(n, bool)
+    for t in range(2):
+        acts = rng.uniform(-1, 1, (n, 2))
+        obs, rew, rst, to = hip.step(acts)
+        orc.step(acts)
+        bad |= rst != orc.reset_buf
+        np.testing.assert_allclose(obs[~bad], orc.obs[~bad], rtol=0, atol=5e-3)
+        np.testing.assert_array_equal(hip.progress, orc.progress)
+    assert bad.mean() < 0.01
+    hip.close(); orc.close()
 
 
 def test_full_size_properties(HipEnv):

@@ -8,7 +8,7 @@ import pytest
 
 from oracle import vine_oracle as vo
 from vine_robot_isaacgymenvs_amd import abi
-from tests.helpers import base_cfg, f6_cfg
+from tests.helpers import F6_CASES, base_cfg, f6_cfg
 
 PRECISIONS = ["f32", "f64"]
 D = C.POINTER(C.c_double)
@@ -162,13 +162,13 @@ def test_f5_reset_sampling(golden, shelf):
     assert abs(np.corrcoef(st[abi.VF_Q0 + 1], st[abi.VF_Q0 + 2])[0, 1]) < 0.12
 
 
-@pytest.mark.parametrize("tag,delay,obs_type", [("delay1", 1, 0), ("delay0_tipobs", 0, 1), ("delay2", 2, 0)])
-def test_f6_step_sequencing(golden, tag, delay, obs_type):
+@pytest.mark.parametrize("tag,delay,obs_type,held", F6_CASES)
+def test_f6_step_sequencing(golden, tag, delay, obs_type, held):
     """The reference's real VecTask.step (VT:319-380) for 64 steps over FakeGym (physics = this oracle, f32,
     held-torque mode): pins reset-next-step ordering, the stale tip after reset, 4x actuation, FIFO, timeouts."""
     g = golden("f6_traj_" + tag)
     T, N, _ = g["actions"].shape
-    cfg = f6_cfg(N, delay, obs_type)
+    cfg = f6_cfg(N, delay, obs_type, held)
     env = vo.OracleEnv(cfg, "f32")
     np.testing.assert_array_equal(g["first_obs"], 0)     # reset() returns the zero buffer (VT:398-410)
     assert g["did_reset"][0].all()                       # reset_buf starts at ones (VT:275)

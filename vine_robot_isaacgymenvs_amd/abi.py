@@ -6,7 +6,7 @@ argument/return types to the C-ABI entry points of a loaded shared library and r
 """
 import ctypes as C
 
-VINE_ABI_VERSION = 2
+VINE_ABI_VERSION = 3
 NUM_LINKS = 5
 NUM_DOFS = 6
 NUM_ACTIONS = 2
@@ -133,6 +133,7 @@ class VineConfig(C.Structure):
         ("fpam_B", C.c_float * NUM_LINKS),
         ("obs_scaling", C.c_float * MAX_OBS),
         ("env_id_offset", C.c_int32),
+        ("effort_limit", C.c_float),
     ]
 
     def set_flag(self, flag, on):

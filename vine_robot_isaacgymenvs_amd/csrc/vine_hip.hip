@@ -56,7 +56,7 @@ struct DevParams {
     int n, num_obs, obs_type, cfi, substeps, max_len, delay;
     unsigned flags, seed_lo, seed_hi, env_off;
     float hsub, dt, cdt, inv_dt, inv_cdt, clip_obs, clip_act;
-    float fpam_min, fpam_span, rail_scale, damping, kq, cad;
+    float fpam_min, fpam_span, rail_scale, damping, kq, cad, eff_lim;
     float soft_limit, p_gain, d_gain, rail_acc, alpha_inf, alpha_def, success_dist;
     float cart_min, cart_span, ty_min, ty_span, tz_min, tz_span, depth_min, depth_span, ty_max, tz_fixed;
     float dyn_min, dyn_span, obs_noise, act_noise;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
                 if (held) t += cv * qdj;
                 t += P.bb[j] * sc[10 + j];
                 t += P.B[j] * sc[15 + j] * u_used;
-                eff[j + 1] = -t;
+                eff[j + 1] = (P.eff_lim > 0.0f) ? clampf(-t, P.eff_lim) : -t;
                 cj[j + 1] = P.damping + (held ? 0.0f : cv);
             }
             {
@@ -1048,14 +1048,14 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             if (held) tq += cv * qdj;
             tq += bb_t * sb;
             tq += B_t * sB * u_used;
-            const float eff_t = -tq, cj_t = P.damping + (held ? 0.0f : cv);
+            const float eff_t = (P.eff_lim > 0.0f) ? clampf(-tq, P.eff_lim) : -tq, cj_t = P.damping + (held ? 0.0f : cv);
             const float q5r = th4 - qbcast<3>(th), qd5r = w4 - qbcast<3>(w);
             float tq4 = P.K[4] * sK4 * q5r;
             const float cv4 = P.C[4] * sC4;
             if (held) tq4 += cv4 * qd5r;
             tq4 += P.bb[4] * sb4;
             tq4 += P.B[4] * sB4 * u_used;
-            const float eff4 = -tq4, cj4 = P.damping + (held ? 0.0f : cv4);
+            const float eff4 = (P.eff_lim > 0.0f) ? clampf(-tq4, P.eff_lim) : -tq4, cj4 = P.damping + (held ? 0.0f : cv4);
             float eff0;
             {   // rail controller (V5:1069-1098), replicated
                 const float err = u_rail - cart_vy;
@@ -1391,6 +1391,28 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
     }
 }
 
+// Tip / cart rigid-body fields of env e from its DOF state (forward kinematics): what a `refresh_rigid_body_state_tensor`
+// after the last simulate left there.
+__device__ __forceinline__ void refresh_body_from_dofs(const DevParams& P, float* __restrict__ st, int n, int e) {
+    float th[NL], w[NL], tip[4];
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { a += ST(VF_Q0 + 1 + k); b += ST(VF_QD0 + 1 + k); th[k] = a; w[k] = b; }
+    const float y = ST(VF_Q0), vy = ST(VF_QD0);
+    tip_fk(P, y, vy, th, w, tip);
+    ST(VF_TIP_Y) = tip[0]; ST(VF_TIP_Z) = tip[1]; ST(VF_TIP_VY) = tip[2]; ST(VF_TIP_VZ) = tip[3];
+    ST(VF_CART_Y) = y; ST(VF_CART_VY) = vy;
+}
+
+// Launched once by the first vine_step after introspection was switched ON mid-run: from then on the step kernels load the
+// body states from memory again, and the copies of envs that were not reset in the last step are out of date.
+__global__ void vine_refresh_body_kernel(const DevParams P, float* __restrict__ st, const long long* __restrict__ progress) {
+    const int n = P.n;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || progress[e] == 0) return;
+    refresh_body_from_dofs(P, st, n, e);
+}
+
 // reset_idx(env_ids) from outside the step (vec_task.py:412-427; V5:715-718).
 __global__ void vine_reset_idx_kernel(const DevParams P, float* __restrict__ st, const long long* __restrict__ env_ids,
                                       long long count, float* __restrict__ rew, long long* __restrict__ reset,
@@ -1403,6 +1425,11 @@ __global__ void vine_reset_idx_kernel(const DevParams P, float* __restrict__ st,
     if (id < 0 || id >= n) return;
     const int e = (int)id;
     const unsigned long long step = counters[0] | (1ull << 62);
+    // Without introspection the four-lanes-per-env kernel stores the tip / cart rigid-body states only in the step in which
+    // an env was reset (it re-derives them from the DOF state otherwise): bring the memory copies up to date from the
+    // pre-reset DOF state before they become the stale-by-design body state (P5) of the reset env.  progress == 0 marks
+    // envs whose stored body state IS the only copy (reset in the last step, or never stepped).
+    if (!(P.flags & VINE_FLAG_INTROSPECT) && progress && progress[e] != 0) refresh_body_from_dofs(P, st, n, e);
     float qn[ND], ty, tz;
     reset_env(P, st, n, e, step, reset_values, qn, ty, tz);
     ST(VF_PREV_TIP_Y) = ST(VF_TIP_Y);
@@ -1585,6 +1612,7 @@ void make_params(const VineConfig& c, DevParams& P) {
     P.clip_obs = c.clip_observations; P.clip_act = c.clip_actions;
     P.fpam_min = c.fpam_min; P.fpam_span = (float)((double)c.fpam_max - (double)c.fpam_min);
     P.rail_scale = c.rail_velocity_scale; P.damping = c.damping; P.kq = c.stiffness; P.cad = c.link_angular_damping;
+    P.eff_lim = c.effort_limit;
     P.soft_limit = c.rail_soft_limit; P.p_gain = c.rail_p_gain; P.d_gain = c.rail_d_gain; P.rail_acc = c.rail_acceleration;
     P.alpha_inf = c.smoothing_alpha_inflate; P.alpha_def = c.smoothing_alpha_deflate; P.success_dist = c.success_dist;
     P.cart_min = c.random_init_cart_min_y; P.cart_span = c.random_init_cart_max_y - c.random_init_cart_min_y;
@@ -1628,6 +1656,8 @@ struct VineHandle {
     unsigned long long* counters;  // [0] step count, [1] workgroup ticket
     const float* reset_values;
     float* reward_matrix;
+    bool refresh_body;             // introspection was switched on since the last step: the next vine_step refreshes the lazily
+                                   // stored tip / cart body states first (vine_refresh_body_kernel)
     int step_kernel;               // 0 = by size, 1 = one lane per env, 2 = four lanes per env where it applies (VINE_STEP_KERNEL)
     double* stats_psum;            // [STATS_BLOCKS][STATS_NSUM + 1] partial sums of vine_stats (allocated on first use)
     float* stats_pmax;             // [STATS_BLOCKS][STATS_NMAX]
@@ -1748,6 +1778,7 @@ int vine_create(const VineConfig* cfg, int device_id, float* state_storage, Vine
     h->stats_psum = nullptr;
     h->stats_pmax = nullptr;
     h->step_kernel = 0;
+    h->refresh_body = false;
     if (const char* k = getenv("VINE_STEP_KERNEL")) h->step_kernel = !strcmp(k, "lane") ? 1 : (!strcmp(k, "quad") ? 2 : 0);
     const size_t bytes = (size_t)VF_COUNT * cfg->num_envs * sizeof(float);
     if (state_storage) {
@@ -1806,6 +1837,11 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     hipStream_t s = (hipStream_t)stream;
     const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
     const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
+    if (h->refresh_body) {
+        h->refresh_body = false;
+        hipLaunchKernelGGL(vine_refresh_body_kernel, dim3((h->P.n + 255) / 256), dim3(256), 0, s, h->P, h->state,
+                           (const long long*)progress);
+    }
     if (use_quad_kernel(h)) {
         const int qblocks = (int)(((long long)h->P.n * 4 + 255) / 256);
 #define LAUNCH_QUAD(OT, RND)                                                                                            \
@@ -1873,12 +1909,16 @@ int vine_bind_reset_values(VineHandle* h, const float* values) {
 int vine_bind_reward_matrix(VineHandle* h, float* reward_matrix) {
     if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
     h->reward_matrix = reward_matrix;
-    if (reward_matrix) h->P.flags |= VINE_FLAG_INTROSPECT;      // whoever asks for the reward matrix reads the dashboard fields too
+    if (reward_matrix) {                                        // whoever asks for the reward matrix reads the dashboard fields too
+        if (!(h->P.flags & VINE_FLAG_INTROSPECT)) h->refresh_body = true;
+        h->P.flags |= VINE_FLAG_INTROSPECT;
+    }
     return VINE_OK;
 }
 
 int vine_set_introspection(VineHandle* h, int on) {
     if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
+    if (on && !(h->P.flags & VINE_FLAG_INTROSPECT)) h->refresh_body = true;
     if (on) h->P.flags |= VINE_FLAG_INTROSPECT;
     else h->P.flags &= ~(unsigned)VINE_FLAG_INTROSPECT;
     return VINE_OK;

@@ -40,23 +40,58 @@ def is_fresh():
         return False
 
 
+def _flags():
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize", "-Wall",
+             "-Wno-unused-function"]
+    extra = os.environ.get("VINE_HIPCC_FLAGS")       # experiments only (e.g. "-fslp-vectorize"); after the defaults, so they win
+    return flags + (extra.split() if extra else [])
+
+
+def _object_fingerprint(src):
+    h = hashlib.sha256()
+    for d in (src, os.path.join(_INC, "vine.h"), os.path.join(_INC, "vine_ppo.h")):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(_flags()).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
-    """hipcc cross-compiles for gfx950 (works without a GPU); output stays in-tree.  A sidecar fingerprint of the
-    sources is written next to the library: ``load()`` refuses to call into a library built from other sources
-    (a stale binary behind a changed C signature is a wild pointer on the GPU)."""
+    """hipcc cross-compiles for gfx950 (works without a GPU); output stays in-tree.  The two translation units are
+    compiled side by side into ``build/obj`` (each object is reused while its source, the headers and the flags are
+    unchanged) and linked into the one library.  A sidecar fingerprint of the sources is written next to the library:
+    ``load()`` refuses to call into a library built from other sources (a stale binary behind a changed C signature is a
+    wild pointer on the GPU)."""
     if not force and is_fresh():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast", "-fno-slp-vectorize",
-           "-Wall", "-Wno-unused-function", "-o", LIB, SRC, SRC_PPO]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    extra = os.environ.get("VINE_HIPCC_FLAGS")       # experiments only (e.g. "-fslp-vectorize")
-    if extra:
-        cmd[-4:-4] = extra.split()      # after the default flags (before "-o"), so that they win
+    objdir = os.path.join(os.path.dirname(_HERE), "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
     if os.path.exists(FINGERPRINT):
         os.remove(FINGERPRINT)
-    subprocess.check_call(cmd)
+    jobs, objs = [], []
+    for src in (SRC, SRC_PPO):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        fp = _object_fingerprint(src)
+        try:
+            fresh = not force and os.path.exists(obj) and open(obj + ".fingerprint").read().strip() == fp
+        except OSError:
+            fresh = False
+        if fresh:
+            continue
+        cmd = [hipcc] + _flags() + ["-c", "-o", obj, src]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        if os.path.exists(obj + ".fingerprint"):
+            os.remove(obj + ".fingerprint")
+        jobs.append((subprocess.Popen(cmd), cmd, obj, fp))
+    for proc, cmd, obj, fp in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        with open(obj + ".fingerprint", "w") as f:
+            f.write(fp + "\n")
+    subprocess.check_call([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     with open(FINGERPRINT, "w") as f:
         f.write(source_fingerprint() + "\n")
     return LIB
@@ -86,8 +121,8 @@ def load():
                 with open(LIB + ".lock", "w") as lock:      # ranks of one job: one of them rebuilds, the others wait
                     fcntl.flock(lock, fcntl.LOCK_EX)
                     if not is_fresh():
-                        print("libvine_hip.so does not match the sources: rebuilding (hipcc, ~90 s)", flush=True)
-                        build(force=True)
+                        print("libvine_hip.so does not match the sources: rebuilding (hipcc, ~2 min)", flush=True)
+                        build()
             else:
                 raise RuntimeError("libvine_hip.so was built from different sources and no hipcc is available")
         _lib = abi.declare_ppo(abi.declare(C.CDLL(LIB)))

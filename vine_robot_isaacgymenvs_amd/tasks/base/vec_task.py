@@ -149,8 +149,13 @@ class VecTask(Env):
 
     def step_into(self, actions: torch.Tensor, obs_out: torch.Tensor):
         """``step`` with the observation written straight into the caller's buffer (e.g. the next slot of a rollout
-        buffer: saves the copy a trainer would make) -- an extension of the reference API; ``obs_buf`` keeps its
-        previous contents.  obs_out: [num_envs, num_obs] float32, contiguous, on the sim device.  Returns obs_out."""
+        buffer: saves the copy a trainer would make) -- an extension of the reference API.  ``obs_buf`` (and
+        ``obs_dict["obs"]``, ``extras["time_outs"]``) are re-bound to the caller's tensor as views, no copy, so that
+        ``reset()`` / ``reset_done()`` / a player on the same env keep returning the CURRENT observation (the reference
+        re-binds obs_buf every step too, V5:1385).  A trainer that replays captured steps from a hipGraph must make the
+        LAST step of the captured sequence write to a tensor it keeps (the agent's ``_obs_last``): the binding made at
+        capture time then stays the current observation after every replay.
+        obs_out: [num_envs, num_obs] float32, contiguous, on the sim device.  Returns obs_out."""
         if (obs_out.shape != self.obs_buf.shape or obs_out.dtype != torch.float32 or not obs_out.is_contiguous()
                 or obs_out.device != self.obs_buf.device):
             raise ValueError("step_into: obs_out must be a contiguous float32 [num_envs, num_obs] tensor on the sim device")
@@ -158,6 +163,9 @@ class VecTask(Env):
         if a.device != self.rew_buf.device or a.dtype != torch.float32 or not a.is_contiguous():
             a = a.to(device=self.device, dtype=torch.float32).contiguous()
         self._native_step(a, obs_out)
+        self.obs_buf = obs_out
+        self.obs_dict["obs"] = obs_out.to(self.rl_device)          # same device: the tensor itself
+        self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
         return obs_out
 
     def zero_actions(self) -> torch.Tensor:

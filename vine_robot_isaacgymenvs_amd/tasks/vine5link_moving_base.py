@@ -121,6 +121,7 @@ def vine_config_from_cfg(cfg, lib, seed=None):
     c.set_flag(abi.FLAG_IMPLICIT_JOINT_DAMPING, bool(model.get("implicitJointDamping", True)))
     c.set_flag(abi.FLAG_FPAM_DAMPING_HELD, bool(model.get("fpamDampingHeld", False)))
     c.link_angular_damping = float(model.get("linkAngularDamping", 0.0))
+    c.effort_limit = float(model.get("effortLimit", 0.0))
     c.set_flag(abi.FLAG_INTROSPECT, bool(env.get("introspection", False)))
     c.env_id_offset = int(env.get("envIdOffset", 0))
     if seed is not None:
