@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument("--no-saturated", action="store_true", help="skip the 2^20-env run of the step kernel")
     p.add_argument("--no-other-configs", action="store_true",
                    help="skip the env-step timings of the other BASELINE configs (4096 free-space, shelf, default pipe)")
+    p.add_argument("--override", action="append", default=[],
+                   help="extra Hydra-style override (repeatable), applied last, e.g. --override task.env.CREATE_SHELF=True: "
+                        "profiling of the other task configurations; the default line never passes any")
     p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
     p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
                    help="ppo mode: update precision: off = fp32, bf16 = hand-written mixed precision (the packaged "
@@ -70,7 +73,7 @@ def make_env(args, rank, device_index, world=1, extra_overrides=()):
           "task.env.CREATE_PIPE=False",      # default task YAML except CREATE_PIPE / CAPTURE_VIDEO
           "sim_device=cuda:%d" % device_index,
           "rl_device=cuda:%d" % device_index, "multi_gpu=%s" % (args.gpus > 1)]
-    cfg = load_config(overrides=ov + list(extra_overrides))
+    cfg = load_config(overrides=ov + list(extra_overrides) + list(getattr(args, "override", [])))
     if strong:
         # one batch of --num-envs envs cut into W shards: same seed everywhere, the RNG keyed by the global env id, and
         # the global minibatch (PY:80: 32768 samples) split evenly so that the optimiser takes the same number of steps

@@ -14,6 +14,10 @@ class HipEnv:
     def __init__(self, cfg, device_id=0):
         import os
         self.lib = native.load()
+        # the parity tests compare every field, also those the step only stores on request: created with introspection ON
+        # (a private copy of the config; switching it on later would make the first step refresh the body states)
+        cfg = type(cfg).from_buffer_copy(cfg)
+        cfg.set_flag(abi.FLAG_INTROSPECT, True)
         self.cfg = cfg
         self.n = cfg.num_envs
         self.dev = torch.device("cuda", device_id)
@@ -39,8 +43,6 @@ class HipEnv:
         self.timeouts_t = torch.zeros(self.n, device=self.dev, dtype=torch.bool)
         self.reward_matrix_t = None
         self._rv = None
-        # the parity tests compare every field, also those the step only stores on request
-        native.check(self.lib.vine_set_introspection(self.h, 1), self.lib)
 
     def set_introspection(self, on):
         native.check(self.lib.vine_set_introspection(self.h, int(bool(on))), self.lib)

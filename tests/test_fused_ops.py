@@ -1076,10 +1076,13 @@ def test_default_loss_kernel_against_reference_text_golden_per_sample():
         act[0] += np.sqrt(2.0 * (float(g["neglogp"][i]) + shift - const))
         actions = full(act, A)
         old_mu, old_sigma = full(mu_i, A), torch.ones(n, A, device=dev)
+        # (named tensors: a temporary's storage would be recycled by the next allocation while the kernel still reads it)
+        onlp, adv = full(g["old_neglogp"][i] + shift), full(g["advantage"][i])
+        oval, ret = full(g["old_values"][i, 0]), full(g["returns"][i, 0])
         rc = lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
-                                    logstd.data_ptr(), actions.data_ptr(), full(g["old_neglogp"][i] + shift).data_ptr(),
-                                    full(g["advantage"][i]).data_ptr(), full(g["old_values"][i, 0]).data_ptr(),
-                                    full(g["returns"][i, 0]).data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(),
+                                    logstd.data_ptr(), actions.data_ptr(), onlp.data_ptr(),
+                                    adv.data_ptr(), oval.data_ptr(),
+                                    ret.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(),
                                     float(g["e_clip"]), 1, 2.0, 0.0, 1e-4, 1.0,
                                     heads.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
                                     gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),

@@ -244,16 +244,28 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
 // shelf_contact): (a) 6 points of every link rectangle vs the two boards, (b) the two front corners of the
 // `shelf_link` strip vs every link rectangle.  Writes generalised forces in ABSOLUTE coordinates
 // (d x / d th_i = L n_i for i < k, z n_k + y d_k for i = k) and returns |F| on the strip.
+//
+// Broad phase (round 3): the narrow phase above is ~230 instructions per link, 40 times per env step, and almost always
+// finds nothing.  Every link first takes a CONSERVATIVE bounding test against each board (a few instructions: the link
+// rectangle lies within LINK_REACH of the segment between its two joints); the narrow phase of a (link, board) pair runs
+// only where that test cannot exclude contact.  A wave skips a block none of its lanes needs (the compiler branches
+// on EXEC == 0 around it), so links far from the obstacle -- the proximal ones nearly always -- cost the test alone.
+// Culled pairs contribute exactly zero, so the result is bit-identical to the unculled evaluation.
 #define CONTACT_K 2000.0f
 #define CONTACT_C 2.0f
 #define LINK_Y0 (-0.0381f)
 #define LINK_Y1 0.0719f
+#define LINK_REACH 0.078f   // lateral half-extent 0.0719 + link_0's 5.75 mm axial overhang beyond its joints, rounded up
 __device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s, float shelf_y, float shelf_z,
                                                float (&qa)[ND]) {
     const float board[2][4] = {{-0.001f, 0.0f, 0.1995f, 0.005f}, {0.0f, 0.2f, 0.2f, 0.005f}};
     float strip_fy = 0.0f, strip_fz = 0.0f;
     float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
     float Fy[NL], Fz[NL], ny_[NL], nz_[NL];
+    bool any = false;
+    // every shelf shape lies at y <= shelf_y + 0.2; board A / the strip around z = shelf_z, board B around shelf_z + 0.2
+    const float ycut = shelf_y + 0.2f;
+    const float a_lo = shelf_z - 0.005f, a_hi = shelf_z + 0.005f, b_lo = shelf_z + 0.195f, b_hi = shelf_z + 0.205f;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
         const float sp = s.sn[k], cp = s.cs[k];              // sin/cos of the world link angle
@@ -262,56 +274,72 @@ __device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s,
         const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
         float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
         ny_[k] = -cp; nz_[k] = -sp;
+        const float qy = py + P.L * dy, qz = pz + P.L * dz;  // the next joint
+        const float ylo = fminf(py, qy) - LINK_REACH;
+        const float zlo = fminf(pz, qz) - LINK_REACH, zhi = fmaxf(pz, qz) + LINK_REACH;
+        const bool near_a = ylo < ycut && zlo < a_hi && zhi > a_lo;      // board A and the strip's corners
+        const bool near_b = ylo < ycut && zlo < b_hi && zhi > b_lo;
+        // one block per board (a link near both at once is rare: they are 0.2 m apart), so a wave pays one branch per
+        // (link, board) and runs only the blocks some lane of it needs
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int bx = 0; bx < 2; ++bx) {
+            if (bx == 0 ? near_a : near_b) {
+                any = true;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const float yl = e ? LINK_Y1 : LINK_Y0;
-                const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
-                const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
-                const float wy = py + ry, wz = pz + rz;
-                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                for (int e = 0; e < 2; ++e) {
 #pragma unroll
-                for (int bx = 0; bx < 2; ++bx) {
-                    const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
-                    const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
-                    if (ey > 0.0f && ez > 0.0f) {
-                        float fy = 0.0f, fz = 0.0f;
-                        if (ey < ez) {
-                            const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
-                            fy = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vy, 0.0f);
-                        } else {
-                            const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
-                            fz = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vz, 0.0f);
+                    for (int t = 0; t < 3; ++t) {
+                        const float yl = e ? LINK_Y1 : LINK_Y0;
+                        const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+                        const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                        const float wy = py + ry, wz = pz + rz;
+                        const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
+                        const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
+                        if (ey > 0.0f && ez > 0.0f) {
+                            const float vy = pvy - om * rz, vz = pvz + om * ry;
+                            float fy = 0.0f, fz = 0.0f;
+                            if (ey < ez) {
+                                const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                                fy = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vy, 0.0f);
+                            } else {
+                                const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                                fz = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vz, 0.0f);
+                            }
+                            fy_tot += fy; fz_tot += fz;
+                            mom += -rz * fy + ry * fz;          // F . (z n_k + y d_k) = r x F about joint k
                         }
-                        fy_tot += fy; fz_tot += fz;
-                        mom += -rz * fy + ry * fz;          // F . (z n_k + y d_k) = r x F about joint k
                     }
                 }
             }
         }
+        if (near_a) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float wy = shelf_y + 0.2f, wz = shelf_z + (e ? 0.005f : -0.005f);
-            const float ry = wy - py, rz = wz - pz;
-            const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
-            if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
-                float dep = zl - z0, ny = -dy, nz = -dz;
-                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
-                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
-                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
-                const float vy = pvy - om * rz, vz = pvz + om * ry;
-                const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
-                strip_fy += f * ny; strip_fz += f * nz;
-                const float fy = -f * ny, fz = -f * nz;
-                fy_tot += fy; fz_tot += fz;
-                mom += -rz * fy + ry * fz;
+            for (int e = 0; e < 2; ++e) {
+                const float wy = shelf_y + 0.2f, wz = shelf_z + (e ? 0.005f : -0.005f);
+                const float ry = wy - py, rz = wz - pz;
+                const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+                if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                    float dep = zl - z0, ny = -dy, nz = -dz;
+                    if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                    if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                    if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                    const float vy = pvy - om * rz, vz = pvz + om * ry;
+                    const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                    strip_fy += f * ny; strip_fz += f * nz;
+                    const float fy = -f * ny, fz = -f * nz;
+                    fy_tot += fy; fz_tot += fz;
+                    mom += -rz * fy + ry * fz;
+                }
             }
         }
         Fy[k] = fy_tot; Fz[k] = fz_tot;
         qa[k + 1] = mom;
-        py += P.L * dy; pz += P.L * dz;
+        py = qy; pz = qz;
         pvy += P.L * om * (-cp); pvz += P.L * om * (-sp);
+    }
+    if (!any) {          // (qa[1..5] are zero already)
+        qa[0] = 0.0f;
+        return 0.0f;
     }
     // forces on distal links act on joint i through the lever L n_i
     float sy = 0.0f, sz = 0.0f;
@@ -326,14 +354,25 @@ __device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s,
 
 // Planar pipe contact (CREATE_PIPE): the tube of assets/urdf/pipe as two wall rectangles in the pipe frame
 // (oracle/vine_oracle.c pipe_contact).  ADDS its generalised forces to qa.
+// Broad phase, three levels per link: (1) bounding circles of the link and of the whole tube (7 instructions);
+// (2) the link rectangle's exact axis-aligned box in the pipe frame against each wall's box; (3) the narrow phase of
+// the (link, wall) pairs that are left.  A vine reaching INTO the tube sits between the walls: level 2 is what keeps it
+// out of the narrow phase until it actually comes within a rounding margin of a wall.
 #define PIPE_LEN 0.34125f
 #define PIPE_WALL 0.00525f
 #define PIPE_OUTER 0.1554f
+#define PIPE_CULL_EPS 1.0e-5f      // the box tests use other (equivalent) expressions than the narrow phase: rounding margin
 __device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, float pipe_y, float pipe_z, float ct,
                                              float st, float (&qa)[ND]) {
     const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
     float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
     float Fy[NL], Fz[NL], ny_[NL], nz_[NL], mom_[NL];
+    bool any = false;
+    // centre of the tube's cross-section box in the world, radius of its bounding circle + the link's (half-length 0.05,
+    // lateral reach 0.0719 about the axis midpoint -> 0.0876)
+    const float hcy = 0.5f * PIPE_OUTER, hcz = 0.5f * PIPE_LEN;
+    const float ccy = pipe_y + hcy * ct - hcz * st, ccz = pipe_z + hcy * st + hcz * ct;
+    const float rsum = 0.18748f + 0.0877f + 1.0e-4f;       // hypot(0.0777, 0.170625) + hypot(0.05, 0.0719)
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
         const float sp = s.sn[k], cp = s.cs[k];
@@ -342,54 +381,77 @@ __device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, f
         const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
         float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
         ny_[k] = -cp; nz_[k] = -sp;
+        const float my = py + 0.04425f * dy - ccy, mz = pz + 0.04425f * dz - ccz;     // axis midpoint - tube centre
+        if (my * my + mz * mz < rsum * rsum) {
+            // level 2: the rectangle's box in the pipe frame.  Local axis / lateral directions, local joint position.
+            const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;          // d in the pipe frame; l = (dlz, -dly)
+            const float gy0 = py - pipe_y, gz0 = pz - pipe_z;
+            const float jy = gy0 * ct + gz0 * st, jz = -gy0 * st + gz0 * ct;
+            const float ay0 = z0 * dly, ay1 = z1 * dly, by0 = LINK_Y0 * dlz, by1 = LINK_Y1 * dlz;
+            const float az0 = z0 * dlz, az1 = z1 * dlz, bz0 = LINK_Y0 * -dly, bz1 = LINK_Y1 * -dly;
+            const float ymin = jy + fminf(ay0, ay1) + fminf(by0, by1) - PIPE_CULL_EPS;
+            const float ymax = jy + fmaxf(ay0, ay1) + fmaxf(by0, by1) + PIPE_CULL_EPS;
+            const float zmin = jz + fminf(az0, az1) + fminf(bz0, bz1) - PIPE_CULL_EPS;
+            const float zmax = jz + fmaxf(az0, az1) + fmaxf(bz0, bz1) + PIPE_CULL_EPS;
+            const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
+            const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
+            const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
+            if (near0 || near1) {
+                any = true;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < 2; ++e) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const float yl = e ? LINK_Y1 : LINK_Y0;
-                const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
-                const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
-                const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
-                const float vy = pvy - om * rz, vz = pvz + om * ry;
-                const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
-                const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
+                    for (int t = 0; t < 3; ++t) {
+                        const float yl = e ? LINK_Y1 : LINK_Y0;
+                        const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+                        const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                        const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
+                        const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
 #pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
-                    const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
-                    if (ey > 0.0f && ez > 0.0f) {
-                        float fyl = 0.0f, fzl = 0.0f;
-                        if (ey < ez) {
-                            const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
-                            fyl = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vyl, 0.0f);
-                        } else {
-                            const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
-                            fzl = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vzl, 0.0f);
+                        for (int w = 0; w < 2; ++w) {
+                            if (w == 0 ? near0 : near1) {
+                                const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
+                                const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
+                                if (ey > 0.0f && ez > 0.0f) {
+                                    const float vy = pvy - om * rz, vz = pvz + om * ry;
+                                    const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
+                                    float fyl = 0.0f, fzl = 0.0f;
+                                    if (ey < ez) {
+                                        const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                                        fyl = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vyl, 0.0f);
+                                    } else {
+                                        const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                                        fzl = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vzl, 0.0f);
+                                    }
+                                    const float fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;
+                                    fy_tot += fy; fz_tot += fz;
+                                    mom += -rz * fy + ry * fz;
+                                }
+                            }
                         }
-                        const float fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;
-                        fy_tot += fy; fz_tot += fz;
-                        mom += -rz * fy + ry * fz;
                     }
                 }
-            }
-        }
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
+                for (int w = 0; w < 2; ++w) {
+                    if (w == 0 ? near0 : near1) {
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                const float pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0.0f), pzl = (cidx & 2) ? PIPE_LEN : 0.0f;
-                const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
-                const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
-                if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
-                    float dep = zl - z0, ny = -dy, nz = -dz;
-                    if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
-                    if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
-                    if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
-                    const float vy = pvy - om * rz, vz = pvz + om * ry;
-                    const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
-                    const float fy = -f * ny, fz = -f * nz;
-                    fy_tot += fy; fz_tot += fz;
-                    mom += -rz * fy + ry * fz;
+                        for (int cidx = 0; cidx < 4; ++cidx) {
+                            const float pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0.0f), pzl = (cidx & 2) ? PIPE_LEN : 0.0f;
+                            const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
+                            const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+                            if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                                float dep = zl - z0, ny = -dy, nz = -dz;
+                                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                                const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                                const float fy = -f * ny, fz = -f * nz;
+                                fy_tot += fy; fz_tot += fz;
+                                mom += -rz * fy + ry * fz;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -397,6 +459,7 @@ __device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, f
         py += P.L * dy; pz += P.L * dz;
         pvy += P.L * om * (-cp); pvz += P.L * om * (-sp);
     }
+    if (!any) return;        // nothing to add
     float sy = 0.0f, sz = 0.0f;
 #pragma unroll
     for (int i = NL - 1; i >= 0; --i) {
@@ -1920,7 +1983,7 @@ int vine_set_introspection(VineHandle* h, int on) {
     if (!h) return fail(VINE_ERR_INVALID_ARG, "handle is NULL");
     if (on && !(h->P.flags & VINE_FLAG_INTROSPECT)) h->refresh_body = true;
     if (on) h->P.flags |= VINE_FLAG_INTROSPECT;
-    else h->P.flags &= ~(unsigned)VINE_FLAG_INTROSPECT;
+    else { h->P.flags &= ~(unsigned)VINE_FLAG_INTROSPECT; h->refresh_body = false; }
     return VINE_OK;
 }
 
