@@ -257,10 +257,12 @@ int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, 
 int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean, const double* var, float eps, float clip,
                        void* out, int64_t out_stride, int32_t out_bf16, void* stream);
 
-/* Up to 16 vine_column_sums jobs in one launch (arrays of length njobs, host memory, same meaning per entry). */
+/* Up to 16 vine_column_sums jobs in one launch (arrays of length njobs, host memory, same meaning per entry).
+ * found_inf (nullable, device): set to 1.0 when any finished sum is not finite -- the weight gradients of a loss-scaled
+ * fp16 backward pass end here, and an overflowed 16-bit gradient shows up in them as inf / NaN (vine_adam_step_amp). */
 int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
                              const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
-                             const int32_t* dup, void* stream);
+                             const int32_t* dup, float* found_inf, void* stream);
 
 /* Up to 24 small 2-D element moves in one launch (arrays of length njobs in host memory): dst[r, c] for r < rows,
  * c < cols, rows of dst / src dst_stride / src_stride ELEMENTS apart.  op: 0 copy, 1 zero, 2 transpose (dst[r, c] =
@@ -298,7 +300,10 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
                   float* grad_value_bias, float* scratch, float* kl_out, float* logstd_grad_accum, float* mu_store,
-                  float* sigma_store, void* stream);
+                  float* sigma_store, const float* loss_scale, void* stream);
+/* loss_scale (nullable, device scalar): every GRADIENT the call produces is multiplied by *loss_scale (the statistics are
+ * not) -- torch.amp.GradScaler's `scaler.scale(loss).backward()` (rl_games drives the reference's `mixed_precision: True`
+ * update through one); vine_adam_step_amp unscales. */
 
 /* LayerNorm + heads + PPO loss + their backward in ONE launch (H = 256, NH = A + 1 in 2..5): from the LSTM output x [n, H] it forms heads = W LN(x) + wb ([n, NH], written out),
  * the loss terms and statistics of vine_ppo_loss on them, and d loss / d x ([n, H], dx: fp32, or bfloat16 with dx_bf16 --
@@ -313,8 +318,22 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
                        const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
                        float bounds_coef, float soft_bound, float* heads, void* dx, int32_t dx_bf16, float* ln_partial,
                        float* stats, float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch,
-                       float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream);
+                       float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, const float* loss_scale,
+                       float* found_inf, void* stream);
+/* dx_bf16: dx is stored in the library's 16-bit format (vine_lp16_format()).  loss_scale: as in vine_ppo_loss.  found_inf
+ * (nullable, device): set to 1.0 when a 16-bit dx element overflows the format or is NaN. */
 int vine_ln_heads_loss_rows(void);
+
+/* "fp16" (default build: IEEE half operands, the reference's autocast dtype; needs the loss scaling above) or "bf16"
+ * (-DVINE_LP_BF16): the 16-bit storage format of every `bf16` / `lp16` operand, saved activation and parameter copy of
+ * this header.  Parameter names containing "bf16" date from round 2 and mean "this 16-bit format". */
+const char* vine_lp16_format(void);
+
+/* Allocates the library's small per-device bookkeeping (the ticket words of the loss / Adam kernels' "last workgroup"
+ * elections) for the CURRENT device.  It happens by itself on the first vine_ppo_loss / vine_ln_heads_loss /
+ * vine_adam_step* call on a device; call this once beforehand when that first call would sit inside a stream capture
+ * (an allocation is not allowed there).  The host mirror (learning/fused.py) calls it when it loads the library. */
+int vine_ppo_runtime_init(void);
 
 /* Rollout, policy head (row R1; rl_games play_steps_rnn / ModelA2CContinuousLogStd eval branch): from the LayerNorm
  * output y [N,H]: mu = y W_mu^T + b_mu, v = y w_v^T + b_v, sigma = exp(logstd), action = mu + sigma * eps
@@ -357,10 +376,24 @@ int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float
 /* The same step with rl_games' AdaptiveScheduler (`schedule_type: legacy`) folded in: every workgroup reads the OLD
  * learning rate, the last one to finish writes lr = max(lr/1.5, min_lr) if kl*kl_scale > 2*thr, min(lr*1.5, max_lr) if
  * kl*kl_scale < 0.5*thr -- i.e. exactly vine_adam_step followed by vine_adaptive_lr, in one launch (kl NULL: no
- * schedule).  The step counter is bumped the same way.  One Adam launch in flight per device at a time. */
+ * schedule).  The step counter is bumped the same way.  (The "last workgroup" election uses a ticket word per
+ * (device, stream): launches on different streams do not interfere.) */
 int vine_adam_step_sched(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
                          float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow,
                          const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, void* stream);
+
+/* vine_adam_step_sched with torch.amp.GradScaler restated on the device (rl_games: `self.scaler.step(self.optimizer);
+ * self.scaler.update()` for `mixed_precision: True`, PY:53).  amp_state (nullable, device float[4]) = {loss scale, growth
+ * tracker, growth interval, unused}: gradients are unscaled by 1 / scale.  found_inf (nullable, device scalar; with
+ * several ranks it rides in the all-reduced gradient block, so every rank sees the sum): when non-zero the step is
+ * SKIPPED -- parameters, moments, step counter and the 16-bit copies keep their values, the gradient block is cleared --
+ * and the scale is halved; otherwise the tracker counts up and the scale doubles every `growth interval` good steps
+ * (GradScaler defaults: 65536, x2 every 2000, x0.5 on overflow).  The flag is cleared by the launch.  The learning-rate
+ * schedule runs either way. */
+int vine_adam_step_amp(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* lp16_shadow,
+                       const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, float* amp_state,
+                       float* found_inf, void* stream);
 
 /* rl_games' AdaptiveScheduler on device scalars (`schedule_type: legacy`, PY:64-66):
  * kl > 2*thr -> lr = max(lr/1.5, min_lr); kl < 0.5*thr -> lr = min(lr*1.5, max_lr).  kl_scale = 1/world. */

@@ -123,16 +123,16 @@ def test_pointwise_kernels_against_torch():
         wide = torch.zeros(n, Cc + 32, device=dev)
         assert lib.vine_bias_elu(n, Cc, z.data_ptr(), bias.data_ptr(), 1.0, wide.data_ptr(), Cc + 32, 0, st) == 0
         assert float((wide[:, :Cc] - ref).abs().max()) < 1e-6 and float(wide[:, Cc:].abs().max()) == 0.0
-        wb = torch.zeros(n, Cc + 32, device=dev, dtype=torch.bfloat16)
+        wb = torch.zeros(n, Cc + 32, device=dev, dtype=fused.lp_dtype())
         assert lib.vine_bias_elu(n, Cc, z.data_ptr(), bias.data_ptr(), 1.0, wb.data_ptr(), Cc + 32, 1, st) == 0
         # round-to-nearest-even like torch; the fast exp may land an element on the other side of a rounding boundary
         assert float(((wb[:, :Cc].float() - ref).abs() - ref.abs() * 2.0 ** -8).max()) < 1e-6
-        assert float((wb[:, :Cc] != ref.to(torch.bfloat16)).float().mean()) < 1e-3
+        assert float((wb[:, :Cc] != ref.to(fused.lp_dtype())).float().mean()) < 1e-3
         gin = torch.randn(n, Cc, device=dev)
         ref_g = gin * torch.where(ref > 0, torch.ones_like(ref), ref + 1.0)
         for a_bf, o_bf in ((0, 0), (1, 1), (1, 0), (0, 1)):
             a_t = wb if a_bf else wide
-            out = torch.empty(n, Cc, device=dev, dtype=torch.bfloat16 if o_bf else torch.float32)
+            out = torch.empty(n, Cc, device=dev, dtype=fused.lp_dtype() if o_bf else torch.float32)
             part = torch.empty(PPO_PARTIAL_BLOCKS, Cc, device=dev)
             assert lib.vine_elu_backward(n, Cc, gin.data_ptr(), Cc, a_t.data_ptr(), Cc + 32, 1.0, out.data_ptr(), Cc,
                                          part.data_ptr(), a_bf, o_bf, st) == 0
@@ -152,7 +152,7 @@ def test_lstm_step_mfma_matches_gemm_plus_pointwise(B, K, with_ig):
     lib = fused._lib()
     st = torch.cuda.current_stream().cuda_stream
     H = 256
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     A = (torch.randn(B, K + 16, device=dev) * 0.5).to(bf)[:, :K]                  # padded rows
     W = (torch.randn(4 * H, K, device=dev) / K ** 0.5).to(bf)
     ig = torch.randn(B, 4 * H, device=dev) if with_ig else None
@@ -206,7 +206,7 @@ def test_lstm_backward_mfma_matches_gemm_plus_pointwise(B, H, use_dones):
     torch.manual_seed(7)
     lib = fused._lib()
     T = 4
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     w_hh = (torch.randn(4 * H, H, device=dev) / H ** 0.5).to(bf)
     g_out = torch.randn(B * T, H, device=dev) * 0.1
     c_all = torch.randn(T + 1, B, H, device=dev)
@@ -250,7 +250,7 @@ def test_lstm_sequence_kernels_match_float64_autograd(low_precision):
     torch.manual_seed(3)
     lib = fused._lib()
     B, T, H, width, wpad = 256, 4, 256, 92, 96
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     xfull = torch.zeros(B * T, wpad, device=dev, dtype=bf)
     xfull[:, :width] = (torch.randn(B * T, width, device=dev) * 0.7).to(bf)
     w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
@@ -335,7 +335,7 @@ def test_lstm_sequence_kernels_equal_step_kernels(B, use_dones):
     lib = fused._lib()
     st = torch.cuda.current_stream().cuda_stream
     T, H, width, wpad = 4, 256, 92, 96
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     xfull = torch.zeros(B * T, wpad, device=dev, dtype=bf)
     xfull[:, :width] = (torch.randn(B * T, width, device=dev) * 0.7).to(bf)
     w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
@@ -443,7 +443,7 @@ def test_weight_grad_mfma_matches_float64_product(monkeypatch):
     import time
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     n = 32768
     monkeypatch.setattr(fused, "WGRAD_MAX_OUT", 1 << 30)          # the kernel is opt-in (see fused.WGRAD_MAX_OUT)
     xfull = (torch.randn(n, 96, device=dev) * 0.5).to(bf)
@@ -496,7 +496,7 @@ def test_weight_grad_cat_matches_float64_products(n, width, wide, monkeypatch):
     monkeypatch.setattr(fused, "WGRAD_CAT_WIDE", wide)
     dev = torch.device("cuda:0")
     torch.manual_seed(5)
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     H, M = 256, 1024
     xfull = (torch.randn(n, 96, device=dev) * 0.5).to(bf)
     xfull[:, width:] = float("nan")
@@ -533,7 +533,7 @@ def test_weight_grad_cat_single_operand(M, N, stride, off):
     output tiles, the first layer's [256, num_obs] with a 32-wide tile over a column block of the padded operand buffer."""
     dev = torch.device("cuda:0")
     torch.manual_seed(6)
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     n = 32768
     full = torch.full((n, stride), float("nan"), device=dev, dtype=bf)
     full[:, off:off + N] = (torch.randn(n, N, device=dev) * 0.5).to(bf)
@@ -558,7 +558,7 @@ def test_mlp3_kernels_match_float64_autograd(n, raw):
     torch.manual_seed(21)
     lib = fused._lib()
     st = torch.cuda.current_stream().cuda_stream
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     F_in, U, K0 = 28, 64, 1024
     obs = torch.randn(n, F_in, device=dev) * 3.0 + 0.5
     mean, var = torch.randn(F_in, device=dev, dtype=torch.float64) * 0.3, torch.rand(F_in, device=dev, dtype=torch.float64) + 0.5
@@ -618,7 +618,7 @@ def test_weight_grad_group_equals_single_launches(monkeypatch):
     single launches of the same kernel family, and match the float64 products."""
     dev = torch.device("cuda:0")
     torch.manual_seed(7)
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     n = 32768
     xfull = torch.full((n, 96), float("nan"), device=dev, dtype=bf)
     xfull[:, 64:92] = (torch.randn(n, 28, device=dev) * 0.5).to(bf)
@@ -676,7 +676,7 @@ def test_linear_elu_mfma_matches_gemm_plus_bias_elu(n, K, N):
     torch.manual_seed(8)
     lib = fused._lib()
     st = torch.cuda.current_stream().cuda_stream
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     A = (torch.randn(n, K + 8, device=dev) * 0.7).to(bf)[:, :K]
     W = (torch.randn(N, K, device=dev) / K ** 0.5).to(bf)
     bias = torch.randn(N, device=dev) * 0.2
@@ -719,7 +719,7 @@ def test_linear_bwd_elu_mfma_matches_gemm_plus_elu_backward(n, K, N):
     torch.manual_seed(12)
     lib = fused._lib()
     st = torch.cuda.current_stream().cuda_stream
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     G = (torch.randn(n, K, device=dev) / n).to(bf)
     W = (torch.randn(K, N, device=dev) / K ** 0.5).to(bf)                  # the layer's weight [out, in]
     a = torch.nn.functional.elu(torch.randn(n, N + 16, device=dev)).to(bf)[:, :N]
@@ -764,7 +764,7 @@ def test_copy_batch_ops():
     """vine_copy_batched: copy / zero / transpose / fp32->bf16 cast / add / masked, strided views, 20 jobs (two launches)."""
     dev = torch.device("cuda:0")
     torch.manual_seed(13)
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     cb, checks = fused.CopyBatch(), []
     for rep in range(3):
         src = torch.randn(1024, 92, device=dev).to(bf)
@@ -908,7 +908,7 @@ def test_fused_trunk_matches_float64_composition(obs_dim, use_slots, mixed):
             p.grad = torch.zeros_like(p)
     obs_d = obs.to(dev)
     if mixed:
-        net.op_weight_lookup = lambda p: p.detach().to(torch.bfloat16)
+        net.op_weight_lookup = lambda p: p.detach().to(fused.lp_dtype())
     out_tol, grad_tol = (2e-2, 4e-2) if mixed else (2e-5, 2e-4)
     assert net.trunk_supported(obs_d, T)
     heads, (h2, c2) = net.forward_heads(obs_d, (h0.to(dev), c0.to(dev)), T, dones.to(dev))
@@ -969,7 +969,7 @@ def test_ln_heads_loss_kernel_matches_float64_autograd(clip_value):
                                     old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
                                     heads.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
                                     gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
-                                    mu_st.data_ptr(), sg_st.data_ptr(), st)
+                                    mu_st.data_ptr(), sg_st.data_ptr(), None, None, st)
         assert rc == 0
     torch.cuda.synchronize()
     # float64 reference
@@ -994,19 +994,20 @@ def test_ln_heads_loss_kernel_matches_float64_autograd(clip_value):
     assert abs(float(kl_out) - float(ref["kl"])) < 2e-5
     assert rel(mu_st, hd.detach()[:, :A]) < 1e-5 and rel(sg_st, lsd.detach().exp().expand(n, A)) < 1e-6
     # the gradient handed to the LSTM backward as bfloat16 (dx_bf16): the fp32 result rounded, everything else unchanged
-    dx16, heads2 = torch.empty(n, H, device=dev, dtype=torch.bfloat16), torch.empty_like(heads)
+    dx16, heads2 = torch.empty(n, H, device=dev, dtype=fused.lp_dtype()), torch.empty_like(heads)
     gmb.zero_(); gvb.zero_(); gls_acc.zero_()
     assert lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
                                   logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
                                   old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
                                   heads2.data_ptr(), dx16.data_ptr(), 1, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
                                   gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
-                                  mu_st.data_ptr(), sg_st.data_ptr(), st) == 0
+                                  mu_st.data_ptr(), sg_st.data_ptr(), None, None, st) == 0
     torch.cuda.synchronize()
-    assert torch.equal(dx16, dx.to(torch.bfloat16)) and torch.equal(heads2, heads)
+    # (the two instantiations may contract their fp32 arithmetic differently: one 16-bit ulp, incl. fp16 subnormals)
+    assert torch.allclose(dx16.float(), dx.to(fused.lp_dtype()).float(), rtol=2e-3, atol=1.2e-7) and torch.equal(heads2, heads)
     # shapes outside the family are refused
     assert lib.vine_ln_heads_loss(n + 8, H, NH, *([x.data_ptr()] * 3), 1e-5, *([x.data_ptr()] * 10), *scal,
-                                  x.data_ptr(), x.data_ptr(), 0, *([x.data_ptr()] * 10), st) == -2
+                                  x.data_ptr(), x.data_ptr(), 0, *([x.data_ptr()] * 10), None, None, st) == -2
 
 
 @pytest.mark.gpu
@@ -1086,7 +1087,7 @@ def test_default_loss_kernel_against_reference_text_golden_per_sample():
                                     float(g["e_clip"]), 1, 2.0, 0.0, 1e-4, 1.0,
                                     heads.data_ptr(), dx.data_ptr(), 0, part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
                                     gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), kl_out.data_ptr(), gls_acc.data_ptr(),
-                                    mu_st.data_ptr(), sg_st.data_ptr(), st)
+                                    mu_st.data_ptr(), sg_st.data_ptr(), None, None, st)
         assert rc == 0
         got[i] = stats[:3].cpu().numpy()
     tol = lambda ref: 3e-5 * (1.0 + np.abs(ref))
@@ -1241,9 +1242,10 @@ def test_checkpoint_restore_continues_bit_identically(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("amp", ["fp16", "bf16"])
 def test_torch_autocast_path_still_trains(amp):
-    """``mixed_precision_dtype: fp16`` (the reference's literal mechanism: torch autocast + GradScaler) and autocast bf16
-    with ``use_fused_ops: False`` run the stock composition: the hand-written fp32 kernels must step aside under
-    autocast (they once received half-precision tensors there)."""
+    """The reference's literal mechanism -- torch autocast (+ GradScaler for fp16) over the stock composition -- stays
+    available: ``use_fused_ops: False``, or a ``mixed_precision_dtype`` other than the library's 16-bit format with the
+    fused ops on (the hand-written fp32 kernels must step aside under autocast: they once received half-precision
+    tensors there)."""
     from vine_robot_isaacgymenvs_amd import load_config
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
@@ -1252,8 +1254,9 @@ def test_torch_autocast_path_still_trains(amp):
     env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
                                                   graphics_device_id=0, headless=True)
     params = cfg["train"]["params"]
+    lib_fmt = {torch.float16: "fp16", torch.bfloat16: "bf16"}[fused.lp_dtype()]
     params["config"].update(write_files=False, print_stats=False, mixed_precision=True, mixed_precision_dtype=amp,
-                            use_fused_ops=(amp == "fp16"))
+                            use_fused_ops=(amp != lib_fmt))
     torch.manual_seed(0)
     agent = A2CAgent("t", params, vec_env=env)
     assert agent.mixed_precision and not agent.fused_mixed
@@ -1339,7 +1342,7 @@ def test_flat_adam_kernel_matches_torch_adam():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("mixed", [False, True, "lp16"])
 def test_fused_rollout_matches_stock_and_graph_replay(mixed):
     """Fused rollout (hand-written inference trunk, policy head, post-step kernels) vs the stock PyTorch model on the
     stored inputs: deterministic quantities equal (to bf16 operand tolerance in the mixed-precision mode); eager and
@@ -1355,15 +1358,17 @@ def test_fused_rollout_matches_stock_and_graph_replay(mixed):
         env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
                                                       graphics_device_id=0, headless=True)
         params = cfg["train"]["params"]
-        params["config"].update(write_files=False, print_stats=False, use_graphs=use_graphs, mixed_precision=mixed)
+        params["config"].update(write_files=False, print_stats=False, use_graphs=use_graphs, mixed_precision=bool(mixed),
+                                rollout_precision="lp16" if mixed == "lp16" else "fp32")
         torch.manual_seed(0)
         agent = A2CAgent("t", params, vec_env=env)
         agent.init_tensors()
         agent.obs = agent.env_reset()["obs"]
-        assert agent._fast is not None and agent._fast["op"] == (torch.bfloat16 if mixed else torch.float32)
+        # rollout inference is fp32 (the reference's) whatever the update's precision, unless rollout_precision says lp16
+        assert agent._fast is not None and agent._fast["op"] == (fused.lp_dtype() if mixed == "lp16" else torch.float32)
         return agent, env
 
-    tol = 3e-2 if mixed else 2e-4
+    tol = 3e-2 if mixed == "lp16" else 2e-4
 
     outs = []
     for use_graphs in (False, True):
@@ -1395,3 +1400,169 @@ def test_fused_rollout_matches_stock_and_graph_replay(mixed):
             assert torch.allclose(outs[0][k], outs[1][k], rtol=1e-5)
         else:
             assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+# --------------------------------------------------------------------------- GradScaler semantics on the device
+@pytest.mark.gpu
+def test_adam_amp_is_gradscaler_step_and_update():
+    """vine_adam_step_amp = torch.amp.GradScaler's step + update around torch.optim.Adam (rl_games wraps the reference's
+    ``mixed_precision: True`` update in one): gradients unscaled by 1 / scale, an overflowed step skipped entirely
+    (parameters, moments, step counter, 16-bit copies untouched; gradients cleared) with the scale halved, the scale
+    doubled after `growth_interval` consecutive good steps, the flag cleared by the launch."""
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n = 4099                                    # not a multiple of 4: the scalar tail too
+    p0 = torch.randn(n, device=dev)
+    p = p0.clone()
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lr, step = torch.tensor(3e-4, device=dev), torch.zeros((), device=dev)
+    shadow = p.to(fused.lp_dtype())
+    amp = torch.tensor([1024.0, 0.0, 3.0, 0.0], device=dev)          # scale, tracker, growth interval
+    found = torch.zeros(1, device=dev)
+    ref_p = torch.nn.Parameter(p0.clone())
+    ref = torch.optim.Adam([ref_p], lr=3e-4, eps=1e-8)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch(g_unscaled, overflow):
+        g = (g_unscaled * float(amp[0])).contiguous()
+        if overflow:
+            g[7] = float("inf")
+            found.fill_(1.0)
+        rc = lib.vine_adam_step_amp(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr.data_ptr(), step.data_ptr(),
+                                    0.9, 0.999, 1e-8, 0.0, 1.0, shadow.data_ptr(), None, 0.0, 0.0, 0.0, 0.0, amp.data_ptr(),
+                                    found.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert float(g.abs().max()) == 0.0 and float(found) == 0.0       # gradient block and flag cleared either way
+        return g
+
+    scales = []
+    for k, overflow in enumerate([False, True, False, False, False, False]):
+        g = torch.randn(n, device=dev) * 1e-3
+        before = (p.clone(), m.clone(), v.clone(), float(step), shadow.clone())
+        launch(g, overflow)
+        if overflow:
+            assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+            assert float(step) == before[3] and torch.equal(shadow, before[4])
+        else:
+            ref_p.grad = g.clone()
+            ref.step()
+            assert float((p - ref_p.detach()).abs().max()) < 2e-6
+            assert torch.equal(shadow, p.to(fused.lp_dtype()))
+        scales.append((float(amp[0]), float(amp[1])))
+    # good -> tracker 1; overflow -> scale / 2, tracker 0; three good steps -> scale x 2 at the third, tracker 0; good -> 1
+    assert scales == [(1024.0, 1.0), (512.0, 0.0), (512.0, 1.0), (512.0, 2.0), (1024.0, 0.0), (1024.0, 1.0)], scales
+    assert float(step) == 5.0
+
+
+@pytest.mark.gpu
+def test_loss_scale_and_overflow_flags():
+    """The loss scale multiplies every gradient of vine_ln_heads_loss (dx, the LayerNorm / head partial sums, the head
+    bias and log-sigma gradients), not its statistics; a 16-bit dx that overflows the format raises found_inf; the
+    batched column sums raise it for non-finite results."""
+    from vine_robot_isaacgymenvs_amd import native
+    from vine_robot_isaacgymenvs_amd.abi import PPO_LOSS_SCRATCH_FLOATS, PPO_PARTIAL_BLOCKS
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    H, A = 256, 2
+    NH = A + 1
+    n = 4 * lib.vine_ln_heads_loss_rows()
+    x = torch.randn(n, H, device=dev)
+    gamma, beta = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+    w, wb = torch.randn(NH, H, device=dev) * 0.05, torch.randn(NH, device=dev) * 0.1
+    logstd = torch.randn(A, device=dev) * 0.1
+    actions, old_mu = torch.randn(n, A, device=dev), torch.randn(n, A, device=dev) * 0.3
+    old_sigma = torch.rand(n, A, device=dev) + 0.5
+    old_nlp, adv = torch.randn(n, device=dev) * 0.3 + 2.0, torch.randn(n, device=dev)
+    old_values, returns = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    scal = (0.2, 1, 2.0, 0.0, 1e-4, 1.1)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(scale, lp16):
+        heads = torch.empty(n, NH, device=dev)
+        dx = torch.empty(n, H, device=dev, dtype=fused.lp_dtype() if lp16 else torch.float32)
+        part = torch.empty(PPO_PARTIAL_BLOCKS, 2 * H + NH * H, device=dev)
+        stats, gls = torch.zeros(8, device=dev), torch.zeros(A, device=dev)
+        gmb, gvb, acc = torch.zeros(A, device=dev), torch.zeros(1, device=dev), torch.zeros(A, device=dev)
+        scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=dev)
+        s_t = torch.tensor([scale], device=dev) if scale is not None else None
+        found = torch.zeros(1, device=dev)
+        rc = lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(), wb.data_ptr(),
+                                    logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
+                                    old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
+                                    heads.data_ptr(), dx.data_ptr(), int(lp16), part.data_ptr(), stats.data_ptr(), gls.data_ptr(),
+                                    gmb.data_ptr(), gvb.data_ptr(), scratch.data_ptr(), None, acc.data_ptr(), None, None,
+                                    s_t.data_ptr() if s_t is not None else None, found.data_ptr(), st)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return dict(dx=dx.float(), part=part[:n // lib.vine_ln_heads_loss_rows()].clone(), stats=stats, gls=gls, gmb=gmb,
+                    gvb=gvb, acc=acc, found=float(found))
+
+    base, scaled = run(None, False), run(4096.0, False)
+    assert torch.equal(base["stats"], scaled["stats"]) and base["found"] == scaled["found"] == 0.0
+    for k in ("dx", "part", "gls", "gmb", "gvb", "acc"):        # a power-of-two scale: exact
+        assert torch.equal(scaled[k], base[k] * 4096.0), k
+    if fused.lp_dtype() == torch.float16:
+        ok = run(4096.0, True)
+        assert ok["found"] == 0.0 and float((ok["dx"] - scaled["dx"]).abs().max()) <= 1e-3 * float(scaled["dx"].abs().max())
+        big = 65504.0 * 4.0 / float(base["dx"].abs().max())      # pushes the largest dx element out of the fp16 range
+        assert run(big, True)["found"] == 1.0 and run(big, False)["found"] == 0.0
+    # column sums: a non-finite result raises the flag, finite ones leave it alone
+    src = torch.randn(64, 512, device=dev)
+    out = torch.empty(512, device=dev)
+    found = torch.zeros(1, device=dev)
+    fused.set_amp(torch.ones(1, device=dev), found)
+    try:
+        b = fused.ColumnSumBatch(check_overflow=True)
+        b.add(src, out)
+        b.flush(src)
+        torch.cuda.synchronize()
+        assert float(found) == 0.0 and torch.allclose(out, src.sum(0), atol=1e-4)
+        src[3, 100] = float("nan")
+        b = fused.ColumnSumBatch(check_overflow=True)
+        b.add(src, out)
+        b.flush(src)
+        torch.cuda.synchronize()
+        assert float(found) == 1.0
+    finally:
+        fused.set_amp(None, None)
+
+
+@pytest.mark.gpu
+def test_fp16_update_recovers_from_an_absurd_loss_scale():
+    """End to end: the default mixed-precision update (fp16 operands, device-side GradScaler) started at a loss scale that
+    overflows float16: the first optimiser steps are skipped (parameters unchanged) while the scale backs off, then
+    training proceeds; nothing ever becomes non-finite, and the learning-rate schedule keeps running."""
+    if fused.lp_dtype() != torch.float16:
+        pytest.skip("bf16 build: no loss scaling")
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048"])
+    cfg["task"]["seed"] = 42
+    env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                  graphics_device_id=0, headless=True)
+    params = cfg["train"]["params"]
+    params["config"].update(write_files=False, print_stats=False, use_graphs=True, mixed_precision=True,
+                            loss_scale_init=2.0 ** 40)
+    torch.manual_seed(0)
+    agent = A2CAgent("t", params, vec_env=env)
+    assert agent.fused_mixed and agent.optimizer.amp_state is not None and agent._fast_op_is_fp32()
+    agent.init_tensors()
+    agent.obs = agent.env_reset()["obs"]
+    p0 = agent.optimizer.flat_params.clone()
+    scales, steps = [], []
+    for _ in range(4):
+        _, _, stats = agent.train_epoch()
+        torch.cuda.synchronize()
+        scales.append(agent.optimizer.loss_scale)
+        steps.append(float(agent.optimizer.step_t))
+        assert torch.isfinite(agent.optimizer.flat_params).all() and all(np.isfinite(float(v)) for v in stats.values())
+    n_steps = 4 * agent.mini_epochs_num * agent.num_minibatches
+    assert scales[0] < 2.0 ** 40 and steps[-1] < n_steps            # some steps were skipped while the scale backed off
+    assert steps[-1] > 0 and not torch.equal(agent.optimizer.flat_params, p0)     # ... and then it trained
+    assert scales[-1] >= 1.0
+    env.close()

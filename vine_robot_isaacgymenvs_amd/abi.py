@@ -196,7 +196,9 @@ PPO_PROTOTYPES = {
                                      _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _VP, _VP, _I64, _VP]),
     "vine_ln_heads_loss": (C.c_int, [_I64, _I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                      _VP, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _VP, _VP, C.c_int32,
-                                     _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+                                     _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_lp16_format": (C.c_char_p, []),
+    "vine_ppo_runtime_init": (C.c_int, []),
     "vine_ln_heads_loss_rows": (C.c_int, []),
     "vine_mlp3_bwd_elu_mfma": (C.c_int, [_I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _I64,
                                          _I64, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -211,9 +213,9 @@ PPO_PROTOTYPES = {
                                     _VP]),
     "vine_bias_elu": (C.c_int, [_I64, _I64, _VP, _VP, C.c_float, _VP, _I64, C.c_int32, _VP]),
     "vine_ppo_loss": (C.c_int, [_I64, C.c_int32] + [_VP] * 10 + [C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float,
-                                                                C.c_float] + [_VP] * 4 + [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+                                                                C.c_float] + [_VP] * 4 + [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_copy_batched": (C.c_int, [C.c_int32] + [_VP] * 10 + [_VP]),
-    "vine_column_sums_batched": (C.c_int, [C.c_int32] + [_VP] * 8 + [_VP]),
+    "vine_column_sums_batched": (C.c_int, [C.c_int32] + [_VP] * 8 + [_VP, _VP]),
     "vine_column_sums": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_int32, _VP]),
     "vine_policy_head": (C.c_int, [_I64, C.c_int32, _I64] + [_VP] * 8 + [C.c_int32, C.c_uint64] + [_VP] * 6 +
                          [_VP, _VP, C.c_float, _VP]),
@@ -226,6 +228,8 @@ PPO_PROTOTYPES = {
                                  C.c_float, _VP, _VP]),
     "vine_adam_step_sched": (C.c_int, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
+    "vine_adam_step_amp": (C.c_int, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP]),
     "vine_adaptive_lr": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
 }
 

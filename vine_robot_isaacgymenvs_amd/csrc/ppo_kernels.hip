@@ -26,31 +26,68 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// bfloat16 storage (GEMM operands of the mixed-precision update; arithmetic stays fp32): round to nearest even, by
-// the hardware conversion of gfx950 (v_cvt_pk_bf16_f32: one instruction per two values)
-typedef unsigned short bf16_t;
-typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_hw;
+// 16-bit storage of the mixed-precision update (GEMM operands and backward-only saved activations; arithmetic and
+// accumulation stay fp32).  The format is a build-time choice of this translation unit:
+//   default        IEEE half (fp16: 11-bit significand) -- what the reference's `mixed_precision: True` autocasts to
+//                  (Vine5LinkMovingBasePPO.yaml:53), with its GradScaler restated on the device (loss scale applied by the
+//                  loss kernel, overflow flagged where a gradient is rounded to 16 bits, skip / back-off / growth in the
+//                  Adam kernel): v_mfma_f32_16x16x32_f16, same rate as the bf16 form;
+//   -DVINE_LP_BF16 bfloat16 (8-bit significand, fp32 range, no loss scaling needed): the round-2 format, kept as an A/B build.
+// vine_lp16_format() reports which one the library was built with; the host allocates torch.float16 / torch.bfloat16 to match.
+typedef unsigned short lp16_t;
 typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2_hw;
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    const __bf16 h = (__bf16)f;
-    return *reinterpret_cast<const bf16_t*>(&h);
+#ifdef VINE_LP_BF16
+typedef __bf16 lp16_hw;
+#define VINE_LP16_NAME "bf16"
+#define MFMA_LP16_BUILTIN __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+typedef __bf16 lp16_tr_hw;
+#define LP16_MAX 3.3895314e38f
+#else
+typedef _Float16 lp16_hw;
+#define VINE_LP16_NAME "fp16"
+#define MFMA_LP16_BUILTIN __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define DS_READ_TR16_B64 __builtin_amdgcn_ds_read_tr16_b64_v4f16
+typedef __fp16 lp16_tr_hw;
+#define LP16_MAX 65504.0f
+#endif
+typedef __attribute__((__vector_size__(2 * sizeof(lp16_hw)))) lp16_hw lp16x2_hw;
+// round to nearest even (v_cvt_pk_bf16_f32 / v_cvt_f16_f32)
+__device__ __forceinline__ lp16_t f2lp(float f) {
+    const lp16_hw h = (lp16_hw)f;
+    return *reinterpret_cast<const lp16_t*>(&h);
 }
-__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {      // two values -> one packed dword
+__device__ __forceinline__ unsigned f2lp2(float lo, float hi) {      // two values -> one packed dword
     const f32x2_hw v = {lo, hi};
-    const bf16x2_hw h = __builtin_convertvector(v, bf16x2_hw);
+    const lp16x2_hw h = __builtin_convertvector(v, lp16x2_hw);
     return *reinterpret_cast<const unsigned*>(&h);
 }
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
-// 4 consecutive elements, fp32 or bf16 storage
-__device__ __forceinline__ float4 ld4(const bf16_t* p) {
-    const uint2 r = *reinterpret_cast<const uint2*>(p);
-    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16),
-                       __uint_as_float(r.y & 0xFFFF0000u));
+#ifdef VINE_LP_BF16
+__device__ __forceinline__ float lp2f(lp16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void unpack2(unsigned r, float& lo, float& hi) {
+    lo = __uint_as_float(r << 16);
+    hi = __uint_as_float(r & 0xFFFF0000u);
 }
-__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+#else
+__device__ __forceinline__ float lp2f(lp16_t h) { return (float)*reinterpret_cast<const lp16_hw*>(&h); }
+__device__ __forceinline__ void unpack2(unsigned r, float& lo, float& hi) {
+    const lp16x2_hw h = *reinterpret_cast<const lp16x2_hw*>(&r);
+    lo = (float)h[0];
+    hi = (float)h[1];
+}
+#endif
+// 4 consecutive elements, fp32 or 16-bit storage
+__device__ __forceinline__ float4 ld4(const lp16_t* p) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    float4 v;
+    unpack2(r.x, v.x, v.y);
+    unpack2(r.y, v.z, v.w);
+    return v;
+}
+__device__ __forceinline__ void st4(lp16_t* p, float4 v) {
     uint2 r;
-    r.x = f2bf2(v.x, v.y);
-    r.y = f2bf2(v.z, v.w);
+    r.x = f2lp2(v.x, v.y);
+    r.y = f2lp2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = r;
 }
 
@@ -130,23 +167,24 @@ __global__ void lstm_fwd_kernel(long long B, int H, const float* __restrict__ ig
 // slab while one workgroup walks over several 64-row blocks (fewer, longer workgroups: 37 us at K = 352).
 // What did pay for the K = 352 [x | h] shapes: lstm_step_mfma64_kernel below (64 units per workgroup, the A fragments
 // are re-read 4 instead of 16 times, W streamed one 32-wide k-step at a time): 28.9 us against 32.3 us.
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(8 * sizeof(lp16_hw)))) lp16_hw lp16x8_t;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+__device__ __forceinline__ f32x4_t MFMA_LP16(lp16x8_t a, lp16x8_t b, f32x4_t c) { return MFMA_LP16_BUILTIN(a, b, c, 0, 0, 0); }
 #define LSTM_MFMA_MAX_K 512
 
 template <int KSTEPS, int KS1>      // K = 32 * KSTEPS; the first KS1 k-steps of A come from A, the rest from A2
 __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
-    long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ A2, long long lda2,
-    const bf16_t* __restrict__ W, long long ldw,
+    long long B, int H, const lp16_t* __restrict__ A, long long lda, const lp16_t* __restrict__ A2, long long lda2,
+    const lp16_t* __restrict__ W, long long ldw,
     const float* __restrict__ igates, long long ig_stride, const float* __restrict__ bias,
     const float* __restrict__ c_prev, const unsigned char* __restrict__ done, long long done_stride,
-    float* __restrict__ h_out, long long h_stride, float* __restrict__ c_out, bf16_t* __restrict__ gates_act,
-    bf16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next, long long done_next_stride,
+    float* __restrict__ h_out, long long h_stride, float* __restrict__ c_out, lp16_t* __restrict__ gates_act,
+    lp16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next, long long done_next_stride,
     long long hp_stride) {
     constexpr int K = 32 * KSTEPS;
     constexpr int PITCH = K + 8;                               // bf16 elements: K*2 + 16 bytes
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    bf16_t* wl = reinterpret_cast<bf16_t*>(lds_raw);           // [4 gates x 16 units][PITCH]
+    lp16_t* wl = reinterpret_cast<lp16_t*>(lds_raw);           // [4 gates x 16 units][PITCH]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 16;                            // first hidden unit of this workgroup
     const long long b0 = (long long)blockIdx.x * 64 + wave * 16;
@@ -155,13 +193,13 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     // operands (this lane owns batch row b, hidden units j .. j+3 of every gate).
     const long long b = b0 + (lane & 15);
     const int j = u0 + 4 * (lane >> 4);
-    bf16x8_t af[KSTEPS];
-    const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
-    const bf16_t* arow2 = KS1 < KSTEPS && KS1 > 0 ? A2 + b * lda2 + 8 * (lane >> 4) : arow;
+    lp16x8_t af[KSTEPS];
+    const lp16_t* arow = A + b * lda + 8 * (lane >> 4);
+    const lp16_t* arow2 = KS1 < KSTEPS && KS1 > 0 ? A2 + b * lda2 + 8 * (lane >> 4) : arow;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk)
-        af[kk] = (KS1 == 0 || kk < KS1) ? *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk)
-                                        : *reinterpret_cast<const bf16x8_t*>(arow2 + 32 * (kk - KS1));
+        af[kk] = (KS1 == 0 || kk < KS1) ? *reinterpret_cast<const lp16x8_t*>(arow + 32 * kk)
+                                        : *reinterpret_cast<const lp16x8_t*>(arow2 + 32 * (kk - KS1));
     float4 igv[4], bbv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -199,9 +237,9 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const bf16x8_t wf =
-                *reinterpret_cast<const bf16x8_t*>(&wl[(g * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[g], 0, 0, 0);
+            const lp16x8_t wf =
+                *reinterpret_cast<const lp16x8_t*>(&wl[(g * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
+            acc[g] = MFMA_LP16(wf, af[kk], acc[g]);
         }
     }
     float pre[4][4];
@@ -225,7 +263,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
     st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
     if (hp_next) st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
     if (gates_act) {
-        bf16_t* ga = gates_act + b * 4LL * H;
+        lp16_t* ga = gates_act + b * 4LL * H;
         st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
         st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
         st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
@@ -239,34 +277,34 @@ __global__ __launch_bounds__(256) void lstm_step_mfma_kernel(
 // through LDS so that 16 lanes cover one row's 64 units: 256 contiguous bytes per row and array instead of 64.
 template <int KSTEPS, int KS1>
 __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
-    long long B, int H, const bf16_t* __restrict__ A, long long lda, const bf16_t* __restrict__ A2, long long lda2,
-    const bf16_t* __restrict__ W, long long ldw, const float* __restrict__ igates, long long ig_stride,
+    long long B, int H, const lp16_t* __restrict__ A, long long lda, const lp16_t* __restrict__ A2, long long lda2,
+    const lp16_t* __restrict__ W, long long ldw, const float* __restrict__ igates, long long ig_stride,
     const float* __restrict__ bias, const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
     long long done_stride, float* __restrict__ h_out, long long h_stride, float* __restrict__ c_out,
-    bf16_t* __restrict__ gates_act, bf16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
+    lp16_t* __restrict__ gates_act, lp16_t* __restrict__ hp_next, const unsigned char* __restrict__ done_next,
     long long done_next_stride, long long hp_stride) {
     constexpr int PITCH = 32 + 8;                              // 80 B rows: 16 fragment rows x 16 B tile the banks
     constexpr int GP = 4 * 64 + 4;                             // floats per row of the pre-activation hand-over tile
     // one LDS block: the two weight buffers (2 x 20 KB) during the product, the [64][GP] fp32 tile (65 KB) after it
     __shared__ __attribute__((aligned(16))) float smem[64 * GP];
-    bf16_t (*wl)[256 * PITCH] = reinterpret_cast<bf16_t (*)[256 * PITCH]>(smem);
+    lp16_t (*wl)[256 * PITCH] = reinterpret_cast<lp16_t (*)[256 * PITCH]>(smem);
     float* gt = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
     // A fragments, all k-steps up front
-    bf16x8_t af[KSTEPS];
-    const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
-    const bf16_t* arow2 = KS1 < KSTEPS && KS1 > 0 ? A2 + b * lda2 + 8 * (lane >> 4) : arow;
+    lp16x8_t af[KSTEPS];
+    const lp16_t* arow = A + b * lda + 8 * (lane >> 4);
+    const lp16_t* arow2 = KS1 < KSTEPS && KS1 > 0 ? A2 + b * lda2 + 8 * (lane >> 4) : arow;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk)
-        af[kk] = (KS1 == 0 || kk < KS1) ? *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk)
-                                        : *reinterpret_cast<const bf16x8_t*>(arow2 + 32 * (kk - KS1));
+        af[kk] = (KS1 == 0 || kk < KS1) ? *reinterpret_cast<const lp16x8_t*>(arow + 32 * kk)
+                                        : *reinterpret_cast<const lp16x8_t*>(arow2 + 32 * (kk - KS1));
     // weight chunk kk: LDS row g*64 + i <- W[g*H + u0 + i][32 kk : 32 kk + 32]; 1024 16-B pieces, 4 per thread
     // (piece p = tid + 256 q: row p >> 2, 16-B column p & 3)
     const int pcol = threadIdx.x & 3;
     int prow[4];
-    const bf16_t* wsrc[4];
+    const lp16_t* wsrc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         prow[q] = ((int)threadIdx.x + 256 * q) >> 2;
@@ -297,12 +335,12 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
 #define LSTM_STEP(kk, SL, SS)                                                                                  \
     if (KSTEPS > (kk)) {                                                                                       \
         if ((kk) > 0 && (kk) + 2 < KSTEPS) { LOAD_W(SL, (kk) + 2); }                                           \
-        const bf16_t* wb_ = wl[(kk) & 1];                                                                      \
+        const lp16_t* wb_ = wl[(kk) & 1];                                                                      \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                          \
             _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
-                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(                                        \
+                const lp16x8_t wf = *reinterpret_cast<const lp16x8_t*>(                                        \
                     wb_ + (g * 64 + t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4));                          \
-                acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[(kk) < KSTEPS ? (kk) : 0], acc[g][t], 0, 0, 0); \
+                acc[g][t] = MFMA_LP16(wf, af[(kk) < KSTEPS ? (kk) : 0], acc[g][t]); \
             }                                                                                                  \
         if ((kk) + 1 < KSTEPS) { STORE_W(SS, (kk) + 1); }                                                      \
         __syncthreads();                                                                                       \
@@ -383,7 +421,7 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
         st4(h_out + b * h_stride + j, make_float4(hn[0], hn[1], hn[2], hn[3]));
         if (hp_next) st4(hp_next + b * hp_stride + j, make_float4(kn * hn[0], kn * hn[1], kn * hn[2], kn * hn[3]));
         if (gates_act) {
-            bf16_t* ga = gates_act + b * 4LL * H;
+            lp16_t* ga = gates_act + b * 4LL * H;
             st4(ga + 0 * H + j, make_float4(gi[0], gi[1], gi[2], gi[3]));
             st4(ga + 1 * H + j, make_float4(gf[0], gf[1], gf[2], gf[3]));
             st4(ga + 2 * H + j, make_float4(gg[0], gg[1], gg[2], gg[3]));
@@ -426,8 +464,8 @@ __device__ __forceinline__ void seq_barrier() {
 // dst chunk -> source elements.  transposed = 0: Wsrc [rows, ld] row-major, row(g, unit) = g * H + unit, k along the
 // row (forward: [w_ih | 0 | w_hh], K = 32 KSTEPS).  transposed = 1: element (unit, k) = Wsrc[k * ld + unit] (backward:
 // Wsrc = w_hh [4H, H], the product dG W_hh sums over k = gate-major 4H index; NJ = 2, row(g, unit) = unit).
-__global__ __launch_bounds__(256) void lstm_tile_weights_kernel(const bf16_t* __restrict__ src, long long ld, int H, int ksteps,
-                                                                int nj, int transposed, bf16_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void lstm_tile_weights_kernel(const lp16_t* __restrict__ src, long long ld, int H, int ksteps,
+                                                                int nj, int transposed, lp16_t* __restrict__ dst) {
     const long long chunks = (long long)(H / 32) * ksteps * nj * 64;
     for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(c & 63);
@@ -442,7 +480,7 @@ __global__ __launch_bounds__(256) void lstm_tile_weights_kernel(const bf16_t* __
         if (!transposed) {
             v = *reinterpret_cast<const uint4*>(src + (long long)(g * H + unit) * ld + k0);
         } else {
-            bf16_t e[8];
+            lp16_t e[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) e[i] = src[(long long)(k0 + i) * ld + unit];
             v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
@@ -457,24 +495,24 @@ __device__ __forceinline__ uint4 seq_load_frag(__amdgpu_buffer_rsrc_t rsrc, int 
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ uint4 pack_bf16x8(const float (&v)[8]) {
+__device__ __forceinline__ uint4 pack_lp16x8(const float (&v)[8]) {
     uint4 r;
-    r.x = f2bf2(v[0], v[1]); r.y = f2bf2(v[2], v[3]); r.z = f2bf2(v[4], v[5]); r.w = f2bf2(v[6], v[7]);
+    r.x = f2lp2(v[0], v[1]); r.y = f2lp2(v[2], v[3]); r.z = f2lp2(v[4], v[5]); r.w = f2lp2(v[6], v[7]);
     return r;
 }
 
-// CT: storage type of the saved cell states c_1 .. c_{T-1} (read again by the backward kernel only): float, or bf16_t
+// CT: storage type of the saved cell states c_1 .. c_{T-1} (read again by the backward kernel only): float, or lp16_t
 // -- the recurrence itself always runs on the fp32 registers, and c_T then goes to `c_last` in fp32.
 template <int KS1, int RING, typename CT>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
 __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
-    int T, long long B, const bf16_t* __restrict__ x, long long ldx, bf16_t* hp, long long hp_stride,
+    int T, long long B, const lp16_t* __restrict__ x, long long ldx, lp16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
     const unsigned char* __restrict__ done, float* __restrict__ h_out, CT* __restrict__ c_all,
-    bf16_t* __restrict__ gates, int ablate, float* __restrict__ c_last, const float* __restrict__ h0) {
+    lp16_t* __restrict__ gates, int ablate, float* __restrict__ c_last, const float* __restrict__ h0) {
     constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
     constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
-    __shared__ __attribute__((aligned(16))) bf16_t xh[2][SEQ_ROWS * PITCH];      // [x_t | masked h_{t-1}] operand rows
+    __shared__ __attribute__((aligned(16))) lp16_t xh[2][SEQ_ROWS * PITCH];      // [x_t | masked h_{t-1}] operand rows
     __shared__ __attribute__((aligned(16))) float bias_l[4 * H];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the stream base below lives in SGPRs
@@ -509,7 +547,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 const float keep0 = (done && done[(b0 + r) * T]) ? 0.0f : 1.0f;
                 const float4 a = ld4(h0 + (b0 + r) * H + 8 * c8), b = ld4(h0 + (b0 + r) * H + 8 * c8 + 4);
                 const float v[8] = {keep0 * a.x, keep0 * a.y, keep0 * a.z, keep0 * a.w, keep0 * b.x, keep0 * b.y, keep0 * b.z, keep0 * b.w};
-                hv = pack_bf16x8(v);
+                hv = pack_lp16x8(v);
                 *reinterpret_cast<uint4*>(hp + (b0 + r) * hp_stride + 8 * c8) = hv;
             } else {
                 hv = *reinterpret_cast<const uint4*>(hp + (b0 + r) * hp_stride + 8 * c8);      // slot 0: masked h_{-1}
@@ -534,8 +572,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
         seq_barrier();                                           // xh[t & 1] complete (and bias_l on the first pass)
-        const bf16_t* xb = xh[t & 1];
-        bf16_t* xn = xh[(t + 1) & 1];
+        const lp16_t* xb = xh[t & 1];
+        lp16_t* xn = xh[(t + 1) & 1];
         const bool last = t == T - 1;
         // x_{t+1}: requested now, moved into the other operand buffer after the matrix loop
         uint4 xstage = make_uint4(0, 0, 0, 0);
@@ -551,15 +589,15 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 for (int rt = 0; rt < 2; ++rt) acc[g][ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
-            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
+            const lp16x8_t a0 = *reinterpret_cast<const lp16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
+            const lp16x8_t a1 = *reinterpret_cast<const lp16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = kk * 8 + j, slot = f % RING;
                 const uint4 wr = ring[slot];
-                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wr);
-                acc[j >> 1][j & 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[j >> 1][j & 1][0], 0, 0, 0);
-                acc[j >> 1][j & 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[j >> 1][j & 1][1], 0, 0, 0);
+                const lp16x8_t wf = __builtin_bit_cast(lp16x8_t, wr);
+                acc[j >> 1][j & 1][0] = MFMA_LP16(wf, a0, acc[j >> 1][j & 1][0]);
+                acc[j >> 1][j & 1][1] = MFMA_LP16(wf, a1, acc[j >> 1][j & 1][1]);
                 if (!(ablate & 2)) ring[slot] = SEQ_WFRAG((f + RING) % NF);      // the fragment RING places further down the stream
                 // pin the order {2 MFMAs, reload}: left alone, the scheduler sinks every reload down to its use one
                 // step later (to save registers) and the ring degenerates into load -> wait -> use
@@ -604,17 +642,17 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
                 }
                 uint2 pk[5];
-                pk[0] = make_uint2(f2bf2(gi[0], gi[1]), f2bf2(gi[2], gi[3]));
-                pk[1] = make_uint2(f2bf2(gf[0], gf[1]), f2bf2(gf[2], gf[3]));
-                pk[2] = make_uint2(f2bf2(gg[0], gg[1]), f2bf2(gg[2], gg[3]));
-                pk[3] = make_uint2(f2bf2(go[0], go[1]), f2bf2(go[2], go[3]));
-                pk[4] = make_uint2(f2bf2(kn * hn[0], kn * hn[1]), f2bf2(kn * hn[2], kn * hn[3]));
+                pk[0] = make_uint2(f2lp2(gi[0], gi[1]), f2lp2(gi[2], gi[3]));
+                pk[1] = make_uint2(f2lp2(gf[0], gf[1]), f2lp2(gf[2], gf[3]));
+                pk[2] = make_uint2(f2lp2(gg[0], gg[1]), f2lp2(gg[2], gg[3]));
+                pk[3] = make_uint2(f2lp2(go[0], go[1]), f2lp2(go[2], go[3]));
+                pk[4] = make_uint2(f2lp2(kn * hn[0], kn * hn[1]), f2lp2(kn * hn[2], kn * hn[3]));
                 if (ut == 0) {
 #pragma unroll
                     for (int a = 0; a < 5; ++a) lo[a] = pk[a];
                 } else {
                     if (gates && !(ablate & 1)) {
-                        bf16_t* ga = gates + ((long long)t * B + b) * 4 * H + U0;
+                        lp16_t* ga = gates + ((long long)t * B + b) * 4 * H + U0;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
                             *reinterpret_cast<uint4*>(ga + g * H) = make_uint4(lo[g].x, lo[g].y, pk[g].x, pk[g].y);
@@ -644,25 +682,22 @@ __device__ __forceinline__ float dpp_row_sum16(float v) {
     s += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(s), 0x118, 0xf, 0xc, true));                // row_shr:8
     return s;
 }
-__device__ __forceinline__ void unpack_bf16x8(uint4 r, float (&v)[8]) {
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xFFFF0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xFFFF0000u);
-    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xFFFF0000u);
-    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xFFFF0000u);
+__device__ __forceinline__ void unpack_lp16x8(uint4 r, float (&v)[8]) {
+    unpack2(r.x, v[0], v[1]); unpack2(r.y, v[2], v[3]); unpack2(r.z, v[4], v[5]); unpack2(r.w, v[6], v[7]);
 }
 
-// CT: storage type of the saved cell states (see the forward kernel; with bf16_t, c_T comes from `c_last` in fp32);
-// GT: type of the incoming gradient w.r.t. the hidden states (float, or bf16_t as written by ln_heads_loss_kernel).
+// CT: storage type of the saved cell states (see the forward kernel; with lp16_t, c_T comes from `c_last` in fp32);
+// GT: type of the incoming gradient w.r.t. the hidden states (float, or lp16_t as written by ln_heads_loss_kernel).
 template <int RING, typename CT, typename GT>
 __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
-    int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const bf16_t* __restrict__ gates,
+    int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const lp16_t* __restrict__ gates,
     const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
-    bf16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
+    lp16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
     constexpr int H = SEQ_H, K = 4 * H, KSTEPS = K / 32, NF = KSTEPS * 2;
     constexpr int PITCH = K + 8;
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
     extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
-    bf16_t (*dgl)[SEQ_ROWS * PITCH] = reinterpret_cast<bf16_t (*)[SEQ_ROWS * PITCH]>(seq_lds);     // [2][32 rows][4H + 8]
+    lp16_t (*dgl)[SEQ_ROWS * PITCH] = reinterpret_cast<lp16_t (*)[SEQ_ROWS * PITCH]>(seq_lds);     // [2][32 rows][4H + 8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15, lq = lane >> 4;
@@ -713,7 +748,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
                 const CT* cpp_ = c_all + ((long long)t * B + b_) * H + U0;                                 \
                 cp4[rt][0] = ld4(cpp_); cp4[rt][1] = ld4(cpp_ + 4);                                        \
             }                                                                                              \
-            const bf16_t* ga_ = gates + ((long long)t * B + b_) * 4 * H + U0;                              \
+            const lp16_t* ga_ = gates + ((long long)t * B + b_) * 4 * H + U0;                              \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) gpk[rt][g] = *reinterpret_cast<const uint4*>(ga_ + g * H); \
         }
         SEQ_BWD_LOAD(0)
@@ -724,23 +759,23 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
             for (int rt = 0; rt < 2; ++rt) acc[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
         if (!first) {
             seq_barrier();                                       // dG_{t+1} complete in dgl[(t + 1) & 1]
-            const bf16_t* xb = dgl[(t + 1) & 1];
+            const lp16_t* xb = dgl[(t + 1) & 1];
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
-                const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
-                const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
+                const lp16x8_t a0 = *reinterpret_cast<const lp16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
+                const lp16x8_t a1 = *reinterpret_cast<const lp16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int f = kk * 2 + j, slot = f % RING;
-                    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, ring[slot]);
-                    acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a0, acc[j][0], 0, 0, 0);
-                    acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a1, acc[j][1], 0, 0, 0);
+                    const lp16x8_t wf = __builtin_bit_cast(lp16x8_t, ring[slot]);
+                    acc[j][0] = MFMA_LP16(wf, a0, acc[j][0]);
+                    acc[j][1] = MFMA_LP16(wf, a1, acc[j][1]);
                     if (!(ablate & 2)) ring[slot] = SEQ_WFRAG((f + RING) % NF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        bf16_t* dgn = dgl[t & 1];
+        lp16_t* dgn = dgl[t & 1];
         SEQ_BWD_LOAD(1)
 #undef SEQ_BWD_LOAD
 #pragma unroll
@@ -748,7 +783,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
             const long long b = b0 + 16 * rt + col;
             const float keep = ((dmask[rt] >> t) & 1u) ? 0.0f : 1.0f;
             const float keep_n = ((dmask[rt] >> (t + 1)) & 1u) ? 0.0f : 1.0f;
-            bf16_t* dgp = dG + (b * T + t) * 4 * H + U0;
+            lp16_t* dgp = dG + (b * T + t) * 4 * H + U0;
             uint2 lo[4];                                         // packed dG of unit tile 0 (waits for tile 1: 16-B pieces)
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut) {
@@ -758,14 +793,10 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
                 const unsigned fa = ut ? gpk[rt][1].z : gpk[rt][1].x, fb = ut ? gpk[rt][1].w : gpk[rt][1].y;
                 const unsigned ga_ = ut ? gpk[rt][2].z : gpk[rt][2].x, gb_ = ut ? gpk[rt][2].w : gpk[rt][2].y;
                 const unsigned oa = ut ? gpk[rt][3].z : gpk[rt][3].x, ob = ut ? gpk[rt][3].w : gpk[rt][3].y;
-                gi[0] = __uint_as_float(ia << 16); gi[1] = __uint_as_float(ia & 0xFFFF0000u);
-                gi[2] = __uint_as_float(ib << 16); gi[3] = __uint_as_float(ib & 0xFFFF0000u);
-                gf[0] = __uint_as_float(fa << 16); gf[1] = __uint_as_float(fa & 0xFFFF0000u);
-                gf[2] = __uint_as_float(fb << 16); gf[3] = __uint_as_float(fb & 0xFFFF0000u);
-                gg[0] = __uint_as_float(ga_ << 16); gg[1] = __uint_as_float(ga_ & 0xFFFF0000u);
-                gg[2] = __uint_as_float(gb_ << 16); gg[3] = __uint_as_float(gb_ & 0xFFFF0000u);
-                go[0] = __uint_as_float(oa << 16); go[1] = __uint_as_float(oa & 0xFFFF0000u);
-                go[2] = __uint_as_float(ob << 16); go[3] = __uint_as_float(ob & 0xFFFF0000u);
+                unpack2(ia, gi[0], gi[1]); unpack2(ib, gi[2], gi[3]);
+                unpack2(fa, gf[0], gf[1]); unpack2(fb, gf[2], gf[3]);
+                unpack2(ga_, gg[0], gg[1]); unpack2(gb_, gg[2], gg[3]);
+                unpack2(oa, go[0], go[1]); unpack2(ob, go[2], go[3]);
                 const float gout[4] = {go4[rt][ut].x, go4[rt][ut].y, go4[rt][ut].z, go4[rt][ut].w};
                 const float cp[4] = {cp4[rt][ut].x, cp4[rt][ut].y, cp4[rt][ut].z, cp4[rt][ut].w};
                 float di[4], df[4], dg[4], dout[4];
@@ -787,15 +818,15 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
                     bsum[0][e] += di[u]; bsum[1][e] += df[u]; bsum[2][e] += dg[u]; bsum[3][e] += dout[u];
                 }
                 uint2 pk[4];
-                pk[0] = make_uint2(f2bf2(di[0], di[1]), f2bf2(di[2], di[3]));
-                pk[1] = make_uint2(f2bf2(df[0], df[1]), f2bf2(df[2], df[3]));
-                pk[2] = make_uint2(f2bf2(dg[0], dg[1]), f2bf2(dg[2], dg[3]));
-                pk[3] = make_uint2(f2bf2(dout[0], dout[1]), f2bf2(dout[2], dout[3]));
+                pk[0] = make_uint2(f2lp2(di[0], di[1]), f2lp2(di[2], di[3]));
+                pk[1] = make_uint2(f2lp2(df[0], df[1]), f2lp2(df[2], df[3]));
+                pk[2] = make_uint2(f2lp2(dg[0], dg[1]), f2lp2(dg[2], dg[3]));
+                pk[3] = make_uint2(f2lp2(dout[0], dout[1]), f2lp2(dout[2], dout[3]));
                 if (ut == 0) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) lo[g] = pk[g];
                 } else {
-                    bf16_t* row = dgn + (16 * rt + col) * PITCH + U0;
+                    lp16_t* row = dgn + (16 * rt + col) * PITCH + U0;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint4 v = make_uint4(lo[g].x, lo[g].y, pk[g].x, pk[g].y);
@@ -827,21 +858,21 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
 // lane holds 4 consecutive output units of one row per 16-unit tile, W's 64 x K slab in LDS, A fragments from global
 // memory; workgroup = 64 rows x 64 units, so every output row segment is one full 128-B line of bf16.
 template <int KSTEPS>
-__global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N, const bf16_t* __restrict__ A,
-                                                              long long lda, const bf16_t* __restrict__ W, long long ldw,
+__global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N, const lp16_t* __restrict__ A,
+                                                              long long lda, const lp16_t* __restrict__ W, long long ldw,
                                                               const float* __restrict__ bias, float alpha,
-                                                              bf16_t* __restrict__ out, long long out_stride) {
+                                                              lp16_t* __restrict__ out, long long out_stride) {
     constexpr int K = 32 * KSTEPS;
     constexpr int PITCH = K + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    bf16_t* wl = reinterpret_cast<bf16_t*>(lds_raw);           // [64 units][PITCH]
+    lp16_t* wl = reinterpret_cast<lp16_t*>(lds_raw);           // [64 units][PITCH]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
-    bf16x8_t af[KSTEPS];
-    const bf16_t* arow = A + b * lda + 8 * (lane >> 4);
+    lp16x8_t af[KSTEPS];
+    const lp16_t* arow = A + b * lda + 8 * (lane >> 4);
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const bf16x8_t*>(arow + 32 * kk);
+    for (int kk = 0; kk < KSTEPS; ++kk) af[kk] = *reinterpret_cast<const lp16x8_t*>(arow + 32 * kk);
     float4 bbv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bbv[t] = ld4(bias + u0 + 16 * t + 4 * (lane >> 4));
@@ -869,9 +900,9 @@ __global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N
     for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8_t wf =
-                *reinterpret_cast<const bf16x8_t*>(&wl[(t * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[kk], acc[t], 0, 0, 0);
+            const lp16x8_t wf =
+                *reinterpret_cast<const lp16x8_t*>(&wl[(t * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
+            acc[t] = MFMA_LP16(wf, af[kk], acc[t]);
         }
     }
 #pragma unroll
@@ -903,26 +934,26 @@ __device__ __forceinline__ int mlp3_tile_row(int u) {      // unit -> LDS row: 3
 __device__ __forceinline__ float elu1(float x, float alpha) { return x > 0.0f ? x : alpha * (__expf(x) - 1.0f); }
 
 template <int C1, int C2, int C3, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_elu_mfma_kernel(long long n, bf16_t* x, long long ldx,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_elu_mfma_kernel(long long n, lp16_t* x, long long ldx,
                                                             const float* __restrict__ raw, int F_in,
                                                             const double* __restrict__ mean, const double* __restrict__ var,
-                                                            float eps, float clip, const bf16_t* __restrict__ w1,
-                                                            const float* __restrict__ b1, const bf16_t* __restrict__ w2,
+                                                            float eps, float clip, const lp16_t* __restrict__ w1,
+                                                            const float* __restrict__ b1, const lp16_t* __restrict__ w2,
                                                             long long ldw2, const float* __restrict__ b2,
-                                                            const bf16_t* __restrict__ w3, long long ldw3,
+                                                            const lp16_t* __restrict__ w3, long long ldw3,
                                                             const float* __restrict__ b3, float alpha,
-                                                            bf16_t* __restrict__ act1, bf16_t* __restrict__ act2,
-                                                            bf16_t* out, long long out_stride) {
+                                                            lp16_t* __restrict__ act1, lp16_t* __restrict__ act2,
+                                                            lp16_t* out, long long out_stride) {
     constexpr int P1 = 32 + 8, P2 = C1 + 8, P3 = C2 + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    bf16_t* w1l = reinterpret_cast<bf16_t*>(lds_raw);            // [C1][P1], rows in tile order
-    bf16_t* w2l = w1l + C1 * P1;                                 // [C2][P2], rows in tile order
-    bf16_t* w3l = w2l + C2 * P2;                                 // [C3][P3], natural order (its output goes to memory)
+    lp16_t* w1l = reinterpret_cast<lp16_t*>(lds_raw);            // [C1][P1], rows in tile order
+    lp16_t* w2l = w1l + C1 * P1;                                 // [C2][P2], rows in tile order
+    lp16_t* w3l = w2l + C2 * P2;                                 // [C3][P3], natural order (its output goes to memory)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const long long b = ((long long)blockIdx.x * NW + wave) * 16 + i;
     // ---- this lane's B fragment of layer 1: columns 8 q .. 8 q + 7 of its row (requested before the weight staging)
-    bf16x8_t af1;
+    lp16x8_t af1;
     if (raw) {
         float v[8];
 #pragma unroll
@@ -937,11 +968,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
             }
             v[e] = y;
         }
-        const uint4 pk = pack_bf16x8(v);
-        af1 = __builtin_bit_cast(bf16x8_t, pk);
+        const uint4 pk = pack_lp16x8(v);
+        af1 = __builtin_bit_cast(lp16x8_t, pk);
         *reinterpret_cast<uint4*>(x + b * ldx + 8 * q) = pk;     // the LSTM operand's observation block (+ zero pad)
     } else {
-        af1 = *reinterpret_cast<const bf16x8_t*>(x + b * ldx + 8 * q);
+        af1 = *reinterpret_cast<const lp16x8_t*>(x + b * ldx + 8 * q);
     }
     // ---- weights -> LDS.  Every request leaves before anything is waited for (compile-time trip counts: the staging is
     // one L2 round trip, not one per chunk); layer 1 starts as soon as ITS weights are in LDS, the two larger weights
@@ -971,20 +1002,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
     __syncthreads();
     // ---- layer 1: K = 32, C1 / 32 pairs of output tiles; pair kk becomes the B fragment of k-step kk of layer 2
-    bf16x8_t af2[C1 / 32];
+    lp16x8_t af2[C1 / 32];
 #pragma unroll
     for (int kk = 0; kk < C1 / 32; ++kk) {
         float y[8];
 #pragma unroll
         for (int ut = 0; ut < 2; ++ut) {
-            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w1l[(32 * kk + 16 * ut + i) * P1 + 8 * q]);
-            const f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af1, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            const lp16x8_t wf = *reinterpret_cast<const lp16x8_t*>(&w1l[(32 * kk + 16 * ut + i) * P1 + 8 * q]);
+            const f32x4_t a = MFMA_LP16(wf, af1, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f});
             const float4 bb = ld4(b1 + 32 * kk + 8 * q + 4 * ut);
             y[4 * ut + 0] = elu1(a[0] + bb.x, alpha); y[4 * ut + 1] = elu1(a[1] + bb.y, alpha);
             y[4 * ut + 2] = elu1(a[2] + bb.z, alpha); y[4 * ut + 3] = elu1(a[3] + bb.w, alpha);
         }
-        const uint4 pk = pack_bf16x8(y);
-        af2[kk] = __builtin_bit_cast(bf16x8_t, pk);
+        const uint4 pk = pack_lp16x8(y);
+        af2[kk] = __builtin_bit_cast(lp16x8_t, pk);
         if (act1) *reinterpret_cast<uint4*>(act1 + b * C1 + 32 * kk + 8 * q) = pk;
     }
 #pragma unroll
@@ -999,7 +1030,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     }
     __syncthreads();
     // ---- layer 2: K = C1
-    bf16x8_t af3[C2 / 32];
+    lp16x8_t af3[C2 / 32];
 #pragma unroll
     for (int kp = 0; kp < C2 / 32; ++kp) {
         f32x4_t a[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -1007,8 +1038,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         for (int kk = 0; kk < C1 / 32; ++kk)
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut) {
-                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w2l[(32 * kp + 16 * ut + i) * P2 + 32 * kk + 8 * q]);
-                a[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af2[kk], a[ut], 0, 0, 0);
+                const lp16x8_t wf = *reinterpret_cast<const lp16x8_t*>(&w2l[(32 * kp + 16 * ut + i) * P2 + 32 * kk + 8 * q]);
+                a[ut] = MFMA_LP16(wf, af2[kk], a[ut]);
             }
         float y[8];
 #pragma unroll
@@ -1017,8 +1048,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
             y[4 * ut + 0] = elu1(a[ut][0] + bb.x, alpha); y[4 * ut + 1] = elu1(a[ut][1] + bb.y, alpha);
             y[4 * ut + 2] = elu1(a[ut][2] + bb.z, alpha); y[4 * ut + 3] = elu1(a[ut][3] + bb.w, alpha);
         }
-        const uint4 pk = pack_bf16x8(y);
-        af3[kp] = __builtin_bit_cast(bf16x8_t, pk);
+        const uint4 pk = pack_lp16x8(y);
+        af3[kp] = __builtin_bit_cast(lp16x8_t, pk);
         if (act2) *reinterpret_cast<uint4*>(act2 + b * C2 + 32 * kp + 8 * q) = pk;
     }
     // ---- layer 3: K = C2, natural tile order: lane holds units 16 t + 4 q + {0..3} of its row
@@ -1027,8 +1058,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         f32x4_t a = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kk = 0; kk < C2 / 32; ++kk) {
-            const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w3l[(16 * t + i) * P3 + 32 * kk + 8 * q]);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af3[kk], a, 0, 0, 0);
+            const lp16x8_t wf = *reinterpret_cast<const lp16x8_t*>(&w3l[(16 * t + i) * P3 + 32 * kk + 8 * q]);
+            a = MFMA_LP16(wf, af3[kk], a);
         }
         const float4 bb = ld4(b3 + 16 * t + 4 * q);
         st4(out + b * out_stride + 16 * t + 4 * q,
@@ -1043,23 +1074,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
 // plus one row of column sums of gz per workgroup (= partial bias gradient of the previous layer).  Same transposed
 // product scheme as linear_elu_mfma_kernel; the fp32 input gradient is never stored.
 template <int KSTEPS>
-__global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, int N, const bf16_t* __restrict__ G,
-                                                                  long long ldg, const bf16_t* __restrict__ Wt,
-                                                                  long long ldw, const bf16_t* __restrict__ a,
+__global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, int N, const lp16_t* __restrict__ G,
+                                                                  long long ldg, const lp16_t* __restrict__ Wt,
+                                                                  long long ldw, const lp16_t* __restrict__ a,
                                                                   long long a_stride, float alpha,
-                                                                  bf16_t* __restrict__ gz, long long gz_stride,
+                                                                  lp16_t* __restrict__ gz, long long gz_stride,
                                                                   float* __restrict__ partial) {
     constexpr int K = 32 * KSTEPS;
     constexpr int PITCH = K + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    bf16_t* wl = reinterpret_cast<bf16_t*>(lds_raw);           // [64 units][PITCH], later reused for the column sums
+    lp16_t* wl = reinterpret_cast<lp16_t*>(lds_raw);           // [64 units][PITCH], later reused for the column sums
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
-    bf16x8_t gf[KSTEPS];
-    const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
+    lp16x8_t gf[KSTEPS];
+    const lp16_t* grow = G + b * ldg + 8 * (lane >> 4);
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) gf[kk] = *reinterpret_cast<const bf16x8_t*>(grow + 32 * kk);
+    for (int kk = 0; kk < KSTEPS; ++kk) gf[kk] = *reinterpret_cast<const lp16x8_t*>(grow + 32 * kk);
     float4 av[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) av[t] = ld4(a + b * a_stride + u0 + 16 * t + 4 * (lane >> 4));
@@ -1087,9 +1118,9 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, i
     for (int kk = 0; kk < KSTEPS; ++kk) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16x8_t wf =
-                *reinterpret_cast<const bf16x8_t*>(&wl[(t * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf[kk], acc[t], 0, 0, 0);
+            const lp16x8_t wf =
+                *reinterpret_cast<const lp16x8_t*>(&wl[(t * 16 + (lane & 15)) * PITCH + 32 * kk + 8 * (lane >> 4)]);
+            acc[t] = MFMA_LP16(wf, gf[kk], acc[t]);
         }
     }
     float d[4][4];
@@ -1124,22 +1155,22 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_kernel(long long n, i
 // scratch).  N = 64 output units per workgroup; with N == 64 every G row is read exactly once from HBM.
 template <int NCH>
 __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
-    long long n, int N, const bf16_t* __restrict__ G, long long ldg, const bf16_t* __restrict__ Wt, long long ldw,
-    const bf16_t* __restrict__ a, long long a_stride, float alpha, bf16_t* __restrict__ gz, long long gz_stride,
+    long long n, int N, const lp16_t* __restrict__ G, long long ldg, const lp16_t* __restrict__ Wt, long long ldw,
+    const lp16_t* __restrict__ a, long long a_stride, float alpha, lp16_t* __restrict__ gz, long long gz_stride,
     float* __restrict__ partial) {
     constexpr int CK = 128;                                    // k per chunk = 4 MFMA k-steps
     constexpr int PITCH = CK + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t wl[2][64 * PITCH];
+    __shared__ __attribute__((aligned(16))) lp16_t wl[2][64 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
-    const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
+    const lp16_t* grow = G + b * ldg + 8 * (lane >> 4);
     // this thread's 4 weight pieces of a chunk: piece p = tid + 256 q -> row p >> 4, 16-B column p & 15
     const int prow[4] = {(int)threadIdx.x >> 4, ((int)threadIdx.x + 256) >> 4, ((int)threadIdx.x + 512) >> 4,
                          ((int)threadIdx.x + 768) >> 4};
     const int pcol = threadIdx.x & 15;
     uint4 w0, w1, w2, w3;
-    bf16x8_t g0, g1, g2, g3, h0, h1, h2, h3;
+    lp16x8_t g0, g1, g2, g3, h0, h1, h2, h3;
 #define LOAD_W(c)                                                                                              \
     w0 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[0]) * ldw + (c) * CK + pcol * 8);          \
     w1 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[1]) * ldw + (c) * CK + pcol * 8);          \
@@ -1151,10 +1182,10 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
     *reinterpret_cast<uint4*>(&wl[buf][prow[2] * PITCH + pcol * 8]) = w2;                                      \
     *reinterpret_cast<uint4*>(&wl[buf][prow[3] * PITCH + pcol * 8]) = w3
 #define LOAD_G(c, x0, x1, x2, x3)                                                                              \
-    x0 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK);                                                  \
-    x1 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 32);                                             \
-    x2 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 64);                                             \
-    x3 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 96)
+    x0 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK);                                                  \
+    x1 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK + 32);                                             \
+    x2 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK + 64);                                             \
+    x3 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK + 96)
     LOAD_W(0);
     LOAD_G(0, g0, g1, g2, g3);
     float4 av[4];
@@ -1171,14 +1202,14 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
             LOAD_W(c + 1);
             LOAD_G(c + 1, h0, h1, h2, h3);
         }
-        const bf16_t* wb = wl[c & 1];
+        const lp16_t* wb = wl[c & 1];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16_t* wr = wb + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr), g0, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32), g1, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 64), g2, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 96), g3, acc[t], 0, 0, 0);
+            const lp16_t* wr = wb + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr), g0, acc[t]);
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 32), g1, acc[t]);
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 64), g2, acc[t]);
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 96), g3, acc[t]);
         }
         if (c + 1 < NCH) {
             STORE_W((c + 1) & 1);                              // buffer (c+1)&1 was last read before the previous barrier
@@ -1227,24 +1258,24 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
 // a wave (dpp_row_sum16), then across the waves through LDS -- fixed order, no atomics.
 template <int C3, int C2, int C1, int NCH, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_bwd_elu_mfma_kernel(
-    long long n, const bf16_t* __restrict__ G, long long ldg, const bf16_t* __restrict__ Wt0, long long ldw0,
-    const bf16_t* __restrict__ Wt1, long long ldw1, const bf16_t* __restrict__ Wt2, long long ldw2,
-    const bf16_t* __restrict__ a3, long long a3_stride, const bf16_t* __restrict__ a2, const bf16_t* __restrict__ a1,
-    float alpha, bf16_t* __restrict__ gz3, bf16_t* __restrict__ gz2, bf16_t* __restrict__ gz1,
+    long long n, const lp16_t* __restrict__ G, long long ldg, const lp16_t* __restrict__ Wt0, long long ldw0,
+    const lp16_t* __restrict__ Wt1, long long ldw1, const lp16_t* __restrict__ Wt2, long long ldw2,
+    const lp16_t* __restrict__ a3, long long a3_stride, const lp16_t* __restrict__ a2, const lp16_t* __restrict__ a1,
+    float alpha, lp16_t* __restrict__ gz3, lp16_t* __restrict__ gz2, lp16_t* __restrict__ gz1,
     float* __restrict__ part3, float* __restrict__ part2, float* __restrict__ part1) {
     constexpr int CK = 128, PC = CK + 8, P1 = C3 + 8, P2 = C2 + 8, TH = 64 * NW;
     constexpr int NPC = C3 * (CK / 8) / TH;                     // weight pieces of a chunk per thread
     constexpr int N1 = C2 * (C3 / 8) / TH, N2 = C1 * (C2 / 8) / TH;
     static_assert(C3 == 64 && C3 * (CK / 8) % TH == 0 && C2 * (C3 / 8) % TH == 0 && C1 * (C2 / 8) % TH == 0, "shapes");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    bf16_t* wc = reinterpret_cast<bf16_t*>(lds_raw);            // [2][C3][PC] chunk buffers of Wt0, rows in tile order
-    bf16_t* w1l = wc + 2 * C3 * PC;                             // [C2][P1], rows in tile order
-    bf16_t* w2l = w1l + C2 * P1;                                // [C1][P2], rows in tile order
+    lp16_t* wc = reinterpret_cast<lp16_t*>(lds_raw);            // [2][C3][PC] chunk buffers of Wt0, rows in tile order
+    lp16_t* w1l = wc + 2 * C3 * PC;                             // [C2][P1], rows in tile order
+    lp16_t* w2l = w1l + C2 * P1;                                // [C1][P2], rows in tile order
     float* red = reinterpret_cast<float*>(w2l + C1 * P2);       // [NW][C3 + C2 + C1] column sums of the waves
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const long long b = ((long long)blockIdx.x * NW + wave) * 16 + i;
-    const bf16_t* grow = G + b * ldg + 8 * q;
+    const lp16_t* grow = G + b * ldg + 8 * q;
     // ---- requests: the two small weights, chunk 0 of Wt0, this lane's dG fragments of chunk 0
     u32x4_t s1[N1], s2[N2], wp[NPC];
 #pragma unroll
@@ -1267,10 +1298,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         const int c_ = tid + TH * it;                                                                          \
         *reinterpret_cast<u32x4_t*>(&wc[((buf) * C3 + mlp3_tile_row(c_ >> 4)) * PC + 8 * (c_ & 15)]) = wp[it]; \
     }
-    bf16x8_t gq[3][4];                                          // dG fragments of chunks c, c + 1, c + 2 (two in flight)
+    lp16x8_t gq[3][4];                                          // dG fragments of chunks c, c + 1, c + 2 (two in flight)
 #define MB_LOAD_G(ch)                                                                                          \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                           \
-        gq[(ch) % 3][k_] = *reinterpret_cast<const bf16x8_t*>(grow + (ch) * CK + 32 * k_);
+        gq[(ch) % 3][k_] = *reinterpret_cast<const lp16x8_t*>(grow + (ch) * CK + 32 * k_);
     MB_LOAD_W(0)
     MB_LOAD_G(0)
     if (NCH > 1) { MB_LOAD_G(1) }
@@ -1284,14 +1315,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     for (int c = 0; c < NCH; ++c) {
         if (c + 1 < NCH) { MB_LOAD_W(c + 1) }
         if (c + 2 < NCH) { MB_LOAD_G(c + 2) }
-        const bf16_t* wb = wc + (c & 1) * C3 * PC;
+        const lp16_t* wb = wc + (c & 1) * C3 * PC;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const bf16_t* wr = wb + (t * 16 + i) * PC + 8 * q;
+            const lp16_t* wr = wb + (t * 16 + i) * PC + 8 * q;
 #pragma unroll
             for (int k_ = 0; k_ < 4; ++k_)
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32 * k_), gq[c % 3][k_],
-                                                                 acc[t], 0, 0, 0);
+                acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 32 * k_), gq[c % 3][k_], acc[t]);
         }
         if (c + 1 < NCH) { MB_STORE_W((c + 1) & 1) }            // buffer (c+1)&1 was last read before the previous barrier
         __syncthreads();
@@ -1316,12 +1346,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #define MB_FINISH(a_lo, a_hi, aptr, gzptr, redoff, pk)                                                         \
     {                                                                                                          \
         float av_[8], d_[8];                                                                                   \
-        unpack_bf16x8(*reinterpret_cast<const uint4*>(aptr), av_);                                             \
+        unpack_lp16x8(*reinterpret_cast<const uint4*>(aptr), av_);                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
             d_[e] = (a_lo)[e] * (av_[e] > 0.0f ? 1.0f : av_[e] + alpha);                                       \
             d_[4 + e] = (a_hi)[e] * (av_[4 + e] > 0.0f ? 1.0f : av_[4 + e] + alpha);                           \
         }                                                                                                      \
-        pk = pack_bf16x8(d_);                                                                                  \
+        pk = pack_lp16x8(d_);                                                                                  \
         *reinterpret_cast<uint4*>(gzptr) = pk;                                                                 \
         float r_[8];                                                                                           \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) r_[e] = dpp_row_sum16(d_[e]);                            \
@@ -1330,17 +1360,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
             st4(myred + (redoff) + 4, make_float4(r_[4], r_[5], r_[6], r_[7]));                                \
         }                                                                                                      \
     }
-    bf16x8_t gf2[C3 / 32];
+    lp16x8_t gf2[C3 / 32];
 #pragma unroll
     for (int kk = 0; kk < C3 / 32; ++kk) {
         uint4 pk;
         MB_FINISH(acc[2 * kk], acc[2 * kk + 1], a3 + b * a3_stride + 32 * kk + 8 * q, gz3 + b * C3 + 32 * kk + 8 * q,
                   32 * kk + 8 * q, pk)
-        gf2[kk] = __builtin_bit_cast(bf16x8_t, pk);
+        gf2[kk] = __builtin_bit_cast(lp16x8_t, pk);
     }
     __syncthreads();                                             // w1l / w2l complete
     // ---- stage 2: C2 units, K = C3
-    bf16x8_t gf1[C2 / 32];
+    lp16x8_t gf1[C2 / 32];
 #pragma unroll
     for (int kp = 0; kp < C2 / 32; ++kp) {
         f32x4_t a[2] = {f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}, f32x4_t{0.0f, 0.0f, 0.0f, 0.0f}};
@@ -1348,12 +1378,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         for (int kk = 0; kk < C3 / 32; ++kk)
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut) {
-                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w1l[(32 * kp + 16 * ut + i) * P1 + 32 * kk + 8 * q]);
-                a[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf2[kk], a[ut], 0, 0, 0);
+                const lp16x8_t wf = *reinterpret_cast<const lp16x8_t*>(&w1l[(32 * kp + 16 * ut + i) * P1 + 32 * kk + 8 * q]);
+                a[ut] = MFMA_LP16(wf, gf2[kk], a[ut]);
             }
         uint4 pk;
         MB_FINISH(a[0], a[1], a2 + b * C2 + 32 * kp + 8 * q, gz2 + b * C2 + 32 * kp + 8 * q, C3 + 32 * kp + 8 * q, pk)
-        gf1[kp] = __builtin_bit_cast(bf16x8_t, pk);
+        gf1[kp] = __builtin_bit_cast(lp16x8_t, pk);
     }
     // ---- stage 3: C1 units, K = C2
 #pragma unroll
@@ -1363,8 +1393,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         for (int kk = 0; kk < C2 / 32; ++kk)
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut) {
-                const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&w2l[(32 * kp + 16 * ut + i) * P2 + 32 * kk + 8 * q]);
-                a[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, gf1[kk], a[ut], 0, 0, 0);
+                const lp16x8_t wf = *reinterpret_cast<const lp16x8_t*>(&w2l[(32 * kp + 16 * ut + i) * P2 + 32 * kk + 8 * q]);
+                a[ut] = MFMA_LP16(wf, gf1[kk], a[ut]);
             }
         uint4 pk;
         MB_FINISH(a[0], a[1], a1 + b * C1 + 32 * kp + 8 * q, gz1 + b * C1 + 32 * kp + 8 * q, C3 + C2 + 32 * kp + 8 * q, pk)
@@ -1475,16 +1505,16 @@ __global__ void lstm_bwd_kernel(long long B, int H, const float* __restrict__ g_
 // bias_partial: [B / 64, 4H] rows, chained over the time steps like lstm_bwd_kernel's.
 template <int NCH>
 __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
-    long long B, int H, const float* __restrict__ g_out, long long g_stride, const bf16_t* __restrict__ G, long long ldg,
-    const bf16_t* __restrict__ Wt, long long ldw, const float* __restrict__ dc_next,
-    const unsigned char* __restrict__ done_next, long long done_next_stride, const bf16_t* __restrict__ gates_act,
+    long long B, int H, const float* __restrict__ g_out, long long g_stride, const lp16_t* __restrict__ G, long long ldg,
+    const lp16_t* __restrict__ Wt, long long ldw, const float* __restrict__ dc_next,
+    const unsigned char* __restrict__ done_next, long long done_next_stride, const lp16_t* __restrict__ gates_act,
     const float* __restrict__ c_new, const float* __restrict__ c_prev, const unsigned char* __restrict__ done,
-    long long done_stride, bf16_t* __restrict__ dgates, long long dg_stride, float* __restrict__ dc_prev,
+    long long done_stride, lp16_t* __restrict__ dgates, long long dg_stride, float* __restrict__ dc_prev,
     float* __restrict__ bias_partial, const float* __restrict__ bias_partial_prev) {
     constexpr int CK = 128;
     constexpr int PITCH = CK + 8;
     constexpr int GP = 68;                                     // floats per row of the g_rec hand-over tile
-    __shared__ __attribute__((aligned(16))) bf16_t wl[2][64 * PITCH];
+    __shared__ __attribute__((aligned(16))) lp16_t wl[2][64 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u0 = blockIdx.y * 64;
     float* gt = reinterpret_cast<float*>(&wl[0][0]);           // 64 x 68 floats == one weight buffer
@@ -1507,22 +1537,22 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
     }
     if (NCH > 0) {
         const long long b = (long long)blockIdx.x * 64 + wave * 16 + (lane & 15);
-        const bf16_t* grow = G + b * ldg + 8 * (lane >> 4);
+        const lp16_t* grow = G + b * ldg + 8 * (lane >> 4);
         const int prow[4] = {(int)threadIdx.x >> 4, ((int)threadIdx.x + 256) >> 4, ((int)threadIdx.x + 512) >> 4,
                              ((int)threadIdx.x + 768) >> 4};
         const int pcol = threadIdx.x & 15;
         // three register sets {weight pieces, G fragments}: chunk c + 2 is requested while chunk c is multiplied
         uint4 wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3, wc0, wc1, wc2, wc3;
-        bf16x8_t ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3, gc0, gc1, gc2, gc3;
+        lp16x8_t ga0, ga1, ga2, ga3, gb0, gb1, gb2, gb3, gc0, gc1, gc2, gc3;
 #define LOAD_WG(S, c)                                                                                            \
     w##S##0 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[0]) * ldw + (c) * CK + pcol * 8);       \
     w##S##1 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[1]) * ldw + (c) * CK + pcol * 8);       \
     w##S##2 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[2]) * ldw + (c) * CK + pcol * 8);       \
     w##S##3 = *reinterpret_cast<const uint4*>(Wt + (long long)(u0 + prow[3]) * ldw + (c) * CK + pcol * 8);       \
-    g##S##0 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK);                                               \
-    g##S##1 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 32);                                          \
-    g##S##2 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 64);                                          \
-    g##S##3 = *reinterpret_cast<const bf16x8_t*>(grow + (c) * CK + 96)
+    g##S##0 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK);                                               \
+    g##S##1 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK + 32);                                          \
+    g##S##2 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK + 64);                                          \
+    g##S##3 = *reinterpret_cast<const lp16x8_t*>(grow + (c) * CK + 96)
 #define STORE_W(S, c)                                                                                            \
     *reinterpret_cast<uint4*>(&wl[(c) & 1][prow[0] * PITCH + pcol * 8]) = w##S##0;                               \
     *reinterpret_cast<uint4*>(&wl[(c) & 1][prow[1] * PITCH + pcol * 8]) = w##S##1;                               \
@@ -1534,13 +1564,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
 #define BWD_STEP(c, SL, SC, SS)                                                                                  \
     if (NCH > (c)) {                                                                                             \
         if ((c) > 0 && (c) + 2 < NCH) { LOAD_WG(SL, (c) + 2); }                                                  \
-        const bf16_t* wb_ = wl[(c) & 1];                                                                         \
+        const lp16_t* wb_ = wl[(c) & 1];                                                                         \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
-            const bf16_t* wr = wb_ + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);                           \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr), g##SC##0, acc[t], 0, 0, 0);      \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 32), g##SC##1, acc[t], 0, 0, 0); \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 64), g##SC##2, acc[t], 0, 0, 0); \
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(wr + 96), g##SC##3, acc[t], 0, 0, 0); \
+            const lp16_t* wr = wb_ + (t * 16 + (lane & 15)) * PITCH + 8 * (lane >> 4);                           \
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr), g##SC##0, acc[t]);      \
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 32), g##SC##1, acc[t]); \
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 64), g##SC##2, acc[t]); \
+            acc[t] = MFMA_LP16(*reinterpret_cast<const lp16x8_t*>(wr + 96), g##SC##3, acc[t]); \
         }                                                                                                        \
         if ((c) + 1 < NCH) { STORE_W(SS, (c) + 1); }                                                             \
         __syncthreads();                                                                                         \
@@ -1584,7 +1614,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
             const float4 rr = p == 0 ? pre_dc : ld4(dc_next + b * H + j);
             dc[0] = keep_n * rr.x; dc[1] = keep_n * rr.y; dc[2] = keep_n * rr.z; dc[3] = keep_n * rr.w;
         }
-        const bf16_t* ga = gates_act + b * 4LL * H;
+        const lp16_t* ga = gates_act + b * 4LL * H;
         const float4 i4 = p == 0 ? pre_i : ld4(ga + j), f4 = p == 0 ? pre_f : ld4(ga + H + j);
         const float4 g4 = p == 0 ? pre_g : ld4(ga + 2 * H + j), o4 = p == 0 ? pre_o : ld4(ga + 3 * H + j);
         const float4 cn4 = p == 0 ? pre_cn : ld4(c_new + b * H + j), cp4 = p == 0 ? pre_cp : ld4(c_prev + b * H + j);
@@ -1603,7 +1633,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
             dout[u] = d_o * go[u] * (1.0f - go[u]);
             dcp[u] = d_c * gf[u];
         }
-        bf16_t* dgp = dgates + b * dg_stride;
+        lp16_t* dgp = dgates + b * dg_stride;
         st4(dgp + 0 * H + j, make_float4(di[0], di[1], di[2], di[3]));
         st4(dgp + 1 * H + j, make_float4(df[0], df[1], df[2], df[3]));
         st4(dgp + 2 * H + j, make_float4(dg[0], dg[1], dg[2], dg[3]));
@@ -1639,36 +1669,37 @@ __global__ __launch_bounds__(256) void lstm_bwd_mfma_kernel(
 // over all 64 banks.  Workgroup = 4 waves along M: (64 MT) x (16 NT) outputs; stages of 32 rows, double-buffered in
 // LDS behind a register prefetch, one barrier per stage.  The slices are summed by the column-sum kernel
 // (deterministic, no atomics).
-typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
+typedef __attribute__((__vector_size__(4 * sizeof(lp16_hw)))) lp16_hw lp16x4_t;
 #define VINE_LDS __attribute__((address_space(3)))
-__device__ __forceinline__ bf16x8_t tr_read8(const bf16_t* p, int second_block_elems) {
+__device__ __forceinline__ lp16x8_t tr_read8(const lp16_t* p, int second_block_elems) {
     // two transposed reads: rows (.., +3) at p and the block `second_block_elems` further on
-    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VINE_LDS bf16x4_t*)(p));
-    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((VINE_LDS bf16x4_t*)(p + second_block_elems));
+    typedef __attribute__((__vector_size__(4 * sizeof(lp16_tr_hw)))) lp16_tr_hw tr4_t;
+    const lp16x4_t lo = __builtin_bit_cast(lp16x4_t, DS_READ_TR16_B64((VINE_LDS tr4_t*)(p)));
+    const lp16x4_t hi = __builtin_bit_cast(lp16x4_t, DS_READ_TR16_B64((VINE_LDS tr4_t*)(p + second_block_elems)));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 template <int MT, int NT>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_t* __restrict__ dy, long long ldy,
-                                                         const bf16_t* __restrict__ x, long long ldx,
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const lp16_t* __restrict__ dy, long long ldy,
+                                                         const lp16_t* __restrict__ x, long long ldx,
                                                          float* __restrict__ part, int M, int Nv) {
     constexpr int MTW = 64 * MT, NTW = 16 * NT;
     constexpr int PA = MTW + 16, PB = NTW + 16;                 // bf16 elements per LDS row
     constexpr int AC = MTW / 8, BC = NTW / 8;                   // 16-B pieces per row
     constexpr int AP = 32 * AC, BP = 32 * BC;
     constexpr int NA = (AP + 255) / 256, NB = (BP + 255) / 256;
-    __shared__ __attribute__((aligned(16))) bf16_t al[2][32 * PA];
-    __shared__ __attribute__((aligned(16))) bf16_t bl[2][32 * PB];
+    __shared__ __attribute__((aligned(16))) lp16_t al[2][32 * PA];
+    __shared__ __attribute__((aligned(16))) lp16_t bl[2][32 * PB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = blockIdx.x * MTW, n0 = blockIdx.y * NTW;
     const long long k0 = (long long)blockIdx.z * stages * 32;
     // up to two 16-B pieces of each tile per thread and stage (named scalars: indexed arrays end up in scratch)
     const int pa0 = (int)threadIdx.x, pa1 = (int)threadIdx.x + 256;
     const bool va0 = pa0 < AP, va1 = NA > 1 && pa1 < AP, vb0 = pa0 < BP, vb1 = NB > 1 && pa1 < BP;
-    const bf16_t* asrc0 = dy + (k0 + pa0 / AC) * ldy + m0 + 8 * (pa0 % AC);
-    const bf16_t* asrc1 = dy + (k0 + pa1 / AC) * ldy + m0 + 8 * (pa1 % AC);
-    const bf16_t* bsrc0 = x + (k0 + pa0 / BC) * ldx + n0 + 8 * (pa0 % BC);
-    const bf16_t* bsrc1 = x + (k0 + pa1 / BC) * ldx + n0 + 8 * (pa1 % BC);
+    const lp16_t* asrc0 = dy + (k0 + pa0 / AC) * ldy + m0 + 8 * (pa0 % AC);
+    const lp16_t* asrc1 = dy + (k0 + pa1 / AC) * ldy + m0 + 8 * (pa1 % AC);
+    const lp16_t* bsrc0 = x + (k0 + pa0 / BC) * ldx + n0 + 8 * (pa0 % BC);
+    const lp16_t* bsrc1 = x + (k0 + pa1 / BC) * ldx + n0 + 8 * (pa1 % BC);
     const int aoff0 = (pa0 / AC) * PA + 8 * (pa0 % AC), aoff1 = (pa1 / AC) * PA + 8 * (pa1 % AC);
     const int boff0 = (pa0 / BC) * PB + 8 * (pa0 % BC), boff1 = (pa1 / BC) * PB + 8 * (pa1 % BC);
     uint4 wa0 = make_uint4(0, 0, 0, 0), wa1 = wa0, wb0 = wa0, wb1 = wa0;
@@ -1697,17 +1728,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_
     for (int it = 0; it < stages; ++it) {
         const bool more = it + 1 < stages;
         if (more) { WG_LOAD(it + 1); }
-        const bf16_t* ab = al[it & 1];
-        const bf16_t* bb = bl[it & 1];
-        bf16x8_t af[MT];
+        const lp16_t* ab = al[it & 1];
+        const lp16_t* bb = bl[it & 1];
+        lp16x8_t af[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = tr_read8(ab + ra + 16 * mt, 16 * PA);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8_t bf = tr_read8(bb + rb + 16 * nt, 16 * PB);
+            const lp16x8_t bf = tr_read8(bb + rb + 16 * nt, 16 * PB);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = MFMA_LP16(af[mt], bf, acc[mt][nt]);
         }
         if (more) { WG_STORE((it + 1) & 1); }
         __syncthreads();
@@ -1744,7 +1775,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(int stages, const bf16_
 // One problem of a grouped launch (several independent products in ONE kernel: every node of the replayed update graph
 // costs ~4.5 us of dispatch + drain, and the three MLP weight gradients are ready at the same time).
 struct WgProblem {
-    const bf16_t *dy, *x1, *x2;
+    const lp16_t *dy, *x1, *x2;
     float *part1, *part2;
     long long ldy, ldx1, ldx2;
     int stages, mtiles, ntiles, slices, N1p, Nv1, Nv2, M, NT, first_block;
@@ -1760,9 +1791,9 @@ template <int NT>
 __device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int block, unsigned char* lds_raw) {
     const int stages = P.stages, mtiles = P.mtiles, ntiles = P.ntiles, slices = P.slices, N1p = P.N1p, Nv1 = P.Nv1,
               Nv2 = P.Nv2, M = P.M;
-    const bf16_t* __restrict__ dy = P.dy;
-    const bf16_t* __restrict__ x1 = P.x1;
-    const bf16_t* __restrict__ x2 = P.x2;
+    const lp16_t* __restrict__ dy = P.dy;
+    const lp16_t* __restrict__ x1 = P.x1;
+    const lp16_t* __restrict__ x2 = P.x2;
     float* __restrict__ part1 = P.part1;
     float* __restrict__ part2 = P.part2;
     const long long ldy = P.ldy, ldx1 = P.ldx1, ldx2 = P.ldx2;
@@ -1773,8 +1804,8 @@ __device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int blo
     constexpr int NB = (BP + 255) / 256;
     static_assert(NB <= 3 && BP % 64 == 0, "at most 3 staging slots for the x tile; its end on a wave boundary");
     static_assert(2 * 32 * (PA + PB) * 2 <= WGC_LDS_BYTES, "LDS of the grouped kernel");
-    bf16_t (*al)[32 * PA] = reinterpret_cast<bf16_t (*)[32 * PA]>(lds_raw);
-    bf16_t (*bl)[32 * PB] = reinterpret_cast<bf16_t (*)[32 * PB]>(lds_raw + 2 * 32 * PA * sizeof(bf16_t));
+    lp16_t (*al)[32 * PA] = reinterpret_cast<lp16_t (*)[32 * PA]>(lds_raw);
+    lp16_t (*bl)[32 * PB] = reinterpret_cast<lp16_t (*)[32 * PB]>(lds_raw + 2 * 32 * PA * sizeof(lp16_t));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // blocks b, b + 8, ... share an XCD: give one XCD all tiles of its slices
     const int xcd = block & 7, q = block >> 3, tps = mtiles * ntiles;
@@ -1784,12 +1815,12 @@ __device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int blo
     // staging: piece p = tid + 256 i; the dy piece is one per thread; x pieces pick their operand by virtual column
     // (a pointer select, not a branch); named scalars (an indexed array lands in scratch memory); a slot past the last
     // piece re-reads piece 0 and is never stored
-    const bf16_t* asrc = dy + (k0 + tid / 8) * ldy + m0 + 8 * (tid % 8);
+    const lp16_t* asrc = dy + (k0 + tid / 8) * ldy + m0 + 8 * (tid % 8);
     const int aoff = (tid / 8) * PA + 8 * (tid % 8);
     uint4 ra_0, rb_0, rb_1, rb_2;
     rb_1 = rb_2 = make_uint4(0, 0, 0, 0);
 #define WGC_SRC(i)                                                                                             \
-    const bf16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
+    const lp16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
     {                                                                                                          \
         const int p = tid + 256 * (i);                                                                         \
         bval##i = p < BP;                                                                                      \
@@ -1824,13 +1855,13 @@ __device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int blo
     for (int it = 0; it < stages; ++it) {
         const bool more = it + 1 < stages;
         if (more) { WGC_LOAD(it + 1) }
-        const bf16_t* ab = al[it & 1];
-        const bf16_t* bb = bl[it & 1];
-        const bf16x8_t af = tr_read8(ab + ra, 16 * PA);
+        const lp16_t* ab = al[it & 1];
+        const lp16_t* bb = bl[it & 1];
+        const lp16x8_t af = tr_read8(ab + ra, 16 * PA);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[nt], 0, 0, 0);
+            const lp16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);
+            acc[nt] = MFMA_LP16(af, bfr, acc[nt]);
         }
         if (more) { WGC_STORE((it + 1) & 1) }
         __syncthreads();
@@ -1874,9 +1905,9 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroupArgs G) {
 // own loads (32 stages x 1.4 us); two stages are kept in flight in two named register sets (the loop is unrolled by two
 // so that the set is a compile-time choice; an indexed array lands in scratch memory).
 template <int NT1, int MT>      // MT = 16-row MFMA tiles per wave along M: workgroup tile = (64 MT) x 352
-__global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mtiles, int slices, const bf16_t* __restrict__ dy,
-                                                             long long ldy, const bf16_t* __restrict__ x1, long long ldx1,
-                                                             const bf16_t* __restrict__ x2, long long ldx2,
+__global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mtiles, int slices, const lp16_t* __restrict__ dy,
+                                                             long long ldy, const lp16_t* __restrict__ x1, long long ldx1,
+                                                             const lp16_t* __restrict__ x2, long long ldx2,
                                                              float* __restrict__ part1, int Nv1, float* __restrict__ part2,
                                                              int Nv2, int M) {
     constexpr int NT = 11, WM = 4, WN = 2, TH = 64 * WM * WN;
@@ -1888,8 +1919,8 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
                       (B1P + B2P) % 64 == 0,
                   "staging slots: <= 1 piece of dy and 3 of [x1 | x2] per thread, operand boundaries on wave boundaries");
     extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
-    bf16_t (*al)[32 * PA] = reinterpret_cast<bf16_t (*)[32 * PA]>(wg_lds);
-    bf16_t (*bl)[32 * PB] = reinterpret_cast<bf16_t (*)[32 * PB]>(wg_lds + 2 * 32 * PA * sizeof(bf16_t));
+    lp16_t (*al)[32 * PA] = reinterpret_cast<lp16_t (*)[32 * PA]>(wg_lds);
+    lp16_t (*bl)[32 * PB] = reinterpret_cast<lp16_t (*)[32 * PB]>(wg_lds + 2 * 32 * PA * sizeof(lp16_t));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // blocks b, b + 8, ... share an XCD: give one XCD all m tiles of its slices
@@ -1900,10 +1931,10 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
     // per-thread source of piece p = tid + TH i (the slot past the last piece re-reads piece 0 and is never stored)
     const bool aval = tid < AP;                                  // (wave-uniform; the other waves re-read piece 0)
     const int ap = aval ? tid : 0;
-    const bf16_t* asrc = dy + (k0 + ap / APC) * ldy + m0 + 8 * (ap % APC);
+    const lp16_t* asrc = dy + (k0 + ap / APC) * ldy + m0 + 8 * (ap % APC);
     const int aoff = (ap / APC) * PA + 8 * (ap % APC);
 #define WGW_SRC(i)                                                                                             \
-    const bf16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
+    const lp16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
     {                                                                                                          \
         const int p = tid + TH * (i);                                                                          \
         bval##i = p < B1P + B2P;                                                                               \
@@ -1943,14 +1974,14 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
     const int rb = (4 * g + (il >> 2)) * PB + 4 * (il & 3) + wn * NT * 16;
 #define WGW_COMPUTE(buf)                                                                                       \
     {                                                                                                          \
-        const bf16_t* ab = al[buf];                                                                            \
-        const bf16_t* bb = bl[buf];                                                                            \
-        bf16x8_t af[MT];                                                                                       \
+        const lp16_t* ab = al[buf];                                                                            \
+        const lp16_t* bb = bl[buf];                                                                            \
+        lp16x8_t af[MT];                                                                                       \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = tr_read8(ab + ra + 16 * mt, 16 * PA);       \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                    \
-            const bf16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);                                         \
+            const lp16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);                                         \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr, acc[mt][nt], 0, 0, 0);      \
+                acc[mt][nt] = MFMA_LP16(af[mt], bfr, acc[mt][nt]);      \
         }                                                                                                      \
     }
     // invariant at the top of an even stage `it`: LDS buffer 0 holds stage it, the odd set holds stage it + 1 (in flight)
@@ -2118,7 +2149,7 @@ __global__ void normalize_obs_kernel(long long n, int F, const float* __restrict
         const float m = (float)mean[c], sd = sqrtf((float)var[c] + eps);
         float y = (x[idx] - m) / sd;
         y = fminf(fmaxf(y, -clip), clip);
-        if (sizeof(OT) == 2) reinterpret_cast<bf16_t*>(out)[r * out_stride + c] = f2bf(y);
+        if (sizeof(OT) == 2) reinterpret_cast<lp16_t*>(out)[r * out_stride + c] = f2lp(y);
         else reinterpret_cast<float*>(out)[r * out_stride + c] = y;
     }
 }
@@ -2461,7 +2492,10 @@ struct ColsumJob {
 struct ColsumBatch {
     ColsumJob job[VINE_COLSUM_MAX_JOBS];
     int njobs;
+    float* found_inf;      // optional: set to 1 when a finished column sum is not finite (loss-scaled fp16 backward: an
+                           // overflowed 16-bit gradient ends as inf / NaN in the weight gradients these jobs finish)
 };
+__device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) <= 3.0e38f); }
 __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) {
     int j = 0;
 #pragma unroll 1
@@ -2489,6 +2523,7 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
             const float4 a = rq[cl], b = rq[64 + cl], cc = rq[128 + cl], d = rq[192 + cl];
             const float4 v = make_float4((a.x + cc.x) + (b.x + d.x), (a.y + cc.y) + (b.y + d.y), (a.z + cc.z) + (b.z + d.z),
                                          (a.w + cc.w) + (b.w + d.w));      // the order of the tree below
+            if (batch.found_inf && (not_finite(v.x) || not_finite(v.y) || not_finite(v.z) || not_finite(v.w))) *batch.found_inf = 1.0f;
             if (J.dup) { st4(J.out0 + c, v); st4(J.out1 + c, v); }
             else if (J.out1 && c >= J.n0) st4(J.out1 + (c - J.n0), v);
             else st4(J.out0 + c, v);
@@ -2522,6 +2557,7 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
     }
     if (rl == 0 && c < J.C) {
         const float v = red[cl];
+        if (batch.found_inf && not_finite(v)) *batch.found_inf = 1.0f;
         if (J.dup) { J.out0[c] = v; J.out1[c] = v; }
         else if (J.out1 && c >= J.n0) J.out1[c - J.n0] = v;
         else J.out0[c] = v;
@@ -2569,9 +2605,9 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
         const int H = SEQ_H;
         const int cols1 = (int)(J.aux & 0xffff), K1 = (int)(J.aux >> 16);
         const int nj = J.op == 6 ? 8 : 2, ksteps = J.op == 6 ? (K1 + H) / 32 : (4 * H) / 32;
-        const bf16_t* s1 = reinterpret_cast<const bf16_t*>(J.src);
-        const bf16_t* s2 = reinterpret_cast<const bf16_t*>(J.src2);
-        bf16_t* d = reinterpret_cast<bf16_t*>(J.dst);
+        const lp16_t* s1 = reinterpret_cast<const lp16_t*>(J.src);
+        const lp16_t* s2 = reinterpret_cast<const lp16_t*>(J.src2);
+        lp16_t* d = reinterpret_cast<lp16_t*>(J.dst);
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const long long idx = base + q4;
@@ -2585,10 +2621,10 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
             const int ut = J.op == 6 ? (jj & 1) : jj, g = J.op == 6 ? (jj >> 1) : 0;
             const int unit = 32 * wv + 8 * ((lane & 15) >> 2) + 4 * ut + (lane & 3);
             const int k = 32 * kk + 8 * (lane >> 4) + i;
-            bf16_t v;
+            lp16_t v;
             if (J.op == 6) {
                 const long long row = (long long)g * H + unit;
-                v = k < K1 ? (k < cols1 ? s1[row * J.src_stride + k] : (bf16_t)0) : s2[row * J.dst_stride + (k - K1)];
+                v = k < K1 ? (k < cols1 ? s1[row * J.src_stride + k] : (lp16_t)0) : s2[row * J.dst_stride + (k - K1)];
             } else {
                 v = s1[(long long)k * J.src_stride + unit];
             }
@@ -2606,17 +2642,17 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
         switch (J.op) {
             case 0:
                 if (J.elem == 2)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(J.dst) + d) =
-                        *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(J.src) + sidx);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(J.dst) + d) =
+                        *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src) + sidx);
                 else
                     st4(reinterpret_cast<float*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
                 break;
             case 1:
-                if (J.elem == 2) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(J.dst) + d) = make_uint2(0u, 0u);
+                if (J.elem == 2) *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(J.dst) + d) = make_uint2(0u, 0u);
                 else st4(reinterpret_cast<float*>(J.dst) + d, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
                 break;
             case 3:
-                st4(reinterpret_cast<bf16_t*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
+                st4(reinterpret_cast<lp16_t*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
                 break;
             case 4: {
                 const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
@@ -2628,7 +2664,7 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
                 const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
                 const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
                 const float4 v = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
-                if (J.elem == 2) st4(reinterpret_cast<bf16_t*>(J.dst) + d, v);
+                if (J.elem == 2) st4(reinterpret_cast<lp16_t*>(J.dst) + d, v);
                 else st4(reinterpret_cast<float*>(J.dst) + d, v);
             }
         }
@@ -2642,15 +2678,15 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
         switch (J.op) {
             case 0:
             case 2:
-                if (J.elem == 2) reinterpret_cast<bf16_t*>(J.dst)[d] = reinterpret_cast<const bf16_t*>(J.src)[sidx];
+                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = reinterpret_cast<const lp16_t*>(J.src)[sidx];
                 else reinterpret_cast<float*>(J.dst)[d] = reinterpret_cast<const float*>(J.src)[sidx];
                 break;
             case 1:
-                if (J.elem == 2) reinterpret_cast<bf16_t*>(J.dst)[d] = 0;
+                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = 0;
                 else reinterpret_cast<float*>(J.dst)[d] = 0.0f;
                 break;
             case 3:
-                reinterpret_cast<bf16_t*>(J.dst)[d] = f2bf(reinterpret_cast<const float*>(J.src)[sidx]);
+                reinterpret_cast<lp16_t*>(J.dst)[d] = f2lp(reinterpret_cast<const float*>(J.src)[sidx]);
                 break;
             case 4:
                 reinterpret_cast<float*>(J.dst)[d] =
@@ -2659,7 +2695,7 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
             default: {
                 const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
                 const float v = reinterpret_cast<const float*>(J.src)[sidx] * keep;
-                if (J.elem == 2) reinterpret_cast<bf16_t*>(J.dst)[d] = f2bf(v);
+                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = f2lp(v);
                 else reinterpret_cast<float*>(J.dst)[d] = v;
             }
         }
@@ -2676,7 +2712,8 @@ __device__ __forceinline__ void ppo_loss_finalize(int blocks, int A, long long n
                                                   float bounds_coef, float* __restrict__ stats,
                                                   float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
                                                   float* __restrict__ grad_value_bias, float* __restrict__ kl_out,
-                                                  float* __restrict__ logstd_grad_accum) {
+                                                  float* __restrict__ logstd_grad_accum, float S) {
+    // S: loss scale; the partial sums are unscaled, every GRADIENT written here is multiplied by it
     // (called by whole workgroups of 256 or 512 threads: the first 256 do the work, all take part in the barriers)
     const int q = threadIdx.x & (PPO_LOSS_ROW - 1), rl = threadIdx.x / PPO_LOSS_ROW;     // 32 columns x 8 row-lanes
     __shared__ float fred[8][PPO_LOSS_ROW];
@@ -2720,21 +2757,22 @@ __device__ __forceinline__ void ppo_loss_finalize(int blocks, int A, long long n
         stats[5] = a + 0.5f * critic_coef * c + bounds_coef * b - entropy_coef * ent;
         stats[6] = 0.0f; stats[7] = 0.0f;
         for (int k = 0; k < A; ++k) {
-            const float gl = tot[5 + k] - entropy_coef;
+            const float gl = (tot[5 + k] - entropy_coef) * S;
             grad_logstd[k] = gl;
             if (logstd_grad_accum) logstd_grad_accum[k] += gl;
         }
         if (kl_out) kl_out[0] = kl;
         if (grad_mu_bias) {
-            for (int k = 0; k < A; ++k) grad_mu_bias[k] += tot[5 + PPO_MAX_A + k];
-            grad_value_bias[0] += tot[5 + 2 * PPO_MAX_A];
+            for (int k = 0; k < A; ++k) grad_mu_bias[k] += tot[5 + PPO_MAX_A + k] * S;
+            grad_value_bias[0] += tot[5 + 2 * PPO_MAX_A] * S;
         }
     }
 }
 
-// ticket of the loss kernel's workgroups (the last one to finish runs the finalize step and resets it: a launch always
-// finds 0).  One loss kernel in flight per device at a time -- launches on one stream are ordered.
-__device__ unsigned int g_ppo_loss_ticket = 0;
+// Ticket of the loss / Adam kernels' workgroups (the last one to finish runs the finalize step and resets it: a launch
+// always finds 0).  The word is NOT a module global: the host wrappers hand every (device, stream) pair its own zeroed
+// slot (ticket_slot below), so launches in flight on different streams -- two agents in one process, a warm-up on a side
+// stream -- cannot corrupt each other's election; launches on one stream are ordered.
 
 __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const float* __restrict__ mu,
                                                        const float* __restrict__ logstd, const float* __restrict__ value,
@@ -2752,9 +2790,13 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
                                                        long long value_stride, float* partial,
                                                        float* mu_store, float* sigma_store,
                                                        float* __restrict__ grad_mu_bias, float* __restrict__ grad_value_bias,
-                                                       float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum) {
+                                                       float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum,
+                                                       const float* __restrict__ loss_scale, unsigned int* ticket) {
     // mu / grad_mu rows are mu_stride floats apart, value / grad_value elements value_stride apart (A and 1 when the
     // heads are separate tensors; A+1 when one GEMM produced [mu | value] rows)
+    // loss scale (GradScaler restated on the device: every gradient this kernel hands on is multiplied by it; the loss
+    // statistics are not)
+    const float S = loss_scale ? *loss_scale : 1.0f;
     const float inv_n = 1.0f / (float)n;
     float ls[PPO_MAX_A], sg[PPO_MAX_A], isg2[PPO_MAX_A];
     float sum_ls = 0.0f;
@@ -2800,7 +2842,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
             dL_dv = 2.0f * (v - R);
         }
         const float gval = 0.5f * critic_coef * dL_dv * inv_n;
-        grad_value[i * value_stride] = gval;
+        grad_value[i * value_stride] = gval * S;
         gmb[PPO_MAX_A] += gval;
         float b_loss = 0.0f, kl = 0.0f;
         for (int k = 0; k < A; ++k) {
@@ -2808,7 +2850,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
             b_loss += hi * hi + lo * lo;
             // d nlp / d mu = -(a - mu)/sigma^2 ; d nlp / d logstd = 1 - z^2
             const float gm = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
-            grad_mu[i * mu_stride + k] = gm;
+            grad_mu[i * mu_stride + k] = gm * S;
             gmb[k] += gm;
             gls[k] += dL_dnlp * (1.0f - z2[k]);
             const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
@@ -2851,15 +2893,15 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
     __shared__ bool is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(&g_ppo_loss_ticket, 1u);
+        const unsigned t = atomicAdd(ticket, 1u);
         is_last = t == gridDim.x - 1;
-        if (is_last) g_ppo_loss_ticket = 0;
+        if (is_last) *ticket = 0;
     }
     __syncthreads();
     if (is_last) {
         __threadfence();
         ppo_loss_finalize((int)gridDim.x, A, n, partial, logstd, critic_coef, entropy_coef, bounds_coef, stats, grad_logstd,
-                          grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
+                          grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, S);
     }
 }
 
@@ -2891,7 +2933,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // cl + 16 j, j = 0..3, of row `sub`), so that a LayerNorm / head reduction is four DPP rotate-adds inside a 16-lane row
 // instead of a wave-wide sum (9 DPP steps + a readlane, one row at a time: that version took 39 us).  NP passes of 4
 // rows per wave; the rows are re-read in phase 3 (L2 hits) rather than kept in 64 registers.
-template <int NH, int NP, typename DXT>      // DXT: type of the gradient handed to the LSTM backward (float or bf16_t)
+template <int NH, int NP, typename DXT>      // DXT: type of the gradient handed to the LSTM backward (float or lp16_t)
 __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     long long n, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const float* __restrict__ w, const float* __restrict__ wb, const float* __restrict__ logstd,
@@ -2901,8 +2943,11 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     float* __restrict__ heads, DXT* __restrict__ dx, float* __restrict__ ln_partial, float* loss_partial,
     float* __restrict__ stats, float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
     float* __restrict__ grad_value_bias, float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum, float* mu_store,
-    float* sigma_store) {
+    float* sigma_store, const float* __restrict__ loss_scale, float* __restrict__ found_inf, unsigned int* ticket) {
     constexpr int H = 256, A = NH - 1, NWV = 8, W = (2 + NH) * H, RW = 4 * NP;
+    // loss scale: applied where the per-row head gradients are formed, so dx and every parameter partial sum of this
+    // kernel carry it; the bias / log-sigma gradients of the finalize step are multiplied there; statistics unscaled
+    const float S = loss_scale ? *loss_scale : 1.0f;
     constexpr int NRED = 5 + 2 * PPO_MAX_A + 1;
     __shared__ float red[NWV][W];
     __shared__ float lred[NWV][PPO_LOSS_ROW];
@@ -3011,7 +3056,7 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
             dL_dv = 2.0f * (v - R);
         }
         const float gval = 0.5f * critic_coef * dL_dv * inv_n;
-        gh[A] = gval;
+        gh[A] = gval * S;
         vals[5 + 2 * PPO_MAX_A] = gval;
         float b_loss = 0.0f, kl = 0.0f;
 #pragma unroll
@@ -3020,7 +3065,7 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
             const float hi = fmaxf(m - soft_bound, 0.0f), lo = fminf(m + soft_bound, 0.0f);
             b_loss += hi * hi + lo * lo;
             const float gmk = dL_dnlp * (-dm[k] * isg2[k]) + bounds_coef * inv_n * 2.0f * (hi + lo);
-            gh[k] = gmk;
+            gh[k] = gmk * S;
             vals[5 + PPO_MAX_A + k] = gmk;
             vals[5 + k] = dL_dnlp * (1.0f - z2[k]);
             const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
@@ -3085,11 +3130,18 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
             }
         }
         const float m1 = row_allsum16(s1) * (1.0f / H), m2 = row_allsum16(s2) * (1.0f / H);
+        bool bad = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            st4(dx + r * H + 4 * (cl + 16 * j),
-                make_float4(rstd * (gg[j][0] - m1 - xh[j][0] * m2), rstd * (gg[j][1] - m1 - xh[j][1] * m2),
-                            rstd * (gg[j][2] - m1 - xh[j][2] * m2), rstd * (gg[j][3] - m1 - xh[j][3] * m2)));
+        for (int j = 0; j < 4; ++j) {
+            const float4 o = make_float4(rstd * (gg[j][0] - m1 - xh[j][0] * m2), rstd * (gg[j][1] - m1 - xh[j][1] * m2),
+                                         rstd * (gg[j][2] - m1 - xh[j][2] * m2), rstd * (gg[j][3] - m1 - xh[j][3] * m2));
+            st4(dx + r * H + 4 * (cl + 16 * j), o);
+            bad = bad || !(fabsf(o.x) <= LP16_MAX) || !(fabsf(o.y) <= LP16_MAX) || !(fabsf(o.z) <= LP16_MAX) || !(fabsf(o.w) <= LP16_MAX);
+        }
+        // a gradient that does not fit the 16-bit format (or is NaN) marks the optimiser step as overflowed: the Adam
+        // kernel then skips it and backs the loss scale off, as torch's GradScaler does.  (Plain store of a constant by
+        // whoever sees it: no atomic needed.  The column-sum kernel checks the final gradients as well.)
+        if (sizeof(DXT) == 2 && found_inf && bad) *found_inf = 1.0f;
     }
     // the four 16-lane rows of the wave hold sums for the same columns: add them (lane l <- l ^ 16, l ^ 32), then one
     // row of W sums per wave in LDS, added over the waves in wave order
@@ -3132,31 +3184,46 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     __shared__ bool is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(&g_ppo_loss_ticket, 1u);
+        const unsigned t = atomicAdd(ticket, 1u);
         is_last = t == gridDim.x - 1;
-        if (is_last) g_ppo_loss_ticket = 0;
+        if (is_last) *ticket = 0;
     }
     __syncthreads();
     if (is_last) {
         __threadfence();
         ppo_loss_finalize((int)gridDim.x, A, n, loss_partial, logstd, critic_coef, entropy_coef, bounds_coef, stats,
-                          grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
+                          grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, S);
     }
 }
 
-// ticket of the Adam kernel's workgroups: the last one to finish bumps the step counter and applies the learning-rate
-// schedule (every workgroup has read the old step / lr by then); it resets the ticket, so a launch always finds 0
-__device__ unsigned int g_adam_ticket = 0;
-
+// The Adam kernel's last workgroup to finish bumps the step counter and applies the learning-rate schedule (every
+// workgroup has read the old step / lr by then); it resets the ticket, so a launch always finds 0.
+// amp = {loss scale, growth tracker, growth interval, -} and found_inf (both optional) restate torch.amp.GradScaler on the
+// device (the reference's `mixed_precision: True` drives its fp16 update through one): gradients arrive multiplied by the
+// loss scale and are unscaled here; when *found_inf is set the whole step is skipped (parameters, moments, step counter
+// and the 16-bit parameter copies keep their values; the gradient block is still cleared) and the scale is halved;
+// after `growth interval` consecutive good steps it is doubled.  The learning-rate schedule runs either way
+// (rl_games updates it after scaler.step whatever that did).
 __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, float* lr_p, float* step_p,
-                            float beta1, float beta2, float eps, float wd, float gscale, bf16_t* __restrict__ shadow,
-                            const float* kl, float kl_scale, float kl_thr, float min_lr, float max_lr) {
+                            float beta1, float beta2, float eps, float wd, float gscale, lp16_t* __restrict__ shadow,
+                            const float* kl, float kl_scale, float kl_thr, float min_lr, float max_lr,
+                            float* amp, float* found_inf, unsigned int* ticket) {
+    const float loss_scale = amp ? amp[0] : 1.0f;
+    const bool skip = found_inf && *found_inf != 0.0f;
+    if (amp) gscale = gscale / loss_scale;
+    if (skip) {      // (uniform over the grid) clear the gradient block, touch nothing else
+        const long long n4s = n >> 2;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4s; i += (long long)gridDim.x * blockDim.x)
+            st4(g + 4 * i, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        const long long ts = (n4s << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (ts < n) g[ts] = 0.0f;
+    }
     const float step = *step_p + 1.0f;                    // every thread reads the old values; the last workgroup
     const float lr = *lr_p;                               // to finish writes the new ones
     const float bc1 = 1.0f - __powf(beta1, step), bc2 = 1.0f - __powf(beta2, step);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-    const long long n4 = n >> 2;
+    const long long n4 = skip ? 0 : n >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pp = ld4(p + 4 * i), gg = ld4(g + 4 * i), mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
         float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w};
@@ -3175,22 +3242,31 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restric
         if (shadow) st4(shadow + 4 * i, make_float4(pa[0], pa[1], pa[2], pa[3]));   // bf16 copy for the GEMM operands
     }
     // tail (n not a multiple of 4)
-    const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) {
+    const long long t = ((n >> 2) << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n && !skip) {
         float gr = g[t] * gscale + wd * p[t];
         float mt = beta1 * m[t] + (1.0f - beta1) * gr, vt = beta2 * v[t] + (1.0f - beta2) * gr * gr;
         p[t] -= step_size * mt / (sqrtf(vt) * inv_sqrt_bc2 + eps);
         m[t] = mt; v[t] = vt; g[t] = 0.0f;
-        if (shadow) shadow[t] = f2bf(p[t]);
+        if (shadow) shadow[t] = f2lp(p[t]);
     }
     // step counter (+ rl_games' AdaptiveScheduler when `kl` is given) by the last workgroup to finish -- formerly two
     // 1-thread launches behind this one
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned tk = atomicAdd(&g_adam_ticket, 1u);
+        const unsigned tk = atomicAdd(ticket, 1u);
         if (tk == gridDim.x - 1) {
-            g_adam_ticket = 0;
-            *step_p = step;
+            *ticket = 0;
+            if (!skip) *step_p = step;
+            if (amp) {                                    // GradScaler.update()
+                if (skip) { amp[0] = loss_scale * 0.5f; amp[1] = 0.0f; }
+                else {
+                    const float tr = amp[1] + 1.0f;
+                    if (tr >= amp[2]) { amp[0] = loss_scale * 2.0f; amp[1] = 0.0f; }
+                    else amp[1] = tr;
+                }
+            }
+            if (found_inf) *found_inf = 0.0f;
             if (kl) {
                 const float k = *kl * kl_scale;
                 float out = lr;
@@ -3428,7 +3504,7 @@ __global__ __launch_bounds__(256) void rollout_post_kernel(
                 st4(h_state + e * H + j, z);
                 st4(c_state + e * H + j, z);
                 if (h_op) {   // the GEMM-operand copy of h (column block of the [x | h] buffer of the fused inference)
-                    if (h_op_bf16) st4((bf16_t*)h_op + e * h_op_stride + j, z);
+                    if (h_op_bf16) st4((lp16_t*)h_op + e * h_op_stride + j, z);
                     else st4((float*)h_op + e * h_op_stride + j, z);
                 }
             }
@@ -3490,6 +3566,39 @@ int grid_for(long long work, int threads) {
 
 }  // namespace
 
+// One zeroed ticket word per (device, stream, kernel family) for the "last workgroup to finish" elections of the loss
+// and Adam kernels, so that launches in flight on different streams never share a ticket.  The words come from a
+// per-device pool that is allocated and zeroed ONCE (first use on that device, or vine_ppo_runtime_init): handing a new
+// stream its slot later needs no allocation and no memset, so it is legal inside a stream capture (torch captures on a
+// side stream the library has not seen before).  Returns nullptr when the pool is exhausted or cannot be allocated
+// (the wrappers then report VINE_ERR_DEVICE).
+#include <mutex>
+namespace {
+enum { TICKET_LOSS = 0, TICKET_ADAM = 1, TICKET_KINDS = 2, TICKET_MAX_STREAMS = 64, TICKET_MAX_DEVICES = 16 };
+struct TicketPool { unsigned int* words; void* stream[TICKET_MAX_STREAMS]; int used; };
+TicketPool g_ticket_pool[TICKET_MAX_DEVICES];
+std::mutex g_ticket_mutex;
+unsigned int* ticket_slot(void* stream, int kind) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TICKET_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ticket_mutex);
+    TicketPool& P = g_ticket_pool[dev];
+    if (!P.words) {
+        unsigned int* w = nullptr;
+        const size_t bytes = (size_t)TICKET_MAX_STREAMS * TICKET_KINDS * sizeof(unsigned int);
+        if (hipMalloc(&w, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(w, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); return nullptr; }
+        P.words = w;
+        P.used = 0;
+    }
+    for (int i = 0; i < P.used; ++i)
+        if (P.stream[i] == stream) return P.words + i * TICKET_KINDS + kind;
+    if (P.used == TICKET_MAX_STREAMS) return nullptr;
+    P.stream[P.used] = stream;
+    return P.words + (P.used++) * TICKET_KINDS + kind;
+}
+}  // namespace
+
 extern "C" {
 
 int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig_stride, const float* hgates,
@@ -3504,9 +3613,9 @@ int vine_lstm_cell_forward(int64_t B, int64_t H, const float* igates, int64_t ig
     const int threads = 256;
     const dim3 grid(grid_for(B * (H / 4), threads));
     if (hp_bf16)
-        hipLaunchKernelGGL(lstm_fwd_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
+        hipLaunchKernelGGL(lstm_fwd_kernel<lp16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)B, (int)H,
                            igates, (long long)ig_stride, hgates, bias, c_prev, done, (long long)done_stride, h_out,
-                           (long long)h_stride, c_out, (bf16_t*)gates_act, (bf16_t*)hp_next, done_next,
+                           (long long)h_stride, c_out, (lp16_t*)gates_act, (lp16_t*)hp_next, done_next,
                            (long long)done_next_stride,
                            (long long)hp_stride);
     else
@@ -3531,7 +3640,7 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
     if ((B & 63) || (H & 15) || (K & 31) || (K1 & 31) || K > LSTM_MFMA_MAX_K) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B / 64), (unsigned)(H / 16)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);            // 33 KB at K = 256, 45 KB at K = 352
+    const size_t lds = (size_t)64 * (K + 8) * sizeof(lp16_t);            // 33 KB at K = 256, 45 KB at K = 352
     static bool lds_raised[LSTM_MFMA_MAX_K / 32 + 1] = {};               // K = 512 needs more than the 64 KB default
 #define VINE_LSTM_MFMA(KS, KS1)                                                                                         \
     do {                                                                                                                \
@@ -3542,9 +3651,9 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
             lds_raised[KS] = true;                                                                                      \
         }                                                                                                               \
         hipLaunchKernelGGL((lstm_step_mfma_kernel<KS, KS1>), grid, block, lds, s, (long long)B, (int)H,                 \
-                           (const bf16_t*)A, (long long)lda, (const bf16_t*)A2, (long long)lda2, (const bf16_t*)W,      \
+                           (const lp16_t*)A, (long long)lda, (const lp16_t*)A2, (long long)lda2, (const lp16_t*)W,      \
                            (long long)ldw, igates, (long long)ig_stride, bias, c_prev, done, (long long)done_stride,    \
-                           h_out, (long long)h_stride, c_out, (bf16_t*)gates_act, (bf16_t*)hp_next, done_next,          \
+                           h_out, (long long)h_stride, c_out, (lp16_t*)gates_act, (lp16_t*)hp_next, done_next,          \
                            (long long)done_next_stride, (long long)hp_stride);                                          \
     } while (0)
     const int ks = (int)(K / 32), ks1 = (int)(K1 / 32);
@@ -3555,9 +3664,9 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
         const dim3 grid64((unsigned)(B / 64), (unsigned)(H / 64));
 #define VINE_LSTM_MFMA64(KS, KS1)                                                                                       \
         hipLaunchKernelGGL((lstm_step_mfma64_kernel<KS, KS1>), grid64, block, 0, s, (long long)B, (int)H,               \
-                           (const bf16_t*)A, (long long)lda, (const bf16_t*)A2, (long long)lda2, (const bf16_t*)W,      \
+                           (const lp16_t*)A, (long long)lda, (const lp16_t*)A2, (long long)lda2, (const lp16_t*)W,      \
                            (long long)ldw, igates, (long long)ig_stride, bias, c_prev, done, (long long)done_stride,    \
-                           h_out, (long long)h_stride, c_out, (bf16_t*)gates_act, (bf16_t*)hp_next, done_next,          \
+                           h_out, (long long)h_stride, c_out, (lp16_t*)gates_act, (lp16_t*)hp_next, done_next,          \
                            (long long)done_next_stride, (long long)hp_stride)
         if (ks1 == 0) VINE_LSTM_MFMA64(11, 0);
         else VINE_LSTM_MFMA64(11, 3);
@@ -3596,7 +3705,7 @@ int vine_lstm_tile_weights(int64_t H, int64_t K, const void* src, int64_t ld, in
     const int ksteps = (int)(K / 32), nj = transposed ? 2 : 8;
     const long long chunks = (long long)(H / 32) * ksteps * nj * 64;
     hipLaunchKernelGGL(lstm_tile_weights_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)src, (long long)ld, (int)H, ksteps, nj, (int)transposed, (bf16_t*)dst);
+                       (const lp16_t*)src, (long long)ld, (int)H, ksteps, nj, (int)transposed, (lp16_t*)dst);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -3620,12 +3729,12 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
     hipStream_t s = (hipStream_t)stream;
     const int ablate = seq_ablate();
 #define VINE_SEQ_FWD_T(KS1, RING, CT)                                                                                   \
-    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT>), grid, block, 0, s, (int)T, (long long)B, (const bf16_t*)x, \
-                       (long long)ldx, (bf16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
-                       (CT*)c_all, (bf16_t*)gates, ablate, c_last, h0)
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT>), grid, block, 0, s, (int)T, (long long)B, (const lp16_t*)x, \
+                       (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
+                       (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0)
 #define VINE_SEQ_FWD(KS1, RING)                                                                                         \
     {                                                                                                                   \
-        if (c_bf16) VINE_SEQ_FWD_T(KS1, RING, bf16_t);                                                                  \
+        if (c_bf16) VINE_SEQ_FWD_T(KS1, RING, lp16_t);                                                                  \
         else VINE_SEQ_FWD_T(KS1, RING, float);                                                                          \
     }
     switch (KX / 32) {
@@ -3650,7 +3759,7 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_o
 #define SEQ_BWD_RING 8      // 16 does not fit the register file without spills: 76.7 us against 65.3 us per 4-step sequence
 #endif
     constexpr int RING = SEQ_BWD_RING;
-    const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(bf16_t);          // 129 KiB: one workgroup per CU
+    const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(lp16_t);          // 129 KiB: one workgroup per CU
     const int ablate = seq_ablate();
 #define VINE_SEQ_BWD(CT, GT)                                                                                              \
     {                                                                                                                     \
@@ -3663,12 +3772,12 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_o
         }                                                                                                                 \
         hipLaunchKernelGGL((lstm_seq_bwd_kernel<RING, CT, GT>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds,           \
                            (hipStream_t)stream, (int)T, (long long)B, (const GT*)g_out, (const uint4*)w_hh_tiled,         \
-                           (const bf16_t*)gates, (const CT*)c_all, c0, done, (bf16_t*)dgates, bias_partial, ablate,       \
+                           (const lp16_t*)gates, (const CT*)c_all, c0, done, (lp16_t*)dgates, bias_partial, ablate,       \
                            c_last);                                                                                       \
     }
-    if (c_bf16 && g_bf16) VINE_SEQ_BWD(bf16_t, bf16_t)
-    else if (c_bf16) VINE_SEQ_BWD(bf16_t, float)
-    else if (g_bf16) VINE_SEQ_BWD(float, bf16_t)
+    if (c_bf16 && g_bf16) VINE_SEQ_BWD(lp16_t, lp16_t)
+    else if (c_bf16) VINE_SEQ_BWD(lp16_t, float)
+    else if (g_bf16) VINE_SEQ_BWD(float, lp16_t)
     else VINE_SEQ_BWD(float, float)
 #undef VINE_SEQ_BWD
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
@@ -3680,11 +3789,11 @@ int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t
         return VINE_ERR_INVALID_ARG;
     if ((n & 63) || (N & 63) || (K & 31) || K > 256) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(n / 64), (unsigned)(N / 64)), block(256);
-    const size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);
+    const size_t lds = (size_t)64 * (K + 8) * sizeof(lp16_t);
     hipStream_t s = (hipStream_t)stream;
 #define VINE_LIN_MFMA(KS)                                                                                             \
-    hipLaunchKernelGGL(linear_elu_mfma_kernel<KS>, grid, block, lds, s, (long long)n, (int)N, (const bf16_t*)A,       \
-                       (long long)lda, (const bf16_t*)W, (long long)ldw, bias, alpha, (bf16_t*)out, (long long)out_stride)
+    hipLaunchKernelGGL(linear_elu_mfma_kernel<KS>, grid, block, lds, s, (long long)n, (int)N, (const lp16_t*)A,       \
+                       (long long)lda, (const lp16_t*)W, (long long)ldw, bias, alpha, (lp16_t*)out, (long long)out_stride)
     switch (K / 32) {
         case 1: VINE_LIN_MFMA(1); break;
         case 2: VINE_LIN_MFMA(2); break;
@@ -3706,7 +3815,7 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
         return VINE_ERR_INVALID_ARG;
     if (C1 != 256 || C2 != 128 || C3 != 64 || (n & 63)) return VINE_ERR_UNSUPPORTED;
     const int threads = (n % 128 == 0 && n >= 32768) ? 512 : 256;        // 8 waves per CU when one round covers the chip
-    const size_t lds = ((size_t)256 * 40 + 128 * 264 + 64 * 136) * sizeof(bf16_t);
+    const size_t lds = ((size_t)256 * 40 + 128 * 264 + 64 * 136) * sizeof(lp16_t);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 4>),
@@ -3718,9 +3827,9 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
     }
 #define VINE_MLP3(NW_)                                                                                                   \
     hipLaunchKernelGGL((mlp3_elu_mfma_kernel<256, 128, 64, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), lds,  \
-                       (hipStream_t)stream, (long long)n, (bf16_t*)x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip, \
-                       (const bf16_t*)w1p, b1, (const bf16_t*)w2, (long long)ldw2, b2, (const bf16_t*)w3, (long long)ldw3, \
-                       b3, alpha, (bf16_t*)act1, (bf16_t*)act2, (bf16_t*)out, (long long)out_stride)
+                       (hipStream_t)stream, (long long)n, (lp16_t*)x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip, \
+                       (const lp16_t*)w1p, b1, (const lp16_t*)w2, (long long)ldw2, b2, (const lp16_t*)w3, (long long)ldw3, \
+                       b3, alpha, (lp16_t*)act1, (lp16_t*)act2, (lp16_t*)out, (long long)out_stride)
     if (threads == 512) VINE_MLP3(8);
     else VINE_MLP3(4);
 #undef VINE_MLP3
@@ -3739,7 +3848,7 @@ int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, 
         return VINE_ERR_INVALID_ARG;
     if (C3 != 64 || C2 != 128 || C1 != 256 || K0 != 1024 || (n & 63)) return VINE_ERR_UNSUPPORTED;
     const int nw = (n % 128 == 0 && n >= 32768) ? 8 : 4;
-    const size_t lds = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(bf16_t) + (size_t)nw * (64 + 128 + 256) * sizeof(float);
+    const size_t lds = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(lp16_t) + (size_t)nw * (64 + 128 + 256) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 4>),
@@ -3751,10 +3860,10 @@ int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, 
     }
 #define VINE_MLP3B(NW_)                                                                                                   \
     hipLaunchKernelGGL((mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), \
-                       lds, (hipStream_t)stream, (long long)n, (const bf16_t*)dG, (long long)lddg, (const bf16_t*)wt0,     \
-                       (long long)ldw0, (const bf16_t*)wt1, (long long)ldw1, (const bf16_t*)wt2, (long long)ldw2,          \
-                       (const bf16_t*)a3, (long long)a3_stride, (const bf16_t*)a2, (const bf16_t*)a1, alpha, (bf16_t*)gz3, \
-                       (bf16_t*)gz2, (bf16_t*)gz1, part3, part2, part1)
+                       lds, (hipStream_t)stream, (long long)n, (const lp16_t*)dG, (long long)lddg, (const lp16_t*)wt0,     \
+                       (long long)ldw0, (const lp16_t*)wt1, (long long)ldw1, (const lp16_t*)wt2, (long long)ldw2,          \
+                       (const lp16_t*)a3, (long long)a3_stride, (const lp16_t*)a2, (const lp16_t*)a1, alpha, (lp16_t*)gz3, \
+                       (lp16_t*)gz2, (lp16_t*)gz1, part3, part2, part1)
     if (nw == 8) VINE_MLP3B(8);
     else VINE_MLP3B(4);
 #undef VINE_MLP3B
@@ -3772,21 +3881,21 @@ int vine_linear_bwd_elu_mfma(int64_t n, int64_t N, int64_t K, const void* G, int
         hipStream_t s2 = (hipStream_t)stream;
         if (K == 512)
             hipLaunchKernelGGL(linear_bwd_elu_mfma_chunked_kernel<4>, grid, block, 0, s2, (long long)n, (int)N,
-                               (const bf16_t*)G, (long long)ldg, (const bf16_t*)Wt, (long long)ldw, (const bf16_t*)a,
-                               (long long)a_stride, alpha, (bf16_t*)gz, (long long)gz_stride, partial);
+                               (const lp16_t*)G, (long long)ldg, (const lp16_t*)Wt, (long long)ldw, (const lp16_t*)a,
+                               (long long)a_stride, alpha, (lp16_t*)gz, (long long)gz_stride, partial);
         else
             hipLaunchKernelGGL(linear_bwd_elu_mfma_chunked_kernel<8>, grid, block, 0, s2, (long long)n, (int)N,
-                               (const bf16_t*)G, (long long)ldg, (const bf16_t*)Wt, (long long)ldw, (const bf16_t*)a,
-                               (long long)a_stride, alpha, (bf16_t*)gz, (long long)gz_stride, partial);
+                               (const lp16_t*)G, (long long)ldg, (const lp16_t*)Wt, (long long)ldw, (const lp16_t*)a,
+                               (long long)a_stride, alpha, (lp16_t*)gz, (long long)gz_stride, partial);
         return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
     }
-    size_t lds = (size_t)64 * (K + 8) * sizeof(bf16_t);
+    size_t lds = (size_t)64 * (K + 8) * sizeof(lp16_t);
     if (lds < 64 * 65 * sizeof(float)) lds = 64 * 65 * sizeof(float);       // the column-sum stage reuses the slab
     hipStream_t s = (hipStream_t)stream;
 #define VINE_LINB_MFMA(KS)                                                                                             \
-    hipLaunchKernelGGL(linear_bwd_elu_mfma_kernel<KS>, grid, block, lds, s, (long long)n, (int)N, (const bf16_t*)G,    \
-                       (long long)ldg, (const bf16_t*)Wt, (long long)ldw, (const bf16_t*)a, (long long)a_stride, alpha,  \
-                       (bf16_t*)gz, (long long)gz_stride, partial)
+    hipLaunchKernelGGL(linear_bwd_elu_mfma_kernel<KS>, grid, block, lds, s, (long long)n, (int)N, (const lp16_t*)G,    \
+                       (long long)ldg, (const lp16_t*)Wt, (long long)ldw, (const lp16_t*)a, (long long)a_stride, alpha,  \
+                       (lp16_t*)gz, (long long)gz_stride, partial)
     switch (K / 32) {
         case 2: VINE_LINB_MFMA(2); break;
         case 4: VINE_LINB_MFMA(4); break;
@@ -3810,9 +3919,9 @@ int vine_lstm_cell_backward(int64_t B, int64_t H, const float* g_out, int64_t g_
     // with partial sums the grid is fixed: the caller's buffer has VINE_PPO_PARTIAL_BLOCKS rows
     const int blocks = bias_partial ? VINE_PPO_PARTIAL_BLOCKS : grid_for(B * (H / 4), threads);
     if (dgates_bf16)
-        hipLaunchKernelGGL(lstm_bwd_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
+        hipLaunchKernelGGL(lstm_bwd_kernel<lp16_t>, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)B,
                            (int)H, g_out, (long long)g_stride, g_rec, dc_next, done_next, (long long)done_next_stride,
-                           (const bf16_t*)gates_act, c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates,
+                           (const lp16_t*)gates_act, c_new, c_prev, done, (long long)done_stride, (lp16_t*)dgates,
                            (long long)dg_stride,
                            dc_prev, bias_partial, bias_partial_prev);
     else
@@ -3839,9 +3948,9 @@ int vine_lstm_step_backward_mfma(int64_t B, int64_t H, const float* g_out, int64
     hipStream_t s = (hipStream_t)stream;
 #define VINE_LSTM_BWD_MFMA(NCH)                                                                                        \
     hipLaunchKernelGGL(lstm_bwd_mfma_kernel<NCH>, grid, dim3(256), 0, s, (long long)B, (int)H, g_out,                  \
-                       (long long)g_stride, (const bf16_t*)dgates_next, (long long)dgn_stride, (const bf16_t*)w_hh_t,  \
-                       (long long)ldw, dc_next, done_next, (long long)done_next_stride, (const bf16_t*)gates_act,      \
-                       c_new, c_prev, done, (long long)done_stride, (bf16_t*)dgates, (long long)dg_stride, dc_prev,    \
+                       (long long)g_stride, (const lp16_t*)dgates_next, (long long)dgn_stride, (const lp16_t*)w_hh_t,  \
+                       (long long)ldw, dc_next, done_next, (long long)done_next_stride, (const lp16_t*)gates_act,      \
+                       c_new, c_prev, done, (long long)done_stride, (lp16_t*)dgates, (long long)dg_stride, dc_prev,    \
                        bias_partial, bias_partial_prev)
     if (!dgates_next) VINE_LSTM_BWD_MFMA(0);
     else if (H == 256) VINE_LSTM_BWD_MFMA(8);
@@ -3866,8 +3975,8 @@ int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const
     const int stages = (int)(rows / slices / 32);
     hipStream_t s = (hipStream_t)stream;
 #define VINE_WGRAD(MT_, NT_)                                                                                          \
-    hipLaunchKernelGGL((wgrad_mfma_kernel<MT_, NT_>), grid, dim3(256), 0, s, stages, (const bf16_t*)dy, (long long)ldy, \
-                       (const bf16_t*)x, (long long)ldx, part, (int)M, (int)Nv)
+    hipLaunchKernelGGL((wgrad_mfma_kernel<MT_, NT_>), grid, dim3(256), 0, s, stages, (const lp16_t*)dy, (long long)ldy, \
+                       (const lp16_t*)x, (long long)ldx, part, (int)M, (int)Nv)
     if (mt == 2) { if (nt == 2) VINE_WGRAD(2, 2); else if (nt == 6) VINE_WGRAD(2, 6); else VINE_WGRAD(2, 8); }
     else { if (nt == 2) VINE_WGRAD(1, 2); else if (nt == 6) VINE_WGRAD(1, 6); else VINE_WGRAD(1, 8); }
 #undef VINE_WGRAD
@@ -3895,9 +4004,9 @@ int vine_weight_grad_group(int32_t nprob, const int64_t* rows, const int64_t* M,
             (slices[k] & 7) || rows[k] % (slices[k] * 32) || slices[k] > 8192)
             return VINE_ERR_UNSUPPORTED;
         WgProblem& P = G.p[k];
-        P.dy = (const bf16_t*)dy[k]; P.ldy = ldy[k];
-        P.x2 = (const bf16_t*)x2[k]; P.ldx2 = ldx2[k]; P.part2 = part2[k]; P.Nv2 = (int)Nv2[k];
-        P.x1 = two ? (const bf16_t*)x1[k] : P.x2; P.ldx1 = two ? ldx1[k] : ldx2[k];
+        P.dy = (const lp16_t*)dy[k]; P.ldy = ldy[k];
+        P.x2 = (const lp16_t*)x2[k]; P.ldx2 = ldx2[k]; P.part2 = part2[k]; P.Nv2 = (int)Nv2[k];
+        P.x1 = two ? (const lp16_t*)x1[k] : P.x2; P.ldx1 = two ? ldx1[k] : ldx2[k];
         P.part1 = two ? part1[k] : part2[k]; P.Nv1 = two ? (int)Nv1[k] : (int)Nv2[k];
         P.N1p = (int)N1p[k]; P.M = (int)M[k]; P.NT = (int)NT[k]; P.slices = (int)slices[k];
         P.mtiles = (int)(M[k] / 64); P.ntiles = (int)((N1p[k] + N2p[k]) / (16 * NT[k]));
@@ -3921,7 +4030,7 @@ int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t l
         const int bm = NT == 22 ? 128 : 64;
         if (N1p != 96 || N2p != 256 || (M % bm) || (slices & 7) || rows % (slices * 64) || slices > 8192) return VINE_ERR_UNSUPPORTED;
         const int mtiles = (int)(M / bm), stages = (int)(rows / slices / 32);
-        const size_t lds = (size_t)2 * 32 * ((bm + 16) + (352 + 16)) * sizeof(bf16_t);      // 64 / 56 KiB
+        const size_t lds = (size_t)2 * 32 * ((bm + 16) + (352 + 16)) * sizeof(lp16_t);      // 64 / 56 KiB
 #define VINE_WGW(MT_)                                                                                                     \
         {                                                                                                                 \
             static bool attr_set = false;                                                                                 \
@@ -3932,8 +4041,8 @@ int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t l
                 attr_set = true;                                                                                          \
             }                                                                                                             \
             hipLaunchKernelGGL((wgrad_cat_wide_kernel<6, MT_>), dim3((unsigned)(mtiles * slices)), dim3(512), lds,        \
-                               (hipStream_t)stream, stages, mtiles, (int)slices, (const bf16_t*)dy, (long long)ldy,       \
-                               (const bf16_t*)x1, (long long)ldx1, (const bf16_t*)x2, (long long)ldx2, part1, (int)Nv1,   \
+                               (hipStream_t)stream, stages, mtiles, (int)slices, (const lp16_t*)dy, (long long)ldy,       \
+                               (const lp16_t*)x1, (long long)ldx1, (const lp16_t*)x2, (long long)ldx2, part1, (int)Nv1,   \
                                part2, (int)Nv2, (int)M);                                                                  \
         }
         if (NT == 22) VINE_WGW(2)
@@ -4013,9 +4122,9 @@ int vine_elu_backward(int64_t n, int64_t C, const float* g, int64_t g_stride, co
 #define VINE_ELU_BWD(AT, OT)                                                                                         \
     hipLaunchKernelGGL((elu_bwd_kernel<AT, OT>), grid, block, 0, s, (long long)n, (int)C, g, (long long)g_stride,    \
                        (const AT*)a, (long long)a_stride, alpha, (OT*)out, (long long)out_stride, partial)
-    if (a_bf16 && out_bf16) VINE_ELU_BWD(bf16_t, bf16_t);
-    else if (a_bf16) VINE_ELU_BWD(bf16_t, float);
-    else if (out_bf16) VINE_ELU_BWD(float, bf16_t);
+    if (a_bf16 && out_bf16) VINE_ELU_BWD(lp16_t, lp16_t);
+    else if (a_bf16) VINE_ELU_BWD(lp16_t, float);
+    else if (out_bf16) VINE_ELU_BWD(float, lp16_t);
     else VINE_ELU_BWD(float, float);
 #undef VINE_ELU_BWD
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
@@ -4064,8 +4173,8 @@ int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean,
     const int threads = 256;
     const dim3 grid(grid_for(n * F, threads));
     if (out_bf16)
-        hipLaunchKernelGGL(normalize_obs_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)F,
-                           x, mean, var, eps, clip, (bf16_t*)out, (long long)out_stride);
+        hipLaunchKernelGGL(normalize_obs_kernel<lp16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)F,
+                           x, mean, var, eps, clip, (lp16_t*)out, (long long)out_stride);
     else
         hipLaunchKernelGGL(normalize_obs_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)F,
                            x, mean, var, eps, clip, (float*)out, (long long)out_stride);
@@ -4074,7 +4183,7 @@ int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean,
 
 int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
                              const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
-                             const int32_t* dup, void* stream) {
+                             const int32_t* dup, float* found_inf, void* stream) {
     if (njobs <= 0 || njobs > VINE_COLSUM_MAX_JOBS || !R || !C || !src || !row_stride || !out0 || !n0 || !out1 || !dup)
         return VINE_ERR_INVALID_ARG;
     ColsumBatch b;
@@ -4092,6 +4201,7 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
         blocks += (int)((C[k] + ct - 1) / ct);
     }
     b.njobs = njobs;
+    b.found_inf = found_inf;
     hipLaunchKernelGGL(colsum_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
@@ -4128,8 +4238,8 @@ int vine_bias_elu(int64_t n, int64_t C, const float* z, const float* bias, float
     const int threads = 256;
     const dim3 grid(grid_for(n * (C / 4), threads));
     if (out_bf16)
-        hipLaunchKernelGGL(bias_elu_kernel<bf16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)C, z,
-                           bias, alpha, (bf16_t*)out, (long long)out_stride);
+        hipLaunchKernelGGL(bias_elu_kernel<lp16_t>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)C, z,
+                           bias, alpha, (lp16_t*)out, (long long)out_stride);
     else
         hipLaunchKernelGGL(bias_elu_kernel<float>, grid, dim3(threads), 0, (hipStream_t)stream, (long long)n, (int)C, z,
                            bias, alpha, (float*)out, (long long)out_stride);
@@ -4142,13 +4252,15 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                   float entropy_coef, float bounds_coef, float soft_bound, float* grad_mu, float* grad_value,
                   float* grad_logstd, float* stats, int64_t mu_stride, int64_t value_stride, float* grad_mu_bias,
                   float* grad_value_bias, float* scratch, float* kl_out, float* logstd_grad_accum, float* mu_store,
-                  float* sigma_store, void* stream) {
+                  float* sigma_store, const float* loss_scale, void* stream) {
     if (n <= 0 || A <= 0 || A > PPO_MAX_A || !mu || !logstd || !value || !actions || !old_neglogp || !advantages ||
         !old_values || !returns || !old_mu || !old_sigma || !grad_mu || !grad_value || !grad_logstd || !stats ||
         ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || !scratch ||
         ((mu_store == nullptr) != (sigma_store == nullptr)))
         return VINE_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
+    unsigned int* ticket = ticket_slot(stream, TICKET_LOSS);
+    if (!ticket) return VINE_ERR_DEVICE;
     const int threads = 256;
     int blocks = (int)((n + threads - 1) / threads);
     if (blocks > VINE_PPO_LOSS_BLOCKS) blocks = VINE_PPO_LOSS_BLOCKS;
@@ -4158,7 +4270,7 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
                        actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip, (int)clip_value,
                        critic_coef, entropy_coef, bounds_coef, soft_bound, grad_mu, grad_value, grad_logstd, stats,
                        (long long)(mu_stride > 0 ? mu_stride : A), (long long)(value_stride > 0 ? value_stride : 1),
-                       scratch, mu_store, sigma_store, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum);
+                       scratch, mu_store, sigma_store, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, loss_scale, ticket);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
@@ -4168,7 +4280,8 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
                        const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
                        float bounds_coef, float soft_bound, float* heads, void* dx, int32_t dx_bf16, float* ln_partial,
                        float* stats, float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch,
-                       float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, void* stream) {
+                       float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, const float* loss_scale,
+                       float* found_inf, void* stream) {
     if (n <= 0 || !x || !gamma || !beta || !w || !wb || !logstd || !actions || !old_neglogp || !advantages || !old_values ||
         !returns || !old_mu || !old_sigma || !heads || !dx || !ln_partial || !stats || !grad_logstd || !scratch ||
         ((grad_mu_bias == nullptr) != (grad_value_bias == nullptr)) || ((mu_store == nullptr) != (sigma_store == nullptr)))
@@ -4185,15 +4298,17 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
     if (H != 256 || NH < 2 || NH > 5 || n % rows_wg || n / rows_wg > VINE_PPO_LOSS_BLOCKS) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(n / rows_wg)), block(512);
     hipStream_t s = (hipStream_t)stream;
+    unsigned int* ticket = ticket_slot(stream, TICKET_LOSS);
+    if (!ticket) return VINE_ERR_DEVICE;
 #define VINE_LHL_T(K, R, DXT)                                                                                             \
     hipLaunchKernelGGL((ln_heads_loss_kernel<K, R, DXT>), grid, block, 0, s, (long long)n, x, gamma, beta, eps, w, wb,     \
                        logstd, actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip,           \
                        (int)clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound, heads, (DXT*)dx, ln_partial,   \
                        scratch, stats, grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store,    \
-                       sigma_store)
+                       sigma_store, loss_scale, found_inf, ticket)
 #define VINE_LHL(K, R)                                                                                                    \
     {                                                                                                                     \
-        if (dx_bf16) VINE_LHL_T(K, R, bf16_t);                                                                            \
+        if (dx_bf16) VINE_LHL_T(K, R, lp16_t);                                                                            \
         else VINE_LHL_T(K, R, float);                                                                                     \
     }
 #define VINE_LHL_R(K)                                                                                                     \
@@ -4268,16 +4383,30 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_adam_step_sched(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
-                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow,
-                         const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, void* stream) {
+int vine_adam_step_amp(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
+                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* lp16_shadow,
+                       const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, float* amp_state,
+                       float* found_inf, void* stream) {
     if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr || !step) return VINE_ERR_INVALID_ARG;
+    unsigned int* ticket = ticket_slot(stream, TICKET_ADAM);
+    if (!ticket) return VINE_ERR_DEVICE;
     const int threads = 256;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, threads)), dim3(threads), 0, (hipStream_t)stream, (long long)n,
                        params, grads, exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
-                       (bf16_t*)bf16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr);
+                       (lp16_t*)lp16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr, amp_state, found_inf, ticket);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
+
+int vine_adam_step_sched(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* bf16_shadow,
+                         const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, void* stream) {
+    return vine_adam_step_amp(n, params, grads, exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
+                              bf16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr, nullptr, nullptr, stream);
+}
+
+const char* vine_lp16_format(void) { return VINE_LP16_NAME; }
+
+int vine_ppo_runtime_init(void) { return ticket_slot(nullptr, TICKET_LOSS) ? VINE_OK : VINE_ERR_DEVICE; }
 
 int vine_adam_step(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, const float* lr,
                    float* step, float beta1, float beta2, float eps, float weight_decay, float grad_scale,

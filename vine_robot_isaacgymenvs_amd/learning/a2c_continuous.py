@@ -210,16 +210,22 @@ class A2CAgent:
         self.value_bootstrap = config.get("value_bootstrap")
         self.reward_scale = config.get("reward_shaper", {}).get("scale_value", 1.0)
         self.reward_shift = config.get("reward_shaper", {}).get("shift_value", 0.0)
-        # mixed_precision (PY:53).  On the MI355X with the fused ops this is the hand-written mixed-precision update
-        # (`fused_mixed`): bfloat16 GEMM operands, fp32 accumulation, state, loss and optimiser -- no autocast, no
-        # GradScaler.  `mixed_precision_dtype: fp16` (or use_fused_ops: False) selects torch autocast instead, which is
-        # the reference's literal mechanism and slower than fp32 here.
+        # mixed_precision (PY:53): rl_games runs the UPDATE under fp16 autocast with a GradScaler; rollout inference stays
+        # fp32.  On the MI355X with the fused ops this is the hand-written mixed-precision update (`fused_mixed`): GEMM
+        # operands and backward-only saved activations in the library's 16-bit format -- float16 in the default build,
+        # i.e. the reference's dtype, with the GradScaler restated on the device (loss scale in the loss kernel, overflow
+        # flags, skip / back-off / growth in the Adam kernel) -- fp32 accumulation, state, loss and optimiser; no
+        # autocast.  `mixed_precision_dtype` other than the library's format (or use_fused_ops: False) selects torch
+        # autocast instead, the reference's literal mechanism, slower than fp32 here.
+        # `rollout_precision` (not an rl_games key): "fp32" = the reference's (hand-written fp32 matrix-core inference
+        # kernels); "lp16" = 16-bit GEMM operands in the rollout too (the round-2 behaviour, an extra).
         want_mixed = bool(config.get("mixed_precision", False)) and self.is_cuda
-        mp_dtype = config.get("mixed_precision_dtype", "bf16")
+        mp_dtype = config.get("mixed_precision_dtype", "fp16")
         self.use_fused = bool(config.get("use_fused_ops", True))
-        self.fused_mixed = want_mixed and self.use_fused and mp_dtype == "bf16"
-        self.mixed_precision = want_mixed and not self.fused_mixed          # the torch-autocast path
         self.amp_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[mp_dtype]
+        self.fused_mixed = want_mixed and self.use_fused and self.amp_dtype == fused.lp_dtype()
+        self.mixed_precision = want_mixed and not self.fused_mixed          # the torch-autocast path
+        self.rollout_lp16 = self.fused_mixed and config.get("rollout_precision", "fp32") != "fp32"
         self.save_freq = config.get("save_frequency", 0)
         self.save_best_after = config.get("save_best_after", 100)
         self.print_stats = config.get("print_stats", True)
@@ -263,8 +269,15 @@ class A2CAgent:
             self.flat_grads = self.optimizer.flat_grads
             self.num_params = self.optimizer.num_params
             if self.fused_mixed:
-                self.optimizer.enable_bf16_shadow()
+                self.optimizer.enable_lp16_shadow(self.amp_dtype)
                 self.model.a2c_network.op_weight_lookup = self.optimizer.shadow_of
+                if self.amp_dtype == torch.float16:      # fp16 operands: GradScaler semantics (PY:53 via rl_games)
+                    fused.set_amp(*self.optimizer.enable_loss_scaling(
+                        float(config.get("loss_scale_init", 65536.0)), int(config.get("loss_scale_growth_interval", 2000))))
+                else:
+                    fused.set_amp(None, None)
+            else:
+                fused.set_amp(None, None)
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_grad_scaler)
 
         self.frame = 0
@@ -381,7 +394,7 @@ class A2CAgent:
                 and net.rnn_units in (256, 512, 1024) and all(u % 4 == 0 for u in net.units)):
             return
         dev, N, H = self.device, self.num_actors, net.rnn_units
-        op = torch.bfloat16 if self.fused_mixed else torch.float32
+        op = self.amp_dtype if self.rollout_lp16 else torch.float32
         U, F_in = net.units[-1], self.obs_shape[0]
         width = U + (F_in if net.rnn_concat_input else 0)
         XW = (width + 15) // 16 * 16
@@ -397,16 +410,20 @@ class A2CAgent:
         f["ln_in_head"] = H == 256           # vine_policy_head applies the LayerNorm itself (one launch less per step)
         # padded layer-1 weight [units, 32] for the matrix-core kernel (mixed precision, concatenated input)
         f["w1p"] = None
-        if (self.fused_mixed and net.rnn_concat_input and XW - U == 32
+        if (self.rollout_lp16 and net.rnn_concat_input and XW - U == 32
                 and fused.linear_elu_mfma_ok(N, net.units[0], 32)):
             f["w1p"] = torch.zeros((net.units[0], 32), device=dev, dtype=op)
         self._fast = f
+
+    def _fast_op_is_fp32(self):
+        """True when rollout inference runs on fp32 operands (the reference's rollout precision)."""
+        return not self.rollout_lp16
 
     def _infer_begin(self):
         """Once per rollout: operand copies of the recurrent weights and of h (the update changed the weights)."""
         f, net = self._fast, self.model.a2c_network
         r = net.rnn.rnn
-        src = self.optimizer.shadow_of if self.fused_mixed else (lambda p: p)
+        src = self.optimizer.shadow_of if self.rollout_lp16 else (lambda p: p)
         f["wcat"][:, :r.weight_ih_l0.shape[1]].copy_(src(r.weight_ih_l0))
         f["wcat"][:, f["XW"]:].copy_(src(r.weight_hh_l0))
         f["mlp"] = [(src(m.weight), m.bias) for m in net.actor_mlp if isinstance(m, torch.nn.Linear)]
@@ -426,7 +443,7 @@ class A2CAgent:
         f, m = self._fast, self.model
         net, rms = m.a2c_network, m.running_mean_std
         N, H, XW = self.num_actors, f["H"], f["XW"]
-        bf = int(f["op"] == torch.bfloat16)
+        bf = int(f["op"] != torch.float32)
         st = torch.cuda.current_stream(self.device).cuda_stream
         xh, xh_next = f["xh2"][f["cur"]], f["xh2"][f["cur"] ^ 1]
         x0 = f["x0_sep"] if f["x0_sep"] is not None else xh[:, f["U"]:f["U"] + f["F"]]
@@ -545,7 +562,7 @@ class A2CAgent:
         if direct and getattr(self, "_obs_last", None) is None:
             self._obs_last = torch.empty_like(obs)
         h_op_stride = self._fast["XW"] + H if fast else 0
-        h_op_bf16 = int(fast and self._fast["op"] == torch.bfloat16)
+        h_op_bf16 = int(fast and self._fast["op"] != torch.float32)
         for n in range(self.horizon_length):
             if n % self.seq_len == 0:
                 for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
@@ -811,6 +828,14 @@ class A2CAgent:
         """Forward, ONE kernel for the whole PPO loss and its gradient w.r.t. the head outputs, hand-written backward
         into the flat gradient block; the minibatch KL is parked next to the gradients so that one all-reduce
         averages both.  -> (stats[8], mu, logstd)"""
+        out = self._fused_grad_half_body(mb, obs_n, stats_out)
+        if self.optimizer.amp_state is not None and fused.AMP["covered"] is not None:
+            # loss-scaled fp16 backward: unless every parameter gradient ends in the overflow-checked column-sum launch
+            # the optimiser looks for non-finite gradients itself before it steps
+            self.optimizer.check_grads = not fused.AMP["covered"]
+        return out
+
+    def _fused_grad_half_body(self, mb, obs_n, stats_out):
         net = self.model.a2c_network
         hb = (net.mu.bias.grad, net.value.bias.grad)
         ext = all(g is not None and g.is_cuda for g in hb)     # head-bias gradients straight from the loss kernel

@@ -26,7 +26,8 @@ class FlatAdam:
         self.numel = off
         self.flat_params = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         # the gradient block carries ALIGN extra floats (`aux`) that ride along in the multi-GPU all-reduce: the
-        # agent puts the minibatch KL there, so gradient and KL averaging cost ONE collective per optimiser step
+        # agent puts the minibatch KL there (aux[0]) and the loss-scaling overflow flag lives there (aux[1]: any rank's
+        # overflow reaches every rank with the gradients), so all of it costs ONE collective per optimiser step
         self.comm_buffer = torch.zeros(self.numel + ALIGN, device=dev, dtype=torch.float32)
         self.flat_grads = self.comm_buffer[:self.numel]
         self.aux = self.comm_buffer[self.numel:]
@@ -42,24 +43,46 @@ class FlatAdam:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.param_groups = [{"params": self.params, "lr": self.lr, "betas": betas, "eps": eps,
                               "weight_decay": weight_decay}]
-        self.shadow = None          # bfloat16 copy of flat_params (GEMM operands of the mixed-precision update)
+        self.shadow = None          # 16-bit copy of flat_params (GEMM operands of the mixed-precision update)
+        self.amp_state = None       # [loss scale, growth tracker, growth interval, -] (enable_loss_scaling)
+        self.found_inf = self.aux[1:2]
+        self.check_grads = False    # look for non-finite gradients here (set when the backward pass does not check itself)
         self._lib = None
         if dev.type == "cuda":
-            from .. import native
-            self._lib = native.load()
+            from . import fused
+            self._lib = fused._lib()        # (also readies the library's per-device bookkeeping outside any capture)
 
-    def enable_bf16_shadow(self):
-        """Keep a bfloat16 copy of the parameter block: written by the Adam kernel itself after every step;
-        ``refresh_shadow`` after anything else touched the parameters (checkpoint load, broadcast)."""
-        self.shadow = self.flat_params.to(torch.bfloat16)
+    def enable_lp16_shadow(self, dtype=None):
+        """Keep a 16-bit copy of the parameter block (the library's operand format: float16, or bfloat16 in a
+        -DVINE_LP_BF16 build): written by the Adam kernel itself after every step; ``refresh_shadow`` after anything
+        else touched the parameters (checkpoint load, broadcast)."""
+        if dtype is None:
+            from . import fused
+            dtype = fused.lp_dtype()
+        self.shadow = self.flat_params.to(dtype)
         return self.shadow
+
+    enable_bf16_shadow = enable_lp16_shadow      # round-2 name
+
+    def enable_loss_scaling(self, init_scale=65536.0, growth_interval=2000):
+        """torch.amp.GradScaler restated on the device (its defaults: scale 2^16, x2 after 2000 good steps, x0.5 and a
+        skipped step on overflow) -- what rl_games wraps the reference's ``mixed_precision: True`` update in.  The
+        loss kernels multiply their gradients by ``amp_state[0]`` and flag overflows in ``found_inf``; ``step``
+        unscales, skips and adapts, all inside the Adam launch (no host synchronisation, graph-capturable)."""
+        self.amp_state = torch.tensor([float(init_scale), 0.0, float(growth_interval), 0.0], device=self.flat_params.device,
+                                      dtype=torch.float32)
+        return self.amp_state[0:1], self.found_inf
+
+    @property
+    def loss_scale(self):
+        return None if self.amp_state is None else float(self.amp_state[0])
 
     def refresh_shadow(self):
         if self.shadow is not None:
             self.shadow.copy_(self.flat_params)
 
     def shadow_of(self, p):
-        """The bfloat16 view matching parameter ``p`` (identity lookup)."""
+        """The 16-bit view matching parameter ``p`` (identity lookup)."""
         for q, off in zip(self.params, self.offsets):
             if q is p:
                 return self.shadow[off:off + p.numel()].view_as(p)
@@ -75,16 +98,21 @@ class FlatAdam:
         b1, b2 = self.betas
         if self._lib is not None:
             kl, kscale, thr, lo, hi = lr_schedule if lr_schedule is not None else (None, 0.0, 0.0, 0.0, 0.0)
-            rc = self._lib.vine_adam_step_sched(self.numel, self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
-                                                self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.lr.data_ptr(),
-                                                self.step_t.data_ptr(), b1, b2, self.eps, self.weight_decay,
-                                                float(grad_scale),
-                                                self.shadow.data_ptr() if self.shadow is not None else None,
-                                                kl.data_ptr() if kl is not None else None, float(kscale), float(thr),
-                                                float(lo), float(hi),
-                                                torch.cuda.current_stream(self.flat_params.device).cuda_stream)
+            amp = self.amp_state is not None
+            if amp and self.check_grads:
+                # backward passes whose kernels do not flag overflows themselves: one reduction over the gradient block
+                self.found_inf.add_((~torch.isfinite(self.flat_grads)).any().to(torch.float32))
+            rc = self._lib.vine_adam_step_amp(self.numel, self.flat_params.data_ptr(), self.flat_grads.data_ptr(),
+                                              self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.lr.data_ptr(),
+                                              self.step_t.data_ptr(), b1, b2, self.eps, self.weight_decay,
+                                              float(grad_scale),
+                                              self.shadow.data_ptr() if self.shadow is not None else None,
+                                              kl.data_ptr() if kl is not None else None, float(kscale), float(thr),
+                                              float(lo), float(hi), self.amp_state.data_ptr() if amp else None,
+                                              self.found_inf.data_ptr() if amp else None,
+                                              torch.cuda.current_stream(self.flat_params.device).cuda_stream)
             if rc != 0:
-                raise RuntimeError("vine_adam_step_sched failed with status %d" % rc)
+                raise RuntimeError("vine_adam_step_amp failed with status %d" % rc)
             return
         assert lr_schedule is None, "the fused learning-rate schedule exists on the GPU path only"
         g = self.flat_grads * grad_scale
@@ -110,9 +138,16 @@ class FlatAdam:
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
         group = {"lr": float(self.lr), "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "params": list(range(len(self.params)))}
-        return {"state": state, "param_groups": [group]}
+        sd = {"state": state, "param_groups": [group]}
+        if self.amp_state is not None:      # torch.amp.GradScaler.state_dict() keys
+            sd["scaler"] = {"scale": float(self.amp_state[0]), "growth_factor": 2.0, "backoff_factor": 0.5,
+                            "growth_interval": int(self.amp_state[2]), "_growth_tracker": int(self.amp_state[1])}
+        return sd
 
     def load_state_dict(self, sd):
+        sc = sd.get("scaler")
+        if sc is not None and self.amp_state is not None:
+            self.amp_state[0], self.amp_state[1], self.amp_state[2] = float(sc["scale"]), float(sc["_growth_tracker"]), float(sc["growth_interval"])
         for i, (p, off) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
             st = sd["state"].get(i)

@@ -25,9 +25,18 @@ import torch
 import torch.nn.functional as F
 
 
+_runtime_ready = set()
+
+
 def _lib():
     from .. import native
-    return native.load()
+    lib = native.load()
+    if torch.cuda.is_available():
+        dev = torch.cuda.current_device()
+        if dev not in _runtime_ready:       # per-device bookkeeping of the library, outside any stream capture
+            _runtime_ready.add(dev)
+            lib.vine_ppo_runtime_init()
+    return lib
 
 
 def _stream(t):
@@ -44,9 +53,39 @@ def _check(rc, what):
         raise RuntimeError("%s failed with status %d" % (what, rc))
 
 
+_LP16 = (torch.float16, torch.bfloat16)
+_lp = None
+
+
+def lp_dtype():
+    """torch dtype of the library's 16-bit operand format (``vine_lp16_format()``): float16 in the default build -- the
+    dtype the reference's ``mixed_precision: True`` autocasts to -- or bfloat16 (``-DVINE_LP_BF16``)."""
+    global _lp
+    if _lp is None:
+        try:
+            _lp = torch.float16 if _lib().vine_lp16_format() == b"fp16" else torch.bfloat16
+        except (RuntimeError, OSError):      # library not built (CPU-only use of the fallback compositions)
+            return torch.float16
+    return _lp
+
+
+# torch.amp.GradScaler restated on the device (fp16 operands need it, bf16 do not): the device scalars the loss kernels
+# multiply their gradients by / flag an overflow in.  Set by the agent (FlatAdam.enable_loss_scaling); None = scale 1.
+AMP = {"scale": None, "found_inf": None, "covered": None}
+
+
+def set_amp(scale, found_inf):
+    AMP["scale"], AMP["found_inf"], AMP["covered"] = scale, found_inf, None
+
+
+def _amp_ptrs():
+    return (AMP["scale"].data_ptr() if AMP["scale"] is not None else None,
+            AMP["found_inf"].data_ptr() if AMP["found_inf"] is not None else None)
+
+
 def _mm(a, b):
-    """a @ b with an fp32 result: plain fp32 GEMM, or bf16 operands accumulated and written in fp32."""
-    if a.dtype == torch.bfloat16:
+    """a @ b with an fp32 result: plain fp32 GEMM, or 16-bit operands accumulated and written in fp32."""
+    if a.dtype in _LP16:
         return torch.mm(a, b, out_dtype=torch.float32)
     return a.mm(b)
 
@@ -62,15 +101,15 @@ def splitk_tn(dy, x, out=None, batch=None):
     while K % (s * 2) == 0 and K // (s * 2) >= SPLITK_ROWS and s < 64:
         s *= 2
     if s == 1 or not dy.is_cuda:
-        if dy.dtype == torch.bfloat16:
+        if dy.dtype in _LP16:
             r = torch.mm(dy.t(), x, out_dtype=torch.float32)
             return out.copy_(r) if out is not None else r
         return torch.mm(dy.t(), x, out=out) if out is not None else dy.t().mm(x)
     # unflatten: also valid for operands whose rows are padded (a column block of a wider buffer)
     a, b = dy.unflatten(0, (s, K // s)).transpose(1, 2), x.unflatten(0, (s, K // s))
-    if dy.dtype not in (torch.float32, torch.bfloat16) or dy.dtype != x.dtype:
-        raise TypeError("splitk_tn: operands must both be fp32 or both bf16 (got %s, %s)" % (dy.dtype, x.dtype))
-    part = torch.bmm(a, b, out_dtype=torch.float32) if dy.dtype == torch.bfloat16 else torch.bmm(a, b)
+    if dy.dtype not in (torch.float32,) + _LP16 or dy.dtype != x.dtype:
+        raise TypeError("splitk_tn: operands must both be fp32 or both 16-bit (got %s, %s)" % (dy.dtype, x.dtype))
+    part = torch.bmm(a, b, out_dtype=torch.float32) if dy.dtype in _LP16 else torch.bmm(a, b)
     return column_sums(part, out if out is not None else torch.empty(part.shape[1:], device=part.device), batch=batch)
 
 
@@ -99,7 +138,7 @@ def _wgrad_plan(dy, x):
     """(Np, slices) when ``vine_weight_grad_mfma`` covers dy^T x for these operands, else None.  Np: x's columns
     rounded up to a tile width of the kernel; the extra columns must lie inside x's own rows (a column block of a
     wider, padded buffer) -- they are read, their products are not stored."""
-    if not (dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 2 and x.dim() == 2):
+    if not (dy.is_cuda and dy.dtype == lp_dtype() and x.dtype == lp_dtype() and dy.dim() == 2 and x.dim() == 2):
         return None
     n, M = dy.shape
     N = x.shape[1]
@@ -122,7 +161,7 @@ def _wgrad_plan(dy, x):
 def weight_grad(dy, x, out=None, batch=None):
     """``dy^T @ x`` -> [M, N] fp32 (into ``out`` when given): the matrix-core kernel with transposed LDS reads when the
     operands allow it (bf16, the mixed-precision update), else ``splitk_tn``."""
-    if dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_cuda:
+    if dy.dtype == lp_dtype() and x.dtype == lp_dtype() and dy.is_cuda:
         o = out if out is not None else torch.empty((dy.shape[1], x.shape[1]), device=dy.device, dtype=torch.float32)
         if o.is_contiguous() and weight_grad_cat(dy, None, x, None, o, batch=batch):
             return o
@@ -155,7 +194,7 @@ WGRAD_CAT_WIDE = _os.environ.get("VINE_WGRAD_CAT_WIDE", "1") != "0"  # 128 x 352
 def _cat_operand(x, n):
     """(columns read, columns stored) of a bf16 operand of ``vine_weight_grad_cat_mfma``: the columns are rounded up to
     a multiple of 16 that must lie inside the rows of the buffer x is a column block of (read, never stored)."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[0] == n and x.stride(1) == 1
+    if not (x.is_cuda and x.dtype == lp_dtype() and x.dim() == 2 and x.shape[0] == n and x.stride(1) == 1
             and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
         return None
     N = x.shape[1]
@@ -167,7 +206,7 @@ def _cat_operand(x, n):
 
 def _wgrad_cat_plan(dy, x1, x2, out1, out2, allow_wide=True, wgs=None):
     """Arguments of ``vine_weight_grad_cat_mfma`` for ``dy^T @ [x1 | x2]`` -> (n, M, N1p, Nv1, N2p, Nv2, NT, S) or None."""
-    if not (WGRAD_CAT and dy.is_cuda and dy.dtype == torch.bfloat16 and dy.dim() == 2 and dy.stride(1) == 1
+    if not (WGRAD_CAT and dy.is_cuda and dy.dtype == lp_dtype() and dy.dim() == 2 and dy.stride(1) == 1
             and dy.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and out2.is_contiguous()
             and (out1 is None or out1.is_contiguous())):
         return None
@@ -371,18 +410,18 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
         # ONE launch for the whole sequence: h_t stays in LDS, c_t in registers, weights stream from the
         # fragment-ordered copy (``wtile``); x = the padded operand buffer whose first K1 columns are the step input
         K1 = wtile.numel() // (4 * H) - H
-        assert op == torch.bfloat16 and lstm_seq_ok(B, H, T, K1) and x.stride(0) >= K1 and hp.is_contiguous()
+        assert op == lp_dtype() and lstm_seq_ok(B, H, T, K1) and x.stride(0) >= K1 and hp.is_contiguous()
         _check(lib.vine_lstm_seq_forward_mfma(B, T, H, K1, x.data_ptr(), x.stride(0), hp.data_ptr(), T * H,
                                               wtile.data_ptr(), bias.data_ptr(), c_prev[0].data_ptr(), d_ptr,
                                               out.data_ptr(), c_all.data_ptr(), gates.data_ptr() if need_grad else None,
-                                              int(c_all.dtype == torch.bfloat16),
+                                              int(c_all.dtype == lp_dtype()),
                                               c_last.data_ptr() if c_last is not None else None,
                                               h0_direct.data_ptr() if h0_direct is not None else None, st),
                "vine_lstm_seq_forward_mfma")
         return out, c_all, gates, hp
     w_hh_t = w_hh.t()
     # mixed precision: the recurrent GEMM runs inside the step kernel on the matrix cores (vine_lstm_step_mfma)
-    mfma = (op == torch.bfloat16 and B % 64 == 0 and H in (128, 256, 512))
+    mfma = (op == lp_dtype() and B % 64 == 0 and H in (128, 256, 512))
     for t in range(T):
         last = t == T - 1
         if mfma and wcat is not None:
@@ -411,7 +450,7 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
             (d_ptr + t) if d_ptr is not None else None, T, out.data_ptr() + 4 * (t * H), T * H,
             c_all[t + 1].data_ptr(), gates[t].data_ptr() if need_grad else None,
             None if last else hp.data_ptr() + hp.element_size() * ((t + 1) * H),
-            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, int(op == torch.bfloat16), 0, st),
+            (d_ptr + t + 1) if (d_ptr is not None and not last) else None, T, int(op == lp_dtype()), 0, st),
             "vine_lstm_cell_forward")
     return out, c_all, gates, hp
 
@@ -439,18 +478,18 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, 
         c_prev[0] = c0_direct
     assert w_hh_tiled is not None or (g_out.dtype == torch.float32 and c_all.dtype == torch.float32)
     if w_hh_tiled is not None:           # ONE launch for all T steps (dG_{t+1} in LDS, dc / c in registers)
-        assert dG.dtype == torch.bfloat16 and lstm_seq_ok(B, H, T, 32) and gates.is_contiguous() and c_all.is_contiguous()
+        assert dG.dtype == lp_dtype() and lstm_seq_ok(B, H, T, 32) and gates.is_contiguous() and c_all.is_contiguous()
         bias_partial = torch.empty((B // 32, 4 * H), device=dev, dtype=torch.float32)
         _check(lib.vine_lstm_seq_backward_mfma(B, T, H, g_out.data_ptr(), w_hh_tiled.data_ptr(), gates.data_ptr(),
                                                c_all.data_ptr(), c_prev[0].data_ptr(),
                                                dones.data_ptr() if dones is not None else None, dG.data_ptr(),
-                                               bias_partial.data_ptr(), int(c_all.dtype == torch.bfloat16),
+                                               bias_partial.data_ptr(), int(c_all.dtype == lp_dtype()),
                                                c_last.data_ptr() if c_last is not None else None,
-                                               int(g_out.dtype == torch.bfloat16), _stream(g_out)),
+                                               int(g_out.dtype == lp_dtype()), _stream(g_out)),
                "vine_lstm_seq_backward_mfma")
         return dG, bias_partial
     if w_hh_t is not None:
-        assert dG.dtype == torch.bfloat16 and lstm_bwd_mfma_ok(B, H)
+        assert dG.dtype == lp_dtype() and lstm_bwd_mfma_ok(B, H)
         bias_partial = torch.empty((2, B // 64, 4 * H), device=dev, dtype=torch.float32)
         st = _stream(g_out)
         d_ptr = dones.data_ptr() if dones is not None else None
@@ -483,7 +522,7 @@ def _lstm_backward_steps(lib, g_out, w_hh, c_all, gates, dones, T, w_hh_t=None, 
             dG.data_ptr() + dG.element_size() * (t * 4 * H), T * 4 * H, dc[t & 1].data_ptr(),
             bias_partial[t & 1].data_ptr() if use_partial else None,
             bias_partial[(t + 1) & 1].data_ptr() if (use_partial and t < T - 1) else None,
-            int(dG.dtype == torch.bfloat16), st), "vine_lstm_cell_backward")
+            int(dG.dtype == lp_dtype()), st), "vine_lstm_cell_backward")
         dc_next = dc[t & 1]
         if t > 0:
             g_rec = _mm(dG3[:, t], w_hh)
@@ -513,8 +552,9 @@ class ColumnSumBatch:
     """Collects column-sum jobs and runs them in ONE launch (``vine_column_sums_batched``, 16 jobs per launch): the
     network's backward pass ends with ~13 of them, each far too small to fill the chip."""
 
-    def __init__(self):
+    def __init__(self, check_overflow=False):
         self.jobs, self.keep = [], []
+        self.check_overflow = check_overflow      # flag non-finite results in AMP["found_inf"] (loss-scaled backward)
 
     def add(self, src, out, out1=None, n0=0, dup=False):
         flat = _as_rows(src)
@@ -533,7 +573,8 @@ class ColumnSumBatch:
             i64 = lambda v: (C.c_int64 * n)(*v)
             ptr = lambda v: (C.c_void_p * n)(*v)
             _check(lib.vine_column_sums_batched(n, i64(cols[0]), i64(cols[1]), ptr(cols[2]), i64(cols[3]), ptr(cols[4]),
-                                                i64(cols[5]), ptr(cols[6]), (C.c_int32 * n)(*cols[7]), st),
+                                                i64(cols[5]), ptr(cols[6]), (C.c_int32 * n)(*cols[7]),
+                                                _amp_ptrs()[1] if self.check_overflow else None, st),
                    "vine_column_sums_batched")
         self.jobs, self.keep = [], []
 
@@ -549,7 +590,7 @@ class CopyBatch:
         w_hh^T (either may be None)."""
         H4, width = w_ih.shape
         H = w_hh.shape[1]
-        assert w_ih.dtype == w_hh.dtype == torch.bfloat16 and w_ih.stride(1) == 1 and w_hh.stride(1) == 1 and H == 256
+        assert w_ih.dtype == w_hh.dtype == lp_dtype() and w_ih.stride(1) == 1 and w_hh.stride(1) == 1 and H == 256
         if fwd_dst is not None:
             assert fwd_dst.numel() == H4 * (wpad + H) and fwd_dst.is_contiguous() and width <= wpad < 65536
             self.keep.append((fwd_dst, w_ih, w_hh))
@@ -584,7 +625,7 @@ class CopyBatch:
         elif op in (self.COPY, self.ADD):
             assert tuple(s2.shape) == (rows, cols) and s2.dtype == d2.dtype
         elif op == self.CAST_BF16:
-            assert tuple(s2.shape) == (rows, cols) and s2.dtype == torch.float32 and d2.dtype == torch.bfloat16
+            assert tuple(s2.shape) == (rows, cols) and s2.dtype == torch.float32 and d2.dtype == lp_dtype()
         if op == self.ADD:
             assert t2.stride(0) == s2.stride(0) and d2.dtype == torch.float32
         self.keep.append((d2, s2, t2))
@@ -701,7 +742,7 @@ class _Trunk(torch.autograd.Function):
         w_ih, w_hh, b_ih, b_hh, ln_g, ln_b, ln_eps, mu_w, mu_b, v_w, v_b = params[2 * n_mlp:]
         # GEMM operands: the fp32 parameters themselves, or their bfloat16 shadows (W_1..W_L, w_ih, w_hh)
         mixed = op_weights is not None
-        op = torch.bfloat16 if mixed else torch.float32
+        op = lp_dtype() if mixed else torch.float32
         Wop = list(op_weights[:n_mlp]) if mixed else [W for W, _ in mlp]
         w_ih_op, w_hh_op = (op_weights[n_mlp], op_weights[n_mlp + 1]) if mixed else (w_ih, w_hh)
         n, F_in = obs_n.shape
@@ -794,7 +835,7 @@ class _Trunk(torch.autograd.Function):
             c_last = torch.empty((B, H), device=dev, dtype=torch.float32) if lp else None
             h0_direct = h0 if (seq and h0.dtype == torch.float32 and h0.is_contiguous()) else None
             lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep,
-                                               copy_c0=c0_direct is None, c_dtype=torch.bfloat16 if lp else torch.float32,
+                                               copy_c0=c0_direct is None, c_dtype=lp_dtype() if lp else torch.float32,
                                                mask_h0=h0_direct is None)
             prep.flush(obs_n)
         else:
@@ -871,7 +912,7 @@ class _Trunk(torch.autograd.Function):
             # known before this node's backward runs (which ignores the gradient it is handed for `heads`)
             y = out.new_empty(0)
             heads = torch.empty((n, NH), device=dev, dtype=torch.float32)
-            d_out = torch.empty((n, H), device=dev, dtype=torch.bfloat16 if lp else torch.float32)
+            d_out = torch.empty((n, H), device=dev, dtype=lp_dtype() if lp else torch.float32)
             ln_part = torch.empty((n // lhl_rows, (2 + NH) * H), device=dev, dtype=torch.float32)
             lpk = loss_pack
             _check(lib.vine_ln_heads_loss(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
@@ -879,7 +920,8 @@ class _Trunk(torch.autograd.Function):
                                           *[t.data_ptr() for t in lpk["args"]], *lpk["scal"], heads.data_ptr(),
                                           d_out.data_ptr(), int(lp), ln_part.data_ptr(), lpk["stats"].data_ptr(),
                                           lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
-                                          lpk["head_bias_grads"][1].data_ptr(), lpk["scratch"].data_ptr(), *lpk["extra"], st),
+                                          lpk["head_bias_grads"][1].data_ptr(), lpk["scratch"].data_ptr(), *lpk["extra"],
+                                          *_amp_ptrs(), st),
                    "vine_ln_heads_loss")
             ctx.loss_fused = (d_out, ln_part)
         elif fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
@@ -942,7 +984,12 @@ class _Trunk(torch.autograd.Function):
 
         base = 2 * n_mlp
         # with the optimiser's gradient slots in place all column sums are deferred into one launch at the end
-        batch = ColumnSumBatch() if all(sl is not None for k, sl in enumerate(slots) if ctx.pshapes[k] is not None) else None
+        batch = (ColumnSumBatch(check_overflow=mixed and AMP["found_inf"] is not None)
+                 if all(sl is not None for k, sl in enumerate(slots) if ctx.pshapes[k] is not None) else None)
+        if mixed and AMP["found_inf"] is not None and AMP["covered"] is None:
+            # do ALL parameter gradients of this backward pass end in the overflow-checked column-sum launch?  (else the
+            # optimiser checks the gradient block itself before it steps: FlatAdam.step)
+            AMP["covered"] = batch is not None
         NH = w_heads.shape[0]
         if ctx.loss_fused is not None:
             d_out, part = ctx.loss_fused             # computed in forward by the fused LayerNorm + heads + loss kernel
@@ -1013,7 +1060,7 @@ class _Trunk(torch.autograd.Function):
             # the whole MLP backward in one launch (vine_mlp3_bwd_elu_mfma): LSTM input gradient (MLP columns) x ELU' ->
             # gz3 -> gz2 -> gz1 carried in registers, bias partial sums per workgroup
             rows_wg = 128 if (n % 128 == 0 and n >= 32768) else 64
-            gzs = [torch.empty((n, c), device=dev, dtype=torch.bfloat16) for c in (256, 128, 64)]       # layers 1, 2, 3
+            gzs = [torch.empty((n, c), device=dev, dtype=lp_dtype()) for c in (256, 128, 64)]       # layers 1, 2, 3
             parts = [torch.empty((n // rows_wg, c), device=dev, dtype=torch.float32) for c in (256, 128, 64)]
             _check(lib.vine_mlp3_bwd_elu_mfma(n, dG.data_ptr(), dG.stride(0), 4 * H, ctx.wts[0].data_ptr(),
                                               ctx.wts[0].stride(0), ctx.wts[2].data_ptr(), ctx.wts[2].stride(0),
@@ -1035,7 +1082,7 @@ class _Trunk(torch.autograd.Function):
         elif mixed and ctx.wts[0] is not None:
             # LSTM input gradient (MLP columns only) x ELU' of the last MLP layer + its bias partial sums: one
             # matrix-core kernel streaming the 4H-long reduction in k chunks
-            gz = torch.empty((n, U), device=dev, dtype=torch.bfloat16)
+            gz = torch.empty((n, U), device=dev, dtype=lp_dtype())
             part = torch.empty((n // 64, U), device=dev, dtype=torch.float32)
             _check(lib.vine_linear_bwd_elu_mfma(n, U, 4 * H, dG.data_ptr(), dG.stride(0), ctx.wts[0].data_ptr(),
                                                 ctx.wts[0].stride(0), xcat.data_ptr(), xcat.stride(0), 1.0,
@@ -1052,7 +1099,7 @@ class _Trunk(torch.autograd.Function):
                 a = xcat if i == n_mlp - 1 else acts[i]
                 C_ = g.shape[1]
                 part = torch.empty((PPO_PARTIAL_BLOCKS, C_), device=dev, dtype=torch.float32)
-                gz = torch.empty((n, C_), device=dev, dtype=torch.bfloat16) if mixed else g     # fp32: in place
+                gz = torch.empty((n, C_), device=dev, dtype=lp_dtype()) if mixed else g     # fp32: in place
                 _check(lib.vine_elu_backward(n, C_, g.data_ptr(), C_, a.data_ptr(), a.stride(0), 1.0, gz.data_ptr(), C_,
                                              part.data_ptr(), int(mixed), int(mixed), st), "vine_elu_backward")
             x_in = acts[i - 1] if i > 0 else x0
@@ -1063,7 +1110,7 @@ class _Trunk(torch.autograd.Function):
             C_in = weights[i].shape[1]
             if mixed and ctx.wts[i] is not None:
                 wt = ctx.wts[i]                                                    # [C_in, C_i] bf16, made in forward
-                gz_next = torch.empty((n, C_in), device=dev, dtype=torch.bfloat16)
+                gz_next = torch.empty((n, C_in), device=dev, dtype=lp_dtype())
                 part = torch.empty((n // 64, C_in), device=dev, dtype=torch.float32)
                 _check(lib.vine_linear_bwd_elu_mfma(n, C_in, gz.shape[1], gz.data_ptr(), gz.stride(0), wt.data_ptr(),
                                                     wt.stride(0), acts[i - 1].data_ptr(), acts[i - 1].stride(0), 1.0,
@@ -1212,7 +1259,7 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
                                  *scal, g.data_ptr(), g.data_ptr() + 4 * A, grad_logstd.data_ptr(), stats.data_ptr(),
                                  A + 1, A + 1, head_bias_grads[0].data_ptr() if head_bias_grads else None,
                                  head_bias_grads[1].data_ptr() if head_bias_grads else None, scratch.data_ptr(), *extra,
-                                 _stream(hd)),
+                                 _amp_ptrs()[0], _stream(hd)),
                "vine_ppo_loss")
         return g, None, grad_logstd, stats
     n = mu.shape[0]
@@ -1222,6 +1269,6 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     grad_value = torch.empty_like(val_c)
     _check(lib.vine_ppo_loss(n, A, mu_c.data_ptr(), ls.data_ptr(), val_c.data_ptr(), *[a.data_ptr() for a in args],
                              *scal, grad_mu.data_ptr(), grad_value.data_ptr(), grad_logstd.data_ptr(),
-                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), *extra, _stream(mu)),
+                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), *extra, _amp_ptrs()[0], _stream(mu)),
            "vine_ppo_loss")
     return grad_mu, grad_value.view_as(value), grad_logstd, stats
