@@ -58,8 +58,10 @@ def parse_args():
                         "profiling of the other task configurations; the default line never passes any")
     p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
     p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
-                   help="ppo mode: update precision: off = fp32, bf16 = hand-written mixed precision (the packaged "
-                        "default, mixed_precision: True as in the reference YAML), fp16 = torch autocast + GradScaler")
+                   help="ppo mode: update precision: off = fp32; fp16 (the packaged default, mixed_precision: True as in the "
+                        "reference YAML) = hand-written mixed precision with device-side loss scaling when the library is "
+                        "built for fp16 operands (default build), torch autocast otherwise; bf16 likewise for a "
+                        "-DVINE_LP_BF16 build")
     return p.parse_args()
 
 
@@ -431,12 +433,12 @@ def main():
                          "compute": compute_roofline(env.step_kernel_name, n, kernel_ms)},
         }
         out.update(extra)
-        if str(extra.get("update_precision", "")).startswith("bf16"):
-            # env step kernel, LSTM/LayerNorm state, loss and optimiser compute in f32; the GEMMs of the PPO update
-            # take bf16 operands with f32 accumulation (the reference YAML's mixed_precision: True; it uses fp16
-            # autocast).  `other_precision` carries the same iteration with an all-f32 update.
-            out["dtype"] = ("f32 (env step, recurrent state, LayerNorm/heads, loss, parameter gradients, optimiser) + bf16 GEMM "
-                            "operands and backward-only saved activations / f32 accumulate (PPO update)")
+        if mode == "ppo":
+            # env step kernel f32; rollout inference f32 (the reference's); the update takes the reference's
+            # `mixed_precision: True` dtype (fp16 GEMM operands, f32 accumulation / state / loss / optimiser, GradScaler loss
+            # scaling).  `other_precision` carries the same iteration with an all-f32 update, `extra_lp16_rollout` the
+            # narrower 16-bit-rollout variant of round 2.
+            out["dtype"] = "f32 (env step, rollout inference); " + str(extra.get("update_precision", ""))
         if world == 1 and not args.no_saturated:
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
         if world == 1 and not args.no_other_configs:

@@ -329,6 +329,26 @@ int vine_ln_heads_loss_rows(void);
  * this header.  Parameter names containing "bf16" date from round 2 and mean "this 16-bit format". */
 const char* vine_lp16_format(void);
 
+/* Rollout inference at the reference's precision (rl_games play_steps runs fp32; only the update is autocast): the
+ * policy trunk of one rollout step on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: f32 operands, f32 accumulate).
+ * vine_mlp3_elu_f32: observation normalisation ((raw - mean) / sqrt(var + eps), clamped to +-clip: vine_normalize_obs'
+ *   arithmetic) and the three ELU layers in one launch; writes x[row] = [mlp output (C3 = 64) | normalised obs (F_in) |
+ *   zeros up to 32 columns] (rows ldx floats apart) -- the x block of the LSTM operand.  C1 = 256, C2 = 128, C3 = 64,
+ *   F_in <= 32, n % 64 == 0, else VINE_ERR_UNSUPPORTED.  w1 [C1, 32] = the first layer's weight zero-padded to 32 columns
+ *   (rows ldw1 >= 32 apart), w2 [C2, C1], w3 [C3, C2].
+ * vine_lstm_step_f32: gates = [x | h] Wcat^T + bias, cell update as the epilogue (gate order i, f, g, o as torch.nn.LSTM):
+ *   xh [N, K = 352] (rows ldx apart), w_tiled = vine_lstm_tile_weights_f32(Wcat [4H, K]), c_prev / c_out [N, H], h_out
+ *   [N, H] (rows ldh apart), hp_next (nullable): a second copy of h (the h block of the NEXT step's operand, rows ldhp
+ *   apart).  H = 256, K = 352, N % 512 == 0, else VINE_ERR_UNSUPPORTED. */
+int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
+                      float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1, const float* w2,
+                      int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3, const float* b3, int64_t C3,
+                      float alpha, void* stream);
+int vine_lstm_step_f32(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const float* w_tiled, const float* bias,
+                       const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next, int64_t ldhp,
+                       void* stream);
+int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t ldw, float* dst, void* stream);
+
 /* Allocates the library's small per-device bookkeeping (the ticket words of the loss / Adam kernels' "last workgroup"
  * elections) for the CURRENT device.  It happens by itself on the first vine_ppo_loss / vine_ln_heads_loss /
  * vine_adam_step* call on a device; call this once beforehand when that first call would sit inside a stream capture

@@ -1566,3 +1566,79 @@ def test_fp16_update_recovers_from_an_absurd_loss_scale():
     assert steps[-1] > 0 and not torch.equal(agent.optimizer.flat_params, p0)     # ... and then it trained
     assert scales[-1] >= 1.0
     env.close()
+
+
+# --------------------------------------------------------------------------- fp32 matrix-core rollout kernels
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [28, 18])
+def test_mlp3_elu_f32_against_float64_torch(F):
+    """vine_mlp3_elu_f32 (observation normalisation + three ELU layers on v_mfma_f32_16x16x4_f32, fp32 operands and
+    accumulation: the reference's rollout precision) against the float64 torch composition; also the normalised
+    observation block it writes behind the MLP output, zero-padded to 32 columns.  fp32 tolerance."""
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(F)
+    n, ldx = 1024, 352
+    raw = torch.randn(n, F, device=dev) * 2.0 + 0.3
+    mean = torch.randn(F, device=dev, dtype=torch.float64) * 0.2
+    var = torch.rand(F, device=dev, dtype=torch.float64) + 0.3
+    Ws = [torch.randn(o, i, device=dev) / np.sqrt(i) for o, i in ((256, F), (128, 256), (64, 128))]
+    bs = [torch.randn(o, device=dev) * 0.1 for o in (256, 128, 64)]
+    x = torch.full((n, ldx), 7.0, device=dev)
+    w1p = torch.zeros(256, 32, device=dev)
+    w1p[:, :F] = Ws[0]
+    rc = lib.vine_mlp3_elu_f32(n, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                               w1p.data_ptr(), 32, bs[0].data_ptr(), 256, Ws[1].data_ptr(), Ws[1].stride(0),
+                               bs[1].data_ptr(), 128, Ws[2].data_ptr(), Ws[2].stride(0), bs[2].data_ptr(), 64, 1.0,
+                               torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    xn = torch.clamp((raw - mean.float()) / torch.sqrt(var.float() + 1e-5), -5.0, 5.0)      # vine_normalize_obs' arithmetic
+    a = xn.double()
+    for W, b in zip(Ws, bs):
+        a = torch.nn.functional.elu(a @ W.double().t() + b.double())
+    assert float((x[:, :64].double() - a).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
+    assert torch.equal(x[:, 64:64 + F], xn) and float(x[:, 64 + F:96].abs().max()) == 0.0
+    assert float((x[:, 96:] - 7.0).abs().max()) == 0.0                    # nothing else touched
+    assert lib.vine_mlp3_elu_f32(n + 8, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                                 w1p.data_ptr(), 32, bs[0].data_ptr(), 256, Ws[1].data_ptr(), 256, bs[1].data_ptr(), 128,
+                                 Ws[2].data_ptr(), 128, bs[2].data_ptr(), 64, 1.0, torch.cuda.current_stream().cuda_stream) == -2
+
+
+@pytest.mark.gpu
+def test_lstm_step_f32_against_float64_torch():
+    """vine_lstm_step_f32 (gate GEMM over [x | h] on the fp32 matrix cores + the cell update as its epilogue) against
+    float64 torch with torch.nn.LSTM's gate order; the second copy of h (next step's operand block) too."""
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    N, H, K = 1024, 256, 352
+    xh = torch.randn(N, K, device=dev)
+    xh[:, 92:96] = 0.0
+    wcat = torch.randn(4 * H, K, device=dev) / np.sqrt(K)
+    bias = torch.randn(4 * H, device=dev) * 0.1
+    c_prev = torch.randn(N, H, device=dev)
+    wt = torch.empty(4 * H * K, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.vine_lstm_tile_weights_f32(H, K, wcat.data_ptr(), wcat.stride(0), wt.data_ptr(), st) == 0
+    h_out, c_out = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+    nxt = torch.zeros(N, K, device=dev)
+    assert lib.vine_lstm_step_f32(N, H, K, xh.data_ptr(), K, wt.data_ptr(), bias.data_ptr(), c_prev.data_ptr(), h_out.data_ptr(),
+                                  H, c_out.data_ptr(), nxt.data_ptr() + 4 * 96, K, st) == 0
+    torch.cuda.synchronize()
+    g = xh.double() @ wcat.double().t() + bias.double()
+    i, f, gg, o = (g[:, k * H:(k + 1) * H] for k in range(4))
+    c = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    assert float((c_out.double() - c).abs().max()) < 1e-5 and float((h_out.double() - h).abs().max()) < 1e-5
+    assert torch.equal(nxt[:, 96:], h_out) and float(nxt[:, :96].abs().max()) == 0.0
+    # in place on the cell state (what the rollout does) gives the same result
+    c_io = c_prev.clone()
+    assert lib.vine_lstm_step_f32(N, H, K, xh.data_ptr(), K, wt.data_ptr(), bias.data_ptr(), c_io.data_ptr(), h_out.data_ptr(),
+                                  H, c_io.data_ptr(), None, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(c_io, c_out)
+    assert lib.vine_lstm_step_f32(N + 64, H, K, xh.data_ptr(), K, wt.data_ptr(), bias.data_ptr(), c_prev.data_ptr(),
+                                  h_out.data_ptr(), H, c_out.data_ptr(), None, 0, st) == -2

@@ -199,6 +199,10 @@ PPO_PROTOTYPES = {
                                      _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_lp16_format": (C.c_char_p, []),
     "vine_ppo_runtime_init": (C.c_int, []),
+    "vine_mlp3_elu_f32": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _I64, _VP, _I64, _VP, _I64,
+                                    _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP]),
+    "vine_lstm_step_f32": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _I64, _VP]),
+    "vine_lstm_tile_weights_f32": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP]),
     "vine_ln_heads_loss_rows": (C.c_int, []),
     "vine_mlp3_bwd_elu_mfma": (C.c_int, [_I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _I64,
                                          _I64, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -3564,6 +3564,281 @@ int grid_for(long long work, int threads) {
     return (int)blocks;
 }
 
+
+// ================================================================================================================
+// Rollout inference at the reference's precision (rl_games runs play_steps in fp32; only the update is autocast):
+// the policy trunk of one rollout step as TWO fp32 matrix-core kernels, v_mfma_f32_16x16x4_f32 (f32 operands, f32
+// accumulate: bitwise an fmaf chain per output, 64 FLOP/clk/SIMD = the fp32 vector rate on gfx950).
+// Both compute the transposed product D^T = W X^T like the 16-bit kernels above, so that a lane ends up with 4
+// CONSECUTIVE units of ONE batch row (C/D map of the 16x16 tile: column = lane & 15 -> batch row, row = 4 (lane >> 4) + r
+// -> unit).  The k index of an MFMA is free as long as both operands agree: lane group g = lane >> 4 takes
+// k = 16 j + 4 g + i for the i-th MFMA of k-block j, i.e. ONE float4 per lane and operand feeds four MFMAs.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma_f32(float a, float b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- LSTM step, fp32: gates = [x | h] Wcat^T + bias on the matrix cores, pointwise cell update as the epilogue; the
+// [N, 4H] pre-activations never reach memory.  Workgroup = 4 waves = 64 batch rows x 64 hidden units (x 4 gates); each
+// wave owns 16 rows and all 16 (gate, unit-tile) accumulators.  The wave's X fragments (16 rows x K) are loaded ONCE
+// into registers (KB float4 per lane); the weights arrive pre-tiled ([unit block][k-block][gate * 64 + unit][16], one
+// contiguous 16 KB chunk per workgroup and k-block: vine_lstm_tile_weights_f32) and are streamed through two LDS buffers
+// (row pitch 20 floats: the 16 lanes of a fragment read hit 16 disjoint 4-bank groups), the next chunk's global loads in
+// flight under the current chunk's 64 MFMAs per wave.  MFMA-bound by construction: 64 MFMAs x 32 cycles per 16
+// ds_read_b128 + 4 global loads per lane.
+#define LSTM_F32_PITCH 20
+template <int KB>      // K = 16 KB
+__global__ __launch_bounds__(256, 4) void lstm_step_f32_kernel(long long N, const float* __restrict__ xh, long long ldx,
+                                                               const float* __restrict__ wt, const float* __restrict__ bias,
+                                                               const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                               long long ldh, float* __restrict__ c_out,
+                                                               float* __restrict__ hp_next, long long ldhp) {
+    // Register budget: 128 per lane (4 waves per SIMD = 4 workgroups per CU, 4 x 40 KB of LDS): all 1024 workgroups of the
+    // rollout's 16384 rows are resident at once, and a SIMD always has another wave's MFMAs to issue while one waits at its
+    // workgroup's barrier or for its LDS reads (2 waves per SIMD with the whole X fragment in registers: 125 us, the MFMA
+    // pipe busy 60 % of the time).  X is therefore streamed like the weights: one float4 per lane and k-block, requested
+    // two k-blocks ahead.
+    constexpr int H = 256;
+    __shared__ __attribute__((aligned(16))) float wl[2][256 * LSTM_F32_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    // workgroups w, w + 8, w + 16, w + 24 (same XCD under round-robin dispatch) share one row block: its X is read from
+    // HBM once per XCD-local L2 instead of four times
+    const int w = blockIdx.x;
+    const int rb = (w >> 5) * 8 + (w & 7), ub = (w >> 3) & 3;
+    const long long row = (long long)rb * 64 + wave * 16 + u;
+    const float* wsrc = wt + (long long)ub * KB * 4096;
+    const float* xrow = xh + row * ldx + 4 * g;
+    float4 sreg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sreg[i] = ld4(wsrc + 4 * (tid + 256 * i));
+    float4 xq[3];                                                      // k-blocks j, j + 1, j + 2 (ring, static indices)
+    xq[0] = ld4(xrow);
+    xq[1] = ld4(xrow + 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;                                   // float4 index: row q >> 2, chunk q & 3
+        st4(&wl[0][(q >> 2) * LSTM_F32_PITCH + 4 * (q & 3)], sreg[i]);
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[gg][t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {                      // fully unrolled: the rings stay register names
+        const int buf = j & 1;
+        if (j + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sreg[i] = ld4(wsrc + (long long)(j + 1) * 4096 + 4 * (tid + 256 * i));
+        }
+        if (j + 2 < KB) xq[(j + 2) % 3] = ld4(xrow + 16 * (j + 2));
+        const float xa[4] = {xq[j % 3].x, xq[j % 3].y, xq[j % 3].z, xq[j % 3].w};
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            // four unit tiles at a time: consecutive MFMAs go to different accumulators (a dependent MFMA of this shape
+            // waits 40 cycles, an independent one issues after 32)
+            float wa[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 wv = ld4(&wl[buf][(gg * 64 + 16 * t + u) * LSTM_F32_PITCH + 4 * g]);
+                wa[t][0] = wv.x; wa[t][1] = wv.y; wa[t][2] = wv.z; wa[t][3] = wv.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[gg][t] = mfma_f32(wa[t][i], xa[i], acc[gg][t]);
+        }
+        if (j + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + 256 * i;
+                st4(&wl[buf ^ 1][(q >> 2) * LSTM_F32_PITCH + 4 * (q & 3)], sreg[i]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: lane holds, per unit tile t, the 4 gates of units ub*64 + 16 t + 4 g + {0..3} of its row
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int unit = ub * 64 + 16 * t + 4 * g;
+        const float4 bi = ld4(bias + 0 * H + unit), bf = ld4(bias + 1 * H + unit), bg = ld4(bias + 2 * H + unit),
+                     bo = ld4(bias + 3 * H + unit);
+        const float4 cp = ld4(c_prev + row * H + unit);
+        const float bia[4] = {bi.x, bi.y, bi.z, bi.w}, bfa[4] = {bf.x, bf.y, bf.z, bf.w}, bga[4] = {bg.x, bg.y, bg.z, bg.w},
+                    boa[4] = {bo.x, bo.y, bo.z, bo.w}, cpa[4] = {cp.x, cp.y, cp.z, cp.w};
+        float cn[4], hn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gi = sigmoidf_(acc[0][t][r] + bia[r]), gf = sigmoidf_(acc[1][t][r] + bfa[r]);
+            const float gc = tanhf_(acc[2][t][r] + bga[r]), go = sigmoidf_(acc[3][t][r] + boa[r]);
+            cn[r] = gf * cpa[r] + gi * gc;
+            hn[r] = go * tanhf_(cn[r]);
+        }
+        st4(c_out + row * H + unit, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(h_out + row * ldh + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        if (hp_next) st4(hp_next + row * ldhp + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
+    }
+}
+
+// [w_ih | 0 | w_hh] rows (4H x K, row stride ldw) -> the step kernel's tiles: dst[((ub * KB + j) * 256 + gate * 64 + uu) * 16 + c]
+// = W[gate * H + ub * 64 + uu][16 j + c]
+__global__ void lstm_tile_weights_f32_kernel(int KB, const float* __restrict__ w, long long ldw, float* __restrict__ dst) {
+    const long long total = 4LL * KB * 256 * 4;                         // float4 elements
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(q & 3);
+        const long long rest = q >> 2;
+        const int r = (int)(rest & 255);
+        const long long bj = rest >> 8;
+        const int j = (int)(bj % KB), ub = (int)(bj / KB);
+        const int gate = r >> 6, uu = r & 63;
+        st4(dst + 4 * q, ld4(w + (long long)(gate * 256 + ub * 64 + uu) * ldw + 16 * j + 4 * c4));
+    }
+}
+
+// ---- observation normalisation + the three MLP layers (C1 = 256, C2 = 128, C3 = 64, ELU), fp32, ONE launch: a wave
+// carries its 16 rows through the layers in registers -- the accumulator of unit tile t of layer L (lane: units
+// 16 t + 4 g + {0..3} of its row) IS the B operand float4 of k-block t of layer L + 1 (k = 16 t + 4 g + i), no exchange.
+// The weights of one layer at a time are staged in LDS (row pitch K + 4 floats: conflict-free fragment reads), the
+// same region for all three (W2 alone is 130 KB in fp32).  Writes the normalised observations (zero-padded to 32
+// columns) and the MLP output into the LSTM operand row: x[row] = [mlp(64) | obs_n(F) | 0 ...].
+__global__ __launch_bounds__(256) void mlp3_elu_f32_kernel(long long n, float* __restrict__ x, long long ldx,
+                                                           const float* __restrict__ raw, int F_in,
+                                                           const double* __restrict__ mean, const double* __restrict__ var,
+                                                           float eps, float clip, const float* __restrict__ w1, long long ldw1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           long long ldw2, const float* __restrict__ b2,
+                                                           const float* __restrict__ w3, long long ldw3,
+                                                           const float* __restrict__ b3, float alpha) {
+    constexpr int C1 = 256, C2 = 128, C3 = 64, P1 = 36, P2 = C1 + 4, P3 = C2 + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw_f32[];
+    float* wl = reinterpret_cast<float*>(lds_raw_f32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const long long row = ((long long)blockIdx.x * 4 + wave) * 16 + u;
+    // ---- layer-1 operand: normalised observation columns 16 j + 4 g + i (j = 0, 1), zero beyond F_in; the same values go
+    // into the LSTM operand's observation block (32 columns behind the MLP output)
+    float xn[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 16 * j + 4 * g + i;
+            float y = 0.0f;
+            if (c < F_in) {
+                // same arithmetic as normalize_obs_kernel: statistics cast to float first
+                const float m = (float)mean[c], sd = sqrtf((float)var[c] + eps);
+                y = (raw[row * F_in + c] - m) / sd;
+                y = fminf(fmaxf(y, -clip), clip);
+            }
+            xn[j][i] = y;
+        }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) st4(x + row * ldx + C3 + 16 * j + 4 * g, make_float4(xn[j][0], xn[j][1], xn[j][2], xn[j][3]));
+    // ---- weights -> LDS, one layer at a time.  The global loads of a layer's weights are issued BEFORE the previous
+    // layer's arithmetic (W1 and W2 right here), so that every staging step finds its data in registers: one L2 round trip
+    // at the start of the kernel, none between the layers.
+    // W1: [C1][32] zero-padded on the host (rows ldw1 apart) -> [C1][P1]
+    float4 s1[8], s2[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i;
+        s1[i] = ld4(w1 + (long long)(q >> 3) * ldw1 + 4 * (q & 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int q = tid + 256 * i, r = q / (C1 / 4), c4 = q - r * (C1 / 4);
+        s2[i] = ld4(w2 + (long long)r * ldw2 + 4 * c4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i;
+        st4(wl + (q >> 3) * P1 + 4 * (q & 7), s1[i]);
+    }
+    __syncthreads();
+    // (unit tiles four at a time in all three layers: consecutive MFMAs then go to different accumulators -- a dependent
+    // MFMA of this shape waits 40 cycles, an independent one issues after 32)
+#define MLP_F32_LAYER(WPITCH, NJ, OPERAND, T0, ACC)                                                         \
+    {                                                                                                       \
+        _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) ACC[tt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};         \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                    \
+            float wa[4][4];                                                                                 \
+            _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) {                                              \
+                const float4 wv = ld4(wl + (16 * (T0 + tt) + u) * WPITCH + 16 * j + 4 * g);                 \
+                wa[tt][0] = wv.x; wa[tt][1] = wv.y; wa[tt][2] = wv.z; wa[tt][3] = wv.w;                     \
+            }                                                                                               \
+            const float xa[4] = OPERAND;                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+                _Pragma("unroll") for (int tt = 0; tt < 4; ++tt) ACC[tt] = mfma_f32(wa[tt][i], xa[i], ACC[tt]); \
+        }                                                                                                   \
+    }
+#define MLP_F32_XN {xn[j][0], xn[j][1], xn[j][2], xn[j][3]}
+#define MLP_F32_A1 {a1[j].x, a1[j].y, a1[j].z, a1[j].w}
+#define MLP_F32_A2 {a2[j].x, a2[j].y, a2[j].z, a2[j].w}
+    float4 a1[C1 / 16];                                                // layer-1 activations = layer-2 operand
+#pragma unroll
+    for (int t0 = 0; t0 < C1 / 16; t0 += 4) {
+        f32x4_t a[4];
+        MLP_F32_LAYER(P1, 2, MLP_F32_XN, t0, a)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const float4 bb = ld4(b1 + 16 * (t0 + tt) + 4 * g);
+            a1[t0 + tt] = make_float4(elu1(a[tt][0] + bb.x, alpha), elu1(a[tt][1] + bb.y, alpha), elu1(a[tt][2] + bb.z, alpha),
+                                      elu1(a[tt][3] + bb.w, alpha));
+        }
+    }
+    __syncthreads();                                                   // everyone is done with W1
+    // ---- W2 (already in registers) -> LDS [C2][P2]; W3's loads leave now, under layer 2
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int q = tid + 256 * i, r = q / (C1 / 4), c4 = q - r * (C1 / 4);
+        st4(wl + r * P2 + 4 * c4, s2[i]);
+    }
+    float4 s3[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i, r = q / (C2 / 4), c4 = q - r * (C2 / 4);
+        s3[i] = ld4(w3 + (long long)r * ldw3 + 4 * c4);
+    }
+    __syncthreads();
+    float4 a2[C2 / 16];
+#pragma unroll
+    for (int t0 = 0; t0 < C2 / 16; t0 += 4) {
+        f32x4_t a[4];
+        MLP_F32_LAYER(P2, C1 / 16, MLP_F32_A1, t0, a)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const float4 bb = ld4(b2 + 16 * (t0 + tt) + 4 * g);
+            a2[t0 + tt] = make_float4(elu1(a[tt][0] + bb.x, alpha), elu1(a[tt][1] + bb.y, alpha), elu1(a[tt][2] + bb.z, alpha),
+                                      elu1(a[tt][3] + bb.w, alpha));
+        }
+    }
+    __syncthreads();
+    // ---- W3 (in registers) -> LDS [C3][P3]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = tid + 256 * i, r = q / (C2 / 4), c4 = q - r * (C2 / 4);
+        st4(wl + r * P3 + 4 * c4, s3[i]);
+    }
+    __syncthreads();
+    {
+        f32x4_t a[4];
+        MLP_F32_LAYER(P3, C2 / 16, MLP_F32_A2, 0, a)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const float4 bb = ld4(b3 + 16 * tt + 4 * g);
+            st4(x + row * ldx + 16 * tt + 4 * g,
+                make_float4(elu1(a[tt][0] + bb.x, alpha), elu1(a[tt][1] + bb.y, alpha), elu1(a[tt][2] + bb.z, alpha),
+                            elu1(a[tt][3] + bb.w, alpha)));
+        }
+    }
+#undef MLP_F32_LAYER
+#undef MLP_F32_XN
+#undef MLP_F32_A1
+#undef MLP_F32_A2
+}
+
 }  // namespace
 
 // One zeroed ticket word per (device, stream, kernel family) for the "last workgroup to finish" elections of the loss
@@ -4402,6 +4677,54 @@ int vine_adam_step_sched(int64_t n, float* params, float* grads, float* exp_avg,
                          const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, void* stream) {
     return vine_adam_step_amp(n, params, grads, exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
                               bf16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr, nullptr, nullptr, stream);
+}
+
+
+int vine_lstm_step_f32(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const float* w_tiled, const float* bias,
+                       const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next, int64_t ldhp,
+                       void* stream) {
+    if (N <= 0 || !xh || !w_tiled || !bias || !c_prev || !h_out || !c_out) return VINE_ERR_INVALID_ARG;
+    if (H != 256 || K != 352 || (N & 63) || (ldx & 3) || ldx < K || (ldh & 3) || ldh < H || (hp_next && ((ldhp & 3) || ldhp < H)) ||
+        ((uintptr_t)xh & 15) || ((uintptr_t)w_tiled & 15) || ((uintptr_t)h_out & 15) || ((uintptr_t)hp_next & 15))
+        return VINE_ERR_UNSUPPORTED;
+    const int rbs = (int)(N / 64);
+    if (rbs & 7) return VINE_ERR_UNSUPPORTED;             // the XCD-aware block mapping walks row blocks in groups of 8
+    hipLaunchKernelGGL(lstm_step_f32_kernel<22>, dim3(rbs * 4), dim3(256), 0, (hipStream_t)stream, (long long)N, xh,
+                       (long long)ldx, w_tiled, bias, c_prev, h_out, (long long)ldh, c_out, hp_next, (long long)ldhp);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t ldw, float* dst, void* stream) {
+    if (!wcat || !dst) return VINE_ERR_INVALID_ARG;
+    if (H != 256 || (K & 15) || K <= 0 || (ldw & 3) || ldw < K || ((uintptr_t)wcat & 15) || ((uintptr_t)dst & 15))
+        return VINE_ERR_UNSUPPORTED;
+    const int KB = (int)(K / 16);
+    hipLaunchKernelGGL(lstm_tile_weights_f32_kernel, dim3(grid_for(4LL * KB * 1024, 256)), dim3(256), 0, (hipStream_t)stream, KB,
+                       wcat, (long long)ldw, dst);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
+                      float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1, const float* w2,
+                      int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3, const float* b3, int64_t C3,
+                      float alpha, void* stream) {
+    if (n <= 0 || !x || !raw || !mean || !var || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return VINE_ERR_INVALID_ARG;
+    if (C1 != 256 || C2 != 128 || C3 != 64 || (n & 63) || F_in <= 0 || F_in > 32 || ldx < C3 + 32 || (ldx & 3) || (ldw2 & 3) ||
+        ldw2 < C1 || (ldw3 & 3) || ldw3 < C2 || ldw1 < 32 || (ldw1 & 3) || ((uintptr_t)w1 & 15) || ((uintptr_t)x & 15) || ((uintptr_t)w2 & 15) ||
+        ((uintptr_t)w3 & 15) || ((uintptr_t)b1 & 15) || ((uintptr_t)b2 & 15) || ((uintptr_t)b3 & 15))
+        return VINE_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)128 * (256 + 4) * sizeof(float);          // W2 [C2][C1 + 4]: the largest of the three stages
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_elu_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return VINE_ERR_DEVICE;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp3_elu_f32_kernel, dim3((unsigned)(n / 64)), dim3(256), lds, (hipStream_t)stream, (long long)n, x,
+                       (long long)ldx, raw, (int)F_in, mean, var, eps, clip, w1, (long long)ldw1, b1, w2, (long long)ldw2, b2, w3,
+                       (long long)ldw3, b3, alpha);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
 const char* vine_lp16_format(void) { return VINE_LP16_NAME; }

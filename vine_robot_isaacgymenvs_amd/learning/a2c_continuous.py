@@ -413,6 +413,11 @@ class A2CAgent:
         if (self.rollout_lp16 and net.rnn_concat_input and XW - U == 32
                 and fused.linear_elu_mfma_ok(N, net.units[0], 32)):
             f["w1p"] = torch.zeros((net.units[0], 32), device=dev, dtype=op)
+        # fp32 matrix-core kernels (vine_mlp3_elu_f32 / vine_lstm_step_f32): the default network at N % 512 == 0
+        f["f32_mfma"] = (op == torch.float32 and fused.ROLLOUT_F32_MFMA and net.rnn_concat_input and H == 256 and XW + H == 352
+                         and XW - U == 32 and U == 64 and F_in <= 32 and tuple(net.units) == (256, 128, 64) and N % 512 == 0)
+        f["wt_f32"] = torch.empty(4 * H * (XW + H), device=dev) if f["f32_mfma"] else None
+        f["w1p_f32"] = torch.zeros((net.units[0], 32), device=dev) if f["f32_mfma"] else None     # layer 1, zero-padded
         self._fast = f
 
     def _fast_op_is_fp32(self):
@@ -432,6 +437,12 @@ class A2CAgent:
             w1 = f["mlp"][0][0]
             f["w1p"][:, :w1.shape[1]].copy_(w1)
         f["bias"] = r.bias_ih_l0 + r.bias_hh_l0
+        if f["f32_mfma"]:           # [w_ih | 0 | w_hh] in the step kernel's tile order; layer-1 weight padded to 32 columns
+            w1 = f["mlp"][0][0]
+            f["w1p_f32"][:, :w1.shape[1]].copy_(w1)
+            fused._check(fused._lib().vine_lstm_tile_weights_f32(
+                f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_f32"].data_ptr(),
+                torch.cuda.current_stream(self.device).cuda_stream), "vine_lstm_tile_weights_f32")
         f["cur"] = 0
         f["xh2"][0][:, f["XW"]:].copy_(self.rnn_states[0][0])
 
@@ -452,7 +463,16 @@ class A2CAgent:
         mlp3 = (bf and fused.MLP3 and f["w1p"] is not None and f["x0_sep"] is None and n_mlp == 3 and N % 64 == 0
                 and f["U"] == 64 and f["F"] <= 32 and obs.is_contiguous() and obs.dtype == torch.float32
                 and tuple(W.shape for W, _ in f["mlp"][1:]) == ((128, 256), (64, 128)) and f["mlp"][0][0].shape[0] == 256)
-        if mlp3:
+        f32k = bool(f["f32_mfma"]) and obs.is_contiguous() and obs.dtype == torch.float32 and n_mlp == 3
+        if f32k:
+            # fp32 (the reference's rollout precision) on the matrix cores: normalisation + the three layers in one launch
+            (W1, b1), (W2, b2), (W3, b3) = f["mlp"]
+            fused._check(lib.vine_mlp3_elu_f32(N, xh.data_ptr(), xh.stride(0), obs.data_ptr(), f["F"],
+                                               rms.running_mean.data_ptr(), rms.running_var.data_ptr(), float(rms.epsilon),
+                                               5.0, f["w1p_f32"].data_ptr(), 32, b1.data_ptr(), 256, W2.data_ptr(),
+                                               W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(), W3.stride(0), b3.data_ptr(),
+                                               64, 1.0, st), "vine_mlp3_elu_f32")
+        elif mlp3:
             # observation normalisation and the whole MLP in ONE launch: the kernel normalises the raw observations
             # itself, writes them (bf16, zero-padded) into the LSTM operand's observation block and carries the
             # activations through the three layers in registers (the intermediate activations are not needed here)
@@ -463,12 +483,12 @@ class A2CAgent:
                                                 W2.data_ptr(), W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(), W3.stride(0),
                                                 b3.data_ptr(), 64, 1.0, None, None, xh.data_ptr(), xh.stride(0), st),
                          "vine_mlp3_elu_mfma")
-        else:
+        elif not f32k:
             fused._check(lib.vine_normalize_obs(N, f["F"], obs.data_ptr(), rms.running_mean.data_ptr(),
                                                 rms.running_var.data_ptr(), float(rms.epsilon), 5.0, x0.data_ptr(),
                                                 x0.stride(0), bf, st), "vine_normalize_obs")
         x = x0
-        for i, (W, b) in enumerate(f["mlp"] if not mlp3 else ()):
+        for i, (W, b) in enumerate(f["mlp"] if not (mlp3 or f32k) else ()):
             out = xh if i == n_mlp - 1 else f["acts"][i]
             if i == 0 and f["w1p"] is not None:
                 fused._check(lib.vine_linear_elu_mfma(N, W.shape[0], 32, xh.data_ptr() + 2 * f["U"], xh.stride(0),
@@ -486,7 +506,13 @@ class A2CAgent:
         h32, c = self.rnn_states[0][0], self.rnn_states[1][0]
         h_out, c_out = (h32, c) if commit else (f["h_tmp"], f["c_tmp"])
         Kx = XW + H
-        if bf and N % 64 == 0 and Kx in (128, 256, 288, 320, 352, 384, 512) and H % 16 == 0:
+        if f32k:
+            # gate GEMM over [x | h] + the cell update, fp32 on the matrix cores
+            fused._check(lib.vine_lstm_step_f32(N, H, Kx, xh.data_ptr(), xh.stride(0), f["wt_f32"].data_ptr(),
+                                                f["bias"].data_ptr(), c.data_ptr(), h_out.data_ptr(), H, c_out.data_ptr(),
+                                                hp_ptr, xh_next.stride(0), st), "vine_lstm_step_f32")
+            gates = None
+        elif bf and N % 64 == 0 and Kx in (128, 256, 288, 320, 352, 384, 512) and H % 16 == 0:
             # gate GEMM over [x | h] fused with the pointwise update on the matrix cores
             fused._check(lib.vine_lstm_step_mfma(
                 N, H, Kx, xh.data_ptr(), xh.stride(0), None, 0, 0, f["wcat"].data_ptr(), f["wcat"].stride(0), None, 4 * H,

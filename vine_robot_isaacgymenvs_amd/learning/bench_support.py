@@ -168,16 +168,25 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         dist.all_gather(gathered, chk)
         in_sync = all(bool(torch.equal(g, gathered[0])) for g in gathered)
     frames = agent.horizon_length * agent.num_actors
-    precision = ("bf16 GEMM operands and backward-only saved activations (gates, saved cell states, dG, dh), f32 "
-                 "accumulate/recurrent state/heads/loss/optimiser (mixed_precision: True, the reference YAML's value)"
-                 if agent.fused_mixed else
-                 "torch autocast %s" % conf.get("mixed_precision_dtype") if agent.mixed_precision else "f32")
-    other = None
-    if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
-        # the same PPO iteration with the update in the OTHER precision (fp32 <-> bf16 operands), same env, same
-        # process: reported beside the headline so that both numbers are always visible
+    def describe(a):
+        lp = {torch.float16: "fp16", torch.bfloat16: "bf16"}.get(a.amp_dtype, "?")
+        if a.fused_mixed:
+            upd = ("update: %s GEMM operands and backward-only saved activations (gates, saved cell states, dG, dh), f32 "
+                   "accumulate / recurrent state / heads / loss / optimiser%s (mixed_precision: True = the reference YAML's "
+                   "value, PY:53)" % (lp, ", device-side GradScaler loss scaling" if a.optimizer.amp_state is not None else ""))
+        elif a.mixed_precision:
+            upd = "update: torch autocast %s" % lp
+        else:
+            upd = "update: f32"
+        roll = ("rollout inference: %s GEMM operands" % lp) if getattr(a, "rollout_lp16", False) else \
+               "rollout inference: f32 (the reference's; fp32 matrix-core kernels)"
+        return upd + "; " + roll
+
+    precision = describe(agent)
+
+    def rerun(**over):
         conf2 = dict(conf)
-        conf2["mixed_precision"] = not agent.fused_mixed
+        conf2.update(over)
         params2 = dict(params)
         params2["config"] = conf2
         agent2 = A2CAgent("bench2", params2, vec_env=env)
@@ -194,9 +203,17 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
             u2 += u
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t2
-        other = {"update_precision": "bf16 GEMM operands, f32 accumulate/state" if agent2.fused_mixed else "f32",
-                 "value": frames * steps / e2, "unit": "env-steps/s", "ppo_iters_per_sec": steps / e2,
-                 "rollout_ms": p2 / steps * 1e3, "update_ms": u2 / steps * 1e3}
+        return {"update_precision": describe(agent2), "value": frames * steps / e2, "unit": "env-steps/s",
+                "ppo_iters_per_sec": steps / e2, "rollout_ms": p2 / steps * 1e3, "update_ms": u2 / steps * 1e3}
+
+    other = lp16_rollout = None
+    if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
+        # the same PPO iteration in the OTHER update precision (fp32 <-> 16-bit operands), and -- an extra, NARROWER than the
+        # reference's fp32 rollout -- with 16-bit GEMM operands in the rollout inference as well (the round-2 configuration);
+        # same env, same process: reported beside the headline so that all of them are always visible
+        other = rerun(mixed_precision=not agent.fused_mixed)
+        if agent.fused_mixed and not agent.rollout_lp16:
+            lp16_rollout = rerun(rollout_precision="lp16")
     ppo_kernels = None
     if world == 1 and agent.fused_mixed and not getattr(args, "no_secondary", False):
         try:
@@ -207,6 +224,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         "update_precision": precision,
         "ppo_kernel_rooflines": ppo_kernels,
         "other_precision": other,
+        "extra_lp16_rollout": lp16_rollout,
         "replicas_in_sync": in_sync,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
                      "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},
