@@ -56,6 +56,11 @@ def parse_args():
     p.add_argument("--override", action="append", default=[],
                    help="extra Hydra-style override (repeatable), applied last, e.g. --override task.env.CREATE_SHELF=True: "
                         "profiling of the other task configurations; the default line never passes any")
+    p.add_argument("--minibatch-size", type=int, default=None, help="ppo mode: override train.params.config.minibatch_size")
+    p.add_argument("--force-multi-gpu-path", action="store_true",
+                   help="ppo mode on ONE GPU: run the multi-rank code path (multi_gpu=True, world size 1: two graph replays "
+                        "per optimiser step with the eager RCCL all-reduce between them) -- the per-rank cost of a shard, "
+                        "used by scripts/scaling_projection.py; never part of the default line")
     p.add_argument("--no-graph", action="store_true", help="ppo mode: eager rollout instead of hipGraph replay")
     p.add_argument("--amp", choices=["fp16", "bf16", "off"], default=None,
                    help="ppo mode: update precision: off = fp32; fp16 (the packaged default, mixed_precision: True as in the "
@@ -76,6 +81,8 @@ def make_env(args, rank, device_index, world=1, extra_overrides=()):
           "sim_device=cuda:%d" % device_index,
           "rl_device=cuda:%d" % device_index, "multi_gpu=%s" % (args.gpus > 1)]
     cfg = load_config(overrides=ov + list(extra_overrides) + list(getattr(args, "override", [])))
+    if getattr(args, "minibatch_size", None):
+        cfg["train"]["params"]["config"]["minibatch_size"] = int(args.minibatch_size)
     if strong:
         # one batch of --num-envs envs cut into W shards: same seed everywhere, the RNG keyed by the global env id, and
         # the global minibatch (PY:80: 32768 samples) split evenly so that the optimiser takes the same number of steps
@@ -357,6 +364,11 @@ def main():
     if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.force_multi_gpu_path and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK=str(local_rank))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
@@ -447,7 +459,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds, mode, cfg)
         print(json.dumps(out), file=real_stdout, flush=True)
     env.close()
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 

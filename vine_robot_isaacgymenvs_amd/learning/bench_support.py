@@ -99,7 +99,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     conf = params["config"]
     conf["device"] = str(env.device)
     conf["device_pinned"] = True          # bench.py already chose the device of this rank
-    conf["multi_gpu"] = world > 1
+    conf["multi_gpu"] = world > 1 or bool(getattr(args, "force_multi_gpu_path", False))
     conf["write_files"] = False
     conf["print_stats"] = False
     conf["use_graphs"] = not args.no_graph
