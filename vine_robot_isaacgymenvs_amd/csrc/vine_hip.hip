@@ -256,85 +256,96 @@ __device__ __forceinline__ void substep(const DevParams& P, Dyn& s, const float 
 #define LINK_Y0 (-0.0381f)
 #define LINK_Y1 0.0719f
 #define LINK_REACH 0.078f   // lateral half-extent 0.0719 + link_0's 5.75 mm axial overhang beyond its joints, rounded up
-__device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s, float shelf_y, float shelf_z,
-                                               float (&qa)[ND]) {
+// One link against the shelf: the link's joint position (py, pz) and velocity (pvy, pvz), sin / cos of its world angle,
+// its rate, the axial extent [z0, z1] of its rectangle.  Adds the force on the link (fy, fz), its moment about the
+// link's joint (mom) and the reaction on the `shelf_link` strip (sfy, sfz); returns whether any narrow phase ran.
+__device__ __forceinline__ bool shelf_link_contact(const DevParams& P, float z0, float z1, float py, float pz, float pvy,
+                                                   float pvz, float sp, float cp, float om, float shelf_y, float shelf_z,
+                                                   float& fy_tot, float& fz_tot, float& mom, float& strip_fy,
+                                                   float& strip_fz) {
     const float board[2][4] = {{-0.001f, 0.0f, 0.1995f, 0.005f}, {0.0f, 0.2f, 0.2f, 0.005f}};
-    float strip_fy = 0.0f, strip_fz = 0.0f;
-    float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
-    float Fy[NL], Fz[NL], ny_[NL], nz_[NL];
-    bool any = false;
+    const float dy = -sp, dz = cp, ly = cp, lz = sp;     // link axis d, lateral l; n = d(d)/d(phi) = (-cp, -sp) = -l
     // every shelf shape lies at y <= shelf_y + 0.2; board A / the strip around z = shelf_z, board B around shelf_z + 0.2
     const float ycut = shelf_y + 0.2f;
     const float a_lo = shelf_z - 0.005f, a_hi = shelf_z + 0.005f, b_lo = shelf_z + 0.195f, b_hi = shelf_z + 0.205f;
+    const float qy = py + P.L * dy, qz = pz + P.L * dz;  // the next joint
+    const float ylo = fminf(py, qy) - LINK_REACH;
+    const float zlo = fminf(pz, qz) - LINK_REACH, zhi = fmaxf(pz, qz) + LINK_REACH;
+    const bool near_a = ylo < ycut && zlo < a_hi && zhi > a_lo;      // board A and the strip's corners
+    const bool near_b = ylo < ycut && zlo < b_hi && zhi > b_lo;
+    // one block per board (a link near both at once is rare: they are 0.2 m apart), so a wave pays one branch per
+    // (link, board) and runs only the blocks some lane of it needs
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        const float sp = s.sn[k], cp = s.cs[k];              // sin/cos of the world link angle
-        const float dy = -sp, dz = cp, ly = cp, lz = sp;     // link axis d, lateral l; n = d(d)/d(phi) = (-cp, -sp) = -l
-        const float om = s.w[k];
-        const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
-        float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
-        ny_[k] = -cp; nz_[k] = -sp;
-        const float qy = py + P.L * dy, qz = pz + P.L * dz;  // the next joint
-        const float ylo = fminf(py, qy) - LINK_REACH;
-        const float zlo = fminf(pz, qz) - LINK_REACH, zhi = fmaxf(pz, qz) + LINK_REACH;
-        const bool near_a = ylo < ycut && zlo < a_hi && zhi > a_lo;      // board A and the strip's corners
-        const bool near_b = ylo < ycut && zlo < b_hi && zhi > b_lo;
-        // one block per board (a link near both at once is rare: they are 0.2 m apart), so a wave pays one branch per
-        // (link, board) and runs only the blocks some lane of it needs
+    for (int bx = 0; bx < 2; ++bx) {
+        if (bx == 0 ? near_a : near_b) {
 #pragma unroll
-        for (int bx = 0; bx < 2; ++bx) {
-            if (bx == 0 ? near_a : near_b) {
-                any = true;
+            for (int e = 0; e < 2; ++e) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const float yl = e ? LINK_Y1 : LINK_Y0;
-                        const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
-                        const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
-                        const float wy = py + ry, wz = pz + rz;
-                        const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
-                        const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
-                        if (ey > 0.0f && ez > 0.0f) {
-                            const float vy = pvy - om * rz, vz = pvz + om * ry;
-                            float fy = 0.0f, fz = 0.0f;
-                            if (ey < ez) {
-                                const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
-                                fy = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vy, 0.0f);
-                            } else {
-                                const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
-                                fz = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vz, 0.0f);
-                            }
-                            fy_tot += fy; fz_tot += fz;
-                            mom += -rz * fy + ry * fz;          // F . (z n_k + y d_k) = r x F about joint k
+                for (int t = 0; t < 3; ++t) {
+                    const float yl = e ? LINK_Y1 : LINK_Y0;
+                    const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+                    const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                    const float wy = py + ry, wz = pz + rz;
+                    const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
+                    const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
+                    if (ey > 0.0f && ez > 0.0f) {
+                        const float vy = pvy - om * rz, vz = pvz + om * ry;
+                        float fy = 0.0f, fz = 0.0f;
+                        if (ey < ez) {
+                            const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                            fy = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vy, 0.0f);
+                        } else {
+                            const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                            fz = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vz, 0.0f);
                         }
+                        fy_tot += fy; fz_tot += fz;
+                        mom += -rz * fy + ry * fz;          // F . (z n_k + y d_k) = r x F about joint k
                     }
                 }
             }
         }
-        if (near_a) {
+    }
+    if (near_a) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float wy = shelf_y + 0.2f, wz = shelf_z + (e ? 0.005f : -0.005f);
-                const float ry = wy - py, rz = wz - pz;
-                const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
-                if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
-                    float dep = zl - z0, ny = -dy, nz = -dz;
-                    if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
-                    if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
-                    if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
-                    const float vy = pvy - om * rz, vz = pvz + om * ry;
-                    const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
-                    strip_fy += f * ny; strip_fz += f * nz;
-                    const float fy = -f * ny, fz = -f * nz;
-                    fy_tot += fy; fz_tot += fz;
-                    mom += -rz * fy + ry * fz;
-                }
+        for (int e = 0; e < 2; ++e) {
+            const float wy = shelf_y + 0.2f, wz = shelf_z + (e ? 0.005f : -0.005f);
+            const float ry = wy - py, rz = wz - pz;
+            const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+            if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                float dep = zl - z0, ny = -dy, nz = -dz;
+                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                strip_fy += f * ny; strip_fz += f * nz;
+                const float fy = -f * ny, fz = -f * nz;
+                fy_tot += fy; fz_tot += fz;
+                mom += -rz * fy + ry * fz;
             }
         }
+    }
+    return near_a || near_b;
+}
+
+__device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s, float shelf_y, float shelf_z,
+                                               float (&qa)[ND]) {
+    float strip_fy = 0.0f, strip_fz = 0.0f;
+    float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
+    float Fy[NL], Fz[NL], ny_[NL], nz_[NL];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const float sp = s.sn[k], cp = s.cs[k];              // sin/cos of the world link angle
+        const float om = s.w[k];
+        const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
+        float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
+        ny_[k] = -cp; nz_[k] = -sp;
+        any |= shelf_link_contact(P, z0, z1, py, pz, pvy, pvz, sp, cp, om, shelf_y, shelf_z, fy_tot, fz_tot, mom, strip_fy,
+                                  strip_fz);
         Fy[k] = fy_tot; Fz[k] = fz_tot;
         qa[k + 1] = mom;
-        py = qy; pz = qz;
+        py += P.L * (-sp); pz += P.L * cp;
         pvy += P.L * om * (-cp); pvz += P.L * om * (-sp);
     }
     if (!any) {          // (qa[1..5] are zero already)
@@ -362,101 +373,109 @@ __device__ __forceinline__ float shelf_contact(const DevParams& P, const Dyn& s,
 #define PIPE_WALL 0.00525f
 #define PIPE_OUTER 0.1554f
 #define PIPE_CULL_EPS 1.0e-5f      // the box tests use other (equivalent) expressions than the narrow phase: rounding margin
-__device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, float pipe_y, float pipe_z, float ct,
-                                             float st, float (&qa)[ND]) {
-    const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
-    float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
-    float Fy[NL], Fz[NL], ny_[NL], nz_[NL], mom_[NL];
-    bool any = false;
-    // centre of the tube's cross-section box in the world, radius of its bounding circle + the link's (half-length 0.05,
-    // lateral reach 0.0719 about the axis midpoint -> 0.0876)
+struct PipePose { float y, z, ct, st, ccy, ccz; };      // origin, cos / sin of the tube's axis angle, centre of its box
+__device__ __forceinline__ PipePose pipe_pose(float pipe_y, float pipe_z, float ct, float st) {
     const float hcy = 0.5f * PIPE_OUTER, hcz = 0.5f * PIPE_LEN;
-    const float ccy = pipe_y + hcy * ct - hcz * st, ccz = pipe_z + hcy * st + hcz * ct;
+    return PipePose{pipe_y, pipe_z, ct, st, pipe_y + hcy * ct - hcz * st, pipe_z + hcy * st + hcz * ct};
+}
+__device__ __forceinline__ bool pipe_link_contact(const DevParams& P, float z0, float z1, float py, float pz, float pvy,
+                                                  float pvz, float sp, float cp, float om, const PipePose& T, float& fy_tot,
+                                                  float& fz_tot, float& mom) {
+    const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
+    const float pipe_y = T.y, pipe_z = T.z, ct = T.ct, st = T.st;
+    const float dy = -sp, dz = cp, ly = cp, lz = sp;
+    // radius of the tube's bounding circle + the link's (half-length 0.05, lateral reach 0.0719 about the axis midpoint)
     const float rsum = 0.18748f + 0.0877f + 1.0e-4f;       // hypot(0.0777, 0.170625) + hypot(0.05, 0.0719)
+    const float my = py + 0.04425f * dy - T.ccy, mz = pz + 0.04425f * dz - T.ccz;     // axis midpoint - tube centre
+    if (!(my * my + mz * mz < rsum * rsum)) return false;
+    // level 2: the rectangle's box in the pipe frame.  Local axis / lateral directions, local joint position.
+    const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;          // d in the pipe frame; l = (dlz, -dly)
+    const float gy0 = py - pipe_y, gz0 = pz - pipe_z;
+    const float jy = gy0 * ct + gz0 * st, jz = -gy0 * st + gz0 * ct;
+    const float ay0 = z0 * dly, ay1 = z1 * dly, by0 = LINK_Y0 * dlz, by1 = LINK_Y1 * dlz;
+    const float az0 = z0 * dlz, az1 = z1 * dlz, bz0 = LINK_Y0 * -dly, bz1 = LINK_Y1 * -dly;
+    const float ymin = jy + fminf(ay0, ay1) + fminf(by0, by1) - PIPE_CULL_EPS;
+    const float ymax = jy + fmaxf(ay0, ay1) + fmaxf(by0, by1) + PIPE_CULL_EPS;
+    const float zmin = jz + fminf(az0, az1) + fminf(bz0, bz1) - PIPE_CULL_EPS;
+    const float zmax = jz + fmaxf(az0, az1) + fmaxf(bz0, bz1) + PIPE_CULL_EPS;
+    const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
+    const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
+    const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
+    if (!(near0 || near1)) return false;
 #pragma unroll
-    for (int k = 0; k < NL; ++k) {
-        const float sp = s.sn[k], cp = s.cs[k];
-        const float dy = -sp, dz = cp, ly = cp, lz = sp;
-        const float om = s.w[k];
-        const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
-        float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
-        ny_[k] = -cp; nz_[k] = -sp;
-        const float my = py + 0.04425f * dy - ccy, mz = pz + 0.04425f * dz - ccz;     // axis midpoint - tube centre
-        if (my * my + mz * mz < rsum * rsum) {
-            // level 2: the rectangle's box in the pipe frame.  Local axis / lateral directions, local joint position.
-            const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;          // d in the pipe frame; l = (dlz, -dly)
-            const float gy0 = py - pipe_y, gz0 = pz - pipe_z;
-            const float jy = gy0 * ct + gz0 * st, jz = -gy0 * st + gz0 * ct;
-            const float ay0 = z0 * dly, ay1 = z1 * dly, by0 = LINK_Y0 * dlz, by1 = LINK_Y1 * dlz;
-            const float az0 = z0 * dlz, az1 = z1 * dlz, bz0 = LINK_Y0 * -dly, bz1 = LINK_Y1 * -dly;
-            const float ymin = jy + fminf(ay0, ay1) + fminf(by0, by1) - PIPE_CULL_EPS;
-            const float ymax = jy + fmaxf(ay0, ay1) + fmaxf(by0, by1) + PIPE_CULL_EPS;
-            const float zmin = jz + fminf(az0, az1) + fminf(bz0, bz1) - PIPE_CULL_EPS;
-            const float zmax = jz + fmaxf(az0, az1) + fmaxf(bz0, bz1) + PIPE_CULL_EPS;
-            const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
-            const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
-            const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
-            if (near0 || near1) {
-                any = true;
+    for (int e = 0; e < 2; ++e) {
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+        for (int t = 0; t < 3; ++t) {
+            const float yl = e ? LINK_Y1 : LINK_Y0;
+            const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+            const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+            const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
+            const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-                        const float yl = e ? LINK_Y1 : LINK_Y0;
-                        const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
-                        const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
-                        const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
-                        const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
-#pragma unroll
-                        for (int w = 0; w < 2; ++w) {
-                            if (w == 0 ? near0 : near1) {
-                                const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
-                                const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
-                                if (ey > 0.0f && ez > 0.0f) {
-                                    const float vy = pvy - om * rz, vz = pvz + om * ry;
-                                    const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
-                                    float fyl = 0.0f, fzl = 0.0f;
-                                    if (ey < ez) {
-                                        const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
-                                        fyl = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vyl, 0.0f);
-                                    } else {
-                                        const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
-                                        fzl = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vzl, 0.0f);
-                                    }
-                                    const float fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;
-                                    fy_tot += fy; fz_tot += fz;
-                                    mom += -rz * fy + ry * fz;
-                                }
-                            }
+            for (int w = 0; w < 2; ++w) {
+                if (w == 0 ? near0 : near1) {
+                    const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
+                    const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
+                    if (ey > 0.0f && ez > 0.0f) {
+                        const float vy = pvy - om * rz, vz = pvz + om * ry;
+                        const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
+                        float fyl = 0.0f, fzl = 0.0f;
+                        if (ey < ez) {
+                            const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                            fyl = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vyl, 0.0f);
+                        } else {
+                            const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                            fzl = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vzl, 0.0f);
                         }
-                    }
-                }
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    if (w == 0 ? near0 : near1) {
-#pragma unroll
-                        for (int cidx = 0; cidx < 4; ++cidx) {
-                            const float pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0.0f), pzl = (cidx & 2) ? PIPE_LEN : 0.0f;
-                            const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
-                            const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
-                            if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
-                                float dep = zl - z0, ny = -dy, nz = -dz;
-                                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
-                                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
-                                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
-                                const float vy = pvy - om * rz, vz = pvz + om * ry;
-                                const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
-                                const float fy = -f * ny, fz = -f * nz;
-                                fy_tot += fy; fz_tot += fz;
-                                mom += -rz * fy + ry * fz;
-                            }
-                        }
+                        const float fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;
+                        fy_tot += fy; fz_tot += fz;
+                        mom += -rz * fy + ry * fz;
                     }
                 }
             }
         }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        if (w == 0 ? near0 : near1) {
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const float pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0.0f), pzl = (cidx & 2) ? PIPE_LEN : 0.0f;
+                const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
+                const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+                if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                    float dep = zl - z0, ny = -dy, nz = -dz;
+                    if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                    if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                    if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                    const float vy = pvy - om * rz, vz = pvz + om * ry;
+                    const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                    const float fy = -f * ny, fz = -f * nz;
+                    fy_tot += fy; fz_tot += fz;
+                    mom += -rz * fy + ry * fz;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, float pipe_y, float pipe_z, float ct,
+                                             float st, float (&qa)[ND]) {
+    float py = s.y, pz = P.z1, pvy = s.vy, pvz = 0.0f;
+    float Fy[NL], Fz[NL], ny_[NL], nz_[NL], mom_[NL];
+    bool any = false;
+    const PipePose T = pipe_pose(pipe_y, pipe_z, ct, st);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const float sp = s.sn[k], cp = s.cs[k];
+        const float om = s.w[k];
+        const float z0 = (k == 0) ? -0.00575f : 0.0f, z1 = (k == 0) ? 0.09425f : P.L;
+        float fy_tot = 0.0f, fz_tot = 0.0f, mom = 0.0f;
+        ny_[k] = -cp; nz_[k] = -sp;
+        any |= pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sp, cp, om, T, fy_tot, fz_tot, mom);
         Fy[k] = fy_tot; Fz[k] = fz_tot; mom_[k] = mom;
-        py += P.L * dy; pz += P.L * dz;
+        py += P.L * (-sp); pz += P.L * cp;
         pvy += P.L * om * (-cp); pvz += P.L * om * (-sp);
     }
     if (!any) return;        // nothing to add
@@ -960,7 +979,13 @@ __device__ __forceinline__ unsigned qbcast_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, true);
 }
 
-template <int OBS_TYPE, bool RANDOMIZE>
+// inclusive prefix sum over the quad (lane t: v_0 + ... + v_t): two DPP steps
+__device__ __forceinline__ float quad_scan_incl(float v, int t) {
+    const float s = v + pick(t > 0, qprev(v), 0.0f);
+    return s + pick(t >= 2, qperm<0x4E>(s), 0.0f);
+}
+
+template <int OBS_TYPE, bool RANDOMIZE, int OBST>   // OBST bit 0: shelf, bit 1: pipe
 __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, float* __restrict__ st,
                                                              const float* __restrict__ actions, float* __restrict__ obs,
                                                              float* __restrict__ rew, long long* __restrict__ reset,
@@ -971,6 +996,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                                                              unsigned long long* __restrict__ counters) {
     static_assert(OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || OBS_TYPE == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, "");
     constexpr int NOBS = OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ? 28 : 18;
+    constexpr bool SHELF = (OBST & 1) != 0, PIPE = (OBST & 2) != 0, CONTACT = OBST != 0;
     const int n = P.n;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gid >> 2, t = threadIdx.x & 3;
@@ -1042,6 +1068,16 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         float prev_u_rail = u_rail;
         float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
         float rail_force = 0.0f;
+        // obstacles (replicated on the quad): the shelf's force on its front strip as the last simulate left it, the
+        // obstacle poses of THIS step (a reset below moves them for the next one)
+        float contact = SHELF ? ST(VF_CONTACT) : 0.0f, contact_sum = 0.0f;
+        const float shelf_y = SHELF ? ST(VF_SHELF_Y) : 0.0f, shelf_z = SHELF ? ST(VF_SHELF_Z) : 0.0f;
+        PipePose pipeT = PipePose{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f};
+        if (PIPE) {
+            float pst, pct;
+            sincosf(ST(VF_OBJ_ANGLE) + 1.5707963267948966f, &pst, &pct);
+            pipeT = pipe_pose(ST(VF_PIPE_Y), ST(VF_PIPE_Z), pct, pst);
+        }
         const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
         const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
         // absolute angles / rates: inclusive prefix sums over the quad, then link 4 on top of lane 3's
@@ -1144,7 +1180,44 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             const float adiag4 = a44 + hc4;
             const float a00 = P.mtot + hc0;
             const float inv_a00 = 1.0f / a00;
+            if (SHELF) contact_sum += contact;            // vec_task.py:348-351: force left by the previous simulate
+            float csum = 0.0f;
             for (int ss = 0; ss < P.substeps; ++ss) {
+                // ---- obstacle contacts: lane t evaluates link t (broad phase + narrow phase of shelf_link_contact /
+                // pipe_link_contact, the same code as the one-lane kernel), link 4 is evaluated on every lane; joint
+                // positions / velocities are prefix sums over the quad, the forces on the links beyond link t a suffix sum
+                float Qt = 0.0f, Q4 = 0.0f, Qc = 0.0f;
+                if (CONTACT) {
+                    const float L = P.L;
+                    const float dyo = -sn, dzo = cs, vyo = -(w * cs), vzo = -(w * sn);
+                    const float iy = quad_scan_incl(dyo, t), iz = quad_scan_incl(dzo, t);
+                    const float ivy = quad_scan_incl(vyo, t), ivz = quad_scan_incl(vzo, t);
+                    const float py = y + L * (iy - dyo), pz = P.z1 + L * (iz - dzo);
+                    const float pvy = vy + L * (ivy - vyo), pvz = L * (ivz - vzo);
+                    const float p4y = y + L * qbcast<3>(iy), p4z = P.z1 + L * qbcast<3>(iz);
+                    const float pv4y = vy + L * qbcast<3>(ivy), pv4z = L * qbcast<3>(ivz);
+                    const float z0 = t == 0 ? -0.00575f : 0.0f, z1 = t == 0 ? 0.09425f : L;
+                    float fy = 0.0f, fz = 0.0f, mom = 0.0f, f4y = 0.0f, f4z = 0.0f, mom4 = 0.0f;
+                    float sfy = 0.0f, sfz = 0.0f, s4y = 0.0f, s4z = 0.0f;
+                    if (SHELF) {
+                        shelf_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, shelf_y, shelf_z, fy, fz, mom, sfy, sfz);
+                        shelf_link_contact(P, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, shelf_y, shelf_z, f4y, f4z, mom4, s4y, s4z);
+                    }
+                    if (PIPE) {
+                        pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom);
+                        pipe_link_contact(P, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, pipeT, f4y, f4z, mom4);
+                    }
+                    if (SHELF) {
+                        const float ty_ = quad_sum(sfy) + s4y, tz_ = quad_sum(sfz) + s4z;
+                        csum += sqrtf(ty_ * ty_ + tz_ * tz_);
+                    }
+                    const float ify = quad_scan_incl(fy, t), ifz = quad_scan_incl(fz, t);
+                    const float toty = qbcast<3>(ify), totz = qbcast<3>(ifz);
+                    const float sy = (toty - ify) + f4y, sz = (totz - ifz) + f4z;      // forces on the links beyond link t
+                    Qt = mom + L * (-cs * sy - sn * sz);                               // lever L n_t, n_t = (-cos, -sin)
+                    Q4 = mom4;
+                    Qc = toty + f4y;
+                }
                 const float w2 = w * w, w24 = w4 * w4;
                 // right-hand sides
                 const float dwm = w - pick(t > 0, qprev(w), 0.0f);
@@ -1153,7 +1226,8 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 const float Tn = pick(t == 3, T4, qnext(T));
                 float r = T - Tn + gb_t * sn;
                 float r4 = T4 + gb4 * sn4;
-                const float rc = eff0 - cj0 * vy - quad_sum(b_t * sn * w2) - b4 * sn4 * w24;
+                float rc = eff0 - cj0 * vy - quad_sum(b_t * sn * w2) - b4 * sn4 * w24;
+                if (CONTACT) { r += Qt; r4 += Q4; rc += Qc; }
                 // cart column
                 const float Ac = nb_t * cs, A4c = -b4 * cs4;
                 // rows of the 4x4 block (absolute column index k), link-4 column
@@ -1230,6 +1304,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                     cs4 = fmaf(c_old, cd, -(s_old * sd));
                 }
             }
+            if (SHELF) contact = csum / (float)P.substeps;
             cart_y = y;
             cart_vy = vy;
         };
@@ -1284,7 +1359,26 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 qn1_4[0] = qn1_4[1] = qn1_4[2] = qn1_4[3] = 0.0f; qn5 = 0.0f; qn0 = 0.0f;
             }
             if (!(P.flags & VINE_FLAG_RANDOMIZE_TARGETS)) { ty = P.ty_max; tz = P.tz_fixed; }
-            (void)depth; (void)pdepth;         // obstacle poses: this kernel runs without obstacles
+            (void)depth; (void)pdepth;
+            if (SHELF && t == 0) {             // obstacle poses of the new episode (reset_env's arithmetic, V5:818-885)
+                ST(VF_SHELF_Y) = ty + (-0.2f + depth);
+                ST(VF_SHELF_Z) = tz - 0.01f;
+                ST(VF_OBJ_DEPTH) = depth;
+            }
+            if (PIPE) {
+                const float R = 0.0735f;             // PIPE_RADIUS = 0.07 * 1.05 (V5:88)
+                const float ez = 1.0f - tz;
+                const float deg = ((13199.0f * ez - 12276.0f) * ez + 4045.0f) * ez - 447.0f;
+                const float tp = deg * 0.017453292519943295f;
+                float stp, ctp;
+                sincosf(tp, &stp, &ctp);
+                if (t == 0) {
+                    ST(VF_PIPE_Y) = ty + pdepth * ctp + R * stp;
+                    ST(VF_PIPE_Z) = tz + pdepth * stp - R * ctp;
+                    ST(VF_OBJ_DEPTH) = pdepth;
+                    ST(VF_OBJ_ANGLE) = tp;
+                }
+            }
             rst = 0;
             prog = 0;
             q_own = sel4(t, qn1_4[0], qn1_4[1], qn1_4[2], qn1_4[3]);
@@ -1394,6 +1488,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         const bool limit_hit = (cart_y > P.soft_limit) || (cart_y < -P.soft_limit);
         const bool tip_limit_hit = tip_y < ty;
         const float vnorm = sqrtf(tip_vy * tip_vy + tip_vz * tip_vz);
+        const float cmean = SHELF ? contact_sum / (float)P.cfi : 0.0f;      // V5:1242-1248
         float rm[VINE_NUM_REWARDS];
         rm[0] = -dist;
         rm[1] = -1.0f;
@@ -1407,7 +1502,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         rm[9] = limit_hit ? -100.0f : 0.0f;
         rm[10] = -fabsf(cart_y);
         rm[11] = tip_limit_hit ? -100.0f : 0.0f;
-        rm[12] = -0.0f;
+        rm[12] = -((cmean > 0.0f) ? cmean : 0.0f);
         float total = 0.0f;
 #pragma unroll
         for (int i = 0; i < VINE_NUM_REWARDS; ++i) total += rm[i] * P.rw[i];
@@ -1416,6 +1511,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         if (reached && (P.flags & VINE_FLAG_USE_TARGET_REACHED_RESET)) rst = 1;
         if (tip_limit_hit && (P.flags & VINE_FLAG_USE_TIP_LIMIT_HIT_RESET)) rst = 1;
         if (limit_hit) rst = 1;
+        if (SHELF && cmean > 0.0f && (P.flags & VINE_FLAG_USE_NONZERO_CONTACT_FORCE_RESET)) rst = 1;
         const unsigned char to = (prog >= (long long)P.max_len - 1) && (rst != 0);
         if (t == 0) {
             rew[e] = total;
@@ -1433,11 +1529,13 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             ST(VF_SMOOTHED_U) = smoothed;
             ST(VF_PREV_CART_VEL) = pcv; ST(VF_PREV_CART_VEL_ERR) = pce;
             ST(VF_AGG_REW) = agg;
+            if (SHELF) ST(VF_CONTACT) = contact;
             if (introspect) {
                 ST(VF_TIP_VY) = tip_vy; ST(VF_TIP_VZ) = tip_vz;
                 ST(VF_PREV_TIP_Y) = prev_tip_y; ST(VF_PREV_TIP_Z) = prev_tip_z;
                 ST(VF_U_FPAM) = u_fpam; ST(VF_U_RAIL) = u_rail; ST(VF_PREV_U_RAIL) = prev_u_rail;
                 ST(VF_RAIL_FORCE) = rail_force;
+                if (SHELF) ST(VF_CONTACT_MEAN) = cmean;
             }
         }
     }
@@ -1879,7 +1977,8 @@ void vine_destroy(VineHandle* h) {
 // 32.5 -> 30.2 us, 32768 envs 35.3 -> 43.4 us: up to 16384 envs the quad kernel, beyond one lane per env.
 static bool use_quad_kernel(const VineHandle* h) {
     const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
-    const bool quad_ok = obst == 0 && h->P.cfi == 4 && (h->P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) && h->P.kq == 0.0f &&
+    (void)obst;      // (obstacles are covered since round 3: lane t evaluates link t's contacts)
+    const bool quad_ok = h->P.cfi == 4 && (h->P.flags & VINE_FLAG_IMPLICIT_JOINT_DAMPING) && h->P.kq == 0.0f &&
                          h->P.cad == 0.0f && (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ||
                                               h->P.obs_type == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO);
     return quad_ok && (h->step_kernel == 2 || (h->step_kernel == 0 && h->P.n <= 16384));
@@ -1907,10 +2006,17 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     }
     if (use_quad_kernel(h)) {
         const int qblocks = (int)(((long long)h->P.n * 4 + 255) / 256);
-#define LAUNCH_QUAD(OT, RND)                                                                                            \
-    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND>), dim3(qblocks), dim3(256), 0, s, h->P, h->state, actions, obs, rew, \
+#define LAUNCH_QUAD_O(OT, RND, OB)                                                                                         \
+    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB>), dim3(qblocks), dim3(256), 0, s, h->P, h->state, actions, obs, rew, \
                        (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,              \
                        h->reset_values, h->counters)
+#define LAUNCH_QUAD(OT, RND)                        \
+    do {                                            \
+        if (obst == 0) LAUNCH_QUAD_O(OT, RND, 0);   \
+        else if (obst == 1) LAUNCH_QUAD_O(OT, RND, 1); \
+        else if (obst == 2) LAUNCH_QUAD_O(OT, RND, 2); \
+        else LAUNCH_QUAD_O(OT, RND, 3);             \
+    } while (0)
         if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
             if (rnd) LAUNCH_QUAD(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, true);
             else LAUNCH_QUAD(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, false);
@@ -1919,6 +2025,7 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
             else LAUNCH_QUAD(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, false);
         }
 #undef LAUNCH_QUAD
+#undef LAUNCH_QUAD_O
         HIP_TRY(hipGetLastError());
         return VINE_OK;
     }
