@@ -979,6 +979,30 @@ __device__ __forceinline__ unsigned qbcast_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, true);
 }
 
+// acc += (value of `src` on lane K of the quad) * b as ONE instruction, v_fmac_f32_dpp.  The compiler folds a DPP read into
+// v_mul / v_add / v_sub consumers by itself but not into v_fmac (it leaves a v_mov_b32_dpp in front of it: 30 of the 178
+// instructions of a substep).  A DPP read of a VGPR needs two wait states after the VALU instruction that wrote it, which the
+// compiler cannot see inside an asm statement: NOP = true puts an `s_nop 1` in front (for operands that may have been
+// produced by the instruction just before); scripts/check_dpp_hazards.py scans the generated assembly of every
+// instantiation for an unprotected read (run it after touching this kernel).
+template <int K, bool NOP>
+__device__ __forceinline__ void fmac_bcast(float& acc, float src, float b) {
+    static_assert(K >= 0 && K < 4, "lane of the quad");
+    if (K == 0) {
+        if (NOP) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+        else asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+    } else if (K == 1) {
+        if (NOP) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+        else asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+    } else if (K == 2) {
+        if (NOP) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+        else asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+    } else {
+        if (NOP) asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+        else asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(b));
+    }
+}
+
 // inclusive prefix sum over the quad (lane t: v_0 + ... + v_t): two DPP steps
 __device__ __forceinline__ float quad_scan_incl(float v, int t) {
     const float s = v + pick(t > 0, qprev(v), 0.0f);
@@ -1123,6 +1147,15 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         }
         const float h = P.hsub;
         const float gb4 = P.gb[4], b4 = P.b[4], a44 = P.a[4][4];
+        // The cart row has a constant pivot (a00 = total mass + h * DOF damping), so its elimination is folded into the
+        // CONSTANTS of the remaining 5x5 system: row t, column k becomes (a_tk - b_t b_k / a00) cos cos + a_tk sin sin.
+        const float a00 = P.mtot + h * P.damping, inv_a00 = 1.0f / a00;
+        float al_k[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) al_k[k] = a_k[k] - b_t * (P.b[k] * inv_a00);
+        const float al_4 = a_t4 - b_t * (b4 * inv_a00);
+        const float nm_t = t > 0 ? -1.0f : 0.0f;
+        const float be_t = b_t * inv_a00, be4 = b4 * inv_a00, b4sq = b4 * b4 * inv_a00;
         // ---- control_freq_inv x [actuation (V5:1028-1106), simulate]: iterations unrolled by 4 (the broadcasting lane
         // of the scaling factors is a compile-time constant), any further ones reuse the pattern
 #define VINE_QUAD_ITER(IT)                                                                                               \
@@ -1178,8 +1211,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             for (int k = 0; k < 4; ++k) nbase[k] = t == k ? hc_t + hc_n : (t == k + 1 ? -hc_t : (t == k - 1 ? -hc_n : 0.0f));
             const float nb4 = t == 3 ? -hc4 : 0.0f;
             const float adiag4 = a44 + hc4;
-            const float a00 = P.mtot + hc0;
-            const float inv_a00 = 1.0f / a00;
+            (void)hc0;
             if (SHELF) contact_sum += contact;            // vec_task.py:348-351: force left by the previous simulate
             float csum = 0.0f;
             for (int ss = 0; ss < P.substeps; ++ss) {
@@ -1218,9 +1250,14 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                     Q4 = mom4;
                     Qc = toty + f4y;
                 }
+                // Every cross-lane operand below is a DPP read with ONE consumer of VOP2 shape (v_mul / v_fmac / v_add /
+                // v_subrev with the permuted value as src0): the compiler then folds the permutation into the consumer
+                // instead of issuing a v_mov_b32_dpp in front of it (45 of the 184 instructions of the round-2 substep were
+                // such moves).  Hence the operand orders, the pre-negated factors and the products formed on the SOURCE
+                // lane (U, V) rather than on the consumer.
                 const float w2 = w * w, w24 = w4 * w4;
                 // right-hand sides
-                const float dwm = w - pick(t > 0, qprev(w), 0.0f);
+                const float dwm = fmaf(nm_t, qprev(w), w);                   // w_t - w_{t-1}  (w_{-1} = 0)
                 const float T = eff_t - cj_t * dwm;
                 const float T4 = eff4 - cj4 * (w4 - qbcast<3>(w));
                 const float Tn = pick(t == 3, T4, qnext(T));
@@ -1228,55 +1265,56 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 float r4 = T4 + gb4 * sn4;
                 float rc = eff0 - cj0 * vy - quad_sum(b_t * sn * w2) - b4 * sn4 * w24;
                 if (CONTACT) { r += Qt; r4 += Q4; rc += Qc; }
-                // cart column
-                const float Ac = nb_t * cs, A4c = -b4 * cs4;
-                // rows of the 4x4 block (absolute column index k), link-4 column
+                // centrifugal terms: sum_k a_tk sin(th_t - th_k) w_k^2 = sn_t sum_k a_tk (cs_k w_k^2) - cs_t sum_k a_tk (sn_k w_k^2)
+                const float U = cs * w2, V = sn * w2;
+                float accU = qbcast<0>(U) * as_k[0], accV = qbcast<0>(V) * as_k[0];
+                fmac_bcast<1, true>(accU, U, as_k[1]); fmac_bcast<1, false>(accV, V, as_k[1]);
+                fmac_bcast<2, false>(accU, U, as_k[2]); fmac_bcast<2, false>(accV, V, as_k[2]);
+                fmac_bcast<3, false>(accU, U, as_k[3]); fmac_bcast<3, false>(accV, V, as_k[3]);
+                r = fmaf(cs, accV, fmaf(-sn, accU, r));
+                // rows of the 4x4 block (absolute column index k) with the cart already eliminated (constants al_k), link-4 column
                 float R[4];
+                const float Ac = nb_t * cs, A4c = -b4 * cs4;
 #define VINE_QUAD_COL(KK)                                                                                \
                 {                                                                                        \
-                    const float ck = qbcast<KK>(cs), sk = qbcast<KK>(sn), w2k = qbcast<KK>(w2);          \
-                    const float cosd = fmaf(sn, sk, cs * ck), sind = fmaf(sn, ck, -(cs * sk));           \
-                    R[KK] = fmaf(a_k[KK], cosd, nbase[KK]);                                              \
-                    r = fmaf(-(as_k[KK] * sind), w2k, r);                                                \
+                    float v = qbcast<KK>(cs) * (al_k[KK] * cs);                                          \
+                    fmac_bcast<KK, false>(v, sn, a_k[KK] * sn);    /* (sn: written a substep ago) */       \
+                    R[KK] = v + nbase[KK];                                                               \
                 }
                 VINE_QUAD_COL(0) VINE_QUAD_COL(1) VINE_QUAD_COL(2) VINE_QUAD_COL(3)
 #undef VINE_QUAD_COL
-                const float cos4 = fmaf(sn, sn4, cs * cs4), sin4 = fmaf(sn, cs4, -(cs * sn4));
-                float A4 = fmaf(a_t4, cos4, nb4);
+                const float sin4 = fmaf(sn, cs4, -(cs * sn4));
+                float A4 = fmaf(al_4 * cs, cs4, fmaf(a_t4 * sn, sn4, nb4));
                 const float as4 = a_t4 * sin4;
                 r = fmaf(-as4, w24, r);
                 r4 += quad_sum(as4 * w2);
-                // eliminate the cart (constant pivot a00)
-                const float fc = Ac * inv_a00;
-                R[0] = fmaf(-fc, qbcast<0>(Ac), R[0]); R[1] = fmaf(-fc, qbcast<1>(Ac), R[1]);
-                R[2] = fmaf(-fc, qbcast<2>(Ac), R[2]); R[3] = fmaf(-fc, qbcast<3>(Ac), R[3]);
-                A4 = fmaf(-fc, A4c, A4);
-                r = fmaf(-fc, rc, r);
-                const float f4c = A4c * inv_a00;
-                const float A44 = fmaf(-f4c, A4c, adiag4);
-                r4 = fmaf(-f4c, rc, r4);
+                r = fmaf(be_t * cs, rc, r);
+                r4 = fmaf(be4 * cs4, rc, r4);
+                const float A44 = fmaf(-b4sq, cs4 * cs4, adiag4);
                 // eliminate link 4
-                const float i44 = __builtin_amdgcn_rcpf(A44);
-                const float f4 = A4 * i44;
-                R[0] = fmaf(-f4, qbcast<0>(A4), R[0]); R[1] = fmaf(-f4, qbcast<1>(A4), R[1]);
-                R[2] = fmaf(-f4, qbcast<2>(A4), R[2]); R[3] = fmaf(-f4, qbcast<3>(A4), R[3]);
-                r = fmaf(-f4, r4, r);
+                const float ni44 = __builtin_amdgcn_rcpf(-A44);            // -1 / A44
+                const float nf4 = A4 * ni44;
+                fmac_bcast<0, true>(R[0], A4, nf4); fmac_bcast<1, false>(R[1], A4, nf4);
+                fmac_bcast<2, false>(R[2], A4, nf4); fmac_bcast<3, false>(R[3], A4, nf4);
+                r = fmaf(nf4, r4, r);
                 // Gauss-Jordan on the 4x4 system, one row per lane, pivot row broadcast from lane j
                 float pown = 0.0f;
 #define VINE_QUAD_PIVOT(J)                                                                               \
                 {                                                                                        \
                     const float pinv = __builtin_amdgcn_rcpf(R[J]);                                      \
-                    const float nf = pick(t == J, 0.0f, -(R[J] * qbcast<J>(pinv)));                          \
-                    if (J < 1) R[1] = fmaf(nf, qbcast<J>(R[1]), R[1]);                                   \
-                    if (J < 2) R[2] = fmaf(nf, qbcast<J>(R[2]), R[2]);                                   \
-                    if (J < 3) R[3] = fmaf(nf, qbcast<J>(R[3]), R[3]);                                   \
-                    r = fmaf(nf, qbcast<J>(r), r);                                                       \
+                    const float m = qbcast<J>(pinv) * R[J];                                              \
+                    const float nf = pick(t == J, 0.0f, -m);                                             \
+                    /* (the permuted operands were written by the previous pivot step: the checker confirms the distance) */ \
+                    if (J < 1) fmac_bcast<J, false>(R[1], R[1], nf);                                     \
+                    if (J < 2) fmac_bcast<J, false>(R[2], R[2], nf);                                     \
+                    if (J < 3) fmac_bcast<J, false>(R[3], R[3], nf);                                     \
+                    fmac_bcast<J, false>(r, r, nf);                                                      \
                     pown = t == J ? pinv : pown;                                                         \
                 }
                 VINE_QUAD_PIVOT(0) VINE_QUAD_PIVOT(1) VINE_QUAD_PIVOT(2) VINE_QUAD_PIVOT(3)
 #undef VINE_QUAD_PIVOT
                 const float x = r * pown;                                   // angular acceleration of link t
-                const float x4 = (r4 - quad_sum(A4 * x)) * i44;
+                const float x4 = (quad_sum(A4 * x) - r4) * ni44;
                 const float ydd = (rc - A4c * x4 - quad_sum(Ac * x)) * inv_a00;
                 // semi-implicit Euler + incremental rotation of (sin, cos) (see substep() above)
                 vy += h * ydd;
