@@ -100,16 +100,30 @@ def make_env(args, rank, device_index, world=1, extra_overrides=()):
     return env, cfg
 
 
+def kernel_instance(env):
+    """Name of the step-kernel instantiation `env` launches, as rocprofv3 prints it: template arguments = observation
+    layout (0: 28 columns, 1: 18), vine_randomize, obstacles (bit 0 shelf, bit 1 pipe)."""
+    from vine_robot_isaacgymenvs_amd import abi
+    c = env._vcfg
+    obst = (1 if c.has_flag(abi.FLAG_CREATE_SHELF) else 0) | (2 if c.has_flag(abi.FLAG_CREATE_PIPE) else 0)
+    return "%s<%d, %s, %d>" % (env.step_kernel_name, c.obs_type, "true" if c.has_flag(abi.FLAG_VINE_RANDOMIZE) else "false", obst)
+
+
 def _pmc_summary(kernel):
     """Latest committed PMC summary (profiles/rNN/env_step_*_pmc_summary.json, written by scripts/pmc_summary.py) whose
-    kernel-trace row is `kernel` ("vine_step_kernel<": one lane per env; "vine_step_quad_kernel": four lanes per env)."""
+    kernel-trace row is the instantiation `kernel` (kernel_instance(): e.g. "vine_step_quad_kernel<0, true, 0>"; the
+    round-1/2 summaries predate the obstacle template argument of the four-lane kernel: "<0, true>" matches there)."""
     import glob
+    old = kernel.rsplit(",", 1)[0] + ">" if kernel.endswith(", 0>") and "quad" in kernel else None
+    # newest round first, and within a round the newest summary of that instantiation (file modification order is not
+    # preserved by git: the version tag in the file name decides -- later tags sort later)
     for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "env_step_*pmc_summary.json")), reverse=True):
         try:
             d = json.load(open(f))
         except ValueError:
             continue
-        if kernel in d.get("kernel_stats", {}).get("name", ""):
+        name = d.get("kernel_stats", {}).get("name", "")
+        if kernel in name or (old and old in name):
             return f, d
     return None, None
 
@@ -161,7 +175,7 @@ def saturated_env_rate(args, device_index, n_sat=1 << 20, steps=40):
     out = {"num_envs": n_sat, "kernel_ms": ms, "env_steps_per_sec": rate, "achieved_GBs": gbs,
            "hbm_frac": gbs / HBM_PEAK_GBS}
     out["kernel"] = env.step_kernel_name
-    per_wave = pmc_valu_per_wave(out["kernel"] + "<")
+    per_wave = pmc_valu_per_wave(kernel_instance(env))
     if per_wave:
         peak = VALU_ISSUE_PEAK
         out.update({"valu_insts_per_wave_step": per_wave, "valu_wave_insts_per_sec": rate / 64.0 * per_wave,
@@ -170,14 +184,14 @@ def saturated_env_rate(args, device_index, n_sat=1 << 20, steps=40):
     return out
 
 
-def compute_roofline(kernel_name, n_envs, kernel_ms):
+def compute_roofline(kernel_name, n_envs, kernel_ms, instance=None):
     """What actually binds the env-step kernel (~85 flop per algorithmic byte, state resident in L2): the
     fp32 VALU.  Two fractions at the metric's own env count: VALU ISSUE (instructions per wave from the committed PMC
     pass of this kernel x waves per launch / kernel time, against VALU_ISSUE_PEAK) and fp32 FLOPs (the oracle's
     instrumented algorithmic flop count per env step, against the 157.3 TFLOP/s vector peak)."""
     lanes_per_env = 4 if "quad" in kernel_name else 1
     waves = (n_envs * lanes_per_env + 63) // 64
-    per_wave = pmc_valu_per_wave(kernel_name + "<")
+    per_wave = pmc_valu_per_wave(instance or (kernel_name + "<"))
     out = {"waves_per_launch": waves, "valu_issue_peak_wave_insts_per_sec": VALU_ISSUE_PEAK,
            "algorithmic_flops_per_env_step": ALGO_FLOPS_PER_ENV_STEP,
            "achieved_TFLOPs": ALGO_FLOPS_PER_ENV_STEP * n_envs / (kernel_ms * 1e-3) / 1e12,
@@ -226,7 +240,7 @@ def other_config_rates(args, device_index, steps=200):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        rows.append({"config": name, "num_envs": n, "kernel": env.step_kernel_name, "kernel_us": ms * 1e3,
+        rows.append({"config": name, "num_envs": n, "kernel": kernel_instance(env), "kernel_us": ms * 1e3,
                      "env_steps_per_sec": n / (ms * 1e-3),
                      "hbm_frac": ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         env.close()
@@ -425,7 +439,7 @@ def main():
         value = units_per_step * world * steps / elapsed
         algo_bytes = ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(env.step_kernel_name + "<")
+        traffic, traffic_src = pmc_traffic(kernel_instance(env))
         out = {
             "metric": ("env-steps/sec Vine5LinkMovingBase %d envs over %d GPUs" % (n * world, world)) if strong
                       else "env-steps/sec Vine5LinkMovingBase %d envs per GPU" % n,
@@ -442,7 +456,7 @@ def main():
             "roofline": {"bound": "valu", "kernel": env.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
-                         "compute": compute_roofline(env.step_kernel_name, n, kernel_ms)},
+                         "compute": compute_roofline(env.step_kernel_name, n, kernel_ms, kernel_instance(env))},
         }
         out.update(extra)
         if mode == "ppo":

@@ -1514,21 +1514,17 @@ def test_loss_scale_and_overflow_flags():
     src = torch.randn(64, 512, device=dev)
     out = torch.empty(512, device=dev)
     found = torch.zeros(1, device=dev)
-    fused.set_amp(torch.ones(1, device=dev), found)
-    try:
-        b = fused.ColumnSumBatch(check_overflow=True)
-        b.add(src, out)
-        b.flush(src)
-        torch.cuda.synchronize()
-        assert float(found) == 0.0 and torch.allclose(out, src.sum(0), atol=1e-4)
-        src[3, 100] = float("nan")
-        b = fused.ColumnSumBatch(check_overflow=True)
-        b.add(src, out)
-        b.flush(src)
-        torch.cuda.synchronize()
-        assert float(found) == 1.0
-    finally:
-        fused.set_amp(None, None)
+    b = fused.ColumnSumBatch(found_inf=found)
+    b.add(src, out)
+    b.flush(src)
+    torch.cuda.synchronize()
+    assert float(found) == 0.0 and torch.allclose(out, src.sum(0), atol=1e-4)
+    src[3, 100] = float("nan")
+    b = fused.ColumnSumBatch(found_inf=found)
+    b.add(src, out)
+    b.flush(src)
+    torch.cuda.synchronize()
+    assert float(found) == 1.0
 
 
 @pytest.mark.gpu

@@ -488,6 +488,150 @@ __device__ __forceinline__ void pipe_contact(const DevParams& P, const Dyn& s, f
     qa[0] += sy;
 }
 
+// ---- cooperative narrow phases for the four-lanes-per-env kernel.  Under a trained policy the distal links sit AT the
+// obstacle (inside the tube, at the shelf's edge): their narrow phases run in nearly every substep, and a wave pays for
+// a whole link whenever one lane needs it.  For links 3 and 4 (whose state every lane of the quad holds: link 4 is
+// replicated, link 3 is broadcast) the 6 rectangle points and the obstacle's corners are therefore SPLIT over the four
+// lanes -- lane t takes point t (and point t + 4 on lanes 0, 1) and corner t of every wall / strip corner t -- and the
+// partial forces are added with quad sums by the caller.  Same arithmetic per point / corner as the functions above; the
+// broad-phase decisions are uniform over the quad (same inputs on all four lanes).
+__device__ __forceinline__ void coop_point(int t, int slot, float z0, float z1, float& yl, float& zl, bool& valid) {
+    // slot 0: point t  -> (edge, position) = (0, t) for t < 3, (1, 0) for t = 3;  slot 1: point t + 4 -> (1, t + 1), lanes 0, 1
+    const int e = slot ? 1 : (t == 3), pos = slot ? t + 1 : (t == 3 ? 0 : t);
+    valid = slot ? t < 2 : true;
+    yl = e ? LINK_Y1 : LINK_Y0;
+    zl = pos == 0 ? z0 : (pos == 1 ? 0.5f * (z0 + z1) : z1);
+}
+__device__ __forceinline__ void shelf_link_contact_coop(const DevParams& P, int t, float z0, float z1, float py, float pz,
+                                                        float pvy, float pvz, float sp, float cp, float om, float shelf_y,
+                                                        float shelf_z, float& fy_tot, float& fz_tot, float& mom,
+                                                        float& strip_fy, float& strip_fz) {
+    const float board[2][4] = {{-0.001f, 0.0f, 0.1995f, 0.005f}, {0.0f, 0.2f, 0.2f, 0.005f}};
+    const float dy = -sp, dz = cp, ly = cp, lz = sp;
+    const float ycut = shelf_y + 0.2f;
+    const float a_lo = shelf_z - 0.005f, a_hi = shelf_z + 0.005f, b_lo = shelf_z + 0.195f, b_hi = shelf_z + 0.205f;
+    const float qy = py + P.L * dy, qz = pz + P.L * dz;
+    const float ylo = fminf(py, qy) - LINK_REACH;
+    const float zlo = fminf(pz, qz) - LINK_REACH, zhi = fmaxf(pz, qz) + LINK_REACH;
+    const bool near_a = ylo < ycut && zlo < a_hi && zhi > a_lo;
+    const bool near_b = ylo < ycut && zlo < b_hi && zhi > b_lo;
+    if (!(near_a || near_b)) return;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        float yl, zl;
+        bool valid;
+        coop_point(t, slot, z0, z1, yl, zl, valid);
+        const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+        const float wy = py + ry, wz = pz + rz;
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx) {
+            const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
+            const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
+            if (valid && (bx == 0 ? near_a : near_b) && ey > 0.0f && ez > 0.0f) {
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                float fy = 0.0f, fz = 0.0f;
+                if (ey < ez) {
+                    const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                    fy = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vy, 0.0f);
+                } else {
+                    const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                    fz = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vz, 0.0f);
+                }
+                fy_tot += fy; fz_tot += fz;
+                mom += -rz * fy + ry * fz;
+            }
+        }
+    }
+    if (near_a && t < 2) {                                   // strip corner t
+        const float wy = shelf_y + 0.2f, wz = shelf_z + (t ? 0.005f : -0.005f);
+        const float ry = wy - py, rz = wz - pz;
+        const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+        if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+            float dep = zl - z0, ny = -dy, nz = -dz;
+            if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+            if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+            if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+            const float vy = pvy - om * rz, vz = pvz + om * ry;
+            const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+            strip_fy += f * ny; strip_fz += f * nz;
+            const float fy = -f * ny, fz = -f * nz;
+            fy_tot += fy; fz_tot += fz;
+            mom += -rz * fy + ry * fz;
+        }
+    }
+}
+__device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t, float z0, float z1, float py, float pz,
+                                                       float pvy, float pvz, float sp, float cp, float om, const PipePose& T,
+                                                       float& fy_tot, float& fz_tot, float& mom) {
+    const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
+    const float pipe_y = T.y, pipe_z = T.z, ct = T.ct, st = T.st;
+    const float dy = -sp, dz = cp, ly = cp, lz = sp;
+    const float rsum = 0.18748f + 0.0877f + 1.0e-4f;
+    const float my = py + 0.04425f * dy - T.ccy, mz = pz + 0.04425f * dz - T.ccz;
+    if (!(my * my + mz * mz < rsum * rsum)) return;
+    const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;
+    const float gy0 = py - pipe_y, gz0 = pz - pipe_z;
+    const float jy = gy0 * ct + gz0 * st, jz = -gy0 * st + gz0 * ct;
+    const float ay0 = z0 * dly, ay1 = z1 * dly, by0 = LINK_Y0 * dlz, by1 = LINK_Y1 * dlz;
+    const float az0 = z0 * dlz, az1 = z1 * dlz, bz0 = LINK_Y0 * -dly, bz1 = LINK_Y1 * -dly;
+    const float ymin = jy + fminf(ay0, ay1) + fminf(by0, by1) - PIPE_CULL_EPS;
+    const float ymax = jy + fmaxf(ay0, ay1) + fmaxf(by0, by1) + PIPE_CULL_EPS;
+    const float zmin = jz + fminf(az0, az1) + fminf(bz0, bz1) - PIPE_CULL_EPS;
+    const float zmax = jz + fmaxf(az0, az1) + fmaxf(bz0, bz1) + PIPE_CULL_EPS;
+    const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
+    const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
+    const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
+    if (!(near0 || near1)) return;
+#pragma unroll
+    for (int slot = 0; slot < 2; ++slot) {
+        float yl, zl;
+        bool valid;
+        coop_point(t, slot, z0, z1, yl, zl, valid);
+        const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+        const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
+        const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
+            const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
+            if (valid && (w == 0 ? near0 : near1) && ey > 0.0f && ez > 0.0f) {
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
+                float fyl = 0.0f, fzl = 0.0f;
+                if (ey < ez) {
+                    const float sg = (ddy > 0.0f) ? 1.0f : -1.0f;
+                    fyl = sg * fmaxf(CONTACT_K * ey - CONTACT_C * sg * vyl, 0.0f);
+                } else {
+                    const float sg = (ddz > 0.0f) ? 1.0f : -1.0f;
+                    fzl = sg * fmaxf(CONTACT_K * ez - CONTACT_C * sg * vzl, 0.0f);
+                }
+                const float fy = fyl * ct - fzl * st, fz = fyl * st + fzl * ct;
+                fy_tot += fy; fz_tot += fz;
+                mom += -rz * fy + ry * fz;
+            }
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        if (w == 0 ? near0 : near1) {                        // corner t of wall w
+            const float pyl = wall_lo[w] + ((t & 1) ? PIPE_WALL : 0.0f), pzl = (t & 2) ? PIPE_LEN : 0.0f;
+            const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
+            const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
+            if (zl > z0 && zl < z1 && yl > LINK_Y0 && yl < LINK_Y1) {
+                float dep = zl - z0, ny = -dy, nz = -dz;
+                if (z1 - zl < dep) { dep = z1 - zl; ny = dy; nz = dz; }
+                if (yl - LINK_Y0 < dep) { dep = yl - LINK_Y0; ny = -ly; nz = -lz; }
+                if (LINK_Y1 - yl < dep) { dep = LINK_Y1 - yl; ny = ly; nz = lz; }
+                const float vy = pvy - om * rz, vz = pvz + om * ry;
+                const float f = fmaxf(CONTACT_K * dep + CONTACT_C * (vy * ny + vz * nz), 0.0f);
+                const float fy = -f * ny, fz = -f * nz;
+                fy_tot += fy; fz_tot += fz;
+                mom += -rz * fy + ry * fz;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ float clampf(float v, float lim) { return fminf(fmaxf(v, -lim), lim); }
 
 #define ST(f) st[(size_t)(f) * n + e]
@@ -1231,16 +1375,33 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                     const float z0 = t == 0 ? -0.00575f : 0.0f, z1 = t == 0 ? 0.09425f : L;
                     float fy = 0.0f, fz = 0.0f, mom = 0.0f, f4y = 0.0f, f4z = 0.0f, mom4 = 0.0f;
                     float sfy = 0.0f, sfz = 0.0f, s4y = 0.0f, s4z = 0.0f;
+                    // links 0..2: by their own lanes (rarely anywhere near the obstacle); links 3 and 4: their points and
+                    // the obstacle's corners split over the quad (shelf/pipe_link_contact_coop), partial sums added below
+                    const float p3y = qbcast<3>(py), p3z = qbcast<3>(pz), pv3y = qbcast<3>(pvy), pv3z = qbcast<3>(pvz);
+                    const float sn3 = qbcast<3>(sn), cs3 = qbcast<3>(cs), w3 = qbcast<3>(w);
+                    float c3y = 0.0f, c3z = 0.0f, cm3 = 0.0f, c4y = 0.0f, c4z = 0.0f, cm4 = 0.0f, cs3y = 0.0f, cs3z = 0.0f;
+                    // (measured at 16384 envs: the split pays for the pipe -- a reaching vine has links 3 and 4 INSIDE the tube:
+                    // default-config training rollout 5.06 -> 4.66 ms -- while the shelf is touched by link 4 almost alone:
+                    // there link 3 stays with its own lane (random policy 85 us; with link 3 split as well 95 us))
                     if (SHELF) {
                         shelf_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, shelf_y, shelf_z, fy, fz, mom, sfy, sfz);
-                        shelf_link_contact(P, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, shelf_y, shelf_z, f4y, f4z, mom4, s4y, s4z);
+                        shelf_link_contact_coop(P, t, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, shelf_y, shelf_z, c4y, c4z, cm4, s4y, s4z);
                     }
                     if (PIPE) {
-                        pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom);
-                        pipe_link_contact(P, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, pipeT, f4y, f4z, mom4);
+                        if (t < 3) pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom);
+                        pipe_link_contact_coop(P, t, 0.0f, L, p3y, p3z, pv3y, pv3z, sn3, cs3, w3, pipeT, c3y, c3z, cm3);
+                        pipe_link_contact_coop(P, t, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, pipeT, c4y, c4z, cm4);
+                    }
+                    {   // fold the cooperative partial sums: link 3's totals go to lane 3's slots, link 4's to every lane
+                        f4y = quad_sum(c4y); f4z = quad_sum(c4z); mom4 = quad_sum(cm4);
+                        if (PIPE) {
+                            const float f3y = quad_sum(c3y), f3z = quad_sum(c3z), m3 = quad_sum(cm3);
+                            fy += pick(t == 3, f3y, 0.0f); fz += pick(t == 3, f3z, 0.0f); mom += pick(t == 3, m3, 0.0f);
+                        }
                     }
                     if (SHELF) {
-                        const float ty_ = quad_sum(sfy) + s4y, tz_ = quad_sum(sfz) + s4z;
+                        // (sfy / sfz: own-lane strip reactions of links 0..2; cs3* / s4*: per-lane partials of links 3, 4)
+                        const float ty_ = quad_sum(sfy + cs3y + s4y), tz_ = quad_sum(sfz + cs3z + s4z);
                         csum += sqrtf(ty_ * ty_ + tz_ * tz_);
                     }
                     const float ify = quad_scan_incl(fy, t), ifz = quad_scan_incl(fz, t);

@@ -258,6 +258,7 @@ class A2CAgent:
         self.last_lr = float(config["learning_rate"])
         self.lr = torch.tensor(self.last_lr, device=self.device, dtype=torch.float32)
         self.use_grad_scaler = self.mixed_precision and self.amp_dtype == torch.float16
+        self._amp = None            # (loss scale, overflow flag) of the device-side GradScaler: the fp16 fused update only
         if self.use_grad_scaler:
             # fp16 autocast (the reference's mixed_precision: True) needs GradScaler, which drives a torch optimiser
             self._setup_flat_grads()
@@ -272,12 +273,8 @@ class A2CAgent:
                 self.optimizer.enable_lp16_shadow(self.amp_dtype)
                 self.model.a2c_network.op_weight_lookup = self.optimizer.shadow_of
                 if self.amp_dtype == torch.float16:      # fp16 operands: GradScaler semantics (PY:53 via rl_games)
-                    fused.set_amp(*self.optimizer.enable_loss_scaling(
-                        float(config.get("loss_scale_init", 65536.0)), int(config.get("loss_scale_growth_interval", 2000))))
-                else:
-                    fused.set_amp(None, None)
-            else:
-                fused.set_amp(None, None)
+                    self._amp = self.optimizer.enable_loss_scaling(
+                        float(config.get("loss_scale_init", 65536.0)), int(config.get("loss_scale_growth_interval", 2000)))
         self.scaler = torch.amp.GradScaler("cuda", enabled=self.use_grad_scaler)
 
         self.frame = 0
@@ -854,11 +851,12 @@ class A2CAgent:
         """Forward, ONE kernel for the whole PPO loss and its gradient w.r.t. the head outputs, hand-written backward
         into the flat gradient block; the minibatch KL is parked next to the gradients so that one all-reduce
         averages both.  -> (stats[8], mu, logstd)"""
+        self._amp_covered = False
         out = self._fused_grad_half_body(mb, obs_n, stats_out)
-        if self.optimizer.amp_state is not None and fused.AMP["covered"] is not None:
-            # loss-scaled fp16 backward: unless every parameter gradient ends in the overflow-checked column-sum launch
+        if self._amp is not None:
+            # loss-scaled fp16 backward: unless every parameter gradient ended in the overflow-checked column-sum launch
             # the optimiser looks for non-finite gradients itself before it steps
-            self.optimizer.check_grads = not fused.AMP["covered"]
+            self.optimizer.check_grads = not self._amp_covered
         return out
 
     def _fused_grad_half_body(self, mb, obs_n, stats_out):
@@ -874,11 +872,12 @@ class A2CAgent:
             pack = fused.ppo_loss_pack(net.sigma, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"],
                                        mb["returns"], mb["mu"], mb["sigma"], self.e_clip, self.clip_value, self.critic_coef,
                                        self.entropy_coef, self.bounds_loss_coef or 0.0, hb, kl_out=self.optimizer.aux[0:1],
-                                       logstd_grad=net.sigma.grad, update_old=True, stats_out=stats_out)
+                                       logstd_grad=net.sigma.grad, update_old=True, stats_out=stats_out, amp=self._amp)
             batch_dict["loss_pack"] = pack
         mu, value, logstd, _, heads = self.model.forward_raw(batch_dict)
         if pack is not None and heads is not None and heads.grad_fn is not None and getattr(heads.grad_fn, "loss_fused", None):
             torch.autograd.backward([heads], [heads.detach()])      # the gradient handed over is ignored by the node
+            self._amp_covered = bool(pack.get("amp_covered", False))
             return pack["stats"], mu.detach(), logstd.detach()
         g_mu, g_val, g_ls, stats = fused.ppo_loss_fused(
             mu, logstd, value, mb["actions"], mb["old_logp_actions"], mb["advantages"], mb["old_values"], mb["returns"],
@@ -886,7 +885,7 @@ class A2CAgent:
             self.bounds_loss_coef or 0.0, heads=heads, head_bias_grads=hb if (ext and heads is not None) else None,
             # KL next to the gradients (it rides in the all-reduce), log-sigma gradient into its slot and the dataset's
             # mu / sigma refreshed in place: all by the loss kernels themselves
-            kl_out=self.optimizer.aux[0:1], logstd_grad=net.sigma.grad, update_old=True, stats_out=stats_out)
+            kl_out=self.optimizer.aux[0:1], logstd_grad=net.sigma.grad, update_old=True, stats_out=stats_out, amp=self._amp)
         # the gradient block was left zeroed by the last Adam step
         if heads is not None:
             torch.autograd.backward([heads], [g_mu])            # g_mu is the [n, A+1] gradient of [mu | value]
@@ -1255,6 +1254,8 @@ class A2CAgent:
         w.add_scalar("losses/entropy", stats["entropy"], frame)
         w.add_scalar("losses/bounds_loss", stats["b_loss"], frame)
         w.add_scalar("info/last_lr", self.last_lr, frame)
+        if getattr(self.optimizer, "amp_state", None) is not None:      # device-side GradScaler (fp16 update)
+            w.add_scalar("info/loss_scale", self.optimizer.loss_scale, frame)
         w.add_scalar("info/e_clip", self.e_clip, frame)
         w.add_scalar("info/kl", stats["kl"], frame)
         w.add_scalar("info/epochs", epoch_num, frame)

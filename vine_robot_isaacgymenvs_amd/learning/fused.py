@@ -69,18 +69,14 @@ def lp_dtype():
     return _lp
 
 
-# torch.amp.GradScaler restated on the device (fp16 operands need it, bf16 do not): the device scalars the loss kernels
-# multiply their gradients by / flag an overflow in.  Set by the agent (FlatAdam.enable_loss_scaling); None = scale 1.
-AMP = {"scale": None, "found_inf": None, "covered": None}
-
-
-def set_amp(scale, found_inf):
-    AMP["scale"], AMP["found_inf"], AMP["covered"] = scale, found_inf, None
-
-
-def _amp_ptrs():
-    return (AMP["scale"].data_ptr() if AMP["scale"] is not None else None,
-            AMP["found_inf"].data_ptr() if AMP["found_inf"] is not None else None)
+# torch.amp.GradScaler restated on the device (fp16 operands need it, bf16 do not): `amp` = (loss scale, overflow flag),
+# two 1-element device tensors owned by the optimiser (FlatAdam.enable_loss_scaling).  It travels explicitly -- in the
+# loss pack of the trunk, as an argument of ppo_loss_fused -- never as module state: two agents in one process, or a test
+# calling a kernel directly after an agent existed, must not inherit each other's scale.
+def _amp_ptrs(amp):
+    if amp is None:
+        return None, None
+    return amp[0].data_ptr(), amp[1].data_ptr()
 
 
 def _mm(a, b):
@@ -553,9 +549,9 @@ class ColumnSumBatch:
     """Collects column-sum jobs and runs them in ONE launch (``vine_column_sums_batched``, 16 jobs per launch): the
     network's backward pass ends with ~13 of them, each far too small to fill the chip."""
 
-    def __init__(self, check_overflow=False):
+    def __init__(self, found_inf=None):
         self.jobs, self.keep = [], []
-        self.check_overflow = check_overflow      # flag non-finite results in AMP["found_inf"] (loss-scaled backward)
+        self.found_inf = found_inf      # 1-element device tensor set to 1 by a non-finite result (loss-scaled backward)
 
     def add(self, src, out, out1=None, n0=0, dup=False):
         flat = _as_rows(src)
@@ -575,7 +571,7 @@ class ColumnSumBatch:
             ptr = lambda v: (C.c_void_p * n)(*v)
             _check(lib.vine_column_sums_batched(n, i64(cols[0]), i64(cols[1]), ptr(cols[2]), i64(cols[3]), ptr(cols[4]),
                                                 i64(cols[5]), ptr(cols[6]), (C.c_int32 * n)(*cols[7]),
-                                                _amp_ptrs()[1] if self.check_overflow else None, st),
+                                                self.found_inf.data_ptr() if self.found_inf is not None else None, st),
                    "vine_column_sums_batched")
         self.jobs, self.keep = [], []
 
@@ -906,6 +902,7 @@ class _Trunk(torch.autograd.Function):
         NH = w_heads.shape[0]
         fuse_heads = H == 256 and 2 <= NH <= 5
         ctx.loss_fused = None
+        ctx.loss_pack = loss_pack       # (its "amp" entry: loss scale / overflow flag of the device-side GradScaler)
         lhl_rows = lib.vine_ln_heads_loss_rows()
         if (fuse_heads and loss_pack is not None and HEADS_LOSS and n % lhl_rows == 0 and n // lhl_rows <= 1024
                 and head_bias_external):
@@ -922,7 +919,7 @@ class _Trunk(torch.autograd.Function):
                                           d_out.data_ptr(), int(lp), ln_part.data_ptr(), lpk["stats"].data_ptr(),
                                           lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
                                           lpk["head_bias_grads"][1].data_ptr(), lpk["scratch"].data_ptr(), *lpk["extra"],
-                                          *_amp_ptrs(), st),
+                                          *_amp_ptrs(lpk.get("amp")), st),
                    "vine_ln_heads_loss")
             ctx.loss_fused = (d_out, ln_part)
         elif fuse_heads:      # LayerNorm + both heads in one kernel; LN(x) is never written
@@ -985,12 +982,13 @@ class _Trunk(torch.autograd.Function):
 
         base = 2 * n_mlp
         # with the optimiser's gradient slots in place all column sums are deferred into one launch at the end
-        batch = (ColumnSumBatch(check_overflow=mixed and AMP["found_inf"] is not None)
+        amp = ctx.loss_pack.get("amp") if ctx.loss_pack is not None else None
+        batch = (ColumnSumBatch(found_inf=amp[1] if (mixed and amp is not None) else None)
                  if all(sl is not None for k, sl in enumerate(slots) if ctx.pshapes[k] is not None) else None)
-        if mixed and AMP["found_inf"] is not None and AMP["covered"] is None:
+        if amp is not None:
             # do ALL parameter gradients of this backward pass end in the overflow-checked column-sum launch?  (else the
             # optimiser checks the gradient block itself before it steps: FlatAdam.step)
-            AMP["covered"] = batch is not None
+            ctx.loss_pack["amp_covered"] = bool(mixed and batch is not None)
         NH = w_heads.shape[0]
         if ctx.loss_fused is not None:
             d_out, part = ctx.loss_fused             # computed in forward by the fused LayerNorm + heads + loss kernel
@@ -1197,7 +1195,7 @@ def ppo_loss_reference(mu, logstd, value, actions, old_neglogp, adv, old_values,
 
 def ppo_loss_pack(logstd, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip, clip_value,
                   critic_coef, entropy_coef, bounds_coef, head_bias_grads, soft_bound=1.1, kl_out=None, logstd_grad=None,
-                  update_old=False, stats_out=None):
+                  update_old=False, stats_out=None, amp=None):
     """Arguments of the PPO loss for the trunk's one-launch LayerNorm + heads + loss kernel (``trunk(loss_pack=...)``):
     same meaning as ``ppo_loss_fused``; ``pack["stats"]`` / ``pack["grad_logstd"]`` receive the results."""
     from ..abi import PPO_LOSS_SCRATCH_FLOATS
@@ -1219,12 +1217,14 @@ def ppo_loss_pack(logstd, actions, old_neglogp, adv, old_values, returns, old_mu
             "extra": (kl_out.data_ptr() if kl_out is not None else None,
                       logstd_grad.data_ptr() if logstd_grad is not None else None,
                       args[5].data_ptr() if update_old else None, args[6].data_ptr() if update_old else None),
-            "keep": (kl_out, logstd_grad)}
+            "keep": (kl_out, logstd_grad),
+            # (loss scale, overflow flag) of the device-side GradScaler, or None; "amp_covered" is filled in by the backward
+            "amp": amp, "amp_covered": False}
 
 
 def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, returns, old_mu, old_sigma, e_clip,
                    clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound=1.1, heads=None, head_bias_grads=None,
-                   kl_out=None, logstd_grad=None, update_old=False, stats_out=None):
+                   kl_out=None, logstd_grad=None, update_old=False, stats_out=None, amp=None):
     """One HIP kernel: returns (grad_mu [n,A], grad_value [n,1], grad_logstd [A], stats[8]) where the gradients are
     d(loss)/d(.) of the same scalar loss as ``ppo_loss_reference``.  With ``heads`` ([n, A+1] = [mu | value], the
     output of the fused trunk) mu/value are read from it in place and the first return value is the matching
@@ -1260,7 +1260,7 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
                                  *scal, g.data_ptr(), g.data_ptr() + 4 * A, grad_logstd.data_ptr(), stats.data_ptr(),
                                  A + 1, A + 1, head_bias_grads[0].data_ptr() if head_bias_grads else None,
                                  head_bias_grads[1].data_ptr() if head_bias_grads else None, scratch.data_ptr(), *extra,
-                                 _amp_ptrs()[0], _stream(hd)),
+                                 _amp_ptrs(amp)[0], _stream(hd)),
                "vine_ppo_loss")
         return g, None, grad_logstd, stats
     n = mu.shape[0]
@@ -1270,6 +1270,6 @@ def ppo_loss_fused(mu, logstd, value, actions, old_neglogp, adv, old_values, ret
     grad_value = torch.empty_like(val_c)
     _check(lib.vine_ppo_loss(n, A, mu_c.data_ptr(), ls.data_ptr(), val_c.data_ptr(), *[a.data_ptr() for a in args],
                              *scal, grad_mu.data_ptr(), grad_value.data_ptr(), grad_logstd.data_ptr(),
-                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), *extra, _amp_ptrs()[0], _stream(mu)),
+                             stats.data_ptr(), 0, 0, None, None, scratch.data_ptr(), *extra, _amp_ptrs(amp)[0], _stream(mu)),
            "vine_ppo_loss")
     return grad_mu, grad_value.view_as(value), grad_logstd, stats
