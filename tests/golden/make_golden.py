@@ -647,6 +647,36 @@ def f8_ppo_loss_terms(out):
                                     b_loss_soft_bound_1=npf(b))
 
 
+def f9_gae(out):
+    """F9: generalised advantage estimation as the reference's in-tree text states it (isaacgymenvs/learning/
+    common_agent.py:413-425, ``discount_values``: lifted out of the file by name like F8's loss terms).  It takes the
+    terminal flags AFTER each step and next values already masked by them; rl_games' own form (next-value /
+    next-nonterminal, the one this build implements) is the same recurrence on dones[t + 1] / values[t + 1]: the fixture
+    stores the T + 1 flags and values both forms are fed from."""
+    import ast
+    import types
+    path = os.path.join(REF, "isaacgymenvs/learning/common_agent.py")
+    tree = ast.parse(open(path).read())
+    funcs = [n for cls in tree.body if isinstance(cls, ast.ClassDef) for n in cls.body
+             if isinstance(n, ast.FunctionDef) and n.name == "discount_values"]
+    assert len(funcs) == 1
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), path, "exec"), ns)
+    T, N = 16, 64
+    agent = types.SimpleNamespace(horizon_length=T, gamma=0.99, tau=0.95)
+    g = torch.Generator().manual_seed(909)
+    rewards = torch.randn(T, N, 1, generator=g)
+    values = torch.randn(T + 1, N, 1, generator=g)                    # V_0 .. V_T (V_T = the bootstrap "last values")
+    dones = (torch.rand(T + 1, N, generator=g) < 0.15).float()        # dones[t]: the episode ended at step t - 1
+    dones[:, :4] = 0.0                                                # some envs never finish
+    dones[5, 4:8] = 1.0
+    fdones = dones[1:]                                                # flags after step t
+    next_values = values[1:] * (1.0 - fdones).unsqueeze(2)
+    advs = ns["discount_values"](agent, fdones, values[:T], rewards, next_values)
+    out["f9_gae"] = dict(rewards=npf(rewards), values=npf(values), dones=npf(dones), advs=npf(advs),
+                         gamma=np.float64(0.99), tau=np.float64(0.95))
+
+
 def main():
     install_stubs()
     vt, v5 = load_reference()
@@ -658,6 +688,7 @@ def main():
     f5_reset_sampling(vt, v5, out)
     f6_trajectory(vt, v5, out)       # also writes F7 (wandb_dict keys)
     f8_ppo_loss_terms(out)
+    f9_gae(out)
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)

@@ -1638,3 +1638,24 @@ def test_lstm_step_f32_against_float64_torch():
     assert torch.equal(c_io, c_out)
     assert lib.vine_lstm_step_f32(N + 64, H, K, xh.data_ptr(), K, wt.data_ptr(), bias.data_ptr(), c_prev.data_ptr(),
                                   h_out.data_ptr(), H, c_out.data_ptr(), None, 0, st) == -2
+
+
+@pytest.mark.gpu
+def test_gae_kernel_against_reference_text_golden():
+    """F9 through the HIP kernel (vine_gae: one env per lane, reverse scan in registers)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f9_gae.npz"))
+    dev = torch.device("cuda:0")
+    T, N = g["rewards"].shape[:2]
+    rew = torch.from_numpy(g["rewards"]).to(dev).contiguous()
+    val = torch.from_numpy(g["values"][:T]).to(dev).contiguous()
+    last_v = torch.from_numpy(g["values"][T]).to(dev).contiguous()
+    dones = torch.from_numpy(g["dones"][:T]).to(dev).to(torch.uint8).contiguous()
+    last_d = torch.from_numpy(g["dones"][T]).to(dev).to(torch.uint8).contiguous()
+    advs, rets = torch.empty_like(rew), torch.empty_like(rew)
+    assert fused._lib().vine_gae(T, N, rew.data_ptr(), val.data_ptr(), dones.data_ptr(), last_v.data_ptr(), last_d.data_ptr(),
+                                 float(g["gamma"]), float(g["tau"]), advs.data_ptr(), rets.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g["advs"]).to(dev)
+    assert float((advs - ref).abs().max()) < 2e-6 and float((rets - (ref + val)).abs().max()) < 2e-6

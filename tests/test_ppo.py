@@ -295,3 +295,18 @@ def test_robot_side_control_model(tmp_path, num_actions):
         assert u_range[0] - 1e-5 <= float(a[-1]) <= u_range[1] + 1e-5
     with pytest.raises(ValueError):
         m.get_action(args[0], args[1], args[2], args[3], torch.zeros(5))
+
+
+def test_gae_against_reference_text_golden(golden):
+    """F9: the reference's in-tree ``discount_values`` (common_agent.py:413-425, lifted by name into the fixture
+    generator) on T + 1 terminal flags / values; this build's next-nonterminal form (rl_games') must give the same
+    advantages -- pins row R2 against the only GAE text the reference holds."""
+    import torch
+    from vine_robot_isaacgymenvs_amd.learning import a2c_continuous as a2c
+    g = golden("f9_gae")
+    T = g["rewards"].shape[0]
+    t = lambda k: torch.from_numpy(g[k])
+    dones, values = t("dones"), t("values")
+    adv = a2c.discount_values(float(g["gamma"]), float(g["tau"]), dones[T], values[T], dones[:T], values[:T], t("rewards"))
+    assert float((adv - t("advs")).abs().max()) < 2e-6
+    assert float(dones.sum()) > 50 and float(t("advs").abs().max()) > 1.0
