@@ -10,7 +10,8 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
     shapes (the LSTM over the 4-step sequences of a 32768-sample minibatch, ONE persistent launch per direction),
     priced against HBM with their algorithmic bytes.  Every launch runs on its own operand / output set, `sets` of them
     in rotation (> 256 MB in total: more than the Infinity Cache holds), so the figures are cold-cache ones; the
-    in-situ durations of the same kernels are in profiles/r02/ppo_iteration_graphed_kernel_stats.csv.
+    in-situ durations of the same kernels are in profiles/r03/ppo_iteration_graphed_kernel_stats.csv.  ("bf16" below =
+    the library's 16-bit operand format: float16 in the default build.)
       lstm_seq_fwd_kernel: reads x bf16 [B*T, wpad] + masked h0 bf16 [B, H] + c0 fp32 [B, H] + weights (bf16, 4H x
           (wpad + H)); writes h fp32 [B*T, H], c bf16 [T-1, B, H] + c_T fp32, gate activations bf16 [T, B, 4H], masked h
           bf16 [B, T-1, H]
@@ -19,7 +20,7 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
     from . import fused
     lib = fused._lib()
     st = torch.cuda.current_stream(device).cuda_stream
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()          # the library's 16-bit operand format (float16 in the default build)
     w_ih = (torch.randn(4 * H, width, device=device) / 10).to(bf)
     w_hh = (torch.randn(4 * H, H, device=device) / 16).to(bf)
     wtile = torch.empty(4 * H * (wpad + H), device=device, dtype=bf)
@@ -55,7 +56,7 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
                                                d["c_all"].data_ptr(), d["c0"].data_ptr(), d["dones"].data_ptr(),
                                                d["dG"].data_ptr(), part.data_ptr(), 1, d["c_last"].data_ptr(), 1, st) == 0
 
-    # (production configuration: saved cell states c_1 .. c_{T-1} and the hidden-state gradient as bfloat16, c_T fp32)
+    # (production configuration: saved cell states c_1 .. c_{T-1} and the hidden-state gradient in 16 bits, c_T fp32)
     fwd_bytes = (B * T * wpad * 2 + B * H * 2 + B * H * 4 + wtile.numel() * 2 + B * T
                  + B * T * H * 4 + ((T - 1) * B * H * 2 + B * H * 4) + T * B * 4 * H * 2 + B * (T - 1) * H * 2)
     bwd_bytes = (B * T * H * 2 + T * B * 4 * H * 2 + (2 * B * H * 4 + (T - 1) * B * H * 2) + whh_tiled.numel() * 2 + B * T
