@@ -1375,11 +1375,12 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                     const float z0 = t == 0 ? -0.00575f : 0.0f, z1 = t == 0 ? 0.09425f : L;
                     float fy = 0.0f, fz = 0.0f, mom = 0.0f, f4y = 0.0f, f4z = 0.0f, mom4 = 0.0f;
                     float sfy = 0.0f, sfz = 0.0f, s4y = 0.0f, s4z = 0.0f;
-                    // links 0..2: by their own lanes (rarely anywhere near the obstacle); links 3 and 4: their points and
-                    // the obstacle's corners split over the quad (shelf/pipe_link_contact_coop), partial sums added below
+                    // proximal links: by their own lanes (rarely anywhere near the obstacle); distal links (pipe: 3 and 4,
+                    // shelf: 4): their points and the obstacle's corners split over the quad (*_link_contact_coop), the
+                    // partial sums added below
                     const float p3y = qbcast<3>(py), p3z = qbcast<3>(pz), pv3y = qbcast<3>(pvy), pv3z = qbcast<3>(pvz);
                     const float sn3 = qbcast<3>(sn), cs3 = qbcast<3>(cs), w3 = qbcast<3>(w);
-                    float c3y = 0.0f, c3z = 0.0f, cm3 = 0.0f, c4y = 0.0f, c4z = 0.0f, cm4 = 0.0f, cs3y = 0.0f, cs3z = 0.0f;
+                    float c3y = 0.0f, c3z = 0.0f, cm3 = 0.0f, c4y = 0.0f, c4z = 0.0f, cm4 = 0.0f;
                     // (measured at 16384 envs: the split pays for the pipe -- a reaching vine has links 3 and 4 INSIDE the tube:
                     // default-config training rollout 5.06 -> 4.66 ms -- while the shelf is touched by link 4 almost alone:
                     // there link 3 stays with its own lane (random policy 85 us; with link 3 split as well 95 us))
@@ -1400,8 +1401,8 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                         }
                     }
                     if (SHELF) {
-                        // (sfy / sfz: own-lane strip reactions of links 0..2; cs3* / s4*: per-lane partials of links 3, 4)
-                        const float ty_ = quad_sum(sfy + cs3y + s4y), tz_ = quad_sum(sfz + cs3z + s4z);
+                        // (sfy / sfz: own-lane strip reactions of links 0..3; s4y / s4z: this lane's share of link 4's)
+                        const float ty_ = quad_sum(sfy + s4y), tz_ = quad_sum(sfz + s4z);
                         csum += sqrtf(ty_ * ty_ + tz_ * tz_);
                     }
                     const float ify = quad_scan_incl(fy, t), ifz = quad_scan_incl(fz, t);

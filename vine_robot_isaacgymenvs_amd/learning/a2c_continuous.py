@@ -12,8 +12,10 @@ MI355X-first choices (none changes the arithmetic):
   * the 16-step rollout is captured in one hipGraph (``use_graphs``): policy GEMMs + the fused env-step
     kernel + bookkeeping replay with a single launch; from the second iteration on every optimiser step is two
     hipGraph replays as well (forward/backward | Adam + schedule) with the all-reduce between them;
-  * ``mixed_precision: True`` (the reference YAML's value) = hand-written mixed precision: bfloat16 GEMM operands,
-    fp32 accumulation, state, loss and optimiser (learning/fused.py ``trunk``), not autocast.
+  * ``mixed_precision: True`` (the reference YAML's value) = the reference's precisions, hand-written: the UPDATE takes
+    fp16 GEMM operands with fp32 accumulation, state, loss and optimiser (learning/fused.py ``trunk``) and
+    torch.amp.GradScaler's semantics restated on the device (FlatAdam.enable_loss_scaling), not autocast; rollout
+    inference runs in fp32 on the matrix cores (``_infer``: vine_mlp3_elu_f32 / vine_lstm_step_f32).
 """
 import copy
 import os
