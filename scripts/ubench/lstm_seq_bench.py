@@ -17,7 +17,7 @@ def one():
     dev = torch.device("cuda:0")
     lib = fused._lib()
     B, T, H, width, wpad, SETS = 8192, 4, 256, 92, 96, 4
-    bf = torch.bfloat16
+    bf = fused.lp_dtype()
     torch.manual_seed(0)
     w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
     w_hh = (torch.randn(4 * H, H, device=dev) / 16).to(bf)
