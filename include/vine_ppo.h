@@ -70,10 +70,14 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
  *            the final state c_T goes to c_last [B, H] fp32 (the LSTM state handed back to the caller)
  *   h0 (nullable) [B, H] fp32: the initial hidden state; the kernel then forms the masked bf16 copy itself
  *            (h0 * (1 - done[b, 0])) and WRITES it to slot 0 of hp instead of reading it from there
+ *   c_bf16 bit 1 ("h once"; needs bit 0 and h0): h_out is [B, T + 1, H] in the 16-bit format, UNMASKED, and is the only
+ *            copy of the hidden states -- slot 0 receives h0, slot t + 1 the state h_t; vine_ln_heads_loss reads slots
+ *            1 .. T (dx_bf16 bit 1 + T in bits 8-15) and vine_weight_grad_cat_seq_mfma slots 0 .. T - 1 with done[k] applied
+ *            as the recurrent weight gradient's operand; hp is not used (may be NULL)
  * Needs B % 32 == 0, H == 256, T <= 8; VINE_ERR_UNSUPPORTED otherwise (callers use the per-step kernels). */
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
-                               const uint8_t* done, float* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
+                               const uint8_t* done, void* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
                                const float* h0, void* stream);
 
 /* Fragment-ordered copy of an LSTM weight for the persistent kernels (H == 256; dst: H * K bf16 elements... K columns
@@ -190,6 +194,16 @@ int vine_weight_grad_mfma(int64_t rows, int64_t M, int64_t Np, int64_t Nv, const
 int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1, int64_t N1p,
                               int64_t Nv1, const void* x2, int64_t ldx2, int64_t N2p, int64_t Nv2, int64_t NT, int64_t slices,
                               float* part1, float* part2, void* stream);
+
+/* The LSTM's two weight gradients with the recurrent operand formed on the fly from the ONE copy of the hidden states that
+ * vine_lstm_seq_forward_mfma writes with c_bf16 bit 1: operand row k = seq * T + t of the second product is
+ * (1 - done[k]) * h_{t-1} = slot t of sequence seq in h_all [rows / T, T + 1, ldh] (16-bit, unmasked; slot 0 = the
+ * initial state).  x1 = the 96-column step-input block (Nv1 stored), 256 hidden units (Nv2 stored); NT = 22 | 21 as in
+ * vine_weight_grad_cat_mfma (the wide tile only); needs 32 % T == 0 and done 16-B aligned.  Same partial sums, bit for
+ * bit, as vine_weight_grad_cat_mfma on the masked [rows, 256] tensor. */
+int vine_weight_grad_cat_seq_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1,
+                                  int64_t Nv1, const void* h_all, int64_t ldh, const uint8_t* done, int64_t T, int64_t Nv2,
+                                  int64_t NT, int64_t slices, float* part1, float* part2, void* stream);
 
 /* Up to VINE_WEIGHT_GRAD_MAX_GROUP products of the small-tile family above (NT in {11, 8, 2}) in ONE launch: problem k
  * takes element k of every array, with the argument meaning of vine_weight_grad_cat_mfma (x1[k] / part1[k] unused when
@@ -312,7 +326,7 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
  * same arithmetic.  ln_partial [n / R, (2 + NH) H] with R = vine_ln_heads_loss_rows() rows per workgroup (128 by default;
  * n % R == 0, n / R <= VINE_PPO_LOSS_BLOCKS): per-workgroup sums {d gamma | d beta | d W} (finish with vine_column_sums).  stats / grad_logstd / grad_mu_bias / grad_value_bias / scratch / kl_out / logstd_grad_accum /
  * mu_store / sigma_store: as in vine_ppo_loss. */
-int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const float* gamma, const float* beta, float eps,
+int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const void* x, const float* gamma, const float* beta, float eps,
                        const float* w, const float* wb, const float* logstd, const float* actions, const float* old_neglogp,
                        const float* advantages, const float* old_values, const float* returns, const float* old_mu,
                        const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
@@ -320,8 +334,11 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
                        float* stats, float* grad_logstd, float* grad_mu_bias, float* grad_value_bias, float* scratch,
                        float* kl_out, float* logstd_grad_accum, float* mu_store, float* sigma_store, const float* loss_scale,
                        float* found_inf, void* stream);
-/* dx_bf16: dx is stored in the library's 16-bit format (vine_lp16_format()).  loss_scale: as in vine_ppo_loss.  found_inf
- * (nullable, device): set to 1.0 when a 16-bit dx element overflows the format or is NaN. */
+/* dx_bf16 bit 0: dx is stored in the library's 16-bit format (vine_lp16_format()).  Bit 1 (needs bit 0): x is in that
+ * format too -- what an autocast LSTM hands its LayerNorm; otherwise x is fp32.  Bits 8-15 = T > 0 (needs bit 1): x is the
+ * [n / T, T + 1, H] tensor vine_lstm_seq_forward_mfma writes with c_bf16 bit 1 and sample seq * T + t is slot t + 1 of
+ * sequence seq; 0: x is [n, H].  loss_scale: as in vine_ppo_loss.  found_inf (nullable, device): set to 1.0 when a
+ * 16-bit dx element overflows the format or is NaN. */
 int vine_ln_heads_loss_rows(void);
 
 /* "fp16" (default build: IEEE half operands, the reference's autocast dtype; needs the loss scaling above) or "bf16"

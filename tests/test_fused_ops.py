@@ -527,6 +527,65 @@ def test_weight_grad_cat_matches_float64_products(n, width, wide, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(8192, 4), (512, 8), (4096, 1), (64, 2)])
+def test_hidden_states_stored_once(B, T):
+    """"h once": the persistent forward kernel writes ONE 16-bit, unmasked copy of the hidden states (+ the 16-bit h0)
+    ([B, T + 1, H], slot 0 = h0) instead of fp32 for the LayerNorm and masked 16-bit for the recurrent weight gradient,
+    and vine_weight_grad_cat_seq_mfma masks that copy itself.  Against the two-copy form, bit for bit: the 16-bit
+    states are the rounded fp32 ones, every other forward output is unchanged, and the weight gradients' partial sums are
+    those of vine_weight_grad_cat_mfma on the masked tensor."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(23)
+    lib = fused._lib()
+    H, width, wpad = 256, 92, 96
+    bf = fused.lp_dtype()
+    xfull = torch.zeros(B * T, wpad, device=dev, dtype=bf)
+    xfull[:, :width] = (torch.randn(B * T, width, device=dev) * 0.7).to(bf)
+    w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
+    w_hh = (torch.randn(4 * H, H, device=dev) / 16).to(bf)
+    bias = torch.randn(4 * H, device=dev) * 0.1
+    h0, c0 = torch.randn(B, H, device=dev) * 0.5, torch.randn(B, H, device=dev) * 0.5
+    dones = (torch.rand(B * T, device=dev) < 0.25).to(torch.uint8)
+    wtile, whh_tiled = torch.empty(4 * H * (wpad + H), device=dev, dtype=bf), torch.empty(4 * H * H, device=dev, dtype=bf)
+    prep = fused.CopyBatch()
+    prep.add_lstm_tiles(w_ih, w_hh, wpad, wtile, whh_tiled)
+    prep.flush(xfull)
+
+    def forward(h_once):
+        bufs = fused._lstm_state_buffers(xfull, w_hh, h0, c0, dones, T, True, prep=fused.CopyBatch(), copy_c0=False, c_dtype=bf,
+                                         mask_h0=False, h_once=h_once)
+        for b in bufs:
+            if b is not None:
+                b.view(torch.int16 if b.dtype == bf else torch.int32).fill_(-1)      # NaN patterns: every element must be written
+        c_last = torch.empty(B, H, device=dev)
+        out, c_all, gates, hp = fused._lstm_forward_steps(lib, xfull, None, w_hh, bias, h0, c0, dones, T, True, buffers=bufs,
+                                                          c0_direct=c0, wtile=wtile, c_last=c_last, h0_direct=h0)
+        return out, c_all, gates, hp, c_last
+    out2, c2, g2, hp2, cl2 = forward(False)
+    out1, c1, g1, hp1, cl1 = forward(True)
+    torch.cuda.synchronize()
+    assert out1.dtype == bf and out1.shape == (B * (T + 1), H) and hp1 is None
+    slots = out1.view(B, T + 1, H)
+    assert torch.equal(slots[:, 1:], out2.to(bf).view(B, T, H)) and torch.equal(slots[:, 0], h0.to(bf))
+    assert torch.equal(g1, g2) and torch.equal(c1[1:T], c2[1:T]) and torch.equal(cl1, cl2)
+    # the operand the recurrent weight gradient needs, rebuilt from the one copy, is the masked tensor of the two-copy form
+    assert torch.equal(fused.masked_previous_hidden(out1, dones, T), hp2.view(B * T, H))
+    n, M = B * T, 4 * H
+    dG = (torch.randn(n, M, device=dev) * 0.1).to(bf)
+    o1, o2, a1, a2 = (torch.empty(M, w_, device=dev) for w_ in (width, H, width, H))
+    plan = fused._wgrad_cat_plan(dG, xfull[:, :width], hp2.view(n, H), o1, o2)
+    if plan is None or plan[6] not in (21, 22):      # (too few rows for the wide tile: the forward half was the test)
+        assert not fused.weight_grad_cat(dG, xfull[:, :width], out1, a1, a2, seq=(dones, T))
+        return
+    assert fused.weight_grad_cat(dG, xfull[:, :width], hp2.view(n, H), o1, o2)
+    assert fused.weight_grad_cat(dG, xfull[:, :width], out1, a1, a2, seq=(dones, T))
+    torch.cuda.synchronize()
+    assert torch.equal(a1, o1) and torch.equal(a2, o2)
+    # a sequence length the kernel's stage layout does not cover is refused (callers build the masked tensor in torch)
+    assert not fused.weight_grad_cat(dG, xfull[:, :width], out1, a1, a2, seq=(dones, 3))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,stride,off", [(128, 256, 256, 0), (64, 128, 128, 0), (256, 28, 96, 64), (256, 18, 32, 0)])
 def test_weight_grad_cat_single_operand(M, N, stride, off):
     """The MLP's weight gradients through the same kernel (no first operand): [128, 256] and [64, 128] with 128-wide
@@ -1011,6 +1070,77 @@ def test_ln_heads_loss_kernel_matches_float64_autograd(clip_value):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 32768])
+def test_ln_heads_loss_kernel_16bit_input(n):
+    """vine_ln_heads_loss reading the LSTM output in the 16-bit format (dx_bf16 bit 1: other column ownership per lane,
+    all rows requested up front and kept in registers) against the same kernel fed the SAME values as fp32: every output
+    agrees to summation-order accuracy, dx to one 16-bit ulp."""
+    from vine_robot_isaacgymenvs_amd.abi import PPO_LOSS_SCRATCH_FLOATS
+    dev = torch.device("cuda:0")
+    torch.manual_seed(12)
+    H, A = 256, 2
+    NH = A + 1
+    lib = fused._lib()
+    bf = fused.lp_dtype()
+    x16 = (torch.randn(n, H, device=dev) * 0.6 + 0.1).to(bf)
+    x32 = x16.float()
+    gamma, beta = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+    w, wb = torch.randn(NH, H, device=dev) * 0.05, torch.randn(NH, device=dev) * 0.1
+    logstd = torch.tensor([-0.3, 0.2], device=dev)
+    actions = torch.randn(n, A, device=dev)
+    old_mu, old_sigma = 0.5 * actions + 0.1 * torch.randn(n, A, device=dev), torch.rand(n, A, device=dev) * 0.5 + 0.7      # (moderate probability ratios: no 16-bit overflow)
+    old_nlp = (0.5 * (((actions - old_mu) / old_sigma) ** 2).sum(-1) + 0.9189385 * A + old_sigma.log().sum(-1))
+    adv, old_values, returns = torch.randn(n, device=dev), torch.randn(n, device=dev), torch.randn(n, device=dev)
+    scal = (0.2, 1, 2.0, 0.01, 0.0001, 1.1)
+    R = lib.vine_ln_heads_loss_rows()
+    st = torch.cuda.current_stream().cuda_stream
+    scale, found = torch.full((1,), 4.0, device=dev), torch.zeros(1, device=dev)
+
+    def run(x, flags):
+        o = dict(heads=torch.empty(n, NH, device=dev), dx=torch.empty(n, H, device=dev, dtype=bf),
+                 part=torch.empty(n // R, (2 + NH) * H, device=dev), stats=torch.empty(8, device=dev),
+                 gls=torch.empty(A, device=dev), gmb=torch.zeros(A, device=dev), gvb=torch.zeros(1, device=dev),
+                 kl=torch.zeros(1, device=dev), acc=torch.zeros(A, device=dev), mu=torch.empty(n, A, device=dev),
+                 sg=torch.empty(n, A, device=dev))
+        scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=dev)
+        for _ in range(2):      # twice: the ticket is back at zero, the accumulating outputs are re-zeroed
+            o["gmb"].zero_(); o["gvb"].zero_(); o["acc"].zero_()
+            assert lib.vine_ln_heads_loss(n, H, NH, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(),
+                                          wb.data_ptr(), logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(),
+                                          adv.data_ptr(), old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(),
+                                          old_sigma.data_ptr(), *scal, o["heads"].data_ptr(), o["dx"].data_ptr(), flags,
+                                          o["part"].data_ptr(), o["stats"].data_ptr(), o["gls"].data_ptr(),
+                                          o["gmb"].data_ptr(), o["gvb"].data_ptr(), scratch.data_ptr(), o["kl"].data_ptr(),
+                                          o["acc"].data_ptr(), o["mu"].data_ptr(), o["sg"].data_ptr(), scale.data_ptr(),
+                                          found.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        return o
+    a, b = run(x16, 3), run(x32, 1)
+    assert float(found) == 0.0
+    # ... and reading the samples from slots 1 .. T of a [n / T, T + 1, H] tensor (the LSTM kernel's "h once" layout)
+    for T in (4, 1, 8):
+        xs = torch.full((n // T, T + 1, H), float("nan"), device=dev, dtype=bf)
+        xs[:, 1:] = x16.view(n // T, T, H)
+        c = run(xs, 3 | (T << 8))
+        for k in a:
+            assert torch.equal(a[k], c[k]), (T, k)
+    rel = lambda u, v: float((u.double() - v.double()).abs().max() / (v.double().abs().max() + 1e-12))
+    assert rel(a["heads"], b["heads"]) < 2e-6 and rel(a["mu"], b["mu"]) < 2e-6 and torch.equal(a["sg"], b["sg"])
+    assert torch.allclose(a["dx"].float(), b["dx"].float(), rtol=4e-3, atol=2.4e-7)
+    assert rel(a["part"].sum(0), b["part"].sum(0)) < 1e-5
+    for k in ("stats", "gls", "gmb", "gvb", "kl", "acc"):
+        assert rel(a[k], b[k]) < 1e-5, k
+    # 16-bit input with an fp32 gradient is not a supported combination
+    assert lib.vine_ln_heads_loss(n, H, NH, x16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(),
+                                  wb.data_ptr(), logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
+                                  old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
+                                  a["heads"].data_ptr(), a["dx"].data_ptr(), 2, a["part"].data_ptr(), a["stats"].data_ptr(),
+                                  a["gls"].data_ptr(), a["gmb"].data_ptr(), a["gvb"].data_ptr(), a["part"].data_ptr(),
+                                  a["kl"].data_ptr(), a["acc"].data_ptr(), a["mu"].data_ptr(), a["sg"].data_ptr(), None, None,
+                                  st) == -2
+
+
+@pytest.mark.gpu
 def test_ppo_loss_kernel_against_reference_text_golden():
     """Golden F8 through the HIP loss kernel: the means of the actor, clipped-critic and bound (soft bound 1.0) terms the
     reference's in-tree text computes per sample (isaacgymenvs/learning/common_agent.py:482-516, 427-435)."""
@@ -1174,6 +1304,53 @@ def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
     assert torch.equal(m1, m2)
     assert s1 == s2, (s1, s2)
     assert torch.equal(p1, p2)
+
+
+@pytest.mark.gpu
+def test_default_update_stores_the_hidden_states_once(monkeypatch):
+    """The default (mixed-precision) update takes the "h once" route -- one 16-bit copy of the LSTM's hidden states read
+    by the loss kernel and by the weight-gradient kernel -- and lands where the two-copy route (fp32 states for the
+    LayerNorm) lands, to the rounding of the LayerNorm's input."""
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    calls = {"seq": 0, "plain": 0}
+    real = fused.weight_grad_cat
+
+    def counting(dy, x1, x2, out1, out2, batch=None, seq=None):
+        ok = real(dy, x1, x2, out1, out2, batch=batch, seq=seq)
+        if ok and x1 is not None:
+            calls["seq" if seq is not None else "plain"] += 1
+        return ok
+    monkeypatch.setattr(fused, "weight_grad_cat", counting)
+    outs = []
+    for h_once in (True, False):
+        monkeypatch.setattr(fused, "H_ONCE", h_once)
+        cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048"])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False, use_graphs=False)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        assert agent.fused_mixed
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        before = dict(calls)
+        for _ in range(2):
+            _, _, stats = agent.train_epoch()
+        torch.cuda.synchronize()
+        steps = 2 * agent.mini_epochs_num * agent.num_minibatches
+        assert calls["seq" if h_once else "plain"] - before["seq" if h_once else "plain"] == steps
+        assert calls["plain" if h_once else "seq"] == before["plain" if h_once else "seq"]
+        outs.append((torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone(),
+                     {k: float(v) for k, v in stats.items()}))
+        env.close()
+    (p1, s1), (p2, s2) = outs
+    assert torch.isfinite(p1).all() and float((p1 - p2).abs().max()) < 3e-3, float((p1 - p2).abs().max())
+    for k in s1:
+        assert abs(s1[k] - s2[k]) < 2e-2 * (1 + abs(s2[k])), (k, s1[k], s2[k])
 
 
 @pytest.mark.gpu

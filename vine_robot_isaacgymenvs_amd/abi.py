@@ -209,6 +209,8 @@ PPO_PROTOTYPES = {
     "vine_weight_grad_group": (C.c_int, [C.c_int32] + [_VP] * 16 + [_VP]),
     "vine_weight_grad_cat_mfma": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _I64, _I64, _VP, _I64, _I64, _I64, _I64, _I64,
                                             _VP, _VP, _VP]),
+    "vine_weight_grad_cat_seq_mfma": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _I64, _I64,
+                                                _VP, _VP, _VP]),
     "vine_layernorm_forward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP]),
     "vine_layernorm_backward": (C.c_int, [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_layernorm_heads_forward": (C.c_int, [_I64, _I64, _I64, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),

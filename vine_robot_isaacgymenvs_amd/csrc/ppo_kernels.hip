@@ -503,11 +503,16 @@ __device__ __forceinline__ uint4 pack_lp16x8(const float (&v)[8]) {
 
 // CT: storage type of the saved cell states c_1 .. c_{T-1} (read again by the backward kernel only): float, or lp16_t
 // -- the recurrence itself always runs on the fp32 registers, and c_T then goes to `c_last` in fp32.
-template <int KS1, int RING, typename CT>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
+// HT: type of the hidden states written out.  float: h_out [B*T, H] fp32 for the LayerNorm, and the MASKED 16-bit h_{t-1}
+// a second time into `hp` (slot t) for the recurrent weight gradient.  lp16_t ("h once"): h_out [B, T + 1, H] in the
+// 16-bit format, unmasked, is the only copy -- slot 0 = h0, slot t + 1 = h_t; the LayerNorm reads slots 1 .. T as an
+// autocast LSTM's output, the weight-gradient kernel reads slots 0 .. T - 1 and applies done[k] itself (`hp` unused):
+// 30 MB fewer stores per launch at the update's shape.
+template <int KS1, int RING, typename CT, typename HT>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
 __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     int T, long long B, const lp16_t* __restrict__ x, long long ldx, lp16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
-    const unsigned char* __restrict__ done, float* __restrict__ h_out, CT* __restrict__ c_all,
+    const unsigned char* __restrict__ done, HT* __restrict__ h_out, CT* __restrict__ c_all,
     lp16_t* __restrict__ gates, int ablate, float* __restrict__ c_last, const float* __restrict__ h0) {
     constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
     constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
@@ -548,7 +553,12 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 const float4 a = ld4(h0 + (b0 + r) * H + 8 * c8), b = ld4(h0 + (b0 + r) * H + 8 * c8 + 4);
                 const float v[8] = {keep0 * a.x, keep0 * a.y, keep0 * a.z, keep0 * a.w, keep0 * b.x, keep0 * b.y, keep0 * b.z, keep0 * b.w};
                 hv = pack_lp16x8(v);
-                *reinterpret_cast<uint4*>(hp + (b0 + r) * hp_stride + 8 * c8) = hv;
+                if (sizeof(HT) == 2) {      // "h once": slot 0 of h_out receives the UNMASKED 16-bit h0
+                    const float u8[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    *reinterpret_cast<uint4*>(reinterpret_cast<lp16_t*>(h_out) + (b0 + r) * (T + 1) * H + 8 * c8) = pack_lp16x8(u8);
+                } else {
+                    *reinterpret_cast<uint4*>(hp + (b0 + r) * hp_stride + 8 * c8) = hv;
+                }
             } else {
                 hv = *reinterpret_cast<const uint4*>(hp + (b0 + r) * hp_stride + 8 * c8);      // slot 0: masked h_{-1}
             }
@@ -614,8 +624,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
             const float kn = ((dmask[rt] >> (t + 1)) & 1u) ? 0.0f : 1.0f;
             CT* cp = c_all + ((long long)(t + 1) * B + b) * H + U0;
             float* cl = c_last + b * H + U0;                       // (only dereferenced in the low-precision mode)
-            float* hpo = h_out + (b * T + t) * H + U0;
-            uint2 lo[5];                                         // i, f, g, o, masked h of tile 0
+            HT* hpo = h_out + (sizeof(HT) == 2 ? b * (T + 1) + t + 1 : b * T + t) * H + U0;
+            uint2 lo[6];                                         // i, f, g, o, masked h, h of tile 0
 #pragma unroll
             for (int ut = 0; ut < 2; ++ut) {
                 const float4 bi = *reinterpret_cast<const float4*>(&bias_l[0 * H + U0 + 4 * ut]);
@@ -639,9 +649,10 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     const float4 cv = make_float4(c[rt][4 * ut], c[rt][4 * ut + 1], c[rt][4 * ut + 2], c[rt][4 * ut + 3]);
                     if (sizeof(CT) == 2 && last) st4(cl + 4 * ut, cv);
                     else st4(cp + 4 * ut, cv);
-                    st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
+                    if (sizeof(HT) == 4) st4(hpo + 4 * ut, make_float4(hn[0], hn[1], hn[2], hn[3]));
                 }
-                uint2 pk[5];
+                uint2 pk[6];
+                pk[5] = make_uint2(f2lp2(hn[0], hn[1]), f2lp2(hn[2], hn[3]));
                 pk[0] = make_uint2(f2lp2(gi[0], gi[1]), f2lp2(gi[2], gi[3]));
                 pk[1] = make_uint2(f2lp2(gf[0], gf[1]), f2lp2(gf[2], gf[3]));
                 pk[2] = make_uint2(f2lp2(gg[0], gg[1]), f2lp2(gg[2], gg[3]));
@@ -649,8 +660,10 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 pk[4] = make_uint2(f2lp2(kn * hn[0], kn * hn[1]), f2lp2(kn * hn[2], kn * hn[3]));
                 if (ut == 0) {
 #pragma unroll
-                    for (int a = 0; a < 5; ++a) lo[a] = pk[a];
+                    for (int a = 0; a < 6; ++a) lo[a] = pk[a];
                 } else {
+                    if (sizeof(HT) == 2 && !(ablate & 1))
+                        *reinterpret_cast<uint4*>(hpo) = make_uint4(lo[5].x, lo[5].y, pk[5].x, pk[5].y);
                     if (gates && !(ablate & 1)) {
                         lp16_t* ga = gates + ((long long)t * B + b) * 4 * H + U0;
 #pragma unroll
@@ -660,7 +673,8 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     if (!last) {   // the masked state step t + 1 consumes: next operand (LDS) + weight-gradient operand (HBM)
                         const uint4 hm = make_uint4(lo[4].x, lo[4].y, pk[4].x, pk[4].y);
                         *reinterpret_cast<uint4*>(&xn[(16 * rt + col) * PITCH + KX + U0]) = hm;
-                        if (!(ablate & 1)) *reinterpret_cast<uint4*>(hp + b * hp_stride + (long long)(t + 1) * H + U0) = hm;
+                        if (sizeof(HT) == 4 && !(ablate & 1))
+                            *reinterpret_cast<uint4*>(hp + b * hp_stride + (long long)(t + 1) * H + U0) = hm;
                     }
                 }
             }
@@ -1904,16 +1918,23 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroupArgs G) {
 // the row slices (32: 46 MB of partial sums).  With one stage of prefetch the kernel is bound by the latency of its
 // own loads (32 stages x 1.4 us); two stages are kept in flight in two named register sets (the loop is unrolled by two
 // so that the set is a compile-time choice; an indexed array lands in scratch memory).
+// SEQ ("h once"): the second operand is formed on the fly from the LSTM's one copy of its hidden states -- row k = seq * T + t
+// of the operand is (1 - done[k]) * h_{t-1} = slot t of x2 = the 16-bit h_out [rows / T, T + 1, ldx2] of
+// vine_lstm_seq_forward_mfma, i.e. its row k + k / T.  T divides 32 and a stage starts on a multiple of 32, so a stage
+// advances every piece by the same 32 + 32 / T rows: one base pointer per piece and a uniform stride, as before.
+// The done flags of the workgroup's row slice are packed once, in the prologue, into one 32-bit word per stage (LDS);
+// a piece is zeroed on its way to LDS when its row's bit is set (a byte load per piece and stage instead cost 4.5 us).
 template <int NT1, int MT>      // MT = 16-row MFMA tiles per wave along M: workgroup tile = (64 MT) x 352
 __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mtiles, int slices, const lp16_t* __restrict__ dy,
                                                              long long ldy, const lp16_t* __restrict__ x1, long long ldx1,
                                                              const lp16_t* __restrict__ x2, long long ldx2,
                                                              float* __restrict__ part1, int Nv1, float* __restrict__ part2,
-                                                             int Nv2, int M) {
+                                                             int Nv2, int M, const unsigned char* __restrict__ done, int T) {
     constexpr int NT = 11, WM = 4, WN = 2, TH = 64 * WM * WN;
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN, N1 = 16 * NT1, N2 = BN - N1;
     constexpr int PA = BM + 16, PB = BN + 16;
     constexpr int APC = BM / 8, AP = 32 * APC;                  // 16-B pieces per A row / per A stage
+    const bool SEQ = done != nullptr;
     constexpr int B1C = N1 / 8, B1P = 32 * B1C, B2C = N2 / 8, B2P = 32 * B2C;
     static_assert(AP <= TH && AP % 64 == 0 && B1P + B2P <= 3 * TH && B1P + B2P > 2 * TH && B1P % 64 == 0 &&
                       (B1P + B2P) % 64 == 0,
@@ -1935,6 +1956,7 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
     const int aoff = (ap / APC) * PA + 8 * (ap % APC);
 #define WGW_SRC(i)                                                                                             \
     const lp16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
+    unsigned dbit##i = 0;                         /* SEQ: this piece's row bit in a stage's done word (x2 pieces only) */ \
     {                                                                                                          \
         const int p = tid + TH * (i);                                                                          \
         bval##i = p < B1P + B2P;                                                                               \
@@ -1943,13 +1965,30 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
             boff##i = (p / B1C) * PB + 8 * (p % B1C);                                                          \
         } else {                                                                                               \
             const int p2 = bval##i ? p - B1P : 0;                                                              \
-            bsrc##i = x2 + (k0 + p2 / B2C) * ldx2 + 8 * (p2 % B2C); bstep##i = 32 * ldx2;                      \
-            boff##i = (p2 / B2C) * PB + N1 + 8 * (p2 % B2C);                                                   \
+            const int r2 = p2 / B2C;                                                                           \
+            /* (the plain form passes T = 2^30: row k, 32 rows per stage) */                                    \
+            if (SEQ && bval##i) dbit##i = 1u << r2;                                                            \
+            bsrc##i = x2 + (k0 + r2 + (k0 + r2) / T) * ldx2 + 8 * (p2 % B2C); bstep##i = (32 + 32 / T) * ldx2; \
+            boff##i = r2 * PB + N1 + 8 * (p2 % B2C);                                                           \
         }                                                                                                      \
     }
     WGW_SRC(0) WGW_SRC(1) WGW_SRC(2)
 #undef WGW_SRC
     uint4 ra_e, rb0_e, rb1_e, rb2_e, ra_o, rb0_o, rb1_o, rb2_o;     // stages of even / odd index in flight
+    __shared__ unsigned dwords[1024];                            // SEQ: bit r of word `it` = done[k0 + 32 it + r]
+    if (SEQ) {
+        for (int it = tid; it < stages; it += TH) {
+            const uint4 a = *reinterpret_cast<const uint4*>(done + k0 + 32 * it);
+            const uint4 b = *reinterpret_cast<const uint4*>(done + k0 + 32 * it + 16);
+            const unsigned q[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            unsigned wbits = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wbits |= (((q[c] >> (8 * e)) & 0xffu) ? 1u : 0u) << (4 * c + e);
+            dwords[it] = wbits;
+        }
+    }
 #define WGW_LOAD(S, it)                                                                                        \
     {                                                                                                          \
         const long long t_ = (it) < stages ? (it) : stages - 1;   /* past the end: a harmless re-read */        \
@@ -1959,11 +1998,18 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
         rb2_##S = *reinterpret_cast<const uint4*>(bsrc2 + t_ * bstep2);                                        \
         __builtin_amdgcn_sched_barrier(0);   /* requests leave before the products, not after them */          \
     }
-#define WGW_STORE(S, buf)                                                                                      \
-    if (aval) *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_##S;                                              \
-    *reinterpret_cast<uint4*>(&bl[buf][boff0]) = rb0_##S;                                                      \
-    *reinterpret_cast<uint4*>(&bl[buf][boff1]) = rb1_##S;                                                      \
-    if (bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = rb2_##S;
+    /* branch-free: an all-ones / all-zeros word per piece, ANDed in (a select on the uint4 became exec-masked moves) */ \
+#define WGW_MASKED(v, bit)                                                                                     \
+    ([&] { const unsigned m_ = (dw_##bit) ? 0u : 0xffffffffu; return make_uint4((v).x & m_, (v).y & m_, (v).z & m_, (v).w & m_); }())
+#define WGW_STORE(S, buf, it)                                                                                  \
+    {                                                                                                          \
+        const unsigned dw_ = SEQ ? dwords[(it) < stages ? (it) : stages - 1] : 0u;                             \
+        const unsigned dw_dbit0 = dw_ & dbit0, dw_dbit1 = dw_ & dbit1, dw_dbit2 = dw_ & dbit2;                 \
+        if (aval) *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_##S;                                          \
+        *reinterpret_cast<uint4*>(&bl[buf][boff0]) = WGW_MASKED(rb0_##S, dbit0);                               \
+        *reinterpret_cast<uint4*>(&bl[buf][boff1]) = WGW_MASKED(rb1_##S, dbit1);                               \
+        if (bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = WGW_MASKED(rb2_##S, dbit2);                    \
+    }
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1976,32 +2022,37 @@ __global__ __launch_bounds__(512) void wgrad_cat_wide_kernel(int stages, int mti
     {                                                                                                          \
         const lp16_t* ab = al[buf];                                                                            \
         const lp16_t* bb = bl[buf];                                                                            \
-        lp16x8_t af[MT];                                                                                       \
+        lp16x8_t af[MT], bfr[NT];                                                                              \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = tr_read8(ab + ra + 16 * mt, 16 * PA);       \
+        /* every fragment of the stage requested before the first product (the scheduler, left alone, sometimes     \
+           pairs each read with its own wait: 57 instead of 50 us) */                                            \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bfr[nt] = tr_read8(bb + rb + 16 * nt, 16 * PB);      \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                    \
-            const lp16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);                                         \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                  \
-                acc[mt][nt] = MFMA_LP16(af[mt], bfr, acc[mt][nt]);      \
+                acc[mt][nt] = MFMA_LP16(af[mt], bfr[nt], acc[mt][nt]);                                         \
         }                                                                                                      \
     }
     // invariant at the top of an even stage `it`: LDS buffer 0 holds stage it, the odd set holds stage it + 1 (in flight)
     WGW_LOAD(e, 0)
     WGW_LOAD(o, 1)
-    WGW_STORE(e, 0)
+    if (SEQ) __syncthreads();                                    // the done words
+    WGW_STORE(e, 0, 0)
     __syncthreads();
 #pragma unroll 1
     for (int it = 0; it < stages; it += 2) {                     // stages is even (host check)
         WGW_LOAD(e, it + 2)
         WGW_COMPUTE(0)
-        WGW_STORE(o, 1)
+        WGW_STORE(o, 1, it + 1)
         __syncthreads();
         WGW_LOAD(o, it + 3)
         WGW_COMPUTE(1)
-        WGW_STORE(e, 0)
+        WGW_STORE(e, 0, it + 2)
         __syncthreads();
     }
 #undef WGW_LOAD
 #undef WGW_STORE
+#undef WGW_MASKED
 #undef WGW_COMPUTE
     // D[m = 4g + r][n = il] of tile (mt, nt); tiles below NT1 (global tile index) belong to part1, the rest to part2
     const long long mrow = (long long)slice * M + m0 + wm * MT * 16 + 4 * g;
@@ -2933,9 +2984,13 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // cl + 16 j, j = 0..3, of row `sub`), so that a LayerNorm / head reduction is four DPP rotate-adds inside a 16-lane row
 // instead of a wave-wide sum (9 DPP steps + a readlane, one row at a time: that version took 39 us).  NP passes of 4
 // rows per wave; the rows are re-read in phase 3 (L2 hits) rather than kept in 64 registers.
-template <int NH, int NP, typename DXT>      // DXT: type of the gradient handed to the LSTM backward (float or lp16_t)
+// XT = lp16_t (the LSTM output as the 16-bit tensor an autocast LSTM hands its LayerNorm): a lane then owns 8
+// consecutive columns twice (16-B loads, 16-B dx stores), ALL rows of the wave and the per-sample loss inputs are
+// requested before anything is computed and the rows stay in registers (32 per lane) for phase 3 -- the fp32 form spends
+// most of its life in nine dependent memory round trips (SQ_WAIT_ANY 64 % of its wave cycles).
+template <int NH, int NP, typename DXT, typename XT>      // DXT: type of the gradient handed to the LSTM backward (float or lp16_t)
 __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
-    long long n, const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    long long n, const XT* __restrict__ x, int xT, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const float* __restrict__ w, const float* __restrict__ wb, const float* __restrict__ logstd,
     const float* __restrict__ actions, const float* __restrict__ old_neglogp, const float* __restrict__ adv,
     const float* __restrict__ old_values, const float* __restrict__ returns, const float* old_mu, const float* old_sigma,
@@ -2954,17 +3009,56 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, cl = lane & 15;
     const long long r0 = ((long long)blockIdx.x * NWV + wave) * RW;
+    constexpr bool X16 = sizeof(XT) == 2;
+    // first column of the lane's j-th group of 4: fp32 rows in 16-B pieces (columns 4 (cl + 16 j)), 16-bit rows in 16-B
+    // pieces of 8 columns (groups 2 jj, 2 jj + 1 = columns 8 (cl + 16 jj) .. + 7)
+#define LHL_COL(j) (X16 ? 8 * (cl + 16 * ((j) >> 1)) + 4 * ((j) & 1) : 4 * (cl + 16 * (j)))
+    // 16-bit rows: every row of the wave and the per-sample loss inputs are requested here, ahead of the parameters
+    uint4 xq[X16 ? NP : 1][2];
+    float q_act[A], q_om[A], q_os[A], q_onl = 0.0f, q_adv = 0.0f, q_ov = 0.0f, q_ret = 0.0f;
+    if (X16) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            // xT > 0: x is the [n / xT, xT + 1, H] tensor of vine_lstm_seq_forward_mfma's "h once" form (slot 0 = h0):
+            // sample r = seq * xT + t is its row r + seq + 1
+            const long long r_ = r0 + 4 * p + sub;
+            const XT* xr = x + (xT > 0 ? r_ + r_ / xT + 1 : r_) * H;
+            xq[p][0] = *reinterpret_cast<const uint4*>(xr + 8 * cl);
+            xq[p][1] = *reinterpret_cast<const uint4*>(xr + 8 * (cl + 16));
+        }
+        if (cl < NP) {
+            const long long i = r0 + 4 * cl + sub;
+#pragma unroll
+            for (int k = 0; k < A; ++k) { q_act[k] = actions[i * A + k]; q_om[k] = old_mu[i * A + k]; q_os[k] = old_sigma[i * A + k]; }
+            q_onl = old_neglogp[i]; q_adv = adv[i]; q_ov = old_values[i]; q_ret = returns[i];
+        }
+    }
     float gm[4][4], bt[4][4], wv[NH][4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float4 g4 = ld4(gamma + 4 * (cl + 16 * j)), b4 = ld4(beta + 4 * (cl + 16 * j));
+        const float4 g4 = ld4(gamma + LHL_COL(j)), b4 = ld4(beta + LHL_COL(j));
         gm[j][0] = g4.x; gm[j][1] = g4.y; gm[j][2] = g4.z; gm[j][3] = g4.w;
         bt[j][0] = b4.x; bt[j][1] = b4.y; bt[j][2] = b4.z; bt[j][3] = b4.w;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const float4 t = ld4(w + h * H + 4 * (cl + 16 * j));
+            const float4 t = ld4(w + h * H + LHL_COL(j));
             wv[h][j][0] = t.x; wv[h][j][1] = t.y; wv[h][j][2] = t.z; wv[h][j][3] = t.w;
         }
+    }
+    // the 16 values of a lane's share of a row, from the packed registers (16-bit) or from memory (fp32)
+#define LHL_ROW(p, r, dst)                                                                                        \
+    if (X16) {                                                                                                    \
+        float lo_[8], hi_[8];                                                                                     \
+        unpack_lp16x8(xq[X16 ? (p) : 0][0], lo_);                                                                 \
+        unpack_lp16x8(xq[X16 ? (p) : 0][1], hi_);                                                                 \
+        _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                        \
+            dst[0][u_] = lo_[u_]; dst[1][u_] = lo_[4 + u_]; dst[2][u_] = hi_[u_]; dst[3][u_] = hi_[4 + u_];       \
+        }                                                                                                         \
+    } else {                                                                                                      \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                        \
+            const float4 v_ = ld4(x + (r) * H + 4 * (cl + 16 * j_));                                              \
+            dst[j_][0] = v_.x; dst[j_][1] = v_.y; dst[j_][2] = v_.z; dst[j_][3] = v_.w;                           \
+        }                                                                                                         \
     }
     // ---- phase 1: LayerNorm statistics and heads of 4 rows per pass; lane (sub, cl = p) keeps row 4 p + sub
     float myp[NH], mymean = 0.0f, myrstd = 0.0f;
@@ -2972,15 +3066,11 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     for (int h = 0; h < NH; ++h) myp[h] = 0.0f;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const float* xr = x + (r0 + 4 * p + sub) * H;
         float xa[4][4];
+        LHL_ROW(p, r0 + 4 * p + sub, xa)
         float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 v = ld4(xr + 4 * (cl + 16 * j));
-            xa[j][0] = v.x; xa[j][1] = v.y; xa[j][2] = v.z; xa[j][3] = v.w;
-            s += (v.x + v.y) + (v.z + v.w);
-        }
+        for (int j = 0; j < 4; ++j) s += (xa[j][0] + xa[j][1]) + (xa[j][2] + xa[j][3]);
         const float mean = row_allsum16(s) * (1.0f / H);
         float q = 0.0f;
 #pragma unroll
@@ -3030,12 +3120,12 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
         }
 #pragma unroll
         for (int k = 0; k < A; ++k) {
-            dm[k] = actions[i * A + k] - myp[k];
+            dm[k] = (X16 ? q_act[k] : actions[i * A + k]) - myp[k];
             z2[k] = dm[k] * dm[k] * isg2[k];
             nlp += 0.5f * z2[k];
         }
-        const float a = adv[i];
-        const float ratio = __expf(old_neglogp[i] - nlp);
+        const float a = X16 ? q_adv : adv[i];
+        const float ratio = __expf((X16 ? q_onl : old_neglogp[i]) - nlp);
         const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
         const float s1 = -a * ratio, s2 = -a * rc;
         const bool first = s1 >= s2;                     // torch.max sends the tie's gradient to the first operand
@@ -3043,7 +3133,7 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
         const float inside = (ratio > 1.0f - e_clip && ratio < 1.0f + e_clip) ? 1.0f : 0.0f;
         const float dL_dratio = first ? -a : -a * inside;
         const float dL_dnlp = -ratio * dL_dratio * inv_n;
-        const float v = myp[A], vp = old_values[i], R = returns[i];
+        const float v = myp[A], vp = X16 ? q_ov : old_values[i], R = X16 ? q_ret : returns[i];
         float c_loss, dL_dv;
         if (clip_value) {
             const float dv = v - vp;
@@ -3068,7 +3158,7 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
             gh[k] = gmk * S;
             vals[5 + PPO_MAX_A + k] = gmk;
             vals[5 + k] = dL_dnlp * (1.0f - z2[k]);
-            const float om = old_mu[i * A + k], os = old_sigma[i * A + k];
+            const float om = X16 ? q_om[k] : old_mu[i * A + k], os = X16 ? q_os[k] : old_sigma[i * A + k];
             const float c1 = __logf(os / sg[k] + 1e-5f);
             const float c2 = (sg[k] * sg[k] + (om - m) * (om - m)) / (2.0f * (os * os + 1e-5f));
             kl += c1 + c2 - 0.5f;
@@ -3109,13 +3199,13 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
         const float mean = lane_bcast(mymean, src), rstd = lane_bcast(myrstd, src);
         const long long r = r0 + 4 * p + sub;
         float xh[4][4], gg[4][4], s1 = 0.0f, s2 = 0.0f;
+        float xrow[4][4];
+        LHL_ROW(p, r, xrow)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 v = ld4(x + r * H + 4 * (cl + 16 * j));
-            const float xv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                xh[j][u] = (xv[u] - mean) * rstd;
+                xh[j][u] = (xrow[j][u] - mean) * rstd;
                 float dy = 0.0f;
 #pragma unroll
                 for (int h = 0; h < NH; ++h) dy += ghr[h] * wv[h][j][u];
@@ -3131,12 +3221,24 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
         }
         const float m1 = row_allsum16(s1) * (1.0f / H), m2 = row_allsum16(s2) * (1.0f / H);
         bool bad = false;
+        float4 o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 o = make_float4(rstd * (gg[j][0] - m1 - xh[j][0] * m2), rstd * (gg[j][1] - m1 - xh[j][1] * m2),
-                                         rstd * (gg[j][2] - m1 - xh[j][2] * m2), rstd * (gg[j][3] - m1 - xh[j][3] * m2));
-            st4(dx + r * H + 4 * (cl + 16 * j), o);
-            bad = bad || !(fabsf(o.x) <= LP16_MAX) || !(fabsf(o.y) <= LP16_MAX) || !(fabsf(o.z) <= LP16_MAX) || !(fabsf(o.w) <= LP16_MAX);
+            o[j] = make_float4(rstd * (gg[j][0] - m1 - xh[j][0] * m2), rstd * (gg[j][1] - m1 - xh[j][1] * m2),
+                               rstd * (gg[j][2] - m1 - xh[j][2] * m2), rstd * (gg[j][3] - m1 - xh[j][3] * m2));
+            bad = bad || !(fabsf(o[j].x) <= LP16_MAX) || !(fabsf(o[j].y) <= LP16_MAX) || !(fabsf(o[j].z) <= LP16_MAX) ||
+                  !(fabsf(o[j].w) <= LP16_MAX);
+        }
+        if (X16 && sizeof(DXT) == 2) {      // 8 consecutive columns per 16-B store
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const float v8[8] = {o[2 * jj].x, o[2 * jj].y, o[2 * jj].z, o[2 * jj].w,
+                                     o[2 * jj + 1].x, o[2 * jj + 1].y, o[2 * jj + 1].z, o[2 * jj + 1].w};
+                *reinterpret_cast<uint4*>(dx + r * H + 8 * (cl + 16 * jj)) = pack_lp16x8(v8);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st4(dx + r * H + LHL_COL(j), o[j]);
         }
         // a gradient that does not fit the 16-bit format (or is NaN) marks the optimiser step as overflowed: the Adam
         // kernel then skips it and backs the loss scale off, as torch's GradScaler does.  (Plain store of a constant by
@@ -3160,7 +3262,7 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int c = 4 * (cl + 16 * j) + u;
+                const int c = LHL_COL(j) + u;
                 red[wave][c] = dgm[j][u];
                 red[wave][H + c] = dbt[j][u];
 #pragma unroll
@@ -3195,6 +3297,8 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
                           grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, S);
     }
 }
+#undef LHL_COL
+#undef LHL_ROW
 
 // The Adam kernel's last workgroup to finish bumps the step counter and applies the learning-rate schedule (every
 // workgroup has read the old step / lr by then); it resets the ticket, so a launch always finds 0.
@@ -3994,23 +4098,27 @@ static int seq_ablate() {
 
 int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, const void* x, int64_t ldx, void* hp,
                                int64_t hp_stride, const void* w_tiled, const float* bias, const float* c0,
-                               const uint8_t* done, float* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
+                               const uint8_t* done, void* h_out, void* c_all, void* gates, int32_t c_bf16, float* c_last,
                                const float* h0, void* stream) {
-    if (B <= 0 || T <= 0 || !x || !hp || !w_tiled || !bias || !c0 || !h_out || !c_all || ldx < KX || (ldx & 7) ||
-        hp_stride < T * H || (hp_stride & 7) || (c_bf16 && !c_last))
+    const bool h16 = (c_bf16 & 2) != 0;      // bit 1: "h once" (h_out = 16-bit unmasked [B, T + 1, H]; hp unused)
+    c_bf16 &= 1;
+    if (B <= 0 || T <= 0 || !x || (!hp && !h16) || !w_tiled || !bias || !c0 || !h_out || !c_all || ldx < KX || (ldx & 7) ||
+        (!h16 && (hp_stride < T * H || (hp_stride & 7))) || (c_bf16 && !c_last) || (h16 && !h0))
         return VINE_ERR_INVALID_ARG;
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8 || (KX != 32 && KX != 64 && KX != 96 && KX != 128)) return VINE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(B / SEQ_ROWS)), block(512);
     hipStream_t s = (hipStream_t)stream;
     const int ablate = seq_ablate();
-#define VINE_SEQ_FWD_T(KS1, RING, CT)                                                                                   \
-    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT>), grid, block, 0, s, (int)T, (long long)B, (const lp16_t*)x, \
-                       (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, c0, done, h_out, \
-                       (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0)
+#define VINE_SEQ_FWD_T(KS1, RING, CT, HT)                                                                               \
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT>), grid, block, 0, s, (int)T, (long long)B,               \
+                       (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, \
+                       c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0)
 #define VINE_SEQ_FWD(KS1, RING)                                                                                         \
     {                                                                                                                   \
-        if (c_bf16) VINE_SEQ_FWD_T(KS1, RING, lp16_t);                                                                  \
-        else VINE_SEQ_FWD_T(KS1, RING, float);                                                                          \
+        if (h16 && !c_bf16) return VINE_ERR_UNSUPPORTED;                                                                \
+        if (h16) VINE_SEQ_FWD_T(KS1, RING, lp16_t, lp16_t);                                                             \
+        else if (c_bf16) VINE_SEQ_FWD_T(KS1, RING, lp16_t, float);                                                      \
+        else VINE_SEQ_FWD_T(KS1, RING, float, float);                                                                   \
     }
     switch (KX / 32) {
         case 1: VINE_SEQ_FWD(1, 24) break;      // 72 fragments per step
@@ -4294,6 +4402,45 @@ int vine_weight_grad_group(int32_t nprob, const int64_t* rows, const int64_t* M,
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+// one (128 | 64) x 352 tile per workgroup over [x1 96 | x2 256]; seq: the "h once" form of the second operand
+static int wgrad_cat_wide_launch(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1,
+                                 int64_t Nv1, const void* x2, int64_t ldx2, int64_t Nv2, int64_t NT, int64_t slices,
+                                 float* part1, float* part2, const uint8_t* done, int64_t T, void* stream) {
+    const int bm = NT == 22 ? 128 : 64;
+    if ((M % bm) || (slices & 7) || rows % (slices * 64) || slices > 8192) return VINE_ERR_UNSUPPORTED;
+    const int mtiles = (int)(M / bm), stages = (int)(rows / slices / 32);
+    const size_t lds = (size_t)2 * 32 * ((bm + 16) + (352 + 16)) * sizeof(lp16_t);      // 64 / 56 KiB
+#define VINE_WGW(MT_)                                                                                                     \
+    {                                                                                                                     \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            if (hipFuncSetAttribute((const void*)wgrad_cat_wide_kernel<6, MT_>,                                           \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                  \
+                return VINE_ERR_DEVICE;                                                                                   \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((wgrad_cat_wide_kernel<6, MT_>), dim3((unsigned)(mtiles * slices)), dim3(512), lds,            \
+                           (hipStream_t)stream, stages, mtiles, (int)slices, (const lp16_t*)dy, (long long)ldy,           \
+                           (const lp16_t*)x1, (long long)ldx1, (const lp16_t*)x2, (long long)ldx2, part1, (int)Nv1,       \
+                           part2, (int)Nv2, (int)M, done, done ? (int)T : (1 << 30));                                     \
+    }
+    if (NT == 22) VINE_WGW(2)
+    else VINE_WGW(1)
+#undef VINE_WGW
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_weight_grad_cat_seq_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1,
+                                  int64_t Nv1, const void* h_all, int64_t ldh, const uint8_t* done, int64_t T, int64_t Nv2,
+                                  int64_t NT, int64_t slices, float* part1, float* part2, void* stream) {
+    if (rows <= 0 || M <= 0 || slices <= 0 || T <= 0 || !dy || !x1 || !h_all || !done || !part1 || !part2 || ldy < M ||
+        ldx1 < 96 || ldh < 256 || ((ldy | ldx1 | ldh) & 7) || (((uintptr_t)dy | (uintptr_t)x1 | (uintptr_t)h_all) & 15) ||
+        Nv1 <= 0 || Nv1 > 96 || Nv2 <= 0 || Nv2 > 256 || rows % T)
+        return VINE_ERR_INVALID_ARG;
+    if ((NT != 22 && NT != 21) || (32 % T) || ((uintptr_t)done & 15) || rows / slices / 32 > 1024) return VINE_ERR_UNSUPPORTED;
+    return wgrad_cat_wide_launch(rows, M, dy, ldy, x1, ldx1, Nv1, h_all, ldh, Nv2, NT, slices, part1, part2, done, T, stream);
+}
+
 int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t ldy, const void* x1, int64_t ldx1, int64_t N1p,
                               int64_t Nv1, const void* x2, int64_t ldx2, int64_t N2p, int64_t Nv2, int64_t NT, int64_t slices,
                               float* part1, float* part2, void* stream) {
@@ -4301,29 +4448,10 @@ int vine_weight_grad_cat_mfma(int64_t rows, int64_t M, const void* dy, int64_t l
         ((uintptr_t)dy & 15) || ((uintptr_t)x2 & 15) || N2p <= 0 || Nv2 <= 0 || Nv2 > N2p || N1p < 0 ||
         (N1p > 0 && (!x1 || !part1 || ldx1 < N1p || (ldx1 & 7) || ((uintptr_t)x1 & 15) || Nv1 <= 0 || Nv1 > N1p)))
         return VINE_ERR_INVALID_ARG;
-    if (NT == 22 || NT == 21) {      // one (128 | 64) x 352 tile per workgroup over [x1 96 | x2 256]
-        const int bm = NT == 22 ? 128 : 64;
-        if (N1p != 96 || N2p != 256 || (M % bm) || (slices & 7) || rows % (slices * 64) || slices > 8192) return VINE_ERR_UNSUPPORTED;
-        const int mtiles = (int)(M / bm), stages = (int)(rows / slices / 32);
-        const size_t lds = (size_t)2 * 32 * ((bm + 16) + (352 + 16)) * sizeof(lp16_t);      // 64 / 56 KiB
-#define VINE_WGW(MT_)                                                                                                     \
-        {                                                                                                                 \
-            static bool attr_set = false;                                                                                 \
-            if (!attr_set) {                                                                                              \
-                if (hipFuncSetAttribute((const void*)wgrad_cat_wide_kernel<6, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                        (int)lds) != hipSuccess)                                                          \
-                    return VINE_ERR_DEVICE;                                                                               \
-                attr_set = true;                                                                                          \
-            }                                                                                                             \
-            hipLaunchKernelGGL((wgrad_cat_wide_kernel<6, MT_>), dim3((unsigned)(mtiles * slices)), dim3(512), lds,        \
-                               (hipStream_t)stream, stages, mtiles, (int)slices, (const lp16_t*)dy, (long long)ldy,       \
-                               (const lp16_t*)x1, (long long)ldx1, (const lp16_t*)x2, (long long)ldx2, part1, (int)Nv1,   \
-                               part2, (int)Nv2, (int)M);                                                                  \
-        }
-        if (NT == 22) VINE_WGW(2)
-        else VINE_WGW(1)
-#undef VINE_WGW
-        return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    if (NT == 22 || NT == 21) {
+        if (N1p != 96 || N2p != 256) return VINE_ERR_UNSUPPORTED;
+        return wgrad_cat_wide_launch(rows, M, dy, ldy, x1, ldx1, Nv1, x2, ldx2, Nv2, NT, slices, part1, part2, nullptr, 1,
+                                     stream);
     }
     if ((NT != 11 && NT != 8 && NT != 2) || (M & 63) || (N1p & 15) || ((N1p + N2p) % (16 * NT)) || (slices & 7) ||
         rows % (slices * 32) || slices > 8192)
@@ -4549,7 +4677,7 @@ int vine_ppo_loss(int64_t n, int32_t A, const float* mu, const float* logstd, co
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const float* gamma, const float* beta, float eps,
+int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const void* x, const float* gamma, const float* beta, float eps,
                        const float* w, const float* wb, const float* logstd, const float* actions, const float* old_neglogp,
                        const float* advantages, const float* old_values, const float* returns, const float* old_mu,
                        const float* old_sigma, float e_clip, int32_t clip_value, float critic_coef, float entropy_coef,
@@ -4575,16 +4703,21 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const float* x, const f
     hipStream_t s = (hipStream_t)stream;
     unsigned int* ticket = ticket_slot(stream, TICKET_LOSS);
     if (!ticket) return VINE_ERR_DEVICE;
-#define VINE_LHL_T(K, R, DXT)                                                                                             \
-    hipLaunchKernelGGL((ln_heads_loss_kernel<K, R, DXT>), grid, block, 0, s, (long long)n, x, gamma, beta, eps, w, wb,     \
-                       logstd, actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip,           \
+    const bool x16 = (dx_bf16 & 2) != 0;      // bit 1: x holds the library's 16-bit format (then dx does too)
+    const int xT = (dx_bf16 >> 8) & 0xff;     // bits 8-15 (with bit 1): x is [n / T, T + 1, H], the samples in slots 1 .. T
+    if ((x16 && !(dx_bf16 & 1)) || (xT && (!x16 || n % xT))) return VINE_ERR_UNSUPPORTED;
+    dx_bf16 &= 3;
+#define VINE_LHL_T(K, R, DXT, XT)                                                                                         \
+    hipLaunchKernelGGL((ln_heads_loss_kernel<K, R, DXT, XT>), grid, block, 0, s, (long long)n, (const XT*)x, xT, gamma, beta, \
+                       eps, w, wb, logstd, actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip,           \
                        (int)clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound, heads, (DXT*)dx, ln_partial,   \
                        scratch, stats, grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store,    \
                        sigma_store, loss_scale, found_inf, ticket)
 #define VINE_LHL(K, R)                                                                                                    \
     {                                                                                                                     \
-        if (dx_bf16) VINE_LHL_T(K, R, lp16_t);                                                                            \
-        else VINE_LHL_T(K, R, float);                                                                                     \
+        if (x16) VINE_LHL_T(K, R, lp16_t, lp16_t);                                                                        \
+        else if (dx_bf16) VINE_LHL_T(K, R, lp16_t, float);                                                                \
+        else VINE_LHL_T(K, R, float, float);                                                                              \
     }
 #define VINE_LHL_R(K)                                                                                                     \
     do {                                                                                                                  \

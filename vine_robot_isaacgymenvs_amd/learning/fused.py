@@ -229,20 +229,49 @@ def _wgrad_cat_plan(dy, x1, x2, out1, out2, allow_wide=True, wgs=None):
     return n, M, o1[0], o1[1], o2[0], o2[1], NT, S
 
 
-def weight_grad_cat(dy, x1, x2, out1, out2, batch=None):
+def h_once_ok(T):
+    """``vine_weight_grad_cat_seq_mfma`` forms the masked, shifted recurrent operand itself when T divides 32."""
+    return H_ONCE and T >= 1 and 32 % T == 0
+
+
+def masked_previous_hidden(h_all, dones, T):
+    """[n, H] operand of the recurrent weight gradient from the "h once" tensor [B * (T + 1), H] (the slow way, in torch:
+    callers whose shapes ``vine_weight_grad_cat_seq_mfma`` does not cover): row seq * T + t = (1 - done) * h_{t-1}."""
+    H = h_all.shape[1]
+    B = h_all.shape[0] // (T + 1)
+    prev = h_all.view(B, T + 1, H)[:, :T].reshape(B * T, H)
+    if dones is None or dones.numel() == 0:
+        return prev.contiguous()
+    return (prev * (1 - dones.view(B * T, 1).to(prev.dtype))).contiguous()
+
+
+def weight_grad_cat(dy, x1, x2, out1, out2, batch=None, seq=None):
     """``dy^T @ [x1 | x2]`` in ONE pass over ``dy`` on the matrix cores (``vine_weight_grad_cat_mfma``); ``x1`` / ``out1``
     may be None (a plain ``dy^T @ x2``).  dy [n, M], x1 [n, N1], x2 [n, N2] bf16; out1 [M, N1], out2 [M, N2] fp32 receive the
-    sums over the row slices (through ``batch`` when given).  Returns False when the shapes are not covered."""
-    plan = _wgrad_cat_plan(dy, x1, x2, out1, out2)
+    sums over the row slices (through ``batch`` when given).  Returns False when the shapes are not covered.
+    ``seq`` = (dones [n] uint8, T): x2 is the LSTM's one copy of its hidden states [n / T * (T + 1), N2] and the operand
+    row k is (1 - done[k]) * h_{t-1}, formed inside the kernel (``vine_weight_grad_cat_seq_mfma``, wide tile only)."""
+    plan = _wgrad_cat_plan(dy, x1, x2 if seq is None else x2[:dy.shape[0]], out1, out2)
     if plan is None:
         return False
     n, M, N1p, Nv1, N2p, Nv2, NT, S = plan
+    if seq is not None and (NT not in (21, 22) or x1 is None or not h_once_ok(seq[1]) or seq[0].data_ptr() % 16
+                            or n // S // 32 > 1024 or x2.shape[0] != n // seq[1] * (seq[1] + 1) or not x2.is_contiguous()):
+        return False
     part2 = torch.empty((S, M, Nv2), device=dy.device, dtype=torch.float32)
     part1 = torch.empty((S, M, Nv1), device=dy.device, dtype=torch.float32) if x1 is not None else None
-    _check(_lib().vine_weight_grad_cat_mfma(n, M, dy.data_ptr(), dy.stride(0), x1.data_ptr() if x1 is not None else None,
-                                            x1.stride(0) if x1 is not None else 0, N1p, Nv1, x2.data_ptr(), x2.stride(0),
-                                            N2p, Nv2, NT, S, part1.data_ptr() if part1 is not None else None,
-                                            part2.data_ptr(), _stream(dy)), "vine_weight_grad_cat_mfma")
+    if seq is not None:
+        dones, T = seq
+        assert dones.numel() == n and dones.dtype == torch.uint8
+        _check(_lib().vine_weight_grad_cat_seq_mfma(n, M, dy.data_ptr(), dy.stride(0), x1.data_ptr(), x1.stride(0), Nv1,
+                                                    x2.data_ptr(), x2.stride(0), dones.data_ptr(), T, Nv2, NT, S,
+                                                    part1.data_ptr(), part2.data_ptr(), _stream(dy)),
+               "vine_weight_grad_cat_seq_mfma")
+    else:
+        _check(_lib().vine_weight_grad_cat_mfma(n, M, dy.data_ptr(), dy.stride(0), x1.data_ptr() if x1 is not None else None,
+                                                x1.stride(0) if x1 is not None else 0, N1p, Nv1, x2.data_ptr(), x2.stride(0),
+                                                N2p, Nv2, NT, S, part1.data_ptr() if part1 is not None else None,
+                                                part2.data_ptr(), _stream(dy)), "vine_weight_grad_cat_mfma")
     if part1 is not None:
         column_sums(part1, out1, batch=batch)
     column_sums(part2, out2, batch=batch)
@@ -348,13 +377,19 @@ def _lstm_reference(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
 
 
 def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0=True, c_dtype=torch.float32,
-                        mask_h0=True):
+                        mask_h0=True, h_once=False):
     """out / c_all / gates / hp of ``_lstm_forward_steps`` with the step-0 slots initialised (c_all[0] = c0,
-    hp[:, 0] = masked h0 in the operand dtype): through ``prep`` (a CopyBatch flushed by the caller) or directly."""
+    hp[:, 0] = masked h0 in the operand dtype): through ``prep`` (a CopyBatch flushed by the caller) or directly.
+    ``h_once`` (persistent kernels only): ``out`` [B * (T + 1), H] is the ONE copy of the hidden states, 16-bit and
+    unmasked, slot 0 of every sequence = h0, slot t + 1 = h_t (see ``vine_lstm_seq_forward_mfma``); ``hp`` is None."""
     op = w_hh.dtype
     BT, H = x.shape[0], w_hh.shape[1]
     B = BT // T
     dev = x.device
+    if h_once:
+        assert not mask_h0 and not copy_c0 and c_dtype == op == lp_dtype() and need_grad
+        return (torch.empty((B * (T + 1), H), device=dev, dtype=op), torch.empty((T + 1, B, H), device=dev, dtype=c_dtype),
+                torch.empty((T, B, 4 * H), device=dev, dtype=op), None)
     out = torch.empty((BT, H), device=dev, dtype=torch.float32)
     # (c_dtype bfloat16: the persistent sequence kernels' low-precision store of the cell states the backward pass re-reads)
     c_all = torch.empty((T + 1, B, H), device=dev, dtype=c_dtype)
@@ -378,6 +413,9 @@ def _lstm_state_buffers(x, w_hh, h0, c0, dones, T, need_grad, prep=None, copy_c0
 # recurrence, the returned state and every parameter gradient stay fp32); 0: fp32 (A/B knob)
 LSTM_LP = _os.environ.get("VINE_LSTM_LP", "1") != "0"
 LSTM_SEQ = _os.environ.get("VINE_LSTM_SEQ", "1") != "0"      # 0: one launch per time step (the round-1 kernels), for A/B runs
+# the hidden states of the update's LSTM stored ONCE (16-bit, unmasked) instead of fp32 for the LayerNorm + masked 16-bit
+# for the recurrent weight gradient; 0: both copies (A/B knob)
+H_ONCE = _os.environ.get("VINE_H_ONCE", "1") != "0"
 
 
 def lstm_seq_ok(B, H, T, wpad):
@@ -407,11 +445,13 @@ def _lstm_forward_steps(lib, x, ig, w_hh, bias, h0, c0, dones, T, need_grad, wca
         # ONE launch for the whole sequence: h_t stays in LDS, c_t in registers, weights stream from the
         # fragment-ordered copy (``wtile``); x = the padded operand buffer whose first K1 columns are the step input
         K1 = wtile.numel() // (4 * H) - H
-        assert op == lp_dtype() and lstm_seq_ok(B, H, T, K1) and x.stride(0) >= K1 and hp.is_contiguous()
-        _check(lib.vine_lstm_seq_forward_mfma(B, T, H, K1, x.data_ptr(), x.stride(0), hp.data_ptr(), T * H,
+        h_once = hp is None                   # (buffers made with h_once: out is [B * (T + 1), H], 16-bit)
+        assert op == lp_dtype() and lstm_seq_ok(B, H, T, K1) and x.stride(0) >= K1 and (h_once or hp.is_contiguous())
+        assert not h_once or (out.shape == (B * (T + 1), H) and h0_direct is not None and c_last is not None)
+        _check(lib.vine_lstm_seq_forward_mfma(B, T, H, K1, x.data_ptr(), x.stride(0), None if h_once else hp.data_ptr(), T * H,
                                               wtile.data_ptr(), bias.data_ptr(), c_prev[0].data_ptr(), d_ptr,
                                               out.data_ptr(), c_all.data_ptr(), gates.data_ptr() if need_grad else None,
-                                              int(c_all.dtype == lp_dtype()),
+                                              int(c_all.dtype == lp_dtype()) | (2 if h_once else 0),
                                               c_last.data_ptr() if c_last is not None else None,
                                               h0_direct.data_ptr() if h0_direct is not None else None, st),
                "vine_lstm_seq_forward_mfma")
@@ -718,6 +758,13 @@ def lstm_sequence(x, w_ih, w_hh, b_ih, b_hh, h0, c0, dones, T):
 
 
 # --------------------------------------------------------------------------- whole actor-critic trunk
+def _heads_loss_route(n, H, NH, loss_pack, head_bias_external, lib):
+    """Does the trunk run LayerNorm + heads + loss + their backward as the one ``vine_ln_heads_loss`` launch?"""
+    rows = lib.vine_ln_heads_loss_rows()
+    return (H == 256 and 2 <= NH <= 5 and loss_pack is not None and HEADS_LOSS and n % rows == 0 and n // rows <= 1024
+            and bool(head_bias_external))
+
+
 class _Trunk(torch.autograd.Function):
     """The training forward/backward of the Vine5LinkMovingBasePPO network as ONE autograd node:
     obs -> [Linear+ELU]*L -> concat obs -> LSTM(T steps) -> LayerNorm -> [mu | value] heads (one GEMM).
@@ -831,14 +878,18 @@ class _Trunk(torch.autograd.Function):
             lp = seq and LSTM_LP and c0_direct is not None
             c_last = torch.empty((B, H), device=dev, dtype=torch.float32) if lp else None
             h0_direct = h0 if (seq and h0.dtype == torch.float32 and h0.is_contiguous()) else None
+            # the hidden states once, 16-bit: when their only readers are the fused LayerNorm + heads + loss kernel and
+            # the weight-gradient kernel (which both take them that way)
+            h_once = (lp and h0_direct is not None and dones is not None and h_once_ok(T)
+                      and _heads_loss_route(n, H, A_ + v_w.shape[0], loss_pack, head_bias_external, lib))
             lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep,
                                                copy_c0=c0_direct is None, c_dtype=lp_dtype() if lp else torch.float32,
-                                               mask_h0=h0_direct is None)
+                                               mask_h0=h0_direct is None, h_once=h_once)
             prep.flush(obs_n)
         else:
             lstm_buffers = None
             c0_direct = None
-            lp, c_last, h0_direct = False, None, None
+            lp, c_last, h0_direct, h_once = False, None, None, False
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
             torch.cat([mu_b, v_b], 0, out=b_heads)
@@ -904,8 +955,8 @@ class _Trunk(torch.autograd.Function):
         ctx.loss_fused = None
         ctx.loss_pack = loss_pack       # (its "amp" entry: loss scale / overflow flag of the device-side GradScaler)
         lhl_rows = lib.vine_ln_heads_loss_rows()
-        if (fuse_heads and loss_pack is not None and HEADS_LOSS and n % lhl_rows == 0 and n // lhl_rows <= 1024
-                and head_bias_external):
+        ctx.h_once = h_once
+        if _heads_loss_route(n, H, NH, loss_pack, head_bias_external, lib):
             # LayerNorm + heads + PPO loss + their backward in ONE launch: the gradient w.r.t. the LSTM output is
             # known before this node's backward runs (which ignores the gradient it is handed for `heads`)
             y = out.new_empty(0)
@@ -916,7 +967,8 @@ class _Trunk(torch.autograd.Function):
             _check(lib.vine_ln_heads_loss(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
                                           w_heads.data_ptr(), b_heads.data_ptr(), lpk["logstd"].data_ptr(),
                                           *[t.data_ptr() for t in lpk["args"]], *lpk["scal"], heads.data_ptr(),
-                                          d_out.data_ptr(), int(lp), ln_part.data_ptr(), lpk["stats"].data_ptr(),
+                                          d_out.data_ptr(), int(lp) | ((2 | (T << 8)) if h_once else 0), ln_part.data_ptr(),
+                                          lpk["stats"].data_ptr(),
                                           lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
                                           lpk["head_bias_grads"][1].data_ptr(), lpk["scratch"].data_ptr(), *lpk["extra"],
                                           *_amp_ptrs(lpk.get("amp")), st),
@@ -949,7 +1001,7 @@ class _Trunk(torch.autograd.Function):
                               *([c_last] if c_last is not None else []),
                               *([c0_direct] if c0_direct is not None else []))
         # final LSTM state as views (no copies): the update discards it, other callers may clone
-        hT = out.view(B, T, H)[:, T - 1]
+        hT = out.view(B, T + 1, H)[:, T] if h_once else out.view(B, T, H)[:, T - 1]      # (h_once: 16-bit)
         cT = c_last if c_last is not None else c_all[T]
         ctx.mark_non_differentiable(hT, cT)
         ctx.set_materialize_grads(False)       # no zero-filled [B, H] gradients for the two state outputs
@@ -967,7 +1019,7 @@ class _Trunk(torch.autograd.Function):
         c0_direct = saved[-1] if ctx.has_c0 else None
         c_last = saved[-2 if ctx.has_c0 else -1] if ctx.has_clast else None
         slots = ctx.slots
-        n, H = out.shape
+        n, H = xcat.shape[0], out.shape[1]      # (with h_once ``out`` has T + 1 rows per sequence)
         dev = out.device
         st = _stream(out)
         grads = [None] * len(slots)
@@ -1039,7 +1091,12 @@ class _Trunk(torch.autograd.Function):
                                                 w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled,
                                                 c_last=c_last)
         fused2 = False
-        if mixed and slots[base + 0] is not None and slots[base + 1] is not None:
+        if ctx.h_once and mixed and slots[base + 0] is not None and slots[base + 1] is not None:
+            # ``out`` is the one 16-bit copy of the hidden states (slot 0 = h0): the kernel shifts and masks
+            fused2 = weight_grad_cat(dG, xcat, out, slots[base + 0], slots[base + 1], batch=batch, seq=(dones, T))
+        if ctx.h_once and not fused2:
+            hp = masked_previous_hidden(out, dones if has_dones else None, T)
+        if not fused2 and mixed and slots[base + 0] is not None and slots[base + 1] is not None:
             # dW_ih and dW_hh from one pass over dG (the largest tensor of the backward pass)
             fused2 = weight_grad_cat(dG, xcat, hp.view(n, H), slots[base + 0], slots[base + 1], batch=batch)
         if not fused2:
