@@ -341,6 +341,31 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const void* x, const fl
  * 16-bit dx element overflows the format or is NaN. */
 int vine_ln_heads_loss_rows(void);
 
+/* dx_bf16 bit 2 of vine_ln_heads_loss ("defer"): the kernel stops after writing its per-workgroup rows of loss sums to
+ * `scratch` ([n / R, 32] floats) -- stats, grad_logstd, grad_mu_bias / grad_value_bias, kl_out and logstd_grad_accum are
+ * NOT written by it.  The caller hands this record to vine_column_sums_batched_fin (the launch that ends the backward
+ * pass), where one more workgroup folds the rows and writes them, beside the other jobs: the serial tail of the loss
+ * kernel (a ticket behind its own stores + two dependent passes over the rows by one workgroup) disappears. */
+typedef struct VineLossFinalize {
+    const float* partial;      /* the `scratch` of the deferred vine_ln_heads_loss call */
+    int32_t blocks;            /* n / vine_ln_heads_loss_rows() */
+    int32_t A;                 /* NH - 1 */
+    int64_t n;
+    const float* logstd;
+    float critic_coef, entropy_coef, bounds_coef;
+    float* stats;
+    float* grad_logstd;
+    float* grad_mu_bias;       /* nullable (both or neither) */
+    float* grad_value_bias;
+    float* kl_out;             /* nullable */
+    float* logstd_grad_accum;  /* nullable */
+    const float* loss_scale;   /* nullable */
+} VineLossFinalize;
+/* vine_column_sums_batched + the deferred loss finalize (fin nullable: then exactly vine_column_sums_batched). */
+int vine_column_sums_batched_fin(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
+                                 const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
+                                 const int32_t* dup, float* found_inf, const VineLossFinalize* fin, void* stream);
+
 /* "fp16" (default build: IEEE half operands, the reference's autocast dtype; needs the loss scaling above) or "bf16"
  * (-DVINE_LP_BF16): the 16-bit storage format of every `bf16` / `lp16` operand, saved activation and parameter copy of
  * this header.  Parameter names containing "bf16" date from round 2 and mean "this 16-bit format". */

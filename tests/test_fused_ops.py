@@ -1130,6 +1130,36 @@ def test_ln_heads_loss_kernel_16bit_input(n):
     assert rel(a["part"].sum(0), b["part"].sum(0)) < 1e-5
     for k in ("stats", "gls", "gmb", "gvb", "kl", "acc"):
         assert rel(a[k], b[k]) < 1e-5, k
+    # the serial last step deferred (flag bit 2) into the batched column-sum launch: same results, bit for bit
+    import ctypes as C
+    from vine_robot_isaacgymenvs_amd.abi import LossFinalize
+    d = dict(heads=torch.empty(n, NH, device=dev), dx=torch.empty(n, H, device=dev, dtype=bf),
+             part=torch.empty(n // R, (2 + NH) * H, device=dev), stats=torch.full((8,), float("nan"), device=dev),
+             gls=torch.full((A,), float("nan"), device=dev), gmb=torch.zeros(A, device=dev), gvb=torch.zeros(1, device=dev),
+             kl=torch.zeros(1, device=dev), acc=torch.zeros(A, device=dev), mu=torch.empty(n, A, device=dev),
+             sg=torch.empty(n, A, device=dev))
+    scratch = torch.empty(PPO_LOSS_SCRATCH_FLOATS, device=dev)
+    assert lib.vine_ln_heads_loss(n, H, NH, x16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(),
+                                  wb.data_ptr(), logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),
+                                  old_values.data_ptr(), returns.data_ptr(), old_mu.data_ptr(), old_sigma.data_ptr(), *scal,
+                                  d["heads"].data_ptr(), d["dx"].data_ptr(), 3 | 4, d["part"].data_ptr(), d["stats"].data_ptr(),
+                                  d["gls"].data_ptr(), d["gmb"].data_ptr(), d["gvb"].data_ptr(), scratch.data_ptr(),
+                                  d["kl"].data_ptr(), d["acc"].data_ptr(), d["mu"].data_ptr(), d["sg"].data_ptr(),
+                                  scale.data_ptr(), found.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(d["stats"]).all() and float(d["kl"]) == 0.0          # nothing folded yet
+    fin = LossFinalize(scratch.data_ptr(), n // R, A, n, logstd.data_ptr(), scal[2], scal[3], scal[4], d["stats"].data_ptr(),
+                       d["gls"].data_ptr(), d["gmb"].data_ptr(), d["gvb"].data_ptr(), d["kl"].data_ptr(), d["acc"].data_ptr(),
+                       scale.data_ptr())
+    colsum = torch.empty((2 + NH) * H, device=dev)
+    one = lambda v, t=C.c_int64: (t * 1)(v)
+    assert lib.vine_column_sums_batched_fin(1, one(n // R), one((2 + NH) * H), (C.c_void_p * 1)(d["part"].data_ptr()),
+                                            one((2 + NH) * H), (C.c_void_p * 1)(colsum.data_ptr()), one(0),
+                                            (C.c_void_p * 1)(None), one(0, C.c_int32), None, C.byref(fin), st) == 0
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], d[k]), k
+    assert rel(colsum, a["part"].sum(0)) < 1e-5
     # 16-bit input with an fp32 gradient is not a supported combination
     assert lib.vine_ln_heads_loss(n, H, NH, x16.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, w.data_ptr(),
                                   wb.data_ptr(), logstd.data_ptr(), actions.data_ptr(), old_nlp.data_ptr(), adv.data_ptr(),

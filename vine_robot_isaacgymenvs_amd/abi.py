@@ -174,8 +174,17 @@ PPO_PARTIAL_BLOCKS = 512   # VINE_PPO_PARTIAL_BLOCKS
 PPO_LOSS_SCRATCH_FLOATS = 1024 * 32   # VINE_PPO_LOSS_SCRATCH_FLOATS
 ROLLOUT_POST_SCRATCH_FLOATS = 1024 * 3    # VINE_ROLLOUT_POST_SCRATCH_FLOATS
 RMS_BLOCKS = 128   # VINE_RMS_BLOCKS
+class LossFinalize(C.Structure):
+    """``VineLossFinalize`` of include/vine_ppo.h (the deferred last step of ``vine_ln_heads_loss``)."""
+    _fields_ = [("partial", C.c_void_p), ("blocks", C.c_int32), ("A", C.c_int32), ("n", C.c_int64), ("logstd", C.c_void_p),
+                ("critic_coef", C.c_float), ("entropy_coef", C.c_float), ("bounds_coef", C.c_float), ("stats", C.c_void_p),
+                ("grad_logstd", C.c_void_p), ("grad_mu_bias", C.c_void_p), ("grad_value_bias", C.c_void_p),
+                ("kl_out", C.c_void_p), ("logstd_grad_accum", C.c_void_p), ("loss_scale", C.c_void_p)]
+
+
 # include/vine_ppo.h (product library only; the oracle does not implement these)
 PPO_PROTOTYPES = {
+    "vine_column_sums_batched_fin": (C.c_int, [C.c_int32] + [_VP] * 8 + [_VP, _VP, _VP]),
     "vine_lstm_cell_forward": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _I64, _VP, _VP, _VP,
                                          _VP, _I64, C.c_int32, _I64, _VP]),
     "vine_lstm_step_mfma": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP,

@@ -2545,15 +2545,35 @@ struct ColsumBatch {
     int njobs;
     float* found_inf;      // optional: set to 1 when a finished column sum is not finite (loss-scaled fp16 backward: an
                            // overflowed 16-bit gradient ends as inf / NaN in the weight gradients these jobs finish)
+    VineLossFinalize fin;  // fin.partial != NULL: one more workgroup folds the loss kernel's per-workgroup rows
 };
 __device__ __forceinline__ bool not_finite(float v) { return !(fabsf(v) <= 3.0e38f); }
+__device__ __forceinline__ void ppo_loss_finalize(int blocks, int A, long long n, const float* partial,
+                                                  const float* __restrict__ logstd, float critic_coef, float entropy_coef,
+                                                  float bounds_coef, float* __restrict__ stats,
+                                                  float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
+                                                  float* __restrict__ grad_value_bias, float* __restrict__ kl_out,
+                                                  float* __restrict__ logstd_grad_accum, float S);
 __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) {
+    // (workgroup 0: it is the longest job of the launch -- two dependent passes over the rows -- so it starts first)
+    const int fin_blocks = batch.fin.partial ? 1 : 0;
+    if (fin_blocks && blockIdx.x == 0) {
+        // the deferred last step of vine_ln_heads_loss (flag bit 2): loss statistics, KL slot, log-sigma and head-bias
+        // gradients from the per-workgroup rows -- here it runs beside the other jobs instead of as the serial tail of
+        // the loss kernel (ticket + fence behind 17 MB of stores + two dependent passes over the rows: 6 us)
+        const VineLossFinalize& F = batch.fin;
+        ppo_loss_finalize(F.blocks, F.A, F.n, F.partial, F.logstd, F.critic_coef, F.entropy_coef, F.bounds_coef, F.stats,
+                          F.grad_logstd, F.grad_mu_bias, F.grad_value_bias, F.kl_out, F.logstd_grad_accum,
+                          F.loss_scale ? *F.loss_scale : 1.0f);
+        return;
+    }
+    const int bid = (int)blockIdx.x - fin_blocks;
     int j = 0;
 #pragma unroll 1
     for (int k = 1; k < batch.njobs; ++k)
-        if ((int)blockIdx.x >= batch.job[k].first_block) j = k;
+        if (bid >= batch.job[k].first_block) j = k;
     const ColsumJob& J = batch.job[j];
-    const int blk = blockIdx.x - J.first_block;
+    const int blk = bid - J.first_block;
     __shared__ __attribute__((aligned(16))) float red[1024];
     if (J.quad) {
         // short and wide (the slices of a split-K weight gradient): 64 column QUADS x 4 row-lanes, 16-B loads
@@ -2998,7 +3018,8 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     float* __restrict__ heads, DXT* __restrict__ dx, float* __restrict__ ln_partial, float* loss_partial,
     float* __restrict__ stats, float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
     float* __restrict__ grad_value_bias, float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum, float* mu_store,
-    float* sigma_store, const float* __restrict__ loss_scale, float* __restrict__ found_inf, unsigned int* ticket) {
+    float* sigma_store, const float* __restrict__ loss_scale, float* __restrict__ found_inf, unsigned int* ticket,
+    int defer) {
     constexpr int H = 256, A = NH - 1, NWV = 8, W = (2 + NH) * H, RW = 4 * NP;
     // loss scale: applied where the per-row head gradients are formed, so dx and every parameter partial sum of this
     // kernel carry it; the bias / log-sigma gradients of the finalize step are multiplied there; statistics unscaled
@@ -3281,8 +3302,9 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
 #pragma unroll
         for (int wq = 0; wq < NWV; ++wq) sum += lred[wq][threadIdx.x];
         loss_partial[(long long)blockIdx.x * PPO_LOSS_ROW + threadIdx.x] = sum;
-        __threadfence();
+        if (!defer) __threadfence();
     }
+    if (defer) return;      // the rows are folded later, by the batched column-sum launch (VineLossFinalize)
     __shared__ bool is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -4587,7 +4609,17 @@ int vine_normalize_obs(int64_t n, int64_t F, const float* x, const double* mean,
 int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
                              const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
                              const int32_t* dup, float* found_inf, void* stream) {
+    return vine_column_sums_batched_fin(njobs, R, C, src, row_stride, out0, n0, out1, dup, found_inf, nullptr, stream);
+}
+
+int vine_column_sums_batched_fin(int32_t njobs, const int64_t* R, const int64_t* C, const float* const* src,
+                                 const int64_t* row_stride, float* const* out0, const int64_t* n0, float* const* out1,
+                                 const int32_t* dup, float* found_inf, const VineLossFinalize* fin, void* stream) {
     if (njobs <= 0 || njobs > VINE_COLSUM_MAX_JOBS || !R || !C || !src || !row_stride || !out0 || !n0 || !out1 || !dup)
+        return VINE_ERR_INVALID_ARG;
+    if (fin && (!fin->partial || fin->blocks <= 0 || fin->blocks > VINE_PPO_LOSS_BLOCKS || fin->A <= 0 || fin->A > PPO_MAX_A ||
+                fin->n <= 0 || !fin->logstd || !fin->stats || !fin->grad_logstd ||
+                ((fin->grad_mu_bias == nullptr) != (fin->grad_value_bias == nullptr))))
         return VINE_ERR_INVALID_ARG;
     ColsumBatch b;
     int blocks = 0;
@@ -4605,6 +4637,8 @@ int vine_column_sums_batched(int32_t njobs, const int64_t* R, const int64_t* C, 
     }
     b.njobs = njobs;
     b.found_inf = found_inf;
+    if (fin) { b.fin = *fin; ++blocks; }
+    else b.fin.partial = nullptr;
     hipLaunchKernelGGL(colsum_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
@@ -4706,13 +4740,14 @@ int vine_ln_heads_loss(int64_t n, int64_t H, int32_t NH, const void* x, const fl
     const bool x16 = (dx_bf16 & 2) != 0;      // bit 1: x holds the library's 16-bit format (then dx does too)
     const int xT = (dx_bf16 >> 8) & 0xff;     // bits 8-15 (with bit 1): x is [n / T, T + 1, H], the samples in slots 1 .. T
     if ((x16 && !(dx_bf16 & 1)) || (xT && (!x16 || n % xT))) return VINE_ERR_UNSUPPORTED;
+    const int defer = (dx_bf16 >> 2) & 1;     // bit 2: leave the per-workgroup loss rows in `scratch` (vine_column_sums_batched_fin)
     dx_bf16 &= 3;
 #define VINE_LHL_T(K, R, DXT, XT)                                                                                         \
     hipLaunchKernelGGL((ln_heads_loss_kernel<K, R, DXT, XT>), grid, block, 0, s, (long long)n, (const XT*)x, xT, gamma, beta, \
                        eps, w, wb, logstd, actions, old_neglogp, advantages, old_values, returns, old_mu, old_sigma, e_clip,           \
                        (int)clip_value, critic_coef, entropy_coef, bounds_coef, soft_bound, heads, (DXT*)dx, ln_partial,   \
                        scratch, stats, grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store,    \
-                       sigma_store, loss_scale, found_inf, ticket)
+                       sigma_store, loss_scale, found_inf, ticket, defer)
 #define VINE_LHL(K, R)                                                                                                    \
     {                                                                                                                     \
         if (x16) VINE_LHL_T(K, R, lp16_t, lp16_t);                                                                        \

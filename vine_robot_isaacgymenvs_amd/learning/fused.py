@@ -416,6 +416,9 @@ LSTM_SEQ = _os.environ.get("VINE_LSTM_SEQ", "1") != "0"      # 0: one launch per
 # the hidden states of the update's LSTM stored ONCE (16-bit, unmasked) instead of fp32 for the LayerNorm + masked 16-bit
 # for the recurrent weight gradient; 0: both copies (A/B knob)
 H_ONCE = _os.environ.get("VINE_H_ONCE", "1") != "0"
+# the loss kernel's serial last step deferred into the column-sum launch that ends the backward pass; 0: inside the loss
+# kernel (ticket + last workgroup), as its stand-alone callers get it (A/B knob)
+LOSS_DEFER = _os.environ.get("VINE_LOSS_DEFER", "1") != "0"
 
 
 def lstm_seq_ok(B, H, T, wpad):
@@ -592,6 +595,7 @@ class ColumnSumBatch:
     def __init__(self, found_inf=None):
         self.jobs, self.keep = [], []
         self.found_inf = found_inf      # 1-element device tensor set to 1 by a non-finite result (loss-scaled backward)
+        self.fin = None                 # abi.LossFinalize: the deferred last step of vine_ln_heads_loss rides in the launch
 
     def add(self, src, out, out1=None, n0=0, dup=False):
         flat = _as_rows(src)
@@ -609,11 +613,14 @@ class ColumnSumBatch:
             cols = list(zip(*js))
             i64 = lambda v: (C.c_int64 * n)(*v)
             ptr = lambda v: (C.c_void_p * n)(*v)
-            _check(lib.vine_column_sums_batched(n, i64(cols[0]), i64(cols[1]), ptr(cols[2]), i64(cols[3]), ptr(cols[4]),
-                                                i64(cols[5]), ptr(cols[6]), (C.c_int32 * n)(*cols[7]),
-                                                self.found_inf.data_ptr() if self.found_inf is not None else None, st),
-                   "vine_column_sums_batched")
-        self.jobs, self.keep = [], []
+            fin = self.fin if k + 16 >= len(self.jobs) else None      # (with the last launch)
+            _check(lib.vine_column_sums_batched_fin(n, i64(cols[0]), i64(cols[1]), ptr(cols[2]), i64(cols[3]), ptr(cols[4]),
+                                                    i64(cols[5]), ptr(cols[6]), (C.c_int32 * n)(*cols[7]),
+                                                    self.found_inf.data_ptr() if self.found_inf is not None else None,
+                                                    C.byref(fin) if fin is not None else None, st),
+                   "vine_column_sums_batched_fin")
+        assert self.fin is None or self.jobs, "a deferred loss finalize needs at least one column-sum job to ride with"
+        self.jobs, self.keep, self.fin = [], [], None
 
 
 class CopyBatch:
@@ -964,10 +971,24 @@ class _Trunk(torch.autograd.Function):
             d_out = torch.empty((n, H), device=dev, dtype=lp_dtype() if lp else torch.float32)
             ln_part = torch.empty((n // lhl_rows, (2 + NH) * H), device=dev, dtype=torch.float32)
             lpk = loss_pack
+            # the kernel's serial last step (fold of the per-workgroup loss rows -> statistics, KL slot, log-sigma and
+            # head-bias gradients) rides in the column-sum launch that ends this node's backward pass, when there is one
+            slots_now = [_grad_slot(p) if isinstance(p, torch.Tensor) else None for p in params]
+            defer = (LOSS_DEFER and mixed and any(ctx.needs_input_grad)
+                     and all(sl is not None for sl, p in zip(slots_now, params) if isinstance(p, torch.Tensor)))
+            ctx.loss_fin = None
+            if defer:
+                from ..abi import LossFinalize
+                amp_ = _amp_ptrs(lpk.get("amp"))
+                ctx.loss_fin = LossFinalize(lpk["scratch"].data_ptr(), n // lhl_rows, NH - 1, n, lpk["logstd"].data_ptr(),
+                                            lpk["scal"][2], lpk["scal"][3], lpk["scal"][4], lpk["stats"].data_ptr(),
+                                            lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
+                                            lpk["head_bias_grads"][1].data_ptr(), lpk["extra"][0], lpk["extra"][1], amp_[0])
             _check(lib.vine_ln_heads_loss(n, H, NH, out.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps),
                                           w_heads.data_ptr(), b_heads.data_ptr(), lpk["logstd"].data_ptr(),
                                           *[t.data_ptr() for t in lpk["args"]], *lpk["scal"], heads.data_ptr(),
-                                          d_out.data_ptr(), int(lp) | ((2 | (T << 8)) if h_once else 0), ln_part.data_ptr(),
+                                          d_out.data_ptr(), int(lp) | ((2 | (T << 8)) if h_once else 0) | (4 if defer else 0),
+                                          ln_part.data_ptr(),
                                           lpk["stats"].data_ptr(),
                                           lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
                                           lpk["head_bias_grads"][1].data_ptr(), lpk["scratch"].data_ptr(), *lpk["extra"],
@@ -1037,6 +1058,10 @@ class _Trunk(torch.autograd.Function):
         amp = ctx.loss_pack.get("amp") if ctx.loss_pack is not None else None
         batch = (ColumnSumBatch(found_inf=amp[1] if (mixed and amp is not None) else None)
                  if all(sl is not None for k, sl in enumerate(slots) if ctx.pshapes[k] is not None) else None)
+        if getattr(ctx, "loss_fin", None) is not None:
+            assert batch is not None, "the loss finalize was deferred to a column-sum launch that does not exist"
+            batch.fin = ctx.loss_fin
+            ctx.loss_fin = None
         if amp is not None:
             # do ALL parameter gradients of this backward pass end in the overflow-checked column-sum launch?  (else the
             # optimiser checks the gradient block itself before it steps: FlatAdam.step)
