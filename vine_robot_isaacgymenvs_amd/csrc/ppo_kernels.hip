@@ -1319,6 +1319,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     MB_LOAD_W(0)
     MB_LOAD_G(0)
     if (NCH > 1) { MB_LOAD_G(1) }
+    // the stored activations of this lane's units (ELU' of the three layers): requested here, 56 registers, so that their
+    // 29 MB travel under stage 1's stream instead of as 14 exposed round trips in the finishing steps (31.3 -> us)
+    uint4 pa3[C3 / 32], pa2[C2 / 32], pa1[C1 / 32];
+#pragma unroll
+    for (int kk = 0; kk < C3 / 32; ++kk) pa3[kk] = *reinterpret_cast<const uint4*>(a3 + b * a3_stride + 32 * kk + 8 * q);
+#pragma unroll
+    for (int kp = 0; kp < C2 / 32; ++kp) pa2[kp] = *reinterpret_cast<const uint4*>(a2 + b * C2 + 32 * kp + 8 * q);
+#pragma unroll
+    for (int kp = 0; kp < C1 / 32; ++kp) pa1[kp] = *reinterpret_cast<const uint4*>(a1 + b * C1 + 32 * kp + 8 * q);
     MB_STORE_W(0)
     __syncthreads();
     // ---- stage 1: C3 = 64 units = tiles (pair kk, ut), K0 streamed
@@ -1357,10 +1366,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     float* myred = red + wave * (C3 + C2 + C1);
     // gz = acc * elu'(a) for the pair of tiles holding units u0 .. u0 + 7 of this lane; returns the packed bf16 piece,
     // stores it, and leaves the wave's column sums of the 8 units in LDS (lane 15 of every DPP row)
-#define MB_FINISH(a_lo, a_hi, aptr, gzptr, redoff, pk)                                                         \
+#define MB_FINISH(a_lo, a_hi, areg, gzptr, redoff, pk)                                                         \
     {                                                                                                          \
         float av_[8], d_[8];                                                                                   \
-        unpack_lp16x8(*reinterpret_cast<const uint4*>(aptr), av_);                                             \
+        unpack_lp16x8(areg, av_);                                                                              \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
             d_[e] = (a_lo)[e] * (av_[e] > 0.0f ? 1.0f : av_[e] + alpha);                                       \
             d_[4 + e] = (a_hi)[e] * (av_[4 + e] > 0.0f ? 1.0f : av_[4 + e] + alpha);                           \
@@ -1378,8 +1387,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
     for (int kk = 0; kk < C3 / 32; ++kk) {
         uint4 pk;
-        MB_FINISH(acc[2 * kk], acc[2 * kk + 1], a3 + b * a3_stride + 32 * kk + 8 * q, gz3 + b * C3 + 32 * kk + 8 * q,
-                  32 * kk + 8 * q, pk)
+        MB_FINISH(acc[2 * kk], acc[2 * kk + 1], pa3[kk], gz3 + b * C3 + 32 * kk + 8 * q, 32 * kk + 8 * q, pk)
         gf2[kk] = __builtin_bit_cast(lp16x8_t, pk);
     }
     __syncthreads();                                             // w1l / w2l complete
@@ -1396,7 +1404,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
                 a[ut] = MFMA_LP16(wf, gf2[kk], a[ut]);
             }
         uint4 pk;
-        MB_FINISH(a[0], a[1], a2 + b * C2 + 32 * kp + 8 * q, gz2 + b * C2 + 32 * kp + 8 * q, C3 + 32 * kp + 8 * q, pk)
+        MB_FINISH(a[0], a[1], pa2[kp], gz2 + b * C2 + 32 * kp + 8 * q, C3 + 32 * kp + 8 * q, pk)
         gf1[kp] = __builtin_bit_cast(lp16x8_t, pk);
     }
     // ---- stage 3: C1 units, K = C2
@@ -1411,7 +1419,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
                 a[ut] = MFMA_LP16(wf, gf1[kk], a[ut]);
             }
         uint4 pk;
-        MB_FINISH(a[0], a[1], a1 + b * C1 + 32 * kp + 8 * q, gz1 + b * C1 + 32 * kp + 8 * q, C3 + C2 + 32 * kp + 8 * q, pk)
+        MB_FINISH(a[0], a[1], pa1[kp], gz1 + b * C1 + 32 * kp + 8 * q, C3 + C2 + 32 * kp + 8 * q, pk)
         (void)pk;
     }
 #undef MB_FINISH
@@ -3268,7 +3276,20 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     }
     // the four 16-lane rows of the wave hold sums for the same columns: add them (lane l <- l ^ 16, l ^ 32), then one
     // row of W sums per wave in LDS, added over the waves in wave order
-#define LHL_FOLD(v) { v += lane_bcast(v, lane ^ 16); v += lane_bcast(v, lane ^ 32); }
+    // (gfx950's v_permlane16_swap / v_permlane32_swap: the partner row's value without a trip through the LDS crossbar --
+    // 160 ds_bpermute per lane before)
+    // (inline assembly: this compiler's __builtin_amdgcn_permlane{16,32}_swap hands back the first result register for
+    // both elements of its result pair, so the partner rows' values are lost; the s_nop covers the VALU-write ->
+    // permlane-read wait states the compiler would insert for the builtin)
+#define LHL_FOLD(v)                                                                                             \
+    {                                                                                                           \
+        float lo_ = v, hi_ = v;                                                                                 \
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo_), "+v"(hi_));   /* {even row, odd row} of the pair */ \
+        lo_ += hi_;                                                                                             \
+        hi_ = lo_;                                                                                              \
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo_), "+v"(hi_));   /* {lower half, upper half} */ \
+        v = lo_ + hi_;                                                                                          \
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
