@@ -16,7 +16,7 @@ def one():
     from vine_robot_isaacgymenvs_amd.learning import fused
     dev = torch.device("cuda:0")
     lib = fused._lib()
-    B, T, H, width, wpad, SETS = 8192, 4, 256, 92, 96, 4
+    B, T, H, width, wpad, SETS = 8192, int(os.environ.get("SEQ_T", "4")), 256, 92, 96, 4
     bf = fused.lp_dtype()
     torch.manual_seed(0)
     w_ih = (torch.randn(4 * H, width, device=dev) / 10).to(bf)
@@ -67,7 +67,7 @@ def one():
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / n * 1e3
-    print("ABLATE=%s  fwd %.1f us  bwd %.1f us" % (os.environ.get("VINE_SEQ_ABLATE", "0"), res["fwd"], res["bwd"]), flush=True)
+    print("T=%d ABLATE=%s  fwd %.1f us  bwd %.1f us" % (T, os.environ.get("VINE_SEQ_ABLATE", "0"), res["fwd"], res["bwd"]), flush=True)
 
 
 if __name__ == "__main__":

@@ -12,9 +12,9 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
     in rotation (> 256 MB in total: more than the Infinity Cache holds), so the figures are cold-cache ones; the
     in-situ durations of the same kernels are in profiles/r03/ppo_iteration_graphed_kernel_stats.csv.  ("bf16" below =
     the library's 16-bit operand format: float16 in the default build.)
-      lstm_seq_fwd_kernel: reads x bf16 [B*T, wpad] + masked h0 bf16 [B, H] + c0 fp32 [B, H] + weights (bf16, 4H x
-          (wpad + H)); writes h fp32 [B*T, H], c bf16 [T-1, B, H] + c_T fp32, gate activations bf16 [T, B, 4H], masked h
-          bf16 [B, T-1, H]
+      lstm_seq_fwd_kernel ("h once", the update's form since round 3): reads x bf16 [B*T, wpad] + h0, c0 fp32 [B, H] +
+          weights (bf16, 4H x (wpad + H)); writes the ONE copy of the hidden states bf16 [B, T+1, H] (slot 0 = h0),
+          c bf16 [T-1, B, H] + c_T fp32, gate activations bf16 [T, B, 4H]
       lstm_seq_bwd_kernel: reads dh bf16 [B*T, H], gates bf16 [T, B, 4H], c (c0, c_T fp32; the rest bf16), w_hh bf16;
           writes dG bf16 [B*T, 4H]"""
     from . import fused
@@ -34,9 +34,9 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
         x = torch.zeros(B * T, wpad, device=device, dtype=bf)
         x[:, :width] = (torch.randn(B * T, width, device=device) * 0.7).to(bf)
         c0 = torch.randn(B, H, device=device) * 0.5
-        hp = (torch.randn(B, T, H, device=device) * 0.5).to(bf)
+        h0 = torch.randn(B, H, device=device) * 0.5
         dones = (torch.rand(B * T, device=device) < 0.2).to(torch.uint8)
-        data.append(dict(x=x, c0=c0, hp=hp, dones=dones, out=torch.empty(B * T, H, device=device),
+        data.append(dict(x=x, c0=c0, h0=h0, dones=dones, out=torch.empty(B * (T + 1), H, device=device, dtype=bf),
                          c_all=torch.empty(T + 1, B, H, device=device, dtype=bf), c_last=torch.empty(B, H, device=device),
                          gates=torch.empty(T, B, 4 * H, device=device, dtype=bf),
                          g_out=(torch.randn(B * T, H, device=device) * 0.1).to(bf),
@@ -45,10 +45,10 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
 
     def fwd(i):
         d = data[i % sets]
-        assert lib.vine_lstm_seq_forward_mfma(B, T, H, wpad, d["x"].data_ptr(), wpad, d["hp"].data_ptr(), T * H,
+        assert lib.vine_lstm_seq_forward_mfma(B, T, H, wpad, d["x"].data_ptr(), wpad, None, T * H,
                                               wtile.data_ptr(), bias.data_ptr(), d["c0"].data_ptr(), d["dones"].data_ptr(),
-                                              d["out"].data_ptr(), d["c_all"].data_ptr(), d["gates"].data_ptr(), 1,
-                                              d["c_last"].data_ptr(), None, st) == 0
+                                              d["out"].data_ptr(), d["c_all"].data_ptr(), d["gates"].data_ptr(), 1 | 2,
+                                              d["c_last"].data_ptr(), d["h0"].data_ptr(), st) == 0
 
     def bwd(i):
         d = data[i % sets]
@@ -57,8 +57,8 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
                                                d["dG"].data_ptr(), part.data_ptr(), 1, d["c_last"].data_ptr(), 1, st) == 0
 
     # (production configuration: saved cell states c_1 .. c_{T-1} and the hidden-state gradient in 16 bits, c_T fp32)
-    fwd_bytes = (B * T * wpad * 2 + B * H * 2 + B * H * 4 + wtile.numel() * 2 + B * T
-                 + B * T * H * 4 + ((T - 1) * B * H * 2 + B * H * 4) + T * B * 4 * H * 2 + B * (T - 1) * H * 2)
+    fwd_bytes = (B * T * wpad * 2 + 2 * B * H * 4 + wtile.numel() * 2 + B * T
+                 + B * (T + 1) * H * 2 + ((T - 1) * B * H * 2 + B * H * 4) + T * B * 4 * H * 2)
     bwd_bytes = (B * T * H * 2 + T * B * 4 * H * 2 + (2 * B * H * 4 + (T - 1) * B * H * 2) + whh_tiled.numel() * 2 + B * T
                  + B * T * 4 * H * 2 + part.numel() * 4)
     # what the memory system of THIS box sustains for a plain streaming kernel (y = x + 1 over 1 GiB, read + write):
