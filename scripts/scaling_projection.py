@@ -2,7 +2,7 @@
 """Strong / weak scaling PROJECTION from one GPU (RCCL itself is unmeasured: the builder has one
 MI355X).  Times `bench.py --mode ppo` at the per-rank shard sizes of W = 2 / 4 / 8 strong scaling (16384 envs and every
 32768-sample minibatch split over the ranks) and of weak scaling, all on the multi-rank code path (multi_gpu=True with a
-1-rank RCCL group: two graph replays per optimiser step, the all-reduce launched eagerly between them), and adds
+1-rank RCCL group: one graph replay per optimiser step -- Adam of the previous step + forward / backward -- and the all-reduce launched eagerly between the graphs), and adds
 32 x an ASSUMED all-reduce time per iteration (1.63 MB of gradients + KL + overflow flag over xGMI; latency-bound).
 
     python scripts/scaling_projection.py [--steps 10] > profiles/r03/scaling_projection.json

@@ -100,7 +100,8 @@ def test_multi_gpu_code_path_on_one_rank(monkeypatch):
                 agent.train_epoch()
             torch.cuda.synchronize()
             assert agent.graph_status["rollout"] == "graph", agent.graph_status
-            assert agent.graph_status["update"].startswith("graph (2 per" if multi else "graph (1 per"), agent.graph_status
+            assert agent.graph_status["update"].startswith("graph (per optimiser step" if multi else "graph (1 per mini-epoch"), \
+                agent.graph_status
             flat = torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone()
             assert torch.isfinite(flat).all()
             results.append((flat, float(agent.lr)))

@@ -1296,9 +1296,9 @@ def test_fused_update_equals_stock_update():
 @pytest.mark.parametrize("mixed,scope", [(False, "epoch"), (True, "epoch"), (True, "step")])
 def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
     """From the second iteration on the update is replayed from hipGraphs: on one rank a whole mini-epoch per graph
-    (scope "epoch": one graph with and one without the running-statistics update), or per optimiser step two graphs
-    (forward/backward | Adam + schedule; scope "step", the form used with several ranks, where the all-reduce runs
-    between the two).  Five iterations with and without graphs must leave the same parameters, learning rate and loss
+    (scope "epoch": one graph with and one without the running-statistics update), or one graph per optimiser step
+    (scope "step", the form used with several ranks: [Adam + schedule of the previous step | forward / backward], the
+    all-reduce issued between two such graphs, one trailing Adam graph).  Five iterations with and without graphs must leave the same parameters, learning rate and loss
     statistics (fp32 and mixed-precision update)."""
     monkeypatch.setenv("VINE_UPD_GRAPH", scope)
     from vine_robot_isaacgymenvs_amd import load_config
@@ -1322,7 +1322,9 @@ def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
             _, _, stats = agent.train_epoch()
         torch.cuda.synchronize()
         if use_graphs:
-            assert len(agent._upd_graphs) == (2 if scope == "epoch" else 2 * agent.num_minibatches)
+            # per-step form: (step, with / without the RMS update) graphs, each led by the previous step's Adam, + the
+            # un-led first step of an update + the trailing Adam graph
+            assert len(agent._upd_graphs) == (2 if scope == "epoch" else 2 * agent.num_minibatches + 1)
             assert not getattr(agent, "_update_graphs_failed", False)
         outs.append((torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone(), float(agent.lr),
                      {k: float(v) for k, v in stats.items()}, agent.model.running_mean_std.running_mean.clone()))

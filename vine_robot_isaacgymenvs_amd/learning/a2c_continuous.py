@@ -1011,10 +1011,16 @@ class A2CAgent:
                 continue
             whole_epoch = False            # capture refused: the flag set by the failure sends the steps below eager
             graphed = graphed and not getattr(self, "_update_graphs_failed", False)
+            step_graphed = 0
             for i in range(self.num_minibatches):
                 row = mini_ep * self.num_minibatches + i
-                if graphed and self._update_step_graphed(i, rows[row]):
+                if graphed and self._update_step_graphed(i):
+                    step_graphed += 1
                     continue
+                self._flush_pending_adam()     # (a capture was refused mid-update: the previous step's Adam is still owed)
+                if step_graphed:
+                    rows[row - step_graphed:row].copy_(self._step_stats[i - step_graphed:i])
+                    step_graphed = 0
                 mb = self.get_minibatch(i)
                 a_loss, c_loss, entropy, kl, b_loss, cmu, csigma = self.calc_gradients(mb)
                 start, end = mb["range"]
@@ -1025,12 +1031,15 @@ class A2CAgent:
                 rows[row, :5].copy_(torch.stack([a_loss, c_loss, b_loss, entropy, kl / self.rank_size if in_comm else kl]))
                 if self.is_adaptive_lr and self.schedule_type == "legacy":
                     self.update_lr_from_kl(kl)
+            if step_graphed:      # the graphs of this mini-epoch left their statistics in _step_stats: one copy
+                rows[(mini_ep + 1) * nb - step_graphed:(mini_ep + 1) * nb].copy_(self._step_stats[nb - step_graphed:nb])
             if self.is_adaptive_lr and self.schedule_type == "standard":
                 ep = rows[mini_ep * self.num_minibatches:(mini_ep + 1) * self.num_minibatches, 4].mean()
                 self._kl_in_comm = kl_global
                 self.update_lr_from_kl(ep * self.rank_size if kl_global else ep)
             if self.normalize_input:
                 self.model.running_mean_std.eval()   # statistics are updated during the first mini-epoch only
+        self._flush_pending_adam()                   # the last step's Adam (per-step graphs defer it into the next graph)
         if self.is_cuda:
             torch.cuda.synchronize(self.device)
         upd_range.__exit__()
@@ -1043,9 +1052,11 @@ class A2CAgent:
     def _update_graphs_usable(self):
         """The optimiser step is ~105 launches of 5-30 us each: with bf16 GEMM operands (and nearly so in fp32) the
         host cannot issue them as fast as the GPU retires them.  From the second iteration on (the first one runs
-        eagerly and warms every lazily initialised handle) each step is replayed from two hipGraphs:
-        A = normalisation (+ running-statistics update in the first mini-epoch) + forward + loss + backward,
-        B = Adam + dataset/learning-rate update, with the RCCL all-reduce issued between them outside any capture."""
+        eagerly and warms every lazily initialised handle) the steps are replayed from hipGraphs.  One rank: a whole
+        mini-epoch per graph.  Several ranks: the RCCL all-reduce of every step is issued outside any capture, and ONE
+        graph runs from behind one all-reduce to the next -- [Adam + learning-rate schedule of step s - 1] + [normalisation
+        (+ running-statistics update in the first mini-epoch) + forward + loss + backward of step s] -- so an iteration is
+        32 graph replays + 32 collectives + one trailing Adam graph (round 2: two graphs per step, 64 + 32)."""
         return (self.use_graphs and self.is_cuda and self.use_fused and not self.mixed_precision
                 and not self.truncate_grads and self.is_adaptive_lr and self.schedule_type == "legacy"
                 and getattr(self, "_epochs_run", 0) > 1 and not getattr(self, "_update_graphs_failed", False))
@@ -1061,17 +1072,40 @@ class A2CAgent:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item() > 0.5)
 
-    def _update_step_graphed(self, i, row_out):
-        # the running-statistics update of the observation normaliser (first mini-epoch only) is part of graph A:
+    def _flush_pending_adam(self):
+        """Per-step graphs defer a step's Adam launch into the NEXT step's graph (it then sits behind the all-reduce with
+        no graph boundary of its own); whoever leaves that chain -- the end of the update, a refused capture -- runs it."""
+        if not getattr(self, "_adam_pending", False):
+            return
+        self._adam_pending = False
+        rec = self._upd_graphs.get("tail") if hasattr(self, "_upd_graphs") else None
+        if rec is None and not getattr(self, "_update_graphs_failed", False):
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize(self.device)
+                with torch.cuda.graph(g, pool=self._upd_pool, capture_error_mode="thread_local"):
+                    self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
+                rec = self._upd_graphs["tail"] = {"G": g}
+            except RuntimeError:
+                rec = None
+        if rec is not None:
+            with _Range("update_graph_tail_adam_lr"):
+                rec["G"].replay()
+        else:
+            self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
+
+    def _update_step_graphed(self, i):
+        # the running-statistics update of the observation normaliser (first mini-epoch only) is part of the graph:
         # its kernels use fixed-order two-stage sums and no memsets, so they replay faithfully
         if getattr(self, "_update_graphs_failed", False):
             return False
-        key = (i, bool(self.normalize_input and self.model.running_mean_std.training))
+        lead = bool(getattr(self, "_adam_pending", False))      # does the graph start with the previous step's Adam?
+        key = (i, bool(self.normalize_input and self.model.running_mean_std.training), lead)
         rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
         if rec is None:
             err = None
             try:
-                rec = self._capture_update_step(i, key)
+                rec = self._capture_update_step(i, key, lead)
             except RuntimeError as e:        # capture refused: nothing has executed
                 err = e
             if not self._capture_agreed(rec is not None):
@@ -1085,15 +1119,13 @@ class A2CAgent:
                 self.graph_status["update"] = "eager (capture refused)"
                 torch.cuda.synchronize(self.device)
                 return False
-        with _Range("update_graph_A_forward_loss_backward"):
-            rec["A"].replay()
+        with _Range("update_graph_adam_forward_loss_backward"):
+            rec["G"].replay()
         if self.multi_gpu:
             with _Range("grad_all_reduce"):
                 dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)      # gradients + KL, RCCL over xGMI
-        with _Range("update_graph_B_adam_lr"):
-            rec["B"].replay()
-        row_out.copy_(rec["stats"])   # this rank's [a_loss, c_loss, b_loss, entropy, kl, loss, 0, 0]
-        self.graph_status["update"] = "graph (2 per optimiser step, all-reduce between)"
+        self._adam_pending = True
+        self.graph_status["update"] = "graph (per optimiser step: Adam of the previous step + forward / backward; all-reduce between graphs)"
         return True
 
     def _update_epoch_graphed(self, rows_out):
@@ -1138,21 +1170,26 @@ class A2CAgent:
         self._upd_graphs[key] = rec
         return rec
 
-    def _capture_update_step(self, i, key):
+    def _capture_update_step(self, i, key, lead):
         if not hasattr(self, "_upd_graphs"):
             self._upd_graphs = {}
             self._upd_pool = torch.cuda.graph_pool_handle()
+        if getattr(self, "_step_stats", None) is None or self._step_stats.shape[0] != self.num_minibatches:
+            # this rank's [a_loss, c_loss, b_loss, entropy, kl, loss, 0, 0] of every step of a mini-epoch: written by the
+            # graphs, copied into the iteration's rows once per mini-epoch
+            self._step_stats = torch.zeros((self.num_minibatches, 8), device=self.device, dtype=torch.float32)
         torch.cuda.synchronize(self.device)
-        gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph()
         pool = None if os.environ.get("VINE_UPD_POOL") == "separate" else self._upd_pool
-        with torch.cuda.graph(gA, pool=pool, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            if lead:
+                # the step behind the previous all-reduce: the KL next to the gradients is the sum over the ranks by
+                # now, the schedule runs inside the Adam launch (the dataset's mu / sigma slices were refreshed by the
+                # loss kernel of that step)
+                self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
             mb = self.get_minibatch(i)
-            stats, mu_d, _logstd_d = self._fused_grad_half(mb)
-        with torch.cuda.graph(gB, pool=pool, capture_error_mode="thread_local"):
-            # (the dataset's mu / sigma slices were refreshed by the loss kernel in graph A); the KL next to the
-            # gradients is the sum over ranks after the all-reduce: schedule inside the Adam launch
-            self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
-        rec = {"A": gA, "B": gB, "stats": stats, "keep": (mb, stats, mu_d)}
+            stats, mu_d, _logstd_d = self._fused_grad_half(mb, stats_out=self._step_stats[i])
+        rec = {"G": g, "stats": stats, "keep": (mb, stats, mu_d)}
         self._upd_graphs[key] = rec
         return rec
 
