@@ -54,6 +54,7 @@ int hip_fail(hipError_t e, const char* what) {
 // Everything the kernels need, precomputed on the host from VineConfig; passed by value (kernarg).
 struct DevParams {
     int n, num_obs, obs_type, cfi, substeps, max_len, delay;
+    int glog;      // log2 of the step kernel's (power-of-two) grid: see step_of()
     unsigned flags, seed_lo, seed_hi, env_off;
     float hsub, dt, cdt, inv_dt, inv_cdt, clip_obs, clip_act;
     float fpam_min, fpam_span, rail_scale, damping, kq, cad, eff_lim;
@@ -87,6 +88,20 @@ __device__ __forceinline__ void rng4(const DevParams& P, unsigned env, unsigned 
                                      unsigned idx, unsigned out[4]) {
     // env: local index; the key is the GLOBAL env id (VineConfig.env_id_offset), so a shard draws what the whole batch does
     philox4x32_10(env + P.env_off, (unsigned)step, purpose | ((unsigned)(step >> 32) << 8), idx, P.seed_lo, P.seed_hi, out);
+}
+// The step count the random streams are keyed by.  counters[0] = a base the host sets, counters[1] = workgroups of step
+// launches that have FINISHED since then.  A step launch has a power-of-two grid of 2^glog workgroups, each of which adds
+// one to counters[1] as its last act (an atomic without a return value): a workgroup of launch k reads a value in
+// [k G, (k + 1) G) whatever the others are doing -- its own increment comes after its reads -- so counters[1] >> glog is
+// k for every workgroup, with no "last one advances the counter" election.  (Rounds 1-3a: a ticket per workgroup with
+// the last arrival writing step + 1 -- a returning atomic on one word from 256 workgroups, a barrier and a fence behind the
+// workgroup's stores, and two dependent writes by the last workgroup: 2-3 us at the tail of a 24 us kernel.)
+__device__ __forceinline__ unsigned long long step_of(const DevParams& P, const unsigned long long* counters) {
+    return counters[0] + (counters[1] >> P.glog);
+}
+__device__ __forceinline__ void step_arrive(unsigned long long* counters) {
+    __builtin_amdgcn_s_barrier();      // every wave of the workgroup has read the counters long ago; no fence: nothing is published
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(&counters[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ void normal2(unsigned a, unsigned b, float& n0, float& n1) {
@@ -734,7 +749,7 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
     constexpr bool SHELF = (OBST & 1) != 0, PIPE = (OBST & 2) != 0, CONTACT = OBST != 0;
     const int n = P.n;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long step = counters[0];
+    const unsigned long long step = step_of(P, counters);
     if (e < n) {
         // ---- VecTask.step: clamp actions (vec_task.py:333) ----
         const float2 act = reinterpret_cast<const float2*>(actions)[e];
@@ -1068,17 +1083,7 @@ __global__ __launch_bounds__(VINE_STEP_THREADS) void vine_step_kernel(const DevP
             if (SHELF) ST(VF_CONTACT_MEAN) = cmean;
         }
     }
-    // ---- advance the step counter once every workgroup has read it (ticket) ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned long long ticket = atomicAdd(&counters[1], 1ull);
-        if (ticket == (unsigned long long)gridDim.x - 1) {
-            counters[1] = 0ull;
-            counters[0] = step + 1ull;
-            __threadfence();
-        }
-    }
+    step_arrive(counters);
 }
 
 // ================================================================================================================
@@ -1118,6 +1123,13 @@ __device__ __forceinline__ float pick(bool c, float a, float b) { return c ? a :
 __device__ __forceinline__ float sel4(int t, float v0, float v1, float v2, float v3) {
     return t == 0 ? v0 : (t == 1 ? v1 : (t == 2 ? v2 : v3));
 }
+// a wave-uniform value (a kernel-argument word) pinned into a scalar register HERE: left alone, the compiler sinks the
+// argument load into the one arm of a select that uses it, and sel4(t, P.x[0], ..) becomes four branches with a scalar
+// load and a wait each
+__device__ __forceinline__ float pin_s(float x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
 template <int K>
 __device__ __forceinline__ unsigned qbcast_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xf, 0xf, true);
@@ -1153,6 +1165,9 @@ __device__ __forceinline__ float quad_scan_incl(float v, int t) {
     return s + pick(t >= 2, qperm<0x4E>(s), 0.0f);
 }
 
+#ifdef VSQ_TIMING
+__device__ unsigned long long vsq_t[1024 * 8];      // (debug build: 8 time stamps per wave, scripts/ubench/step_phases.py)
+#endif
 template <int OBS_TYPE, bool RANDOMIZE, int OBST>   // OBST bit 0: shelf, bit 1: pipe
 __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, float* __restrict__ st,
                                                              const float* __restrict__ actions, float* __restrict__ obs,
@@ -1168,83 +1183,151 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
     const int n = P.n;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = gid >> 2, t = threadIdx.x & 3;
-    const unsigned long long step = counters[0];
+#ifdef VSQ_TIMING
+    if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 0] = wall_clock64();
+#endif
+    const unsigned long long step = step_of(P, counters);
     if (e < n) {
-        // ---- per-lane constants of link t / joint t
-        const float b_t = sel4(t, P.b[0], P.b[1], P.b[2], P.b[3]);
-        const float gb_t = sel4(t, P.gb[0], P.gb[1], P.gb[2], P.gb[3]);
+        // ---- everything the step needs from memory is requested FIRST, in one batch, and waited for once (behind the
+        // pure-ALU random-number work below).  The prologue used to be four dependent stages -- per-lane constants fetched
+        // one kernel-argument word at a time behind branches (the compiler sinks an unpinned P.x[i] into the arm of the
+        // select that needs it: ~45 scalar loads, each with its own wait), the action load, the action-noise Philox, then
+        // the state loads, with the body-state fields behind `if (progress == 0)` -- and took 6 of the kernel's 24 us.
+        const float2 act = reinterpret_cast<const float2*>(actions)[e];
+        float smoothed = ST(VF_SMOOTHED_U);
+        // relative joint coordinates: lane t holds joint t (dof 1 + t), everyone dof 5 and the cart
+        float q_own = ST(VF_Q0 + 1 + t), qd_own = ST(VF_QD0 + 1 + t);
+        float q5 = ST(VF_Q0 + 5), qd5 = ST(VF_QD0 + 5);
+        float y = ST(VF_Q0), vy = ST(VF_QD0);
+        const long long prog_in = progress[e];
+        long long rst = reset[e];
+        // Rigid-body states of the tip and the cart at the start of the step.  They equal the forward kinematics of the
+        // DOF state EXCEPT in the step after a reset (P5: reset_idx does not move bodies, so they are stale), and they are
+        // then the only copy; progress == 0 marks exactly those envs (and freshly initialised ones, whose body states
+        // vine_init / vine_reset_idx stored).  Everyone else re-derives them (below, once sin / cos exist) and, at the end,
+        // stores them only when the env was reset in this step.  (Loaded unconditionally -- 16 B per env and step -- so
+        // that they do not wait for progress[e]; with introspection on they are stored every step, as attribute views.)
+        const float m_tip_y = ST(VF_TIP_Y), m_tip_z = ST(VF_TIP_Z), m_cart_y = ST(VF_CART_Y), m_cart_vy = ST(VF_CART_VY);
+        float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
+        float agg = ST(VF_AGG_REW);
+        float ty = ST(VF_TARGET_Y), tz = ST(VF_TARGET_Z);
+        float obj_depth = ST(VF_OBJ_DEPTH), obj_angle = ST(VF_OBJ_ANGLE);
+        // obstacles (replicated on the quad): the shelf's force on its front strip as the last simulate left it, the
+        // obstacle poses of THIS step (a reset below moves them for the next one)
+        float contact = SHELF ? ST(VF_CONTACT) : 0.0f, contact_sum = 0.0f;
+        const float shelf_y = SHELF ? ST(VF_SHELF_Y) : 0.0f, shelf_z = SHELF ? ST(VF_SHELF_Z) : 0.0f;
+        const float m_pipe_y = PIPE ? ST(VF_PIPE_Y) : 0.0f, m_pipe_z = PIPE ? ST(VF_PIPE_Z) : 0.0f;
+        float fifo_rail = 0.0f, fifo_fpam = 0.0f;
+        int fifo_slot = 0;
+        if (P.delay > 0) {
+            fifo_slot = (int)(step % (unsigned long long)P.delay);
+            fifo_rail = ST(VF_FIFO0 + 2 * fifo_slot);
+            fifo_fpam = ST(VF_FIFO0 + 2 * fifo_slot + 1);
+        }
+#ifdef VSQ_TIMING
+        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 1] = wall_clock64();
+#endif
+        // ---- per-lane constants of link t / joint t (pin_s: all four candidates in scalar registers, one v_cndmask chain)
+#define SEL4P(x0, x1, x2, x3) sel4(t, pin_s(x0), pin_s(x1), pin_s(x2), pin_s(x3))
+        const float b_t = SEL4P(P.b[0], P.b[1], P.b[2], P.b[3]);
+        const float gb_t = SEL4P(P.gb[0], P.gb[1], P.gb[2], P.gb[3]);
         const float nb_t = -b_t;
         float a_k[4], as_k[4];                           // a_tk (cos terms; a_tt on the diagonal), the same with 0 on the diagonal
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            a_k[k] = sel4(t, P.a[0][k], P.a[1][k], P.a[2][k], P.a[3][k]);
+            a_k[k] = SEL4P(P.a[0][k], P.a[1][k], P.a[2][k], P.a[3][k]);
             as_k[k] = t == k ? 0.0f : a_k[k];
         }
-        const float a_t4 = sel4(t, P.a[0][4], P.a[1][4], P.a[2][4], P.a[3][4]);
-        const float K_t = sel4(t, P.K[0], P.K[1], P.K[2], P.K[3]), C_t = sel4(t, P.C[0], P.C[1], P.C[2], P.C[3]);
-        const float bb_t = sel4(t, P.bb[0], P.bb[1], P.bb[2], P.bb[3]), B_t = sel4(t, P.B[0], P.B[1], P.B[2], P.B[3]);
-        // ---- VecTask.step: clamp actions (vec_task.py:333); pre_physics_step (V5:922-945), replicated on the quad
-        const float2 act = reinterpret_cast<const float2*>(actions)[e];
-        float a0 = clampf(act.x, P.clip_act), a1 = clampf(act.y, P.clip_act);
+        const float a_t4 = SEL4P(P.a[0][4], P.a[1][4], P.a[2][4], P.a[3][4]);
+        const float K_t = SEL4P(P.K[0], P.K[1], P.K[2], P.K[3]), C_t = SEL4P(P.C[0], P.C[1], P.C[2], P.C[3]);
+        const float bb_t = SEL4P(P.bb[0], P.bb[1], P.bb[2], P.bb[3]), B_t = SEL4P(P.B[0], P.B[1], P.B[2], P.B[3]);
+#undef SEL4P
+#ifdef VSQ_TIMING
+        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 2] = wall_clock64();
+#endif
+        // ---- random numbers of the step that do not depend on its state (pure ALU: the loads above are in flight)
+        float an0 = 0.0f, an1 = 0.0f;
         if (RANDOMIZE && P.act_noise != 0.0f) {
             unsigned r[4];
-            float n0, n1;
             rng4(P, (unsigned)e, step, RNG_ACTION_NOISE, 0, r);
-            normal2(r[0], r[1], n0, n1);
-            a0 += P.act_noise * n0;
-            a1 += P.act_noise * n1;
+            normal2(r[0], r[1], an0, an1);
+        }
+        // observation noise of this lane's 8 columns (it does not depend on the state either: drawn here, under the loads,
+        // instead of as 2 Philox calls + 4 Box-Muller pairs at the end of the kernel, where nothing covers them)
+        float onoise[8];
+        if (RANDOMIZE && P.obs_noise != 0.0f) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // Philox call index = first column / 4: t for columns [4t, 4t+4), 4 + t for [16+4t, ...)
+                unsigned r[4];
+                rng4(P, (unsigned)e, step, RNG_OBS_NOISE, (unsigned)(4 * half + t), r);
+                normal2(r[0], r[1], onoise[4 * half], onoise[4 * half + 1]);
+                normal2(r[2], r[3], onoise[4 * half + 2], onoise[4 * half + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) onoise[j] = 0.0f;
+        }
+        // dynamics-scaling factors: lane i draws the 20 factors of control iteration i (V5:1053-1055)
+        float scl[20];
+        if (RANDOMIZE && P.dyn_span != 0.0f) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                unsigned r[4];
+                rng4(P, (unsigned)e, step, RNG_DYN_SCALE, (unsigned)(t * 3 + g), r);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (g * 8 + k < 20) {
+                        const float u = (float)((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) * (1.0f / 65536.0f);
+                        scl[g * 8 + k] = P.dyn_min + P.dyn_span * u;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 20; ++k) scl[k] = RANDOMIZE ? P.dyn_min : 1.0f;
+        }
+#ifdef VSQ_TIMING
+        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 3] = wall_clock64();
+#endif
+        // ---- VecTask.step: clamp actions (vec_task.py:333); pre_physics_step (V5:922-945), replicated on the quad
+        float a0 = clampf(act.x, P.clip_act), a1 = clampf(act.y, P.clip_act);
+        if (RANDOMIZE && P.act_noise != 0.0f) {
+            a0 += P.act_noise * an0;
+            a1 += P.act_noise * an1;
         }
         const float new_rail = a0 * P.rail_scale;
         const float new_fpam = (a1 + 1.0f) * 0.5f * P.fpam_span + P.fpam_min;
         float u_rail = new_rail, u_fpam = new_fpam;
         if (P.delay > 0) {
-            const int slot = (int)(step % (unsigned long long)P.delay);
-            u_rail = ST(VF_FIFO0 + 2 * slot);
-            u_fpam = ST(VF_FIFO0 + 2 * slot + 1);
+            u_rail = fifo_rail;
+            u_fpam = fifo_fpam;
             if (t == 0) {
-                ST(VF_FIFO0 + 2 * slot) = new_rail;
-                ST(VF_FIFO0 + 2 * slot + 1) = new_fpam;
+                ST(VF_FIFO0 + 2 * fifo_slot) = new_rail;
+                ST(VF_FIFO0 + 2 * fifo_slot + 1) = new_fpam;
             }
         }
         if (P.flags & VINE_FLAG_FORCE_U_FPAM) u_fpam = 0.0f;
         if (P.flags & VINE_FLAG_FORCE_U_RAIL_VELOCITY) u_rail = 0.0f;
-        float smoothed = ST(VF_SMOOTHED_U);
         {
             const float alpha = (u_fpam > smoothed) ? P.alpha_inf : P.alpha_def;
             smoothed = alpha * smoothed + (1.0f - alpha) * u_fpam;
         }
-        // relative joint coordinates: lane t holds joint t (dof 1 + t), everyone dof 5 and the cart
-        float q_own = ST(VF_Q0 + 1 + t), qd_own = ST(VF_QD0 + 1 + t);
-        float q5 = ST(VF_Q0 + 5), qd5 = ST(VF_QD0 + 5);
-        float y = ST(VF_Q0), vy = ST(VF_QD0);
         const float prev_q_own = q_own, prev_q5 = q5, prev_y = y;
-        // Rigid-body states of the tip and the cart at the start of the step.  They equal the forward kinematics of the
-        // DOF state EXCEPT in the step after a reset (P5: reset_idx does not move bodies, so they are stale), and they are
-        // then the only copy; progress == 0 marks exactly those envs (and freshly initialised ones, whose body states
-        // vine_init / vine_reset_idx stored).  Everyone else re-derives them (below, once sin / cos exist) instead of
-        // loading four words -- and, at the end, stores them only when the env was reset in this step: 32 B of HBM
-        // traffic per env step less.  With introspection on they are loaded and stored as before (attribute views).
         const bool introspect = (P.flags & VINE_FLAG_INTROSPECT) != 0;
-        const long long prog_in = progress[e];
         const bool body_from_mem = introspect || prog_in == 0;
         float tip_y = 0.0f, tip_z = 0.0f, tip_vy = 0.0f, tip_vz = 0.0f;
         float cart_y = y, cart_vy = vy;
         if (body_from_mem) {
-            tip_y = ST(VF_TIP_Y); tip_z = ST(VF_TIP_Z);
-            cart_y = ST(VF_CART_Y); cart_vy = ST(VF_CART_VY);
+            tip_y = m_tip_y; tip_z = m_tip_z;
+            cart_y = m_cart_y; cart_vy = m_cart_vy;
         }
         float prev_u_rail = u_rail;
-        float pcv = ST(VF_PREV_CART_VEL), pce = ST(VF_PREV_CART_VEL_ERR);
         float rail_force = 0.0f;
-        // obstacles (replicated on the quad): the shelf's force on its front strip as the last simulate left it, the
-        // obstacle poses of THIS step (a reset below moves them for the next one)
-        float contact = SHELF ? ST(VF_CONTACT) : 0.0f, contact_sum = 0.0f;
-        const float shelf_y = SHELF ? ST(VF_SHELF_Y) : 0.0f, shelf_z = SHELF ? ST(VF_SHELF_Z) : 0.0f;
         PipePose pipeT = PipePose{0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f};
         if (PIPE) {
             float pst, pct;
-            sincosf(ST(VF_OBJ_ANGLE) + 1.5707963267948966f, &pst, &pct);
-            pipeT = pipe_pose(ST(VF_PIPE_Y), ST(VF_PIPE_Z), pct, pst);
+            sincosf(obj_angle + 1.5707963267948966f, &pst, &pct);
+            pipeT = pipe_pose(m_pipe_y, m_pipe_z, pct, pst);
         }
         const float u_used = (P.flags & VINE_FLAG_USE_SMOOTHED_FPAM) ? smoothed : u_fpam;
         const bool held = (P.flags & VINE_FLAG_FPAM_DAMPING_HELD) != 0;
@@ -1271,24 +1354,10 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             tip_z = body_from_mem ? tip_z : fk_z;
         }
         float prev_tip_y = tip_y, prev_tip_z = tip_z;
-        // ---- dynamics-scaling factors: lane i draws the 20 factors of control iteration i (V5:1053-1055)
-        float scl[20];
-        if (RANDOMIZE && P.dyn_span != 0.0f) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                unsigned r[4];
-                rng4(P, (unsigned)e, step, RNG_DYN_SCALE, (unsigned)(t * 3 + g), r);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (g * 8 + k < 20) {
-                        const float u = (float)((r[k >> 1] >> (16 * (k & 1))) & 0xffffu) * (1.0f / 65536.0f);
-                        scl[g * 8 + k] = P.dyn_min + P.dyn_span * u;
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 20; ++k) scl[k] = RANDOMIZE ? P.dyn_min : 1.0f;
-        }
+#ifdef VSQ_TIMING
+        if (q_own + y + smoothed + pcv + agg + ty + obj_depth + m_tip_y + (float)rst + (float)prog_in == 1234.5f) rew[e] = 1.0f;   // (all loads back)
+        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 4] = wall_clock64();
+#endif
         const float h = P.hsub;
         const float gb4 = P.gb[4], b4 = P.b[4], a44 = P.a[4][4];
         // The cart row has a constant pivot (a00 = total mass + h * DOF damping), so its elimination is folded into the
@@ -1513,6 +1582,9 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             for (; it + 4 <= P.cfi; it += 4) { VINE_QUAD_ITER(0) VINE_QUAD_ITER(1) VINE_QUAD_ITER(2) VINE_QUAD_ITER(3) }
         }
 #undef VINE_QUAD_ITER
+#ifdef VSQ_TIMING
+        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 5] = wall_clock64();
+#endif
         // ---- refreshed rigid-body states: tip = joint 1 + L sum d_k (quad sums over links 0..3, link 4 on top)
         {
             const float L = P.L;
@@ -1529,10 +1601,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         float prev_q0 = prev_y, prev_qo = prev_q_own, prev_q5v = prev_q5;
         // ---- post_physics_step (V5:1110-1120)
         long long prog = prog_in + 1;
-        long long rst = reset[e];
         const bool was_reset = rst != 0;
-        float agg = ST(VF_AGG_REW);
-        float ty = ST(VF_TARGET_Y), tz = ST(VF_TARGET_Z);
         if (rst != 0) {      // reset_idx (V5:774-839, 887-914): a quad-uniform branch
             const float ten = 0.17453292519943295f;
             float qn1_4[4], qn5, qn0, depth, pdepth;
@@ -1560,6 +1629,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             }
             if (!(P.flags & VINE_FLAG_RANDOMIZE_TARGETS)) { ty = P.ty_max; tz = P.tz_fixed; }
             (void)depth; (void)pdepth;
+            if (SHELF) obj_depth = depth;
             if (SHELF && t == 0) {             // obstacle poses of the new episode (reset_env's arithmetic, V5:818-885)
                 ST(VF_SHELF_Y) = ty + (-0.2f + depth);
                 ST(VF_SHELF_Z) = tz - 0.01f;
@@ -1572,6 +1642,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 const float tp = deg * 0.017453292519943295f;
                 float stp, ctp;
                 sincosf(tp, &stp, &ctp);
+                obj_depth = pdepth; obj_angle = tp;      // (what the observation row shows: the new episode's)
                 if (t == 0) {
                     ST(VF_PIPE_Y) = ty + pdepth * ctp + R * stp;
                     ST(VF_PIPE_Z) = tz + pdepth * stp - R * ctp;
@@ -1620,7 +1691,6 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 if (t == 0) { ST(VF_PREV_Q0) = prev_q0; ST(VF_PREV_Q0 + 5) = prev_q5v; }
             }
         }
-        const float obj_depth = ST(VF_OBJ_DEPTH), obj_angle = ST(VF_OBJ_ANGLE);
         // ---- compute_observations (V5:1339-1390): the row is assembled replicated, then lane t keeps, perturbs, clamps
         // and stores columns [4t, 4t+4) and [16+4t, 16+4t+4)
         float o[32];
@@ -1657,16 +1727,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
         }
         if (RANDOMIZE && P.obs_noise != 0.0f) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                // Philox call index = first column / 4: t for columns [4t, 4t+4), 4 + t for [16+4t, ...)
-                unsigned r[4];
-                float nn[4];
-                rng4(P, (unsigned)e, step, RNG_OBS_NOISE, (unsigned)(4 * half + t), r);
-                normal2(r[0], r[1], nn[0], nn[1]);
-                normal2(r[2], r[3], nn[2], nn[3]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mine[4 * half + j] += P.obs_noise * nn[j];
-            }
+            for (int j = 0; j < 8; ++j) mine[j] += P.obs_noise * onoise[j];      // (drawn in the prologue)
         }
         {
             float* orow = obs + (size_t)e * NOBS;
@@ -1681,6 +1742,9 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 if (t == 0) reinterpret_cast<float2*>(orow)[8] = make_float2(mine[4], mine[5]);
             }
         }
+#ifdef VSQ_TIMING
+        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 6] = wall_clock64();
+#endif
         // ---- compute_reward (V5:1218-1331, 1470-1537), compute_reset (V5:1540-1558): replicated, lane 0 stores
         const float dy = tip_y - ty, dz = tip_z - tz;
         const float dist = sqrtf(dy * dy + dz * dz);
@@ -1739,17 +1803,10 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
             }
         }
     }
-    // ---- advance the step counter once every workgroup has read it (ticket)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        unsigned long long ticket = atomicAdd(&counters[1], 1ull);
-        if (ticket == (unsigned long long)gridDim.x - 1) {
-            counters[1] = 0ull;
-            counters[0] = step + 1ull;
-            __threadfence();
-        }
-    }
+#ifdef VSQ_TIMING
+    if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = wall_clock64();
+#endif
+    step_arrive(counters);
 }
 
 // Tip / cart rigid-body fields of env e from its DOF state (forward kinematics): what a `refresh_rigid_body_state_tensor`
@@ -1785,7 +1842,7 @@ __global__ void vine_reset_idx_kernel(const DevParams P, float* __restrict__ st,
     long long id = env_ids[i];
     if (id < 0 || id >= n) return;
     const int e = (int)id;
-    const unsigned long long step = counters[0] | (1ull << 62);
+    const unsigned long long step = step_of(P, counters) | (1ull << 62);
     // Without introspection the four-lanes-per-env kernel stores the tip / cart rigid-body states only in the step in which
     // an env was reset (it re-derives them from the DOF state otherwise): bring the memory copies up to date from the
     // pre-reset DOF state before they become the stale-by-design body state (P5) of the reset env.  progress == 0 marks
@@ -2014,7 +2071,7 @@ struct VineHandle {
     int device;
     float* state;
     bool owns_state;
-    unsigned long long* counters;  // [0] step count, [1] workgroup ticket
+    unsigned long long* counters;  // [0] step-count base, [1] finished workgroups of step launches since (step_of)
     const float* reset_values;
     float* reward_matrix;
     bool refresh_body;             // introspection was switched on since the last step: the next vine_step refreshes the lazily
@@ -2119,6 +2176,8 @@ int vine_num_obs(const VineConfig* c) {
     return fail(VINE_ERR_INVALID_ARG, "unknown observation type");
 }
 
+static int step_grid_log2(const VineHandle* h);
+
 int vine_create(const VineConfig* cfg, int device_id, float* state_storage, VineHandle** out) {
     int rc = validate(cfg);
     if (rc) return rc;
@@ -2154,6 +2213,7 @@ int vine_create(const VineConfig* cfg, int device_id, float* state_storage, Vine
     if (e != hipSuccess) { if (h->owns_state) (void)hipFree(h->state); delete h; return hip_fail(e, "hipMalloc(counters)"); }
     HIP_TRY(hipMemset(h->state, 0, bytes));
     HIP_TRY(hipMemset(h->counters, 0, 2 * sizeof(unsigned long long)));
+    h->P.glog = step_grid_log2(h);
     const int threads = 256, blocks = (cfg->num_envs + threads - 1) / threads;
     hipLaunchKernelGGL(vine_init_kernel, dim3(blocks), dim3(threads), 0, 0, h->P, h->state);
     HIP_TRY(hipGetLastError());
@@ -2184,6 +2244,16 @@ static bool use_quad_kernel(const VineHandle* h) {
     return quad_ok && (h->step_kernel == 2 || (h->step_kernel == 0 && h->P.n <= 16384));
 }
 
+// log2 of the step launch's grid: the workgroups the kernel needs, rounded up to a power of two (see step_of(); the
+// workgroups past the last env find no live lane and only report their arrival)
+static int step_grid_log2(const VineHandle* h) {
+    const long long blocks = use_quad_kernel(h) ? ((long long)h->P.n * 4 + 255) / 256
+                                                : ((long long)h->P.n + VINE_STEP_THREADS - 1) / VINE_STEP_THREADS;
+    int l = 0;
+    while ((1ll << l) < blocks) ++l;
+    return l;
+}
+
 const char* vine_step_kernel_name(VineHandle* h) {
     if (!h) return "";
     return use_quad_kernel(h) ? "vine_step_quad_kernel" : "vine_step_kernel";
@@ -2195,8 +2265,17 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
         return fail(VINE_ERR_INVALID_ARG, "null argument to vine_step");
     DeviceGuard guard(h->device);
     const int threads = VINE_STEP_THREADS;
-    const int blocks = (h->P.n + threads - 1) / threads;
     hipStream_t s = (hipStream_t)stream;
+    if (step_grid_log2(h) != h->P.glog) {
+        // (the kernel choice changed since the counters were last normalised -- it cannot with the present switches, all of
+        // which are fixed at creation: re-base the step count on the new grid size)
+        const int64_t now = vine_get_step_count(h);
+        if (now < 0) return fail(VINE_ERR_DEVICE, "step count unreadable");
+        h->P.glog = step_grid_log2(h);
+        const int rc = vine_set_step_count(h, now);
+        if (rc != VINE_OK) return rc;
+    }
+    const int blocks = 1 << h->P.glog;
     const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
     const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
     if (h->refresh_body) {
@@ -2205,7 +2284,7 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
                            (const long long*)progress);
     }
     if (use_quad_kernel(h)) {
-        const int qblocks = (int)(((long long)h->P.n * 4 + 255) / 256);
+        const int qblocks = 1 << h->P.glog;
 #define LAUNCH_QUAD_O(OT, RND, OB)                                                                                         \
     hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB>), dim3(qblocks), dim3(256), 0, s, h->P, h->state, actions, obs, rew, \
                        (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,              \
@@ -2321,10 +2400,10 @@ float* vine_state_ptr(VineHandle* h) { return h ? h->state : nullptr; }
 int64_t vine_get_step_count(VineHandle* h) {
     if (!h) return -1;
     DeviceGuard guard(h->device);
-    unsigned long long v = 0;
+    unsigned long long v[2] = {0ull, 0ull};
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(&v, h->counters, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int64_t)v;
+    if (hipMemcpy(v, h->counters, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)(v[0] + (v[1] >> h->P.glog));      // (step_of)
 }
 
 int vine_set_step_count(VineHandle* h, int64_t step_count) {
@@ -2336,4 +2415,9 @@ int vine_set_step_count(VineHandle* h, int64_t step_count) {
     return VINE_OK;
 }
 
+#ifdef VSQ_TIMING
+int vine_debug_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vsq_t), sizeof(unsigned long long) * 1024 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // extern "C"
