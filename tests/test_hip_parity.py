@@ -639,6 +639,30 @@ def test_baseline_config2_free_space_reaching(HipEnv):
     assert orc.reset_buf.sum() > 0          # targets get reached / limits hit within 30 steps
 
 
+@pytest.mark.parametrize("n", [100, 3000, 4097])
+def test_step_counter_on_padded_grids(HipEnv, n):
+    """The step count is base + (finished workgroups >> log2 grid) and step launches have power-of-two grids: env counts
+    whose natural grid is NOT a power of two (the padding workgroups find no live env and only report their arrival) must
+    count one per step, survive set / get, and key the random streams exactly as the oracle's explicit counter does."""
+    cfg = base_cfg(n, 0, True)
+    hip, orc = HipEnv(cfg), vo.OracleEnv(cfg, "f32")
+    rng = np.random.default_rng(9)
+    for k in range(1, 6):
+        a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+        obs, rew, rst, _ = hip.step(a)
+        orc.step(a)
+        assert hip.step_count == k == orc.step_count
+        np.testing.assert_allclose(obs, orc.obs, rtol=0, atol=2e-4)
+    hip.step_count = orc.step_count = 1000
+    assert hip.step_count == 1000
+    a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    obs, rew, rst, _ = hip.step(a)
+    orc.step(a)
+    assert hip.step_count == 1001
+    np.testing.assert_allclose(obs, orc.obs, rtol=0, atol=2e-4)      # (observation noise keyed by step 1000: the same draws)
+    np.testing.assert_array_equal(rst, orc.reset_buf)
+
+
 def test_largest_single_gpu_configuration(HipEnv):
     """BASELINE.json configs[3] puts 131072 envs on 8 GPUs; one GPU takes all of them too (state 31 MB).
     Determinism, bounds and the step counter at that size; first and last env against the oracle."""
