@@ -2176,6 +2176,9 @@ int vine_num_obs(const VineConfig* c) {
     return fail(VINE_ERR_INVALID_ARG, "unknown observation type");
 }
 
+#ifndef VSQ_THREADS
+#define VSQ_THREADS 256      // threads per workgroup of the four-lane step kernel (A/B: 64 / 128)
+#endif
 static int step_grid_log2(const VineHandle* h);
 
 int vine_create(const VineConfig* cfg, int device_id, float* state_storage, VineHandle** out) {
@@ -2247,7 +2250,7 @@ static bool use_quad_kernel(const VineHandle* h) {
 // log2 of the step launch's grid: the workgroups the kernel needs, rounded up to a power of two (see step_of(); the
 // workgroups past the last env find no live lane and only report their arrival)
 static int step_grid_log2(const VineHandle* h) {
-    const long long blocks = use_quad_kernel(h) ? ((long long)h->P.n * 4 + 255) / 256
+    const long long blocks = use_quad_kernel(h) ? ((long long)h->P.n * 4 + VSQ_THREADS - 1) / VSQ_THREADS
                                                 : ((long long)h->P.n + VINE_STEP_THREADS - 1) / VINE_STEP_THREADS;
     int l = 0;
     while ((1ll << l) < blocks) ++l;
@@ -2286,7 +2289,7 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     if (use_quad_kernel(h)) {
         const int qblocks = 1 << h->P.glog;
 #define LAUNCH_QUAD_O(OT, RND, OB)                                                                                         \
-    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB>), dim3(qblocks), dim3(256), 0, s, h->P, h->state, actions, obs, rew, \
+    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB>), dim3(qblocks), dim3(VSQ_THREADS), 0, s, h->P, h->state, actions, obs, rew, \
                        (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,              \
                        h->reset_values, h->counters)
 #define LAUNCH_QUAD(OT, RND)                        \
