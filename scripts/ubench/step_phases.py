@@ -13,11 +13,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from vine_robot_isaacgymenvs_amd import load_config, native
 from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
 
-cfg = load_config(overrides=["num_envs=16384"] + sys.argv[1:])
+N = int(os.environ.get("STEP_N", "16384"))
+cfg = load_config(overrides=["num_envs=%d" % N] + sys.argv[1:])
 env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0", graphics_device_id=0,
                                               headless=True)
 env.reset()
-act = torch.rand(16384, 2, device="cuda:0") * 2 - 1
+act = torch.rand(N, 2, device="cuda:0") * 2 - 1
 for _ in range(200):
     env.step(act)
 torch.cuda.synchronize()
@@ -25,7 +26,7 @@ lib = native.load()
 buf = (C.c_uint64 * (1024 * 8))()
 lib.vine_debug_timing.argtypes = [C.c_void_p]
 assert lib.vine_debug_timing(buf) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
+t = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)[:N * 4 // 64]
 t0 = t[:, 0].min()
 names = ["entry", "loads issued", "constants", "RNG done", "loads back", "iterations done", "post + obs done", "end"]
 for i, nm in enumerate(names):

@@ -105,11 +105,15 @@ __device__ __forceinline__ void step_arrive(unsigned long long* counters) {
 }
 __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 __device__ __forceinline__ void normal2(unsigned a, unsigned b, float& n0, float& n1) {
+    // Box-Muller on the hardware's log2 / sin / cos (v_log_f32, v_sin_f32, v_cos_f32 take the angle in revolutions, i.e.
+    // u2 itself): ~10 instructions instead of the ~250 of logf + sinf + cosf with their range reductions; the step draws
+    // five pairs per lane.  Absolute error of a deviate ~1e-6, scaled by the noise amplitudes (1e-2 .. 1e-3): far below
+    // the fp32 rounding of the observation it is added to; the oracle keeps libm (tests: tolerance).
     float u1 = 1.0f - u01(a), u2 = u01(b);
-    float r = sqrtf(-2.0f * logf(u1));
+    float r = sqrtf(-2.0f * __logf(u1));
     float t = 6.283185307179586f * u2;
-    n0 = r * cosf(t);
-    n1 = r * sinf(t);
+    n0 = r * __cosf(t);
+    n1 = r * __sinf(t);
 }
 
 // Articulation state in absolute coordinates: cart (y, vy), link angles th_k = sum_{i<=k} q_i, rates w_k.
@@ -1227,24 +1231,35 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
 #ifdef VSQ_TIMING
         if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 1] = wall_clock64();
 #endif
-        // ---- per-lane constants of link t / joint t (pin_s: all four candidates in scalar registers, one v_cndmask chain)
-#define SEL4P(x0, x1, x2, x3) sel4(t, pin_s(x0), pin_s(x1), pin_s(x2), pin_s(x3))
-        const float b_t = SEL4P(P.b[0], P.b[1], P.b[2], P.b[3]);
-        const float gb_t = SEL4P(P.gb[0], P.gb[1], P.gb[2], P.gb[3]);
+        // ---- per-lane constants of link t / joint t.  The 44 kernel-argument words they are selected from are pinned into
+        // scalar registers by TWO asm statements (24 + 20 operands): the loads of each group are issued together and waited
+        // for once.  Unpinned, the compiler sinks each P.x[i] into the arm of the select that uses it (45 scalar loads, a
+        // wait each: 1.1 us); pinned one select at a time it still waited eleven times.
+        float cb[4] = {P.b[0], P.b[1], P.b[2], P.b[3]}, cgb[4] = {P.gb[0], P.gb[1], P.gb[2], P.gb[3]};
+        float ca[4][4] = {{P.a[0][0], P.a[1][0], P.a[2][0], P.a[3][0]}, {P.a[0][1], P.a[1][1], P.a[2][1], P.a[3][1]},
+                          {P.a[0][2], P.a[1][2], P.a[2][2], P.a[3][2]}, {P.a[0][3], P.a[1][3], P.a[2][3], P.a[3][3]}};
+        float ca4[4] = {P.a[0][4], P.a[1][4], P.a[2][4], P.a[3][4]};
+        float cK[4] = {P.K[0], P.K[1], P.K[2], P.K[3]}, cC[4] = {P.C[0], P.C[1], P.C[2], P.C[3]};
+        float cbb[4] = {P.bb[0], P.bb[1], P.bb[2], P.bb[3]}, cB[4] = {P.B[0], P.B[1], P.B[2], P.B[3]};
+        asm volatile("" : "+s"(cb[0]), "+s"(cb[1]), "+s"(cb[2]), "+s"(cb[3]), "+s"(cgb[0]), "+s"(cgb[1]), "+s"(cgb[2]), "+s"(cgb[3]),
+                          "+s"(ca[0][0]), "+s"(ca[0][1]), "+s"(ca[0][2]), "+s"(ca[0][3]), "+s"(ca[1][0]), "+s"(ca[1][1]),
+                          "+s"(ca[1][2]), "+s"(ca[1][3]), "+s"(ca[2][0]), "+s"(ca[2][1]), "+s"(ca[2][2]), "+s"(ca[2][3]),
+                          "+s"(ca[3][0]), "+s"(ca[3][1]), "+s"(ca[3][2]), "+s"(ca[3][3]));
+        asm volatile("" : "+s"(ca4[0]), "+s"(ca4[1]), "+s"(ca4[2]), "+s"(ca4[3]), "+s"(cK[0]), "+s"(cK[1]), "+s"(cK[2]), "+s"(cK[3]),
+                          "+s"(cC[0]), "+s"(cC[1]), "+s"(cC[2]), "+s"(cC[3]), "+s"(cbb[0]), "+s"(cbb[1]), "+s"(cbb[2]), "+s"(cbb[3]),
+                          "+s"(cB[0]), "+s"(cB[1]), "+s"(cB[2]), "+s"(cB[3]));
+        const float b_t = sel4(t, cb[0], cb[1], cb[2], cb[3]);
+        const float gb_t = sel4(t, cgb[0], cgb[1], cgb[2], cgb[3]);
         const float nb_t = -b_t;
         float a_k[4], as_k[4];                           // a_tk (cos terms; a_tt on the diagonal), the same with 0 on the diagonal
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            a_k[k] = SEL4P(P.a[0][k], P.a[1][k], P.a[2][k], P.a[3][k]);
+            a_k[k] = sel4(t, ca[k][0], ca[k][1], ca[k][2], ca[k][3]);
             as_k[k] = t == k ? 0.0f : a_k[k];
         }
-        const float a_t4 = SEL4P(P.a[0][4], P.a[1][4], P.a[2][4], P.a[3][4]);
-        const float K_t = SEL4P(P.K[0], P.K[1], P.K[2], P.K[3]), C_t = SEL4P(P.C[0], P.C[1], P.C[2], P.C[3]);
-        const float bb_t = SEL4P(P.bb[0], P.bb[1], P.bb[2], P.bb[3]), B_t = SEL4P(P.B[0], P.B[1], P.B[2], P.B[3]);
-#undef SEL4P
-#ifdef VSQ_TIMING
-        if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 2] = wall_clock64();
-#endif
+        const float a_t4 = sel4(t, ca4[0], ca4[1], ca4[2], ca4[3]);
+        const float K_t = sel4(t, cK[0], cK[1], cK[2], cK[3]), C_t = sel4(t, cC[0], cC[1], cC[2], cC[3]);
+        const float bb_t = sel4(t, cbb[0], cbb[1], cbb[2], cbb[3]), B_t = sel4(t, cB[0], cB[1], cB[2], cB[3]);
         // ---- random numbers of the step that do not depend on its state (pure ALU: the loads above are in flight)
         float an0 = 0.0f, an1 = 0.0f;
         if (RANDOMIZE && P.act_noise != 0.0f) {
