@@ -508,17 +508,29 @@ __device__ __forceinline__ uint4 pack_lp16x8(const float (&v)[8]) {
 // 16-bit format, unmasked, is the only copy -- slot 0 = h0, slot t + 1 = h_t; the LayerNorm reads slots 1 .. T as an
 // autocast LSTM's output, the weight-gradient kernel reads slots 0 .. T - 1 and applies done[k] itself (`hp` unused):
 // 30 MB fewer stores per launch at the update's shape.
+#ifdef SEQ_TIMING
+__device__ unsigned long long seq_t[256 * 8 * 16];      // (debug build: 4 stamps per step and wave, scripts/ubench/lstm_seq_phases.py)
+#endif
 template <int KS1, int RING, typename CT, typename HT>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
 __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     int T, long long B, const lp16_t* __restrict__ x, long long ldx, lp16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
     const unsigned char* __restrict__ done, HT* __restrict__ h_out, CT* __restrict__ c_all,
     lp16_t* __restrict__ gates, int ablate, float* __restrict__ c_last, const float* __restrict__ h0) {
-    constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, K = 32 * KSTEPS, NF = KSTEPS * 8;
-    constexpr int PITCH = K + 8;                                 // bf16 elements per LDS row (16-B row skew)
+    constexpr int H = SEQ_H, KSTEPS = KS1 + 8, KX = 32 * KS1, NF = KSTEPS * 8;
+    // LDS operand rows (16-B row skew; both pitches put the 16 rows of a fragment read on distinct bank groups): the x
+    // blocks of ALL T steps, staged once in the prologue, and the masked h_{t-1} in two buffers.  The x k-steps of a step
+    // need nothing from the step before, so the one workgroup barrier per step sits BEHIND them: a wave that finishes its
+    // pointwise epilogue early runs the next step's x part while the slowest wave is still storing (the waves reach the
+    // barrier up to 2 us apart: per-step stamps, profiles/r03/update_kernel_experiments.txt).
+    constexpr int XP = KX + 8, HP = H + 8;
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
-    __shared__ __attribute__((aligned(16))) lp16_t xh[2][SEQ_ROWS * PITCH];      // [x_t | masked h_{t-1}] operand rows
-    __shared__ __attribute__((aligned(16))) float bias_l[4 * H];
+    // (dynamic: T x 6.5 KB + 33 KB + 4 KB goes past the 64 KB a kernel gets without asking)
+    extern __shared__ __attribute__((aligned(16))) unsigned char seqf_lds[];
+    float* bias_l = reinterpret_cast<float*>(seqf_lds);                                             // [4H]
+    lp16_t (*hl)[SEQ_ROWS * HP] = reinterpret_cast<lp16_t (*)[SEQ_ROWS * HP]>(seqf_lds + 4 * H * sizeof(float));   // [2]: masked h_{t-1}, ping-pong
+    lp16_t (*xs)[SEQ_ROWS * XP] = reinterpret_cast<lp16_t (*)[SEQ_ROWS * XP]>(seqf_lds + 4 * H * sizeof(float) +
+                                                                            2 * SEQ_ROWS * HP * sizeof(lp16_t));   // [T]: x_t of every step
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the stream base below lives in SGPRs
     const int col = lane & 15, lq = lane >> 4;
@@ -535,12 +547,13 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     uint4 ring[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = SEQ_WFRAG(i);
-    // ---- operand tile of step 0, bias, cell state, done flags
+    // ---- x rows of all steps, masked h of step 0, bias, cell state, done flags
     {
-        for (int p = tid; p < SEQ_ROWS * (KX / 8); p += 512) {
-            const int r = p / (KX / 8), c8 = p - r * (KX / 8);
-            *reinterpret_cast<uint4*>(&xh[0][r * PITCH + 8 * c8]) =
-                *reinterpret_cast<const uint4*>(x + ((b0 + r) * T) * ldx + 8 * c8);
+        for (int p = tid; p < T * SEQ_ROWS * (KX / 8); p += 512) {
+            const int tt = p / (SEQ_ROWS * (KX / 8)), q = p - tt * (SEQ_ROWS * (KX / 8));
+            const int r = q / (KX / 8), c8 = q - r * (KX / 8);
+            *reinterpret_cast<uint4*>(&xs[tt][r * XP + 8 * c8]) =
+                *reinterpret_cast<const uint4*>(x + ((b0 + r) * T + tt) * ldx + 8 * c8);
         }
         for (int p = tid; p < SEQ_ROWS * (H / 8); p += 512) {
             const int r = p >> 5, c8 = p & 31;
@@ -562,7 +575,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
             } else {
                 hv = *reinterpret_cast<const uint4*>(hp + (b0 + r) * hp_stride + 8 * c8);      // slot 0: masked h_{-1}
             }
-            *reinterpret_cast<uint4*>(&xh[0][r * PITCH + KX + 8 * c8]) = hv;
+            *reinterpret_cast<uint4*>(&hl[0][r * HP + 8 * c8]) = hv;
         }
         for (int p = tid; p < H; p += 512) st4(&bias_l[4 * p], ld4(bias + 4 * p));
     }
@@ -581,15 +594,14 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     }
 #pragma unroll 1
     for (int t = 0; t < T; ++t) {
-        seq_barrier();                                           // xh[t & 1] complete (and bias_l on the first pass)
-        const lp16_t* xb = xh[t & 1];
-        lp16_t* xn = xh[(t + 1) & 1];
+#ifdef SEQ_TIMING
+        if (lane == 0 && t < 4) seq_t[(blockIdx.x * 8 + w) * 16 + 4 * t + 0] = wall_clock64();
+#endif
+        if (t == 0) seq_barrier();                               // xs (all steps), hl[0] and bias_l complete
+        const lp16_t* xb = xs[t];
+        const lp16_t* hb = hl[t & 1];
+        lp16_t* hnext = hl[(t + 1) & 1];
         const bool last = t == T - 1;
-        // x_{t+1}: requested now, moved into the other operand buffer after the matrix loop
-        uint4 xstage = make_uint4(0, 0, 0, 0);
-        const int xr = tid / (KX / 8), xc8 = tid - xr * (KX / 8);
-        const bool xmine = tid < SEQ_ROWS * (KX / 8) && !last;
-        if (xmine) xstage = *reinterpret_cast<const uint4*>(x + ((b0 + xr) * T + t + 1) * ldx + 8 * xc8);
         f32x4_t acc[4][2][2];                                    // [gate][unit tile][row tile]
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -599,8 +611,15 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 for (int rt = 0; rt < 2; ++rt) acc[g][ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            const lp16x8_t a0 = *reinterpret_cast<const lp16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
-            const lp16x8_t a1 = *reinterpret_cast<const lp16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
+            // (the barrier of steps 1 .. T-1: every wave's masked h_{t-1} is in hl[t & 1]; placed after the x k-steps)
+#ifdef SEQ_TIMING
+            if (kk == KS1 && lane == 0 && t < 4) seq_t[(blockIdx.x * 8 + w) * 16 + 4 * t + 1] = wall_clock64();
+#endif
+            if (kk == KS1 && t > 0) seq_barrier();
+            const lp16_t* ob = kk < KS1 ? xb + 32 * kk : hb + 32 * (kk - KS1);
+            const int op = kk < KS1 ? XP : HP;
+            const lp16x8_t a0 = *reinterpret_cast<const lp16x8_t*>(ob + col * op + 8 * lq);
+            const lp16x8_t a1 = *reinterpret_cast<const lp16x8_t*>(ob + (16 + col) * op + 8 * lq);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = kk * 8 + j, slot = f % RING;
@@ -614,7 +633,9 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (xmine) *reinterpret_cast<uint4*>(&xn[xr * PITCH + 8 * xc8]) = xstage;
+#ifdef SEQ_TIMING
+        if (lane == 0 && t < 4) seq_t[(blockIdx.x * 8 + w) * 16 + 4 * t + 2] = wall_clock64();
+#endif
         // ---- pointwise epilogue on the accumulators: lane = batch row 16 rt + col, units U0 .. U0 + 7 (4 per unit tile;
         // the bf16 outputs of tile 0 wait, packed, for tile 1 so that every bf16 store is one 16-B piece)
 #pragma unroll
@@ -672,13 +693,16 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                     }
                     if (!last) {   // the masked state step t + 1 consumes: next operand (LDS) + weight-gradient operand (HBM)
                         const uint4 hm = make_uint4(lo[4].x, lo[4].y, pk[4].x, pk[4].y);
-                        *reinterpret_cast<uint4*>(&xn[(16 * rt + col) * PITCH + KX + U0]) = hm;
+                        *reinterpret_cast<uint4*>(&hnext[(16 * rt + col) * HP + U0]) = hm;
                         if (sizeof(HT) == 4 && !(ablate & 1))
                             *reinterpret_cast<uint4*>(hp + b * hp_stride + (long long)(t + 1) * H + U0) = hm;
                     }
                 }
             }
         }
+#ifdef SEQ_TIMING
+        if (lane == 0 && t < 4) seq_t[(blockIdx.x * 8 + w) * 16 + 4 * t + 3] = wall_clock64();
+#endif
     }
 }
 
@@ -4121,6 +4145,12 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+#ifdef SEQ_TIMING
+int vine_debug_seq_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(seq_t), sizeof(unsigned long long) * 256 * 8 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int vine_lstm_tile_weights(int64_t H, int64_t K, const void* src, int64_t ld, int32_t transposed, void* dst, void* stream) {
     if (!src || !dst || H <= 0 || K <= 0 || ld <= 0) return VINE_ERR_INVALID_ARG;
     if (H != SEQ_H || (K & 31) || (!transposed && (ld < K || (ld & 7))) || (transposed && ld < H)) return VINE_ERR_UNSUPPORTED;
@@ -4153,9 +4183,20 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
     hipStream_t s = (hipStream_t)stream;
     const int ablate = seq_ablate();
 #define VINE_SEQ_FWD_T(KS1, RING, CT, HT)                                                                               \
-    hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT>), grid, block, 0, s, (int)T, (long long)B,               \
-                       (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled, bias, \
-                       c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0)
+    do {                                                                                                                \
+        const size_t lds_ = 4 * SEQ_H * sizeof(float) + ((size_t)2 * SEQ_ROWS * (SEQ_H + 8) +                            \
+                                                         (size_t)T * SEQ_ROWS * (32 * KS1 + 8)) * sizeof(lp16_t);        \
+        static size_t raised_ = 0;                                                                                      \
+        if (lds_ > raised_) {                                                                                           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT>),             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)               \
+                return VINE_ERR_DEVICE;                                                                                 \
+            raised_ = lds_;                                                                                             \
+        }                                                                                                               \
+        hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT>), grid, block, lds_, s, (int)T, (long long)B,        \
+                           (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled,  \
+                           bias, c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0);                  \
+    } while (0)
 #define VINE_SEQ_FWD(KS1, RING)                                                                                         \
     {                                                                                                                   \
         if (h16 && !c_bf16) return VINE_ERR_UNSUPPORTED;                                                                \
@@ -4164,7 +4205,7 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
         else VINE_SEQ_FWD_T(KS1, RING, float, float);                                                                   \
     }
     switch (KX / 32) {
-        case 1: VINE_SEQ_FWD(1, 24) break;      // 72 fragments per step
+        case 1: VINE_SEQ_FWD(1, 18) break;      // 72 fragments per step (24 in flight spills a few registers)
         case 2: VINE_SEQ_FWD(2, 20) break;      // 80
         case 3: VINE_SEQ_FWD(3, 22) break;      // 88: the update's [x (92 + 4 pad) | h] operand
         default: VINE_SEQ_FWD(4, 24) break;     // 96
