@@ -976,11 +976,17 @@ class A2CAgent:
     def train_epoch(self):
         self._epochs_run = getattr(self, "_epochs_run", 0) + 1
         t_play = time.time()
+        # On the GPU the two phases are timed with events on the stream, NOT with a host synchronisation between them: a
+        # sync after the rollout left the device idle while the host issued the ~40 small launches that turn the rollout
+        # buffers into the dataset (0.4 ms of an 11.7 ms iteration); now the host queues them while the rollout graph runs.
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.is_cuda else None
+        if ev:
+            ev[0].record(torch.cuda.current_stream(self.device))
         self.set_eval()
         with torch.no_grad(), _Range("rollout"):
             batch = self.play_steps_rnn()
-        if self.is_cuda:
-            torch.cuda.synchronize(self.device)
+        if ev:
+            ev[1].record(torch.cuda.current_stream(self.device))
         play_time = time.time() - t_play
         t_upd = time.time()
         upd_range = _Range("update")
@@ -1040,10 +1046,17 @@ class A2CAgent:
             if self.normalize_input:
                 self.model.running_mean_std.eval()   # statistics are updated during the first mini-epoch only
         self._flush_pending_adam()                   # the last step's Adam (per-step graphs defer it into the next graph)
-        if self.is_cuda:
+        if ev:
+            ev[2].record(torch.cuda.current_stream(self.device))
             torch.cuda.synchronize(self.device)
         upd_range.__exit__()
         update_time = time.time() - t_upd
+        if ev:
+            # (the split of the iteration as the device saw it; the sum is the host's wall time of the iteration)
+            gp, gu = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+            total = play_time + update_time
+            play_time = total * gp / max(gp + gu, 1e-12)
+            update_time = total - play_time
         m = rows.mean(0)
         stats = {"a_loss": m[0], "c_loss": m[1], "entropy": m[3], "kl": m[4], "b_loss": m[2]}
         return play_time, update_time, stats
