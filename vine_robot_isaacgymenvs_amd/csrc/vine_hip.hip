@@ -1169,6 +1169,12 @@ __device__ __forceinline__ float quad_scan_incl(float v, int t) {
     return s + pick(t >= 2, qperm<0x4E>(s), 0.0f);
 }
 
+#ifndef VSQ_PIPE_COOP_FROM
+#define VSQ_PIPE_COOP_FROM 2      // first link whose pipe contacts are split over the quad (A/B: 1, 2, 3; see §4.1c of DESIGN.md)
+#endif
+#ifndef VSQ_SHELF_COOP_FROM
+#define VSQ_SHELF_COOP_FROM 4     // first link whose shelf contacts are split over the quad (A/B: 3, 4)
+#endif
 #ifdef VSQ_TIMING
 __device__ unsigned long long vsq_t[1024 * 8];      // (debug build: 8 time stamps per wave, scripts/ubench/step_phases.py)
 #endif
@@ -1468,25 +1474,54 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                     // (measured at 16384 envs: the split pays for the pipe -- a reaching vine has links 3 and 4 INSIDE the tube:
                     // default-config training rollout 5.06 -> 4.66 ms -- while the shelf is touched by link 4 almost alone:
                     // there link 3 stays with its own lane (random policy 85 us; with link 3 split as well 95 us))
+                    float cs3y = 0.0f, cs3z = 0.0f, cms3 = 0.0f, s3y = 0.0f, s3z = 0.0f;      // link 3's shelf share (cooperative form)
                     if (SHELF) {
+#if VSQ_SHELF_COOP_FROM <= 3
+                        if (t < 3) shelf_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, shelf_y, shelf_z, fy, fz, mom, sfy, sfz);
+                        shelf_link_contact_coop(P, t, 0.0f, L, p3y, p3z, pv3y, pv3z, sn3, cs3, w3, shelf_y, shelf_z, cs3y, cs3z, cms3, s3y, s3z);
+#else
                         shelf_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, shelf_y, shelf_z, fy, fz, mom, sfy, sfz);
+#endif
                         shelf_link_contact_coop(P, t, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, shelf_y, shelf_z, c4y, c4z, cm4, s4y, s4z);
                     }
+                    float c2y = 0.0f, c2z = 0.0f, cm2 = 0.0f, c1y = 0.0f, c1z = 0.0f, cm1 = 0.0f;
                     if (PIPE) {
-                        if (t < 3) pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom);
+                        if (t < VSQ_PIPE_COOP_FROM) pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom);
+#if VSQ_PIPE_COOP_FROM <= 1
+                        pipe_link_contact_coop(P, t, 0.0f, L, qbcast<1>(py), qbcast<1>(pz), qbcast<1>(pvy), qbcast<1>(pvz),
+                                               qbcast<1>(sn), qbcast<1>(cs), qbcast<1>(w), pipeT, c1y, c1z, cm1);
+#endif
+#if VSQ_PIPE_COOP_FROM <= 2
+                        pipe_link_contact_coop(P, t, 0.0f, L, qbcast<2>(py), qbcast<2>(pz), qbcast<2>(pvy), qbcast<2>(pvz),
+                                               qbcast<2>(sn), qbcast<2>(cs), qbcast<2>(w), pipeT, c2y, c2z, cm2);
+#endif
                         pipe_link_contact_coop(P, t, 0.0f, L, p3y, p3z, pv3y, pv3z, sn3, cs3, w3, pipeT, c3y, c3z, cm3);
                         pipe_link_contact_coop(P, t, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, pipeT, c4y, c4z, cm4);
                     }
                     {   // fold the cooperative partial sums: link 3's totals go to lane 3's slots, link 4's to every lane
                         f4y = quad_sum(c4y); f4z = quad_sum(c4z); mom4 = quad_sum(cm4);
+#if VSQ_SHELF_COOP_FROM <= 3
+                        if (SHELF) {
+                            const float g3y = quad_sum(cs3y), g3z = quad_sum(cs3z), gm3 = quad_sum(cms3);
+                            fy += pick(t == 3, g3y, 0.0f); fz += pick(t == 3, g3z, 0.0f); mom += pick(t == 3, gm3, 0.0f);
+                        }
+#endif
                         if (PIPE) {
                             const float f3y = quad_sum(c3y), f3z = quad_sum(c3z), m3 = quad_sum(cm3);
                             fy += pick(t == 3, f3y, 0.0f); fz += pick(t == 3, f3z, 0.0f); mom += pick(t == 3, m3, 0.0f);
+#if VSQ_PIPE_COOP_FROM <= 2
+                            const float f2y = quad_sum(c2y), f2z = quad_sum(c2z), m2 = quad_sum(cm2);
+                            fy += pick(t == 2, f2y, 0.0f); fz += pick(t == 2, f2z, 0.0f); mom += pick(t == 2, m2, 0.0f);
+#endif
+#if VSQ_PIPE_COOP_FROM <= 1
+                            const float f1y = quad_sum(c1y), f1z = quad_sum(c1z), m1 = quad_sum(cm1);
+                            fy += pick(t == 1, f1y, 0.0f); fz += pick(t == 1, f1z, 0.0f); mom += pick(t == 1, m1, 0.0f);
+#endif
                         }
                     }
                     if (SHELF) {
                         // (sfy / sfz: own-lane strip reactions of links 0..3; s4y / s4z: this lane's share of link 4's)
-                        const float ty_ = quad_sum(sfy + s4y), tz_ = quad_sum(sfz + s4z);
+                        const float ty_ = quad_sum(sfy + s4y + s3y), tz_ = quad_sum(sfz + s4z + s3z);
                         csum += sqrtf(ty_ * ty_ + tz_ * tz_);
                     }
                     const float ify = quad_scan_incl(fy, t), ifz = quad_scan_incl(fz, t);
