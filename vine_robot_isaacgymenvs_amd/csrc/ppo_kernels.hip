@@ -1863,8 +1863,10 @@ __device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int blo
     // piece re-reads piece 0 and is never stored
     const lp16_t* asrc = dy + (k0 + tid / 8) * ldy + m0 + 8 * (tid % 8);
     const int aoff = (tid / 8) * PA + 8 * (tid % 8);
-    uint4 ra_0, rb_0, rb_1, rb_2;
-    rb_1 = rb_2 = make_uint4(0, 0, 0, 0);
+    // two stages in flight in two named register sets (e / o), as in wgrad_cat_wide_kernel: with one stage of prefetch the
+    // kernel was bound by the latency of its own loads (16 stages x ~1 us for the MLP weights)
+    uint4 ra_e, rb0_e, rb1_e, rb2_e, ra_o, rb0_o, rb1_o, rb2_o;
+    rb1_e = rb2_e = rb1_o = rb2_o = make_uint4(0, 0, 0, 0);
 #define WGC_SRC(i)                                                                                             \
     const lp16_t* bsrc##i; long long bstep##i; int boff##i; bool bval##i;                                      \
     {                                                                                                          \
@@ -1878,42 +1880,57 @@ __device__ __forceinline__ void wgrad_cat_body(const WgProblem& P, const int blo
     }
     WGC_SRC(0) WGC_SRC(1) WGC_SRC(2)
 #undef WGC_SRC
-#define WGC_LOAD(it)                                                                                           \
-    ra_0 = *reinterpret_cast<const uint4*>(asrc + (long long)(it) * 32 * ldy);                                 \
-    rb_0 = *reinterpret_cast<const uint4*>(bsrc0 + (long long)(it) * bstep0);                                  \
-    if (NB > 1) rb_1 = *reinterpret_cast<const uint4*>(bsrc1 + (long long)(it) * bstep1);                      \
-    if (NB > 2) rb_2 = *reinterpret_cast<const uint4*>(bsrc2 + (long long)(it) * bstep2);
-#define WGC_STORE(buf)                                                                                         \
-    *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_0;                                                          \
-    if (bval0) *reinterpret_cast<uint4*>(&bl[buf][boff0]) = rb_0;                                              \
-    if (NB > 1 && bval1) *reinterpret_cast<uint4*>(&bl[buf][boff1]) = rb_1;                                    \
-    if (NB > 2 && bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = rb_2;
+#define WGC_LOAD(S, it)                                                                                        \
+    {                                                                                                          \
+        const long long t_ = (it) < stages ? (it) : stages - 1;   /* past the end: a harmless re-read */        \
+        ra_##S = *reinterpret_cast<const uint4*>(asrc + t_ * 32 * ldy);                                        \
+        rb0_##S = *reinterpret_cast<const uint4*>(bsrc0 + t_ * bstep0);                                        \
+        if (NB > 1) rb1_##S = *reinterpret_cast<const uint4*>(bsrc1 + t_ * bstep1);                            \
+        if (NB > 2) rb2_##S = *reinterpret_cast<const uint4*>(bsrc2 + t_ * bstep2);                            \
+        __builtin_amdgcn_sched_barrier(0);   /* requests leave before the products, not after them */          \
+    }
+#define WGC_STORE(S, buf)                                                                                      \
+    *reinterpret_cast<uint4*>(&al[buf][aoff]) = ra_##S;                                                        \
+    if (bval0) *reinterpret_cast<uint4*>(&bl[buf][boff0]) = rb0_##S;                                           \
+    if (NB > 1 && bval1) *reinterpret_cast<uint4*>(&bl[buf][boff1]) = rb1_##S;                                 \
+    if (NB > 2 && bval2) *reinterpret_cast<uint4*>(&bl[buf][boff2]) = rb2_##S;
     f32x4_t acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
     const int g = lane >> 4, il = lane & 15;
     const int ra = (4 * g + (il >> 2)) * PA + 4 * (il & 3) + wave * 16;
     const int rb = (4 * g + (il >> 2)) * PB + 4 * (il & 3);
-    WGC_LOAD(0)
-    WGC_STORE(0)
+#define WGC_COMPUTE(buf)                                                                                       \
+    {                                                                                                          \
+        const lp16_t* ab = al[buf];                                                                            \
+        const lp16_t* bb = bl[buf];                                                                            \
+        const lp16x8_t af = tr_read8(ab + ra, 16 * PA);                                                        \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                    \
+            const lp16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);                                         \
+            acc[nt] = MFMA_LP16(af, bfr, acc[nt]);                                                             \
+        }                                                                                                      \
+    }
+    // invariant at the top of an even stage `it`: LDS buffer 0 holds stage it, the odd set holds stage it + 1 (in flight)
+    WGC_LOAD(e, 0)
+    WGC_LOAD(o, 1)
+    WGC_STORE(e, 0)
     __syncthreads();
 #pragma unroll 1
-    for (int it = 0; it < stages; ++it) {
-        const bool more = it + 1 < stages;
-        if (more) { WGC_LOAD(it + 1) }
-        const lp16_t* ab = al[it & 1];
-        const lp16_t* bb = bl[it & 1];
-        const lp16x8_t af = tr_read8(ab + ra, 16 * PA);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const lp16x8_t bfr = tr_read8(bb + rb + 16 * nt, 16 * PB);
-            acc[nt] = MFMA_LP16(af, bfr, acc[nt]);
+    for (int it = 0; it < stages; it += 2) {
+        WGC_LOAD(e, it + 2)
+        WGC_COMPUTE(0)
+        WGC_STORE(o, 1)
+        __syncthreads();
+        if (it + 1 < stages) {                                   // (stages may be odd here: wave-uniform)
+            WGC_LOAD(o, it + 3)
+            WGC_COMPUTE(1)
+            WGC_STORE(e, 0)
         }
-        if (more) { WGC_STORE((it + 1) & 1) }
         __syncthreads();
     }
 #undef WGC_LOAD
 #undef WGC_STORE
+#undef WGC_COMPUTE
     // D[m = 4g + r][n = il] of column tile nt; virtual column -> (part1 | part2)
     const long long mrow = (long long)slice * M + m0 + wave * 16 + 4 * g;
 #pragma unroll
