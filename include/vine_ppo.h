@@ -391,6 +391,19 @@ int vine_lstm_step_f32(int64_t N, int64_t H, int64_t K, const float* xh, int64_t
                        void* stream);
 int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t ldw, float* dst, void* stream);
 
+/* vine_lstm_step_f32_split: the same step (same operands, same result layout) with every fp32 product formed EXACTLY on
+ * the bf16 matrix cores: an fp32 number is the exact sum of three bfloat16 pieces (8 + 8 + 8 significand bits), a product
+ * of two pieces is exact in the fp32 accumulator, and the 9 piece pairs of (w, x) sum to the exact 48-bit product -- so
+ * `terms` = 9 v_mfma_f32_16x16x32_bf16 replace 8 v_mfma_f32_16x16x4_f32 per tile and 32 k at 16 / 9 of the fp32 matrix
+ * rate, with fp32 accumulation as before (no operand is rounded; the reference's rollout GEMMs are fp32,
+ * a2c_continuous / torch.nn.LSTM under no autocast).  `terms` = 6 leaves out the three pairs below 2^-24 of a product
+ * (a measured variant).  w_split = vine_lstm_tile_weights_split(Wcat [4H, K]): 3 K 4H bfloat16 (6 bytes per weight).
+ * H = 256, K = 352, N % 1024 == 0, 16-byte aligned pointers, else VINE_ERR_UNSUPPORTED. */
+int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const void* w_split,
+                             const float* bias, const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next,
+                             int64_t ldhp, int terms, void* stream);
+int vine_lstm_tile_weights_split(int64_t H, int64_t K, const float* wcat, int64_t ldw, void* dst, void* stream);
+
 /* Allocates the library's small per-device bookkeeping (the ticket words of the loss / Adam kernels' "last workgroup"
  * elections) for the CURRENT device.  It happens by itself on the first vine_ppo_loss / vine_ln_heads_loss /
  * vine_adam_step* call on a device; call this once beforehand when that first call would sit inside a stream capture

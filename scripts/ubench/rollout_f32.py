@@ -45,7 +45,23 @@ def mlp(i):
                                  Ws[2].data_ptr(), 128, bs[2].data_ptr(), 64, 1.0, st) == 0
 
 
-for name, fn, flop in (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("mlp3_elu_f32", mlp, 2.0 * N * (32 * 256 + 256 * 128 + 128 * 64))):
+ws = torch.empty(3 * 4 * H * K, device=dev, dtype=torch.bfloat16)
+assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), K, ws.data_ptr(), st) == 0
+
+
+def lstm_split(variant):
+    def run(i):
+        a, b = xh[i & 1], xh[(i & 1) ^ 1]
+        assert lib.vine_lstm_step_f32_split(N, H, K, a.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c.data_ptr(), h.data_ptr(),
+                                            H, c.data_ptr(), b.data_ptr() + 4 * 96, K, variant, st) == 0
+    return run
+
+
+SPLITS = tuple(("lstm_split t%d rt%d nb%d" % (t, rt, nb), lstm_split(t + 256 * rt + 65536 * nb), 2.0 * N * K * 4 * H)
+               for t in (9, 6) for rt, nb in ((2, 1), (2, 2), (4, 1)))
+SPLITS += tuple(("lstm_split2 t%d rt%d v%d" % (t, rt, v), lstm_split(t + 256 * rt + 65536 + (v << 24)), 2.0 * N * K * 4 * H)
+                for t in (9, 6) for rt, v in ((2, 1), (2, 2), (4, 1)))
+for name, fn, flop in SPLITS + (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("mlp3_elu_f32", mlp, 2.0 * N * (32 * 256 + 256 * 128 + 128 * 64))):
     for i in range(5):
         fn(i)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1850,6 +1850,67 @@ def test_lstm_step_f32_against_float64_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("terms", [9, 6])
+def test_lstm_step_f32_split_against_float64_torch(terms):
+    """vine_lstm_step_f32_split (fp32 operands split exactly into three bf16 pieces, every piece product exact in the
+    fp32 accumulator of the bf16 matrix cores) against float64 torch: the pre-activations must be at least as close to the
+    float64 product as those of the native fp32 matrix-core kernel (9 terms: no bit of a product is dropped), and
+    h / c within the same 1e-5 the native kernel is held to.  Operand magnitudes span 2^-20 .. 2^6 so that a piece that
+    were rounded away would show."""
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    N, H, K = 2048, 256, 352
+    xh = torch.randn(N, K, device=dev) * torch.exp2(torch.randint(-20, 3, (N, K), device=dev).float())
+    xh[:, 92:96] = 0.0
+    wcat = torch.randn(4 * H, K, device=dev) / np.sqrt(K) * torch.exp2(torch.randint(-12, 3, (4 * H, K), device=dev).float())
+    bias = torch.randn(4 * H, device=dev) * 0.1
+    c_prev = torch.randn(N, H, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(3 * 4 * H * K, device=dev, dtype=torch.bfloat16)
+    assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), wcat.stride(0), ws.data_ptr(), st) == 0
+    # the three pieces sum back to the fp32 weight exactly (checked through the tile order: sums over pieces of a chunk)
+    pieces = ws.view(8, K // 32, 3, 8, 64, 8).float()
+    back = pieces.sum(dim=2)                                   # [ub, j, tile, lane, e]: exact in fp32 (hi + mid + lo)
+    ub, j, tile, lane, e = torch.meshgrid(*(torch.arange(n, device=dev) for n in back.shape), indexing="ij")
+    rows = (tile >> 1) * H + ub * 32 + 16 * (tile & 1) + (lane & 15)
+    cols = 32 * j + 8 * (lane >> 4) + e
+    assert torch.equal(back, wcat[rows, cols])
+    h_out, c_out = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+    nxt = torch.zeros(N, K, device=dev)
+    assert lib.vine_lstm_step_f32_split(N, H, K, xh.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c_prev.data_ptr(),
+                                        h_out.data_ptr(), H, c_out.data_ptr(), nxt.data_ptr() + 4 * 96, K, terms, st) == 0
+    torch.cuda.synchronize()
+    g = xh.double() @ wcat.double().t() + bias.double()
+    i, f, gg, o = (g[:, k * H:(k + 1) * H] for k in range(4))
+    c = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    err_c, err_h = float((c_out.double() - c).abs().max()), float((h_out.double() - h).abs().max())
+    # the native fp32 matrix-core kernel on the same operands
+    wt = torch.empty(4 * H * K, device=dev)
+    assert lib.vine_lstm_tile_weights_f32(H, K, wcat.data_ptr(), wcat.stride(0), wt.data_ptr(), st) == 0
+    h_ref, c_ref = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+    assert lib.vine_lstm_step_f32(N, H, K, xh.data_ptr(), K, wt.data_ptr(), bias.data_ptr(), c_prev.data_ptr(), h_ref.data_ptr(),
+                                  H, c_ref.data_ptr(), None, 0, st) == 0
+    torch.cuda.synchronize()
+    ref_c, ref_h = float((c_ref.double() - c).abs().max()), float((h_ref.double() - h).abs().max())
+    print("terms %d: max |c - f64| %.3e (native fp32 MFMA %.3e), max |h - f64| %.3e (native %.3e)"
+          % (terms, err_c, ref_c, err_h, ref_h))
+    assert err_c < 1e-5 and err_h < 1e-5
+    assert err_c <= 1.5 * ref_c + 1e-7 and err_h <= 1.5 * ref_h + 1e-7
+    assert torch.equal(nxt[:, 96:], h_out) and float(nxt[:, :96].abs().max()) == 0.0
+    # in place on the cell state (what the rollout does) gives the same result
+    c_io = c_prev.clone()
+    assert lib.vine_lstm_step_f32_split(N, H, K, xh.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c_io.data_ptr(),
+                                        h_out.data_ptr(), H, c_io.data_ptr(), None, 0, terms, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(c_io, c_out)
+    assert lib.vine_lstm_step_f32_split(N + 64, H, K, xh.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c_prev.data_ptr(),
+                                        h_out.data_ptr(), H, c_out.data_ptr(), None, 0, terms, st) == -2
+
+
+@pytest.mark.gpu
 def test_gae_kernel_against_reference_text_golden():
     """F9 through the HIP kernel (vine_gae: one env per lane, reverse scan in registers)."""
     import os

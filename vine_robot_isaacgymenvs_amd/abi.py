@@ -212,6 +212,8 @@ PPO_PROTOTYPES = {
                                     _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP]),
     "vine_lstm_step_f32": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _I64, _VP]),
     "vine_lstm_tile_weights_f32": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP]),
+    "vine_lstm_step_f32_split": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _I64, C.c_int, _VP]),
+    "vine_lstm_tile_weights_split": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP]),
     "vine_ln_heads_loss_rows": (C.c_int, []),
     "vine_mlp3_bwd_elu_mfma": (C.c_int, [_I64, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _I64, _I64,
                                          _I64, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -3885,6 +3885,200 @@ __global__ void lstm_tile_weights_f32_kernel(int KB, const float* __restrict__ w
     }
 }
 
+// ---- LSTM step, fp32 operands, EXACT products on the bf16 matrix cores ("split" form).  An fp32 number is the exact sum
+// of three bfloat16 numbers: hi = bf16(v), mid = bf16(v - hi), lo = v - hi - mid (round to nearest: each piece takes 8 of
+// the 24 significand bits; both subtractions are exact in fp32 and lo fits bf16's 8 bits).  A product of two bf16 pieces
+// has 16 significand bits and is exact in the matrix core's fp32 accumulator, so
+//     w x = sum over the 9 piece pairs (w_p x_q)
+// holds exactly, term by term, and gates = [x | h] Wcat^T is formed as NT = 9 v_mfma_f32_16x16x32_bf16 per tile and
+// k-step instead of 8 v_mfma_f32_16x16x4_f32: every bit of every fp32 product enters the fp32 accumulation (the native
+// fp32 MFMA rounds each product into the running sum as well), at 16 / 9 of the fp32 matrix rate.  NT = 6 is the same
+// without the three pairs below 2^-24 of the product (mid lo, lo mid, lo lo: less than the rounding of one fp32
+// multiply); kept as a measured variant, not the default.
+// Shapes: workgroup = 4 waves = 64 RT batch rows x 32 hidden units (x 4 gates = 8 weight tiles); a wave owns RT row tiles
+// of 16 rows and all 8 x RT accumulator tiles (transposed product D^T = W X^T as above: a lane ends up with 4 consecutive
+// units of one batch row per tile, all four gates of a unit on the same lane).  The weights arrive pre-split and
+// pre-tiled in MFMA-fragment order ([unit block][k-step][piece][tile][lane][8], vine_lstm_tile_weights_split: one
+// contiguous 24 KB chunk per workgroup and k-step) and are streamed through two LDS buffers, the next chunk's global loads
+// in flight under the current chunk's 72 RT MFMAs per wave; a fragment read is one conflict-free ds_read_b128 per lane.
+// X is loaded as fp32 (two float4 per lane, row tile and k-step, one k-step ahead) and split in registers.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float a, float b) {          // v_cvt_pk_bf16_f32, round to nearest even
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// eight fp32 values -> the three bf16 pieces of each (packed pairs), v = hi + mid + lo exactly
+__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], uint4& hi, uint4& mid, uint4& lo) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        h[i] = bf16_pack2(a, b);
+        const float ra = a - __uint_as_float(h[i] << 16), rb = b - __uint_as_float(h[i] & 0xFFFF0000u);
+        m[i] = bf16_pack2(ra, rb);
+        const float sa = ra - __uint_as_float(m[i] << 16), sb = rb - __uint_as_float(m[i] & 0xFFFF0000u);
+        l[i] = bf16_pack2(sa, sb);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    mid = make_uint4(m[0], m[1], m[2], m[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ f32x4_t mfma_bf16(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+#define LSTM_SPLIT_CHUNK (3 * 8 * 64 * 8)          // bf16 elements of one (unit block, k-step) weight chunk: 24 KB
+// K = 32 KS; RT row tiles per wave; NT = 9 (exact) or 6 piece pairs.  The split of the NEXT k-step's X sits inside the
+// current k-step's MFMA stream (second set of piece registers): an MFMA holds the SIMD's vector issue for 8 of its 16
+// cycles, so the ~44 RT conversion instructions per k-step ride in the gaps instead of standing in front of the k-step's
+// first MFMA (99.6 -> 76.7 us at RT = 2, profiles/r03/rollout_f32_split.txt).
+template <int KS, int RT, int NT>
+__global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, const float* __restrict__ xh, long long ldx,
+                                                                  const unsigned short* __restrict__ wt,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                                  long long ldh, float* __restrict__ c_out,
+                                                                  float* __restrict__ hp_next, long long ldhp, int xcd_map) {
+    constexpr int H = 256;
+    __shared__ __attribute__((aligned(16))) uint4 wl[2][3 * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x;
+    const int rbs = xcd_map ? (w >> 6) * 8 + (w & 7) : (w >> 3);
+    const int ub = xcd_map ? (w >> 3) & 7 : (w & 7);
+    const long long row0 = (long long)rbs * (64 * RT) + wave * (16 * RT) + u;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(wt) + (long long)ub * KS * (LSTM_SPLIT_CHUNK / 8);
+    const float* xrow = xh + row0 * ldx + 8 * g;
+    float4 xf[RT][2];
+    uint4 xp[2][RT][3];
+    {
+        uint4 sreg[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sreg[i] = wsrc[tid + 256 * i];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            xf[rt][0] = ld4(xrow + (long long)rt * 16 * ldx);
+            xf[rt][1] = ld4(xrow + (long long)rt * 16 * ldx + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wl[0][tid + 256 * i] = sreg[i];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const float v[8] = {xf[rt][0].x, xf[rt][0].y, xf[rt][0].z, xf[rt][0].w,
+                                xf[rt][1].x, xf[rt][1].y, xf[rt][1].z, xf[rt][1].w};
+            split3_bf16x8(v, xp[0][rt][0], xp[0][rt][1], xp[0][rt][2]);
+            if (KS > 1) {
+                xf[rt][0] = ld4(xrow + (long long)rt * 16 * ldx + 32);
+                xf[rt][1] = ld4(xrow + (long long)rt * 16 * ldx + 32 + 4);
+            }
+        }
+    }
+    f32x4_t acc[8][RT];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[t][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    float4 cp[2][RT];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {                      // fully unrolled: buffers and piece sets stay register names
+        const int buf = j & 1;
+        uint4 sreg[6];
+        if (j + 1 < KS) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sreg[i] = wsrc[(long long)(j + 1) * (LSTM_SPLIT_CHUNK / 8) + tid + 256 * i];
+        } else {                                                     // the epilogue's cell states, requested a k-step early
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    cp[ut][rt] = ld4(c_prev + (row0 + 16 * rt) * H + ub * 32 + 16 * ut + 4 * g);
+        }
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            uint4 wf[2][3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[tt][p] = wl[buf][(p * 8 + 2 * tp + tt) * 64 + lane];
+            constexpr int PP[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, QQ[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int n = 9 - NT; n < 9; ++n)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        acc[2 * tp + tt][rt] = mfma_bf16(wf[tt][PP[n]], xp[buf][rt][QQ[n]], acc[2 * tp + tt][rt]);
+            if (tp == 0 && j + 1 < KS) {
+                // X of k-step j + 1 (requested during k-step j - 1) -> the other piece set; then request k-step j + 2
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float v[8] = {xf[rt][0].x, xf[rt][0].y, xf[rt][0].z, xf[rt][0].w,
+                                        xf[rt][1].x, xf[rt][1].y, xf[rt][1].z, xf[rt][1].w};
+                    split3_bf16x8(v, xp[buf ^ 1][rt][0], xp[buf ^ 1][rt][1], xp[buf ^ 1][rt][2]);
+                    if (j + 2 < KS) {
+                        xf[rt][0] = ld4(xrow + (long long)rt * 16 * ldx + 32 * (j + 2));
+                        xf[rt][1] = ld4(xrow + (long long)rt * 16 * ldx + 32 * (j + 2) + 4);
+                    }
+                }
+            }
+        }
+        if (j + 1 < KS) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) wl[buf ^ 1][tid + 256 * i] = sreg[i];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut) {
+        const int unit = ub * 32 + 16 * ut + 4 * g;
+        const float4 bi = ld4(bias + 0 * H + unit), bf = ld4(bias + 1 * H + unit), bg = ld4(bias + 2 * H + unit),
+                     bo = ld4(bias + 3 * H + unit);
+        const float bia[4] = {bi.x, bi.y, bi.z, bi.w}, bfa[4] = {bf.x, bf.y, bf.z, bf.w}, bga[4] = {bg.x, bg.y, bg.z, bg.w},
+                    boa[4] = {bo.x, bo.y, bo.z, bo.w};
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const long long row = row0 + 16 * rt;
+            const float cpa[4] = {cp[ut][rt].x, cp[ut][rt].y, cp[ut][rt].z, cp[ut][rt].w};
+            float cn[4], hn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gi = sigmoidf_(acc[0 + ut][rt][r] + bia[r]), gf = sigmoidf_(acc[2 + ut][rt][r] + bfa[r]);
+                const float gc = tanhf_(acc[4 + ut][rt][r] + bga[r]), go = sigmoidf_(acc[6 + ut][rt][r] + boa[r]);
+                cn[r] = gf * cpa[r] + gi * gc;
+                hn[r] = go * tanhf_(cn[r]);
+            }
+            st4(c_out + row * H + unit, make_float4(cn[0], cn[1], cn[2], cn[3]));
+            st4(h_out + row * ldh + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
+            if (hp_next) st4(hp_next + row * ldhp + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        }
+    }
+}
+
+// [w_ih | 0 | w_hh] rows (4H x K fp32, row stride ldw) -> the split step kernel's chunks of bf16 pieces:
+// dst[((((ub * KS + j) * 3 + piece) * 8 + 2 gate + ut) * 64 + lane) * 8 + e] = piece of W[gate * H + ub * 32 + 16 ut + (lane & 15)]
+// [32 j + 8 (lane >> 4) + e] -- one thread per (chunk, tile, lane): 8 consecutive k of one weight row
+__global__ void lstm_tile_weights_split_kernel(int KS, const float* __restrict__ w, long long ldw, uint4* __restrict__ dst) {
+    const long long total = 8LL * KS * 8 * 64;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(q & 63), tile = (int)((q >> 6) & 7);
+        const long long chunk = q >> 9;                                // ub * KS + j
+        const int j = (int)(chunk % KS), ub = (int)(chunk / KS);
+        const int gate = tile >> 1, ut = tile & 1;
+        const float* src = w + (long long)(gate * 256 + ub * 32 + 16 * ut + (lane & 15)) * ldw + 32 * j + 8 * (lane >> 4);
+        const float4 a = ld4(src), b = ld4(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint4 hi, mid, lo;
+        split3_bf16x8(v, hi, mid, lo);
+        uint4* d = dst + chunk * (LSTM_SPLIT_CHUNK / 8) + tile * 64 + lane;
+        d[0] = hi;
+        d[8 * 64] = mid;
+        d[2 * 8 * 64] = lo;
+    }
+}
+
 // ---- observation normalisation + the three MLP layers (C1 = 256, C2 = 128, C3 = 64, ELU), fp32, ONE launch: a wave
 // carries its 16 rows through the layers in registers -- the accumulator of unit tile t of layer L (lane: units
 // 16 t + 4 g + {0..3} of its row) IS the B operand float4 of k-block t of layer L + 1 (k = 16 t + 4 g + i), no exchange.
@@ -4948,6 +5142,44 @@ int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t 
     const int KB = (int)(K / 16);
     hipLaunchKernelGGL(lstm_tile_weights_f32_kernel, dim3(grid_for(4LL * KB * 1024, 256)), dim3(256), 0, (hipStream_t)stream, KB,
                        wcat, (long long)ldw, dst);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const void* w_split,
+                             const float* bias, const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next,
+                             int64_t ldhp, int terms, void* stream) {
+    if (N <= 0 || !xh || !w_split || !bias || !c_prev || !h_out || !c_out) return VINE_ERR_INVALID_ARG;
+    if ((terms & 255) != 9 && (terms & 255) != 6) return VINE_ERR_INVALID_ARG;
+    if (H != 256 || K != 352 || (N & 127) || (ldx & 3) || ldx < K || (ldh & 3) || ldh < H || (hp_next && ((ldhp & 3) || ldhp < H)) ||
+        ((uintptr_t)xh & 15) || ((uintptr_t)w_split & 15) || ((uintptr_t)h_out & 15) || ((uintptr_t)hp_next & 15) ||
+        ((uintptr_t)c_prev & 15) || ((uintptr_t)c_out & 15) || ((uintptr_t)bias & 15))
+        return VINE_ERR_UNSUPPORTED;
+    // piece pairs in the low byte; second byte: row tiles per wave (tuning knob; 0 = 4 from 16384 rows on when N % 256 == 0:
+    // 512 workgroups = two per CU in one round; else 2)
+    const unsigned short* wt = (const unsigned short*)w_split;
+    const int nt = terms & 255;
+    int rt = (terms >> 8) & 255;
+    if (!rt) rt = (N >= 16384 && N % 256 == 0) ? 4 : 2;
+    if ((rt != 2 && rt != 4) || (terms >> 16) || N % (64LL * rt)) return VINE_ERR_UNSUPPORTED;
+    const long long sets = N / (64LL * rt);
+    const int xcd_map = (sets & 7) == 0;
+#define LAUNCH_SPLIT(RT_, NT_)                                                                                              \
+    hipLaunchKernelGGL((lstm_step_split_kernel<11, RT_, NT_>), dim3((unsigned)sets * 8), dim3(256), 0, (hipStream_t)stream,   \
+                       (long long)N, xh, (long long)ldx, wt, bias, c_prev, h_out, (long long)ldh, c_out, hp_next,              \
+                       (long long)ldhp, xcd_map)
+    if (rt == 2) { if (nt == 9) LAUNCH_SPLIT(2, 9); else LAUNCH_SPLIT(2, 6); }
+    else { if (nt == 9) LAUNCH_SPLIT(4, 9); else LAUNCH_SPLIT(4, 6); }
+#undef LAUNCH_SPLIT
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_tile_weights_split(int64_t H, int64_t K, const float* wcat, int64_t ldw, void* dst, void* stream) {
+    if (!wcat || !dst) return VINE_ERR_INVALID_ARG;
+    if (H != 256 || (K & 31) || K <= 0 || (ldw & 3) || ldw < K || ((uintptr_t)wcat & 15) || ((uintptr_t)dst & 15))
+        return VINE_ERR_UNSUPPORTED;
+    const int KS = (int)(K / 32);
+    hipLaunchKernelGGL(lstm_tile_weights_split_kernel, dim3(grid_for(8LL * KS * 512, 256)), dim3(256), 0, (hipStream_t)stream,
+                       KS, wcat, (long long)ldw, (uint4*)dst);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -228,6 +228,8 @@ class A2CAgent:
         self.fused_mixed = want_mixed and self.use_fused and self.amp_dtype == fused.lp_dtype()
         self.mixed_precision = want_mixed and not self.fused_mixed          # the torch-autocast path
         self.rollout_lp16 = self.fused_mixed and config.get("rollout_precision", "fp32") != "fp32"
+        # fp32 rollout LSTM step: 9 / 6 = products formed from bf16 pieces (vine_lstm_step_f32_split), 0 = native fp32 MFMA
+        self.rollout_f32_terms = int(config.get("rollout_f32_terms", fused.ROLLOUT_F32_SPLIT))
         self.save_freq = config.get("save_frequency", 0)
         self.save_best_after = config.get("save_best_after", 100)
         self.print_stats = config.get("print_stats", True)
@@ -415,7 +417,10 @@ class A2CAgent:
         # fp32 matrix-core kernels (vine_mlp3_elu_f32 / vine_lstm_step_f32): the default network at N % 512 == 0
         f["f32_mfma"] = (op == torch.float32 and fused.ROLLOUT_F32_MFMA and net.rnn_concat_input and H == 256 and XW + H == 352
                          and XW - U == 32 and U == 64 and F_in <= 32 and tuple(net.units) == (256, 128, 64) and N % 512 == 0)
-        f["wt_f32"] = torch.empty(4 * H * (XW + H), device=dev) if f["f32_mfma"] else None
+        f["f32_split"] = self.rollout_f32_terms if (f["f32_mfma"] and self.rollout_f32_terms in (6, 9)) else 0
+        f["wt_f32"] = torch.empty(4 * H * (XW + H), device=dev) if (f["f32_mfma"] and not f["f32_split"]) else None
+        # the three bf16 pieces of every recurrent weight, in the split step kernel's fragment order
+        f["wt_split"] = (torch.empty(3 * 4 * H * (XW + H), device=dev, dtype=torch.bfloat16) if f["f32_split"] else None)
         f["w1p_f32"] = torch.zeros((net.units[0], 32), device=dev) if f["f32_mfma"] else None     # layer 1, zero-padded
         self._fast = f
 
@@ -439,9 +444,15 @@ class A2CAgent:
         if f["f32_mfma"]:           # [w_ih | 0 | w_hh] in the step kernel's tile order; layer-1 weight padded to 32 columns
             w1 = f["mlp"][0][0]
             f["w1p_f32"][:, :w1.shape[1]].copy_(w1)
-            fused._check(fused._lib().vine_lstm_tile_weights_f32(
-                f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_f32"].data_ptr(),
-                torch.cuda.current_stream(self.device).cuda_stream), "vine_lstm_tile_weights_f32")
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            if f["f32_split"]:
+                fused._check(fused._lib().vine_lstm_tile_weights_split(
+                    f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_split"].data_ptr(), st),
+                    "vine_lstm_tile_weights_split")
+            else:
+                fused._check(fused._lib().vine_lstm_tile_weights_f32(
+                    f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_f32"].data_ptr(), st),
+                    "vine_lstm_tile_weights_f32")
         f["cur"] = 0
         f["xh2"][0][:, f["XW"]:].copy_(self.rnn_states[0][0])
 
@@ -505,7 +516,14 @@ class A2CAgent:
         h32, c = self.rnn_states[0][0], self.rnn_states[1][0]
         h_out, c_out = (h32, c) if commit else (f["h_tmp"], f["c_tmp"])
         Kx = XW + H
-        if f32k:
+        if f32k and f["f32_split"]:
+            # gate GEMM over [x | h] + the cell update: fp32 operands, every product exact from bf16 pieces (9 pairs)
+            fused._check(lib.vine_lstm_step_f32_split(N, H, Kx, xh.data_ptr(), xh.stride(0), f["wt_split"].data_ptr(),
+                                                      f["bias"].data_ptr(), c.data_ptr(), h_out.data_ptr(), H,
+                                                      c_out.data_ptr(), hp_ptr, xh_next.stride(0), f["f32_split"], st),
+                         "vine_lstm_step_f32_split")
+            gates = None
+        elif f32k:
             # gate GEMM over [x | h] + the cell update, fp32 on the matrix cores
             fused._check(lib.vine_lstm_step_f32(N, H, Kx, xh.data_ptr(), xh.stride(0), f["wt_f32"].data_ptr(),
                                                 f["bias"].data_ptr(), c.data_ptr(), h_out.data_ptr(), H, c_out.data_ptr(),

@@ -179,8 +179,16 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
             upd = "update: torch autocast %s" % lp
         else:
             upd = "update: f32"
-        roll = ("rollout inference: %s GEMM operands" % lp) if getattr(a, "rollout_lp16", False) else \
-               "rollout inference: f32 (the reference's; fp32 matrix-core kernels)"
+        terms = (getattr(a, "_fast", None) or {}).get("f32_split", 0)
+        if getattr(a, "rollout_lp16", False):
+            roll = "rollout inference: %s GEMM operands" % lp
+        elif terms:
+            roll = ("rollout inference: f32 (the reference's): fp32 operands, fp32 accumulation; MLP on the fp32 matrix cores, "
+                    "LSTM gate products formed from the exact three-way bf16 split of both fp32 operands on the bf16 matrix "
+                    "cores, %s" % ("all 9 piece pairs = every bit of every fp32 product" if terms == 9 else
+                                   "6 of 9 piece pairs (the three below 2^-24 of a product left out)"))
+        else:
+            roll = "rollout inference: f32 (the reference's; fp32 matrix-core kernels)"
         return upd + "; " + roll
 
     precision = describe(agent)
@@ -207,7 +215,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         return {"update_precision": describe(agent2), "value": frames * steps / e2, "unit": "env-steps/s",
                 "ppo_iters_per_sec": steps / e2, "rollout_ms": p2 / steps * 1e3, "update_ms": u2 / steps * 1e3}
 
-    other = lp16_rollout = None
+    other = lp16_rollout = native_f32_rollout = split6_rollout = None
     if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
         # the same PPO iteration in the OTHER update precision (fp32 <-> 16-bit operands), and -- an extra, NARROWER than the
         # reference's fp32 rollout -- with 16-bit GEMM operands in the rollout inference as well (the round-2 configuration);
@@ -215,6 +223,10 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         other = rerun(mixed_precision=not agent.fused_mixed)
         if agent.fused_mixed and not agent.rollout_lp16:
             lp16_rollout = rerun(rollout_precision="lp16")
+        if agent.fused_mixed and not agent.rollout_lp16 and (agent._fast or {}).get("f32_split", 0):
+            # the rollout's LSTM step on the native fp32 matrix-core instruction, and the 6-pair form of the split
+            native_f32_rollout = rerun(rollout_f32_terms=0)
+            split6_rollout = rerun(rollout_f32_terms=6)
     ppo_kernels = None
     if world == 1 and agent.fused_mixed and not getattr(args, "no_secondary", False):
         try:
@@ -226,6 +238,8 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         "ppo_kernel_rooflines": ppo_kernels,
         "other_precision": other,
         "extra_lp16_rollout": lp16_rollout,
+        "extra_native_f32_mfma_rollout": native_f32_rollout,
+        "extra_split6_rollout": split6_rollout,
         "replicas_in_sync": in_sync,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
                      "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},

@@ -180,6 +180,10 @@ def weight_grad(dy, x, out=None, batch=None):
 
 HEADS_LOSS = _os.environ.get("VINE_HEADS_LOSS", "1") != "0"    # LayerNorm + heads + loss + backward in one launch (A/B knob)
 ROLLOUT_F32_MFMA = _os.environ.get("VINE_ROLLOUT_F32_MFMA", "1") != "0"   # fp32 matrix-core rollout kernels (A/B knob)
+# fp32 LSTM step of the rollout with every product formed exactly from bf16 pieces on the bf16 matrix cores
+# (vine_lstm_step_f32_split): 9 = all nine piece pairs (exact products, the default), 6 = without the three pairs below
+# 2^-24 of a product, 0 = the native fp32 matrix-core kernel (vine_lstm_step_f32)
+ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "9"))
 MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
