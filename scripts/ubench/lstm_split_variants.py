@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Back-to-back launches of chosen vine_lstm_step_f32_split variants at the rollout's shapes, for rocprofv3 --pmc passes.
-Usage: python scripts/ubench/lstm_split_variants.py [launches] [variant ...]   (variant = terms + 256 rt + 65536 nb + (ver << 24))"""
+Usage: python scripts/ubench/lstm_split_variants.py [launches] [variant ...]   (variant = terms + 256 rt)"""
 import os
 import sys
 
@@ -25,7 +25,7 @@ h = torch.empty(N, H, device=dev)
 ws = torch.empty(3 * 4 * H * K, device=dev, dtype=torch.bfloat16)
 st = torch.cuda.current_stream().cuda_stream
 assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), K, ws.data_ptr(), st) == 0
-for v in variants:
+for v in variants * int(os.environ.get("SPLIT_ROUNDS", "1")):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for i in range(iters + 3):
         if i == 3:

@@ -57,10 +57,7 @@ def lstm_split(variant):
     return run
 
 
-SPLITS = tuple(("lstm_split t%d rt%d nb%d" % (t, rt, nb), lstm_split(t + 256 * rt + 65536 * nb), 2.0 * N * K * 4 * H)
-               for t in (9, 6) for rt, nb in ((2, 1), (2, 2), (4, 1)))
-SPLITS += tuple(("lstm_split2 t%d rt%d v%d" % (t, rt, v), lstm_split(t + 256 * rt + 65536 + (v << 24)), 2.0 * N * K * 4 * H)
-                for t in (9, 6) for rt, v in ((2, 1), (2, 2), (4, 1)))
+SPLITS = tuple(("lstm_split t%d rt%d" % (t, rt), lstm_split(t + 256 * rt), 2.0 * N * K * 4 * H) for t in (9, 6) for rt in (4, 2))
 for name, fn, flop in SPLITS + (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("mlp3_elu_f32", mlp, 2.0 * N * (32 * 256 + 256 * 128 + 128 * 64))):
     for i in range(5):
         fn(i)

@@ -1850,13 +1850,13 @@ def test_lstm_step_f32_against_float64_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("terms", [9, 6])
+@pytest.mark.parametrize("terms", [9, 6, 9 + (2 << 8), 6 + (4 << 8), 9 + (4 << 8)])
 def test_lstm_step_f32_split_against_float64_torch(terms):
     """vine_lstm_step_f32_split (fp32 operands split exactly into three bf16 pieces, every piece product exact in the
     fp32 accumulator of the bf16 matrix cores) against float64 torch: the pre-activations must be at least as close to the
     float64 product as those of the native fp32 matrix-core kernel (9 terms: no bit of a product is dropped), and
     h / c within the same 1e-5 the native kernel is held to.  Operand magnitudes span 2^-20 .. 2^6 so that a piece that
-    were rounded away would show."""
+    were rounded away would show.  ``terms``: piece pairs in the low byte, row tiles per wave (a tuning knob) in the second."""
     from vine_robot_isaacgymenvs_amd import native
     lib = native.load()
     dev = torch.device("cuda:0")
@@ -1895,7 +1895,7 @@ def test_lstm_step_f32_split_against_float64_torch(terms):
                                   H, c_ref.data_ptr(), None, 0, st) == 0
     torch.cuda.synchronize()
     ref_c, ref_h = float((c_ref.double() - c).abs().max()), float((h_ref.double() - h).abs().max())
-    print("terms %d: max |c - f64| %.3e (native fp32 MFMA %.3e), max |h - f64| %.3e (native %.3e)"
+    print("terms 0x%x: max |c - f64| %.3e (native fp32 MFMA %.3e), max |h - f64| %.3e (native %.3e)"
           % (terms, err_c, ref_c, err_h, ref_h))
     assert err_c < 1e-5 and err_h < 1e-5
     assert err_c <= 1.5 * ref_c + 1e-7 and err_h <= 1.5 * ref_h + 1e-7

@@ -3934,6 +3934,18 @@ __device__ __forceinline__ f32x4_t mfma_bf16(uint4 a, uint4 b, f32x4_t c) {
 // current k-step's MFMA stream (second set of piece registers): an MFMA holds the SIMD's vector issue for 8 of its 16
 // cycles, so the ~44 RT conversion instructions per k-step ride in the gaps instead of standing in front of the k-step's
 // first MFMA (99.6 -> 76.7 us at RT = 2, profiles/r03/rollout_f32_split.txt).
+#ifdef SPLIT_TIMING
+// (debug build, scripts/ubench/lstm_split_clock.py) per wave: shader clock (s_memtime) and 100 MHz real time (s_memrealtime)
+// at kernel entry, after the prologue, after the last k-step, at the end
+__device__ unsigned long long split_t[4096 * 8];
+#define SPLIT_STAMP(i)                                                                                                  \
+    if (lane == 0) {                                                                                                    \
+        split_t[((blockIdx.x * 4 + wave) & 4095) * 8 + 2 * (i)] = __builtin_amdgcn_s_memtime();                          \
+        split_t[((blockIdx.x * 4 + wave) & 4095) * 8 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                  \
+    }
+#else
+#define SPLIT_STAMP(i)
+#endif
 template <int KS, int RT, int NT>
 __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, const float* __restrict__ xh, long long ldx,
                                                                   const unsigned short* __restrict__ wt,
@@ -3951,6 +3963,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, co
     const long long row0 = (long long)rbs * (64 * RT) + wave * (16 * RT) + u;
     const uint4* wsrc = reinterpret_cast<const uint4*>(wt) + (long long)ub * KS * (LSTM_SPLIT_CHUNK / 8);
     const float* xrow = xh + row0 * ldx + 8 * g;
+    SPLIT_STAMP(0)
     float4 xf[RT][2];
     uint4 xp[2][RT][3];
     {
@@ -3982,6 +3995,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, co
         for (int rt = 0; rt < RT; ++rt) acc[t][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
     float4 cp[2][RT];
     __syncthreads();
+    SPLIT_STAMP(1)
 #pragma unroll
     for (int j = 0; j < KS; ++j) {                      // fully unrolled: buffers and piece sets stay register names
         const int buf = j & 1;
@@ -4031,6 +4045,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, co
         }
         __syncthreads();
     }
+    SPLIT_STAMP(2)
 #pragma unroll
     for (int ut = 0; ut < 2; ++ut) {
         const int unit = ub * 32 + 16 * ut + 4 * g;
@@ -4055,6 +4070,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, co
             if (hp_next) st4(hp_next + row * ldhp + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
         }
     }
+    SPLIT_STAMP(3)
 }
 
 // [w_ih | 0 | w_hh] rows (4H x K fp32, row stride ldw) -> the split step kernel's chunks of bf16 pieces:
@@ -5172,6 +5188,12 @@ int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, i
 #undef LAUNCH_SPLIT
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
+
+#ifdef SPLIT_TIMING
+int vine_debug_split_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(split_t), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int vine_lstm_tile_weights_split(int64_t H, int64_t K, const float* wcat, int64_t ldw, void* dst, void* stream) {
     if (!wcat || !dst) return VINE_ERR_INVALID_ARG;
