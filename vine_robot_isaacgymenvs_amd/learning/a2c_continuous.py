@@ -137,19 +137,24 @@ class DeviceAverageMeter:
 
 
 class ScalarLog:
-    """Stand-in for the TensorBoard ``SummaryWriter`` rl_games uses (tensorboard is not on the image):
-    same ``add_scalar(tag, value, step)`` call, appended to ``summaries/scalars.csv``."""
+    """The ``SummaryWriter`` rl_games logs through (tensorboardX; not on the image): same ``add_scalar(tag, value, step)``
+    call, written twice -- as a TensorBoard event file (``utils/tfevents.py`` encodes the format itself, so a stock
+    ``tensorboard --logdir`` elsewhere reads the run) and appended to ``summaries/scalars.csv``."""
 
     def __init__(self, directory):
+        from ..utils.tfevents import EventFileWriter
         os.makedirs(directory, exist_ok=True)
         self.path = os.path.join(directory, "scalars.csv")
         self._f = open(self.path, "a")
+        self.events = EventFileWriter(directory)
 
     def add_scalar(self, tag, value, step):
         self._f.write("%s,%s,%s\n" % (tag, float(value), int(step)))
+        self.events.add_scalar(tag, float(value), int(step))
 
     def flush(self):
         self._f.flush()
+        self.events.flush()
 
 
 class A2CAgent:
