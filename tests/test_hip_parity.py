@@ -414,6 +414,53 @@ def test_pipe_obstacle_matches_oracle(HipEnv, with_shelf):
     hip.close(); orc.close()
 
 
+@pytest.mark.parametrize("obstacle", ["pipe", "shelf"])
+def test_contact_error_is_float32_round_off(HipEnv, obstacle):
+    """How wide the contact tolerances above really are: the HIP kernel (float32) and the oracle run in float32 are both
+    compared with the oracle run in float64 on the same contact-rich step.  The stiff penalty contacts amplify round-off
+    for BOTH float32 runs alike, and the kernel's error distribution must sit inside the float32 oracle's: median and
+    99th percentile of |q - q64| and |qd - qd64| at most 2x the float32 oracle's (+ one float32 ulp of the value range;
+    measured: 0.8x .. 1.5x -- q 2e-7 median / 1.6e-6 at the 99th percentile, qd 1e-5 / 1.5e-4)."""
+    n = 768
+    cfg = base_cfg(n, 0, True, action_delay=1, seed=9)
+    cfg.set_flag(abi.FLAG_CREATE_PIPE if obstacle == "pipe" else abi.FLAG_CREATE_SHELF, True)
+    rng = np.random.default_rng(91)
+    hip, o32 = pair(HipEnv, cfg, "f32")
+    o64 = vo.OracleEnv(cfg, "f64")
+    st = seed_both(hip, o32, rng, n, cfg)
+    if obstacle == "pipe":
+        tp = rng.uniform(0.4, 1.1, n)
+        th = tp + np.pi / 2
+        yl, zl = rng.uniform(-0.01, 0.03, n), rng.uniform(0.0, 0.1, n)
+        st[abi.VF_PIPE_Y] = st[abi.VF_TIP_Y] - (yl * np.cos(th) - zl * np.sin(th))
+        st[abi.VF_PIPE_Z] = st[abi.VF_TIP_Z] - (yl * np.sin(th) + zl * np.cos(th))
+        st[abi.VF_OBJ_ANGLE] = tp
+    else:
+        st[abi.VF_SHELF_Y] = st[abi.VF_TIP_Y] - 0.2 - 0.05 + rng.uniform(-0.04, 0.04, n)
+        st[abi.VF_SHELF_Z] = st[abi.VF_TIP_Z] + rng.uniform(-0.06, 0.06, n)
+    hip.set_state(st)
+    o32.state[:] = st.astype(o32.real)
+    o64.state[:] = st.astype(o64.real)
+    o64.reset_buf[:] = o32.reset_buf
+    o64.progress[:] = o32.progress
+    a = rng.uniform(-1, 1, (n, 2))
+    hip.step(a)
+    o32.step(a)
+    o64.step(a)
+    hs, s32, s64 = hip.state, o32.state.astype(np.float64), o64.state.astype(np.float64)
+    keep = (o32.reset_buf == 0) & (o64.reset_buf == 0)          # (a reset re-draws the state: nothing to compare)
+    assert keep.mean() > 0.5
+    for name, sl, ulp in (("q", QPOS, 1e-6), ("qd", QVEL, 1e-4)):
+        e_hip = np.abs(hs[sl][:, keep] - s64[sl][:, keep]).max(0)
+        e_o32 = np.abs(s32[sl][:, keep] - s64[sl][:, keep]).max(0)
+        stats = [(np.percentile(e_hip, p), np.percentile(e_o32, p)) for p in (50, 90, 99)]
+        print("%s %s: |HIP - f64| / |oracle f32 - f64| at the 50 / 90 / 99th percentile: %s"
+              % (obstacle, name, "  ".join("%.2e / %.2e" % t for t in stats)))
+        for h_, o_ in (stats[0], stats[2]):
+            assert h_ <= 2.0 * o_ + ulp
+    hip.close(); o32.close(); o64.close()
+
+
 def test_first_step_resets_everything(HipEnv):
     """reset_buf starts at ones (vec_task.py:275): the first step simulates the zero pose, then resets all envs."""
     n = 512
