@@ -3901,7 +3901,7 @@ __global__ void lstm_tile_weights_f32_kernel(int KB, const float* __restrict__ w
 // pre-tiled in MFMA-fragment order ([unit block][k-step][piece][tile][lane][8], vine_lstm_tile_weights_split: one
 // contiguous 24 KB chunk per workgroup and k-step) and are streamed through two LDS buffers, the next chunk's global loads
 // in flight under the current chunk's 72 RT MFMAs per wave; a fragment read is one conflict-free ds_read_b128 per lane.
-// X is loaded as fp32 (two float4 per lane, row tile and k-step, one k-step ahead) and split in registers.
+// X is loaded as fp32 (two float4 per lane, row tile and k-step, two k-steps ahead) and split in registers.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
