@@ -677,6 +677,99 @@ def f9_gae(out):
                          gamma=np.float64(0.99), tau=np.float64(0.95))
 
 
+def f10_rollout_bookkeeping(out):
+    """F10: the per-step bookkeeping of the rollout as the reference's in-tree text states it (isaacgymenvs/learning/
+    common_agent.py:257-316, ``play_steps``, lifted by name and run for T steps on a stand-in ``self`` whose env, policy
+    and critic replay prepared tensors): shaped rewards into the buffer, done flags, the running episode return / length
+    accumulators and their masking by ``not_dones``, and WHICH finished episodes' returns / lengths are handed to the
+    ``game_rewards`` / ``game_lengths`` meters at every step (the stand-in meters record the arguments of ``update``).
+    rl_games' own ``play_steps_rnn`` (absent) keeps the same books; the windowed mean inside its AverageMeter is not
+    part of this text and stays unpinned."""
+    import ast
+    import types
+    path = os.path.join(REF, "isaacgymenvs/learning/common_agent.py")
+    tree = ast.parse(open(path).read())
+    wanted = {"play_steps", "discount_values"}
+    funcs = [n for cls in tree.body if isinstance(cls, ast.ClassDef) for n in cls.body
+             if isinstance(n, ast.FunctionDef) and n.name in wanted]
+    assert {f.name for f in funcs} == wanted
+    ns = {"torch": torch, "a2c_common": types.SimpleNamespace(swap_and_flatten01=lambda x: x)}
+    exec(compile(ast.Module(body=funcs, type_ignores=[]), path, "exec"), ns)
+    T, N, scale = 12, 96, 0.01
+    g = torch.Generator().manual_seed(1010)
+    rewards = torch.randn(T, N, 1, generator=g) * 3.0 + 1.0
+    dones = (torch.rand(T, N, generator=g) < 0.2)
+    dones[:, :6] = False                                              # some envs never finish
+    dones[3, 6:40] = True                                             # a step where a third of the envs finish together
+    dones[7] = False                                                  # a step where none does
+    values = torch.randn(T, N, 1, generator=g)
+    snap = {"cur_r": [], "cur_l": [], "upd_r": [], "upd_l": []}
+
+    class Meter:
+        def __init__(self, key):
+            self.key = key
+
+        def update(self, x):
+            snap[self.key].append(x.clone())
+
+    class Buffer:
+        def __init__(self):
+            self.tensor_dict = {}
+
+        def update_data(self, name, n, val):
+            self.tensor_dict.setdefault(name, [None] * T)[n] = val.clone().float() if torch.is_tensor(val) else val
+
+        def get_transformed_list(self, fn, names):
+            return {}
+
+    agent = types.SimpleNamespace(
+        horizon_length=T, gamma=0.99, tau=0.95, num_agents=1, batch_size=T * N, use_action_masks=False, has_central_value=False,
+        update_list=["values"], tensor_list=[], obs={"obs": torch.zeros(N, 4)}, dones=torch.zeros(N, dtype=torch.uint8),
+        current_rewards=torch.zeros(N, 1), current_lengths=torch.zeros(N), experience_buffer=Buffer(),
+        game_rewards=Meter("upd_r"), game_lengths=Meter("upd_l"), rewards_shaper=lambda r: r * scale,
+        algo_observer=types.SimpleNamespace(process_infos=lambda infos, idx: None), set_eval=lambda: None, step=[0])
+
+    def env_reset_done():
+        if agent.step[0] > 0:                                         # accumulators as the previous step left them
+            snap["cur_r"].append(agent.current_rewards.clone())
+            snap["cur_l"].append(agent.current_lengths.clone())
+        return agent.obs, []
+
+    def env_step(actions):
+        n = agent.step[0]
+        agent.step[0] += 1
+        return agent.obs, rewards[n].clone(), dones[n].to(torch.uint8), {"terminate": torch.zeros(N)}
+
+    agent._env_reset_done = env_reset_done
+    agent.env_step = env_step
+    agent.get_action_values = lambda obs: {"actions": torch.zeros(N, 2), "values": values[agent.step[0]]}
+    agent._eval_critic = lambda obs: torch.zeros(N, 1)
+    agent.discount_values = lambda *a: ns["discount_values"](agent, *a)
+    # the buffer's lists become tensors where play_steps reads them back
+    orig_update = agent.experience_buffer.update_data
+    ns["play_steps"].__globals__["a2c_common"] = ns["a2c_common"]
+
+    class Dict(dict):
+        def __getitem__(self, k):
+            v = dict.__getitem__(self, k)
+            return torch.stack(v) if isinstance(v, list) else v
+
+    agent.experience_buffer.tensor_dict = Dict()
+    ns["play_steps"](agent)
+    snap["cur_r"].append(agent.current_rewards.clone())
+    snap["cur_l"].append(agent.current_lengths.clone())
+    td = agent.experience_buffer.tensor_dict
+    assert len(snap["cur_r"]) == T and len(snap["upd_r"]) == T
+    # ragged lists of finished episodes -> (sum, count) per step, the form a device-side meter update consumes
+    out["f10_rollout_bookkeeping"] = dict(
+        rewards=npf(rewards), dones=dones.numpy().astype(np.uint8), reward_scale=np.float64(scale),
+        shaped=npf(td["rewards"]), buffer_dones=npf(td["dones"]),
+        cur_rewards=npf(torch.stack(snap["cur_r"])), cur_lengths=npf(torch.stack(snap["cur_l"])),
+        finished_return_sum=np.array([float(x.double().sum()) for x in snap["upd_r"]]),
+        finished_length_sum=np.array([float(x.double().sum()) for x in snap["upd_l"]]),
+        finished_count=np.array([int(x.shape[0]) for x in snap["upd_r"]], np.int64))
+
+
 def main():
     install_stubs()
     vt, v5 = load_reference()
@@ -689,6 +782,7 @@ def main():
     f6_trajectory(vt, v5, out)       # also writes F7 (wandb_dict keys)
     f8_ppo_loss_terms(out)
     f9_gae(out)
+    f10_rollout_bookkeeping(out)
     for name, d in out.items():
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **d)

@@ -1911,6 +1911,48 @@ def test_lstm_step_f32_split_against_float64_torch(terms):
 
 
 @pytest.mark.gpu
+def test_rollout_post_kernel_against_reference_text_golden():
+    """F10 through the HIP kernel (vine_rollout_post): shaped rewards, done flags, episode accumulators after every step and
+    the per-step totals of the finished episodes (meter[4..6] = sum of returns, sum of lengths, count) as the reference's
+    in-tree play_steps keeps them (common_agent.py:257-316); the LSTM state rows of finished envs are cleared."""
+    import os
+    from vine_robot_isaacgymenvs_amd import native
+    from vine_robot_isaacgymenvs_amd.abi import ROLLOUT_POST_SCRATCH_FLOATS as SF
+    lib = native.load()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "f10_rollout_bookkeeping.npz"))
+    dev = torch.device("cuda:0")
+    T, N = g["dones"].shape
+    H = 256
+    st = torch.cuda.current_stream().cuda_stream
+    cur_r, cur_l = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+    h, c = torch.ones(N, H, device=dev), torch.ones(N, H, device=dev)
+    meter, counter = torch.zeros(8, device=dev), torch.zeros(1, device=dev, dtype=torch.int64)
+    scratch = torch.zeros(SF, device=dev)
+    tmo, val = torch.zeros(N, device=dev, dtype=torch.uint8), torch.zeros(N, device=dev)
+    shaped, dones_out = torch.zeros(N, device=dev), torch.zeros(N, device=dev, dtype=torch.uint8)
+    for t in range(T):
+        rew = torch.from_numpy(g["rewards"][t, :, 0]).to(dev).contiguous()
+        reset = torch.from_numpy(g["dones"][t].astype(np.int64)).to(dev)
+        h.fill_(1.0); c.fill_(1.0)
+        assert lib.vine_rollout_post(N, H, rew.data_ptr(), reset.data_ptr(), tmo.data_ptr(), val.data_ptr(), 0.0,
+                                     float(g["reward_scale"]), 0.0, shaped.data_ptr(), dones_out.data_ptr(), cur_r.data_ptr(),
+                                     cur_l.data_ptr(), h.data_ptr(), c.data_ptr(), meter.data_ptr(), 100.0, counter.data_ptr(),
+                                     None, 0, 0, scratch.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert float((shaped.cpu() - torch.from_numpy(g["shaped"][t, :, 0])).abs().max()) < 1e-7
+        assert np.array_equal(dones_out.cpu().numpy(), g["dones"][t])
+        assert float((cur_r.cpu() - torch.from_numpy(g["cur_rewards"][t, :, 0])).abs().max()) < 1e-5
+        assert np.array_equal(cur_l.cpu().numpy(), g["cur_lengths"][t])
+        m = meter.cpu().double().numpy()
+        assert abs(m[4] - g["finished_return_sum"][t]) < 1e-3 and m[5] == g["finished_length_sum"][t]
+        assert m[6] == g["finished_count"][t]
+        done = torch.from_numpy(g["dones"][t].astype(bool)).to(dev)
+        assert float(h[done].abs().max() if bool(done.any()) else 0.0) == 0.0 and float(h[~done].min()) == 1.0
+        assert float(c[done].abs().max() if bool(done.any()) else 0.0) == 0.0 and float(c[~done].min()) == 1.0
+    assert int(counter) == T
+
+
+@pytest.mark.gpu
 def test_gae_kernel_against_reference_text_golden():
     """F9 through the HIP kernel (vine_gae: one env per lane, reverse scan in registers)."""
     import os

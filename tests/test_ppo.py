@@ -310,3 +310,40 @@ def test_gae_against_reference_text_golden(golden):
     adv = a2c.discount_values(float(g["gamma"]), float(g["tau"]), dones[T], values[T], dones[:T], values[:T], t("rewards"))
     assert float((adv - t("advs")).abs().max()) < 2e-6
     assert float(dones.sum()) > 50 and float(t("advs").abs().max()) > 1.0
+
+
+def test_rollout_bookkeeping_against_reference_text_golden(golden):
+    """F10: the reference's in-tree ``play_steps`` (common_agent.py:257-316, lifted by name into the fixture generator and
+    run on replayed rewards / done flags): the episode accumulators after every step and the finished episodes handed to
+    the meters.  The product's ``A2CAgent._episode_bookkeeping`` (the stock rollout's five lines) must keep the same
+    books; its masked meter must have seen exactly the reference's finished episodes (sum and count per step)."""
+    import types
+    import torch
+    from vine_robot_isaacgymenvs_amd.learning import a2c_continuous as a2c
+    g = golden("f10_rollout_bookkeeping")
+    T, N = g["dones"].shape
+
+    class Recorder(a2c.DeviceAverageMeter):
+        def __init__(self):
+            super().__init__(1, 100, "cpu")
+            self.seen = []
+
+        def update(self, values, mask):
+            self.seen.append((float((values.double() * mask.double().unsqueeze(-1)).sum()), int(mask.sum())))
+            super().update(values, mask)
+
+    agent = types.SimpleNamespace(current_rewards=torch.zeros(N, 1), current_lengths=torch.zeros(N),
+                                  game_rewards=Recorder(), game_lengths=Recorder())
+    for t in range(T):
+        rew, done = torch.from_numpy(g["rewards"][t]), torch.from_numpy(g["dones"][t])
+        nd = a2c.A2CAgent._episode_bookkeeping(agent, rew, done)
+        assert torch.equal(nd, 1.0 - done.float())
+        assert float((agent.current_rewards - torch.from_numpy(g["cur_rewards"][t])).abs().max()) < 1e-5
+        assert torch.equal(agent.current_lengths, torch.from_numpy(g["cur_lengths"][t]))
+        assert agent.game_rewards.seen[t][1] == int(g["finished_count"][t]) == agent.game_lengths.seen[t][1]
+        assert abs(agent.game_rewards.seen[t][0] - float(g["finished_return_sum"][t])) < 1e-3
+        assert agent.game_lengths.seen[t][0] == float(g["finished_length_sum"][t])
+    # the shaper of the fixture is the YAML's scale_value (PY:28) on the raw reward; done flags go to the buffer as they are
+    assert np.allclose(g["shaped"], g["rewards"] * float(g["reward_scale"]), atol=1e-7)
+    assert np.array_equal(g["buffer_dones"], g["dones"].astype(np.float32))
+    assert int(g["finished_count"][3]) >= 34 and int(g["finished_count"][7]) == 0

@@ -676,17 +676,24 @@ class A2CAgent:
                 shaped = shaped + self.gamma * res["values"] * infos["time_outs"].to(self.device).unsqueeze(1).float()
             buf["rewards"][n].copy_(shaped)
             self.dones = dones.to(torch.uint8)
-            self.current_rewards += rewards
-            self.current_lengths += 1
-            done_f = dones.float()
-            self.game_rewards.update(self.current_rewards, done_f)
-            self.game_lengths.update(self.current_lengths.unsqueeze(1), done_f)
-            not_dones = 1.0 - done_f
+            not_dones = self._episode_bookkeeping(rewards, dones)
             self.rnn_states = [s * not_dones.view(1, -1, 1) for s in self.rnn_states]
-            self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
-            self.current_lengths = self.current_lengths * not_dones
         self.obs = obs
         self.last_values.copy_(self.get_action_values(obs)["values"])
+
+    def _episode_bookkeeping(self, rewards, dones):
+        """The running episode return / length accumulators of one rollout step (play_steps, common_agent.py:293-306 in the
+        reference's in-tree text; golden F10): add the step, hand the finished episodes to the two meters, clear them.
+        Returns ``not_dones`` [N].  (``vine_rollout_post`` is the same on the device.)"""
+        self.current_rewards += rewards
+        self.current_lengths += 1
+        done_f = dones.float()
+        self.game_rewards.update(self.current_rewards, done_f)
+        self.game_lengths.update(self.current_lengths.unsqueeze(1), done_f)
+        not_dones = 1.0 - done_f
+        self.current_rewards = self.current_rewards * not_dones.unsqueeze(1)
+        self.current_lengths = self.current_lengths * not_dones
+        return not_dones
 
     def play_steps_rnn(self):
         body = self._rollout_body_fused if self._can_fuse_rollout() else self._rollout_body
