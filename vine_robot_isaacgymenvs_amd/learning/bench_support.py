@@ -90,6 +90,39 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
         res.append({"kernel": name, "us": us, "algorithmic_bytes_per_launch": nbytes, "achieved_GBs": nbytes / us / 1e3,
                     "hbm_frac": nbytes / us / 1e3 / 8000.0, "launches_per_ppo_iteration": 32, "cache_state": "cold (rotating sets)",
                     "streaming_kernel_GBs": stream_gbs, "frac_of_streaming_kernel": nbytes / us / 1e3 / stream_gbs})
+    # the rollout's LSTM step (fp32 operands, exact products from bf16 pieces): MFMA-bound.  Priced twice: the bf16 matrix
+    # work it executes (9 piece pairs) against the dense bf16 peak, and the fp32 product it delivers against the fp32
+    # matrix peak (what the native fp32 instruction could reach at most)
+    try:
+        N, K = 16384, 352
+        xh = [torch.randn(N, K, device=device) for _ in range(2)]
+        wcat = torch.randn(4 * H, K, device=device) / K ** 0.5
+        ws = torch.empty(3 * 4 * H * K, device=device, dtype=torch.bfloat16)
+        c = torch.randn(N, H, device=device)
+        hbuf = torch.empty(N, H, device=device)
+        assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), K, ws.data_ptr(), st) == 0
+
+        def step(i):
+            a, b = xh[i & 1], xh[(i & 1) ^ 1]
+            assert lib.vine_lstm_step_f32_split(N, H, K, a.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c.data_ptr(),
+                                                hbuf.data_ptr(), H, c.data_ptr(), b.data_ptr() + 4 * 96, K, 9, st) == 0
+        for i in range(10):
+            step(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(50):
+            step(i)
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / 50
+        flop32 = 2.0 * N * K * 4 * H
+        res.append({"kernel": "lstm_step_split_kernel", "bound": "mfma", "us": us, "rows": N,
+                    "algorithmic_fp32_flops_per_launch": flop32, "executed_bf16_flops_per_launch": 9 * flop32,
+                    "achieved_TFLOPs": 9 * flop32 / us / 1e6, "peak_TFLOPs": 2500.0, "frac": 9 * flop32 / us / 1e6 / 2500.0,
+                    "delivered_fp32_TFLOPs": flop32 / us / 1e6, "fp32_matrix_peak_TFLOPs": 157.3,
+                    "launches_per_ppo_iteration": 17, "cache_state": "back to back"})
+    except AssertionError:
+        pass
     return res
 
 
