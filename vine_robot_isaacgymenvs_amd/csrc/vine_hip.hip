@@ -430,10 +430,14 @@ __device__ __forceinline__ bool pipe_link_contact(const DevParams& P, float z0, 
             const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
             const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
             const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                if (w == 0 ? near0 : near1) {
-                    const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
+            // the walls are disjoint in the pipe frame's y ((0, 0.00525) and (0.15015, 0.1554)): a point can be inside
+            // the one on its side of the tube's axis only, so ONE test body per point instead of one per (point, wall) --
+            // same arithmetic for the wall that is tested, half the worst-case instruction stream of a wave
+            {
+                const bool w1 = pyl > 0.5f * PIPE_OUTER;
+                const float cw = w1 ? (wall_lo[1] + 0.5f * PIPE_WALL) : (wall_lo[0] + 0.5f * PIPE_WALL);
+                if (w1 ? near1 : near0) {
+                    const float ddy = pyl - cw, ddz = pzl - 0.5f * PIPE_LEN;
                     const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
                     if (ey > 0.0f && ez > 0.0f) {
                         const float vy = pvy - om * rz, vz = pvz + om * ry;
@@ -609,11 +613,12 @@ __device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t
         const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
         const float gy = py + ry - pipe_y, gz = pz + rz - pipe_z;
         const float pyl = gy * ct + gz * st, pzl = -gy * st + gz * ct;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const float ddy = pyl - (wall_lo[w] + 0.5f * PIPE_WALL), ddz = pzl - 0.5f * PIPE_LEN;
+        {   // one test body per point: the wall on the point's side of the tube's axis (see pipe_link_contact)
+            const bool w1 = pyl > 0.5f * PIPE_OUTER;
+            const float cw = w1 ? (wall_lo[1] + 0.5f * PIPE_WALL) : (wall_lo[0] + 0.5f * PIPE_WALL);
+            const float ddy = pyl - cw, ddz = pzl - 0.5f * PIPE_LEN;
             const float ey = 0.5f * PIPE_WALL - fabsf(ddy), ez = 0.5f * PIPE_LEN - fabsf(ddz);
-            if (valid && (w == 0 ? near0 : near1) && ey > 0.0f && ez > 0.0f) {
+            if (valid && (w1 ? near1 : near0) && ey > 0.0f && ez > 0.0f) {
                 const float vy = pvy - om * rz, vz = pvz + om * ry;
                 const float vyl = vy * ct + vz * st, vzl = -vy * st + vz * ct;
                 float fyl = 0.0f, fzl = 0.0f;
