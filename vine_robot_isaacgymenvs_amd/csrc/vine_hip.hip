@@ -292,21 +292,23 @@ __device__ __forceinline__ bool shelf_link_contact(const DevParams& P, float z0,
     const float zlo = fminf(pz, qz) - LINK_REACH, zhi = fmaxf(pz, qz) + LINK_REACH;
     const bool near_a = ylo < ycut && zlo < a_hi && zhi > a_lo;      // board A and the strip's corners
     const bool near_b = ylo < ycut && zlo < b_hi && zhi > b_lo;
-    // one block per board (a link near both at once is rare: they are 0.2 m apart), so a wave pays one branch per
-    // (link, board) and runs only the blocks some lane of it needs
+    // the boards are 0.2 m apart in z and 1 cm thick: a point can be inside the one on its side of z = shelf_z + 0.1 only,
+    // so ONE test body per point (the board selected by the point's height) instead of one block per board -- the waves
+    // that set the kernel's duration hold envs near board A and envs near board B and ran both blocks
+    if (near_a || near_b) {
 #pragma unroll
-    for (int bx = 0; bx < 2; ++bx) {
-        if (bx == 0 ? near_a : near_b) {
+        for (int e = 0; e < 2; ++e) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const float yl = e ? LINK_Y1 : LINK_Y0;
-                    const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
-                    const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
-                    const float wy = py + ry, wz = pz + rz;
-                    const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
-                    const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
+            for (int t = 0; t < 3; ++t) {
+                const float yl = e ? LINK_Y1 : LINK_Y0;
+                const float zl = (t == 0) ? z0 : (t == 1 ? 0.5f * (z0 + z1) : z1);
+                const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
+                const float wy = py + ry, wz = pz + rz;
+                const bool bsel = wz - shelf_z > 0.1f;
+                if (bsel ? near_b : near_a) {
+                    const float ddy = wy - (shelf_y + (bsel ? board[1][0] : board[0][0]));
+                    const float ddz = wz - (shelf_z + (bsel ? board[1][1] : board[0][1]));
+                    const float ey = (bsel ? board[1][2] : board[0][2]) - fabsf(ddy), ez = board[0][3] - fabsf(ddz);
                     if (ey > 0.0f && ez > 0.0f) {
                         const float vy = pvy - om * rz, vz = pvz + om * ry;
                         float fy = 0.0f, fz = 0.0f;
@@ -546,11 +548,12 @@ __device__ __forceinline__ void shelf_link_contact_coop(const DevParams& P, int 
         coop_point(t, slot, z0, z1, yl, zl, valid);
         const float ry = zl * dy + yl * ly, rz = zl * dz + yl * lz;
         const float wy = py + ry, wz = pz + rz;
-#pragma unroll
-        for (int bx = 0; bx < 2; ++bx) {
-            const float ddy = wy - (shelf_y + board[bx][0]), ddz = wz - (shelf_z + board[bx][1]);
-            const float ey = board[bx][2] - fabsf(ddy), ez = board[bx][3] - fabsf(ddz);
-            if (valid && (bx == 0 ? near_a : near_b) && ey > 0.0f && ez > 0.0f) {
+        {   // one test body per point: the board on the point's side of z = shelf_z + 0.1 (see shelf_link_contact)
+            const bool bsel = wz - shelf_z > 0.1f;
+            const float ddy = wy - (shelf_y + (bsel ? board[1][0] : board[0][0]));
+            const float ddz = wz - (shelf_z + (bsel ? board[1][1] : board[0][1]));
+            const float ey = (bsel ? board[1][2] : board[0][2]) - fabsf(ddy), ez = board[0][3] - fabsf(ddz);
+            if (valid && (bsel ? near_b : near_a) && ey > 0.0f && ez > 0.0f) {
                 const float vy = pvy - om * rz, vz = pvz + om * ry;
                 float fy = 0.0f, fz = 0.0f;
                 if (ey < ez) {
