@@ -398,7 +398,8 @@ int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t 
  * rate, with fp32 accumulation as before (no operand is rounded; the reference's rollout GEMMs are fp32,
  * a2c_continuous / torch.nn.LSTM under no autocast).  `terms` = 6 leaves out the three pairs below 2^-24 of a product
  * (a measured variant).  w_split = vine_lstm_tile_weights_split(Wcat [4H, K]): 3 K 4H bfloat16 (6 bytes per weight).
- * H = 256, K = 352, N % 1024 == 0, 16-byte aligned pointers, else VINE_ERR_UNSUPPORTED. */
+ * H = 256, K = 352, N % 128 == 0, 16-byte aligned pointers, else VINE_ERR_UNSUPPORTED.  Bits 8-15 of `terms`: row tiles per wave
+ * (tuning knob: 0 = 4 from 16384 rows on when N % 256 == 0, else 2). */
 int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const void* w_split,
                              const float* bias, const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next,
                              int64_t ldhp, int terms, void* stream);
