@@ -5123,7 +5123,13 @@ int vine_adam_step_amp(int64_t n, float* params, float* grads, float* exp_avg, f
     unsigned int* ticket = ticket_slot(stream, TICKET_ADAM);
     if (!ticket) return VINE_ERR_DEVICE;
     const int threads = 256;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, threads)), dim3(threads), 0, (hipStream_t)stream, (long long)n,
+    // every workgroup ends with a returning atomic on ONE ticket word (the election of the workgroup that advances the step
+    // counter and the schedules): ~23 ns each, serialised -- 400 workgroups spend longer queueing there than on their 4 KB
+    // of parameters, so the grid is capped and a thread takes several float4 groups (grid-stride loop of the kernel)
+    static const int max_blocks = [] { const char* e = getenv("VINE_ADAM_BLOCKS"); return e ? atoi(e) : 128; }();
+    int blocks = grid_for((n + 3) / 4, threads);
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)n,
                        params, grads, exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
                        (lp16_t*)lp16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr, amp_state, found_inf, ticket);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
