@@ -3396,7 +3396,7 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restric
                             float* __restrict__ v, float* lr_p, float* step_p,
                             float beta1, float beta2, float eps, float wd, float gscale, lp16_t* __restrict__ shadow,
                             const float* kl, float kl_scale, float kl_thr, float min_lr, float max_lr,
-                            float* amp, float* found_inf, unsigned int* ticket) {
+                            float* amp, float* found_inf, unsigned int* ticket, unsigned int* sub) {
     const float loss_scale = amp ? amp[0] : 1.0f;
     const bool skip = found_inf && *found_inf != 0.0f;
     if (amp) gscale = gscale / loss_scale;
@@ -3442,8 +3442,23 @@ __global__ void adam_kernel(long long n, float* __restrict__ p, float* __restric
     // 1-thread launches behind this one
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned tk = atomicAdd(ticket, 1u);
-        if (tk == gridDim.x - 1) {
+        // two-level election (returning atomics on one word serialise at ~23 ns each): the workgroups of a group -- blockIdx
+        // modulo 8 -- queue on the group's word, the last of each group on the common word
+        bool last;
+        if (sub) {
+            const unsigned grp = blockIdx.x & 7u;
+            const unsigned members = (gridDim.x - grp + 7u) >> 3;             // workgroups with this blockIdx & 7
+            unsigned int* sw = sub + grp * 32u;
+            last = false;
+            if (atomicAdd(sw, 1u) == members - 1) {
+                *sw = 0;
+                const unsigned groups = gridDim.x < 8u ? gridDim.x : 8u;
+                last = atomicAdd(ticket, 1u) == groups - 1;
+            }
+        } else {
+            last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        }
+        if (last) {
             *ticket = 0;
             if (!skip) *step_p = step;
             if (amp) {                                    // GradScaler.update()
@@ -4246,9 +4261,11 @@ __global__ __launch_bounds__(256) void mlp3_elu_f32_kernel(long long n, float* _
 // side stream the library has not seen before).  Returns nullptr when the pool is exhausted or cannot be allocated
 // (the wrappers then report VINE_ERR_DEVICE).
 #include <mutex>
+#define TICKET_SUB_GROUPS 8
+#define TICKET_SUB_PITCH 32        // words: the group tickets of a stream sit 128 B apart
 namespace {
 enum { TICKET_LOSS = 0, TICKET_ADAM = 1, TICKET_KINDS = 2, TICKET_MAX_STREAMS = 64, TICKET_MAX_DEVICES = 16 };
-struct TicketPool { unsigned int* words; void* stream[TICKET_MAX_STREAMS]; int used; };
+struct TicketPool { unsigned int* words; unsigned int* sub; void* stream[TICKET_MAX_STREAMS]; int used; };
 TicketPool g_ticket_pool[TICKET_MAX_DEVICES];
 std::mutex g_ticket_mutex;
 unsigned int* ticket_slot(void* stream, int kind) {
@@ -4261,7 +4278,13 @@ unsigned int* ticket_slot(void* stream, int kind) {
         const size_t bytes = (size_t)TICKET_MAX_STREAMS * TICKET_KINDS * sizeof(unsigned int);
         if (hipMalloc(&w, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         if (hipMemset(w, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); return nullptr; }
+        // first-level tickets of two-level elections (Adam): TICKET_SUB_GROUPS words per stream
+        unsigned int* sb = nullptr;
+        const size_t sbytes = (size_t)TICKET_MAX_STREAMS * TICKET_SUB_GROUPS * TICKET_SUB_PITCH * sizeof(unsigned int);
+        if (hipMalloc(&sb, sbytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); return nullptr; }
+        if (hipMemset(sb, 0, sbytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); (void)hipFree(sb); return nullptr; }
         P.words = w;
+        P.sub = sb;
         P.used = 0;
     }
     for (int i = 0; i < P.used; ++i)
@@ -4269,6 +4292,15 @@ unsigned int* ticket_slot(void* stream, int kind) {
     if (P.used == TICKET_MAX_STREAMS) return nullptr;
     P.stream[P.used] = stream;
     return P.words + (P.used++) * TICKET_KINDS + kind;
+}
+// the group tickets that belong to a slot returned by ticket_slot (same device, same stream)
+unsigned int* ticket_sub_of(const unsigned int* slot) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TICKET_MAX_DEVICES) return nullptr;
+    TicketPool& P = g_ticket_pool[dev];
+    if (!P.words || !P.sub || slot < P.words) return nullptr;
+    const long long i = (slot - P.words) / TICKET_KINDS;
+    return i < TICKET_MAX_STREAMS ? P.sub + i * TICKET_SUB_GROUPS * TICKET_SUB_PITCH : nullptr;
 }
 }  // namespace
 
@@ -5123,15 +5155,18 @@ int vine_adam_step_amp(int64_t n, float* params, float* grads, float* exp_avg, f
     unsigned int* ticket = ticket_slot(stream, TICKET_ADAM);
     if (!ticket) return VINE_ERR_DEVICE;
     const int threads = 256;
-    // every workgroup ends with a returning atomic on ONE ticket word (the election of the workgroup that advances the step
-    // counter and the schedules): ~23 ns each, serialised -- 400 workgroups spend longer queueing there than on their 4 KB
-    // of parameters, so the grid is capped and a thread takes several float4 groups (grid-stride loop of the kernel)
-    static const int max_blocks = [] { const char* e = getenv("VINE_ADAM_BLOCKS"); return e ? atoi(e) : 128; }();
+    // every workgroup ends with a returning atomic for the election of the one that advances the step counter and the
+    // schedules.  On ONE ticket word these serialise at ~23 ns each: 400 workgroups spent longer queueing there than on their
+    // 4 KB of parameters.  Default: a two-level election (8 group words 128 B apart, then the common word) on the full grid;
+    // VINE_ADAM_TICKETS=1 = the single word, for which the grid is capped at 128 workgroups (VINE_ADAM_BLOCKS overrides)
+    static const bool two_level = [] { const char* e = getenv("VINE_ADAM_TICKETS"); return !e || atoi(e) != 1; }();
+    static const int max_blocks = [] { const char* e = getenv("VINE_ADAM_BLOCKS"); return e ? atoi(e) : (two_level ? 0 : 128); }();
     int blocks = grid_for((n + 3) / 4, threads);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    unsigned int* sub = two_level ? ticket_sub_of(ticket) : nullptr;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)n,
                        params, grads, exp_avg, exp_avg_sq, lr, step, beta1, beta2, eps, weight_decay, grad_scale,
-                       (lp16_t*)lp16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr, amp_state, found_inf, ticket);
+                       (lp16_t*)lp16_shadow, kl, kl_scale, kl_threshold, min_lr, max_lr, amp_state, found_inf, ticket, sub);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
