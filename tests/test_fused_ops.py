@@ -1551,6 +1551,41 @@ def test_flat_adam_kernel_matches_torch_adam():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [700, 5000, 9 * 1024 + 3, 408261])
+def test_adam_election_advances_step_once_per_launch(n):
+    """The Adam kernel's "last workgroup" election (two levels: 8 group tickets, then the common one) at grids of 1, 5, 10 and
+    399 workgroups: every launch advances the device step counter by exactly one, applies the KL schedule once and leaves
+    the tickets reset -- 20 launches in a row -- and the parameters follow torch.optim.Adam."""
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n)
+    p = torch.randn(n, device=dev)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-8)
+    g, m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lr, step = torch.full((1,), 1e-3, device=dev), torch.zeros(1, device=dev)
+    kl = torch.full((1,), 1.0, device=dev)                      # far above the threshold: lr / 1.5 per launch, once
+    st = torch.cuda.current_stream().cuda_stream
+    lr_expect = 1e-3
+    for it in range(20):
+        grad = torch.randn(n, device=dev)
+        g.copy_(grad)
+        ref.grad = grad.clone()
+        for group in opt.param_groups:
+            group["lr"] = lr_expect
+        opt.step()
+        assert lib.vine_adam_step_sched(n, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr.data_ptr(), step.data_ptr(),
+                                        0.9, 0.999, 1e-8, 0.0, 1.0, None, kl.data_ptr(), 1.0, 0.008, 1e-6, 1e-2, st) == 0
+        torch.cuda.synchronize()
+        lr_expect = max(lr_expect / 1.5, 1e-6)
+        assert float(step) == it + 1
+        assert abs(float(lr) - lr_expect) <= 1e-6 * lr_expect + 1e-12
+    assert torch.allclose(p, ref.detach(), rtol=2e-5, atol=2e-7)
+    assert float(g.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mixed", [False, True, "lp16"])
 def test_fused_rollout_matches_stock_and_graph_replay(mixed):
     """Fused rollout (hand-written inference trunk, policy head, post-step kernels) vs the stock PyTorch model on the
