@@ -779,6 +779,37 @@ void vine_oracle_pipe_contact(const VineConfig* cfg, const double* q, const doub
 /* Glue, as pure per-env functions (float-typed like the reference tensors when real=float). */
 
 /* rescale_to_u / rescale_to_u_rail_velocity, V5:1458-1463, 984-997 */
+/* One ``gym.simulate`` (VT:356): ``substeps`` substeps with the efforts held and the obstacle contacts re-evaluated in
+ * each.  Returns what the net-contact-force tensor reports for `shelf_link` after it (this build's choice: the mean
+ * over the substeps of |F| on the front-edge strip; 0 without a shelf).  Shared by the env step and by
+ * ``vine_oracle_simulate_obstacles`` (the ``simulate`` of the golden generator's fake tensor API). */
+static real sim_step(const Model* M, int form, int substeps, const real* cj, real* q, real* qd, const real* eff, real hsub,
+                     int shelf, int pipe, real shelf_y, real shelf_z, real pipe_y, real pipe_z, real pipe_tp) {
+    real csum = 0;
+    for (int s = 0; s < substeps; ++s) {
+        real effc[ND];
+        for (int i = 0; i < ND; ++i) effc[i] = (i > 0 && s > 0 && M->effort_first_substep_only) ? 0 : eff[i];
+        if (shelf) csum += shelf_contact(M, q, qd, shelf_y, shelf_z, effc);
+        if (pipe) pipe_contact(M, q, qd, pipe_y, pipe_z, pipe_tp, effc);
+        FLOP_BUCKET(0); FLOP_CALL(0);
+        substep(M, form, cj, q, qd, effc, hsub);
+        FLOP_BUCKET(2);
+    }
+    return shelf ? csum / (real)substeps : 0;
+}
+/* exported for tests/golden/make_golden.py: one simulate with obstacles; obstacle = {shelf_y, shelf_z, pipe_y, pipe_z,
+ * theta'}; returns the contact value described above. */
+double vine_oracle_simulate_obstacles(const VineConfig* cfg, int form, double* q, double* qd, const double* eff,
+                                      const double* cjoint, double h, int n, int shelf, int pipe, const double* obstacle) {
+    Model M; model_init(&M, cfg);
+    real rq[ND], rqd[ND], re[ND], cj[ND];
+    for (int i = 0; i < ND; ++i) { rq[i] = (real)q[i]; rqd[i] = (real)qd[i]; re[i] = (real)eff[i]; cj[i] = cjoint ? (real)cjoint[i] : M.d; }
+    real contact = sim_step(&M, form, n, cj, rq, rqd, re, (real)h, shelf, pipe, (real)obstacle[0], (real)obstacle[1],
+                            (real)obstacle[2], (real)obstacle[3], (real)obstacle[4]);
+    for (int i = 0; i < ND; ++i) { q[i] = rq[i]; qd[i] = rqd[i]; }
+    return contact;
+}
+
 static void raw_actions_to_actions(const VineConfig* c, real a0, real a1, real* u_rail, real* u_fpam) {
     *u_rail = a0 * (real)c->rail_velocity_scale;
     *u_fpam = (a1 + (real)1.0) / (real)2.0 * (real)((double)c->fpam_max - (double)c->fpam_min) + (real)c->fpam_min;
@@ -1247,17 +1278,8 @@ static void step_env(VineHandle* h, int e, const float* actions, float* obs, flo
             for (int i = 1; i < ND; ++i) eff[i] = eff[i] > lim ? lim : (eff[i] < -lim ? -lim : eff[i]);
         }
         if (shelf) contact_sum += contact;                           /* VT:348-351 */
-        real csum = 0;
-        for (int s = 0; s < c->substeps; ++s) {                      /* gym.simulate, VT:356 */
-            real effc[ND];
-            for (int i = 0; i < ND; ++i) effc[i] = (i > 0 && s > 0 && M->effort_first_substep_only) ? 0 : eff[i];
-            if (shelf) csum += shelf_contact(M, q, qd, shelf_y, shelf_z, effc);
-            if (pipe) pipe_contact(M, q, qd, pipe_y, pipe_z, pipe_tp, effc);
-            FLOP_BUCKET(0); FLOP_CALL(0);
-            substep(M, h->form, cj, q, qd, effc, hsub);
-            FLOP_BUCKET(2);
-        }
-        contact = shelf ? csum / (real)c->substeps : 0;
+        contact = sim_step(M, h->form, c->substeps, cj, q, qd, eff, hsub, shelf, pipe, shelf_y, shelf_z, pipe_y, pipe_z,
+                           pipe_tp);                                 /* gym.simulate, VT:356 */
         tip_kinematics(M, q, qd, tip);                               /* refreshed rigid-body states */
         cart_y = q[0]; cart_vy = qd[0];
     }

@@ -49,6 +49,8 @@ def load(precision="f64", omp=False):
     lib.vine_oracle_forward_dynamics.restype = C.c_int
     lib.vine_oracle_simulate.argtypes = [P, C.c_int, _D, _D, _D, _D, C.c_double, C.c_int]
     lib.vine_oracle_simulate.restype = C.c_int
+    lib.vine_oracle_simulate_obstacles.argtypes = [P, C.c_int, _D, _D, _D, _D, C.c_double, C.c_int, C.c_int, C.c_int, _D]
+    lib.vine_oracle_simulate_obstacles.restype = C.c_double
     lib.vine_oracle_tip.argtypes = [P, _D, _D, _D]
     lib.vine_oracle_energy.argtypes = [P, _D, _D]
     lib.vine_oracle_energy.restype = C.c_double
@@ -148,6 +150,20 @@ def simulate(cfg, q, qd, eff, h, n, form=FORM_ABS, precision="f64", cj=None):
     if rc:
         raise RuntimeError("simulate failed rc=%d" % rc)
     return q, qd
+
+
+def simulate_obstacles(cfg, q, qd, eff, h, n, shelf, pipe, obstacle, form=FORM_ABS, precision="f64", cj=None):
+    """One ``gym.simulate`` with the shelf / pipe contacts re-evaluated per substep (the env step's own inner loop);
+    ``obstacle`` = (shelf_y, shelf_z, pipe_y, pipe_z, theta').  Returns (q, qd, reported shelf-strip contact force)."""
+    lib = load(precision)
+    q = np.array(q, dtype=np.float64)
+    qd = np.array(qd, dtype=np.float64)
+    eff = np.ascontiguousarray(eff, dtype=np.float64)
+    ob = np.ascontiguousarray(obstacle, dtype=np.float64)
+    cjp = None if cj is None else _dp(np.ascontiguousarray(cj, dtype=np.float64))
+    contact = lib.vine_oracle_simulate_obstacles(C.byref(cfg), form, _dp(q), _dp(qd), _dp(eff), cjp, h, n, int(shelf),
+                                                 int(pipe), _dp(ob))
+    return q, qd, contact
 
 
 def tip(cfg, q, qd, precision="f64"):

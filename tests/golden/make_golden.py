@@ -197,6 +197,9 @@ class FakeGym:
         self.efforts = torch.zeros(num_envs, 6)
         self.calls = []
         self._actors = 0
+        self.apn = 1 + int(create_shelf) + int(create_pipe)     # actors per env: [shelf], [pipe], vine (V5:466-500)
+        self.sim_root = torch.zeros(num_envs * self.apn, 13)     # what the SIMULATOR holds: changes only through set_*
+        self.sim_root[:, 6] = 1.0
         self._refresh_bodies()
 
     def __getattr__(self, name):  # every call the fixtures do not care about
@@ -248,6 +251,10 @@ class FakeGym:
 
     def create_actor(self, env, asset, pose, name, group=0, filter=0, segmentationId=0):
         self._actors += 1
+        row = self._actors - 1
+        if row < self.sim_root.shape[0]:            # initial pose of the actor (identity orientation unless given)
+            self.sim_root[row, 0:3] = torch.tensor([pose.p.x, pose.p.y, pose.p.z])
+            self.root_state[row] = self.sim_root[row]
         return 0 if name == "shelf" or not self.shelf else 1
 
     def get_actor_index(self, env, handle, domain):
@@ -290,7 +297,22 @@ class FakeGym:
         self.calls.append("set_dof_state")   # dof_state is live; body states stay stale until simulate
 
     def set_actor_root_state_tensor_indexed(self, sim, state, idx, n):
-        self.calls.append("set_root_state")
+        self.calls.append("set_root_state")          # the teleport: only the named actors move, contacts are not touched
+        rows = idx.long()
+        self.sim_root[rows] = state[rows].clone()
+
+    def _obstacles(self, e):
+        """(shelf_y, shelf_z, pipe_y, pipe_z, theta') of env e as the simulator holds them.  The pipe's root orientation
+        is a rotation about x by theta = theta' + 90 deg (V5:858-861): quaternion (sin(theta/2), 0, 0, cos(theta/2))."""
+        ob = np.zeros(5)
+        row = e * self.apn
+        if self.shelf:
+            ob[0], ob[1] = float(self.sim_root[row, 1]), float(self.sim_root[row, 2])
+            row += 1
+        if self.pipe:
+            ob[2], ob[3] = float(self.sim_root[row, 1]), float(self.sim_root[row, 2])
+            ob[4] = 2.0 * math.atan2(float(self.sim_root[row, 3]), float(self.sim_root[row, 6])) - math.pi / 2
+        return ob
 
     def _refresh_bodies(self):
         ds = self.dof_state.view(self.n, 6, 2).numpy().astype(np.float64)
@@ -324,8 +346,18 @@ class FakeGym:
                 eff[1:] = eff[1:] + C_ * qd0[1:]
                 cj = np.full(6, np.float32(self.ocfg.damping), np.float32)
                 cj[1:] += C_
-            q, qd = vo.simulate(self.ocfg, ds[e, :, 0].numpy(), ds[e, :, 1].numpy(), eff, h,
-                                self.ocfg.substeps, form=vo.FORM_ABS, precision="f32", cj=cj)
+            if self.shelf or self.pipe:
+                # obstacle contacts re-evaluated in every substep (the oracle's own simulate loop); the net contact
+                # force tensor then holds this sim step's force on `shelf_link` -- row SHELF_BODY["shelf_link"] of the
+                # env's bodies -- until the next simulate (a teleport of the shelf does not clear it)
+                q, qd, cf = vo.simulate_obstacles(self.ocfg, ds[e, :, 0].numpy(), ds[e, :, 1].numpy(), eff, h,
+                                                  self.ocfg.substeps, self.shelf, self.pipe, self._obstacles(e),
+                                                  form=vo.FORM_ABS, precision="f32", cj=cj)
+                if self.shelf:
+                    self.contact[e * self.nb + SHELF_BODY["shelf_link"]] = torch.tensor([0.0, cf, 0.0])
+            else:
+                q, qd = vo.simulate(self.ocfg, ds[e, :, 0].numpy(), ds[e, :, 1].numpy(), eff, h,
+                                    self.ocfg.substeps, form=vo.FORM_ABS, precision="f32", cj=cj)
             ds[e, :, 0] = torch.from_numpy(q.astype(np.float32))
             ds[e, :, 1] = torch.from_numpy(qd.astype(np.float32))
         self._refresh_bodies()
@@ -567,20 +599,33 @@ def f6_trajectory(vt, v5, out):
     # included, held over the whole sim step -- at the DAMPING for which this articulation model is stable under them
     # (0.08); "held_efflim03": the same literal semantics at the YAML's own DAMPING (0.02), bounded by
     # a simulator-side joint effort clamp of 0.3 N m.  The other three run the product's default mode at the YAML's DAMPING.
+    # "shelf_*" / "pipe_delay1" (round 4): BASELINE configs[4]'s step sequencing and the task YAML's default obstacle through
+    # the real VecTask.step -- FakeGym.simulate re-evaluates the obstacle contacts per substep and leaves the sim step's
+    # force on `shelf_link` in the net-contact-force tensor, set_actor_root_state_tensor_indexed teleports the obstacle:
+    # pins that entry 0 of a step's four contact norms is the PREVIOUS step's last sim step (VT:343-351 reads the tensor
+    # before each simulate), that a teleport inside reset_idx does not clear it (V5:816-839), the mean (V5:1240-1244), and
+    # the contact term of reward / reset.  Targets and depths are chosen so that the vine meets the front-edge strip.
+    shelf_over = dict(CREATE_SHELF=True, ACTION_DELAY=1, MIN_TARGET_Y=-0.12, MAX_TARGET_Y=-0.02, MIN_TARGET_Z=0.56,
+                      MAX_TARGET_Z=0.66, MIN_TARGET_DEPTH_IN_OBSTACLE=0.0, MAX_TARGET_DEPTH_IN_OBSTACLE=0.1)
     for tag, over in (("delay1", dict(ACTION_DELAY=1)), ("delay0_tipobs", dict(ACTION_DELAY=0, OBSERVATION_TYPE="TIP_AND_CART_AND_OBJ_INFO")),
                       ("delay2", dict(ACTION_DELAY=2)), ("held_damping008", dict(ACTION_DELAY=1, DAMPING=0.08)),
-                      ("held_efflim03", dict(ACTION_DELAY=1))):
+                      ("held_efflim03", dict(ACTION_DELAY=1)),
+                      ("shelf_delay1", dict(shelf_over, USE_NONZERO_CONTACT_FORCE_RESET=False)),
+                      ("shelf_contact_reset", dict(shelf_over, USE_NONZERO_CONTACT_FORCE_RESET=True)),
+                      ("pipe_delay1", dict(CREATE_PIPE=True, ACTION_DELAY=1, MIN_TARGET_Y=-0.3, MAX_TARGET_Y=-0.2,
+                                           MIN_TARGET_Z=0.58, MAX_TARGET_Z=0.67))):
         env_over = dict(maxEpisodeLength=20, SUCCESS_DIST=0.12, RAIL_SOFT_LIMIT=0.2, MIN_TARGET_Y=-0.3,
                         MAX_TARGET_Y=-0.1, MIN_TARGET_Z=0.53, MAX_TARGET_Z=0.6, RANDOM_INIT_CART_MIN_Y=-0.02,
                         RANDOM_INIT_CART_MAX_Y=0.2)
         env_over.update(over)
+        obstacle = env_over.get("CREATE_SHELF", False) or env_over.get("CREATE_PIPE", False)
         cfg = reference_task_cfg(N, **env_over)
         task, gym, ocfg = make_task(vt, v5, cfg, held=tag.startswith("held"), effort_limit=0.3 if "efflim03" in tag else 0.0)
         torch.manual_seed(42)
         g = torch.Generator().manual_seed(2024)
         first = task.reset()
         rec = {k: [] for k in ["actions", "obs", "rew", "reset", "timeouts", "progress", "reset_values", "did_reset", "q",
-                               "qd", "tip", "agg"]}
+                               "qd", "tip", "agg"] + (["contact_norms", "contact_mean", "obstacle_pose"] if obstacle else [])}
         rec_first = npf(first["obs"])
         for t in range(T):
             a = torch.rand(N, 2, generator=g) * 2.6 - 1.3           # exceeds +-1: exercises the action clamp
@@ -591,8 +636,17 @@ def f6_trajectory(vt, v5, out):
             vals = np.zeros((N, 10), np.float32)
             vals[:, 0:5] = npf(task.dof_pos)[:, 1:6]; vals[:, 5] = npf(task.dof_pos)[:, 0]
             vals[:, 6:9] = npf(task.target_positions); vals[:, 9] = npf(task.object_info)[:, 0]
+            if env_over.get("CREATE_PIPE", False):
+                vals[:, 6] = npf(task.object_info)[:, 0]            # the pipe's entrance depth (V5:884); slot 6 is target x = 0 otherwise
             # dof_pos is the post-reset draw only for the envs that were reset inside this step
             vals[~will_reset] = 0
+            if obstacle:
+                # the four norms VT:349-351 collected in this step (zeros without a shelf: V5:1246-1248), their mean as
+                # compute_reward forms it (V5:1242-1243), and where the simulator holds the obstacles after the step
+                norms = (torch.stack(task.shelf_contact_force_norms, dim=0) if cfg["env"]["CREATE_SHELF"]
+                         else torch.zeros(4, N))
+                rec["contact_norms"].append(npf(norms)); rec["contact_mean"].append(npf(torch.mean(norms, dim=0)))
+                rec["obstacle_pose"].append(np.stack([gym._obstacles(e) for e in range(N)]).astype(np.float32))
             rec["actions"].append(npf(a)); rec["obs"].append(npf(obs["obs"])); rec["rew"].append(npf(rew))
             rec["reset"].append(npf(rst)); rec["timeouts"].append(npf(extras["time_outs"]))
             rec["progress"].append(npf(task.progress_buf)); rec["reset_values"].append(vals)

@@ -20,18 +20,22 @@ def base_cfg(num_envs, obs_type=abi.OBS_POS_AND_FD_VEL_AND_OBJ_INFO, randomize=F
 
 
 F6_CASES = [("delay1", 1, 0, False), ("delay0_tipobs", 0, 1, False), ("delay2", 2, 0, False),
-            ("held_damping008", 1, 0, "damping008"), ("held_efflim03", 1, 0, "efflim03")]
+            ("held_damping008", 1, 0, "damping008"), ("held_efflim03", 1, 0, "efflim03"),
+            ("shelf_delay1", 1, 0, "shelf"), ("shelf_contact_reset", 1, 0, "shelf_contact_reset"), ("pipe_delay1", 1, 0, "pipe")]
+F6_OBSTACLE_CASES = [c for c in F6_CASES if c[0].startswith(("shelf", "pipe"))]
 
 
 def f6_cfg(num_envs, action_delay, obs_type, held=False):
     """The configuration tests/golden/make_golden.py used for the F6 trajectories (env_overrides array inside the
     fixture): the task YAML's own DAMPING (0.02) in the product's default physics mode, or -- ``held`` -- the reference's
     literal actuation (efforts of V5:1062 incl. C_j*qd_j held over the sim step) at DAMPING 0.08 ("damping008") or at the
-    YAML's DAMPING with a 0.3 N m joint effort clamp ("efflim03")."""
+    YAML's DAMPING with a 0.3 N m joint effort clamp ("efflim03"); "shelf" / "shelf_contact_reset" / "pipe" = the default
+    mode with that obstacle (BASELINE configs[4]'s step sequencing; the task YAML's default obstacle)."""
     cfg = base_cfg(num_envs, obs_type)
-    if held:
+    variant = held or ""
+    if variant in ("damping008", "efflim03"):
         cfg.set_flag(abi.FLAG_FPAM_DAMPING_HELD, True)
-        if held == "efflim03":
+        if variant == "efflim03":
             cfg.effort_limit = 0.3            # at the YAML's own DAMPING (0.02)
         else:
             cfg.damping = 0.08
@@ -42,6 +46,16 @@ def f6_cfg(num_envs, action_delay, obs_type, held=False):
     cfg.min_target_z, cfg.max_target_z = 0.53, 0.6
     cfg.random_init_cart_min_y, cfg.random_init_cart_max_y = -0.02, 0.2
     cfg.action_delay = action_delay
+    if variant.startswith("shelf"):
+        cfg.set_flag(abi.FLAG_CREATE_SHELF, True)
+        cfg.set_flag(abi.FLAG_USE_NONZERO_CONTACT_FORCE_RESET, variant == "shelf_contact_reset")
+        cfg.min_target_y, cfg.max_target_y = -0.12, -0.02
+        cfg.min_target_z, cfg.max_target_z = 0.56, 0.66
+        cfg.min_target_depth, cfg.max_target_depth = 0.0, 0.1
+    if variant == "pipe":
+        cfg.set_flag(abi.FLAG_CREATE_PIPE, True)
+        cfg.min_target_y, cfg.max_target_y = -0.3, -0.2
+        cfg.min_target_z, cfg.max_target_z = 0.58, 0.67
     return cfg
 
 

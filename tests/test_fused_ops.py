@@ -1808,6 +1808,49 @@ def test_fp16_update_recovers_from_an_absurd_loss_scale():
     env.close()
 
 
+@pytest.mark.gpu
+def test_truncate_grads_with_the_fp16_fused_update():
+    """``truncate_grads: True`` on the default mixed-precision update: the loss-scaled gradient block is
+    clipped against its UNSCALED norm.  A threshold nothing reaches leaves training bit-identical to ``truncate_grads:
+    False`` (round 3 clipped scale * g: every step was clipped and the updates collapsed); a tight threshold clips, and the
+    clipped run's first Adam step still moves every parameter by about the learning rate."""
+    if fused.lp_dtype() != torch.float16:
+        pytest.skip("bf16 build: no loss scaling")
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+
+    def run(truncate, grad_norm):
+        cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048"])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False, use_graphs=False, mixed_precision=True,
+                                truncate_grads=truncate, grad_norm=grad_norm)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        assert agent.fused_mixed and agent.optimizer.amp_state is not None
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        p0 = agent.optimizer.flat_params.clone()
+        for _ in range(2):
+            agent.train_epoch()
+        torch.cuda.synchronize()
+        out = agent.optimizer.flat_params.clone(), p0, float(agent.optimizer.step_t)
+        env.close()
+        return out
+
+    free, p0, steps = run(False, 1.0)
+    loose, _, steps_l = run(True, 1e9)
+    tight, _, steps_t = run(True, 1e-3)
+    assert steps == steps_l == steps_t > 0
+    assert torch.equal(free, loose)                       # clip coefficient exactly 1: nothing changes
+    assert not torch.equal(free, tight)                   # the tight threshold does clip
+    moved = (tight - p0).abs()
+    assert torch.isfinite(tight).all() and float(moved.max()) > 1e-5      # Adam normalises: clipped steps still move
+
+
 # --------------------------------------------------------------------------- fp32 matrix-core rollout kernels
 @pytest.mark.gpu
 @pytest.mark.parametrize("F", [28, 18])

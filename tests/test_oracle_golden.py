@@ -164,8 +164,9 @@ def test_f5_reset_sampling(golden, shelf):
 
 @pytest.mark.parametrize("tag,delay,obs_type,held", F6_CASES)
 def test_f6_step_sequencing(golden, tag, delay, obs_type, held):
-    """The reference's real VecTask.step (VT:319-380) for 64 steps over FakeGym (physics = this oracle, f32,
-    held-torque mode): pins reset-next-step ordering, the stale tip after reset, 4x actuation, FIFO, timeouts."""
+    """The reference's real VecTask.step (VT:319-380) for 64 steps over FakeGym (physics = this oracle, f32):
+    pins reset-next-step ordering, the stale tip after reset, 4x actuation, FIFO, timeouts; the shelf / pipe cases also the
+    contact sequencing of BASELINE configs[4] (norm read before each simulate, carried over steps and teleports)."""
     g = golden("f6_traj_" + tag)
     T, N, _ = g["actions"].shape
     cfg = f6_cfg(N, delay, obs_type, held)
@@ -185,9 +186,25 @@ def test_f6_step_sequencing(golden, tag, delay, obs_type, held):
         np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-4, atol=2e-4)
         np.testing.assert_allclose(rew, g["rew"][t], rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(env.state[abi.VF_AGG_REW], g["agg"][t], rtol=1e-5, atol=1e-3)
+        if "contact_mean" in g:
+            # the mean of the four norms the reference collected BEFORE each simulate (VT:343-351, V5:1240-1244), and the
+            # value its contact tensor holds after the step (= entry 0 of the next step, teleport or not)
+            np.testing.assert_allclose(env.state[abi.VF_CONTACT_MEAN], g["contact_mean"][t], rtol=2e-4, atol=2e-3)   # k = 2000 N/m on float32 positions
+            if t + 1 < T:
+                np.testing.assert_allclose(env.state[abi.VF_CONTACT], g["contact_norms"][t + 1][0], rtol=2e-4, atol=2e-3)
         n_resets += int(will_reset.sum())
         n_timeouts += int(to.sum())
-    assert n_resets > N and n_timeouts > 0               # the trajectory exercises resets and timeouts
+    assert n_resets > N                                   # the trajectory exercises resets ...
+    assert n_timeouts > 0 or tag == "shelf_contact_reset"  # ... and timeouts (contact resets end every episode earlier)
+    if tag.startswith("shelf"):
+        cm, cn, did = g["contact_mean"], g["contact_norms"], g["did_reset"]
+        assert (cm > 0).mean() > 0.15                    # a good share of the env steps touch the strip
+        # carried-over entry 0: a step whose own sim steps 1-3 saw no contact still reports one from the previous step
+        assert ((cn[:, 0] > 0) & (cn[:, 1:].max(axis=1) == 0)).any()
+        # straight after a teleport (the env was reset in the previous step) entry 0 is still the pre-teleport contact
+        assert (did[1:] & (cn[1:, 0] > 0)).any()
+        if tag == "shelf_contact_reset":
+            assert (g["reset"][cm > 0] == 1).all()       # V5:1555-1557
 
 
 @pytest.mark.parametrize("shelf", [0, 1])

@@ -198,6 +198,32 @@ def test_flat_gradient_buffer_views():
         assert p.data_ptr() == agent.optimizer.flat_params.data_ptr() + 4 * off
 
 
+@pytest.mark.parametrize("scale", [None, 65536.0])
+@pytest.mark.parametrize("gain", [0.01, 30.0])
+def test_clip_grad_norm_under_loss_scaling(scale, gain):
+    """``truncate_grads: True`` with the device-side GradScaler: the gradient block holds scale * g until the
+    Adam kernel unscales it, and the clip threshold applies to the UNSCALED norm -- what rl_games gets from
+    ``scaler.unscale_`` followed by ``clip_grad_norm_``."""
+    from vine_robot_isaacgymenvs_amd.learning.flat_adam import FlatAdam
+    torch.manual_seed(3)
+    params = [torch.nn.Parameter(torch.randn(33, 7)), torch.nn.Parameter(torch.randn(130))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    opt = FlatAdam(params, lr=1e-3)
+    if scale is not None:
+        opt.enable_loss_scaling(init_scale=scale)
+    s = 1.0 if scale is None else scale
+    for p, r in zip(params, ref):
+        g = torch.randn_like(r) * gain
+        r.grad = g.clone()
+        p.grad.copy_(g * s)                               # what the loss kernels leave behind
+    expect = torch.nn.utils.clip_grad_norm_(ref, 1.0)     # (the unscaled norm)
+    got = opt.clip_grad_norm_(1.0)
+    assert abs(float(got) - float(expect)) <= 1e-5 * float(expect)
+    assert (float(expect) > 1.0) == (gain > 1.0)          # one case clips, the other does not
+    for p, r in zip(params, ref):
+        torch.testing.assert_close(p.grad / s, r.grad, rtol=1e-5, atol=1e-7)
+
+
 def test_training_runs_and_checkpoint_roundtrip(tmp_path):
     agent, cfg = make_agent(num_envs=16, minibatch=64, max_epochs=2)
     agent.nn_dir = str(tmp_path)

@@ -50,3 +50,15 @@ def test_scalar_log_writes_csv_and_events(tmp_path):
     assert "performance/step_inference_rl_update_fps,23700000.0,262144" in open(log.path).read()
     got = tfevents.read_scalars(log.events.path)
     assert got[0][0] == "performance/step_inference_rl_update_fps" and got[0][2] == 262144 and abs(got[0][1] - 2.37e7) < 2.0
+
+
+def test_scalars_beyond_float32_become_inf(tmp_path):
+    """A diverged loss held as a Python float / float64 (|v| > 3.4e38) must not abort the run: it is logged as
+    +-inf, as tensorboardX would; NaN stays NaN."""
+    w = tfevents.EventFileWriter(str(tmp_path))
+    for i, v in enumerate([1e39, -1e39, float("inf"), float("nan"), 3.0e38]):
+        w.add_scalar("losses/c_loss", v, i)
+    w.close()
+    got = [v for _t, v, _s, _w in tfevents.read_scalars(glob.glob(os.path.join(str(tmp_path), "events.out.tfevents.*"))[0])]
+    assert got[0] == float("inf") and got[1] == float("-inf") and got[2] == float("inf") and got[3] != got[3]
+    assert got[4] == struct.unpack("<f", struct.pack("<f", 3.0e38))[0]

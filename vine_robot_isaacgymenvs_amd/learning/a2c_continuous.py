@@ -966,7 +966,9 @@ class A2CAgent:
             if self.truncate_grads:
                 if self.multi_gpu:
                     self.flat_grads.div_(self.rank_size)
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
+                # the fp16 fused update leaves loss-scaled gradients here (unscaled inside the Adam kernel): clip against
+                # the unscaled norm, as rl_games does after scaler.unscale_
+                self.optimizer.clip_grad_norm_(self.grad_norm)
                 self.optimizer.step()
             else:
                 self.optimizer.step(grad_scale=1.0 / self.rank_size)   # /world folded into the Adam kernel

@@ -92,6 +92,19 @@ class FlatAdam:
         self.flat_grads.zero_()
 
     @torch.no_grad()
+    def clip_grad_norm_(self, max_norm):
+        """``torch.nn.utils.clip_grad_norm_`` over the flat gradient block (the padding is zero).  With device-side loss
+        scaling the block holds ``scale * g`` until the Adam kernel unscales it, so the threshold applies to the UNSCALED
+        norm -- rl_games calls ``scaler.unscale_`` before clipping (``truncate_grads: True``); no host synchronisation.
+        A non-finite norm leaves a non-finite block behind: the overflow flag makes the step skip and clear it."""
+        norm = torch.linalg.vector_norm(self.flat_grads)
+        if self.amp_state is not None:
+            norm = norm / self.amp_state[0]
+        coef = (float(max_norm) / (norm + 1e-6)).clamp(max=1.0)
+        self.flat_grads.mul_(coef)
+        return norm
+
+    @torch.no_grad()
     def step(self, grad_scale=1.0, lr_schedule=None):
         """``lr_schedule`` = (kl device scalar, kl_scale, kl_threshold, min_lr, max_lr): rl_games' AdaptiveScheduler
         applied to ``self.lr`` AFTER this step used the old value, by the same launch (GPU path only)."""

@@ -97,6 +97,8 @@ def splitk_tn(dy, x, out=None, batch=None):
     while K % (s * 2) == 0 and K // (s * 2) >= SPLITK_ROWS and s < 64:
         s *= 2
     if s == 1 or not dy.is_cuda:
+        if batch is not None:
+            batch.bypassed = True       # this gradient does not pass the overflow-checked column-sum launch
         if dy.dtype in _LP16:
             r = torch.mm(dy.t(), x, out_dtype=torch.float32)
             return out.copy_(r) if out is not None else r
@@ -174,6 +176,8 @@ def weight_grad(dy, x, out=None, batch=None):
     _check(_lib().vine_weight_grad_mfma(n, M, Np, N, dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), s,
                                         part.data_ptr(), _stream(dy)), "vine_weight_grad_mfma")
     if direct:
+        if batch is not None:
+            batch.bypassed = True
         return out
     return column_sums(part, out, batch=batch)
 
@@ -600,6 +604,7 @@ class ColumnSumBatch:
         self.jobs, self.keep = [], []
         self.found_inf = found_inf      # 1-element device tensor set to 1 by a non-finite result (loss-scaled backward)
         self.fin = None                 # abi.LossFinalize: the deferred last step of vine_ln_heads_loss rides in the launch
+        self.bypassed = False           # a weight gradient was written straight into its slot (single-slice fallbacks)
 
     def add(self, src, out, out1=None, n0=0, dup=False):
         flat = _as_rows(src)
@@ -1207,6 +1212,8 @@ class _Trunk(torch.autograd.Function):
                 gz = None
         wgroup.flush()                      # the MLP weight gradients: one launch, all operands exist by now
         if batch is not None:
+            if batch.bypassed and amp is not None:
+                ctx.loss_pack["amp_covered"] = False     # (coverage is per delivery, not per batch)
             batch.flush(out)
         return (None, None, None, None, None, None, None, None, None, None, None, *grads)
 

@@ -54,6 +54,17 @@ def _len_delimited(field, payload):
     return _varint((field << 3) | 2) + _varint(len(payload)) + payload
 
 
+def _as_f32(value):
+    """float -> the nearest float32 as a Python float; finite values beyond float32's range become +-inf (``struct.pack``
+    would raise OverflowError and end the training loop over a diverged scalar; tensorboardX logs inf)."""
+    value = float(value)
+    if value != value or value in (float("inf"), float("-inf")):
+        return value
+    if abs(value) > 3.4028234663852886e38:
+        return float("inf") if value > 0 else float("-inf")
+    return value
+
+
 def _event(wall_time, step=None, file_version=None, tag=None, value=None):
     ev = bytes([(1 << 3) | 1]) + struct.pack("<d", wall_time)
     if step is not None:
@@ -61,7 +72,7 @@ def _event(wall_time, step=None, file_version=None, tag=None, value=None):
     if file_version is not None:
         ev += _len_delimited(3, file_version.encode())
     if tag is not None:
-        val = _len_delimited(1, tag.encode()) + bytes([(2 << 3) | 5]) + struct.pack("<f", float(value))
+        val = _len_delimited(1, tag.encode()) + bytes([(2 << 3) | 5]) + struct.pack("<f", _as_f32(value))
         ev += _len_delimited(5, _len_delimited(1, val))
     return ev
 
