@@ -219,7 +219,9 @@ OTHER_CONFIGS = [
 ]
 
 
-def other_config_rates(args, device_index, steps=200):
+def other_config_rates(args, device_index, steps=200, mode="ppo"):
+    """Per configuration: the env-step kernel alone (HIP events, as the headline's `env_only`) and -- mode ppo -- the whole
+    PPO iteration on it (`ppo`: same quantity as the headline's `value`)."""
     import copy
     import torch
     rows = []
@@ -228,7 +230,7 @@ def other_config_rates(args, device_index, steps=200):
         a.num_envs = n
         if any(o.startswith("OBSERVATION_TYPE=") for o in ov):
             a.obs_type = [o for o in ov if o.startswith("OBSERVATION_TYPE=")][0].split("=")[1]
-        env, _ = make_env(a, 0, device_index, extra_overrides=ov)
+        env, cfg_o = make_env(a, 0, device_index, extra_overrides=ov)
         g = torch.Generator(device=env.device).manual_seed(7)
         pool = [torch.rand((n, 2), device=env.device, generator=g) * 2 - 1 for _ in range(16)]
         for i in range(60):                  # past the all-env reset of the first step; episodes de-synchronise
@@ -243,6 +245,12 @@ def other_config_rates(args, device_index, steps=200):
         rows.append({"config": name, "num_envs": n, "kernel": kernel_instance(env), "kernel_us": ms * 1e3,
                      "env_steps_per_sec": n / (ms * 1e-3),
                      "hbm_frac": ALGO_BYTES_PER_ENV_STEP[env.num_obs] * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        if mode == "ppo":
+            try:
+                from vine_robot_isaacgymenvs_amd.learning.bench_support import ppo_iteration_rate
+                rows[-1]["ppo"] = ppo_iteration_rate(env, cfg_o, amp=args.amp, use_graphs=not args.no_graph)
+            except Exception as err:      # a configuration the agent refuses must not cost the line
+                rows[-1]["ppo"] = "unavailable: %s" % str(err)[:160]
         env.close()
     return rows
 
@@ -469,7 +477,7 @@ def main():
         if world == 1 and not args.no_saturated:
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)
         if world == 1 and not args.no_other_configs:
-            out["configs"] = other_config_rates(args, local_rank)
+            out["configs"] = other_config_rates(args, local_rank, mode=mode)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds, mode, cfg)
         print(json.dumps(out), file=real_stdout, flush=True)

@@ -2,10 +2,12 @@
 """Strong / weak scaling PROJECTION from one GPU (RCCL itself is unmeasured: the builder has one
 MI355X).  Times `bench.py --mode ppo` at the per-rank shard sizes of W = 2 / 4 / 8 strong scaling (16384 envs and every
 32768-sample minibatch split over the ranks) and of weak scaling, all on the multi-rank code path (multi_gpu=True with a
-1-rank RCCL group: one graph replay per optimiser step -- Adam of the previous step + forward / backward -- and the all-reduce launched eagerly between the graphs), and adds
+1-rank RCCL group; round 4: one graph replay per mini-epoch with the all-reduce of every optimiser step captured inside it when
+the capture probe passes -- `update_graphs` in the output says which form ran; round 3: one graph per step, collective between
+them), and adds
 32 x an ASSUMED all-reduce time per iteration (1.63 MB of gradients + KL + overflow flag over xGMI; latency-bound).
 
-    python scripts/scaling_projection.py [--steps 10] > profiles/r03/scaling_projection.json
+    python scripts/scaling_projection.py [--steps 10] > profiles/r04/scaling_projection.json
 """
 import argparse
 import json

@@ -79,13 +79,14 @@ def test_multi_gpu_code_path_on_one_rank(monkeypatch):
         monkeypatch.setenv(k, v)
     results = []
     try:
-        for multi in (True, False):
+        for multi, in_graph in ((True, True), (True, False), (False, True)):
             cfg = load_config(overrides=["num_envs=256", "minibatch_size=1024"])
             cfg["task"]["seed"] = 42
             env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
                                                           graphics_device_id=0, headless=True)
             params = cfg["train"]["params"]
-            params["config"].update(write_files=False, print_stats=False, use_graphs=True, multi_gpu=multi, device="cuda")
+            params["config"].update(write_files=False, print_stats=False, use_graphs=True, multi_gpu=multi, device="cuda",
+                                    collective_in_graph=in_graph)
             torch.manual_seed(0)
             agent = A2CAgent("t", params, vec_env=env)
             assert torch.cuda.current_device() == agent.device.index == 0
@@ -100,14 +101,23 @@ def test_multi_gpu_code_path_on_one_rank(monkeypatch):
                 agent.train_epoch()
             torch.cuda.synchronize()
             assert agent.graph_status["rollout"] == "graph", agent.graph_status
-            assert agent.graph_status["update"].startswith("graph (per optimiser step" if multi else "graph (1 per mini-epoch"), \
-                agent.graph_status
+            if multi:
+                # round 4: the collective is captured into the mini-epoch graph when RCCL accepts a capture on this stack
+                # (probed once); refused -> one graph per optimiser step with the eager all-reduce between them
+                cc = agent.collective_capture
+                print("collective capture:", cc, agent.graph_status["update"])
+                assert agent.graph_status["update"].startswith(
+                    "graph (1 per mini-epoch, all-reduces captured" if cc["in_graph"] else "graph (per optimiser step"), agent.graph_status
+            else:
+                assert agent.graph_status["update"].startswith("graph (1 per mini-epoch)"), agent.graph_status
             flat = torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone()
             assert torch.isfinite(flat).all()
             results.append((flat, float(agent.lr)))
             env.close()
-        assert torch.allclose(results[0][0], results[1][0], rtol=1e-5, atol=1e-6)
-        assert results[0][1] == results[1][1]
+        # captured collectives == eager collectives between per-step graphs == the plain single-rank run
+        for other in results[1:]:
+            assert torch.allclose(results[0][0], other[0], rtol=1e-5, atol=1e-6)
+            assert results[0][1] == other[1]
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

@@ -4261,6 +4261,28 @@ __global__ __launch_bounds__(256) void mlp3_elu_f32_kernel(long long n, float* _
 // side stream the library has not seen before).  Returns nullptr when the pool is exhausted or cannot be allocated
 // (the wrappers then report VINE_ERR_DEVICE).
 #include <mutex>
+namespace {
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device: remember the size raised per (kernel,
+// device) -- not once per process (a process driving a second GPU launched without the attribute) -- under a
+// mutex.  Not a stream operation: legal inside a capture.
+struct DynLdsEntry { const void* fn; int dev; size_t bytes; };
+DynLdsEntry g_dyn_lds[256];
+int g_dyn_lds_used = 0;
+std::mutex g_dyn_lds_mutex;
+bool ensure_dyn_lds(const void* fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_dyn_lds_mutex);
+    DynLdsEntry* e = nullptr;
+    for (int i = 0; i < g_dyn_lds_used; ++i)
+        if (g_dyn_lds[i].fn == fn && g_dyn_lds[i].dev == dev) { e = &g_dyn_lds[i]; break; }
+    if (e && e->bytes >= bytes) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    if (!e && g_dyn_lds_used < 256) { e = &g_dyn_lds[g_dyn_lds_used++]; e->fn = fn; e->dev = dev; e->bytes = 0; }
+    if (e) e->bytes = bytes;        // (table full: the attribute is simply set again next time)
+    return true;
+}
+}  // namespace
 #define TICKET_SUB_GROUPS 8
 #define TICKET_SUB_PITCH 32        // words: the group tickets of a stream sit 128 B apart
 namespace {
@@ -4346,15 +4368,11 @@ int vine_lstm_step_mfma(int64_t B, int64_t H, int64_t K, const void* A, int64_t 
     const dim3 grid((unsigned)(B / 64), (unsigned)(H / 16)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)64 * (K + 8) * sizeof(lp16_t);            // 33 KB at K = 256, 45 KB at K = 352
-    static bool lds_raised[LSTM_MFMA_MAX_K / 32 + 1] = {};               // K = 512 needs more than the 64 KB default
 #define VINE_LSTM_MFMA(KS, KS1)                                                                                         \
     do {                                                                                                                \
-        if (lds > 65536 && !lds_raised[KS]) {                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_step_mfma_kernel<KS, KS1>),                     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
-                return VINE_ERR_DEVICE;                                                                                 \
-            lds_raised[KS] = true;                                                                                      \
-        }                                                                                                               \
+        if (lds > 65536 && /* K = 512 needs more than the 64 KB default */                                              \
+            !ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_step_mfma_kernel<KS, KS1>), lds))                       \
+            return VINE_ERR_DEVICE;                                                                                     \
         hipLaunchKernelGGL((lstm_step_mfma_kernel<KS, KS1>), grid, block, lds, s, (long long)B, (int)H,                 \
                            (const lp16_t*)A, (long long)lda, (const lp16_t*)A2, (long long)lda2, (const lp16_t*)W,      \
                            (long long)ldw, igates, (long long)ig_stride, bias, c_prev, done, (long long)done_stride,    \
@@ -4445,13 +4463,8 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
     do {                                                                                                                \
         const size_t lds_ = 4 * SEQ_H * sizeof(float) + ((size_t)2 * SEQ_ROWS * (SEQ_H + 8) +                            \
                                                          (size_t)T * SEQ_ROWS * (32 * KS1 + 8)) * sizeof(lp16_t);        \
-        static size_t raised_ = 0;                                                                                      \
-        if (lds_ > raised_) {                                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT>),             \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_) != hipSuccess)               \
-                return VINE_ERR_DEVICE;                                                                                 \
-            raised_ = lds_;                                                                                             \
-        }                                                                                                               \
+        if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT>), lds_))              \
+            return VINE_ERR_DEVICE;                                                                                     \
         hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT>), grid, block, lds_, s, (int)T, (long long)B,        \
                            (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled,  \
                            bias, c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0);                  \
@@ -4489,13 +4502,8 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_o
     const int ablate = seq_ablate();
 #define VINE_SEQ_BWD(CT, GT)                                                                                              \
     {                                                                                                                     \
-        static bool raised = false;                                                                                       \
-        if (!raised) {                                                                                                    \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_bwd_kernel<RING, CT, GT>),                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                  \
-                return VINE_ERR_DEVICE;                                                                                   \
-            raised = true;                                                                                                \
-        }                                                                                                                 \
+        if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_bwd_kernel<RING, CT, GT>), lds))                      \
+            return VINE_ERR_DEVICE;                                                                                       \
         hipLaunchKernelGGL((lstm_seq_bwd_kernel<RING, CT, GT>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds,           \
                            (hipStream_t)stream, (int)T, (long long)B, (const GT*)g_out, (const uint4*)w_hh_tiled,         \
                            (const lp16_t*)gates, (const CT*)c_all, c0, done, (lp16_t*)dgates, bias_partial, ablate,       \
@@ -4542,15 +4550,9 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
     if (C1 != 256 || C2 != 128 || C3 != 64 || (n & 63)) return VINE_ERR_UNSUPPORTED;
     const int threads = (n % 128 == 0 && n >= 32768) ? 512 : 256;        // 8 waves per CU when one round covers the chip
     const size_t lds = ((size_t)256 * 40 + 128 * 264 + 64 * 136) * sizeof(lp16_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VINE_ERR_DEVICE;
-        attr_set = true;
-    }
+    if (!ensure_dyn_lds(threads == 512 ? reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 8>)
+                                       : reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 4>), lds))
+        return VINE_ERR_DEVICE;
 #define VINE_MLP3(NW_)                                                                                                   \
     hipLaunchKernelGGL((mlp3_elu_mfma_kernel<256, 128, 64, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), lds,  \
                        (hipStream_t)stream, (long long)n, (lp16_t*)x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip, \
@@ -4575,15 +4577,9 @@ int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, 
     if (C3 != 64 || C2 != 128 || C1 != 256 || K0 != 1024 || (n & 63)) return VINE_ERR_UNSUPPORTED;
     const int nw = (n % 128 == 0 && n >= 32768) ? 8 : 4;
     const size_t lds = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(lp16_t) + (size_t)nw * (64 + 128 + 256) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return VINE_ERR_DEVICE;
-        attr_set = true;
-    }
+    if (!ensure_dyn_lds(nw == 8 ? reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 8>)
+                                : reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 4>), 160 * 1024))
+        return VINE_ERR_DEVICE;
 #define VINE_MLP3B(NW_)                                                                                                   \
     hipLaunchKernelGGL((mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), \
                        lds, (hipStream_t)stream, (long long)n, (const lp16_t*)dG, (long long)lddg, (const lp16_t*)wt0,     \
@@ -4755,13 +4751,7 @@ static int wgrad_cat_wide_launch(int64_t rows, int64_t M, const void* dy, int64_
     const size_t lds = (size_t)2 * 32 * ((bm + 16) + (352 + 16)) * sizeof(lp16_t);      // 64 / 56 KiB
 #define VINE_WGW(MT_)                                                                                                     \
     {                                                                                                                     \
-        static bool attr_set = false;                                                                                     \
-        if (!attr_set) {                                                                                                  \
-            if (hipFuncSetAttribute((const void*)wgrad_cat_wide_kernel<6, MT_>,                                           \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                  \
-                return VINE_ERR_DEVICE;                                                                                   \
-            attr_set = true;                                                                                              \
-        }                                                                                                                 \
+        if (!ensure_dyn_lds((const void*)wgrad_cat_wide_kernel<6, MT_>, lds)) return VINE_ERR_DEVICE;                     \
         hipLaunchKernelGGL((wgrad_cat_wide_kernel<6, MT_>), dim3((unsigned)(mtiles * slices)), dim3(512), lds,            \
                            (hipStream_t)stream, stages, mtiles, (int)slices, (const lp16_t*)dy, (long long)ldy,           \
                            (const lp16_t*)x1, (long long)ldx1, (const lp16_t*)x2, (long long)ldx2, part1, (int)Nv1,       \
@@ -5256,13 +5246,7 @@ int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_
         ((uintptr_t)w3 & 15) || ((uintptr_t)b1 & 15) || ((uintptr_t)b2 & 15) || ((uintptr_t)b3 & 15))
         return VINE_ERR_UNSUPPORTED;
     const size_t lds = (size_t)128 * (256 + 4) * sizeof(float);          // W2 [C2][C1 + 4]: the largest of the three stages
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp3_elu_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return VINE_ERR_DEVICE;
-        attr_set = true;
-    }
+    if (!ensure_dyn_lds(reinterpret_cast<const void*>(mlp3_elu_f32_kernel), lds)) return VINE_ERR_DEVICE;
     hipLaunchKernelGGL(mlp3_elu_f32_kernel, dim3((unsigned)(n / 64)), dim3(256), lds, (hipStream_t)stream, (long long)n, x,
                        (long long)ldx, raw, (int)F_in, mean, var, eps, clip, w1, (long long)ldw1, b1, w2, (long long)ldw2, b2, w3,
                        (long long)ldw3, b3, alpha);

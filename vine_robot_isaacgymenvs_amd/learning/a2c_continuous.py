@@ -1040,14 +1040,19 @@ class A2CAgent:
         kl_global = False
         # one rank: nothing has to happen between the optimiser steps of a mini-epoch, so all of them replay as ONE
         # hipGraph (4 graph launches per iteration instead of 64: the launch gaps were ~6 % of the update)
-        whole_epoch = graphed and not self.multi_gpu and os.environ.get("VINE_UPD_GRAPH", "epoch") == "epoch"
+        # several ranks: the same, with the gradient all-reduce of every step captured INSIDE the graph, when RCCL accepts
+        # a capture on this stack (probed once, collectively: ``_collective_capture_ok``); otherwise one graph per step with
+        # the collective issued eagerly between them
+        whole_epoch = (graphed and os.environ.get("VINE_UPD_GRAPH", "epoch") == "epoch"
+                       and (not self.multi_gpu or self._collective_capture_ok()))
         for mini_ep in range(self.mini_epochs_num):
             nb = self.num_minibatches
             if whole_epoch and self._update_epoch_graphed(rows[mini_ep * nb:(mini_ep + 1) * nb]):
                 if self.normalize_input:
                     self.model.running_mean_std.eval()
                 continue
-            whole_epoch = False            # capture refused: the flag set by the failure sends the steps below eager
+            whole_epoch = False            # capture refused: single rank: the flag set by the failure sends the steps below
+                                           # eager; several ranks: they fall back to one graph per step (eager collective)
             graphed = graphed and not getattr(self, "_update_graphs_failed", False)
             step_graphed = 0
             for i in range(self.num_minibatches):
@@ -1173,25 +1178,76 @@ class A2CAgent:
         self.graph_status["update"] = "graph (per optimiser step: Adam of the previous step + forward / backward; all-reduce between graphs)"
         return True
 
+    def _collective_capture_ok(self):
+        """May the RCCL gradient all-reduce live INSIDE a captured graph?  Decided once per agent, by all ranks together:
+        a throw-away graph holding one ``all_reduce`` of a small tensor on this rank's stream is captured and replayed
+        twice, and its result checked (SUM over the ranks).  Any refusal -- config ``collective_in_graph: False``, env
+        ``VINE_COLLECTIVE_IN_GRAPH=0``, a capture error, a wrong sum, on ANY rank -- keeps the collective eager between
+        per-step graphs.  ``self.collective_capture`` records the outcome (bench line: ``ppo.collective_in_graph``)."""
+        state = getattr(self, "_coll_capture", None)
+        if state is not None:
+            return state
+        want = bool(self.config.get("collective_in_graph", True)) and os.environ.get("VINE_COLLECTIVE_IN_GRAPH", "1") != "0"
+        ok, why = False, "disabled"
+        if want and self.is_cuda and dist.get_backend() != "nccl":
+            why = "backend %s cannot be captured" % dist.get_backend()     # (gloo rehearsals: host-side collective)
+        elif want and self.is_cuda:
+            try:
+                probe = torch.full((256,), float(dist.get_rank() + 1), device=self.device)
+                keep = probe.clone()
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+                expect = float(self.rank_size * (self.rank_size + 1) // 2)
+                ok = True
+                for _ in range(2):
+                    probe.copy_(keep)
+                    g.replay()
+                    torch.cuda.synchronize(self.device)
+                    ok = ok and bool((probe == expect).all())
+                why = "captured all-reduce replays correctly" if ok else "captured all-reduce gave a wrong sum"
+                del g
+            except RuntimeError as err:
+                ok, why = False, "capture refused: %s" % str(err)[:160]
+                torch.cuda.synchronize(self.device)
+        ok = self._capture_agreed(ok)
+        self._coll_capture = ok
+        self.collective_capture = {"in_graph": ok, "probe": why}
+        return ok
+
     def _update_epoch_graphed(self, rows_out):
-        """All optimiser steps of one mini-epoch as one graph replay (single rank only: with more ranks the gradient
-        all-reduce has to run between the two halves of every step, see ``_update_step_graphed``)."""
+        """All optimiser steps of one mini-epoch as one graph replay.  Several ranks: the RCCL all-reduce of every step is
+        a node of that graph (``_collective_capture_ok``); if the capture is refused on any rank all of them fall back to
+        one graph per step with the collective between the graphs (``_update_step_graphed``)."""
         key = ("epoch", bool(self.normalize_input and self.model.running_mean_std.training))
         rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
         if rec is None:
+            err = None
             try:
                 rec = self._capture_update_epoch(key)
-            except RuntimeError as err:
+            except RuntimeError as e:
+                err = e
+            if not self._capture_agreed(rec is not None):
+                if rec is not None:
+                    self._upd_graphs.pop(key, None)
+                torch.cuda.synchronize(self.device)
+                if self.multi_gpu:
+                    print("hipGraph capture of the mini-epoch with its all-reduces failed on %s (%s); one graph per optimiser "
+                          "step, collective between the graphs" % ("this rank" if err is not None else "another rank", str(err)[:200]))
+                    self._coll_capture = False
+                    self.collective_capture = {"in_graph": False, "probe": "mini-epoch capture refused: %s" % str(err)[:160]}
+                    return False
                 print("hipGraph capture of the mini-epoch failed (%s); continuing with eager launches" % str(err)[:200])
                 self._update_graphs_failed = True
                 self._kl_in_comm = False
                 self.graph_status["update"] = "eager (capture refused)"
-                torch.cuda.synchronize(self.device)
                 return False
         with _Range("update_graph_mini_epoch"):
             rec["G"].replay()
         rows_out.copy_(rec["stats"])
-        self.graph_status["update"] = "graph (1 per mini-epoch)"
+        self.graph_status["update"] = ("graph (1 per mini-epoch, all-reduces captured)" if self.multi_gpu
+                                       else "graph (1 per mini-epoch)")
         return True
 
     def _capture_update_epoch(self, key):
@@ -1209,6 +1265,9 @@ class A2CAgent:
                 mb = self.get_minibatch(i)
                 # statistics straight into their row, step counter and learning-rate schedule inside the Adam launch
                 stats, mu_d, _logstd_d = self._fused_grad_half(mb, stats_out=stats_all[i])
+                if self.multi_gpu:
+                    # gradients + KL + overflow flag, SUM over the ranks (RCCL over xGMI): a node of the graph
+                    dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)
                 self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
                 keep.append((mb, stats, mu_d))
         rec = {"G": g, "stats": stats_all, "keep": keep}

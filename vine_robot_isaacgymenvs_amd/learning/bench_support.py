@@ -126,6 +126,40 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
     return res
 
 
+def ppo_iteration_rate(env, cfg, steps=5, warmup=3, amp=None, use_graphs=True):
+    """Whole PPO iterations (rollout with policy inference + GAE + every optimiser step) on ``env`` with the packaged
+    train config: the same quantity as the bench line's ``value`` for another task configuration (bench.py `configs`)."""
+    import copy
+    from .a2c_continuous import A2CAgent
+    params = copy.deepcopy(cfg["train"]["params"])
+    conf = params["config"]
+    conf.update(device=str(env.device), device_pinned=True, multi_gpu=False, write_files=False, print_stats=False,
+                use_graphs=use_graphs)
+    if amp == "off":
+        conf["mixed_precision"] = False
+    elif amp:
+        conf["mixed_precision"], conf["mixed_precision_dtype"] = True, amp
+    agent = A2CAgent("bench_cfg", params, vec_env=env)
+    agent.init_tensors()
+    agent.obs = agent.env_reset()["obs"].to(agent.device)
+    for _ in range(warmup):
+        agent.train_epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    play = upd = 0.0
+    for _ in range(steps):
+        p, u, _s = agent.train_epoch()
+        play += p
+        upd += u
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = agent.horizon_length * agent.num_actors
+    return {"env_steps_per_sec": frames * steps / dt, "ms_per_iteration": dt / steps * 1e3, "rollout_ms": play / steps * 1e3,
+            "update_ms": upd / steps * 1e3, "minibatch": agent.minibatch_size,
+            "optimizer_steps_per_iter": agent.mini_epochs_num * agent.num_minibatches,
+            "hipgraphs_active": dict(agent.graph_status), "iterations_timed": steps}
+
+
 def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     from .a2c_continuous import A2CAgent
 
@@ -285,6 +319,8 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
                 # the OUTCOME, not the request: a refused capture falls back to eager launches
                 "hipgraphs_requested": bool(conf["use_graphs"]), "hipgraphs_active": dict(agent.graph_status),
                 "hipgraphs": agent.graph_status["rollout"] == "graph" and agent.graph_status["update"].startswith("graph"),
-                "update_hipgraphs": len(getattr(agent, "_upd_graphs", {}))},
+                "update_hipgraphs": len(getattr(agent, "_upd_graphs", {})),
+                # several ranks: did the RCCL all-reduce go INTO the mini-epoch graph (probe outcome), or between per-step graphs
+                "collective_in_graph": getattr(agent, "collective_capture", None)},
     }
     return elapsed, kernel_ms, frames, extra
