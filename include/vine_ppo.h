@@ -259,6 +259,23 @@ int vine_gae(int32_t T, int64_t N, const float* rewards, const float* values, co
              const float* last_values, const uint8_t* last_dones, float gamma, float tau, float* advs, float* returns,
              void* stream);
 
+/* The rollout buffers [T, N, ...] -> the PPO dataset [N T, ...] in three launches (rows R2 + R5 and rl_games'
+ * swap_and_flatten01 / prepare_dataset; the in-tree text is isaacgymenvs/learning/common_agent.py:318-411): GAE as vine_gae
+ * with returns = A + V and advantages = returns - V; value_mean_std (float64 running statistics, training mode) merged
+ * with the values and then with the returns, each series normalised with the statistics after its own update
+ * (normalize_value) -- the running statistics themselves are READ ONLY here: the twice-updated {mean, var, count} go to
+ * vms_pending [3] and the caller commits them (rl_games updates the module in prepare_dataset, not in the rollout);
+ * advantages normalised by their mean and unbiased std (+1e-8) (normalize_advantage); the three series
+ * land in ds_values / ds_returns / ds_advantages [N T].  Every job transposes one more rollout buffer src [T, N, width]
+ * (elem_bytes 4, or 1 with width 1: done flags) into dst [N T, width].  Arrays of length njobs (<= 8) in host memory.
+ * N % 64 == 0.  scratch: ceil(N / 256) * 6 + 4 doubles.  Fixed summation order, no atomics, no memsets. */
+int vine_dataset_assemble(int32_t T, int64_t N, const float* rewards, const float* values, const uint8_t* dones,
+                          const float* last_values, const uint8_t* last_dones, float gamma, float tau, const double* vms_mean,
+                          const double* vms_var, const double* vms_count, float vms_eps, int32_t normalize_value,
+                          int32_t normalize_advantage, float* ds_values, float* ds_returns, float* ds_advantages,
+                          int32_t njobs, const void* const* job_src, void* const* job_dst, const int32_t* job_width,
+                          const int32_t* job_elem_bytes, double* scratch, double* vms_pending, void* stream);
+
 /* RunningMeanStd of rl_games in training mode: merge the batch moments of x [n,F] (fp32, packed, F <= 64) into the
  * float64 running mean / variance / count (Chan et al.; unbiased batch variance like torch's x.var(0)).  Two launches,
  * fixed summation order, no memsets: safe inside a captured hipGraph.  scratch: VINE_RMS_BLOCKS * 2 * F doubles. */

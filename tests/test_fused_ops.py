@@ -883,6 +883,84 @@ def test_gae_kernel_matches_reference_loop():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,N,F", [(16, 1024, 28), (16, 192, 18), (6, 64, 28), (32, 320, 28)])
+@pytest.mark.parametrize("norm_value,norm_adv", [(True, True), (False, True), (True, False)])
+def test_dataset_assemble_matches_the_stock_composition(T, N, F, norm_value, norm_adv):
+    """vine_dataset_assemble (three launches) against what the stock path does between the rollout and the first optimiser
+    step: discount_values, returns = A + V, swap_and_flatten01 of every buffer, value_mean_std(values) then
+    value_mean_std(returns) in training mode, advantages = returns - values normalised by mean / unbiased std.
+    Transposed buffers bit-exact; normalised series to fp32 round-off; the float64 running statistics to 1e-12."""
+    import ctypes as C
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import discount_values, swap_and_flatten01
+    from vine_robot_isaacgymenvs_amd.learning.running_mean_std import RunningMeanStd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(T * N + F)
+    A = 2
+    rew, val = torch.randn(T, N, 1, device=dev) * 0.3, torch.randn(T, N, 1, device=dev) * 2 + 0.5
+    dones = (torch.rand(T, N, device=dev) < 0.1).to(torch.uint8)
+    last_d = (torch.rand(N, device=dev) < 0.1).to(torch.uint8)
+    last_v = torch.randn(N, 1, device=dev)
+    bufs = {"obs": torch.randn(T, N, F, device=dev), "actions": torch.randn(T, N, A, device=dev),
+            "neglogp": torch.randn(T, N, device=dev), "mu": torch.randn(T, N, A, device=dev),
+            "sigma": torch.rand(T, N, A, device=dev)}
+    vms = RunningMeanStd((1,)).to(dev)
+    vms.running_mean.fill_(0.3); vms.running_var.fill_(1.7); vms.count.fill_(5000.0)     # mid-training statistics
+    ref_vms = RunningMeanStd((1,)).to(dev)
+    ref_vms.load_state_dict(vms.state_dict())
+    # ---- the stock composition (A2CAgent.play_steps_rnn + prepare_dataset)
+    advs = discount_values(0.99, 0.95, last_d.float(), last_v, dones.float(), val, rew)
+    returns, values = swap_and_flatten01(advs + val), swap_and_flatten01(val)
+    adv_ref = (returns - values).sum(dim=1)
+    if norm_value:
+        ref_vms.train()
+        with torch.no_grad():       # (the torch composition, not the module's kernels: the reference of this test)
+            ref_vms.update(values); v_ref = ref_vms.eval()(values)
+            ref_vms.train(); ref_vms.update(returns); r_ref = ref_vms.eval()(returns)
+    else:
+        v_ref, r_ref = values, returns
+    if norm_adv:
+        adv_ref = (adv_ref - adv_ref.mean()) / (adv_ref.std() + 1e-8)
+    # ---- the kernels
+    n = N * T
+    dv, dr, da = (torch.empty(n, 1, device=dev), torch.empty(n, 1, device=dev), torch.empty(n, device=dev))
+    out = {"obs": torch.empty(n, F, device=dev), "actions": torch.empty(n, A, device=dev), "neglogp": torch.empty(n, device=dev),
+           "mu": torch.empty(n, A, device=dev), "sigma": torch.empty(n, A, device=dev)}
+    d_out = torch.empty(n, device=dev, dtype=torch.uint8)
+    jobs = [(bufs[k], out[k], (bufs[k].shape[2] if bufs[k].dim() == 3 else 1), 4) for k in out] + [(dones, d_out, 1, 1)]
+    k = len(jobs)
+    scratch = torch.empty((N + 255) // 256 * 6 + 4, device=dev, dtype=torch.float64)
+    pending = torch.zeros(3, device=dev, dtype=torch.float64)
+    rc = fused._lib().vine_dataset_assemble(
+        T, N, rew.data_ptr(), val.data_ptr(), dones.data_ptr(), last_v.data_ptr(), last_d.data_ptr(), 0.99, 0.95,
+        vms.running_mean.data_ptr() if norm_value else None, vms.running_var.data_ptr() if norm_value else None,
+        vms.count.data_ptr() if norm_value else None, float(vms.epsilon), int(norm_value), int(norm_adv), dv.data_ptr(),
+        dr.data_ptr(), da.data_ptr(), k, (C.c_void_p * k)(*[j[0].data_ptr() for j in jobs]),
+        (C.c_void_p * k)(*[j[1].data_ptr() for j in jobs]), (C.c_int32 * k)(*[int(j[2]) for j in jobs]),
+        (C.c_int32 * k)(*[j[3] for j in jobs]), scratch.data_ptr(), pending.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    if norm_value:      # the module's statistics are read only; the update arrives in `pending` for the caller to commit
+        assert float(vms.running_mean[0]) == 0.3 and float(vms.running_var[0]) == 1.7 and float(vms.count) == 5000.0
+        vms.running_mean[0], vms.running_var[0] = pending[0], pending[1]
+        vms.count.copy_(pending[2])
+    for name in out:
+        assert torch.equal(out[name], swap_and_flatten01(bufs[name])), name
+    assert torch.equal(d_out, swap_and_flatten01(dones))
+    torch.testing.assert_close(dv, v_ref, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(dr, r_ref, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(da, adv_ref, rtol=2e-5, atol=2e-5)
+    if norm_value:
+        for a, b in ((vms.running_mean, ref_vms.running_mean), (vms.running_var, ref_vms.running_var), (vms.count, ref_vms.count)):
+            # (the reference forms its batch moments in float32: x.mean(0), x.var(0))
+            assert abs(float(a.reshape(-1)[0]) - float(b.reshape(-1)[0])) <= 2e-6 * max(1.0, abs(float(b.reshape(-1)[0])))
+    # shapes the kernel refuses are reported, not mangled
+    assert fused._lib().vine_dataset_assemble(
+        T, N + 1, rew.data_ptr(), val.data_ptr(), dones.data_ptr(), last_v.data_ptr(), last_d.data_ptr(), 0.99, 0.95, None, None,
+        None, 0.0, 0, 0, dv.data_ptr(), dr.data_ptr(), da.data_ptr(), 0, None, None, None, None, scratch.data_ptr(), None,
+        torch.cuda.current_stream().cuda_stream) == -2
+
+
+@pytest.mark.gpu
 def test_splitk_linear_gradients():
     dev = torch.device("cuda:0")
     torch.manual_seed(1)

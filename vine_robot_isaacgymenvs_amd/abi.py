@@ -239,6 +239,8 @@ PPO_PROTOTYPES = {
     "vine_rollout_post": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 7 + [C.c_float, _VP, _VP, _I64,
                                                                                                   C.c_int32, _VP, _VP]),
     "vine_gae": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP]),
+    "vine_dataset_assemble": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, C.c_float,
+                                        C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_rms_update": (C.c_int, [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_normalize_obs": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _I64, C.c_int32, _VP]),
     "vine_adam_step": (C.c_int, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -2275,6 +2275,176 @@ __global__ void gae_kernel(int T, long long N, const float* __restrict__ rewards
     }
 }
 
+// ---- The rollout buffers -> the PPO dataset, in three launches (round 4; formerly ~40: GAE, eight transposing copies,
+// two RunningMeanStd updates + normalisations, the advantage mean / std reductions and their elementwise arithmetic):
+//   ds_gae_partial_kernel : GAE as gae_kernel (one env per lane, reverse scan in registers), its outputs written in DATASET
+//       order (sample e T + t; 16-B stores) -- raw values, returns = A + V, advantages = returns - V (the stock
+//       composition's two roundings) -- plus per-workgroup sums of x and x^2 of the three series in double
+//   ds_finalize_kernel    : one wave folds the partial rows in a fixed order; RunningMeanStd (training mode, Chan merge,
+//       unbiased batch variance) updated with the values, then with the returns, as value_mean_std(values) followed by
+//       value_mean_std(returns) does; advantage mean and unbiased standard deviation; six floats for the last kernel
+//   ds_assemble_kernel    : per 64 envs: the three series normalised in place ((x - mean) / sqrt(var + eps) clamped to
+//       +-5 with the statistics AFTER their own update; (A - mean) / (std + 1e-8)), and every other rollout buffer
+//       [T, N, W] transposed into dataset order [N T, W] through LDS (coalesced on both sides)
+// No atomics, no memsets, fixed summation order: captured and replayed like every other kernel of the iteration.
+#define DS_MAX_JOBS 8
+struct DsJobs { int n; const void* src[DS_MAX_JOBS]; void* dst[DS_MAX_JOBS]; int width[DS_MAX_JOBS]; int elem[DS_MAX_JOBS]; };
+
+__global__ __launch_bounds__(256) void ds_gae_partial_kernel(
+    int T, long long N, const float* __restrict__ rewards, const float* __restrict__ values,
+    const unsigned char* __restrict__ dones, const float* __restrict__ last_values,
+    const unsigned char* __restrict__ last_dones, float gamma, float tau, float* __restrict__ ds_values,
+    float* __restrict__ ds_returns, float* __restrict__ ds_adv, double* __restrict__ partial) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // sum / sum of squares of values, returns, advantages
+    if (e < N) {
+        float next_v = last_values[e], nnt = 1.0f - (float)last_dones[e], lam = 0.0f;
+        const long long o = e * T;
+#define DS_GAE_STEP(t_, V_, R_, A_)                                                  \
+        {                                                                            \
+            const float v = values[(long long)(t_) * N + e];                         \
+            const float delta = rewards[(long long)(t_) * N + e] + gamma * next_v * nnt - v; \
+            lam = delta + gamma * tau * nnt * lam;                                   \
+            const float ret = lam + v, adv = ret - v;                                \
+            V_ = v; R_ = ret; A_ = adv;                                              \
+            acc[0] += (double)v; acc[1] += (double)v * (double)v;                    \
+            acc[2] += (double)ret; acc[3] += (double)ret * (double)ret;              \
+            acc[4] += (double)adv; acc[5] += (double)adv * (double)adv;              \
+            next_v = v;                                                              \
+            nnt = 1.0f - (float)dones[(long long)(t_) * N + e];                      \
+        }
+        if ((T & 3) == 0) {
+            for (int t4 = T - 4; t4 >= 0; t4 -= 4) {
+                float vv[4], rr[4], aa[4];
+#pragma unroll
+                for (int k = 3; k >= 0; --k) DS_GAE_STEP(t4 + k, vv[k], rr[k], aa[k])
+                st4(ds_values + o + t4, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                st4(ds_returns + o + t4, make_float4(rr[0], rr[1], rr[2], rr[3]));
+                st4(ds_adv + o + t4, make_float4(aa[0], aa[1], aa[2], aa[3]));
+            }
+        } else {
+            for (int t = T - 1; t >= 0; --t) {
+                float v1, r1, a1;
+                DS_GAE_STEP(t, v1, r1, a1)
+                ds_values[o + t] = v1; ds_returns[o + t] = r1; ds_adv[o + t] = a1;
+            }
+        }
+#undef DS_GAE_STEP
+    }
+    __shared__ double red[6][256];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) red[j][threadIdx.x] = acc[j];
+    __syncthreads();
+    for (int h = 128; h >= 1; h >>= 1) {                  // fixed-order tree
+        if ((int)threadIdx.x < h)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) partial[(long long)blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(64) void ds_finalize_kernel(int blocks, long long n, const double* __restrict__ partial,
+                                                         const double* __restrict__ rmean,
+                                                         const double* __restrict__ rvar,
+                                                         const double* __restrict__ rcount, double* __restrict__ stats_out,
+                                                         float eps, int normalize_value, float* __restrict__ scal) {
+    __shared__ double tot[6];
+    if (threadIdx.x < 6) {
+        double s = 0.0;
+        for (int b = 0; b < blocks; ++b) s += partial[(long long)b * 6 + threadIdx.x];
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double nb = (double)n;
+    if (normalize_value) {
+        double mean = rmean[0], var = rvar[0], cnt = rcount[0];
+        for (int k = 0; k < 2; ++k) {                     // value_mean_std(values), then value_mean_std(returns)
+            const double bmean = tot[2 * k] / nb;
+            const double bvar = n > 1 ? (tot[2 * k + 1] - nb * bmean * bmean) / (nb - 1.0) : 0.0;
+            const double delta = bmean - mean, t = cnt + nb;
+            const double m2 = var * cnt + bvar * nb + delta * delta * cnt * nb / t;
+            mean += delta * nb / t;
+            var = m2 / t;
+            cnt = t;
+            scal[2 * k] = (float)mean;
+            scal[2 * k + 1] = sqrtf((float)var + eps);
+        }
+        stats_out[0] = mean; stats_out[1] = var; stats_out[2] = cnt;
+    }
+    const double amean = tot[4] / nb;
+    const double avar = n > 1 ? (tot[5] - nb * amean * amean) / (nb - 1.0) : 0.0;
+    scal[4] = (float)amean;
+    scal[5] = (float)sqrt(avar > 0.0 ? avar : 0.0);
+}
+
+#define DS_LDS_WORDS 8192
+__global__ __launch_bounds__(256) void ds_assemble_kernel(int T, long long N, const float* __restrict__ scal,
+                                                          int normalize_value, int normalize_advantage,
+                                                          float* __restrict__ ds_values, float* __restrict__ ds_returns,
+                                                          float* __restrict__ ds_adv, const DsJobs J) {
+    __shared__ unsigned int lds[DS_LDS_WORDS];
+    const long long e0 = (long long)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    {
+        const float m1 = scal[0], sd1 = scal[1], m2 = scal[2], sd2 = scal[3], am = scal[4], as_ = scal[5] + 1e-8f;
+        const long long base = e0 * T;
+        for (int i = tid; i < 64 * T; i += 256) {
+            if (normalize_value) {
+                float y = (ds_values[base + i] - m1) / sd1;
+                ds_values[base + i] = fminf(fmaxf(y, -5.0f), 5.0f);
+                y = (ds_returns[base + i] - m2) / sd2;
+                ds_returns[base + i] = fminf(fmaxf(y, -5.0f), 5.0f);
+            }
+            if (normalize_advantage) ds_adv[base + i] = (ds_adv[base + i] - am) / as_;
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < J.n; ++j) {
+        const int W = J.width[j];
+        if (J.elem[j] == 4) {
+            const unsigned int* src = reinterpret_cast<const unsigned int*>(J.src[j]);
+            unsigned int* dst = reinterpret_cast<unsigned int*>(J.dst[j]);
+            int EB = 64;
+            while (EB > 1 && EB * T * W > DS_LDS_WORDS) EB >>= 1;
+            const int seg = EB * W, tw = T * W, total = T * seg;
+            for (int sub = 0; sub < 64; sub += EB) {
+                const long long es = e0 + sub;
+                __syncthreads();                          // (the previous sub-block's / job's readers are done)
+                for (int i = tid; i < total; i += 256) {
+                    const int t = i / seg, r = i - t * seg;
+                    lds[i] = src[((long long)t * N + es) * W + r];
+                }
+                __syncthreads();
+                for (int o = tid; o < total; o += 256) {
+                    const int el = o / tw, rem = o - el * tw, t = rem / W, c = rem - t * W;
+                    dst[es * tw + o] = lds[t * seg + el * W + c];
+                }
+            }
+        } else {                                          // one byte per env and step (done flags)
+            const unsigned int* src = reinterpret_cast<const unsigned int*>(J.src[j]);
+            unsigned int* dst = reinterpret_cast<unsigned int*>(J.dst[j]);
+            const unsigned char* lb = reinterpret_cast<const unsigned char*>(lds);
+            __syncthreads();
+            for (int i = tid; i < 16 * T; i += 256) {
+                const int t = i >> 4, r = i & 15;
+                lds[i] = src[((long long)t * N + e0) / 4 + r];
+            }
+            __syncthreads();
+            for (int o = tid; o < 16 * T; o += 256) {
+                unsigned int wv = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int b = 4 * o + k, el = b / T, t = b - el * T;
+                    wv |= (unsigned int)lb[t * 64 + el] << (8 * k);
+                }
+                dst[(e0 * T) / 4 + o] = wv;
+            }
+        }
+    }
+}
+
 // RunningMeanStd in training mode (rl_games: float64 statistics, Chan et al. merge of the batch moments), two launches:
 //   partial : per-workgroup column sums of x and x^2 in double (64 column lanes x 4 row lanes)
 //   finalize: batch mean / unbiased variance from the partials (fixed order), merged into the running moments
@@ -4887,6 +5057,48 @@ int vine_gae(int32_t T, int64_t N, const float* rewards, const float* values, co
         return VINE_ERR_INVALID_ARG;
     hipLaunchKernelGGL(gae_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)T,
                        (long long)N, rewards, values, dones, last_values, last_dones, gamma, tau, advs, returns);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_dataset_assemble(int32_t T, int64_t N, const float* rewards, const float* values, const uint8_t* dones,
+                          const float* last_values, const uint8_t* last_dones, float gamma, float tau, const double* vms_mean,
+                          const double* vms_var, const double* vms_count, float vms_eps, int32_t normalize_value,
+                          int32_t normalize_advantage, float* ds_values, float* ds_returns, float* ds_advantages,
+                          int32_t njobs, const void* const* job_src, void* const* job_dst, const int32_t* job_width,
+                          const int32_t* job_elem_bytes, double* scratch, double* vms_pending, void* stream) {
+    if (T <= 0 || N <= 0 || !rewards || !values || !dones || !last_values || !last_dones || !ds_values || !ds_returns ||
+        !ds_advantages || !scratch || njobs < 0 || (njobs > 0 && (!job_src || !job_dst || !job_width || !job_elem_bytes)) ||
+        (normalize_value && (!vms_mean || !vms_var || !vms_count || !vms_pending)))
+        return VINE_ERR_INVALID_ARG;
+    if ((N & 63) || T > 256 || njobs > DS_MAX_JOBS) return VINE_ERR_UNSUPPORTED;
+    DsJobs J;
+    J.n = njobs;
+    for (int j = 0; j < DS_MAX_JOBS; ++j) { J.src[j] = nullptr; J.dst[j] = nullptr; J.width[j] = 0; J.elem[j] = 0; }
+    for (int j = 0; j < njobs; ++j) {
+        if (!job_src[j] || !job_dst[j] || job_width[j] <= 0) return VINE_ERR_INVALID_ARG;
+        if (job_elem_bytes[j] == 4) {
+            if ((long long)T * job_width[j] > DS_LDS_WORDS || ((uintptr_t)job_src[j] & 3) || ((uintptr_t)job_dst[j] & 3))
+                return VINE_ERR_UNSUPPORTED;
+        } else if (job_elem_bytes[j] == 1) {
+            if (job_width[j] != 1 || 16 * T > DS_LDS_WORDS || ((uintptr_t)job_src[j] & 3) || ((uintptr_t)job_dst[j] & 3))
+                return VINE_ERR_UNSUPPORTED;
+        } else {
+            return VINE_ERR_UNSUPPORTED;
+        }
+        J.src[j] = job_src[j]; J.dst[j] = job_dst[j]; J.width[j] = job_width[j]; J.elem[j] = job_elem_bytes[j];
+    }
+    if ((((uintptr_t)ds_values | (uintptr_t)ds_returns | (uintptr_t)ds_advantages) & 15)) return VINE_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)((N + 255) / 256);
+    float* scal = reinterpret_cast<float*>(scratch + (size_t)blocks * 6);
+    hipLaunchKernelGGL(ds_gae_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (int)T, (long long)N, rewards, values,
+                       dones, last_values, last_dones, gamma, tau, ds_values, ds_returns, ds_advantages, scratch);
+    // the updated running statistics go to vms_pending {mean, var, count}; the caller commits them (rl_games updates
+    // value_mean_std in prepare_dataset, not in the rollout: a rollout alone must leave the module as it was)
+    hipLaunchKernelGGL(ds_finalize_kernel, dim3(1), dim3(64), 0, s, blocks, (long long)N * T, scratch, vms_mean, vms_var,
+                       vms_count, vms_pending, vms_eps, (int)normalize_value, scal);
+    hipLaunchKernelGGL(ds_assemble_kernel, dim3((unsigned)(N / 64)), dim3(256), 0, s, (int)T, (long long)N, scal,
+                       (int)normalize_value, (int)normalize_advantage, ds_values, ds_returns, ds_advantages, J);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

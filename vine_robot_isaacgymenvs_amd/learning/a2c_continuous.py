@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import fused
+from .. import abi
 from ..abi import ROLLOUT_POST_SCRATCH_FLOATS
 from .flat_adam import FlatAdam
 from .network import ModelA2CContinuousLogStd
@@ -717,6 +718,9 @@ class A2CAgent:
         else:
             body()
         buf = self.buf
+        batch = self._assemble_dataset_fused()
+        if batch is not None:
+            return batch
         if (self.is_cuda and self.use_fused and buf["dones"].dtype == torch.uint8 and self.dones.dtype == torch.uint8
                 and buf["values"].is_contiguous() and buf["rewards"].is_contiguous()):
             # GAE as one kernel (one env per lane, reverse scan in registers) instead of 16 x 6 small launches
@@ -754,6 +758,63 @@ class A2CAgent:
         for mb_s in self.mb_rnn_states:          # already in dataset order: a view, no copy
             states.append(mb_s.view(mb_s.size()[0], mb_s.size()[1] * mb_s.size()[2], mb_s.size()[3]))
         batch["rnn_states"] = states
+        return batch
+
+    def _assemble_dataset_fused(self):
+        """Rollout buffers -> dataset in three launches (``vine_dataset_assemble``: GAE, the value normaliser's two updates
+        and normalisations, the advantage normalisation and every [T, N, .] -> [N T, .] transposition), written straight into
+        the persistent dataset tensors the optimiser steps read.  Returns the ``batch`` marker ``prepare_dataset`` accepts,
+        or None when the shapes / dtypes are not covered (CPU, stock path, N % 64)."""
+        buf, T, N = self.buf, self.horizon_length, self.num_actors
+        if not (self.is_cuda and self.use_fused and os.environ.get("VINE_DATASET_FUSED", "1") != "0" and N % 64 == 0
+                and buf["dones"].dtype == torch.uint8 and self.dones.dtype == torch.uint8
+                and all(buf[k].dtype == torch.float32 and buf[k].is_contiguous()
+                        for k in ("obses", "actions", "neglogpacs", "values", "mus", "sigmas", "rewards"))
+                and buf["dones"].is_contiguous() and buf["values"].shape[-1] == 1):
+            return None
+        vms = self.model.value_mean_std if self.normalize_value else None
+        st = getattr(self, "_ds_static", None)
+        if st is None or not st.get("_assembled", False):
+            n = N * T
+            dev = self.device
+            f32 = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+            st = {"old_values": f32(n, 1), "returns": f32(n, 1), "advantages": f32(n),
+                  "old_logp_actions": f32(n), "actions": f32(n, self.actions_num), "obs": f32(n, *buf["obses"].shape[2:]),
+                  "dones": torch.empty(n, device=dev, dtype=torch.uint8), "mu": f32(n, self.actions_num),
+                  "sigma": f32(n, self.actions_num),
+                  "rnn_states": [mb_s.view(mb_s.size()[0], mb_s.size()[1] * mb_s.size()[2], mb_s.size()[3])
+                                 for mb_s in self.mb_rnn_states],     # already in dataset order: views, no copy
+                  "_assembled": True}
+            if st["obs"].dim() != 2:
+                return None
+            self._ds_static = st
+            self._ds_scratch = torch.empty((N + 255) // 256 * 6 + 4, device=dev, dtype=torch.float64)
+            self._vms_pending = torch.zeros(3, device=dev, dtype=torch.float64)
+            if hasattr(self, "_upd_graphs"):
+                self._upd_graphs.clear()      # (captured steps read the dataset at fixed addresses)
+        jobs = [(buf["obses"], st["obs"], st["obs"].shape[1], 4), (buf["actions"], st["actions"], self.actions_num, 4),
+                (buf["neglogpacs"], st["old_logp_actions"], 1, 4), (buf["mus"], st["mu"], self.actions_num, 4),
+                (buf["sigmas"], st["sigma"], self.actions_num, 4), (buf["dones"], st["dones"], 1, 1)]
+        import ctypes as C
+        k = len(jobs)
+        rc = fused._lib().vine_dataset_assemble(
+            T, N, buf["rewards"].data_ptr(), buf["values"].data_ptr(), buf["dones"].data_ptr(), self.last_values.data_ptr(),
+            self.dones.data_ptr(), float(self.gamma), float(self.tau),
+            vms.running_mean.data_ptr() if vms is not None else None, vms.running_var.data_ptr() if vms is not None else None,
+            vms.count.data_ptr() if vms is not None else None, float(vms.epsilon) if vms is not None else 0.0,
+            int(vms is not None), int(bool(self.normalize_advantage)), st["old_values"].data_ptr(), st["returns"].data_ptr(),
+            st["advantages"].data_ptr(), k, (C.c_void_p * k)(*[j[0].data_ptr() for j in jobs]),
+            (C.c_void_p * k)(*[j[1].data_ptr() for j in jobs]), (C.c_int32 * k)(*[int(j[2]) for j in jobs]),
+            (C.c_int32 * k)(*[j[3] for j in jobs]), self._ds_scratch.data_ptr(), self._vms_pending.data_ptr(),
+            torch.cuda.current_stream(self.device).cuda_stream)
+        if rc == abi.ERR_UNSUPPORTED:
+            return None
+        fused._check(rc, "vine_dataset_assemble")
+        # the finished dataset (normalised series included): ``prepare_dataset`` adopts it as it is -- also on another agent
+        batch = {k: v for k, v in st.items() if not k.startswith("_")}
+        batch.update(assembled=True, played_frames=self.batch_size)
+        if vms is not None:
+            batch["vms_pending"] = self._vms_pending      # committed by prepare_dataset, where rl_games updates the module
         return batch
 
     def _can_fuse_rollout(self):
@@ -835,21 +896,33 @@ class A2CAgent:
 
     # ------------------------------------------------------------------ dataset (R5)
     def prepare_dataset(self, batch):
-        returns, values = batch["returns"], batch["values"]
-        advantages = returns - values
-        if self.normalize_value:
-            self.model.value_mean_std.train()
-            values = self.model.value_mean_std(values)
-            returns = self.model.value_mean_std(returns)
-            self.model.value_mean_std.eval()
-        advantages = torch.sum(advantages, dim=1)
-        if self.normalize_advantage:
-            advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
-        ds = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages,
-              "returns": returns, "actions": batch["actions"], "obs": batch["obses"],
-              "dones": batch["dones"], "rnn_states": batch["rnn_states"],
-              "mu": batch["mus"], "sigma": batch["sigmas"]}
-        if self.use_graphs and self.is_cuda:
+        assembled = bool(batch.get("assembled", False))
+        if assembled:
+            # _assemble_dataset_fused: GAE, value / advantage normalisation and the transpositions are done (and
+            # value_mean_std has taken its two updates); the tensors are this agent's persistent ones, or another agent's
+            ds = {k: batch[k] for k in ("old_values", "old_logp_actions", "advantages", "returns", "actions", "obs", "dones",
+                                        "rnn_states", "mu", "sigma")}
+            pend = batch.get("vms_pending")
+            if pend is not None and self.normalize_value:
+                vms = self.model.value_mean_std       # value_mean_std(values); value_mean_std(returns): one launch
+                torch._foreach_copy_([vms.running_mean, vms.running_var, vms.count],
+                                     [pend[0:1].view_as(vms.running_mean), pend[1:2].view_as(vms.running_var), pend[2].view_as(vms.count)])
+        else:
+            returns, values = batch["returns"], batch["values"]
+            advantages = returns - values
+            if self.normalize_value:
+                self.model.value_mean_std.train()
+                values = self.model.value_mean_std(values)
+                returns = self.model.value_mean_std(returns)
+                self.model.value_mean_std.eval()
+            advantages = torch.sum(advantages, dim=1)
+            if self.normalize_advantage:
+                advantages = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+            ds = {"old_values": values, "old_logp_actions": batch["neglogpacs"], "advantages": advantages,
+                  "returns": returns, "actions": batch["actions"], "obs": batch["obses"],
+                  "dones": batch["dones"], "rnn_states": batch["rnn_states"],
+                  "mu": batch["mus"], "sigma": batch["sigmas"]}
+        if (self.use_graphs and self.is_cuda) or assembled:
             # persistent storage: the captured optimiser steps read their minibatch slices at fixed addresses
             st = getattr(self, "_ds_static", None)
             if st is None:
@@ -863,7 +936,7 @@ class A2CAgent:
                                 dst.copy_(src)
                     elif st[k].data_ptr() != v.data_ptr():
                         st[k].copy_(v)
-            self.dataset = st
+            self.dataset = {k: v for k, v in st.items() if not k.startswith("_")}
         else:
             ds["mu"], ds["sigma"] = ds["mu"].clone(), ds["sigma"].clone()
             self.dataset = ds
