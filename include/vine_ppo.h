@@ -117,6 +117,19 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
                        const float* b2, int64_t C2, const void* w3, int64_t ldw3, const float* b3, int64_t C3, float alpha,
                        void* act1, void* act2, void* out, int64_t out_stride, void* stream);
 
+/* vine_mlp3_elu_mfma with the optimiser step's operand preparation riding in the same launch (round 4): `njobs` moves in
+ * the vocabulary of vine_copy_batched (same arrays, same meaning) are executed by the workgroups of this kernel as a side
+ * job -- they must build nothing this kernel reads; the consumers are the launches behind it.  w1 [C1, ldw1]: ldw1 == 32 =
+ * the zero-padded w1p of vine_mlp3_elu_mfma; ldw1 < 32 (even) = the weight as stored, [C1, ldw1] packed, padded to 32
+ * columns on its way into LDS.  njobs == 0: vine_mlp3_elu_mfma. */
+int vine_mlp3_elu_mfma_prep(int64_t n, void* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean,
+                            const double* var, float eps, float clip, const void* w1p, int64_t ldw1, const float* b1,
+                            int64_t C1, const void* w2, int64_t ldw2, const float* b2, int64_t C2, const void* w3, int64_t ldw3,
+                            const float* b3, int64_t C3, float alpha, void* act1, void* act2, void* out, int64_t out_stride,
+                            int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
+                            const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
+                            const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux, void* stream);
+
 /* Backward of that MLP in ONE launch:  gz3 = (dG wt0^T) * elu'(a3),  gz2 = (gz3 wt1^T) * elu'(a2),  gz1 = (gz2 wt2^T) * elu'(a1)
  * with dG [n, K0] (the LSTM gate gradients), wt0 [C3, K0] = the MLP block of w_ih transposed, wt1 [C2, C3] = W3^T,
  * wt2 [C1, C2] = W2^T, a3 [n, C3] (rows a3_stride apart) / a2 [n, C2] / a1 [n, C1] the stored ELU outputs, all bf16;

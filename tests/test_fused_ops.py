@@ -1887,6 +1887,44 @@ def test_fp16_update_recovers_from_an_absurd_loss_scale():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("obs_type", ["POS_AND_FD_VEL_AND_OBJ_INFO", "TIP_AND_CART_AND_OBJ_INFO"])
+def test_operand_preparation_riding_in_the_mlp_launch_is_bit_identical(obs_type, monkeypatch):
+    """Round 4: the optimiser step's parameter-derived operands (LSTM weight tiles, transposed weights, merged heads, bias
+    sum) are built by the workgroups of the one-launch MLP as a side job (vine_mlp3_elu_mfma_prep), which also pads W1
+    [256, F_in] itself (F_in = 28 and 18) -- same bytes as the former copy_batched launch in front of it: training with
+    and without the ride is bit-identical, graph-replayed included."""
+    if fused.lp_dtype() != torch.float16:
+        pytest.skip("bf16 build")
+    from vine_robot_isaacgymenvs_amd import load_config
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+
+    def run(ride):
+        monkeypatch.setattr(fused, "MLP3_PREP", ride)
+        cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048", "OBSERVATION_TYPE=%s" % obs_type])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False, use_graphs=True, mixed_precision=True)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        assert agent.fused_mixed
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        for _ in range(4):          # (iterations 3 and 4 replay the captured update)
+            agent.train_epoch()
+        torch.cuda.synchronize()
+        assert agent.graph_status["update"].startswith("graph")
+        out = agent.optimizer.flat_params.clone()
+        env.close()
+        return out
+
+    with_ride, without = run(True), run(False)
+    assert torch.isfinite(with_ride).all() and torch.equal(with_ride, without)
+
+
+@pytest.mark.gpu
 def test_truncate_grads_with_the_fp16_fused_update():
     """``truncate_grads: True`` on the default mixed-precision update: the loss-scaled gradient block is
     clipped against its UNSCALED norm.  A threshold nothing reaches leaves training bit-identical to ``truncate_grads:

@@ -203,6 +203,9 @@ PPO_PROTOTYPES = {
     "vine_weight_grad_mfma": (C.c_int, [_I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _VP]),
     "vine_mlp3_elu_mfma": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I64, _VP, _I64, _VP,
                                      _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _VP, _VP, _I64, _VP]),
+    "vine_mlp3_elu_mfma_prep": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _I64, _VP, _I64, _VP,
+                                          _I64, _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _VP, _VP, _I64,
+                                          C.c_int32] + [_VP] * 10 + [_VP]),
     "vine_ln_heads_loss": (C.c_int, [_I64, _I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                      _VP, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _VP, _VP, C.c_int32,
                                      _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -511,7 +511,11 @@ __device__ __forceinline__ uint4 pack_lp16x8(const float (&v)[8]) {
 #ifdef SEQ_TIMING
 __device__ unsigned long long seq_t[256 * 8 * 16];      // (debug build: 4 stamps per step and wave, scripts/ubench/lstm_seq_phases.py)
 #endif
-template <int KS1, int RING, typename CT, typename HT>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
+// NC (round 4): the first NC fragments of every wave's per-step weight stream are kept in LDS after step 0 (a wave-private
+// 16 NC KB region behind the operand rows: no barrier) and re-read from there in steps 1 .. T - 1 -- the kernel is bound
+// by the L2 -> CU weight stream (720 KB per step at 51 of the CU's 64 B/clk), and with T <= 4 the operand rows leave 96 KB
+// of the CU's 160 KB of LDS unused: 12 of a wave's 88 fragments, 13.6 % of the stream of three of the four steps.
+template <int KS1, int RING, typename CT, typename HT, int NC>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
 __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     int T, long long B, const lp16_t* __restrict__ x, long long ldx, lp16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
@@ -547,6 +551,9 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
     uint4 ring[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) ring[i] = SEQ_WFRAG(i);
+    static_assert(NC <= NF - RING && NC <= RING, "cached fragments are re-requested from the tail of the previous step only");
+    uint4* wcache = reinterpret_cast<uint4*>(seqf_lds + 4 * H * sizeof(float) + 2 * SEQ_ROWS * HP * sizeof(lp16_t) +
+                                             (size_t)T * SEQ_ROWS * XP * sizeof(lp16_t)) + (w * NC) * 64 + lane;
     // ---- x rows of all steps, masked h of step 0, bias, cell state, done flags
     {
         for (int p = tid; p < T * SEQ_ROWS * (KX / 8); p += 512) {
@@ -627,7 +634,12 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
                 const lp16x8_t wf = __builtin_bit_cast(lp16x8_t, wr);
                 acc[j >> 1][j & 1][0] = MFMA_LP16(wf, a0, acc[j >> 1][j & 1][0]);
                 acc[j >> 1][j & 1][1] = MFMA_LP16(wf, a1, acc[j >> 1][j & 1][1]);
-                if (!(ablate & 2)) ring[slot] = SEQ_WFRAG((f + RING) % NF);      // the fragment RING places further down the stream
+                if (f < NC && t == 0) wcache[f * 64] = wr;       // (wave-private LDS copy for the later steps)
+                if (!(ablate & 2)) {
+                    const int fn = (f + RING) % NF;              // the fragment RING places further down the stream (folded: unrolled)
+                    if (fn < NC && f + RING >= NF) ring[slot] = wcache[fn * 64];      // next step's: cached in step 0
+                    else ring[slot] = SEQ_WFRAG(fn);
+                }
                 // pin the order {2 MFMAs, reload}: left alone, the scheduler sinks every reload down to its use one
                 // step later (to save registers) and the ring degenerates into load -> wait -> use
                 __builtin_amdgcn_sched_barrier(0);
@@ -953,6 +965,274 @@ __global__ __launch_bounds__(256) void linear_elu_mfma_kernel(long long n, int N
     }
 }
 
+// ---- Several small 2-D element moves in ONE launch: the operand preparation of an optimiser step (concatenated /
+// padded / transposed bf16 weight operands, the merged head weights, fp32 -> bf16 casts of the observations) is a
+// dozen strided copies of a few hundred KB each; as separate launches they cost ~5 us apiece.
+// dst[r, c] (rows dst_stride apart) = op(src) for r < rows, c < cols:
+//   op 0 copy        src[r, c]            (elem = 2 or 4 bytes, same type both sides)
+//   op 1 zero
+//   op 2 transpose   src[c, r]            (elem = 2 or 4 bytes)
+//   op 3 f32 -> bf16 src[r, c]
+//   op 4 add (f32)   src[r, c] + src2[r, c]
+//   op 5 masked      src[r, c] * (1 - mask[r * aux])   src f32, mask = src2 (uint8), dst f32 or bf16 by elem
+//   op 6 / 7         fragment-ordered LSTM weights for the persistent sequence kernels (see the kernel body)
+struct CopyJob {
+    const void* src;
+    const void* src2;
+    void* dst;
+    long long rows, cols, src_stride, dst_stride, aux;
+    int op, elem, first_block, vec;
+};
+#define VINE_COPY_MAX_JOBS 24
+struct CopyBatchArgs {
+    CopyJob job[VINE_COPY_MAX_JOBS];
+    int njobs;
+};
+// (the body of one 256-thread block of the launch: also run as a SIDE JOB by the workgroups of mlp3_elu_mfma_kernel, which
+// opens the optimiser step's forward pass -- the operands it builds are derived from the parameters alone and are first
+// read by the kernels behind it, so they ride in that launch instead of one of their own: vine_mlp3_elu_mfma_prep)
+__device__ __forceinline__ void copy_batched_body(const CopyBatchArgs& batch, int vblock, int vtid) {
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < batch.njobs; ++k)
+        if (vblock >= batch.job[k].first_block) j = k;
+    const CopyJob& J = batch.job[j];
+    const long long total = J.rows * J.cols;
+    const long long base = ((long long)(vblock - J.first_block) * 256 + vtid) * 4;
+    if (base >= total) return;
+    if (J.op >= 6) {
+        // fragment-ordered LSTM weight for the persistent kernels (layout: lstm_tile_weights_kernel).  dst is flat;
+        // element index -> (wave w, k-step kk, fragment j, lane, i) -> (unit, k).
+        //   op 6 (forward operand [w_ih | 0 | w_hh]): src = w_ih [4H, src_stride] with aux & 0xffff valid columns padded
+        //        with zeros to K1 = aux >> 16, src2 = w_hh [4H, dst_stride]; 8 fragments per k-step (j = 2 gate + tile)
+        //   op 7 (backward operand w_hh^T): src = w_hh [4H, src_stride], element (unit, k) = src[k][unit]; 2 fragments
+        const int H = SEQ_H;
+        const int cols1 = (int)(J.aux & 0xffff), K1 = (int)(J.aux >> 16);
+        const int nj = J.op == 6 ? 8 : 2, ksteps = J.op == 6 ? (K1 + H) / 32 : (4 * H) / 32;
+        const lp16_t* s1 = reinterpret_cast<const lp16_t*>(J.src);
+        const lp16_t* s2 = reinterpret_cast<const lp16_t*>(J.src2);
+        lp16_t* d = reinterpret_cast<lp16_t*>(J.dst);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const long long idx = base + q4;
+            if (idx >= total) break;
+            const int i = (int)(idx & 7);
+            long long c = idx >> 3;
+            const int lane = (int)(c & 63); c >>= 6;
+            const int jj = (int)(c % nj); c /= nj;
+            const int kk = (int)(c % ksteps);
+            const int wv = (int)(c / ksteps);
+            const int ut = J.op == 6 ? (jj & 1) : jj, g = J.op == 6 ? (jj >> 1) : 0;
+            const int unit = 32 * wv + 8 * ((lane & 15) >> 2) + 4 * ut + (lane & 3);
+            const int k = 32 * kk + 8 * (lane >> 4) + i;
+            lp16_t v;
+            if (J.op == 6) {
+                const long long row = (long long)g * H + unit;
+                v = k < K1 ? (k < cols1 ? s1[row * J.src_stride + k] : (lp16_t)0) : s2[row * J.dst_stride + (k - K1)];
+            } else {
+                v = s1[(long long)k * J.src_stride + unit];
+            }
+            d[idx] = v;
+        }
+        return;
+    }
+    // (row, column) of the first of this thread's 4 consecutive elements, then carried along: one division per thread
+    long long r = base / J.cols;
+    int c = (int)(base - r * J.cols);
+    const int cols = (int)J.cols;
+    if (J.vec) {
+        // aligned job (cols, strides multiples of 4, pointers aligned): the 4 elements are one 8- or 16-B access
+        const long long d = r * J.dst_stride + c, sidx = r * J.src_stride + c;
+        switch (J.op) {
+            case 0:
+                if (J.elem == 2)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(J.dst) + d) =
+                        *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src) + sidx);
+                else
+                    st4(reinterpret_cast<float*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
+                break;
+            case 1:
+                if (J.elem == 2) *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(J.dst) + d) = make_uint2(0u, 0u);
+                else st4(reinterpret_cast<float*>(J.dst) + d, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+                break;
+            case 3:
+                st4(reinterpret_cast<lp16_t*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
+                break;
+            case 4: {
+                const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
+                const float4 b = ld4(reinterpret_cast<const float*>(J.src2) + sidx);
+                st4(reinterpret_cast<float*>(J.dst) + d, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+                break;
+            }
+            default: {
+                const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
+                const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
+                const float4 v = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
+                if (J.elem == 2) st4(reinterpret_cast<lp16_t*>(J.dst) + d, v);
+                else st4(reinterpret_cast<float*>(J.dst) + d, v);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (base + q >= total) break;
+        const long long d = r * J.dst_stride + c;
+        const long long sidx = (J.op == 2) ? (long long)c * J.src_stride + r : r * J.src_stride + c;
+        switch (J.op) {
+            case 0:
+            case 2:
+                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = reinterpret_cast<const lp16_t*>(J.src)[sidx];
+                else reinterpret_cast<float*>(J.dst)[d] = reinterpret_cast<const float*>(J.src)[sidx];
+                break;
+            case 1:
+                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = 0;
+                else reinterpret_cast<float*>(J.dst)[d] = 0.0f;
+                break;
+            case 3:
+                reinterpret_cast<lp16_t*>(J.dst)[d] = f2lp(reinterpret_cast<const float*>(J.src)[sidx]);
+                break;
+            case 4:
+                reinterpret_cast<float*>(J.dst)[d] =
+                    reinterpret_cast<const float*>(J.src)[sidx] + reinterpret_cast<const float*>(J.src2)[sidx];
+                break;
+            default: {
+                const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
+                const float v = reinterpret_cast<const float*>(J.src)[sidx] * keep;
+                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = f2lp(v);
+                else reinterpret_cast<float*>(J.dst)[d] = v;
+            }
+        }
+        if (++c == cols) { c = 0; ++r; }
+    }
+}
+__global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) {
+    copy_batched_body(batch, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+// ---- The same moves in two phases, for a kernel that carries them as a side job (mlp3_elu_mfma_kernel): `copy_item_load`
+// issues the loads of one thread's 4 elements of one virtual block and keeps them in registers, `copy_item_store` writes
+// them -- the host kernel issues the loads of ALL its virtual blocks and its own first loads before anything is waited for,
+// so the side job costs it no memory round trip of its own (run one block after the other inside the launch it cost three
+// round trips: measured, no gain).  Covers the moves an optimiser step's parameter-derived operands need: the LSTM weight
+// tiles (op 6 / 7), 16-bit transposes (op 2), and the vector forms of copy / zero / add (`side_job_supported`).
+struct CopyItem {
+    int mode, n;                 // 0 nothing; 1: n 16-bit scalars at d[q]; 2: 8 B at d[0] (16-bit elements); 3: 16 B at d[0] (floats)
+    unsigned int v[4];
+    long long d[4];
+    void* dst;
+};
+__host__ __device__ inline bool side_job_supported(const CopyJob& J) {
+    if (J.rows * J.cols >= (1ll << 31) || J.cols >= (1ll << 31)) return false;
+    return J.op >= 6 || (J.op == 2 && J.elem == 2) || (J.vec && (J.op == 0 || J.op == 1 || J.op == 4));
+}
+__device__ __forceinline__ void copy_item_load(const CopyBatchArgs& batch, int vblock, int vtid, CopyItem& it) {
+    it.mode = 0; it.n = 0;
+    int j = 0;
+#pragma unroll 1
+    for (int k = 1; k < batch.njobs; ++k)
+        if (vblock >= batch.job[k].first_block) j = k;
+    const CopyJob& J = batch.job[j];
+    const long long total = J.rows * J.cols;
+    const long long base = ((long long)(vblock - J.first_block) * 256 + vtid) * 4;
+    if (base >= total) return;
+    it.dst = J.dst;
+    if (J.op >= 6) {
+        // (index arithmetic of copy_batched_body, decoded ONCE per thread and in 32 bits: the thread's 4 elements are
+        // i .. i + 3 of one (wave, k-step, fragment, lane) -- base is a multiple of 4 and a fragment row holds 8 -- and the
+        // four 64-bit divisions per ELEMENT of the generic body were most of a side job's time)
+        const int H = SEQ_H;
+        const int cols1 = (int)(J.aux & 0xffff), K1 = (int)(J.aux >> 16);
+        const unsigned ksteps = J.op == 6 ? (unsigned)(K1 + H) / 32u : (unsigned)(4 * H) / 32u;
+        const lp16_t* s1 = reinterpret_cast<const lp16_t*>(J.src);
+        const lp16_t* s2 = reinterpret_cast<const lp16_t*>(J.src2);
+        const unsigned ub = (unsigned)base;
+        const int i0 = (int)(ub & 7u);
+        unsigned c = ub >> 3;
+        const int lane = (int)(c & 63u); c >>= 6;
+        const int jj = J.op == 6 ? (int)(c & 7u) : (int)(c & 1u);
+        c >>= (J.op == 6 ? 3 : 1);
+        const unsigned wv = c / ksteps, kk = c - wv * ksteps;
+        const int ut = J.op == 6 ? (jj & 1) : jj, g = J.op == 6 ? (jj >> 1) : 0;
+        const int unit = 32 * (int)wv + 8 * ((lane & 15) >> 2) + 4 * ut + (lane & 3);
+        const int k0 = 32 * (int)kk + 8 * (lane >> 4) + i0;
+        const int n = (int)(total - base < 4 ? total - base : 4);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            it.v[q4] = 0;
+            it.d[q4] = base + q4;
+            if (q4 < n) {
+                const int k = k0 + q4;
+                lp16_t v;
+                if (J.op == 6) {
+                    const long long row = (long long)g * H + unit;
+                    v = k < K1 ? (k < cols1 ? s1[row * J.src_stride + k] : (lp16_t)0) : s2[row * J.dst_stride + (k - K1)];
+                } else {
+                    v = s1[(long long)k * J.src_stride + unit];
+                }
+                it.v[q4] = (unsigned int)v;
+            }
+        }
+        it.n = n;
+        it.mode = n == 4 ? 2 : 1;
+        if (n == 4) { it.v[0] |= it.v[1] << 16; it.v[1] = it.v[2] | (it.v[3] << 16); }
+        return;
+    }
+    const int cols = (int)J.cols;
+    long long r = (long long)((unsigned)base / (unsigned)cols);      // (32-bit: side jobs are below 2^31 elements)
+    int c = (int)((unsigned)base - (unsigned)r * (unsigned)cols);
+    if (J.op == 2) {             // 16-bit transpose: 4 scalars
+        const lp16_t* sp = reinterpret_cast<const lp16_t*>(J.src);
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            it.v[q] = 0; it.d[q] = 0;
+            if (base + q < total) {
+                it.d[q] = r * J.dst_stride + c;
+                it.v[q] = (unsigned int)sp[(long long)c * J.src_stride + r];
+                ++n;
+                if (++c == cols) { c = 0; ++r; }
+            }
+        }
+        it.n = n;
+        it.mode = 1;
+        return;
+    }
+    // vector forms: the 4 elements are one aligned 8- or 16-B access on both sides
+    const long long d = r * J.dst_stride + c, sidx = r * J.src_stride + c;
+    it.d[0] = d;
+    it.n = 4;
+    if (J.op == 1) {
+        it.v[0] = it.v[1] = it.v[2] = it.v[3] = 0u;
+        it.mode = J.elem == 2 ? 2 : 3;
+    } else if (J.op == 0 && J.elem == 2) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src) + sidx);
+        it.v[0] = w.x; it.v[1] = w.y;
+        it.mode = 2;
+    } else {
+        float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
+        if (J.op == 4) {
+            const float4 b = ld4(reinterpret_cast<const float*>(J.src2) + sidx);
+            a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        }
+        it.v[0] = __float_as_uint(a.x); it.v[1] = __float_as_uint(a.y); it.v[2] = __float_as_uint(a.z); it.v[3] = __float_as_uint(a.w);
+        it.mode = 3;
+    }
+}
+__device__ __forceinline__ void copy_item_store(const CopyItem& it) {
+    if (it.mode == 1) {
+        lp16_t* d = reinterpret_cast<lp16_t*>(it.dst);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < it.n) d[it.d[q]] = (lp16_t)it.v[q];
+    } else if (it.mode == 2) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(it.dst) + it.d[0]) = make_uint2(it.v[0], it.v[1]);
+    } else if (it.mode == 3) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<float*>(it.dst) + it.d[0]) = make_uint4(it.v[0], it.v[1], it.v[2], it.v[3]);
+    }
+}
+#define MLP3_SIDE_ITEMS 4        // virtual blocks per 256 threads of the host kernel (more: the host falls back to its own launch)
+
 // ---- The whole MLP of the default network in ONE kernel (mixed precision):
 //   x [n, 32] bf16 (the normalised observation block of the LSTM operand buffer + its zero pad; or, with `raw`, built
 //   here from the fp32 observations and the RunningMeanStd statistics and written there) -> Linear(32, C1) + ELU ->
@@ -981,7 +1261,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
                                                             const lp16_t* __restrict__ w3, long long ldw3,
                                                             const float* __restrict__ b3, float alpha,
                                                             lp16_t* __restrict__ act1, lp16_t* __restrict__ act2,
-                                                            lp16_t* out, long long out_stride) {
+                                                            lp16_t* out, long long out_stride, int ldw1,
+                                                            const CopyBatchArgs side, int side_blocks) {
     constexpr int P1 = 32 + 8, P2 = C1 + 8, P3 = C2 + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     lp16_t* w1l = reinterpret_cast<lp16_t*>(lds_raw);            // [C1][P1], rows in tile order
@@ -1018,10 +1299,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     constexpr int TH = 64 * NW, N1 = C1 * 4 / TH, N2 = C2 * (C1 / 8) / TH, N3 = C3 * (C2 / 8) / TH;
     static_assert(C1 * 4 % TH == 0 && C2 * (C1 / 8) % TH == 0 && C3 * (C2 / 8) % TH == 0, "whole chunks per thread");
     u32x4_t s1[N1], s2[N2], s3[N3];      // native vectors: arrays of the HIP uint4 struct stay in scratch memory here
+    // ---- side job (vine_mlp3_elu_mfma_prep): this workgroup's share of the optimiser step's operand preparation, the
+    // former copy_batched launch in front of this one (nothing this kernel reads; its loads and stores are in flight under
+    // the weight staging below)
+    CopyItem items[MLP3_SIDE_ITEMS];
 #pragma unroll
-    for (int it = 0; it < N1; ++it) {
-        const int c = tid + TH * it;
-        s1[it] = *reinterpret_cast<const u32x4_t*>(w1 + (c >> 2) * 32 + 8 * (c & 3));
+    for (int k = 0; k < MLP3_SIDE_ITEMS; ++k) {
+        const int vb = ((int)blockIdx.x + k * (int)gridDim.x) * (TH / 256) + (tid >> 8);
+        items[k].mode = 0;
+        if (vb < side_blocks) copy_item_load(side, vb, tid & 255, items[k]);
+    }
+    if (ldw1 == 32) {            // w1 zero-padded to 32 columns (w1p)
+#pragma unroll
+        for (int it = 0; it < N1; ++it) {
+            const int c = tid + TH * it;
+            s1[it] = *reinterpret_cast<const u32x4_t*>(w1 + (c >> 2) * 32 + 8 * (c & 3));
+        }
+    } else {                     // w1 as stored, [C1, ldw1] with ldw1 = F_in (even) valid columns: padded here
+#pragma unroll
+        for (int it = 0; it < N1; ++it) {
+            const int c = tid + TH * it, row = c >> 2, c0 = 8 * (c & 3);
+            unsigned int d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                d[e] = c0 + 2 * e < ldw1 ? *reinterpret_cast<const unsigned int*>(w1 + row * ldw1 + c0 + 2 * e) : 0u;
+            s1[it] = u32x4_t{d[0], d[1], d[2], d[3]};
+        }
     }
 #pragma unroll
     for (int it = 0; it < N2; ++it) {
@@ -1032,6 +1335,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     for (int it = 0; it < N3; ++it) {
         const int c = tid + TH * it, row = c / (C2 / 8), ck = c - row * (C2 / 8);
         s3[it] = *reinterpret_cast<const u32x4_t*>(w3 + (long long)row * ldw3 + 8 * ck);
+    }
+    if (side_blocks > 0) {
+#pragma unroll
+        for (int k = 0; k < MLP3_SIDE_ITEMS; ++k) copy_item_store(items[k]);
     }
 #pragma unroll
     for (int it = 0; it < N1; ++it) {
@@ -2854,145 +3161,6 @@ __global__ __launch_bounds__(256) void colsum_batched_kernel(ColsumBatch batch) 
     }
 }
 
-// ---- Several small 2-D element moves in ONE launch: the operand preparation of an optimiser step (concatenated /
-// padded / transposed bf16 weight operands, the merged head weights, fp32 -> bf16 casts of the observations) is a
-// dozen strided copies of a few hundred KB each; as separate launches they cost ~5 us apiece.
-// dst[r, c] (rows dst_stride apart) = op(src) for r < rows, c < cols:
-//   op 0 copy        src[r, c]            (elem = 2 or 4 bytes, same type both sides)
-//   op 1 zero
-//   op 2 transpose   src[c, r]            (elem = 2 or 4 bytes)
-//   op 3 f32 -> bf16 src[r, c]
-//   op 4 add (f32)   src[r, c] + src2[r, c]
-//   op 5 masked      src[r, c] * (1 - mask[r * aux])   src f32, mask = src2 (uint8), dst f32 or bf16 by elem
-//   op 6 / 7         fragment-ordered LSTM weights for the persistent sequence kernels (see the kernel body)
-struct CopyJob {
-    const void* src;
-    const void* src2;
-    void* dst;
-    long long rows, cols, src_stride, dst_stride, aux;
-    int op, elem, first_block, vec;
-};
-#define VINE_COPY_MAX_JOBS 24
-struct CopyBatchArgs {
-    CopyJob job[VINE_COPY_MAX_JOBS];
-    int njobs;
-};
-__global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) {
-    int j = 0;
-#pragma unroll 1
-    for (int k = 1; k < batch.njobs; ++k)
-        if ((int)blockIdx.x >= batch.job[k].first_block) j = k;
-    const CopyJob& J = batch.job[j];
-    const long long total = J.rows * J.cols;
-    const long long base = ((long long)(blockIdx.x - J.first_block) * 256 + threadIdx.x) * 4;
-    if (base >= total) return;
-    if (J.op >= 6) {
-        // fragment-ordered LSTM weight for the persistent kernels (layout: lstm_tile_weights_kernel).  dst is flat;
-        // element index -> (wave w, k-step kk, fragment j, lane, i) -> (unit, k).
-        //   op 6 (forward operand [w_ih | 0 | w_hh]): src = w_ih [4H, src_stride] with aux & 0xffff valid columns padded
-        //        with zeros to K1 = aux >> 16, src2 = w_hh [4H, dst_stride]; 8 fragments per k-step (j = 2 gate + tile)
-        //   op 7 (backward operand w_hh^T): src = w_hh [4H, src_stride], element (unit, k) = src[k][unit]; 2 fragments
-        const int H = SEQ_H;
-        const int cols1 = (int)(J.aux & 0xffff), K1 = (int)(J.aux >> 16);
-        const int nj = J.op == 6 ? 8 : 2, ksteps = J.op == 6 ? (K1 + H) / 32 : (4 * H) / 32;
-        const lp16_t* s1 = reinterpret_cast<const lp16_t*>(J.src);
-        const lp16_t* s2 = reinterpret_cast<const lp16_t*>(J.src2);
-        lp16_t* d = reinterpret_cast<lp16_t*>(J.dst);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const long long idx = base + q4;
-            if (idx >= total) break;
-            const int i = (int)(idx & 7);
-            long long c = idx >> 3;
-            const int lane = (int)(c & 63); c >>= 6;
-            const int jj = (int)(c % nj); c /= nj;
-            const int kk = (int)(c % ksteps);
-            const int wv = (int)(c / ksteps);
-            const int ut = J.op == 6 ? (jj & 1) : jj, g = J.op == 6 ? (jj >> 1) : 0;
-            const int unit = 32 * wv + 8 * ((lane & 15) >> 2) + 4 * ut + (lane & 3);
-            const int k = 32 * kk + 8 * (lane >> 4) + i;
-            lp16_t v;
-            if (J.op == 6) {
-                const long long row = (long long)g * H + unit;
-                v = k < K1 ? (k < cols1 ? s1[row * J.src_stride + k] : (lp16_t)0) : s2[row * J.dst_stride + (k - K1)];
-            } else {
-                v = s1[(long long)k * J.src_stride + unit];
-            }
-            d[idx] = v;
-        }
-        return;
-    }
-    // (row, column) of the first of this thread's 4 consecutive elements, then carried along: one division per thread
-    long long r = base / J.cols;
-    int c = (int)(base - r * J.cols);
-    const int cols = (int)J.cols;
-    if (J.vec) {
-        // aligned job (cols, strides multiples of 4, pointers aligned): the 4 elements are one 8- or 16-B access
-        const long long d = r * J.dst_stride + c, sidx = r * J.src_stride + c;
-        switch (J.op) {
-            case 0:
-                if (J.elem == 2)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(J.dst) + d) =
-                        *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src) + sidx);
-                else
-                    st4(reinterpret_cast<float*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
-                break;
-            case 1:
-                if (J.elem == 2) *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(J.dst) + d) = make_uint2(0u, 0u);
-                else st4(reinterpret_cast<float*>(J.dst) + d, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-                break;
-            case 3:
-                st4(reinterpret_cast<lp16_t*>(J.dst) + d, ld4(reinterpret_cast<const float*>(J.src) + sidx));
-                break;
-            case 4: {
-                const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
-                const float4 b = ld4(reinterpret_cast<const float*>(J.src2) + sidx);
-                st4(reinterpret_cast<float*>(J.dst) + d, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
-                break;
-            }
-            default: {
-                const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
-                const float4 a = ld4(reinterpret_cast<const float*>(J.src) + sidx);
-                const float4 v = make_float4(a.x * keep, a.y * keep, a.z * keep, a.w * keep);
-                if (J.elem == 2) st4(reinterpret_cast<lp16_t*>(J.dst) + d, v);
-                else st4(reinterpret_cast<float*>(J.dst) + d, v);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (base + q >= total) break;
-        const long long d = r * J.dst_stride + c;
-        const long long sidx = (J.op == 2) ? (long long)c * J.src_stride + r : r * J.src_stride + c;
-        switch (J.op) {
-            case 0:
-            case 2:
-                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = reinterpret_cast<const lp16_t*>(J.src)[sidx];
-                else reinterpret_cast<float*>(J.dst)[d] = reinterpret_cast<const float*>(J.src)[sidx];
-                break;
-            case 1:
-                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = 0;
-                else reinterpret_cast<float*>(J.dst)[d] = 0.0f;
-                break;
-            case 3:
-                reinterpret_cast<lp16_t*>(J.dst)[d] = f2lp(reinterpret_cast<const float*>(J.src)[sidx]);
-                break;
-            case 4:
-                reinterpret_cast<float*>(J.dst)[d] =
-                    reinterpret_cast<const float*>(J.src)[sidx] + reinterpret_cast<const float*>(J.src2)[sidx];
-                break;
-            default: {
-                const float keep = J.src2 ? 1.0f - (float)reinterpret_cast<const unsigned char*>(J.src2)[r * J.aux] : 1.0f;
-                const float v = reinterpret_cast<const float*>(J.src)[sidx] * keep;
-                if (J.elem == 2) reinterpret_cast<lp16_t*>(J.dst)[d] = f2lp(v);
-                else reinterpret_cast<float*>(J.dst)[d] = v;
-            }
-        }
-        if (++c == cols) { c = 0; ++r; }
-    }
-}
-
 #define PPO_MAX_A 8
 #define PPO_LOSS_ROW 32          // floats per workgroup row of the loss kernel's partial sums (22 used)
 // rows of `partial` -> stats[8], grad_logstd[A] and (added into) the two head-bias gradients
@@ -4629,15 +4797,29 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
     const dim3 grid((unsigned)(B / SEQ_ROWS)), block(512);
     hipStream_t s = (hipStream_t)stream;
     const int ablate = seq_ablate();
+    static const bool wcache_on = [] { const char* e = getenv("VINE_SEQ_FWD_WCACHE"); return !(e && e[0] == '0'); }();      // A/B knob
 #define VINE_SEQ_FWD_T(KS1, RING, CT, HT)                                                                               \
     do {                                                                                                                \
-        const size_t lds_ = 4 * SEQ_H * sizeof(float) + ((size_t)2 * SEQ_ROWS * (SEQ_H + 8) +                            \
-                                                         (size_t)T * SEQ_ROWS * (32 * KS1 + 8)) * sizeof(lp16_t);        \
-        if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT>), lds_))              \
-            return VINE_ERR_DEVICE;                                                                                     \
-        hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT>), grid, block, lds_, s, (int)T, (long long)B,        \
-                           (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride, (const uint4*)w_tiled,  \
-                           bias, c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate, c_last, h0);                  \
+        const size_t rows_ = 4 * SEQ_H * sizeof(float) + ((size_t)2 * SEQ_ROWS * (SEQ_H + 8) +                           \
+                                                          (size_t)T * SEQ_ROWS * (32 * KS1 + 8)) * sizeof(lp16_t);       \
+        /* the LDS weight cache (12 fragments per wave = 96 KB) when the operand rows leave room for it */               \
+        const bool cache_ = wcache_on && T > 1 && rows_ + (size_t)8 * 12 * 1024 <= 160 * 1024;                          \
+        const size_t lds_ = rows_ + (cache_ ? (size_t)8 * 12 * 1024 : 0);                                               \
+        if (cache_) {                                                                                                   \
+            if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT, 12>), lds_))      \
+                return VINE_ERR_DEVICE;                                                                                 \
+            hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT, 12>), grid, block, lds_, s, (int)T, (long long)B, \
+                               (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride,                     \
+                               (const uint4*)w_tiled, bias, c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate,   \
+                               c_last, h0);                                                                             \
+        } else {                                                                                                        \
+            if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT, 0>), lds_))       \
+                return VINE_ERR_DEVICE;                                                                                 \
+            hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT, 0>), grid, block, lds_, s, (int)T, (long long)B, \
+                               (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride,                     \
+                               (const uint4*)w_tiled, bias, c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate,   \
+                               c_last, h0);                                                                             \
+        }                                                                                                               \
     } while (0)
 #define VINE_SEQ_FWD(KS1, RING)                                                                                         \
     {                                                                                                                   \
@@ -4709,15 +4891,44 @@ int vine_linear_elu_mfma(int64_t n, int64_t N, int64_t K, const void* A, int64_t
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+static int copy_batch_pack(CopyBatchArgs& b, int& blocks, int32_t njobs, const int32_t* op, const int32_t* elem,
+                           const void* const* src, const void* const* src2, void* const* dst, const int64_t* rows,
+                           const int64_t* cols, const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux);
+
 int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
                        float eps, float clip, const void* w1p, const float* b1, int64_t C1, const void* w2, int64_t ldw2,
                        const float* b2, int64_t C2, const void* w3, int64_t ldw3, const float* b3, int64_t C3, float alpha,
                        void* act1, void* act2, void* out, int64_t out_stride, void* stream) {
+    return vine_mlp3_elu_mfma_prep(n, x, ldx, raw, F_in, mean, var, eps, clip, w1p, 32, b1, C1, w2, ldw2, b2, C2, w3, ldw3, b3, C3,
+                                   alpha, act1, act2, out, out_stride, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int vine_mlp3_elu_mfma_prep(int64_t n, void* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean,
+                            const double* var, float eps, float clip, const void* w1p, int64_t ldw1, const float* b1,
+                            int64_t C1, const void* w2, int64_t ldw2, const float* b2, int64_t C2, const void* w3, int64_t ldw3,
+                            const float* b3, int64_t C3, float alpha, void* act1, void* act2, void* out, int64_t out_stride,
+                            int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
+                            const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
+                            const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux, void* stream) {
     if (n <= 0 || !x || !w1p || !b1 || !w2 || !b2 || !w3 || !b3 || !out || (ldx & 7) || (ldw2 & 7) || (ldw3 & 7) ||
-        (out_stride & 3) || ldx < 32 || ldw2 < C1 || ldw3 < C2 || ((uintptr_t)x & 15) || ((uintptr_t)w1p & 15) ||
+        (out_stride & 3) || ldx < 32 || ldw2 < C1 || ldw3 < C2 || ((uintptr_t)x & 15) ||
+        ((uintptr_t)w1p & (ldw1 == 32 ? 15 : 3)) || ldw1 <= 0 || ldw1 > 32 || (ldw1 & 1) ||
         ((uintptr_t)w2 & 15) || ((uintptr_t)w3 & 15) || ((uintptr_t)out & 7) || (raw && (!mean || !var || F_in <= 0 || F_in > 32)))
         return VINE_ERR_INVALID_ARG;
     if (C1 != 256 || C2 != 128 || C3 != 64 || (n & 63)) return VINE_ERR_UNSUPPORTED;
+    CopyBatchArgs side;
+    side.njobs = 0;
+    int side_blocks = 0;
+    if (njobs > 0) {
+        const int rc = copy_batch_pack(side, side_blocks, njobs, op, elem, src, src2, dst, rows, cols, src_stride, dst_stride, aux);
+        if (rc != VINE_OK) return rc;
+        // the side job keeps every virtual block's elements in registers: only the moves it covers, and no more blocks
+        // than MLP3_SIDE_ITEMS per 256 threads of this launch (the caller then runs vine_copy_batched itself)
+        for (int k = 0; k < njobs; ++k)
+            if (!side_job_supported(side.job[k])) return VINE_ERR_UNSUPPORTED;
+        if ((long long)side_blocks > (long long)MLP3_SIDE_ITEMS * (n / 64)) return VINE_ERR_UNSUPPORTED;
+    }
     const int threads = (n % 128 == 0 && n >= 32768) ? 512 : 256;        // 8 waves per CU when one round covers the chip
     const size_t lds = ((size_t)256 * 40 + 128 * 264 + 64 * 136) * sizeof(lp16_t);
     if (!ensure_dyn_lds(threads == 512 ? reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 8>)
@@ -4727,7 +4938,8 @@ int vine_mlp3_elu_mfma(int64_t n, void* x, int64_t ldx, const float* raw, int64_
     hipLaunchKernelGGL((mlp3_elu_mfma_kernel<256, 128, 64, NW_>), dim3((unsigned)(n / (16 * NW_))), dim3(64 * NW_), lds,  \
                        (hipStream_t)stream, (long long)n, (lp16_t*)x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip, \
                        (const lp16_t*)w1p, b1, (const lp16_t*)w2, (long long)ldw2, b2, (const lp16_t*)w3, (long long)ldw3, \
-                       b3, alpha, (lp16_t*)act1, (lp16_t*)act2, (lp16_t*)out, (long long)out_stride)
+                       b3, alpha, (lp16_t*)act1, (lp16_t*)act2, (lp16_t*)out, (long long)out_stride, (int)ldw1, side,     \
+                       side_blocks)
     if (threads == 512) VINE_MLP3(8);
     else VINE_MLP3(4);
 #undef VINE_MLP3
@@ -5166,14 +5378,13 @@ int vine_column_sums_batched_fin(int32_t njobs, const int64_t* R, const int64_t*
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
-                      const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
-                      const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux, void* stream) {
+static int copy_batch_pack(CopyBatchArgs& b, int& blocks, int32_t njobs, const int32_t* op, const int32_t* elem,
+                           const void* const* src, const void* const* src2, void* const* dst, const int64_t* rows,
+                           const int64_t* cols, const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux) {
     if (njobs <= 0 || njobs > VINE_COPY_MAX_JOBS || !op || !elem || !src || !src2 || !dst || !rows || !cols ||
         !src_stride || !dst_stride || !aux)
         return VINE_ERR_INVALID_ARG;
-    CopyBatchArgs b;
-    int blocks = 0;
+    blocks = 0;
     for (int k = 0; k < njobs; ++k) {
         if (op[k] < 0 || op[k] > 7 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
             ((op[k] == 4 || op[k] == 6) && !src2[k]) || (elem[k] != 2 && elem[k] != 4) || (op[k] >= 6 && elem[k] != 2))
@@ -5188,6 +5399,16 @@ int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, con
         blocks += (int)((rows[k] * cols[k] + 1023) / 1024);
     }
     b.njobs = njobs;
+    return VINE_OK;
+}
+
+int vine_copy_batched(int32_t njobs, const int32_t* op, const int32_t* elem, const void* const* src,
+                      const void* const* src2, void* const* dst, const int64_t* rows, const int64_t* cols,
+                      const int64_t* src_stride, const int64_t* dst_stride, const int64_t* aux, void* stream) {
+    CopyBatchArgs b;
+    int blocks = 0;
+    const int rc = copy_batch_pack(b, blocks, njobs, op, elem, src, src2, dst, rows, cols, src_stride, dst_stride, aux);
+    if (rc != VINE_OK) return rc;
     hipLaunchKernelGGL(copy_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }

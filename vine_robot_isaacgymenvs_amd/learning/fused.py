@@ -189,6 +189,7 @@ ROLLOUT_F32_MFMA = _os.environ.get("VINE_ROLLOUT_F32_MFMA", "1") != "0"   # fp32
 # 2^-24 of a product, 0 = the native fp32 matrix-core kernel (vine_lstm_step_f32)
 ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "9"))
 MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
+MLP3_PREP = _os.environ.get("VINE_MLP3_PREP", "1") != "0"      # the step's operand preparation rides in that launch (A/B knob)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
 WGRAD_WIDE_BM = int(_os.environ.get("VINE_WGRAD_WIDE_BM", "128"))   # 128 | 64 rows of dy^T per workgroup tile (A/B knob)
@@ -686,6 +687,24 @@ class CopyBatch:
                           d2.data_ptr(), rows, cols, 0 if s2 is None else s2.stride(0), d2.stride(0), 0))
         return dst
 
+    def packed(self):
+        """(njobs, the ten ctypes arrays of vine_copy_batched) for a launch that carries these moves as a side job
+        (``vine_mlp3_elu_mfma_prep``), or None when they do not fit one launch; the batch stays filled (``keep`` holds the
+        tensors) until ``clear``."""
+        import ctypes as C
+        n = len(self.jobs)
+        if n == 0 or n > 24:
+            return None
+        cols = list(zip(*self.jobs))
+        i32 = lambda v: (C.c_int32 * n)(*v)
+        i64 = lambda v: (C.c_int64 * n)(*v)
+        ptr = lambda v: (C.c_void_p * n)(*v)
+        return (n, i32(cols[0]), i32(cols[1]), ptr(cols[2]), ptr(cols[3]), ptr(cols[4]), i64(cols[5]), i64(cols[6]),
+                i64(cols[7]), i64(cols[8]), i64(cols[9]))
+
+    def clear(self):
+        self.jobs, self.keep = [], []
+
     def flush(self, ref):
         import ctypes as C
         lib, st = _lib(), _stream(ref)
@@ -852,7 +871,15 @@ class _Trunk(torch.autograd.Function):
                     prep.add(CopyBatch.CAST_BF16, xfull[:, U:width], obs_c)
                 if wpad > width:
                     prep.add(CopyBatch.ZERO, xfull[:, width:])
-            if l1_mfma:
+            # the one-launch MLP opens the forward pass: the operands below are derived from the parameters alone and first
+            # read by the launches behind it, so they ride in ITS launch (vine_mlp3_elu_mfma_prep) instead of one of their
+            # own; it then pads W1 itself on the way into LDS.  Any operand built from the minibatch keeps the own launch
+            ride = (MLP3_PREP and mlp3 and raw is not None and Wop[0].is_contiguous() and Wop[0].shape[1] == F_in
+                    and F_in % 2 == 0)
+            if l1_mfma and ride:
+                x0 = xfull[:, U:width]
+                w1p = None
+            elif l1_mfma:
                 x0 = xfull[:, U:width]                        # strided view; also the operand of layer 1's weight gradient
                 w1p = torch.empty((Wop[0].shape[0], 32), device=dev, dtype=op)
                 prep.add(CopyBatch.COPY, w1p[:, :F_in], Wop[0])
@@ -898,13 +925,21 @@ class _Trunk(torch.autograd.Function):
             # the weight-gradient kernel (which both take them that way)
             h_once = (lp and h0_direct is not None and dones is not None and h_once_ok(T)
                       and _heads_loss_route(n, H, A_ + v_w.shape[0], loss_pack, head_bias_external, lib))
+            n_param_jobs = len(prep.jobs)
             lstm_buffers = _lstm_state_buffers(xfull, w_hh_op, h0, c0, dones, T, True, prep=prep,
                                                copy_c0=c0_direct is None, c_dtype=lp_dtype() if lp else torch.float32,
                                                mask_h0=h0_direct is None, h_once=h_once)
-            prep.flush(obs_n)
+            side = prep.packed() if (ride and len(prep.jobs) == n_param_jobs) else None
+            if ride and side is None:      # (minibatch-derived moves, or too many for one launch: the own launch after all)
+                w1p = torch.empty((Wop[0].shape[0], 32), device=dev, dtype=op)
+                prep.add(CopyBatch.COPY, w1p[:, :F_in], Wop[0])
+                prep.add(CopyBatch.ZERO, w1p[:, F_in:])
+            if side is None:
+                prep.flush(obs_n)
         else:
             lstm_buffers = None
             c0_direct = None
+            side = None
             lp, c_last, h0_direct, h_once = False, None, None, False
             x0 = obs_n.contiguous()
             torch.cat([mu_w, v_w], 0, out=w_heads)
@@ -915,15 +950,32 @@ class _Trunk(torch.autograd.Function):
         if mlp3:
             # the whole MLP in one launch, activations carried in registers (vine_mlp3_elu_mfma)
             acts = [torch.empty((n, 256), device=dev, dtype=op), torch.empty((n, 128), device=dev, dtype=op)]
-            _check(lib.vine_mlp3_elu_mfma(n, xfull.data_ptr() + 2 * U, xfull.stride(0),
-                                          raw.data_ptr() if raw is not None else None, F_in,
-                                          norm[0].data_ptr() if raw is not None else None,
-                                          norm[1].data_ptr() if raw is not None else None,
-                                          float(norm[2]) if raw is not None else 0.0, 5.0,
-                                          w1p.data_ptr(), mlp[0][1].data_ptr(), 256, Wop[1].data_ptr(), Wop[1].stride(0),
-                                          mlp[1][1].data_ptr(), 128, Wop[2].data_ptr(), Wop[2].stride(0),
-                                          mlp[2][1].data_ptr(), 64, 1.0, acts[0].data_ptr(), acts[1].data_ptr(),
-                                          xfull.data_ptr(), xfull.stride(0), st), "vine_mlp3_elu_mfma")
+            if side is not None:
+                rc = lib.vine_mlp3_elu_mfma_prep(n, xfull.data_ptr() + 2 * U, xfull.stride(0), raw.data_ptr(), F_in,
+                                                 norm[0].data_ptr(), norm[1].data_ptr(), float(norm[2]), 5.0,
+                                                 Wop[0].data_ptr(), F_in, mlp[0][1].data_ptr(), 256, Wop[1].data_ptr(),
+                                                 Wop[1].stride(0), mlp[1][1].data_ptr(), 128, Wop[2].data_ptr(),
+                                                 Wop[2].stride(0), mlp[2][1].data_ptr(), 64, 1.0, acts[0].data_ptr(),
+                                                 acts[1].data_ptr(), xfull.data_ptr(), xfull.stride(0), *side, st)
+                if rc == -2:       # VINE_ERR_UNSUPPORTED (a move the side job does not cover, or too small a launch to carry
+                    side = None    # them): nothing has run -- the moves get their own launch after all
+                    w1p = torch.empty((Wop[0].shape[0], 32), device=dev, dtype=op)
+                    prep.add(CopyBatch.COPY, w1p[:, :F_in], Wop[0])
+                    prep.add(CopyBatch.ZERO, w1p[:, F_in:])
+                    prep.flush(obs_n)
+                else:
+                    _check(rc, "vine_mlp3_elu_mfma_prep")
+                    prep.clear()
+            if side is None:
+                _check(lib.vine_mlp3_elu_mfma(n, xfull.data_ptr() + 2 * U, xfull.stride(0),
+                                              raw.data_ptr() if raw is not None else None, F_in,
+                                              norm[0].data_ptr() if raw is not None else None,
+                                              norm[1].data_ptr() if raw is not None else None,
+                                              float(norm[2]) if raw is not None else 0.0, 5.0,
+                                              w1p.data_ptr(), mlp[0][1].data_ptr(), 256, Wop[1].data_ptr(), Wop[1].stride(0),
+                                              mlp[1][1].data_ptr(), 128, Wop[2].data_ptr(), Wop[2].stride(0),
+                                              mlp[2][1].data_ptr(), 64, 1.0, acts[0].data_ptr(), acts[1].data_ptr(),
+                                              xfull.data_ptr(), xfull.stride(0), st), "vine_mlp3_elu_mfma")
         for i, (W, b) in enumerate(mlp if not mlp3 else ()):
             last = i == n_mlp - 1
             if mixed:
