@@ -865,6 +865,42 @@ def test_copy_batch_ops():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("width,wpad", [(92, 96), (64, 64), (82, 96)])
+def test_copy_scatter_forms_write_the_same_bytes(width, wpad, monkeypatch):
+    """Round 4: the LSTM weight tiles and the 16-bit transposes in their coalesced-load / scattered-store forms (copy ops
+    8 - 10) against the gather forms (ops 6, 7, 2): identical destination bytes, zero pad columns included.  width 82 is not
+    a multiple of 4: the batch falls back to the gather forms by itself."""
+    dev = torch.device("cuda:0")
+    lp = fused.lp_dtype()
+    torch.manual_seed(width)
+    H = 256
+    w_ih = torch.randn(4 * H, width, device=dev).to(lp)
+    w_hh = torch.randn(4 * H, H, device=dev).to(lp)
+    w2 = torch.randn(128, 256, device=dev).to(lp)
+    w3 = torch.randn(64, 128, device=dev).to(lp)
+    outs = []
+    for scatter in (False, True):
+        monkeypatch.setattr(fused, "COPY_SCATTER", scatter)
+        fwd = torch.full((4 * H * (wpad + H),), 7.0, device=dev, dtype=lp)
+        bwd = torch.full((4 * H * H,), 7.0, device=dev, dtype=lp)
+        t2, t3 = torch.empty(256, 128, device=dev, dtype=lp), torch.empty(128, 64, device=dev, dtype=lp)
+        tih = torch.empty(64, 4 * H, device=dev, dtype=lp)
+        cb = fused.CopyBatch()
+        cb.add_lstm_tiles(w_ih, w_hh, wpad, fwd, bwd)
+        cb.add(fused.CopyBatch.TRANSPOSE, t2, w2)
+        cb.add(fused.CopyBatch.TRANSPOSE, t3, w3)
+        cb.add(fused.CopyBatch.TRANSPOSE, tih, w_ih[:, :64])
+        ops = [j[0] for j in cb.jobs]
+        assert (8 in ops and 9 in ops) == (scatter and width % 4 == 0) and (10 in ops) == scatter
+        cb.flush(fwd)
+        torch.cuda.synchronize()
+        outs.append((fwd, bwd, t2, t3, tih))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert torch.equal(outs[1][2], w2.t()) and torch.equal(outs[1][4], w_ih[:, :64].t())
+
+
+@pytest.mark.gpu
 def test_gae_kernel_matches_reference_loop():
     """vine_gae against the Python loop (rl_games discount_values, next-nonterminal form)."""
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import discount_values
@@ -1901,7 +1937,8 @@ def test_operand_preparation_riding_in_the_mlp_launch_is_bit_identical(obs_type,
 
     def run(ride):
         monkeypatch.setattr(fused, "MLP3_PREP", ride)
-        cfg = load_config(overrides=["num_envs=512", "minibatch_size=2048", "OBSERVATION_TYPE=%s" % obs_type])
+        # (a 16384-sample minibatch: the MLP launch must be large enough to carry the ~720 blocks of moves)
+        cfg = load_config(overrides=["num_envs=2048", "minibatch_size=16384", "OBSERVATION_TYPE=%s" % obs_type])
         cfg["task"]["seed"] = 42
         env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
                                                       graphics_device_id=0, headless=True)
@@ -1912,10 +1949,12 @@ def test_operand_preparation_riding_in_the_mlp_launch_is_bit_identical(obs_type,
         assert agent.fused_mixed
         agent.init_tensors()
         agent.obs = agent.env_reset()["obs"]
+        rides0 = fused.RIDES[0]
         for _ in range(4):          # (iterations 3 and 4 replay the captured update)
             agent.train_epoch()
         torch.cuda.synchronize()
         assert agent.graph_status["update"].startswith("graph")
+        assert (fused.RIDES[0] > rides0) == ride          # the side job really ran (or really did not)
         out = agent.optimizer.flat_params.clone()
         env.close()
         return out

@@ -299,6 +299,48 @@ def test_default_mode_observation_scales(HipEnv):
     hip.close()
 
 
+@pytest.mark.parametrize("obstacle", ["shelf", "pipe", "shelf+pipe"])
+def test_full_size_obstacle_properties(HipEnv, obstacle):
+    """BASELINE configs[4]'s per-GPU share at FULL size (16384 envs, vine_randomize, ACTION_DELAY 1, shelf and / or pipe),
+    300 random-policy steps, through size-independent properties: two runs from the same seed are
+    bit-identical (no atomics, no order dependence at any occupancy), everything stays finite and bounded, the obstacle is
+    really in play (shelf: a good share of env steps report a strip contact; pipe: the trajectories differ from the
+    obstacle-free run of the same seed for a good share of the envs), and resets keep happening."""
+    import torch
+    n, T = 16384, 300
+    def run(shelf, pipe):
+        cfg = base_cfg(n, 0, True, action_delay=1, seed=123)
+        cfg.set_flag(abi.FLAG_CREATE_SHELF, shelf)
+        cfg.set_flag(abi.FLAG_CREATE_PIPE, pipe)
+        hip = HipEnv(cfg)
+        g = torch.Generator(device=hip.dev).manual_seed(9)
+        touched = torch.zeros((), device=hip.dev, dtype=torch.float64)
+        resets = torch.zeros((), device=hip.dev, dtype=torch.float64)
+        for _ in range(T):
+            hip.step_t(torch.rand((n, 2), device=hip.dev, generator=g) * 2 - 1, sync=False)
+            touched += (hip.state_t[abi.VF_CONTACT_MEAN] > 0).double().sum()
+            resets += (hip.reset_t != 0).double().sum()
+        torch.cuda.synchronize()
+        out = (hip.state_t.clone(), hip.obs_t.clone(), hip.rew_t.clone(), float(touched) / (n * T), float(resets))
+        hip.close()
+        return out
+    shelf, pipe = "shelf" in obstacle, "pipe" in obstacle
+    a, b = run(shelf, pipe), run(shelf, pipe)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])      # deterministic
+    st, obs, rew, contact_frac, resets = a
+    assert torch.isfinite(st).all() and torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert float(st[abi.VF_QD0 + 1:abi.VF_QD0 + 6].abs().max()) < 200 and float(obs.abs().max()) <= 5.0
+    assert resets > n                                         # episodes end and restart
+    if shelf:
+        assert contact_frac > 0.01, contact_frac              # the strip is touched
+    else:
+        assert contact_frac == 0.0                            # no contact report without a shelf (V5:1246-1248)
+    if pipe and not shelf:
+        free = run(False, False)
+        moved = ((st[abi.VF_Q0:abi.VF_Q0 + 6] - free[0][abi.VF_Q0:abi.VF_Q0 + 6]).abs().max(0).values > 1e-3).double().mean()
+        assert float(moved) > 0.05, float(moved)              # the tube's walls deflect a good share of the vines
+
+
 @pytest.mark.parametrize("obs_type", [abi.OBS_POS_ONLY, abi.OBS_POS_AND_VEL, abi.OBS_POS_AND_FD_VEL,
                                       abi.OBS_POS_AND_PREV_POS])
 def test_unscaled_observation_types_match_oracle(HipEnv, obs_type):

@@ -988,6 +988,7 @@ struct CopyBatchArgs {
     CopyJob job[VINE_COPY_MAX_JOBS];
     int njobs;
 };
+__device__ void copy_scatter_forms(const CopyBatchArgs& batch, int vblock, int vtid);
 // (the body of one 256-thread block of the launch: also run as a SIDE JOB by the workgroups of mlp3_elu_mfma_kernel, which
 // opens the optimiser step's forward pass -- the operands it builds are derived from the parameters alone and are first
 // read by the kernels behind it, so they ride in that launch instead of one of their own: vine_mlp3_elu_mfma_prep)
@@ -1000,6 +1001,7 @@ __device__ __forceinline__ void copy_batched_body(const CopyBatchArgs& batch, in
     const long long total = J.rows * J.cols;
     const long long base = ((long long)(vblock - J.first_block) * 256 + vtid) * 4;
     if (base >= total) return;
+    if (J.op >= 8) { copy_scatter_forms(batch, vblock, vtid); return; }      // (coalesced-load forms: copy_item_load)
     if (J.op >= 6) {
         // fragment-ordered LSTM weight for the persistent kernels (layout: lstm_tile_weights_kernel).  dst is flat;
         // element index -> (wave w, k-step kk, fragment j, lane, i) -> (unit, k).
@@ -1117,14 +1119,17 @@ __global__ __launch_bounds__(256) void copy_batched_kernel(CopyBatchArgs batch) 
 // round trips: measured, no gain).  Covers the moves an optimiser step's parameter-derived operands need: the LSTM weight
 // tiles (op 6 / 7), 16-bit transposes (op 2), and the vector forms of copy / zero / add (`side_job_supported`).
 struct CopyItem {
-    int mode, n;                 // 0 nothing; 1: n 16-bit scalars at d[q]; 2: 8 B at d[0] (16-bit elements); 3: 16 B at d[0] (floats)
+    int mode, n;                 // 0 nothing; 1: n 16-bit scalars at d[q]; 2: 8 B at d[0] (16-bit elements); 3: 16 B at d[0] (floats);
+                                 // 4: n 32-bit scalars at d[q]
     unsigned int v[4];
     long long d[4];
     void* dst;
 };
 __host__ __device__ inline bool side_job_supported(const CopyJob& J) {
     if (J.rows * J.cols >= (1ll << 31) || J.cols >= (1ll << 31)) return false;
-    return J.op >= 6 || (J.op == 2 && J.elem == 2) || (J.vec && (J.op == 0 || J.op == 1 || J.op == 4));
+    // (ops 8-10 exist in the two-phase form only)
+    return J.op >= 6 || (J.op == 2 && J.elem == 2) || (J.vec && (J.op == 0 || J.op == 1 || J.op == 4)) ||
+           (J.op == 0 && J.elem == 4);
 }
 __device__ __forceinline__ void copy_item_load(const CopyBatchArgs& batch, int vblock, int vtid, CopyItem& it) {
     it.mode = 0; it.n = 0;
@@ -1137,6 +1142,53 @@ __device__ __forceinline__ void copy_item_load(const CopyBatchArgs& batch, int v
     const long long base = ((long long)(vblock - J.first_block) * 256 + vtid) * 4;
     if (base >= total) return;
     it.dst = J.dst;
+    if (J.op >= 8) {
+        // ---- scatter forms (round 4): the thread's 4 elements are consecutive in the SOURCE (one coalesced 8-B load; the
+        // gather forms read 2 bytes per 64-B line: 47 MB of L2 -> CU traffic per optimiser step for 1.5 MB of operands)
+        // and go to their places in the destination: 8 contiguous bytes (op 8) or four 16-bit stores (ops 9, 10), which
+        // nothing waits for.
+        const unsigned ub = (unsigned)base;
+        const int H = SEQ_H;
+        uint2 w = make_uint2(0u, 0u);
+        if (J.op == 8) {         // virtual source [w_ih | 0 | w_hh]: rows 4H, K = K1 + H columns -> forward tile order
+            const int cols1 = (int)(J.aux & 0xffff), K1 = (int)(J.aux >> 16);
+            const unsigned K = (unsigned)(K1 + H), ksteps = K / 32u;
+            const unsigned row = ub / K;
+            const int k = (int)(ub - row * K);
+            if (k < cols1) w = *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src) + (long long)row * J.src_stride + k);
+            else if (k >= K1) w = *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src2) + (long long)row * J.dst_stride + (k - K1));
+            const int g = (int)(row >> 8), unit = (int)(row & 255u);
+            const int wv = unit >> 5, u5 = unit & 31, lane15 = 4 * (u5 >> 3) + (u5 & 3), ut = (u5 >> 2) & 1;
+            const int kk = k >> 5, k5 = k & 31, lane = (k5 >> 3) * 16 + lane15, i = k5 & 7, jj = 2 * g + ut;
+            it.d[0] = ((((long long)wv * ksteps + kk) * 8 + jj) * 64 + lane) * 8 + i;
+            it.v[0] = w.x; it.v[1] = w.y;
+            it.n = 4;
+            it.mode = 2;
+            return;
+        }
+        unsigned sr, sc;          // source row / first source column of the 4 elements
+        long long dbase, dstep;  // destination index of element 0 and the step to the next one
+        if (J.op == 9) {         // source w_hh [4H (k), H (unit)] -> backward tile order (w_hh^T fragments)
+            sr = ub >> 8; sc = ub & 255u;
+            const int k = (int)sr, unit = (int)sc;
+            const int wv = unit >> 5, u5 = unit & 31, lane15 = 4 * (u5 >> 3) + (u5 & 3), ut = (u5 >> 2) & 1;
+            const int kk = k >> 5, k5 = k & 31, lane = (k5 >> 3) * 16 + lane15, i = k5 & 7;
+            dbase = ((((long long)wv * (4 * H / 32) + kk) * 2 + ut) * 64 + lane) * 8 + i;
+            dstep = 8;           // unit + 1 = the next lane of the fragment
+        } else {                 // op 10: dst [rows, cols] = src^T, src [cols, rows]: 4 consecutive source columns
+            const unsigned R = (unsigned)J.rows;
+            sr = ub / R; sc = ub - sr * R;
+            dbase = (long long)sc * J.dst_stride + sr;
+            dstep = J.dst_stride;
+        }
+        w = *reinterpret_cast<const uint2*>(reinterpret_cast<const lp16_t*>(J.src) + (long long)sr * J.src_stride + sc);
+        it.v[0] = w.x & 0xffffu; it.v[1] = w.x >> 16; it.v[2] = w.y & 0xffffu; it.v[3] = w.y >> 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) it.d[q] = dbase + q * dstep;
+        it.n = 4;
+        it.mode = 1;
+        return;
+    }
     if (J.op >= 6) {
         // (index arithmetic of copy_batched_body, decoded ONCE per thread and in 32 bits: the thread's 4 elements are
         // i .. i + 3 of one (wave, k-step, fragment, lane) -- base is a multiple of 4 and a fragment row holds 8 -- and the
@@ -1198,6 +1250,23 @@ __device__ __forceinline__ void copy_item_load(const CopyBatchArgs& batch, int v
         it.mode = 1;
         return;
     }
+    if (!J.vec) {                // op 0, fp32, unaligned or short rows (the head biases): up to 4 scalars
+        const float* sp = reinterpret_cast<const float*>(J.src);
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            it.v[q] = 0; it.d[q] = 0;
+            if (base + q < total) {
+                it.d[q] = r * J.dst_stride + c;
+                it.v[q] = __float_as_uint(sp[r * J.src_stride + c]);
+                ++n;
+                if (++c == cols) { c = 0; ++r; }
+            }
+        }
+        it.n = n;
+        it.mode = 4;
+        return;
+    }
     // vector forms: the 4 elements are one aligned 8- or 16-B access on both sides
     const long long d = r * J.dst_stride + c, sidx = r * J.src_stride + c;
     it.d[0] = d;
@@ -1229,7 +1298,17 @@ __device__ __forceinline__ void copy_item_store(const CopyItem& it) {
         *reinterpret_cast<uint2*>(reinterpret_cast<lp16_t*>(it.dst) + it.d[0]) = make_uint2(it.v[0], it.v[1]);
     } else if (it.mode == 3) {
         *reinterpret_cast<uint4*>(reinterpret_cast<float*>(it.dst) + it.d[0]) = make_uint4(it.v[0], it.v[1], it.v[2], it.v[3]);
+    } else if (it.mode == 4) {
+        unsigned int* d = reinterpret_cast<unsigned int*>(it.dst);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < it.n) d[it.d[q]] = it.v[q];
     }
+}
+__device__ void copy_scatter_forms(const CopyBatchArgs& batch, int vblock, int vtid) {
+    CopyItem it;
+    copy_item_load(batch, vblock, vtid, it);
+    copy_item_store(it);
 }
 #define MLP3_SIDE_ITEMS 4        // virtual blocks per 256 threads of the host kernel (more: the host falls back to its own launch)
 
@@ -5386,9 +5465,24 @@ static int copy_batch_pack(CopyBatchArgs& b, int& blocks, int32_t njobs, const i
         return VINE_ERR_INVALID_ARG;
     blocks = 0;
     for (int k = 0; k < njobs; ++k) {
-        if (op[k] < 0 || op[k] > 7 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
-            ((op[k] == 4 || op[k] == 6) && !src2[k]) || (elem[k] != 2 && elem[k] != 4) || (op[k] >= 6 && elem[k] != 2))
+        if (op[k] < 0 || op[k] > 10 || rows[k] <= 0 || cols[k] <= 0 || !dst[k] || (op[k] != 1 && !src[k]) ||
+            ((op[k] == 4 || op[k] == 6 || op[k] == 8) && !src2[k]) || (elem[k] != 2 && elem[k] != 4) || (op[k] >= 6 && elem[k] != 2))
             return VINE_ERR_INVALID_ARG;
+        if (op[k] >= 8) {
+            // scatter forms: 4 consecutive source elements = one aligned 8-B load, all index arithmetic in 32 bits
+            const long long tot = rows[k] * cols[k];
+            bool ok = tot < (1ll << 31) && !(tot & 3) && !(src_stride[k] & 3) && !((uintptr_t)src[k] & 7) && !((uintptr_t)dst[k] & 7);
+            if (op[k] == 8) {
+                const long long cols1 = aux[k] & 0xffff, K1 = aux[k] >> 16;
+                ok = ok && !(cols1 & 3) && !(K1 & 3) && !((K1 + SEQ_H) & 31) && !(dst_stride[k] & 3) && !((uintptr_t)src2[k] & 7) &&
+                     tot == 4ll * SEQ_H * (K1 + SEQ_H);
+            } else if (op[k] == 9) {
+                ok = ok && tot == 4ll * SEQ_H * SEQ_H;
+            } else {
+                ok = ok && !(rows[k] & 3);
+            }
+            if (!ok) return VINE_ERR_UNSUPPORTED;
+        }
         // vector path: every group of 4 consecutive elements is one aligned 8-/16-B access on both sides
         const int src_elem = op[k] == 0 ? elem[k] : 4;
         const bool vec = op[k] != 2 && op[k] < 6 && !(cols[k] & 3) && !(dst_stride[k] & 3) && !((uintptr_t)dst[k] & (4 * elem[k] - 1)) &&

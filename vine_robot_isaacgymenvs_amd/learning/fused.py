@@ -190,6 +190,8 @@ ROLLOUT_F32_MFMA = _os.environ.get("VINE_ROLLOUT_F32_MFMA", "1") != "0"   # fp32
 ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "9"))
 MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
 MLP3_PREP = _os.environ.get("VINE_MLP3_PREP", "1") != "0"      # the step's operand preparation rides in that launch (A/B knob)
+COPY_SCATTER = _os.environ.get("VINE_COPY_SCATTER", "1") != "0"  # coalesced-load / scattered-store forms of tiles and transposes
+RIDES = [0]      # forward passes whose operand preparation rode in the MLP launch (tests look at it)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
 WGRAD_WIDE_BM = int(_os.environ.get("VINE_WGRAD_WIDE_BM", "128"))   # 128 | 64 rows of dy^T per workgroup tile (A/B knob)
@@ -637,6 +639,9 @@ class CopyBatch:
     """Collects small 2-D element moves (copy / zero / transpose / fp32->bf16 cast / fp32 add) and runs them in ONE
     launch (``vine_copy_batched``): the operand preparation of an optimiser step is a dozen such moves."""
     COPY, ZERO, TRANSPOSE, CAST_BF16, ADD, MASKED, LSTM_TILE_FWD, LSTM_TILE_BWD = 0, 1, 2, 3, 4, 5, 6, 7
+    # scatter forms of the last three (round 4): coalesced 8-B loads of 4 consecutive SOURCE elements, stores to their
+    # places (the gather forms read 2 bytes per cache line); same bytes in the destination
+    LSTM_TILE_FWD_S, LSTM_TILE_BWD_S, TRANSPOSE_S = 8, 9, 10
 
     def add_lstm_tiles(self, w_ih, w_hh, wpad, fwd_dst, bwd_dst):
         """Fragment-ordered bf16 copies of the LSTM weights for the persistent sequence kernels (csrc/ppo_kernels.hip,
@@ -645,16 +650,18 @@ class CopyBatch:
         H4, width = w_ih.shape
         H = w_hh.shape[1]
         assert w_ih.dtype == w_hh.dtype == lp_dtype() and w_ih.stride(1) == 1 and w_hh.stride(1) == 1 and H == 256
+        scatter = (COPY_SCATTER and width % 4 == 0 and wpad % 4 == 0 and w_ih.stride(0) % 4 == 0 and w_hh.stride(0) % 4 == 0
+                   and w_ih.data_ptr() % 8 == 0 and w_hh.data_ptr() % 8 == 0)
         if fwd_dst is not None:
             assert fwd_dst.numel() == H4 * (wpad + H) and fwd_dst.is_contiguous() and width <= wpad < 65536
             self.keep.append((fwd_dst, w_ih, w_hh))
-            self.jobs.append((self.LSTM_TILE_FWD, 2, w_ih.data_ptr(), w_hh.data_ptr(), fwd_dst.data_ptr(), 1, fwd_dst.numel(),
-                              w_ih.stride(0), w_hh.stride(0), width | (wpad << 16)))
+            self.jobs.append((self.LSTM_TILE_FWD_S if scatter else self.LSTM_TILE_FWD, 2, w_ih.data_ptr(), w_hh.data_ptr(),
+                              fwd_dst.data_ptr(), 1, fwd_dst.numel(), w_ih.stride(0), w_hh.stride(0), width | (wpad << 16)))
         if bwd_dst is not None:
             assert bwd_dst.numel() == H4 * H and bwd_dst.is_contiguous()
             self.keep.append((bwd_dst, w_hh))
-            self.jobs.append((self.LSTM_TILE_BWD, 2, w_hh.data_ptr(), 0, bwd_dst.data_ptr(), 1, bwd_dst.numel(),
-                              w_hh.stride(0), 0, 0))
+            self.jobs.append((self.LSTM_TILE_BWD_S if scatter else self.LSTM_TILE_BWD, 2, w_hh.data_ptr(), 0,
+                              bwd_dst.data_ptr(), 1, bwd_dst.numel(), w_hh.stride(0), 0, 0))
 
     def __init__(self):
         self.jobs, self.keep = [], []
@@ -676,6 +683,9 @@ class CopyBatch:
         rows, cols = d2.shape
         if op == self.TRANSPOSE:
             assert tuple(s2.shape) == (cols, rows) and s2.dtype == d2.dtype
+            if (COPY_SCATTER and d2.element_size() == 2 and rows % 4 == 0 and s2.stride(0) % 4 == 0 and s2.data_ptr() % 8 == 0
+                    and d2.data_ptr() % 8 == 0 and rows * cols < 2 ** 31):
+                op = self.TRANSPOSE_S
         elif op in (self.COPY, self.ADD):
             assert tuple(s2.shape) == (rows, cols) and s2.dtype == d2.dtype
         elif op == self.CAST_BF16:
@@ -966,6 +976,7 @@ class _Trunk(torch.autograd.Function):
                 else:
                     _check(rc, "vine_mlp3_elu_mfma_prep")
                     prep.clear()
+                    RIDES[0] += 1
             if side is None:
                 _check(lib.vine_mlp3_elu_mfma(n, xfull.data_ptr() + 2 * U, xfull.stride(0),
                                               raw.data_ptr() if raw is not None else None, F_in,
