@@ -2735,10 +2735,22 @@ __global__ __launch_bounds__(64) void ds_finalize_kernel(int blocks, long long n
                                                          const double* __restrict__ rvar,
                                                          const double* __restrict__ rcount, double* __restrict__ stats_out,
                                                          float eps, int normalize_value, float* __restrict__ scal) {
+    // fold the partial rows: lane l sums rows l, l + 64, ... (independent loads: the serial form -- six lanes walking the
+    // rows one dependent load at a time -- took 11.5 us for 64 rows), then the 64 lane sums in a fixed order
+    __shared__ double lane_sum[64][6];
     __shared__ double tot[6];
+    {
+        double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int b = threadIdx.x; b < blocks; b += 64)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) a[j] += partial[(long long)b * 6 + j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) lane_sum[threadIdx.x][j] = a[j];
+    }
+    __syncthreads();
     if (threadIdx.x < 6) {
         double s = 0.0;
-        for (int b = 0; b < blocks; ++b) s += partial[(long long)b * 6 + threadIdx.x];
+        for (int l = 0; l < 64; ++l) s += lane_sum[l][threadIdx.x];
         tot[threadIdx.x] = s;
     }
     __syncthreads();
@@ -2766,17 +2778,20 @@ __global__ __launch_bounds__(64) void ds_finalize_kernel(int blocks, long long n
 }
 
 #define DS_LDS_WORDS 8192
+#define DS_ENVS 16
 __global__ __launch_bounds__(256) void ds_assemble_kernel(int T, long long N, const float* __restrict__ scal,
                                                           int normalize_value, int normalize_advantage,
                                                           float* __restrict__ ds_values, float* __restrict__ ds_returns,
                                                           float* __restrict__ ds_adv, const DsJobs J) {
+    // DS_ENVS envs per workgroup (16: 1024 workgroups at 16384 envs = four per CU; with 64 envs and one workgroup per CU
+    // the kernel took 57 us for its 2 x 33 MB: too few loads in flight)
     __shared__ unsigned int lds[DS_LDS_WORDS];
-    const long long e0 = (long long)blockIdx.x * 64;
+    const long long e0 = (long long)blockIdx.x * DS_ENVS;
     const int tid = threadIdx.x;
     {
         const float m1 = scal[0], sd1 = scal[1], m2 = scal[2], sd2 = scal[3], am = scal[4], as_ = scal[5] + 1e-8f;
         const long long base = e0 * T;
-        for (int i = tid; i < 64 * T; i += 256) {
+        for (int i = tid; i < DS_ENVS * T; i += 256) {
             if (normalize_value) {
                 float y = (ds_values[base + i] - m1) / sd1;
                 ds_values[base + i] = fminf(fmaxf(y, -5.0f), 5.0f);
@@ -2792,17 +2807,19 @@ __global__ __launch_bounds__(256) void ds_assemble_kernel(int T, long long N, co
         if (J.elem[j] == 4) {
             const unsigned int* src = reinterpret_cast<const unsigned int*>(J.src[j]);
             unsigned int* dst = reinterpret_cast<unsigned int*>(J.dst[j]);
-            int EB = 64;
+            int EB = DS_ENVS;
             while (EB > 1 && EB * T * W > DS_LDS_WORDS) EB >>= 1;
             const int seg = EB * W, tw = T * W, total = T * seg;
-            for (int sub = 0; sub < 64; sub += EB) {
+            for (int sub = 0; sub < DS_ENVS; sub += EB) {
                 const long long es = e0 + sub;
                 __syncthreads();                          // (the previous sub-block's / job's readers are done)
+#pragma unroll 4
                 for (int i = tid; i < total; i += 256) {
                     const int t = i / seg, r = i - t * seg;
                     lds[i] = src[((long long)t * N + es) * W + r];
                 }
                 __syncthreads();
+#pragma unroll 4
                 for (int o = tid; o < total; o += 256) {
                     const int el = o / tw, rem = o - el * tw, t = rem / W, c = rem - t * W;
                     dst[es * tw + o] = lds[t * seg + el * W + c];
@@ -2812,18 +2829,19 @@ __global__ __launch_bounds__(256) void ds_assemble_kernel(int T, long long N, co
             const unsigned int* src = reinterpret_cast<const unsigned int*>(J.src[j]);
             unsigned int* dst = reinterpret_cast<unsigned int*>(J.dst[j]);
             const unsigned char* lb = reinterpret_cast<const unsigned char*>(lds);
+            constexpr int WPT = DS_ENVS / 4;                // words per step: DS_ENVS flags
             __syncthreads();
-            for (int i = tid; i < 16 * T; i += 256) {
-                const int t = i >> 4, r = i & 15;
+            for (int i = tid; i < WPT * T; i += 256) {
+                const int t = i / WPT, r = i - t * WPT;
                 lds[i] = src[((long long)t * N + e0) / 4 + r];
             }
             __syncthreads();
-            for (int o = tid; o < 16 * T; o += 256) {
+            for (int o = tid; o < WPT * T; o += 256) {
                 unsigned int wv = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int b = 4 * o + k, el = b / T, t = b - el * T;
-                    wv |= (unsigned int)lb[t * 64 + el] << (8 * k);
+                    wv |= (unsigned int)lb[t * DS_ENVS + el] << (8 * k);
                 }
                 dst[(e0 * T) / 4 + o] = wv;
             }
@@ -5371,7 +5389,7 @@ int vine_dataset_assemble(int32_t T, int64_t N, const float* rewards, const floa
             if ((long long)T * job_width[j] > DS_LDS_WORDS || ((uintptr_t)job_src[j] & 3) || ((uintptr_t)job_dst[j] & 3))
                 return VINE_ERR_UNSUPPORTED;
         } else if (job_elem_bytes[j] == 1) {
-            if (job_width[j] != 1 || 16 * T > DS_LDS_WORDS || ((uintptr_t)job_src[j] & 3) || ((uintptr_t)job_dst[j] & 3))
+            if (job_width[j] != 1 || (DS_ENVS / 4) * T > DS_LDS_WORDS || ((uintptr_t)job_src[j] & 3) || ((uintptr_t)job_dst[j] & 3))
                 return VINE_ERR_UNSUPPORTED;
         } else {
             return VINE_ERR_UNSUPPORTED;
@@ -5388,7 +5406,7 @@ int vine_dataset_assemble(int32_t T, int64_t N, const float* rewards, const floa
     // value_mean_std in prepare_dataset, not in the rollout: a rollout alone must leave the module as it was)
     hipLaunchKernelGGL(ds_finalize_kernel, dim3(1), dim3(64), 0, s, blocks, (long long)N * T, scratch, vms_mean, vms_var,
                        vms_count, vms_pending, vms_eps, (int)normalize_value, scal);
-    hipLaunchKernelGGL(ds_assemble_kernel, dim3((unsigned)(N / 64)), dim3(256), 0, s, (int)T, (long long)N, scal,
+    hipLaunchKernelGGL(ds_assemble_kernel, dim3((unsigned)(N / DS_ENVS)), dim3(256), 0, s, (int)T, (long long)N, scal,
                        (int)normalize_value, (int)normalize_advantage, ds_values, ds_returns, ds_advantages, J);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }

@@ -428,6 +428,7 @@ class A2CAgent:
         # the three bf16 pieces of every recurrent weight, in the split step kernel's fragment order
         f["wt_split"] = (torch.empty(3 * 4 * H * (XW + H), device=dev, dtype=torch.bfloat16) if f["f32_split"] else None)
         f["w1p_f32"] = torch.zeros((net.units[0], 32), device=dev) if f["f32_mfma"] else None     # layer 1, zero-padded
+        f["bias_buf"] = torch.empty(4 * H, device=dev) if f["f32_mfma"] else None                  # b_ih + b_hh of a rollout
         self._fast = f
 
     def _fast_op_is_fp32(self):
@@ -439,9 +440,36 @@ class A2CAgent:
         f, net = self._fast, self.model.a2c_network
         r = net.rnn.rnn
         src = self.optimizer.shadow_of if self.rollout_lp16 else (lambda p: p)
+        f["mlp"] = [(src(m.weight), m.bias) for m in net.actor_mlp if isinstance(m, torch.nn.Linear)]
+        if f["f32_mfma"] and f["w1p"] is None and f.get("bias_buf") is not None:
+            # fp32 rollout (the default): every operand copy of the rollout's start in ONE launch (round 4; they were nine:
+            # profiles/r04/iteration_boundary_trace.txt) -- [w_ih | 0 | w_hh], the padded layer-1 weight, b_ih + b_hh, h into
+            # the operand buffer, and the step-0 LSTM-state snapshots / slot-0 observation and done flags of the rollout
+            cb = fused.CopyBatch()
+            cb.add(cb.COPY, f["wcat"][:, :r.weight_ih_l0.shape[1]], r.weight_ih_l0)
+            cb.add(cb.COPY, f["wcat"][:, f["XW"]:], r.weight_hh_l0)
+            w1 = f["mlp"][0][0]
+            cb.add(cb.COPY, f["w1p_f32"][:, :w1.shape[1]], w1)
+            cb.add(cb.ADD, f["bias_buf"], r.bias_ih_l0, r.bias_hh_l0)
+            f["bias"] = f["bias_buf"]
+            f["cur"] = 0
+            cb.add(cb.COPY, f["xh2"][0][:, f["XW"]:], self.rnn_states[0][0])
+            for extra in getattr(self, "_rollout_start_copies", ()):
+                cb.add(cb.COPY, *extra)
+            self._rollout_start_copies = ()
+            cb.flush(f["wcat"])
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            if f["f32_split"]:
+                fused._check(fused._lib().vine_lstm_tile_weights_split(
+                    f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_split"].data_ptr(), st),
+                    "vine_lstm_tile_weights_split")
+            else:
+                fused._check(fused._lib().vine_lstm_tile_weights_f32(
+                    f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_f32"].data_ptr(), st),
+                    "vine_lstm_tile_weights_f32")
+            return
         f["wcat"][:, :r.weight_ih_l0.shape[1]].copy_(src(r.weight_ih_l0))
         f["wcat"][:, f["XW"]:].copy_(src(r.weight_hh_l0))
-        f["mlp"] = [(src(m.weight), m.bias) for m in net.actor_mlp if isinstance(m, torch.nn.Linear)]
         # layer 1 through the matrix-core kernel too: operand = the obs block of xh plus the zero columns behind it
         if f["w1p"] is not None:                      # pad columns stay zero (allocated outside any capture)
             w1 = f["mlp"][0][0]
@@ -601,7 +629,17 @@ class A2CAgent:
             return y.contiguous(), states
 
         fast = getattr(self, "_fast", None) is not None
+        batched = fast and self._fast["f32_mfma"] and self._fast["w1p"] is None and os.environ.get("VINE_ROLLOUT_COPYBATCH", "1") != "0"
         if fast:
+            if batched:
+                # the step-0 snapshots of the LSTM state ride in _infer_begin's one launch
+                self._rollout_start_copies = tuple((mb_s[0, :, 0], s_[0]) for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states))
+                self._slot0_batched = (buf["obses"].dtype == torch.float32 and obs.dtype == torch.float32 and obs.is_contiguous()
+                                       and obs.dim() == 2 and buf["dones"].dtype == torch.uint8 and self.dones.dtype == torch.uint8
+                                       and N % 16 == 0)
+                if self._slot0_batched:      # slot 0 of the observation / done-flag buffers too (flags moved as 4-byte words)
+                    self._rollout_start_copies += ((buf["obses"][0], obs),
+                                                   (buf["dones"][0].view(torch.float32), self.dones.view(torch.float32)))
             self._infer_begin()
         # the env writes the next observation, and the post-step kernel the next done flags, straight into the rollout
         # buffers (30 small copy nodes fewer per iteration) when the task offers step_into on this device
@@ -613,15 +651,22 @@ class A2CAgent:
         h_op_stride = self._fast["XW"] + H if fast else 0
         h_op_bf16 = int(fast and self._fast["op"] != torch.float32)
         for n in range(self.horizon_length):
-            if n % self.seq_len == 0:
-                for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
-                    mb_s[:, :, n // self.seq_len].copy_(s_)
+            if n % self.seq_len == 0 and not (batched and n == 0):
+                if batched:          # both states in one launch
+                    cb = fused.CopyBatch()
+                    for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
+                        cb.add(cb.COPY, mb_s[0, :, n // self.seq_len], s_[0])
+                    cb.flush(self.rnn_states[0])
+                else:
+                    for s_, mb_s in zip(self.rnn_states, self.mb_rnn_states):
+                        mb_s[:, :, n // self.seq_len].copy_(s_)
             if fast:
                 y = self._infer(obs)
             else:
                 y, states = trunk(obs)
                 self.rnn_states = [states[0].contiguous(), states[1].contiguous()]
-            if not direct or n == 0:      # (direct: the env and the post-step kernel wrote slot n themselves, one step ago)
+            if (not direct or n == 0) and not (batched and n == 0 and self._slot0_batched):
+                # (direct: the env and the post-step kernel wrote slot n themselves, one step ago)
                 buf["obses"][n].copy_(obs)
                 buf["dones"][n].copy_(self.dones)
             head(y, n, buf["values"][n], buf["mus"][n], buf["sigmas"][n], buf["actions"][n], buf["neglogpacs"][n])
@@ -1158,12 +1203,25 @@ class A2CAgent:
         self._flush_pending_adam()                   # the last step's Adam (per-step graphs defer it into the next graph)
         if ev:
             ev[2].record(torch.cuda.current_stream(self.device))
-            torch.cuda.synchronize(self.device)
+            # Round 4: the host does not wait for THIS iteration here -- it waits for the previous one (whose events it then
+            # reads), so that the next iteration's rollout graph is already queued when this update ends.  Waiting here
+            # left the device idle for ~125 us per iteration (the sync, the host's bookkeeping, the next graph launch:
+            # profiles/r04/iteration_boundary_trace.txt).  The host never runs more than one iteration ahead; the first
+            # iteration, and `sync_each_iteration: True` / VINE_SYNC_EACH_ITER=1, wait as before.
+            prev = getattr(self, "_ev_prev", None)
+            if prev is None or self.config.get("sync_each_iteration", False) or os.environ.get("VINE_SYNC_EACH_ITER") == "1":
+                torch.cuda.synchronize(self.device)
+                timed = ev
+            else:
+                prev[2].synchronize()
+                timed = prev
+            self._ev_prev = ev
         upd_range.__exit__()
         update_time = time.time() - t_upd
         if ev:
-            # (the split of the iteration as the device saw it; the sum is the host's wall time of the iteration)
-            gp, gu = ev[0].elapsed_time(ev[1]) * 1e-3, ev[1].elapsed_time(ev[2]) * 1e-3
+            # (the split of an iteration as the device saw it -- the previous one's when the wait is deferred: the same in
+            # steady state -- applied to the host's wall time of this call)
+            gp, gu = timed[0].elapsed_time(timed[1]) * 1e-3, timed[1].elapsed_time(timed[2]) * 1e-3
             total = play_time + update_time
             play_time = total * gp / max(gp + gu, 1e-12)
             update_time = total - play_time

@@ -154,8 +154,9 @@ def ppo_iteration_rate(env, cfg, steps=5, warmup=3, amp=None, use_graphs=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     frames = agent.horizon_length * agent.num_actors
-    return {"env_steps_per_sec": frames * steps / dt, "ms_per_iteration": dt / steps * 1e3, "rollout_ms": play / steps * 1e3,
-            "update_ms": upd / steps * 1e3, "minibatch": agent.minibatch_size,
+    k = dt / max(play + upd, 1e-12)
+    return {"env_steps_per_sec": frames * steps / dt, "ms_per_iteration": dt / steps * 1e3, "rollout_ms": play * k / steps * 1e3,
+            "update_ms": upd * k / steps * 1e3, "minibatch": agent.minibatch_size,
             "optimizer_steps_per_iter": agent.mini_epochs_num * agent.num_minibatches,
             "hipgraphs_active": dict(agent.graph_status), "iterations_timed": steps}
 
@@ -205,6 +206,11 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     barrier()
     elapsed = time.perf_counter() - t0
     env._native_step = orig
+    # (train_epoch waits for the PREVIOUS iteration since round 4: the last iteration of the timed region ends inside the
+    # barrier above, so the per-call times sum to a little less than `elapsed` -- the split is rescaled to it)
+    if play + upd > 0:
+        k = elapsed / (play + upd)
+        play, upd = play * k, upd * k
 
     # env step alone (resident random actions), same process, right after the timed region
     g = torch.Generator(device=agent.device).manual_seed(1)
@@ -279,8 +285,9 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
             u2 += u
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t2
+        k2 = e2 / max(p2 + u2, 1e-12)
         return {"update_precision": describe(agent2), "value": frames * steps / e2, "unit": "env-steps/s",
-                "ppo_iters_per_sec": steps / e2, "rollout_ms": p2 / steps * 1e3, "update_ms": u2 / steps * 1e3}
+                "ppo_iters_per_sec": steps / e2, "rollout_ms": p2 * k2 / steps * 1e3, "update_ms": u2 * k2 / steps * 1e3}
 
     other = lp16_rollout = native_f32_rollout = split6_rollout = None
     if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
