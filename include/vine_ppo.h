@@ -98,6 +98,45 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_o
                                 void* dgates, float* bias_partial, int32_t c_bf16, const float* c_last, int32_t g_bf16,
                                 void* stream);
 
+/* vine_lstm_seq_backward_mfma and vine_mlp3_bwd_elu_mfma as two PHASES of one launch (round 4): workgroup b owns sequences
+ * [32 b, 32 b + 32) in both -- rows [128 b, 128 b + 128) of the sequence-major sample order at T = 4 -- and the MLP phase
+ * reads the gate gradients its own LSTM phase wrote; only a workgroup barrier separates them.  T == 4, H == 256, 16-bit
+ * saved cell states (c_T in c_last) and hidden-state gradient; arguments as in the two functions (K0 = 4H, C3 / C2 / C1 =
+ * 64 / 128 / 256, dgates rows 4H apart). */
+int vine_lstm_seq_backward_mlp3_mfma(int64_t B, int64_t T, int64_t H, const void* g_out, const void* w_hh_tiled,
+                                     const void* gates, const void* c_all, const float* c0, const uint8_t* done,
+                                     void* dgates, float* bias_partial, const float* c_last, const void* wt0, int64_t ldw0,
+                                     const void* wt1, int64_t ldw1, const void* wt2, int64_t ldw2, const void* a3,
+                                     int64_t a3_stride, const void* a2, const void* a1, float alpha, void* gz3, void* gz2,
+                                     void* gz1, float* part3, float* part2, float* part1, void* stream);
+
+/* The row-local chain of one optimiser step as four PHASES of one launch (round 4): vine_lstm_seq_forward_mfma ("h once"
+ * form) -> vine_ln_heads_loss (its loss rows left for vine_column_sums_batched_fin: VineLossFinalize) ->
+ * vine_lstm_seq_backward_mfma -> vine_mlp3_bwd_elu_mfma.  Workgroup b owns sequences [32 b, 32 b + 32) = samples
+ * [128 b, 128 b + 128) in all four and every phase reads from its predecessor only what the same workgroup wrote, so a
+ * workgroup barrier separates them.  The update's default configuration only: T == 4, H == 256, x block 96 wide
+ * (rows ldx >= 96 apart), NH == 3 heads, 16-bit hidden states / saved cell states / gate activations / dh / dG, B % 32 == 0; field
+ * meanings as the arguments of the four functions (x: the LSTM operand rows written by vine_mlp3_elu_mfma*; h_out
+ * [B, T + 1, 256]; d_out [B T, 256]; dgates [B T, 1024]; a3 = the MLP block of x, rows a3_stride apart). */
+typedef struct VineTrunkArgs {
+    int64_t B, T;
+    const void* x; int64_t ldx; const void* w_tiled; const float* bias; const float* c0; const float* h0; const uint8_t* done;
+    void* h_out; void* c_all; void* gates; float* c_last;
+    const float* ln_gamma; const float* ln_beta; float ln_eps; int32_t clip_value;
+    const float* w_heads; const float* b_heads; const float* logstd; const float* actions; const float* old_neglogp;
+    const float* advantages; const float* old_values; const float* returns; const float* old_mu; const float* old_sigma;
+    float e_clip, critic_coef, entropy_coef, bounds_coef, soft_bound, alpha;
+    float* heads; void* d_out; float* ln_partial; float* loss_partial; float* stats; float* grad_logstd; float* grad_mu_bias;
+    float* grad_value_bias; float* kl_out; float* logstd_grad_accum; float* mu_store; float* sigma_store;
+    const float* loss_scale; float* found_inf;
+    const void* w_hh_tiled; void* dgates; float* bias_partial;
+    const void* wt0; int64_t ldw0; const void* wt1; int64_t ldw1; const void* wt2; int64_t ldw2; const void* a3; int64_t a3_stride;
+    const void* a2; const void* a1;
+    void* gz3; void* gz2; void* gz1; float* part3; float* part2; float* part1;
+} VineTrunkArgs;
+int vine_trunk_phases(const VineTrunkArgs* args, void* stream);
+int64_t vine_trunk_args_size(void);      /* sizeof(VineTrunkArgs): checked against the host mirror */
+
 /* Linear + bias + ELU on the matrix cores: out = elu(A W^T + bias) with A [n, K] bf16 (rows lda apart), W [N, K] bf16,
  * out [n, N] bf16 (rows out_stride apart, e.g. a column block of the LSTM operand buffer); the fp32 pre-activation is
  * never stored.  Needs n % 64 == 0, N % 64 == 0, K in {32, 64, 128, 256}; otherwise VINE_ERR_UNSUPPORTED (callers fall

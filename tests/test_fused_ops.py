@@ -1964,6 +1964,58 @@ def test_operand_preparation_riding_in_the_mlp_launch_is_bit_identical(obs_type,
 
 
 @pytest.mark.gpu
+def test_backward_phases_in_one_launch_are_bit_identical(monkeypatch):
+    """Round 4: the persistent LSTM backward and the one-launch MLP backward as two phases of ONE launch
+    (vine_lstm_seq_backward_mlp3_mfma: workgroup b owns sequences [32 b, 32 b + 32) = rows [128 b, 128 b + 128) in both)
+    against the two launches: same arithmetic on the same rows, so training is bit-identical (32768-sample minibatches: the
+    fused form needs the 128-row workgroups of the MLP phase)."""
+    if fused.lp_dtype() != torch.float16:
+        pytest.skip("bf16 build")
+    from vine_robot_isaacgymenvs_amd import load_config, native
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    lib = native.load()
+    calls = {"n": 0}
+    real = lib.vine_lstm_seq_backward_mlp3_mfma
+
+    def run(phases, trunk=False):
+        monkeypatch.setattr(fused, "BWD_PHASES", phases)
+        monkeypatch.setattr(fused, "TRUNK_PHASES", trunk)
+        cfg = load_config(overrides=["num_envs=2048", "minibatch_size=32768"])
+        cfg["task"]["seed"] = 42
+        env = isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+        params = cfg["train"]["params"]
+        params["config"].update(write_files=False, print_stats=False, use_graphs=False, mixed_precision=True)
+        torch.manual_seed(0)
+        agent = A2CAgent("t", params, vec_env=env)
+        agent.init_tensors()
+        agent.obs = agent.env_reset()["obs"]
+        for _ in range(2):
+            agent.train_epoch()
+        torch.cuda.synchronize()
+        out = agent.optimizer.flat_params.clone()
+        env.close()
+        return out
+
+    def counting(*a):
+        calls["n"] += 1
+        return real(*a)
+    counting.argtypes, counting.restype = real.argtypes, real.restype
+    monkeypatch.setattr(lib, "vine_lstm_seq_backward_mlp3_mfma", counting)
+    one = run(True)
+    assert calls["n"] == 2 * 4        # 2 iterations x 4 mini-epochs x 1 minibatch: the fused launch really ran
+    two = run(False)
+    assert calls["n"] == 8
+    assert torch.isfinite(one).all() and torch.equal(one, two)
+    # ... and the four-phase launch (LSTM forward + LayerNorm / heads / loss + LSTM backward + MLP backward: vine_trunk_phases)
+    p0 = fused.PHASE_LAUNCHES[0]
+    four = run(True, trunk=True)
+    assert fused.PHASE_LAUNCHES[0] - p0 == 8 and calls["n"] == 8
+    assert torch.equal(four, two)
+
+
+@pytest.mark.gpu
 def test_truncate_grads_with_the_fp16_fused_update():
     """``truncate_grads: True`` on the default mixed-precision update: the loss-scaled gradient block is
     clipped against its UNSCALED norm.  A threshold nothing reaches leaves training bit-identical to ``truncate_grads:

@@ -203,6 +203,10 @@ PPO_PROTOTYPES = {
     "vine_weight_grad_mfma": (C.c_int, [_I64, _I64, _I64, _I64, _VP, _I64, _VP, _I64, _I64, _VP, _VP]),
     "vine_mlp3_elu_mfma": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _I64, _VP, _I64, _VP,
                                      _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _VP, _VP, _I64, _VP]),
+    "vine_lstm_seq_backward_mlp3_mfma": (C.c_int, [_I64, _I64, _I64] + [_VP] * 9 + [_VP, _I64, _VP, _I64, _VP, _I64, _VP, _I64, _VP,
+                                                   _VP, C.c_float] + [_VP] * 6 + [_VP]),
+    "vine_trunk_phases": (C.c_int, [_VP, _VP]),
+    "vine_trunk_args_size": (C.c_int64, []),
     "vine_mlp3_elu_mfma_prep": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _I64, _VP, _I64, _VP,
                                           _I64, _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, _VP, _VP, _I64,
                                           C.c_int32] + [_VP] * 10 + [_VP]),
@@ -254,6 +258,23 @@ PPO_PROTOTYPES = {
                                      C.c_float, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP]),
     "vine_adaptive_lr": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
 }
+
+
+class TrunkArgs(C.Structure):
+    """VineTrunkArgs of include/vine_ppo.h (vine_trunk_phases)."""
+    _fields_ = ([("B", C.c_int64), ("T", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int64)] +
+                [(k, C.c_void_p) for k in ("w_tiled", "bias", "c0", "h0", "done", "h_out", "c_all", "gates", "c_last", "ln_gamma",
+                                           "ln_beta")] +
+                [("ln_eps", C.c_float), ("clip_value", C.c_int32)] +
+                [(k, C.c_void_p) for k in ("w_heads", "b_heads", "logstd", "actions", "old_neglogp", "advantages", "old_values",
+                                           "returns", "old_mu", "old_sigma")] +
+                [(k, C.c_float) for k in ("e_clip", "critic_coef", "entropy_coef", "bounds_coef", "soft_bound", "alpha")] +
+                [(k, C.c_void_p) for k in ("heads", "d_out", "ln_partial", "loss_partial", "stats", "grad_logstd", "grad_mu_bias",
+                                           "grad_value_bias", "kl_out", "logstd_grad_accum", "mu_store", "sigma_store",
+                                           "loss_scale", "found_inf", "w_hh_tiled", "dgates", "bias_partial")] +
+                [("wt0", C.c_void_p), ("ldw0", C.c_int64), ("wt1", C.c_void_p), ("ldw1", C.c_int64), ("wt2", C.c_void_p),
+                 ("ldw2", C.c_int64), ("a3", C.c_void_p), ("a3_stride", C.c_int64), ("a2", C.c_void_p), ("a1", C.c_void_p)] +
+                [(k, C.c_void_p) for k in ("gz3", "gz2", "gz1", "part3", "part2", "part1")])
 
 
 def declare_ppo(lib):

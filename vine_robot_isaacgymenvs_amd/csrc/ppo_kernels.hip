@@ -454,6 +454,9 @@ __device__ __forceinline__ float dpp_i2f(int x);
 __device__ __forceinline__ int dpp_f2i(float x);
 constexpr int SEQ_ROWS = 32;           // sequences per workgroup
 constexpr int SEQ_H = 256;             // hidden units (8 waves x 32)
+#ifndef SEQ_BWD_RING
+#define SEQ_BWD_RING 8      // weight ring of the backward kernel: 16 does not fit the register file without spills (76.7 us against 65.3 us per 4-step sequence)
+#endif
 
 __device__ __forceinline__ void seq_barrier() {
     // LDS hand-over between the waves of the workgroup: only the LDS counter has to drain -- the weight ring and
@@ -516,7 +519,7 @@ __device__ unsigned long long seq_t[256 * 8 * 16];      // (debug build: 4 stamp
 // by the L2 -> CU weight stream (720 KB per step at 51 of the CU's 64 B/clk), and with T <= 4 the operand rows leave 96 KB
 // of the CU's 160 KB of LDS unused: 12 of a wave's 88 fragments, 13.6 % of the stream of three of the four steps.
 template <int KS1, int RING, typename CT, typename HT, int NC>      // K = 32 (KS1 + 8): the x block (KS1 k-steps, zero-padded) then the 256 hidden units
-__global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
+__device__ __forceinline__ void lstm_seq_fwd_body(
     int T, long long B, const lp16_t* __restrict__ x, long long ldx, lp16_t* hp, long long hp_stride,
     const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
     const unsigned char* __restrict__ done, HT* __restrict__ h_out, CT* __restrict__ c_all,
@@ -717,6 +720,15 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
 #endif
     }
 }
+template <int KS1, int RING, typename CT, typename HT, int NC>
+__global__ __launch_bounds__(512) void lstm_seq_fwd_kernel(
+    int T, long long B, const lp16_t* __restrict__ x, long long ldx, lp16_t* hp, long long hp_stride,
+    const uint4* __restrict__ Wt, const float* __restrict__ bias, const float* __restrict__ c0,
+    const unsigned char* __restrict__ done, HT* __restrict__ h_out, CT* __restrict__ c_all,
+    lp16_t* __restrict__ gates, int ablate, float* __restrict__ c_last, const float* __restrict__ h0) {
+    lstm_seq_fwd_body<KS1, RING, CT, HT, NC>(T, B, x, ldx, hp, hp_stride, Wt, bias, c0, done, h_out, c_all, gates, ablate, c_last,
+                                             h0);
+}
 
 // ---- backward twin: all T steps of lstm_bwd_mfma_kernel for 32 sequences in one launch.  dG_{t+1} [32, 4H] stays in
 // LDS (bf16, the operand of the recurrent product dG_{t+1} W_hh), dc_t and c_t stay in registers, the bias-gradient
@@ -739,7 +751,7 @@ __device__ __forceinline__ void unpack_lp16x8(uint4 r, float (&v)[8]) {
 // CT: storage type of the saved cell states (see the forward kernel; with lp16_t, c_T comes from `c_last` in fp32);
 // GT: type of the incoming gradient w.r.t. the hidden states (float, or lp16_t as written by ln_heads_loss_kernel).
 template <int RING, typename CT, typename GT>
-__global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
+__device__ __forceinline__ void lstm_seq_bwd_body(
     int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const lp16_t* __restrict__ gates,
     const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
     lp16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
@@ -900,6 +912,13 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
             }
         }
     }
+}
+template <int RING, typename CT, typename GT>
+__global__ __launch_bounds__(512) void lstm_seq_bwd_kernel(
+    int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const lp16_t* __restrict__ gates,
+    const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
+    lp16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
+    lstm_seq_bwd_body<RING, CT, GT>(T, B, g_out, Wt, gates, c_all, c0, done, dG, bias_partial, ablate, c_last);
 }
 #undef SEQ_WFRAG
 
@@ -1681,7 +1700,7 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
 // weights are requested at the start and parked in LDS after stage 1.  Column sums: DPP row sums over the 16 rows of
 // a wave (dpp_row_sum16), then across the waves through LDS -- fixed order, no atomics.
 template <int C3, int C2, int C1, int NCH, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_bwd_elu_mfma_kernel(
+__device__ __forceinline__ void mlp3_bwd_elu_mfma_body(
     long long n, const lp16_t* __restrict__ G, long long ldg, const lp16_t* __restrict__ Wt0, long long ldw0,
     const lp16_t* __restrict__ Wt1, long long ldw1, const lp16_t* __restrict__ Wt2, long long ldw2,
     const lp16_t* __restrict__ a3, long long a3_stride, const lp16_t* __restrict__ a2, const lp16_t* __restrict__ a1,
@@ -1844,6 +1863,38 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
                                            : part1 + (long long)blockIdx.x * C1 + (u - C3 - C2));
         *dst = sum;
     }
+}
+template <int C3, int C2, int C1, int NCH, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_bwd_elu_mfma_kernel(
+    long long n, const lp16_t* __restrict__ G, long long ldg, const lp16_t* __restrict__ Wt0, long long ldw0,
+    const lp16_t* __restrict__ Wt1, long long ldw1, const lp16_t* __restrict__ Wt2, long long ldw2,
+    const lp16_t* __restrict__ a3, long long a3_stride, const lp16_t* __restrict__ a2, const lp16_t* __restrict__ a1,
+    float alpha, lp16_t* __restrict__ gz3, lp16_t* __restrict__ gz2, lp16_t* __restrict__ gz1,
+    float* __restrict__ part3, float* __restrict__ part2, float* __restrict__ part1) {
+    mlp3_bwd_elu_mfma_body<C3, C2, C1, NCH, NW>(n, G, ldg, Wt0, ldw0, Wt1, ldw1, Wt2, ldw2, a3, a3_stride, a2, a1, alpha, gz3,
+                                                gz2, gz1, part3, part2, part1);
+}
+
+// ---- Round 4: the LSTM backward pass and the MLP backward pass as TWO PHASES OF ONE LAUNCH.  Both kernels give workgroup
+// b the same 128 samples -- sequences [32 b, 32 b + 32) x T = 4 steps are rows [128 b, 128 b + 128) of the sequence-major
+// sample order -- and the MLP phase reads exactly the dG rows the LSTM phase of the SAME workgroup wrote, so nothing but a
+// workgroup barrier separates them: no grid fill / drain between the two (phase-in-launch, MI355X_MICROARCH.md price
+// list), and the MLP phase's K = 1024 stream of dG finds its rows in the CU's L2.  The weight-gradient kernels (reductions
+// over ALL rows) stay launches of their own behind it.  LDS: the phases use the same dynamic block one after the other.
+template <int RING, typename CT, typename GT>
+__global__ __launch_bounds__(512) void lstm_seq_bwd_mlp3_bwd_kernel(
+    int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const lp16_t* __restrict__ gates,
+    const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
+    lp16_t* dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last,
+    const lp16_t* __restrict__ Wt0, long long ldw0, const lp16_t* __restrict__ Wt1, long long ldw1,
+    const lp16_t* __restrict__ Wt2, long long ldw2, const lp16_t* __restrict__ a3, long long a3_stride,
+    const lp16_t* __restrict__ a2, const lp16_t* __restrict__ a1, float alpha, lp16_t* __restrict__ gz3,
+    lp16_t* __restrict__ gz2, lp16_t* __restrict__ gz1, float* __restrict__ part3, float* __restrict__ part2,
+    float* __restrict__ part1) {
+    lstm_seq_bwd_body<RING, CT, GT>(T, B, g_out, Wt, gates, c_all, c0, done, dG, bias_partial, ablate, c_last);
+    __syncthreads();      // (all of this workgroup's dG rows are written and visible to its own waves)
+    mlp3_bwd_elu_mfma_body<64, 128, 256, 8, 8>(B * T, dG, 4 * SEQ_H, Wt0, ldw0, Wt1, ldw1, Wt2, ldw2, a3, a3_stride, a2, a1,
+                                              alpha, gz3, gz2, gz1, part3, part2, part1);
 }
 
 template <typename DG>
@@ -3493,7 +3544,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane) {
 // requested before anything is computed and the rows stay in registers (32 per lane) for phase 3 -- the fp32 form spends
 // most of its life in nine dependent memory round trips (SQ_WAIT_ANY 64 % of its wave cycles).
 template <int NH, int NP, typename DXT, typename XT>      // DXT: type of the gradient handed to the LSTM backward (float or lp16_t)
-__global__ __launch_bounds__(512) void ln_heads_loss_kernel(
+__device__ __forceinline__ void ln_heads_loss_body(
+    float* lds_red, float* lds_lred,      // [8][(2 + NH) * 256] and [8][PPO_LOSS_ROW] floats of LDS (the caller's)
     long long n, const XT* __restrict__ x, int xT, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     const float* __restrict__ w, const float* __restrict__ wb, const float* __restrict__ logstd,
     const float* __restrict__ actions, const float* __restrict__ old_neglogp, const float* __restrict__ adv,
@@ -3509,8 +3561,8 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
     // kernel carry it; the bias / log-sigma gradients of the finalize step are multiplied there; statistics unscaled
     const float S = loss_scale ? *loss_scale : 1.0f;
     constexpr int NRED = 5 + 2 * PPO_MAX_A + 1;
-    __shared__ float red[NWV][W];
-    __shared__ float lred[NWV][PPO_LOSS_ROW];
+    float (*red)[W] = reinterpret_cast<float (*)[W]>(lds_red);
+    float (*lred)[PPO_LOSS_ROW] = reinterpret_cast<float (*)[PPO_LOSS_ROW]>(lds_lred);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane >> 4, cl = lane & 15;
     const long long r0 = ((long long)blockIdx.x * NWV + wave) * RW;
@@ -3815,6 +3867,75 @@ __global__ __launch_bounds__(512) void ln_heads_loss_kernel(
         ppo_loss_finalize((int)gridDim.x, A, n, loss_partial, logstd, critic_coef, entropy_coef, bounds_coef, stats,
                           grad_logstd, grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, S);
     }
+}
+template <int NH, int NP, typename DXT, typename XT>
+__global__ __launch_bounds__(512) void ln_heads_loss_kernel(
+    long long n, const XT* __restrict__ x, int xT, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    const float* __restrict__ w, const float* __restrict__ wb, const float* __restrict__ logstd,
+    const float* __restrict__ actions, const float* __restrict__ old_neglogp, const float* __restrict__ adv,
+    const float* __restrict__ old_values, const float* __restrict__ returns, const float* old_mu, const float* old_sigma,
+    float e_clip, int clip_value, float critic_coef, float entropy_coef, float bounds_coef, float soft_bound,
+    float* __restrict__ heads, DXT* __restrict__ dx, float* __restrict__ ln_partial, float* loss_partial,
+    float* __restrict__ stats, float* __restrict__ grad_logstd, float* __restrict__ grad_mu_bias,
+    float* __restrict__ grad_value_bias, float* __restrict__ kl_out, float* __restrict__ logstd_grad_accum, float* mu_store,
+    float* sigma_store, const float* __restrict__ loss_scale, float* __restrict__ found_inf, unsigned int* ticket,
+    int defer) {
+    __shared__ float red_s[8 * (2 + NH) * 256];
+    __shared__ float lred_s[8 * PPO_LOSS_ROW];
+    ln_heads_loss_body<NH, NP, DXT, XT>(red_s, lred_s, n, x, xT, gamma, beta, eps, w, wb, logstd, actions, old_neglogp, adv,
+                                        old_values, returns, old_mu, old_sigma, e_clip, clip_value, critic_coef, entropy_coef,
+                                        bounds_coef, soft_bound, heads, dx, ln_partial, loss_partial, stats, grad_logstd,
+                                        grad_mu_bias, grad_value_bias, kl_out, logstd_grad_accum, mu_store, sigma_store,
+                                        loss_scale, found_inf, ticket, defer);
+}
+
+// ---- Round 4: the row-local chain of the optimiser step as PHASES OF ONE LAUNCH -- LSTM forward (all T steps) ->
+// LayerNorm + heads + PPO loss + their backward -> LSTM backward (all T steps) -> MLP backward.  Every one of the four
+// kernels gives workgroup b the same 128 samples (sequences [32 b, 32 b + 32) x T = 4 = rows [128 b, 128 b + 128) of the
+// sequence-major order) and reads, from the phase before it, only what the SAME workgroup wrote (hidden states -> loss;
+// dh -> LSTM backward; dG -> MLP backward): a workgroup barrier is all that separates them -- three grid fills / drains
+// fewer per optimiser step, and each phase finds its predecessor's rows in the CU's L2.  (The one-launch MLP forward
+// stays in front as its own launch: its side job builds the weight operands ALL workgroups of this chain read, and the
+// weight-gradient kernels -- reductions over all rows -- stay behind it.)  LDS: one dynamic block used phase after phase.
+struct TrunkPhasesArgs {
+    long long B; int T;
+    // LSTM forward
+    const lp16_t* x; long long ldx; const uint4* w_tiled; const float* bias; const float* c0; const float* h0;
+    const unsigned char* done; lp16_t* h_out; lp16_t* c_all; lp16_t* gates; float* c_last; int ablate;
+    // LayerNorm + heads + loss
+    const float* gamma; const float* beta; float eps; const float* w; const float* wb; const float* logstd;
+    const float* actions; const float* old_neglogp; const float* adv; const float* old_values; const float* returns;
+    const float* old_mu; const float* old_sigma; float e_clip; int clip_value; float critic_coef, entropy_coef, bounds_coef,
+        soft_bound;
+    float* heads; lp16_t* dx; float* ln_partial; float* loss_partial; float* stats; float* grad_logstd; float* grad_mu_bias;
+    float* grad_value_bias; float* kl_out; float* logstd_grad_accum; float* mu_store; float* sigma_store;
+    const float* loss_scale; float* found_inf;
+    // LSTM backward
+    const uint4* w_hh_tiled; lp16_t* dG; float* bias_partial;
+    // MLP backward
+    const lp16_t* wt0; long long ldw0; const lp16_t* wt1; long long ldw1; const lp16_t* wt2; long long ldw2;
+    const lp16_t* a3; long long a3_stride; const lp16_t* a2; const lp16_t* a1; float alpha;
+    lp16_t* gz3; lp16_t* gz2; lp16_t* gz1; float* part3; float* part2; float* part1;
+};
+__global__ __launch_bounds__(512) void trunk_phases_kernel(const TrunkPhasesArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char trunk_lds[];
+    lstm_seq_fwd_body<3, 22, lp16_t, lp16_t, 12>(a.T, a.B, a.x, a.ldx, nullptr, 0, a.w_tiled, a.bias, a.c0, a.done, a.h_out, a.c_all,
+                                                 a.gates, a.ablate, a.c_last, a.h0);
+    __syncthreads();      // this workgroup's hidden states are written (h_out slots 1 .. T of its 32 sequences)
+    ln_heads_loss_body<3, 4, lp16_t, lp16_t>(reinterpret_cast<float*>(trunk_lds),
+                                             reinterpret_cast<float*>(trunk_lds) + 8 * 5 * 256, a.B * a.T, a.h_out, a.T, a.gamma,
+                                             a.beta, a.eps, a.w, a.wb, a.logstd, a.actions, a.old_neglogp, a.adv, a.old_values,
+                                             a.returns, a.old_mu, a.old_sigma, a.e_clip, a.clip_value, a.critic_coef,
+                                             a.entropy_coef, a.bounds_coef, a.soft_bound, a.heads, a.dx, a.ln_partial,
+                                             a.loss_partial, a.stats, a.grad_logstd, a.grad_mu_bias, a.grad_value_bias, a.kl_out,
+                                             a.logstd_grad_accum, a.mu_store, a.sigma_store, a.loss_scale, a.found_inf, nullptr,
+                                             1 /* the loss rows are folded by the column-sum launch (VineLossFinalize) */);
+    __syncthreads();      // dh of this workgroup's rows
+    lstm_seq_bwd_body<SEQ_BWD_RING, lp16_t, lp16_t>(a.T, a.B, a.dx, a.w_hh_tiled, a.gates, a.c_all, a.c0, a.done, a.dG,
+                                                    a.bias_partial, a.ablate, a.c_last);
+    __syncthreads();      // dG of this workgroup's rows
+    mlp3_bwd_elu_mfma_body<64, 128, 256, 8, 8>(a.B * a.T, a.dG, 4 * SEQ_H, a.wt0, a.ldw0, a.wt1, a.ldw1, a.wt2, a.ldw2, a.a3,
+                                              a.a3_stride, a.a2, a.a1, a.alpha, a.gz3, a.gz2, a.gz1, a.part3, a.part2, a.part1);
 }
 #undef LHL_COL
 #undef LHL_ROW
@@ -4943,9 +5064,6 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_o
     if (B <= 0 || T <= 0 || !g_out || !w_hh_tiled || !gates || !c_all || !c0 || !dgates || (c_bf16 && !c_last))
         return VINE_ERR_INVALID_ARG;
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8) return VINE_ERR_UNSUPPORTED;
-#ifndef SEQ_BWD_RING
-#define SEQ_BWD_RING 8      // 16 does not fit the register file without spills: 76.7 us against 65.3 us per 4-step sequence
-#endif
     constexpr int RING = SEQ_BWD_RING;
     const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(lp16_t);          // 129 KiB: one workgroup per CU
     const int ablate = seq_ablate();
@@ -5068,6 +5186,83 @@ int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, 
     if (nw == 8) VINE_MLP3B(8);
     else VINE_MLP3B(4);
 #undef VINE_MLP3B
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_lstm_seq_backward_mlp3_mfma(int64_t B, int64_t T, int64_t H, const void* g_out, const void* w_hh_tiled,
+                                     const void* gates, const void* c_all, const float* c0, const uint8_t* done,
+                                     void* dgates, float* bias_partial, const float* c_last, const void* wt0, int64_t ldw0,
+                                     const void* wt1, int64_t ldw1, const void* wt2, int64_t ldw2, const void* a3,
+                                     int64_t a3_stride, const void* a2, const void* a1, float alpha, void* gz3, void* gz2,
+                                     void* gz1, float* part3, float* part2, float* part1, void* stream) {
+    if (B <= 0 || T <= 0 || !g_out || !w_hh_tiled || !gates || !c_all || !c0 || !dgates || !bias_partial || !c_last || !wt0 ||
+        !wt1 || !wt2 || !a3 || !a2 || !a1 || !gz3 || !gz2 || !gz1 || !part3 || !part2 || !part1 || (ldw0 & 7) || (ldw1 & 7) ||
+        (ldw2 & 7) || (a3_stride & 7) || ldw0 < 4 * SEQ_H || ldw1 < 64 || ldw2 < 128 || ((uintptr_t)dgates & 15) ||
+        ((uintptr_t)wt0 & 15) || ((uintptr_t)wt1 & 15) || ((uintptr_t)wt2 & 15) || ((uintptr_t)a3 & 15) || ((uintptr_t)a2 & 15) ||
+        ((uintptr_t)a1 & 15) || ((uintptr_t)gz3 & 15) || ((uintptr_t)gz2 & 15) || ((uintptr_t)gz1 & 15))
+        return VINE_ERR_INVALID_ARG;
+    // one workgroup = 32 sequences x T steps (the LSTM phase) = 128 rows (the MLP phase, 8 waves x 16 rows): T = 4 only;
+    // 16-bit saved cell states and hidden-state gradient (the update's configuration)
+    if ((B % SEQ_ROWS) || H != SEQ_H || T != 4) return VINE_ERR_UNSUPPORTED;
+    constexpr int RING = SEQ_BWD_RING;
+    const size_t lds_lstm = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(lp16_t);
+    const size_t lds_mlp = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(lp16_t) + (size_t)8 * (64 + 128 + 256) * sizeof(float);
+    const size_t lds = lds_lstm > lds_mlp ? lds_lstm : lds_mlp;
+    if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_bwd_mlp3_bwd_kernel<RING, lp16_t, lp16_t>), 160 * 1024))
+        return VINE_ERR_DEVICE;
+    hipLaunchKernelGGL((lstm_seq_bwd_mlp3_bwd_kernel<RING, lp16_t, lp16_t>), dim3((unsigned)(B / SEQ_ROWS)), dim3(512), lds,
+                       (hipStream_t)stream, (int)T, (long long)B, (const lp16_t*)g_out, (const uint4*)w_hh_tiled,
+                       (const lp16_t*)gates, (const lp16_t*)c_all, c0, done, (lp16_t*)dgates, bias_partial, seq_ablate(), c_last,
+                       (const lp16_t*)wt0, (long long)ldw0, (const lp16_t*)wt1, (long long)ldw1, (const lp16_t*)wt2,
+                       (long long)ldw2, (const lp16_t*)a3, (long long)a3_stride, (const lp16_t*)a2, (const lp16_t*)a1, alpha,
+                       (lp16_t*)gz3, (lp16_t*)gz2, (lp16_t*)gz1, part3, part2, part1);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int64_t vine_trunk_args_size(void) { return (int64_t)sizeof(VineTrunkArgs); }
+
+int vine_trunk_phases(const VineTrunkArgs* p, void* stream) {
+    if (!p) return VINE_ERR_INVALID_ARG;
+    const VineTrunkArgs& q = *p;
+    const void* need[] = {q.x, q.w_tiled, q.bias, q.c0, q.h0, q.h_out, q.c_all, q.gates, q.c_last, q.ln_gamma, q.ln_beta, q.w_heads,
+                          q.b_heads, q.logstd, q.actions, q.old_neglogp, q.advantages, q.old_values, q.returns, q.old_mu,
+                          q.old_sigma, q.heads, q.d_out, q.ln_partial, q.loss_partial, q.stats, q.grad_logstd, q.w_hh_tiled,
+                          q.dgates, q.bias_partial, q.wt0, q.wt1, q.wt2, q.a3, q.a2, q.a1, q.gz3, q.gz2, q.gz1, q.part3, q.part2,
+                          q.part1};
+    for (const void* v : need)
+        if (!v) return VINE_ERR_INVALID_ARG;
+    if (q.B <= 0 || ((q.grad_mu_bias == nullptr) != (q.grad_value_bias == nullptr)) || ((q.mu_store == nullptr) != (q.sigma_store == nullptr)) ||
+        (q.ldx & 7) || (q.ldw0 & 7) || (q.ldw1 & 7) || (q.ldw2 & 7) || (q.a3_stride & 7) || q.ldw0 < 4 * SEQ_H || q.ldw1 < 64 ||
+        q.ldw2 < 128)
+        return VINE_ERR_INVALID_ARG;
+    const void* al16[] = {q.x, q.w_tiled, q.h_out, q.c_all, q.gates, q.d_out, q.w_hh_tiled, q.dgates, q.wt0, q.wt1, q.wt2, q.a3, q.a2,
+                          q.a1, q.gz3, q.gz2, q.gz1, q.c0, q.h0, q.c_last, q.bias};
+    for (const void* v : al16)
+        if ((uintptr_t)v & 15) return VINE_ERR_INVALID_ARG;
+    // the update's default shapes only (the phases are instantiated for them); one workgroup = 32 sequences = 128 samples
+    const long long n = q.B * q.T;
+    if (q.T != 4 || (q.B % SEQ_ROWS) || q.ldx < 96 || n / 128 > VINE_PPO_LOSS_BLOCKS) return VINE_ERR_UNSUPPORTED;
+    TrunkPhasesArgs a;
+    a.B = q.B; a.T = (int)q.T;
+    a.x = (const lp16_t*)q.x; a.ldx = q.ldx; a.w_tiled = (const uint4*)q.w_tiled; a.bias = q.bias; a.c0 = q.c0; a.h0 = q.h0;
+    a.done = q.done; a.h_out = (lp16_t*)q.h_out; a.c_all = (lp16_t*)q.c_all; a.gates = (lp16_t*)q.gates; a.c_last = q.c_last;
+    a.ablate = seq_ablate();
+    a.gamma = q.ln_gamma; a.beta = q.ln_beta; a.eps = q.ln_eps; a.w = q.w_heads; a.wb = q.b_heads; a.logstd = q.logstd;
+    a.actions = q.actions; a.old_neglogp = q.old_neglogp; a.adv = q.advantages; a.old_values = q.old_values; a.returns = q.returns;
+    a.old_mu = q.old_mu; a.old_sigma = q.old_sigma; a.e_clip = q.e_clip; a.clip_value = q.clip_value; a.critic_coef = q.critic_coef;
+    a.entropy_coef = q.entropy_coef; a.bounds_coef = q.bounds_coef; a.soft_bound = q.soft_bound;
+    a.heads = q.heads; a.dx = (lp16_t*)q.d_out; a.ln_partial = q.ln_partial; a.loss_partial = q.loss_partial; a.stats = q.stats;
+    a.grad_logstd = q.grad_logstd; a.grad_mu_bias = q.grad_mu_bias; a.grad_value_bias = q.grad_value_bias; a.kl_out = q.kl_out;
+    a.logstd_grad_accum = q.logstd_grad_accum; a.mu_store = q.mu_store; a.sigma_store = q.sigma_store; a.loss_scale = q.loss_scale;
+    a.found_inf = q.found_inf;
+    a.w_hh_tiled = (const uint4*)q.w_hh_tiled; a.dG = (lp16_t*)q.dgates; a.bias_partial = q.bias_partial;
+    a.wt0 = (const lp16_t*)q.wt0; a.ldw0 = q.ldw0; a.wt1 = (const lp16_t*)q.wt1; a.ldw1 = q.ldw1; a.wt2 = (const lp16_t*)q.wt2;
+    a.ldw2 = q.ldw2; a.a3 = (const lp16_t*)q.a3; a.a3_stride = q.a3_stride; a.a2 = (const lp16_t*)q.a2; a.a1 = (const lp16_t*)q.a1;
+    a.alpha = q.alpha; a.gz3 = (lp16_t*)q.gz3; a.gz2 = (lp16_t*)q.gz2; a.gz1 = (lp16_t*)q.gz1; a.part3 = q.part3; a.part2 = q.part2;
+    a.part1 = q.part1;
+    const size_t lds = 160 * 1024;      // the LSTM forward phase with its weight cache: 63 + 96 KB (the other phases need less)
+    if (!ensure_dyn_lds(reinterpret_cast<const void*>(&trunk_phases_kernel), lds)) return VINE_ERR_DEVICE;
+    hipLaunchKernelGGL(trunk_phases_kernel, dim3((unsigned)(q.B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -192,6 +192,11 @@ MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP l
 MLP3_PREP = _os.environ.get("VINE_MLP3_PREP", "1") != "0"      # the step's operand preparation rides in that launch (A/B knob)
 COPY_SCATTER = _os.environ.get("VINE_COPY_SCATTER", "1") != "0"  # coalesced-load / scattered-store forms of tiles and transposes
 RIDES = [0]      # forward passes whose operand preparation rode in the MLP launch (tests look at it)
+# LSTM backward + MLP backward as two phases of one launch (same rows per workgroup); 0: two launches (A/B knob)
+BWD_PHASES = _os.environ.get("VINE_BWD_PHASES", "1") != "0"
+# LSTM forward + LayerNorm / heads / loss + LSTM backward + MLP backward as four phases of one launch; 0: separate launches
+TRUNK_PHASES = _os.environ.get("VINE_TRUNK_PHASES", "1") != "0"
+PHASE_LAUNCHES = [0]      # vine_trunk_phases launches (tests look at it)
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
 WGRAD_WIDE_BM = int(_os.environ.get("VINE_WGRAD_WIDE_BM", "128"))   # 128 | 64 rows of dy^T per workgroup tile (A/B knob)
@@ -1015,7 +1020,79 @@ class _Trunk(torch.autograd.Function):
                 x = a
         if concat and not mixed:
             xcat[:, U:].copy_(obs_n)
-        if no_proj:
+        NH_ = mu_w.shape[0] + v_w.shape[0]
+        slots_early = [_grad_slot(p) if isinstance(p, torch.Tensor) else None for p in params]
+        # Round 4: LSTM forward -> LayerNorm + heads + loss -> LSTM backward -> MLP backward as four phases of ONE launch
+        # (vine_trunk_phases: same 128 rows per workgroup in all four).  The update's default configuration only; everything
+        # the backward pass of this node would compute up to the weight gradients is then done HERE, in forward.
+        phases = (TRUNK_PHASES and mixed and seq and h_once and lp and mlp3 and no_proj and T == 4 and wpad == 96 and H == 256
+                  and NH_ == 3 and dones is not None and c0_direct is not None and h0_direct is not None
+                  and _heads_loss_route(n, H, NH_, loss_pack, head_bias_external, lib) and LOSS_DEFER
+                  and lib.vine_ln_heads_loss_rows() == 128 and any(ctx.needs_input_grad)
+                  and all(sl is not None for sl, p in zip(slots_early, params) if isinstance(p, torch.Tensor))
+                  and all(w is not None for w in wts) and w_hh_tiled is not None
+                  and tuple(wts[i].shape for i in (1, 2)) == ((256, 128), (128, 64)) and B % 32 == 0 and n // 128 <= 1024)
+        ctx.phases_done = None
+        if _os.environ.get("VINE_DEBUG_PHASES") and not phases:
+            print("trunk phases off:", dict(mixed=mixed, seq=seq, h_once=h_once, lp=lp, mlp3=mlp3, no_proj=no_proj, T=T, wpad=wpad,
+                  H=H, NH=NH_, dones=dones is not None, c0=c0_direct is not None, h0=h0_direct is not None,
+                  route=_heads_loss_route(n, H, NH_, loss_pack, head_bias_external, lib), rows=lib.vine_ln_heads_loss_rows(),
+                  grad=any(ctx.needs_input_grad), slots=[sl is not None for sl in slots_early], wts=[w is not None for w in wts],
+                  tiled=w_hh_tiled is not None, B=B, n=n), flush=True)
+        if phases:
+            from ..abi import LossFinalize, TrunkArgs
+            out, c_all, gates, hp = lstm_buffers
+            lpk = loss_pack
+            heads = torch.empty((n, NH_), device=dev, dtype=torch.float32)
+            d_out = torch.empty((n, H), device=dev, dtype=lp_dtype())
+            ln_part = torch.empty((n // 128, (2 + NH_) * H), device=dev, dtype=torch.float32)
+            dG = torch.empty((n, 4 * H), device=dev, dtype=lp_dtype())
+            bias_partial = torch.empty((B // 32, 4 * H), device=dev, dtype=torch.float32)
+            gzs = [torch.empty((n, c), device=dev, dtype=lp_dtype()) for c in (256, 128, 64)]       # layers 1, 2, 3
+            parts = [torch.empty((n // 128, c), device=dev, dtype=torch.float32) for c in (256, 128, 64)]
+            amp_ = _amp_ptrs(lpk.get("amp"))
+            ta = TrunkArgs()
+            ta.B, ta.T = B, T
+            ta.x, ta.ldx, ta.w_tiled, ta.bias = xfull.data_ptr(), xfull.stride(0), wtile.data_ptr(), bias.data_ptr()
+            ta.c0, ta.h0, ta.done = c0_direct.data_ptr(), h0_direct.data_ptr(), dones.data_ptr()
+            ta.h_out, ta.c_all, ta.gates, ta.c_last = out.data_ptr(), c_all.data_ptr(), gates.data_ptr(), c_last.data_ptr()
+            ta.ln_gamma, ta.ln_beta, ta.ln_eps = ln_g.data_ptr(), ln_b.data_ptr(), float(ln_eps)
+            ta.w_heads, ta.b_heads, ta.logstd = w_heads.data_ptr(), b_heads.data_ptr(), lpk["logstd"].data_ptr()
+            (ta.actions, ta.old_neglogp, ta.advantages, ta.old_values, ta.returns, ta.old_mu,
+             ta.old_sigma) = [t.data_ptr() for t in lpk["args"]]
+            ta.e_clip, ta.clip_value, ta.critic_coef, ta.entropy_coef, ta.bounds_coef, ta.soft_bound = lpk["scal"]
+            ta.alpha = 1.0
+            ta.heads, ta.d_out, ta.ln_partial, ta.loss_partial = heads.data_ptr(), d_out.data_ptr(), ln_part.data_ptr(), lpk["scratch"].data_ptr()
+            ta.stats, ta.grad_logstd = lpk["stats"].data_ptr(), lpk["grad_logstd"].data_ptr()
+            ta.grad_mu_bias, ta.grad_value_bias = lpk["head_bias_grads"][0].data_ptr(), lpk["head_bias_grads"][1].data_ptr()
+            ta.kl_out, ta.logstd_grad_accum, ta.mu_store, ta.sigma_store = lpk["extra"]
+            ta.loss_scale, ta.found_inf = amp_
+            ta.w_hh_tiled, ta.dgates, ta.bias_partial = w_hh_tiled.data_ptr(), dG.data_ptr(), bias_partial.data_ptr()
+            ta.wt0, ta.ldw0, ta.wt1, ta.ldw1 = wts[0].data_ptr(), wts[0].stride(0), wts[2].data_ptr(), wts[2].stride(0)
+            ta.wt2, ta.ldw2 = wts[1].data_ptr(), wts[1].stride(0)
+            ta.a3, ta.a3_stride, ta.a2, ta.a1 = xcat.data_ptr(), xcat.stride(0), acts[1].data_ptr(), acts[0].data_ptr()
+            ta.gz3, ta.gz2, ta.gz1 = gzs[2].data_ptr(), gzs[1].data_ptr(), gzs[0].data_ptr()
+            ta.part3, ta.part2, ta.part1 = parts[2].data_ptr(), parts[1].data_ptr(), parts[0].data_ptr()
+            import ctypes as C_
+            rc = lib.vine_trunk_phases(C_.byref(ta), st)
+            if rc == -2:
+                phases = False
+                if _os.environ.get("VINE_DEBUG_PHASES"):
+                    print("vine_trunk_phases: unsupported shapes", B, T, xfull.stride(0), flush=True)
+            else:
+                _check(rc, "vine_trunk_phases")
+                ctx.loss_fin = LossFinalize(lpk["scratch"].data_ptr(), n // 128, NH_ - 1, n, lpk["logstd"].data_ptr(),
+                                            lpk["scal"][2], lpk["scal"][3], lpk["scal"][4], lpk["stats"].data_ptr(),
+                                            lpk["grad_logstd"].data_ptr(), lpk["head_bias_grads"][0].data_ptr(),
+                                            lpk["head_bias_grads"][1].data_ptr(), lpk["extra"][0], lpk["extra"][1], amp_[0])
+                ctx.loss_fused = (d_out, ln_part)
+                ctx.loss_pack = loss_pack
+                ctx.h_once = h_once
+                ctx.phases_done = (dG, bias_partial, gzs, parts)
+                PHASE_LAUNCHES[0] += 1
+        if phases:
+            pass
+        elif no_proj:
             # no input projection: the step kernel multiplies [x_t | h_{t-1}] by [w_ih | 0 | w_hh] in one product
             out, c_all, gates, hp = _lstm_forward_steps(lib, xfull, None, w_hh_op, bias, h0, c0, dones, T, True, wcat=wcat,
                                                         buffers=lstm_buffers, c0_direct=c0_direct, wtile=wtile,
@@ -1031,11 +1108,14 @@ class _Trunk(torch.autograd.Function):
         rstd = torch.empty(n, device=dev, dtype=torch.float32)
         NH = w_heads.shape[0]
         fuse_heads = H == 256 and 2 <= NH <= 5
-        ctx.loss_fused = None
+        if not phases:
+            ctx.loss_fused = None
         ctx.loss_pack = loss_pack       # (its "amp" entry: loss scale / overflow flag of the device-side GradScaler)
         lhl_rows = lib.vine_ln_heads_loss_rows()
         ctx.h_once = h_once
-        if _heads_loss_route(n, H, NH, loss_pack, head_bias_external, lib):
+        if phases:
+            y = out.new_empty(0)        # (LayerNorm + heads + loss ran as the second phase of vine_trunk_phases)
+        elif _heads_loss_route(n, H, NH, loss_pack, head_bias_external, lib):
             # LayerNorm + heads + PPO loss + their backward in ONE launch: the gradient w.r.t. the LSTM output is
             # known before this node's backward runs (which ignores the gradient it is handed for `heads`)
             y = out.new_empty(0)
@@ -1183,10 +1263,37 @@ class _Trunk(torch.autograd.Function):
         else:
             deliver(base + 4, lambda o: column_sums(ln_part[:, :H], o))
             deliver(base + 5, lambda o: column_sums(ln_part[:, H:], o))
-        # ---- LSTM
-        dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
-                                                w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled,
-                                                c_last=c_last)
+        # ---- LSTM (+ the MLP backward chain as a second phase of the same launch, round 4: vine_lstm_seq_backward_mlp3_mfma)
+        mlp3b = (mixed and MLP3 and n_mlp == 3 and all(w is not None for w in ctx.wts) and n % 64 == 0 and U == 64
+                 and 4 * H == 1024 and tuple(ctx.wts[i].shape for i in (1, 2)) == ((256, 128), (128, 64))
+                 and acts[0].shape[1] == 256 and acts[1].shape[1] == 128)
+        gzs = parts = None
+        B_ = n // T
+        if getattr(ctx, "phases_done", None) is not None:      # vine_trunk_phases ran the LSTM / MLP backward in forward
+            dG, bias_partial, gzs, parts = ctx.phases_done
+            ctx.phases_done = None
+        elif (BWD_PHASES and mlp3b and ctx.w_hh_tiled is not None and T == 4 and c_last is not None and c0_direct is not None
+                and d_out.dtype == lp_dtype() and c_all.dtype == lp_dtype() and n % 128 == 0 and n >= 32768 and B_ % 32 == 0
+                and d_out.is_contiguous() and gates.is_contiguous() and c_all.is_contiguous()):
+            dG = torch.empty((n, 4 * H), device=dev, dtype=lp_dtype())
+            bias_partial = torch.empty((B_ // 32, 4 * H), device=dev, dtype=torch.float32)
+            gzs = [torch.empty((n, c), device=dev, dtype=lp_dtype()) for c in (256, 128, 64)]       # layers 1, 2, 3
+            parts = [torch.empty((n // 128, c), device=dev, dtype=torch.float32) for c in (256, 128, 64)]
+            rc = lib.vine_lstm_seq_backward_mlp3_mfma(
+                B_, T, H, d_out.data_ptr(), ctx.w_hh_tiled.data_ptr(), gates.data_ptr(), c_all.data_ptr(),
+                c0_direct.data_ptr(), dones.data_ptr() if has_dones else None, dG.data_ptr(), bias_partial.data_ptr(),
+                c_last.data_ptr(), ctx.wts[0].data_ptr(), ctx.wts[0].stride(0), ctx.wts[2].data_ptr(), ctx.wts[2].stride(0),
+                ctx.wts[1].data_ptr(), ctx.wts[1].stride(0), xcat.data_ptr(), xcat.stride(0), acts[1].data_ptr(),
+                acts[0].data_ptr(), 1.0, gzs[2].data_ptr(), gzs[1].data_ptr(), gzs[0].data_ptr(), parts[2].data_ptr(),
+                parts[1].data_ptr(), parts[0].data_ptr(), st)
+            if rc == -2:
+                gzs = parts = None
+            else:
+                _check(rc, "vine_lstm_seq_backward_mlp3_mfma")
+        if gzs is None:
+            dG, bias_partial = _lstm_backward_steps(lib, d_out, w_hh, c_all, gates, dones if has_dones else None, T,
+                                                    w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled,
+                                                    c_last=c_last)
         fused2 = False
         if ctx.h_once and mixed and slots[base + 0] is not None and slots[base + 1] is not None:
             # ``out`` is the one 16-bit copy of the hidden states (slot 0 = h0): the kernel shifts and masks
@@ -1206,22 +1313,20 @@ class _Trunk(torch.autograd.Function):
             deliver(base + 3, lambda o: o.copy_(slots[base + 2] if slots[base + 2] is not None else grads[base + 2]))
         gz = part = g = None
         wgroup = WeightGradGroup()
-        mlp3b = (mixed and MLP3 and n_mlp == 3 and all(w is not None for w in ctx.wts) and n % 64 == 0 and U == 64
-                 and 4 * H == 1024 and tuple(ctx.wts[i].shape for i in (1, 2)) == ((256, 128), (128, 64))
-                 and acts[0].shape[1] == 256 and acts[1].shape[1] == 128)
         if mlp3b:
             # the whole MLP backward in one launch (vine_mlp3_bwd_elu_mfma): LSTM input gradient (MLP columns) x ELU' ->
             # gz3 -> gz2 -> gz1 carried in registers, bias partial sums per workgroup
-            rows_wg = 128 if (n % 128 == 0 and n >= 32768) else 64
-            gzs = [torch.empty((n, c), device=dev, dtype=lp_dtype()) for c in (256, 128, 64)]       # layers 1, 2, 3
-            parts = [torch.empty((n // rows_wg, c), device=dev, dtype=torch.float32) for c in (256, 128, 64)]
-            _check(lib.vine_mlp3_bwd_elu_mfma(n, dG.data_ptr(), dG.stride(0), 4 * H, ctx.wts[0].data_ptr(),
-                                              ctx.wts[0].stride(0), ctx.wts[2].data_ptr(), ctx.wts[2].stride(0),
-                                              ctx.wts[1].data_ptr(), ctx.wts[1].stride(0), xcat.data_ptr(), xcat.stride(0),
-                                              acts[1].data_ptr(), acts[0].data_ptr(), 64, 128, 256, 1.0,
-                                              gzs[2].data_ptr(), gzs[1].data_ptr(), gzs[0].data_ptr(),
-                                              parts[2].data_ptr(), parts[1].data_ptr(), parts[0].data_ptr(), st),
-                   "vine_mlp3_bwd_elu_mfma")
+            if gzs is None:      # (else: it ran as the second phase of the LSTM backward launch above)
+                rows_wg = 128 if (n % 128 == 0 and n >= 32768) else 64
+                gzs = [torch.empty((n, c), device=dev, dtype=lp_dtype()) for c in (256, 128, 64)]       # layers 1, 2, 3
+                parts = [torch.empty((n // rows_wg, c), device=dev, dtype=torch.float32) for c in (256, 128, 64)]
+                _check(lib.vine_mlp3_bwd_elu_mfma(n, dG.data_ptr(), dG.stride(0), 4 * H, ctx.wts[0].data_ptr(),
+                                                  ctx.wts[0].stride(0), ctx.wts[2].data_ptr(), ctx.wts[2].stride(0),
+                                                  ctx.wts[1].data_ptr(), ctx.wts[1].stride(0), xcat.data_ptr(), xcat.stride(0),
+                                                  acts[1].data_ptr(), acts[0].data_ptr(), 64, 128, 256, 1.0,
+                                                  gzs[2].data_ptr(), gzs[1].data_ptr(), gzs[0].data_ptr(),
+                                                  parts[2].data_ptr(), parts[1].data_ptr(), parts[0].data_ptr(), st),
+                       "vine_mlp3_bwd_elu_mfma")
             del dG
             for i in range(n_mlp):
                 x_in = acts[i - 1] if i > 0 else x0
