@@ -455,6 +455,14 @@ int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_
                       float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1, const float* w2,
                       int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3, const float* b3, int64_t C3,
                       float alpha, void* stream);
+
+/* vine_mlp3_elu_f32 whose workgroup 0 first runs the finalise step of vine_rollout_post_defer (fin_meter == NULL: none):
+ * meter / max_size / counter as in vine_rollout_post, fin_scratch / fin_blocks = that call's scratch rows. */
+int vine_mlp3_elu_f32_fin(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean,
+                          const double* var, float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1,
+                          const float* w2, int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3,
+                          const float* b3, int64_t C3, float alpha, float* fin_meter, float fin_max_size, int64_t* fin_counter,
+                          const float* fin_scratch, int32_t fin_blocks, void* stream);
 int vine_lstm_step_f32(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const float* w_tiled, const float* bias,
                        const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next, int64_t ldhp,
                        void* stream);
@@ -507,6 +515,15 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
                       float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
                       float* c_state, float* meter, float max_size, int64_t* counter, void* h_op, int64_t h_op_stride,
                       int32_t h_op_bf16, float* scratch, void* stream);
+
+/* The same with the one-workgroup finalise DEFERRED (round 4): only the per-env pass runs; the caller hands `scratch` and
+ * vine_rollout_post_blocks(N) (the rows it holds) to the next launch that can carry the fold as a side job of one workgroup
+ * -- vine_mlp3_elu_f32_fin, the first kernel of the next rollout step -- which must run before anything reads `*counter`. */
+int32_t vine_rollout_post_blocks(int64_t N);
+int vine_rollout_post_defer(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
+                            const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
+                            float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
+                            float* c_state, void* h_op, int64_t h_op_stride, int32_t h_op_bf16, float* scratch, void* stream);
 
 /* Adam step on FLAT buffers (all parameters of the model live in one contiguous block, likewise gradients and
  * moments): torch.optim.Adam arithmetic (rl_games: Adam(lr, eps=1e-8), common_agent.py:80) in ONE launch instead of a

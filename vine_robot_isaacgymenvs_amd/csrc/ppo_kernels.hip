@@ -4281,9 +4281,9 @@ __global__ __launch_bounds__(256) void rollout_post_kernel(
 
 // rl_games AverageMeter.update for both meters from the step's (sum, count) -- the per-workgroup rows of the kernel
 // above summed in a fixed order by one 256-thread workgroup.
-__global__ __launch_bounds__(256) void rollout_finalize_kernel(float* __restrict__ meter, float max_size,
-                                                               long long* __restrict__ counter,
-                                                               const float* __restrict__ partial, int blocks) {
+__device__ __forceinline__ void rollout_finalize_body(float* __restrict__ meter, float max_size,
+                                                      long long* __restrict__ counter,
+                                                      const float* __restrict__ partial, int blocks) {
     float v[3] = {0.0f, 0.0f, 0.0f};
     for (int b = threadIdx.x; b < blocks; b += 256) {
         v[0] += partial[b * 3]; v[1] += partial[b * 3 + 1]; v[2] += partial[b * 3 + 2];
@@ -4314,6 +4314,11 @@ __global__ __launch_bounds__(256) void rollout_finalize_kernel(float* __restrict
     }
     meter[4] = sum_r; meter[5] = sum_l; meter[6] = size;      // this step's totals, for introspection
     counter[0] += 1;
+}
+__global__ __launch_bounds__(256) void rollout_finalize_kernel(float* __restrict__ meter, float max_size,
+                                                               long long* __restrict__ counter,
+                                                               const float* __restrict__ partial, int blocks) {
+    rollout_finalize_body(meter, max_size, counter, partial, blocks);
 }
 
 int grid_for(long long work, int threads) {
@@ -4679,7 +4684,13 @@ __global__ __launch_bounds__(256) void mlp3_elu_f32_kernel(long long n, float* _
                                                            const float* __restrict__ b1, const float* __restrict__ w2,
                                                            long long ldw2, const float* __restrict__ b2,
                                                            const float* __restrict__ w3, long long ldw3,
-                                                           const float* __restrict__ b3, float alpha) {
+                                                           const float* __restrict__ b3, float alpha, float* fin_meter,
+                                                           float fin_max_size, long long* fin_counter,
+                                                           const float* fin_partial, int fin_blocks) {
+    // (round 4) workgroup 0 first folds the PREVIOUS rollout step's episode sums into the meters and advances the rollout
+    // counter (rollout_finalize_kernel's body: formerly a one-workgroup launch of its own per step; the policy head of THIS
+    // step, two launches further on, is the first reader of the counter)
+    if (fin_meter && blockIdx.x == 0) rollout_finalize_body(fin_meter, fin_max_size, fin_counter, fin_partial, fin_blocks);
     constexpr int C1 = 256, C2 = 128, C3 = 64, P1 = 36, P2 = C1 + 4, P3 = C2 + 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw_f32[];
     float* wl = reinterpret_cast<float*>(lds_raw_f32);
@@ -5877,6 +5888,25 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
+int32_t vine_rollout_post_blocks(int64_t N) {
+    long long blocks = (N * 16 + 255) / 256;
+    return (int32_t)(blocks > ROLLOUT_POST_BLOCKS ? ROLLOUT_POST_BLOCKS : blocks);
+}
+
+int vine_rollout_post_defer(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
+                            const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
+                            float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,
+                            float* c_state, void* h_op, int64_t h_op_stride, int32_t h_op_bf16, float* scratch, void* stream) {
+    if (N <= 0 || H <= 0 || (H & 3) || !rew || !reset || !timeouts || !values || !shaped_out || !dones_out ||
+        !cur_rewards || !cur_lengths || !h_state || !c_state || !scratch)
+        return VINE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rollout_post_kernel, dim3((unsigned)vine_rollout_post_blocks(N)), dim3(256), 0, (hipStream_t)stream,
+                       (long long)N, (int)H, rew, (const long long*)reset, timeouts, values, reward_shift, reward_scale,
+                       gamma_bootstrap, shaped_out, dones_out, cur_rewards, cur_lengths, h_state, c_state, scratch, h_op,
+                       (long long)h_op_stride, (int)h_op_bf16);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
 int vine_adam_step_amp(int64_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr, float* step,
                        float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* lp16_shadow,
                        const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr, float* amp_state,
@@ -5976,10 +6006,12 @@ int vine_lstm_tile_weights_split(int64_t H, int64_t K, const float* wcat, int64_
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
-int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
-                      float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1, const float* w2,
-                      int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3, const float* b3, int64_t C3,
-                      float alpha, void* stream) {
+int vine_mlp3_elu_f32_fin(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean,
+                          const double* var, float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1,
+                          const float* w2, int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3,
+                          const float* b3, int64_t C3, float alpha, float* fin_meter, float fin_max_size, int64_t* fin_counter,
+                          const float* fin_scratch, int32_t fin_blocks, void* stream) {
+    if (fin_meter && (!fin_counter || !fin_scratch || fin_blocks <= 0)) return VINE_ERR_INVALID_ARG;
     if (n <= 0 || !x || !raw || !mean || !var || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return VINE_ERR_INVALID_ARG;
     if (C1 != 256 || C2 != 128 || C3 != 64 || (n & 63) || F_in <= 0 || F_in > 32 || ldx < C3 + 32 || (ldx & 3) || (ldw2 & 3) ||
         ldw2 < C1 || (ldw3 & 3) || ldw3 < C2 || ldw1 < 32 || (ldw1 & 3) || ((uintptr_t)w1 & 15) || ((uintptr_t)x & 15) || ((uintptr_t)w2 & 15) ||
@@ -5989,8 +6021,17 @@ int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_
     if (!ensure_dyn_lds(reinterpret_cast<const void*>(mlp3_elu_f32_kernel), lds)) return VINE_ERR_DEVICE;
     hipLaunchKernelGGL(mlp3_elu_f32_kernel, dim3((unsigned)(n / 64)), dim3(256), lds, (hipStream_t)stream, (long long)n, x,
                        (long long)ldx, raw, (int)F_in, mean, var, eps, clip, w1, (long long)ldw1, b1, w2, (long long)ldw2, b2, w3,
-                       (long long)ldw3, b3, alpha);
+                       (long long)ldw3, b3, alpha, fin_meter, fin_max_size, (long long*)fin_counter, (const float*)fin_scratch,
+                       fin_blocks);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_mlp3_elu_f32(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean, const double* var,
+                      float eps, float clip, const float* w1, int64_t ldw1, const float* b1, int64_t C1, const float* w2,
+                      int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3, const float* b3, int64_t C3,
+                      float alpha, void* stream) {
+    return vine_mlp3_elu_f32_fin(n, x, ldx, raw, F_in, mean, var, eps, clip, w1, ldw1, b1, C1, w2, ldw2, b2, C2, w3, ldw3, b3, C3,
+                                 alpha, nullptr, 0.0f, nullptr, nullptr, 0, stream);
 }
 
 const char* vine_lp16_format(void) { return VINE_LP16_NAME; }

@@ -508,14 +508,19 @@ class A2CAgent:
                 and f["U"] == 64 and f["F"] <= 32 and obs.is_contiguous() and obs.dtype == torch.float32
                 and tuple(W.shape for W, _ in f["mlp"][1:]) == ((128, 256), (64, 128)) and f["mlp"][0][0].shape[0] == 256)
         f32k = bool(f["f32_mfma"]) and obs.is_contiguous() and obs.dtype == torch.float32 and n_mlp == 3
+        assert f32k or getattr(self, "_pending_fin", None) is None, "a deferred rollout finalize needs the fp32 MLP launch"
         if f32k:
             # fp32 (the reference's rollout precision) on the matrix cores: normalisation + the three layers in one launch
             (W1, b1), (W2, b2), (W3, b3) = f["mlp"]
-            fused._check(lib.vine_mlp3_elu_f32(N, xh.data_ptr(), xh.stride(0), obs.data_ptr(), f["F"],
-                                               rms.running_mean.data_ptr(), rms.running_var.data_ptr(), float(rms.epsilon),
-                                               5.0, f["w1p_f32"].data_ptr(), 32, b1.data_ptr(), 256, W2.data_ptr(),
-                                               W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(), W3.stride(0), b3.data_ptr(),
-                                               64, 1.0, st), "vine_mlp3_elu_f32")
+            fin = getattr(self, "_pending_fin", None)      # the previous step's meter fold rides on workgroup 0 (round 4)
+            self._pending_fin = None
+            fused._check(lib.vine_mlp3_elu_f32_fin(N, xh.data_ptr(), xh.stride(0), obs.data_ptr(), f["F"],
+                                                   rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                                   float(rms.epsilon), 5.0, f["w1p_f32"].data_ptr(), 32, b1.data_ptr(), 256,
+                                                   W2.data_ptr(), W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(),
+                                                   W3.stride(0), b3.data_ptr(), 64, 1.0,
+                                                   *(fin if fin is not None else (None, 0.0, None, None, 0)), st),
+                         "vine_mlp3_elu_f32_fin")
         elif mlp3:
             # observation normalisation and the whole MLP in ONE launch: the kernel normalises the raw observations
             # itself, writes them (bf16, zero-padded) into the LSTM operand's observation block and carries the
@@ -650,6 +655,10 @@ class A2CAgent:
             self._obs_last = torch.empty_like(obs)
         h_op_stride = self._fast["XW"] + H if fast else 0
         h_op_bf16 = int(fast and self._fast["op"] != torch.float32)
+        defer_fin = bool(fast and self._fast["f32_mfma"] and len(self._fast["mlp"]) == 3 and obs.is_contiguous()
+                         and obs.dtype == torch.float32 and os.environ.get("VINE_ROLLOUT_FIN_RIDE", "1") != "0")
+        post_blocks = int(lib.vine_rollout_post_blocks(N)) if defer_fin else 0
+        self._pending_fin = None
         for n in range(self.horizon_length):
             if n % self.seq_len == 0 and not (batched and n == 0):
                 if batched:          # both states in one launch
@@ -682,6 +691,20 @@ class A2CAgent:
                 obs_d, rewards, dones, infos = self.vec_env.step(buf["actions"][n])
                 obs = obs_d["obs"]
                 dones_dst = self.dones
+            h_op_ptr = ((self._fast["xh2"][self._fast["cur"]].data_ptr()
+                         + self._fast["xh2"][0].element_size() * self._fast["XW"]) if fast else None)
+            if defer_fin:
+                # per-env pass only; the one-workgroup fold of its episode sums (meters, rollout counter) rides in the next
+                # inference's MLP launch -- always one more follows: the next step's, or the last-values forward below
+                fused._check(lib.vine_rollout_post_defer(
+                    N, H, env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), env.timeout_buf.data_ptr(),
+                    buf["values"][n].data_ptr(), float(self.reward_shift), float(self.reward_scale), gamma_b,
+                    buf["rewards"][n].data_ptr(), dones_dst.data_ptr(), self.current_rewards.data_ptr(),
+                    self.current_lengths.data_ptr(), self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr(),
+                    h_op_ptr, h_op_stride, h_op_bf16, self._post_scratch.data_ptr(), st), "vine_rollout_post_defer")
+                self._pending_fin = (self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(),
+                                     self._post_scratch.data_ptr(), post_blocks)
+                continue
             fused._check(lib.vine_rollout_post(
                 N, H, env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), env.timeout_buf.data_ptr(),
                 buf["values"][n].data_ptr(), float(self.reward_shift), float(self.reward_scale), gamma_b,
@@ -689,9 +712,7 @@ class A2CAgent:
                 self.current_lengths.data_ptr(), self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr(),
                 self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(),
                 # the operand copy of h that the NEXT step reads (the buffer _infer just switched to)
-                (self._fast["xh2"][self._fast["cur"]].data_ptr()
-                 + self._fast["xh2"][0].element_size() * self._fast["XW"]) if fast else None, h_op_stride,
-                h_op_bf16, self._post_scratch.data_ptr(), st), "vine_rollout_post")
+                h_op_ptr, h_op_stride, h_op_bf16, self._post_scratch.data_ptr(), st), "vine_rollout_post")
         self.obs = obs
         y = self._infer(obs, commit=False) if fast else trunk(obs)[0]
         scratch = self._head_scratch
@@ -1219,12 +1240,16 @@ class A2CAgent:
         upd_range.__exit__()
         update_time = time.time() - t_upd
         if ev:
-            # (the split of an iteration as the device saw it -- the previous one's when the wait is deferred: the same in
-            # steady state -- applied to the host's wall time of this call)
             gp, gu = timed[0].elapsed_time(timed[1]) * 1e-3, timed[1].elapsed_time(timed[2]) * 1e-3
-            total = play_time + update_time
-            play_time = total * gp / max(gp + gu, 1e-12)
-            update_time = total - play_time
+            if timed is ev:
+                # (the split of the iteration as the device saw it; the sum is the host's wall time of the iteration)
+                total = play_time + update_time
+                play_time = total * gp / max(gp + gu, 1e-12)
+                update_time = total - play_time
+            else:
+                # deferred wait: the host's time inside this call says nothing (it only queues work) -- report the DEVICE
+                # times of the previous iteration (rollout start -> rollout end -> update end: the same quantity in steady state)
+                play_time, update_time = gp, gu
         m = rows.mean(0)
         stats = {"a_loss": m[0], "c_loss": m[1], "entropy": m[3], "kl": m[4], "b_loss": m[2]}
         return play_time, update_time, stats
