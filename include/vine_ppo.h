@@ -500,6 +500,15 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
                      float* mu_out, float* sigma_out, float* value_out, float* action_out, float* neglogp_out,
                      const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
 
+/* vine_policy_head reading the value normaliser's float64 running statistics itself (round 4): value un-normalised as
+ * clamp(v, +-5) * sqrt(float(running_var) + value_eps) + float(running_mean) -- RunningMeanStd's own arithmetic; saves the
+ * caller the four scalar launches that formed the two floats at the head of every rollout. */
+int vine_policy_head_rms(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
+                         const float* w_v, const float* b_v, const float* logstd, const double* running_mean,
+                         const double* running_var, float value_eps, uint64_t seed, const int64_t* counter, float* mu_out,
+                         float* sigma_out, float* value_out, float* action_out, float* neglogp_out, const float* ln_gamma,
+                         const float* ln_beta, float ln_eps, void* stream);
+
 /* Rollout, post-step bookkeeping in two launches (per-env pass + one-workgroup finalise):
  *   shaped = (rew + shift) * scale + gamma_bootstrap * value * time_out          (reward_shaper PY:58-59, value_bootstrap PY:56)
  *   dones_out = reset != 0;  cur_rewards += rew;  cur_lengths += 1

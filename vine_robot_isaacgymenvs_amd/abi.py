@@ -245,6 +245,8 @@ PPO_PROTOTYPES = {
     "vine_column_sums": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _I64, _VP, C.c_int32, _VP]),
     "vine_policy_head": (C.c_int, [_I64, C.c_int32, _I64] + [_VP] * 8 + [C.c_int32, C.c_uint64] + [_VP] * 6 +
                          [_VP, _VP, C.c_float, _VP]),
+    "vine_policy_head_rms": (C.c_int, [_I64, C.c_int32, _I64] + [_VP] * 8 + [C.c_float, C.c_uint64] + [_VP] * 6 +
+                             [_VP, _VP, C.c_float, _VP]),
     "vine_rollout_post": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 7 + [C.c_float, _VP, _VP, _I64,
                                                                                                   C.c_int32, _VP, _VP]),
     "vine_rollout_post_blocks": (C.c_int32, [_I64]),

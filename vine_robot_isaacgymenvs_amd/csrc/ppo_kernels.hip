@@ -4071,7 +4071,7 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
                                                           float* __restrict__ sigma_out, float* __restrict__ value_out,
                                                           float* __restrict__ action_out, float* __restrict__ neglogp_out,
                                                           const float* __restrict__ ln_gamma,
-                                                          const float* __restrict__ ln_beta, float ln_eps) {
+                                                          const float* __restrict__ ln_beta, float ln_eps, float value_eps) {
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -4114,7 +4114,11 @@ __global__ __launch_bounds__(256) void policy_head_kernel(long long N, int A, in
         }
         if (lane == 0) {
             float v = acc[HEAD_MAX_A] + b_v[0];
-            if (normalize_value) v = fminf(fmaxf(v, -5.0f), 5.0f) * vstd[0] + vmean[0];
+            if (normalize_value == 2) {      // RunningMeanStd's own float64 statistics: mean.float(), sqrt(var.float() + eps)
+                const float vm = (float)reinterpret_cast<const double*>(vmean)[0];
+                const float vs = sqrtf((float)reinterpret_cast<const double*>(vstd)[0] + value_eps);
+                v = fminf(fmaxf(v, -5.0f), 5.0f) * vs + vm;
+            } else if (normalize_value) v = fminf(fmaxf(v, -5.0f), 5.0f) * vstd[0] + vmean[0];
             value_out[e] = v;
             float nlp = 0.9189385332046727f * A;
             unsigned r[4];
@@ -4154,7 +4158,7 @@ __global__ __launch_bounds__(256) void policy_head16_kernel(long long N, int A, 
                                                             float* __restrict__ sigma_out, float* __restrict__ value_out,
                                                             float* __restrict__ action_out, float* __restrict__ neglogp_out,
                                                             const float* __restrict__ ln_gamma,
-                                                            const float* __restrict__ ln_beta, float ln_eps) {
+                                                            const float* __restrict__ ln_beta, float ln_eps, float value_eps) {
     constexpr int H = 256;
     const int lane = threadIdx.x & 63, sub = lane >> 4, cl = lane & 15;
     const long long e = ((((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 2) + sub;      // N % 4 == 0 (host check)
@@ -4200,7 +4204,11 @@ __global__ __launch_bounds__(256) void policy_head16_kernel(long long N, int A, 
         if (k < A || k == HEAD_MAX_A) acc[k] = row_allsum16(acc[k]);
     if (cl == 0) {
         float v = acc[HEAD_MAX_A] + b_v[0];
-        if (normalize_value) v = fminf(fmaxf(v, -5.0f), 5.0f) * vstd[0] + vmean[0];
+        if (normalize_value == 2) {          // RunningMeanStd's own float64 statistics: mean.float(), sqrt(var.float() + eps)
+            const float vm = (float)reinterpret_cast<const double*>(vmean)[0];
+            const float vs = sqrtf((float)reinterpret_cast<const double*>(vstd)[0] + value_eps);
+            v = fminf(fmaxf(v, -5.0f), 5.0f) * vs + vm;
+        } else if (normalize_value) v = fminf(fmaxf(v, -5.0f), 5.0f) * vstd[0] + vmean[0];
         value_out[e] = v;
         float nlp = 0.9189385332046727f * A;
         unsigned r[4];
@@ -5840,11 +5848,37 @@ int vine_ln_heads_loss_rows(void) {
     return 8 * ((rw == 8 || rw == 4) ? rw : 16);
 }
 
+static int policy_head_launch(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
+                              const float* w_v, const float* b_v, const float* logstd, const float* value_mean,
+                              const float* value_std, int32_t normalize_value, float value_eps, uint64_t seed,
+                              const int64_t* counter, float* mu_out, float* sigma_out, float* value_out, float* action_out,
+                              float* neglogp_out, const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream);
+
 int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
                      const float* w_v, const float* b_v, const float* logstd, const float* value_mean,
                      const float* value_std, int32_t normalize_value, uint64_t seed, const int64_t* counter,
                      float* mu_out, float* sigma_out, float* value_out, float* action_out, float* neglogp_out,
                      const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
+    return policy_head_launch(N, A, H, y, w_mu, b_mu, w_v, b_v, logstd, value_mean, value_std, normalize_value ? 1 : 0, 0.0f, seed,
+                              counter, mu_out, sigma_out, value_out, action_out, neglogp_out, ln_gamma, ln_beta, ln_eps, stream);
+}
+
+int vine_policy_head_rms(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
+                         const float* w_v, const float* b_v, const float* logstd, const double* running_mean,
+                         const double* running_var, float value_eps, uint64_t seed, const int64_t* counter, float* mu_out,
+                         float* sigma_out, float* value_out, float* action_out, float* neglogp_out, const float* ln_gamma,
+                         const float* ln_beta, float ln_eps, void* stream) {
+    if (!running_mean || !running_var) return VINE_ERR_INVALID_ARG;
+    return policy_head_launch(N, A, H, y, w_mu, b_mu, w_v, b_v, logstd, reinterpret_cast<const float*>(running_mean),
+                              reinterpret_cast<const float*>(running_var), 2, value_eps, seed, counter, mu_out, sigma_out,
+                              value_out, action_out, neglogp_out, ln_gamma, ln_beta, ln_eps, stream);
+}
+
+static int policy_head_launch(int64_t N, int32_t A, int64_t H, const float* y, const float* w_mu, const float* b_mu,
+                              const float* w_v, const float* b_v, const float* logstd, const float* value_mean,
+                              const float* value_std, int32_t normalize_value, float value_eps, uint64_t seed,
+                              const int64_t* counter, float* mu_out, float* sigma_out, float* value_out, float* action_out,
+                              float* neglogp_out, const float* ln_gamma, const float* ln_beta, float ln_eps, void* stream) {
     if (N <= 0 || A <= 0 || A > HEAD_MAX_A || H <= 0 || (H & 3) || !y || !w_mu || !b_mu || !w_v || !b_v || !logstd ||
         !counter || !mu_out || !sigma_out || !value_out || !action_out || !neglogp_out ||
         (normalize_value && (!value_mean || !value_std)) || ((ln_gamma == nullptr) != (ln_beta == nullptr)))
@@ -5854,7 +5888,7 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
         hipLaunchKernelGGL(policy_head16_kernel, dim3((unsigned)(N / 16)), dim3(256), 0, (hipStream_t)stream, (long long)N,
                            (int)A, y, w_mu, b_mu, w_v, b_v, logstd, value_mean, value_std, (int)normalize_value,
                            (unsigned)seed, (unsigned)(seed >> 32), (const long long*)counter, mu_out, sigma_out, value_out,
-                           action_out, neglogp_out, ln_gamma, ln_beta, ln_eps);
+                           action_out, neglogp_out, ln_gamma, ln_beta, ln_eps, value_eps);
         return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
     }
     const int threads = 256;                     // 4 waves per workgroup, one env per wave at a time
@@ -5863,7 +5897,7 @@ int vine_policy_head(int64_t N, int32_t A, int64_t H, const float* y, const floa
     hipLaunchKernelGGL(policy_head_kernel, dim3((int)blocks), dim3(threads), 0, (hipStream_t)stream, (long long)N, (int)A,
                        (int)H, y, w_mu, b_mu, w_v, b_v, logstd, value_mean, value_std, (int)normalize_value,
                        (unsigned)seed, (unsigned)(seed >> 32), (const long long*)counter, mu_out, sigma_out, value_out,
-                       action_out, neglogp_out, ln_gamma, ln_beta, ln_eps);
+                       action_out, neglogp_out, ln_gamma, ln_beta, ln_eps, value_eps);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

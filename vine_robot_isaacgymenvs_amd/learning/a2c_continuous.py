@@ -602,9 +602,13 @@ class A2CAgent:
         env = getattr(self.vec_env, "env", self.vec_env)
         N, A, H = self.num_actors, self.actions_num, net.rnn_units
         st = torch.cuda.current_stream(self.device).cuda_stream
-        if self.normalize_value:
-            vmean = m.value_mean_std.running_mean.float()
-            vstd = torch.sqrt(m.value_mean_std.running_var.float() + m.value_mean_std.epsilon)
+        vms = m.value_mean_std if self.normalize_value else None
+        # the head kernel reads the value normaliser's float64 statistics itself (vine_policy_head_rms: the module's own
+        # mean.float(), sqrt(var.float() + eps)); the two-float form stays for other callers of vine_policy_head
+        head_rms = vms is not None and vms.running_mean.numel() == 1 and vms.running_mean.dtype == torch.float64
+        if vms is not None and not head_rms:
+            vmean = vms.running_mean.float()
+            vstd = torch.sqrt(vms.running_var.float() + vms.epsilon)
         else:
             vmean = vstd = None
         gamma_b = float(self.gamma) if self.value_bootstrap else 0.0
@@ -614,6 +618,15 @@ class A2CAgent:
             # x: the LayerNorm output, or (fused inference with H == 256) the raw LSTM output: the head kernel then
             # applies the LayerNorm itself
             ln = net.layer_norm if (fast and self._fast["ln_in_head"]) else None
+            if head_rms:
+                fused._check(lib.vine_policy_head_rms(
+                    N, A, H, x.data_ptr(), net.mu.weight.data_ptr(), net.mu.bias.data_ptr(), net.value.weight.data_ptr(),
+                    net.value.bias.data_ptr(), net.sigma.data_ptr(), vms.running_mean.data_ptr(), vms.running_var.data_ptr(),
+                    float(vms.epsilon), self.head_seed, self.roll_counter.data_ptr(), mu_out.data_ptr(), sigma_out.data_ptr(),
+                    value_out.data_ptr(), act_out.data_ptr(), nlp_out.data_ptr(),
+                    ln.weight.data_ptr() if ln is not None else None, ln.bias.data_ptr() if ln is not None else None,
+                    float(ln.eps) if ln is not None else 0.0, st), "vine_policy_head_rms")
+                return
             fused._check(lib.vine_policy_head(
                 N, A, H, x.data_ptr(), net.mu.weight.data_ptr(), net.mu.bias.data_ptr(), net.value.weight.data_ptr(),
                 net.value.bias.data_ptr(), net.sigma.data_ptr(), vmean.data_ptr() if vmean is not None else None,
