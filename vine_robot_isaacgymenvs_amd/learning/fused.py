@@ -197,6 +197,15 @@ BWD_PHASES = _os.environ.get("VINE_BWD_PHASES", "1") != "0"
 # LSTM forward + LayerNorm / heads / loss + LSTM backward + MLP backward as four phases of one launch; 0: separate launches
 TRUNK_PHASES = _os.environ.get("VINE_TRUNK_PHASES", "1") != "0"
 PHASE_LAUNCHES = [0]      # vine_trunk_phases launches (tests look at it)
+WGRAD_SIDE = _os.environ.get("VINE_WGRAD_SIDE", "0") == "1"      # MLP weight gradients on a parallel branch (experiment)
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 WGRAD_CAT = _os.environ.get("VINE_WGRAD_CAT", "1") != "0"      # second-generation weight-gradient kernel (A/B knob)
 WGRAD_CAT_WGS = int(_os.environ.get("VINE_WGRAD_CAT_WGS", "512"))   # workgroups a launch aims for (2 per CU)
 WGRAD_WIDE_BM = int(_os.environ.get("VINE_WGRAD_WIDE_BM", "128"))   # 128 | 64 rows of dy^T per workgroup tile (A/B knob)
@@ -1295,6 +1304,12 @@ class _Trunk(torch.autograd.Function):
                                                     w_hh_t=ctx.w_hh_t, c0_direct=c0_direct, w_hh_tiled=ctx.w_hh_tiled,
                                                     c_last=c_last)
         fused2 = False
+        ctx.wgrad_fork = None
+        if WGRAD_SIDE and gzs is not None:
+            cur = torch.cuda.current_stream(dev)
+            side = _side_stream(dev)
+            side.wait_stream(cur)            # (fork: everything the MLP weight gradients read is complete on `cur`)
+            ctx.wgrad_fork = (side, cur)
         if ctx.h_once and mixed and slots[base + 0] is not None and slots[base + 1] is not None:
             # ``out`` is the one 16-bit copy of the hidden states (slot 0 = h0): the kernel shifts and masks
             fused2 = weight_grad_cat(dG, xcat, out, slots[base + 0], slots[base + 1], batch=batch, seq=(dones, T))
@@ -1378,7 +1393,17 @@ class _Trunk(torch.autograd.Function):
             else:
                 g = _mm(gz, weights[i])
                 gz = None
-        wgroup.flush()                      # the MLP weight gradients: one launch, all operands exist by now
+        # the MLP weight gradients: one launch, all operands exist by now.  WGRAD_SIDE (round 4 experiment): on a side stream --
+        # a parallel branch of the captured graph -- beside the LSTM weight-gradient kernel issued above: that kernel holds
+        # 8 waves x 196 VGPRs and 64 KB of LDS per CU, which leaves room for exactly one 4-wave workgroup of this one
+        if WGRAD_SIDE and getattr(ctx, "wgrad_fork", None) is not None:
+            side, cur = ctx.wgrad_fork
+            with torch.cuda.stream(side):
+                wgroup.flush()
+            cur.wait_stream(side)
+            ctx.wgrad_fork = None
+        else:
+            wgroup.flush()
         if batch is not None:
             if batch.bypassed and amp is not None:
                 ctx.loss_pack["amp_covered"] = False     # (coverage is per delivery, not per batch)
