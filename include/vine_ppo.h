@@ -463,6 +463,22 @@ int vine_mlp3_elu_f32_fin(int64_t n, float* x, int64_t ldx, const float* raw, in
                           const float* w2, int64_t ldw2, const float* b2, int64_t C2, const float* w3, int64_t ldw3,
                           const float* b3, int64_t C3, float alpha, float* fin_meter, float fin_max_size, int64_t* fin_counter,
                           const float* fin_scratch, int32_t fin_blocks, void* stream);
+/* The same launch with EXACT products from bf16 pieces (the arithmetic of vine_lstm_step_f32_split, below): the four waves
+ * of a workgroup share 16 rt rows and own a quarter of each layer's units; weights as vine_mlp3_tile_weights_split
+ * leaves them (wt: 288 fragments x 1 KB of bfloat16 pieces), activations between the layers split once by their producer
+ * and exchanged through LDS.  terms: piece pairs (9 = every bit of every product, 6 = without the three pairs below
+ * 2^-26 of a product) in the low byte, row tiles per workgroup (1, 2, 4; 0 = chosen from n) in the second.  C1 = 256,
+ * C2 = 128, C3 = 64 fixed; F_in <= 32, n % (16 rt) == 0, ldx >= 96, else VINE_ERR_UNSUPPORTED.  fin_* as
+ * vine_mlp3_elu_f32_fin.  Same output block as vine_mlp3_elu_f32.  (Replaces, on the rollout path, the fp32 network forward
+ * of rl_games' play_steps: a2c_common.py's get_action_values -> model(...) under torch.no_grad, not autocast.) */
+int vine_mlp3_elu_f32_split(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean,
+                            const double* var, float eps, float clip, const void* wt, const float* b1, const float* b2,
+                            const float* b3, float alpha, int terms, float* fin_meter, float fin_max_size,
+                            int64_t* fin_counter, const float* fin_scratch, int32_t fin_blocks, void* stream);
+/* w1 [256, F_in] (rows ldw1 apart; columns F_in .. 31 are taken as zero), w2 [128, 256], w3 [64, 128], fp32 -> dst:
+ * 288 * 512 bfloat16 (16-byte aligned), [layer][wave][k-block][unit tile][piece][lane][8]. */
+int vine_mlp3_tile_weights_split(const float* w1, int64_t ldw1, int64_t F_in, const float* w2, int64_t ldw2, const float* w3,
+                                 int64_t ldw3, void* dst, void* stream);
 int vine_lstm_step_f32(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const float* w_tiled, const float* bias,
                        const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next, int64_t ldhp,
                        void* stream);

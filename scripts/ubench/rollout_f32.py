@@ -45,6 +45,32 @@ def mlp(i):
                                  Ws[2].data_ptr(), 128, bs[2].data_ptr(), 64, 1.0, st) == 0
 
 
+wm = torch.empty(288 * 512, device=dev, dtype=torch.bfloat16)
+assert lib.vine_mlp3_tile_weights_split(Ws[0].data_ptr(), F, F, Ws[1].data_ptr(), 256, Ws[2].data_ptr(), 128, wm.data_ptr(), st) == 0
+
+
+def mlp_split(variant, rows):
+    def run(i):
+        a = xh[i & 1]
+        assert lib.vine_mlp3_elu_f32_split(rows, a.data_ptr(), K, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                                           wm.data_ptr(), bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr(), 1.0, variant,
+                                           None, 0.0, None, None, 0, st) == 0
+    return run
+
+
+def mlp_rows(rows):
+    def run(i):
+        a = xh[i & 1]
+        assert lib.vine_mlp3_elu_f32(rows, a.data_ptr(), K, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                                     w1p.data_ptr(), 32, bs[0].data_ptr(), 256, Ws[1].data_ptr(), 256, bs[1].data_ptr(), 128,
+                                     Ws[2].data_ptr(), 128, bs[2].data_ptr(), 64, 1.0, st) == 0
+    return run
+
+
+MLP_FLOP = 2.0 * (32 * 256 + 256 * 128 + 128 * 64)
+MLPS = tuple(("mlp_split t%d rt%d n%d" % (t, rt, rows), mlp_split(t + 256 * rt, rows), MLP_FLOP * rows)
+             for rows in (16384, 4096) for t in (9, 6) for rt in (4, 2, 1)) + \
+    (("mlp3_elu_f32 n4096", mlp_rows(4096), MLP_FLOP * 4096),)
 ws = torch.empty(3 * 4 * H * K, device=dev, dtype=torch.bfloat16)
 assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), K, ws.data_ptr(), st) == 0
 
@@ -58,7 +84,7 @@ def lstm_split(variant):
 
 
 SPLITS = tuple(("lstm_split t%d rt%d" % (t, rt), lstm_split(t + 256 * rt), 2.0 * N * K * 4 * H) for t in (9, 6) for rt in (4, 2))
-for name, fn, flop in SPLITS + (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("mlp3_elu_f32", mlp, 2.0 * N * (32 * 256 + 256 * 128 + 128 * 64))):
+for name, fn, flop in MLPS + SPLITS + (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("mlp3_elu_f32", mlp, 2.0 * N * (32 * 256 + 256 * 128 + 128 * 64))):
     for i in range(5):
         fn(i)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,4 +94,4 @@ for name, fn, flop in SPLITS + (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
-    print("%-16s %7.1f us   %6.1f TFLOP/s  (%.0f %% of the 157.3 TFLOP/s fp32 matrix peak)" % (name, us, flop / us / 1e6, flop / us / 1e6 / 157.3 * 100))
+    print("%-24s %7.1f us   %6.1f TFLOP/s  (%.0f %% of the 157.3 TFLOP/s fp32 matrix peak)" % (name, us, flop / us / 1e6, flop / us / 1e6 / 157.3 * 100))

@@ -2097,6 +2097,64 @@ def test_mlp3_elu_f32_against_float64_torch(F):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F,n,terms", [(28, 1024, 9 + 256 * 1), (18, 1024, 9 + 256 * 2), (28, 4096, 9), (28, 16384, 9),
+                                       (18, 8192, 9), (28, 2048, 6 + 256 * 4), (28, 4096, 6)])
+def test_mlp3_elu_f32_split_against_float64_torch(F, n, terms):
+    """vine_mlp3_elu_f32_split (products formed exactly from bf16 pieces on the bf16 matrix cores, four waves sharing the rows
+    and splitting the units, activations exchanged through LDS as pieces) against the float64 torch composition: held to
+    the native fp32 kernel's bound AND to that kernel's own error on the same inputs; the observation block is bit-identical
+    to the native kernel's.  ``terms``: piece pairs in the low byte, row tiles per workgroup in the second (0: from n)."""
+    from vine_robot_isaacgymenvs_amd import native
+    lib = native.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(F + n)
+    ldx = 352
+    raw = torch.randn(n, F, device=dev) * 2.0 + 0.3
+    mean = torch.randn(F, device=dev, dtype=torch.float64) * 0.2
+    var = torch.rand(F, device=dev, dtype=torch.float64) + 0.3
+    # weights spanning several binades, so that a piece rounded away would show
+    Ws = [torch.randn(o, i, device=dev) / np.sqrt(i) * torch.exp2(torch.randint(-6, 2, (o, i), device=dev).float())
+          for o, i in ((256, F), (128, 256), (64, 128))]
+    bs = [torch.randn(o, device=dev) * 0.1 for o in (256, 128, 64)]
+    st = torch.cuda.current_stream().cuda_stream
+    wt = torch.empty(288 * 512, device=dev, dtype=torch.bfloat16)
+    assert lib.vine_mlp3_tile_weights_split(Ws[0].data_ptr(), Ws[0].stride(0), F, Ws[1].data_ptr(), Ws[1].stride(0),
+                                            Ws[2].data_ptr(), Ws[2].stride(0), wt.data_ptr(), st) == 0
+    # the pieces of a fragment sum back to the fp32 weights (layer 2: [wave][k-block][tile][piece][lane][8])
+    l2 = wt[48 * 512:(48 + 192) * 512].view(4, 8, 2, 3, 64, 8).float().sum(dim=3)
+    wv, kb, t, lane, e = torch.meshgrid(*(torch.arange(k, device=dev) for k in l2.shape), indexing="ij")
+    assert torch.equal(l2, Ws[1][32 * wv + 16 * t + (lane & 15), 32 * kb + 8 * (lane >> 4) + e])
+    x = torch.full((n, ldx), 7.0, device=dev)
+    rc = lib.vine_mlp3_elu_f32_split(n, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                                     wt.data_ptr(), bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr(), 1.0, terms,
+                                     None, 0.0, None, None, 0, st)
+    assert rc == 0
+    # the native fp32 matrix-core kernel on the same inputs
+    x_ref = torch.full((n, ldx), 7.0, device=dev)
+    w1p = torch.zeros(256, 32, device=dev)
+    w1p[:, :F] = Ws[0]
+    assert lib.vine_mlp3_elu_f32(n, x_ref.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                                 w1p.data_ptr(), 32, bs[0].data_ptr(), 256, Ws[1].data_ptr(), Ws[1].stride(0),
+                                 bs[1].data_ptr(), 128, Ws[2].data_ptr(), Ws[2].stride(0), bs[2].data_ptr(), 64, 1.0, st) == 0
+    torch.cuda.synchronize()
+    xn = torch.clamp((raw - mean.float()) / torch.sqrt(var.float() + 1e-5), -5.0, 5.0)
+    a = xn.double()
+    for W, b in zip(Ws, bs):
+        a = torch.nn.functional.elu(a @ W.double().t() + b.double())
+    err = float((x[:, :64].double() - a).abs().max())
+    err_ref = float((x_ref[:, :64].double() - a).abs().max())
+    print("terms 0x%x: max |y - f64| %.3e (native fp32 MFMA kernel %.3e), max |y| %.2f" % (terms, err, err_ref, float(a.abs().max())))
+    assert err < 2e-5 * max(1.0, float(a.abs().max()))
+    assert err <= 1.5 * err_ref + 1e-7
+    assert torch.equal(x[:, 64:], x_ref[:, 64:])                       # observation block; nothing else touched
+    assert torch.equal(x[:, 64:64 + F], xn) and float(x[:, 64 + F:96].abs().max()) == 0.0
+    bad = lib.vine_mlp3_elu_f32_split(n + 8, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5,
+                                      5.0, wt.data_ptr(), bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr(), 1.0, terms,
+                                      None, 0.0, None, None, 0, st)
+    assert bad == -2
+
+
+@pytest.mark.gpu
 def test_lstm_step_f32_against_float64_torch():
     """vine_lstm_step_f32 (gate GEMM over [x | h] on the fp32 matrix cores + the cell update as its epilogue) against
     float64 torch with torch.nn.LSTM's gate order; the second copy of h (next step's operand block) too."""

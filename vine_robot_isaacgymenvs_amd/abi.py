@@ -219,6 +219,9 @@ PPO_PROTOTYPES = {
                                     _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP]),
     "vine_mlp3_elu_f32_fin": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _I64, _VP, _I64, _VP, _I64,
                                         _VP, _I64, _VP, _I64, _VP, _I64, C.c_float, _VP, C.c_float, _VP, _VP, C.c_int32, _VP]),
+    "vine_mlp3_elu_f32_split": (C.c_int, [_I64, _VP, _I64, _VP, _I64, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, _VP, C.c_float,
+                                          C.c_int, _VP, C.c_float, _VP, _VP, C.c_int32, _VP]),
+    "vine_mlp3_tile_weights_split": (C.c_int, [_VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP]),
     "vine_lstm_step_f32": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _I64, _VP]),
     "vine_lstm_tile_weights_f32": (C.c_int, [_I64, _I64, _VP, _I64, _VP, _VP]),
     "vine_lstm_step_f32_split": (C.c_int, [_I64, _I64, _I64, _VP, _I64, _VP, _VP, _VP, _VP, _I64, _VP, _VP, _I64, C.c_int, _VP]),

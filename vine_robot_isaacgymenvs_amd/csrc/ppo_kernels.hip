@@ -1372,18 +1372,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     // ---- this lane's B fragment of layer 1: columns 8 q .. 8 q + 7 of its row (requested before the weight staging)
     lp16x8_t af1;
     if (raw) {
-        float v[8];
+        // (branch-free, clamped addresses: all 24 loads in flight at once -- a per-column `if` compiles to one memory
+        // round trip per column, in front of the weight staging below)
+        float rv[8], v[8];
+        double mud[8], vrd[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = 8 * q + e;
-            float y = 0.0f;
-            if (c < F_in) {
-                // same arithmetic as normalize_obs_kernel: statistics cast to float first
-                const float m = (float)mean[c], sd = sqrtf((float)var[c] + eps);
-                y = (raw[b * F_in + c] - m) / sd;
-                y = fminf(fmaxf(y, -clip), clip);
-            }
-            v[e] = y;
+            const int cc = min(8 * q + e, F_in - 1);
+            rv[e] = raw[b * F_in + cc];
+            mud[e] = mean[cc];
+            vrd[e] = var[cc];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // same arithmetic as normalize_obs_kernel: statistics cast to float first
+            const float m = (float)mud[e], sd = sqrtf((float)vrd[e] + eps);
+            const float y = fminf(fmaxf((rv[e] - m) / sd, -clip), clip);
+            v[e] = 8 * q + e < F_in ? y : 0.0f;
         }
         const uint4 pk = pack_lp16x8(v);
         af1 = __builtin_bit_cast(lp16x8_t, pk);
@@ -4827,6 +4832,272 @@ __global__ __launch_bounds__(256) void mlp3_elu_f32_kernel(long long n, float* _
 #undef MLP_F32_A2
 }
 
+// ---- the same three layers with EXACT products from bf16 pieces (round 4; the arithmetic of lstm_step_split_kernel: an fp32
+// operand is the exact sum of three bfloat16 pieces, a piece product is exact in the matrix core's fp32 accumulator, NT = 9
+// piece pairs = every bit of every fp32 product, 9 v_mfma_f32_16x16x32_bf16 instead of 8 v_mfma_f32_16x16x4_f32 at twice the
+// rate per instruction: 864 x 16 cycles per 16 rows instead of 768 x 32).
+// The split of the work is the other way round than in mlp3_elu_f32_kernel: the four waves of a workgroup share the SAME
+// 16 RT rows and each owns a QUARTER OF THE UNITS of every layer (layer 1: 4 unit tiles, layer 2: 2, layer 3: 1).  A wave's
+// weight fragments are then its own: they come straight from global memory in fragment order (vine_mlp3_tile_weights_split:
+// [layer][wave][k-block][tile][piece][lane][8], one 16-B load per lane and fragment, D k-blocks ahead), every weight byte
+// enters the CU once and never touches LDS.  LDS carries the activations between the layers instead: the producing wave
+// applies bias + ELU, splits each value ONCE into its three pieces and writes them in the consumer's fragment order
+// ([row tile][k-block][piece][lane][8]: a B fragment is one conflict-free ds_read_b128 per lane); two barriers per
+// launch.  With RT row tiles a weight fragment feeds 3 RT matrix instructions, an activation fragment 3 TILES.
+// At 4096 rows (RT = 1) all 1024 SIMDs work on 256 row tiles, where the one-wave-per-row-tile kernel above fills a quarter
+// of them with 768 dependent instructions each.
+#ifdef SPLIT_TIMING
+// (debug build, scripts/ubench/mlp_split_clock.py) per wave: s_memtime / s_memrealtime at 8 points of mlp3_elu_split_kernel
+__device__ unsigned long long mlp_split_t[4096 * 16];
+#define MLP_STAMP(i)                                                                                                    \
+    if (lane == 0) {                                                                                                    \
+        mlp_split_t[((blockIdx.x * 4 + wave) & 4095) * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime();                     \
+        mlp_split_t[((blockIdx.x * 4 + wave) & 4095) * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();             \
+    }
+#else
+#define MLP_STAMP(i)
+#endif
+__device__ __forceinline__ void split3_bf16x4(const float (&v)[4], uint2& hi, uint2& mid, uint2& lo) {
+    unsigned h[2], m[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // (two values at a time: the residual subtractions as one packed instruction each)
+        const f32x2_t ab = {v[2 * i], v[2 * i + 1]};
+        h[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(ab, bf16x2_t));
+        const f32x2_t hf = {__uint_as_float(h[i] << 16), __uint_as_float(h[i] & 0xFFFF0000u)};
+        const f32x2_t r = ab - hf;
+        m[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+        const f32x2_t mf = {__uint_as_float(m[i] << 16), __uint_as_float(m[i] & 0xFFFF0000u)};
+        const f32x2_t s2 = r - mf;
+        l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(s2, bf16x2_t));
+    }
+    hi = make_uint2(h[0], h[1]);
+    mid = make_uint2(m[0], m[1]);
+    lo = make_uint2(l[0], l[1]);
+}
+// fragments (64 uint4 each) of the tiled weights: layer 1 [4 waves][1][4 tiles][3], layer 2 [4][8][2][3], layer 3 [4][4][1][3]
+#define MLP_SPLIT_L2_BASE 48
+#define MLP_SPLIT_L3_BASE (48 + 192)
+#define MLP_SPLIT_FRAGS (48 + 192 + 48)
+// the weight fragments of one layer in flight: a ring of D + 1 k-blocks (all indices are compile-time after unrolling)
+template <int TILES, int D>
+struct MlpSplitRing {
+    uint4 f[D + 1][TILES][3];
+    __device__ __forceinline__ void issue(const uint4* __restrict__ src, int kb) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[kb % (D + 1)][t][p] = src[((kb * TILES + t) * 3 + p) * 64];
+    }
+};
+// one layer of one wave: acc[t][rt] += W(tile t) . act(row tile rt) over KB k-blocks.  `ring` holds k-blocks 0 .. min(D, KB) - 1
+// on entry (requested by the caller ahead of the barrier in front of the layer).
+template <int TILES, int KB, int RT, int NT, int D>
+__device__ __forceinline__ void mlp_split_layer(MlpSplitRing<TILES, D>& ring, const uint4* __restrict__ a_src,
+                                                const uint4* b_lds, f32x4_t (&acc)[TILES][RT]) {
+    constexpr int NC = TILES * RT == 1 ? 2 : 1;        // a lone accumulator: alternate between two (dependent-issue stall)
+    constexpr int PP[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, QQ[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+    f32x4_t part[NC][TILES][RT];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) part[c][t][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    uint4 bfr[2][RT][3];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bfr[0][rt][p] = b_lds[((rt * KB + 0) * 3 + p) * 64];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (kb + D < KB) ring.issue(a_src, kb + D);
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bfr[(kb + 1) & 1][rt][p] = b_lds[((rt * KB + kb + 1) * 3 + p) * 64];
+        }
+#pragma unroll
+        for (int n = 9 - NT; n < 9; ++n)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    part[n % NC][t][rt] = mfma_bf16(ring.f[kb % (D + 1)][t][PP[n]], bfr[kb & 1][rt][QQ[n]], part[n % NC][t][rt]);
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[t][rt] = part[0][t][rt];
+            if (NC == 2) acc[t][rt] += part[NC - 1][t][rt];
+        }
+}
+// bias + ELU of one accumulator tile (units k0 + 4 g + {0..3} of the NEXT layer's K, batch row u of row tile rt), split into
+// pieces and written where the next layer's B fragments are read: k-block k >> 5, lane slot ((k & 31) >> 3) * 16 + u,
+// bytes 8 ((k >> 2) & 1) .. + 7 of the slot's 16
+template <int KBN>
+__device__ __forceinline__ void mlp_split_store(uint4* act, int rt, int k0, int lane, f32x4_t a, float4 bb, float alpha) {
+    const int u = lane & 15, g = lane >> 4;
+    const int k = k0 + 4 * g;
+    const float v[4] = {elu1(a[0] + bb.x, alpha), elu1(a[1] + bb.y, alpha), elu1(a[2] + bb.z, alpha), elu1(a[3] + bb.w, alpha)};
+    uint2 pc[3];
+    split3_bf16x4(v, pc[0], pc[1], pc[2]);
+    const int kb = k >> 5, slot = ((k & 31) >> 3) * 16 + u, half = (k >> 2) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        reinterpret_cast<uint2*>(act + ((rt * KBN + kb) * 3 + p) * 64 + slot)[half] = pc[p];
+}
+template <int RT, int NT>
+__global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float* __restrict__ x, long long ldx,
+                                                             const float* __restrict__ raw, int F_in,
+                                                             const double* __restrict__ mean, const double* __restrict__ var,
+                                                             float eps, float clip, const uint4* __restrict__ wt,
+                                                             const float* __restrict__ b1, const float* __restrict__ b2,
+                                                             const float* __restrict__ b3, float alpha, float* fin_meter,
+                                                             float fin_max_size, long long* fin_counter,
+                                                             const float* fin_partial, int fin_blocks) {
+    if (fin_meter && blockIdx.x == 0) rollout_finalize_body(fin_meter, fin_max_size, fin_counter, fin_partial, fin_blocks);
+    constexpr int R = 16 * RT;
+    constexpr int D = RT >= 4 ? 1 : (RT == 2 ? 2 : 3);       // k-blocks of weight fragments in flight ahead of the matrix loop
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw_split[];
+    // activations as B fragments: A0 (observations, 1 k-block) and A2 (layer-2 output, 4 k-blocks) share the front region
+    // (A0 is dead once layer 1 is through), A1 (layer-1 output, 8 k-blocks) sits behind it
+    uint4* act02 = reinterpret_cast<uint4*>(lds_raw_split);
+    uint4* act1 = act02 + RT * 4 * 3 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const long long row_base = (long long)blockIdx.x * R;
+    MLP_STAMP(0)
+    // this wave's weight fragments; layer 1 and the head of layer 2 are requested before anything else
+    const uint4* a1_src = wt + (long long)(wave * 1 * 4 * 3) * 64 + lane;
+    const uint4* a2_src = wt + (long long)(MLP_SPLIT_L2_BASE + wave * 8 * 2 * 3) * 64 + lane;
+    const uint4* a3_src = wt + (long long)(MLP_SPLIT_L3_BASE + wave * 4 * 1 * 3) * 64 + lane;
+    // the observation loads go first (everything waits for them: one memory round trip), the weight requests behind
+    const bool obs_thread = tid < 4 * R;
+    const int rl = tid >> 2, gq = tid & 3;
+    const long long row = row_base + rl;
+    // (branch-free: clamped addresses, every load in flight at once -- per-column `if`s compile to one round trip each)
+    float rv[8];
+    double mud[8], vrd[8];
+    const float* rrow = raw + (obs_thread ? row : row_base) * F_in;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int cc = min(8 * gq + i, F_in - 1);
+        rv[i] = rrow[cc];
+        mud[i] = mean[cc];
+        vrd[i] = var[cc];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler moved the 25 weight-fragment loads in front of them otherwise)
+    MlpSplitRing<4, 1> ring1;
+    MlpSplitRing<2, D> ring2;
+    MlpSplitRing<1, D> ring3;
+    ring1.issue(a1_src, 0);
+    // (the biases of this lane's units, all three layers: requested here, not in front of the epilogues)
+    float4 bb1[4], bb2[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bb1[t] = ld4(b1 + 64 * wave + 16 * t + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bb2[t] = ld4(b2 + 32 * wave + 16 * t + 4 * g);
+    const float4 bb = ld4(b3 + 16 * wave + 4 * g);
+    // ---- normalised observations: thread (row, 8-column group) -> the LSTM operand's observation block (fp32) and A0
+    // (computed AND written to LDS by every thread -- threads without a row write into the still unused A1 region: with
+    // every use under `if (obs_thread)` the compiler sinks the loads into the branch, behind the weight requests)
+    {
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // same arithmetic as normalize_obs_kernel: statistics cast to float first
+            const float sd = sqrtf((float)vrd[i] + eps);
+            const float v = fminf(fmaxf((rv[i] - (float)mud[i]) / sd, -clip), clip);
+            y[i] = 8 * gq + i < F_in ? v : 0.0f;
+        }
+        uint4 pc[3];
+        split3_bf16x8(y, pc[0], pc[1], pc[2]);
+        if (obs_thread) {
+            st4(x + row * ldx + 64 + 8 * gq, make_float4(y[0], y[1], y[2], y[3]));
+            st4(x + row * ldx + 64 + 8 * gq + 4, make_float4(y[4], y[5], y[6], y[7]));
+        }
+        uint4* dst = obs_thread ? act02 + ((rl >> 4) * 3) * 64 + gq * 16 + (rl & 15) : act1 + tid;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p * 64] = pc[p];
+    }
+    __syncthreads();
+    // (layer 2's first weight fragments have all of layer 1 to arrive)
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring2.issue(a2_src, d);
+    MLP_STAMP(1)
+    // ---- layer 1: units 64 wave + 16 t + ...
+    {
+        f32x4_t acc[4][RT];
+        mlp_split_layer<4, 1, RT, NT, 1>(ring1, a1_src, act02 + lane, acc);
+        MLP_STAMP(2)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) mlp_split_store<8>(act1, rt, 64 * wave + 16 * t, lane, acc[t][rt], bb1[t], alpha);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) ring3.issue(a3_src, d);
+    __syncthreads();
+    MLP_STAMP(3)
+    // ---- layer 2: units 32 wave + 16 t + ...
+    {
+        f32x4_t acc[2][RT];
+        mlp_split_layer<2, 8, RT, NT, D>(ring2, a2_src, act1 + lane, acc);
+        MLP_STAMP(4)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) mlp_split_store<4>(act02, rt, 32 * wave + 16 * t, lane, acc[t][rt], bb2[t], alpha);
+    }
+    __syncthreads();
+    MLP_STAMP(5)
+    // ---- layer 3: units 16 wave + 4 g + {0..3} of batch row u
+    {
+        f32x4_t acc[1][RT];
+        mlp_split_layer<1, 4, RT, NT, D>(ring3, a3_src, act02 + lane, acc);
+        MLP_STAMP(6)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const f32x4_t a = acc[0][rt];
+            st4(x + (row_base + 16 * rt + u) * ldx + 16 * wave + 4 * g,
+                make_float4(elu1(a[0] + bb.x, alpha), elu1(a[1] + bb.y, alpha), elu1(a[2] + bb.z, alpha),
+                            elu1(a[3] + bb.w, alpha)));
+        }
+    }
+    MLP_STAMP(7)
+}
+
+// W1 [256][F_in] (row stride ldw1, columns beyond F_in read as zero), W2 [128][256], W3 [64][128] fp32 -> the fragments of
+// bf16 pieces mlp3_elu_split_kernel reads: one thread per (layer, wave, k-block, tile, lane) = 8 consecutive k of one unit
+__global__ void mlp3_tile_weights_split_kernel(const float* __restrict__ w1, long long ldw1, int F_in,
+                                               const float* __restrict__ w2, long long ldw2, const float* __restrict__ w3,
+                                               long long ldw3, uint4* __restrict__ dst) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= (MLP_SPLIT_FRAGS / 3) * 64) return;
+    const int lane = q & 63;
+    int trip = q >> 6;                                  // (wave, k-block, tile) triple of pieces, layers back to back
+    const float* w;
+    long long ldw;
+    int tiles, kbs, kmax, upw;                          // unit tiles per wave, k-blocks, valid k, units per wave
+    if (trip < 16) { w = w1; ldw = ldw1; tiles = 4; kbs = 1; kmax = F_in; upw = 64; }
+    else if (trip < 16 + 64) { trip -= 16; w = w2; ldw = ldw2; tiles = 2; kbs = 8; kmax = 256; upw = 32; dst += MLP_SPLIT_L2_BASE * 64; }
+    else { trip -= 80; w = w3; ldw = ldw3; tiles = 1; kbs = 4; kmax = 128; upw = 16; dst += MLP_SPLIT_L3_BASE * 64; }
+    const int t = trip % tiles, kb = (trip / tiles) % kbs, wave = trip / (tiles * kbs);
+    const int unit = upw * wave + 16 * t + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (k0 + e < kmax) ? w[(long long)unit * ldw + k0 + e] : 0.0f;
+    uint4 hi, mid, lo;
+    split3_bf16x8(v, hi, mid, lo);
+    uint4* d = dst + (long long)(trip * 3) * 64 + lane;
+    d[0] = hi;
+    d[64] = mid;
+    d[128] = lo;
+}
+
 }  // namespace
 
 // One zeroed ticket word per (device, stream, kernel family) for the "last workgroup to finish" elections of the loss
@@ -6028,6 +6299,9 @@ int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, i
 int vine_debug_split_timing(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(split_t), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
 }
+int vine_debug_mlp_split_timing(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mlp_split_t), sizeof(unsigned long long) * 4096 * 16) == hipSuccess ? 0 : -1;
+}
 #endif
 
 int vine_lstm_tile_weights_split(int64_t H, int64_t K, const float* wcat, int64_t ldw, void* dst, void* stream) {
@@ -6057,6 +6331,44 @@ int vine_mlp3_elu_f32_fin(int64_t n, float* x, int64_t ldx, const float* raw, in
                        (long long)ldx, raw, (int)F_in, mean, var, eps, clip, w1, (long long)ldw1, b1, w2, (long long)ldw2, b2, w3,
                        (long long)ldw3, b3, alpha, fin_meter, fin_max_size, (long long*)fin_counter, (const float*)fin_scratch,
                        fin_blocks);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_mlp3_tile_weights_split(const float* w1, int64_t ldw1, int64_t F_in, const float* w2, int64_t ldw2, const float* w3,
+                                 int64_t ldw3, void* dst, void* stream) {
+    if (!w1 || !w2 || !w3 || !dst) return VINE_ERR_INVALID_ARG;
+    if (F_in <= 0 || F_in > 32 || ldw1 < F_in || ldw2 < 256 || ldw3 < 128 || ((uintptr_t)dst & 15)) return VINE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(mlp3_tile_weights_split_kernel, dim3((MLP_SPLIT_FRAGS / 3) * 64 / 256), dim3(256), 0, (hipStream_t)stream,
+                       w1, (long long)ldw1, (int)F_in, w2, (long long)ldw2, w3, (long long)ldw3, (uint4*)dst);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_mlp3_elu_f32_split(int64_t n, float* x, int64_t ldx, const float* raw, int64_t F_in, const double* mean,
+                            const double* var, float eps, float clip, const void* wt, const float* b1, const float* b2,
+                            const float* b3, float alpha, int terms, float* fin_meter, float fin_max_size,
+                            int64_t* fin_counter, const float* fin_scratch, int32_t fin_blocks, void* stream) {
+    if (fin_meter && (!fin_counter || !fin_scratch || fin_blocks <= 0)) return VINE_ERR_INVALID_ARG;
+    if (n <= 0 || !x || !raw || !mean || !var || !wt || !b1 || !b2 || !b3) return VINE_ERR_INVALID_ARG;
+    if ((terms & 255) != 9 && (terms & 255) != 6) return VINE_ERR_INVALID_ARG;
+    int rt = (terms >> 8) & 255;                     // row tiles per workgroup (0: chosen here), a tuning knob as in the LSTM step
+    if (!rt) rt = n >= 32768 ? 4 : (n >= 16384 ? 2 : 1);       // two workgroups per CU from 16384 rows on (measured in situ)
+    if ((rt != 1 && rt != 2 && rt != 4) || (terms >> 16) || n % (16 * rt) || F_in <= 0 || F_in > 32 || ldx < 64 + 32 || (ldx & 3) ||
+        ((uintptr_t)x & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)b1 & 15) || ((uintptr_t)b2 & 15) || ((uintptr_t)b3 & 15))
+        return VINE_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)rt * (4 + 8) * 3 * 64 * sizeof(uint4);
+    const int nt = terms & 255;
+#define LAUNCH_MLP_SPLIT(RT_, NT_)                                                                                           \
+    {                                                                                                                        \
+        if (!ensure_dyn_lds(reinterpret_cast<const void*>(mlp3_elu_split_kernel<RT_, NT_>), lds)) return VINE_ERR_DEVICE;   \
+        hipLaunchKernelGGL((mlp3_elu_split_kernel<RT_, NT_>), dim3((unsigned)(n / (16 * RT_))), dim3(256), lds,              \
+                           (hipStream_t)stream, (long long)n, x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip,        \
+                           (const uint4*)wt, b1, b2, b3, alpha, fin_meter, fin_max_size, (long long*)fin_counter,             \
+                           (const float*)fin_scratch, fin_blocks);                                                           \
+    }
+    if (rt == 4) { if (nt == 9) LAUNCH_MLP_SPLIT(4, 9) else LAUNCH_MLP_SPLIT(4, 6) }
+    else if (rt == 2) { if (nt == 9) LAUNCH_MLP_SPLIT(2, 9) else LAUNCH_MLP_SPLIT(2, 6) }
+    else { if (nt == 9) LAUNCH_MLP_SPLIT(1, 9) else LAUNCH_MLP_SPLIT(1, 6) }
+#undef LAUNCH_MLP_SPLIT
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -428,6 +428,9 @@ class A2CAgent:
         # the three bf16 pieces of every recurrent weight, in the split step kernel's fragment order
         f["wt_split"] = (torch.empty(3 * 4 * H * (XW + H), device=dev, dtype=torch.bfloat16) if f["f32_split"] else None)
         f["w1p_f32"] = torch.zeros((net.units[0], 32), device=dev) if f["f32_mfma"] else None     # layer 1, zero-padded
+        # the MLP's weights as fragments of bf16 pieces (vine_mlp3_elu_f32_split), rebuilt at every rollout start
+        f["mlp_wt_split"] = (torch.empty(288 * 512, device=dev, dtype=torch.bfloat16)
+                             if (f["f32_split"] and fused.MLP3_F32_SPLIT and N % 64 == 0) else None)
         f["bias_buf"] = torch.empty(4 * H, device=dev) if f["f32_mfma"] else None                  # b_ih + b_hh of a rollout
         self._fast = f
 
@@ -467,6 +470,7 @@ class A2CAgent:
                 fused._check(fused._lib().vine_lstm_tile_weights_f32(
                     f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_f32"].data_ptr(), st),
                     "vine_lstm_tile_weights_f32")
+            self._tile_mlp_weights(st)
             return
         f["wcat"][:, :r.weight_ih_l0.shape[1]].copy_(src(r.weight_ih_l0))
         f["wcat"][:, f["XW"]:].copy_(src(r.weight_hh_l0))
@@ -487,8 +491,20 @@ class A2CAgent:
                 fused._check(fused._lib().vine_lstm_tile_weights_f32(
                     f["H"], f["XW"] + f["H"], f["wcat"].data_ptr(), f["wcat"].stride(0), f["wt_f32"].data_ptr(), st),
                     "vine_lstm_tile_weights_f32")
+            self._tile_mlp_weights(st)
         f["cur"] = 0
         f["xh2"][0][:, f["XW"]:].copy_(self.rnn_states[0][0])
+
+    def _tile_mlp_weights(self, st):
+        """The MLP weights in the split kernel's fragment order (once per rollout: the update changed them)."""
+        f = self._fast
+        if f.get("mlp_wt_split") is None or len(f["mlp"]) != 3:
+            return
+        (W1, _), (W2, _), (W3, _) = f["mlp"]
+        fused._check(fused._lib().vine_mlp3_tile_weights_split(W1.data_ptr(), W1.stride(0), W1.shape[1], W2.data_ptr(),
+                                                               W2.stride(0), W3.data_ptr(), W3.stride(0),
+                                                               f["mlp_wt_split"].data_ptr(), st),
+                     "vine_mlp3_tile_weights_split")
 
     def _infer(self, obs, commit=True):
         """Policy trunk for one step, no autograd: normalise -> [GEMM + bias/ELU kernel] x L -> ONE gate GEMM over
@@ -514,13 +530,23 @@ class A2CAgent:
             (W1, b1), (W2, b2), (W3, b3) = f["mlp"]
             fin = getattr(self, "_pending_fin", None)      # the previous step's meter fold rides on workgroup 0 (round 4)
             self._pending_fin = None
-            fused._check(lib.vine_mlp3_elu_f32_fin(N, xh.data_ptr(), xh.stride(0), obs.data_ptr(), f["F"],
-                                                   rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
-                                                   float(rms.epsilon), 5.0, f["w1p_f32"].data_ptr(), 32, b1.data_ptr(), 256,
-                                                   W2.data_ptr(), W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(),
-                                                   W3.stride(0), b3.data_ptr(), 64, 1.0,
-                                                   *(fin if fin is not None else (None, 0.0, None, None, 0)), st),
-                         "vine_mlp3_elu_f32_fin")
+            if f.get("mlp_wt_split") is not None:
+                # exact products from bf16 pieces, as the LSTM step below (four waves share the rows, split the units)
+                fused._check(lib.vine_mlp3_elu_f32_split(N, xh.data_ptr(), xh.stride(0), obs.data_ptr(), f["F"],
+                                                         rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                                         float(rms.epsilon), 5.0, f["mlp_wt_split"].data_ptr(),
+                                                         b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), 1.0,
+                                                         f["f32_split"] | (fused.MLP3_F32_SPLIT_RT << 8),
+                                                         *(fin if fin is not None else (None, 0.0, None, None, 0)), st),
+                             "vine_mlp3_elu_f32_split")
+            else:
+                fused._check(lib.vine_mlp3_elu_f32_fin(N, xh.data_ptr(), xh.stride(0), obs.data_ptr(), f["F"],
+                                                       rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
+                                                       float(rms.epsilon), 5.0, f["w1p_f32"].data_ptr(), 32, b1.data_ptr(),
+                                                       256, W2.data_ptr(), W2.stride(0), b2.data_ptr(), 128, W3.data_ptr(),
+                                                       W3.stride(0), b3.data_ptr(), 64, 1.0,
+                                                       *(fin if fin is not None else (None, 0.0, None, None, 0)), st),
+                             "vine_mlp3_elu_f32_fin")
         elif mlp3:
             # observation normalisation and the whole MLP in ONE launch: the kernel normalises the raw observations
             # itself, writes them (bf16, zero-padded) into the LSTM operand's observation block and carries the

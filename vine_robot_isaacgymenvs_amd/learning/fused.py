@@ -188,6 +188,10 @@ ROLLOUT_F32_MFMA = _os.environ.get("VINE_ROLLOUT_F32_MFMA", "1") != "0"   # fp32
 # (vine_lstm_step_f32_split): 9 = all nine piece pairs (exact products, the default), 6 = without the three pairs below
 # 2^-24 of a product, 0 = the native fp32 matrix-core kernel (vine_lstm_step_f32)
 ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "9"))
+# the fp32 rollout MLP with the same piece products (vine_mlp3_elu_f32_split: four waves share the rows and split the units);
+# 0 = the native fp32 matrix-core kernel (vine_mlp3_elu_f32).  VINE_MLP3_F32_SPLIT_RT: row tiles per workgroup (0: from N)
+MLP3_F32_SPLIT = _os.environ.get("VINE_MLP3_F32_SPLIT", "1") != "0"
+MLP3_F32_SPLIT_RT = int(_os.environ.get("VINE_MLP3_F32_SPLIT_RT", "0"))
 MLP3 = _os.environ.get("VINE_MLP3", "1") != "0"                # the three MLP layers in one launch (A/B knob)
 MLP3_PREP = _os.environ.get("VINE_MLP3_PREP", "1") != "0"      # the step's operand preparation rides in that launch (A/B knob)
 COPY_SCATTER = _os.environ.get("VINE_COPY_SCATTER", "1") != "0"  # coalesced-load / scattered-store forms of tiles and transposes
