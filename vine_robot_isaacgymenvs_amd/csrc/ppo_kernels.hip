@@ -1349,6 +1349,17 @@ __device__ __forceinline__ int mlp3_tile_row(int u) {      // unit -> LDS row: 3
 }
 __device__ __forceinline__ float elu1(float x, float alpha) { return x > 0.0f ? x : alpha * (__expf(x) - 1.0f); }
 
+#ifdef SPLIT_TIMING
+// (debug build, scripts/ubench/mlp_split_clock.py / mlp_mfma_clock.py) per wave: s_memtime / s_memrealtime at up to 8 points
+__device__ unsigned long long mlp_split_t[4096 * 16];
+#define MLPM_STAMP(i)                                                                                                   \
+    if (lane == 0) {                                                                                                    \
+        mlp_split_t[((blockIdx.x * NW + wave) & 4095) * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime();                    \
+        mlp_split_t[((blockIdx.x * NW + wave) & 4095) * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();            \
+    }
+#else
+#define MLPM_STAMP(i)
+#endif
 template <int C1, int C2, int C3, int NW>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2))) void mlp3_elu_mfma_kernel(long long n, lp16_t* x, long long ldx,
                                                             const float* __restrict__ raw, int F_in,
@@ -1369,49 +1380,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const long long b = ((long long)blockIdx.x * NW + wave) * 16 + i;
-    // ---- this lane's B fragment of layer 1: columns 8 q .. 8 q + 7 of its row (requested before the weight staging)
-    lp16x8_t af1;
-    if (raw) {
-        // (branch-free, clamped addresses: all 24 loads in flight at once -- a per-column `if` compiles to one memory
-        // round trip per column, in front of the weight staging below)
-        float rv[8], v[8];
-        double mud[8], vrd[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int cc = min(8 * q + e, F_in - 1);
-            rv[e] = raw[b * F_in + cc];
-            mud[e] = mean[cc];
-            vrd[e] = var[cc];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            // same arithmetic as normalize_obs_kernel: statistics cast to float first
-            const float m = (float)mud[e], sd = sqrtf((float)vrd[e] + eps);
-            const float y = fminf(fmaxf((rv[e] - m) / sd, -clip), clip);
-            v[e] = 8 * q + e < F_in ? y : 0.0f;
-        }
-        const uint4 pk = pack_lp16x8(v);
-        af1 = __builtin_bit_cast(lp16x8_t, pk);
-        *reinterpret_cast<uint4*>(x + b * ldx + 8 * q) = pk;     // the LSTM operand's observation block (+ zero pad)
-    } else {
-        af1 = *reinterpret_cast<const lp16x8_t*>(x + b * ldx + 8 * q);
-    }
+    MLPM_STAMP(0)
     // ---- weights -> LDS.  Every request leaves before anything is waited for (compile-time trip counts: the staging is
     // one L2 round trip, not one per chunk); layer 1 starts as soon as ITS weights are in LDS, the two larger weights
-    // arrive under its arithmetic
+    // arrive under its arithmetic.  Order of the prologue (round 4): W1, the observations and their statistics, W2 / W3, the
+    // side job's requests (its job table is a chain of dependent loads), THEN the observation arithmetic and the side job's
+    // stores -- the weight requests used to stand behind the observation arithmetic and the side job, three round trips in
+    // a row.
     constexpr int TH = 64 * NW, N1 = C1 * 4 / TH, N2 = C2 * (C1 / 8) / TH, N3 = C3 * (C2 / 8) / TH;
     static_assert(C1 * 4 % TH == 0 && C2 * (C1 / 8) % TH == 0 && C3 * (C2 / 8) % TH == 0, "whole chunks per thread");
     u32x4_t s1[N1], s2[N2], s3[N3];      // native vectors: arrays of the HIP uint4 struct stay in scratch memory here
-    // ---- side job (vine_mlp3_elu_mfma_prep): this workgroup's share of the optimiser step's operand preparation, the
-    // former copy_batched launch in front of this one (nothing this kernel reads; its loads and stores are in flight under
-    // the weight staging below)
-    CopyItem items[MLP3_SIDE_ITEMS];
-#pragma unroll
-    for (int k = 0; k < MLP3_SIDE_ITEMS; ++k) {
-        const int vb = ((int)blockIdx.x + k * (int)gridDim.x) * (TH / 256) + (tid >> 8);
-        items[k].mode = 0;
-        if (vb < side_blocks) copy_item_load(side, vb, tid & 255, items[k]);
-    }
     if (ldw1 == 32) {            // w1 zero-padded to 32 columns (w1p)
 #pragma unroll
         for (int it = 0; it < N1; ++it) {
@@ -1429,6 +1407,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
             s1[it] = u32x4_t{d[0], d[1], d[2], d[3]};
         }
     }
+    // ---- this lane's B fragment of layer 1: columns 8 q .. 8 q + 7 of its row.  The float64 statistics are read and turned
+    // into (mean, sqrt(var + eps)) by 32 threads, once per workgroup, and handed round through LDS: 16 float64 loads per
+    // thread compile to one memory round trip each (the conversion of one is waited for before the next is requested),
+    // and per-column `if`s around the observation loads to one round trip per column -- clamped addresses instead
+    __shared__ float stat_m[32], stat_sd[32];
+    float rv[8];
+    double stat_mean = 0.0, stat_var = 1.0;
+    if (raw) {
+        if (tid < 32) {
+            stat_mean = mean[min(tid, F_in - 1)];
+            stat_var = var[min(tid, F_in - 1)];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = raw[b * F_in + min(8 * q + e, F_in - 1)];
+    }
+    // (the two larger weights behind the observations: their 120 KB per CU would stand in front of them otherwise)
 #pragma unroll
     for (int it = 0; it < N2; ++it) {
         const int c = tid + TH * it, row = c / (C1 / 8), ck = c - row * (C1 / 8);
@@ -1438,6 +1432,38 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
     for (int it = 0; it < N3; ++it) {
         const int c = tid + TH * it, row = c / (C2 / 8), ck = c - row * (C2 / 8);
         s3[it] = *reinterpret_cast<const u32x4_t*>(w3 + (long long)row * ldw3 + 8 * ck);
+    }
+    // ---- side job (vine_mlp3_elu_mfma_prep): this workgroup's share of the optimiser step's operand preparation, the
+    // former copy_batched launch in front of this one (nothing this kernel reads)
+    CopyItem items[MLP3_SIDE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < MLP3_SIDE_ITEMS; ++k) {
+        const int vb = ((int)blockIdx.x + k * (int)gridDim.x) * (TH / 256) + (tid >> 8);
+        items[k].mode = 0;
+        if (vb < side_blocks) copy_item_load(side, vb, tid & 255, items[k]);
+    }
+    lp16x8_t af1;
+    if (raw) {
+        if (tid < 32) {
+            // same arithmetic as normalize_obs_kernel: statistics cast to float first
+            stat_m[tid] = (float)stat_mean;
+            stat_sd[tid] = sqrtf((float)stat_var + eps);
+        }
+        __syncthreads();
+        float v[8];
+        const float4 m0 = ld4(stat_m + 8 * q), m1 = ld4(stat_m + 8 * q + 4), d0 = ld4(stat_sd + 8 * q), d1 = ld4(stat_sd + 8 * q + 4);
+        const float ms[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const float sds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = fminf(fmaxf((rv[e] - ms[e]) / sds[e], -clip), clip);
+            v[e] = 8 * q + e < F_in ? y : 0.0f;
+        }
+        const uint4 pk = pack_lp16x8(v);
+        af1 = __builtin_bit_cast(lp16x8_t, pk);
+        *reinterpret_cast<uint4*>(x + b * ldx + 8 * q) = pk;     // the LSTM operand's observation block (+ zero pad)
+    } else {
+        af1 = *reinterpret_cast<const lp16x8_t*>(x + b * ldx + 8 * q);
     }
     if (side_blocks > 0) {
 #pragma unroll
@@ -1449,6 +1475,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         *reinterpret_cast<u32x4_t*>(&w1l[mlp3_tile_row(c >> 2) * P1 + 8 * (c & 3)]) = s1[it];
     }
     __syncthreads();
+    MLPM_STAMP(1)
     // ---- layer 1: K = 32, C1 / 32 pairs of output tiles; pair kk becomes the B fragment of k-step kk of layer 2
     lp16x8_t af2[C1 / 32];
 #pragma unroll
@@ -1466,6 +1493,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         af2[kk] = __builtin_bit_cast(lp16x8_t, pk);
         if (act1) *reinterpret_cast<uint4*>(act1 + b * C1 + 32 * kk + 8 * q) = pk;
     }
+    MLPM_STAMP(2)
 #pragma unroll
     for (int it = 0; it < N2; ++it) {
         const int c = tid + TH * it, row = c / (C1 / 8), ck = c - row * (C1 / 8);
@@ -1477,6 +1505,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         *reinterpret_cast<u32x4_t*>(&w3l[row * P3 + 8 * ck]) = s3[it];
     }
     __syncthreads();
+    MLPM_STAMP(3)
     // ---- layer 2: K = C1
     lp16x8_t af3[C2 / 32];
 #pragma unroll
@@ -1500,6 +1529,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         af3[kp] = __builtin_bit_cast(lp16x8_t, pk);
         if (act2) *reinterpret_cast<uint4*>(act2 + b * C2 + 32 * kp + 8 * q) = pk;
     }
+    MLPM_STAMP(4)
     // ---- layer 3: K = C2, natural tile order: lane holds units 16 t + 4 q + {0..3} of its row
 #pragma unroll
     for (int t = 0; t < C3 / 16; ++t) {
@@ -1513,6 +1543,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
         st4(out + b * out_stride + 16 * t + 4 * q,
             make_float4(elu1(a[0] + bb.x, alpha), elu1(a[1] + bb.y, alpha), elu1(a[2] + bb.z, alpha), elu1(a[3] + bb.w, alpha)));
     }
+    MLPM_STAMP(5)
 }
 
 // ---- backward of a Linear through the previous layer's ELU on the matrix cores:
@@ -4847,8 +4878,6 @@ __global__ __launch_bounds__(256) void mlp3_elu_f32_kernel(long long n, float* _
 // At 4096 rows (RT = 1) all 1024 SIMDs work on 256 row tiles, where the one-wave-per-row-tile kernel above fills a quarter
 // of them with 768 dependent instructions each.
 #ifdef SPLIT_TIMING
-// (debug build, scripts/ubench/mlp_split_clock.py) per wave: s_memtime / s_memrealtime at 8 points of mlp3_elu_split_kernel
-__device__ unsigned long long mlp_split_t[4096 * 16];
 #define MLP_STAMP(i)                                                                                                    \
     if (lane == 0) {                                                                                                    \
         mlp_split_t[((blockIdx.x * 4 + wave) & 4095) * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime();                     \
@@ -4978,17 +5007,18 @@ __global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float*
     const bool obs_thread = tid < 4 * R;
     const int rl = tid >> 2, gq = tid & 3;
     const long long row = row_base + rl;
-    // (branch-free: clamped addresses, every load in flight at once -- per-column `if`s compile to one round trip each)
+    // (branch-free: clamped addresses, every load in flight at once -- per-column `if`s compile to one round trip each; the
+    // float64 statistics -> (mean, sqrt(var + eps)) by 32 threads through LDS, as in mlp3_elu_mfma_kernel)
+    __shared__ float stat_m[32], stat_sd[32];
+    double stat_mean = 0.0, stat_var = 1.0;
+    if (tid < 32) {
+        stat_mean = mean[min(tid, F_in - 1)];
+        stat_var = var[min(tid, F_in - 1)];
+    }
     float rv[8];
-    double mud[8], vrd[8];
     const float* rrow = raw + (obs_thread ? row : row_base) * F_in;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int cc = min(8 * gq + i, F_in - 1);
-        rv[i] = rrow[cc];
-        mud[i] = mean[cc];
-        vrd[i] = var[cc];
-    }
+    for (int i = 0; i < 8; ++i) rv[i] = rrow[min(8 * gq + i, F_in - 1)];
     __builtin_amdgcn_sched_barrier(0);      // (the scheduler moved the 25 weight-fragment loads in front of them otherwise)
     MlpSplitRing<4, 1> ring1;
     MlpSplitRing<2, D> ring2;
@@ -5004,13 +5034,20 @@ __global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float*
     // ---- normalised observations: thread (row, 8-column group) -> the LSTM operand's observation block (fp32) and A0
     // (computed AND written to LDS by every thread -- threads without a row write into the still unused A1 region: with
     // every use under `if (obs_thread)` the compiler sinks the loads into the branch, behind the weight requests)
+    if (tid < 32) {
+        // same arithmetic as normalize_obs_kernel: statistics cast to float first
+        stat_m[tid] = (float)stat_mean;
+        stat_sd[tid] = sqrtf((float)stat_var + eps);
+    }
+    __syncthreads();
     {
         float y[8];
+        const float4 m0 = ld4(stat_m + 8 * gq), m1 = ld4(stat_m + 8 * gq + 4), d0 = ld4(stat_sd + 8 * gq), d1 = ld4(stat_sd + 8 * gq + 4);
+        const float ms[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const float sds[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            // same arithmetic as normalize_obs_kernel: statistics cast to float first
-            const float sd = sqrtf((float)vrd[i] + eps);
-            const float v = fminf(fmaxf((rv[i] - (float)mud[i]) / sd, -clip), clip);
+            const float v = fminf(fmaxf((rv[i] - ms[i]) / sds[i], -clip), clip);
             y[i] = 8 * gq + i < F_in ? v : 0.0f;
         }
         uint4 pc[3];
