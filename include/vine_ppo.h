@@ -492,7 +492,9 @@ int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t 
  * a2c_continuous / torch.nn.LSTM under no autocast).  `terms` = 6 leaves out the three pairs below 2^-24 of a product
  * (a measured variant).  w_split = vine_lstm_tile_weights_split(Wcat [4H, K]): 3 K 4H bfloat16 (6 bytes per weight).
  * H = 256, K = 352, N % 128 == 0, 16-byte aligned pointers, else VINE_ERR_UNSUPPORTED.  Bits 8-15 of `terms`: row tiles per wave
- * (tuning knob: 0 = 4 from 16384 rows on when N % 256 == 0, else 2). */
+ * (tuning knob: 0 = 4 from 16384 rows on when N % 256 == 0, else 2).  Bit 16 (bits 8-15 then zero): the same arithmetic
+ * with one gate per wave -- four waves share 64 rows of one 32-unit block, weight fragments straight from global memory,
+ * operand pieces exchanged through LDS -- the faster form below 16384 rows. */
 int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const void* w_split,
                              const float* bias, const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next,
                              int64_t ldhp, int terms, void* stream);

@@ -14,7 +14,7 @@ from vine_robot_isaacgymenvs_amd.learning import fused  # noqa: E402
 lib = fused._lib()
 dev = torch.device("cuda:0")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-N, H, K, F = 16384, 256, 352, 28
+N, H, K, F = int(os.environ.get("ROLLOUT_N", "16384")), 256, 352, 28
 torch.manual_seed(0)
 xh = [torch.randn(N, K, device=dev) for _ in range(2)]
 wcat = torch.randn(4 * H, K, device=dev) / np.sqrt(K)
@@ -69,7 +69,7 @@ def mlp_rows(rows):
 
 MLP_FLOP = 2.0 * (32 * 256 + 256 * 128 + 128 * 64)
 MLPS = tuple(("mlp_split t%d rt%d n%d" % (t, rt, rows), mlp_split(t + 256 * rt, rows), MLP_FLOP * rows)
-             for rows in (16384, 4096) for t in (9, 6) for rt in (4, 2, 1)) + \
+             for rows in sorted({N, 4096}, reverse=True) for t in (9, 6) for rt in (4, 2, 1)) + \
     (("mlp3_elu_f32 n4096", mlp_rows(4096), MLP_FLOP * 4096),)
 ws = torch.empty(3 * 4 * H * K, device=dev, dtype=torch.bfloat16)
 assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), K, ws.data_ptr(), st) == 0
@@ -83,7 +83,8 @@ def lstm_split(variant):
     return run
 
 
-SPLITS = tuple(("lstm_split t%d rt%d" % (t, rt), lstm_split(t + 256 * rt), 2.0 * N * K * 4 * H) for t in (9, 6) for rt in (4, 2))
+SPLITS = tuple(("lstm_split t%d rt%d" % (t, rt), lstm_split(t + 256 * rt), 2.0 * N * K * 4 * H) for t in (9, 6) for rt in (4, 2)) + \
+    tuple(("lstm_nsplit t%d" % t, lstm_split(t + (1 << 16)), 2.0 * N * K * 4 * H) for t in (9, 6))
 for name, fn, flop in MLPS + SPLITS + (("lstm_step_f32", lstm, 2.0 * N * K * 4 * H), ("mlp3_elu_f32", mlp, 2.0 * N * (32 * 256 + 256 * 128 + 128 * 64))):
     for i in range(5):
         fn(i)

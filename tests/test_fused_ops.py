@@ -2193,13 +2193,14 @@ def test_lstm_step_f32_against_float64_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("terms", [9, 6, 9 + (2 << 8), 6 + (4 << 8), 9 + (4 << 8)])
+@pytest.mark.parametrize("terms", [9, 6, 9 + (2 << 8), 6 + (4 << 8), 9 + (4 << 8), 9 + (1 << 16), 6 + (1 << 16)])
 def test_lstm_step_f32_split_against_float64_torch(terms):
     """vine_lstm_step_f32_split (fp32 operands split exactly into three bf16 pieces, every piece product exact in the
     fp32 accumulator of the bf16 matrix cores) against float64 torch: the pre-activations must be at least as close to the
     float64 product as those of the native fp32 matrix-core kernel (9 terms: no bit of a product is dropped), and
     h / c within the same 1e-5 the native kernel is held to.  Operand magnitudes span 2^-20 .. 2^6 so that a piece that
-    were rounded away would show.  ``terms``: piece pairs in the low byte, row tiles per wave (a tuning knob) in the second."""
+    were rounded away would show.  ``terms``: piece pairs in the low byte, row tiles per wave (a tuning knob) in the second.
+    Bit 16 of ``terms``: the one-gate-per-wave kernel (four waves share 64 rows, operand pieces exchanged through LDS)."""
     from vine_robot_isaacgymenvs_amd import native
     lib = native.load()
     dev = torch.device("cuda:0")

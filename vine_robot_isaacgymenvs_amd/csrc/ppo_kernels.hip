@@ -4693,6 +4693,140 @@ __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, co
     SPLIT_STAMP(3)
 }
 
+// ---- The same step with the work of a workgroup split the other way round (round 4, as mlp3_elu_split_kernel): the four
+// waves share the SAME 64 batch rows (4 row tiles) of one 32-unit block and each owns ONE GATE of it (2 of the 8 weight
+// tiles).  A wave's weight fragments are then its own and come straight from global memory (same tiled array as above:
+// 6 fragments per k-step, a k-step ahead), nothing of the weights touches LDS; LDS carries the operand rows instead:
+// wave w loads and splits row tile w of the k-step ahead and writes its three pieces as B fragments (12 KB per k-step,
+// two buffers, one barrier per k-step), every wave reads all four row tiles.  A wave holds 8 accumulator tiles instead
+// of 32: ~150 registers, three workgroups per CU instead of two with a quarter of the rows each -- the memory stages of
+// one wave (exposed in the lone-wave loop of the kernel above: 66 % of the matrix rate) stand under the products of the
+// other two waves of its SIMD.  The gate pre-activations meet in LDS once, after the last k-step (32 KB, over the operand
+// buffers): wave w then runs the cell update of row tile w with all four gates of a unit on one lane, as above.
+// Price: every workgroup streams its 264 KB of weight pieces for 64 rows instead of 256 (540 MB instead of 135 MB through
+// the L1s per launch at 16384 rows, a third of their bandwidth over the kernel's duration).
+template <int KS, int NT>
+__global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, const float* __restrict__ xh, long long ldx,
+                                                                   const unsigned short* __restrict__ wt,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ c_prev, float* __restrict__ h_out,
+                                                                   long long ldh, float* __restrict__ c_out,
+                                                                   float* __restrict__ hp_next, long long ldhp, int xcd_map) {
+    constexpr int H = 256, XB = 4 * 3 * 64;                      // uint4 per operand buffer: [row tile][piece][lane]
+    __shared__ __attribute__((aligned(16))) uint4 lds[2048];      // 2 operand buffers (24 KB); the gate exchange (32 KB) over them
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = lane & 15, g = lane >> 4;
+    const int w = blockIdx.x;
+    const int rb = xcd_map ? (w >> 6) * 8 + (w & 7) : (w >> 3);
+    const int ub = xcd_map ? (w >> 3) & 7 : (w & 7);
+    const long long row = (long long)rb * 64 + 16 * wave + u;    // this lane's row: operand staging and the cell update
+    const uint4* asrc = reinterpret_cast<const uint4*>(wt) + (long long)ub * KS * (LSTM_SPLIT_CHUNK / 8) + (2 * wave) * 64 + lane;
+    const float* xrow = xh + row * ldx + 8 * g;
+    uint4 af[2][2][3];
+    float4 xf[2];
+    xf[0] = ld4(xrow);
+    xf[1] = ld4(xrow + 4);
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[0][ut][p] = asrc[(p * 8 + ut) * 64];
+    {
+        const float v[8] = {xf[0].x, xf[0].y, xf[0].z, xf[0].w, xf[1].x, xf[1].y, xf[1].z, xf[1].w};
+        uint4 pc[3];
+        split3_bf16x8(v, pc[0], pc[1], pc[2]);
+        if (KS > 1) {
+            xf[0] = ld4(xrow + 32);
+            xf[1] = ld4(xrow + 32 + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) lds[(wave * 3 + p) * 64 + lane] = pc[p];
+    }
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    float4 cp[2];
+    __syncthreads();
+    constexpr int PP[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, QQ[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {                      // fully unrolled: buffers and fragment sets stay register names
+        const int buf = j & 1;
+        if (j + 1 < KS) {
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[buf ^ 1][ut][p] = asrc[(long long)(j + 1) * (LSTM_SPLIT_CHUNK / 8) + (p * 8 + ut) * 64];
+        } else {                                                     // the cell states of the epilogue, a k-step early
+#pragma unroll
+            for (int ut = 0; ut < 2; ++ut) cp[ut] = ld4(c_prev + row * H + ub * 32 + 16 * ut + 4 * g);
+        }
+        const uint4* bl = lds + buf * XB + lane;
+        uint4 bfr[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bfr[0][p] = bl[p * 64];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            if (rt + 1 < 4) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bfr[(rt + 1) & 1][p] = bl[((rt + 1) * 3 + p) * 64];
+            }
+#pragma unroll
+            for (int n = 9 - NT; n < 9; ++n)
+#pragma unroll
+                for (int ut = 0; ut < 2; ++ut)
+                    acc[ut][rt] = mfma_bf16(af[buf][ut][PP[n]], bfr[rt & 1][QQ[n]], acc[ut][rt]);
+            if (rt == 0 && j + 1 < KS) {
+                // row tile `wave` of k-step j + 1 (requested during k-step j - 1) -> pieces -> the other buffer; then
+                // request k-step j + 2
+                const float v[8] = {xf[0].x, xf[0].y, xf[0].z, xf[0].w, xf[1].x, xf[1].y, xf[1].z, xf[1].w};
+                uint4 pc[3];
+                split3_bf16x8(v, pc[0], pc[1], pc[2]);
+                if (j + 2 < KS) {
+                    xf[0] = ld4(xrow + 32 * (j + 2));
+                    xf[1] = ld4(xrow + 32 * (j + 2) + 4);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; ++p) lds[(buf ^ 1) * XB + (wave * 3 + p) * 64 + lane] = pc[p];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the gates meet: wave (= gate) writes its 8 tiles, wave w reads the four gates of row tile w
+    float4* ex = reinterpret_cast<float4*>(lds);
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+            ex[((rt * 4 + wave) * 2 + ut) * 64 + lane] = make_float4(acc[ut][rt][0], acc[ut][rt][1], acc[ut][rt][2], acc[ut][rt][3]);
+    __syncthreads();
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut) {
+        const int unit = ub * 32 + 16 * ut + 4 * g;
+        const float4 bi = ld4(bias + 0 * H + unit), bf = ld4(bias + 1 * H + unit), bg = ld4(bias + 2 * H + unit),
+                     bo = ld4(bias + 3 * H + unit);
+        const float4 ai = ex[((wave * 4 + 0) * 2 + ut) * 64 + lane], af_ = ex[((wave * 4 + 1) * 2 + ut) * 64 + lane],
+                     ag = ex[((wave * 4 + 2) * 2 + ut) * 64 + lane], ao = ex[((wave * 4 + 3) * 2 + ut) * 64 + lane];
+        const float pi[4] = {ai.x + bi.x, ai.y + bi.y, ai.z + bi.z, ai.w + bi.w};
+        const float pf[4] = {af_.x + bf.x, af_.y + bf.y, af_.z + bf.z, af_.w + bf.w};
+        const float pg[4] = {ag.x + bg.x, ag.y + bg.y, ag.z + bg.z, ag.w + bg.w};
+        const float po[4] = {ao.x + bo.x, ao.y + bo.y, ao.z + bo.z, ao.w + bo.w};
+        const float cpa[4] = {cp[ut].x, cp[ut].y, cp[ut].z, cp[ut].w};
+        float cn[4], hn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gi = sigmoidf_(pi[r]), gf = sigmoidf_(pf[r]);
+            const float gc = tanhf_(pg[r]), go = sigmoidf_(po[r]);
+            cn[r] = gf * cpa[r] + gi * gc;
+            hn[r] = go * tanhf_(cn[r]);
+        }
+        st4(c_out + row * H + unit, make_float4(cn[0], cn[1], cn[2], cn[3]));
+        st4(h_out + row * ldh + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        if (hp_next) st4(hp_next + row * ldhp + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
+    }
+}
+
 // [w_ih | 0 | w_hh] rows (4H x K fp32, row stride ldw) -> the split step kernel's chunks of bf16 pieces:
 // dst[((((ub * KS + j) * 3 + piece) * 8 + 2 gate + ut) * 64 + lane) * 8 + e] = piece of W[gate * H + ub * 32 + 16 ut + (lane & 15)]
 // [32 j + 8 (lane >> 4) + e] -- one thread per (chunk, tile, lane): 8 consecutive k of one weight row
@@ -6319,6 +6453,19 @@ int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, i
     const int nt = terms & 255;
     int rt = (terms >> 8) & 255;
     if (!rt) rt = (N >= 16384 && N % 256 == 0) ? 4 : 2;
+    if ((terms >> 16) == 1) {
+        // bit 16: the one-gate-per-wave form (64 rows and one 32-unit block per workgroup; the second byte is not used)
+        if ((terms >> 8) & 255) return VINE_ERR_UNSUPPORTED;
+        const long long sets64 = N / 64;
+        const int xmap = (sets64 & 7) == 0;
+#define LAUNCH_NSPLIT(NT_)                                                                                                   \
+    hipLaunchKernelGGL((lstm_step_nsplit_kernel<11, NT_>), dim3((unsigned)sets64 * 8), dim3(256), 0, (hipStream_t)stream,      \
+                       (long long)N, xh, (long long)ldx, wt, bias, c_prev, h_out, (long long)ldh, c_out, hp_next,              \
+                       (long long)ldhp, xmap)
+        if (nt == 9) LAUNCH_NSPLIT(9); else LAUNCH_NSPLIT(6);
+#undef LAUNCH_NSPLIT
+        return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+    }
     if ((rt != 2 && rt != 4) || (terms >> 16) || N % (64LL * rt)) return VINE_ERR_UNSUPPORTED;
     const long long sets = N / (64LL * rt);
     const int xcd_map = (sets & 7) == 0;

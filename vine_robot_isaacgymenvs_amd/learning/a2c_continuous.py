@@ -585,7 +585,8 @@ class A2CAgent:
             # gate GEMM over [x | h] + the cell update: fp32 operands, every product exact from bf16 pieces (9 pairs)
             fused._check(lib.vine_lstm_step_f32_split(N, H, Kx, xh.data_ptr(), xh.stride(0), f["wt_split"].data_ptr(),
                                                       f["bias"].data_ptr(), c.data_ptr(), h_out.data_ptr(), H,
-                                                      c_out.data_ptr(), hp_ptr, xh_next.stride(0), f["f32_split"], st),
+                                                      c_out.data_ptr(), hp_ptr, xh_next.stride(0),
+                                                      f["f32_split"] | (int(fused.rollout_f32_nsplit(N)) << 16), st),
                          "vine_lstm_step_f32_split")
             gates = None
         elif f32k:

@@ -188,6 +188,14 @@ ROLLOUT_F32_MFMA = _os.environ.get("VINE_ROLLOUT_F32_MFMA", "1") != "0"   # fp32
 # (vine_lstm_step_f32_split): 9 = all nine piece pairs (exact products, the default), 6 = without the three pairs below
 # 2^-24 of a product, 0 = the native fp32 matrix-core kernel (vine_lstm_step_f32)
 ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "9"))
+# the one-gate-per-wave form of that kernel (four waves share 64 rows, operand pieces exchanged through LDS; bit 16 of
+# `terms`): "auto" = below 16384 rows, where it is faster (23.1 against 24.9 us at 4096 rows, 14.7 against 22.0 at 2048;
+# level at 16384: profiles/r04/rollout_kernels_round4.txt); "1" / "0" = always / never
+ROLLOUT_F32_NSPLIT = _os.environ.get("VINE_LSTM_STEP_NSPLIT", "auto")
+
+
+def rollout_f32_nsplit(rows):
+    return ROLLOUT_F32_NSPLIT == "1" or (ROLLOUT_F32_NSPLIT == "auto" and rows < 16384)
 # the fp32 rollout MLP with the same piece products (vine_mlp3_elu_f32_split: four waves share the rows and split the units);
 # 0 = the native fp32 matrix-core kernel (vine_mlp3_elu_f32).  VINE_MLP3_F32_SPLIT_RT: row tiles per workgroup (0: from N)
 MLP3_F32_SPLIT = _os.environ.get("VINE_MLP3_F32_SPLIT", "1") != "0"
