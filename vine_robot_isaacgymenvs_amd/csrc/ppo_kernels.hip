@@ -3559,6 +3559,16 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(long long n, int A, const
 // Per-workgroup rows of partial sums (LayerNorm / head parameters: ln_partial; loss statistics: loss_partial) are
 // folded by the column-sum kernel and, for the loss, by the last workgroup to finish (ppo_loss_finalize): fixed order,
 // no atomics on floats.  Workgroup = 8 waves x 16 rows.
+#ifdef SPLIT_TIMING
+// (debug build, scripts/ubench/trunk_phases_clock.py) per wave: s_memtime / s_memrealtime at the phase boundaries
+#define TRUNK_STAMP(i)                                                                                                  \
+    if ((threadIdx.x & 63) == 0) {                                                                                      \
+        mlp_split_t[((blockIdx.x * 8 + (threadIdx.x >> 6)) & 4095) * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime();      \
+        mlp_split_t[((blockIdx.x * 8 + (threadIdx.x >> 6)) & 4095) * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#else
+#define TRUNK_STAMP(i)
+#endif
 // sum over the 16 lanes of a DPP row, result in EVERY lane of the row: four rotate-and-add steps
 __device__ __forceinline__ float row_allsum16(float v) {
     v += dpp_i2f(__builtin_amdgcn_update_dpp(0, dpp_f2i(v), 0x128, 0xf, 0xf, true));      // row_ror:8
@@ -3615,7 +3625,8 @@ __device__ __forceinline__ void ln_heads_loss_body(
             // xT > 0: x is the [n / xT, xT + 1, H] tensor of vine_lstm_seq_forward_mfma's "h once" form (slot 0 = h0):
             // sample r = seq * xT + t is its row r + seq + 1
             const long long r_ = r0 + 4 * p + sub;
-            const XT* xr = x + (xT > 0 ? r_ + r_ / xT + 1 : r_) * H;
+            // (32-bit quotient: the 64-bit division is a ~100-instruction routine per lane and pass, in front of the loads)
+            const XT* xr = x + (xT > 0 ? r_ + (long long)((unsigned)r_ / (unsigned)xT) + 1 : r_) * H;
             xq[p][0] = *reinterpret_cast<const uint4*>(xr + 8 * cl);
             xq[p][1] = *reinterpret_cast<const uint4*>(xr + 8 * (cl + 16));
         }
@@ -3692,6 +3703,7 @@ __device__ __forceinline__ void ln_heads_loss_body(
         }
         if (cl == p) { mymean = mean; myrstd = rstd; }
     }
+    TRUNK_STAMP(5)
     // ---- phase 2: lanes with cl < NP hold one row each (row 4 cl + sub): ppo_loss_kernel's arithmetic
     float gh[NH];
 #pragma unroll
@@ -3773,6 +3785,7 @@ __device__ __forceinline__ void ln_heads_loss_body(
         if (lane == 0) lred[wave][qq] = t;
     }
     if (lane >= NRED && lane < PPO_LOSS_ROW) lred[wave][lane] = 0.0f;
+    TRUNK_STAMP(6)
     // ---- phase 3: d heads -> d LN output -> LayerNorm backward -> dx; parameter partial sums per lane
     float dgm[4][4], dbt[4][4], dw[NH][4][4];
 #pragma unroll
@@ -3838,6 +3851,7 @@ __device__ __forceinline__ void ln_heads_loss_body(
         // whoever sees it: no atomic needed.  The column-sum kernel checks the final gradients as well.)
         if (sizeof(DXT) == 2 && found_inf && bad) *found_inf = 1.0f;
     }
+    TRUNK_STAMP(7)
     // the four 16-lane rows of the wave hold sums for the same columns: add them (lane l <- l ^ 16, l ^ 32), then one
     // row of W sums per wave in LDS, added over the waves in wave order
     // (gfx950's v_permlane16_swap / v_permlane32_swap: the partner row's value without a trip through the LDS crossbar --
@@ -3955,9 +3969,11 @@ struct TrunkPhasesArgs {
 };
 __global__ __launch_bounds__(512) void trunk_phases_kernel(const TrunkPhasesArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char trunk_lds[];
+    TRUNK_STAMP(0)
     lstm_seq_fwd_body<3, 22, lp16_t, lp16_t, 12>(a.T, a.B, a.x, a.ldx, nullptr, 0, a.w_tiled, a.bias, a.c0, a.done, a.h_out, a.c_all,
                                                  a.gates, a.ablate, a.c_last, a.h0);
     __syncthreads();      // this workgroup's hidden states are written (h_out slots 1 .. T of its 32 sequences)
+    TRUNK_STAMP(1)
     ln_heads_loss_body<3, 4, lp16_t, lp16_t>(reinterpret_cast<float*>(trunk_lds),
                                              reinterpret_cast<float*>(trunk_lds) + 8 * 5 * 256, a.B * a.T, a.h_out, a.T, a.gamma,
                                              a.beta, a.eps, a.w, a.wb, a.logstd, a.actions, a.old_neglogp, a.adv, a.old_values,
@@ -3967,11 +3983,14 @@ __global__ __launch_bounds__(512) void trunk_phases_kernel(const TrunkPhasesArgs
                                              a.logstd_grad_accum, a.mu_store, a.sigma_store, a.loss_scale, a.found_inf, nullptr,
                                              1 /* the loss rows are folded by the column-sum launch (VineLossFinalize) */);
     __syncthreads();      // dh of this workgroup's rows
+    TRUNK_STAMP(2)
     lstm_seq_bwd_body<SEQ_BWD_RING, lp16_t, lp16_t>(a.T, a.B, a.dx, a.w_hh_tiled, a.gates, a.c_all, a.c0, a.done, a.dG,
                                                     a.bias_partial, a.ablate, a.c_last);
     __syncthreads();      // dG of this workgroup's rows
+    TRUNK_STAMP(3)
     mlp3_bwd_elu_mfma_body<64, 128, 256, 8, 8>(a.B * a.T, a.dG, 4 * SEQ_H, a.wt0, a.ldw0, a.wt1, a.ldw1, a.wt2, a.ldw2, a.a3,
                                               a.a3_stride, a.a2, a.a1, a.alpha, a.gz3, a.gz2, a.gz1, a.part3, a.part2, a.part1);
+    TRUNK_STAMP(4)
 }
 #undef LHL_COL
 #undef LHL_ROW
