@@ -4741,6 +4741,7 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
     const long long row = (long long)rb * 64 + 16 * wave + u;    // this lane's row: operand staging and the cell update
     const uint4* asrc = reinterpret_cast<const uint4*>(wt) + (long long)ub * KS * (LSTM_SPLIT_CHUNK / 8) + (2 * wave) * 64 + lane;
     const float* xrow = xh + row * ldx + 8 * g;
+    SPLIT_STAMP(0)
     uint4 af[2][2][3];
     float4 xf[2];
     xf[0] = ld4(xrow);
@@ -4767,6 +4768,7 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
         for (int rt = 0; rt < 4; ++rt) acc[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
     float4 cp[2];
     __syncthreads();
+    SPLIT_STAMP(1)
     constexpr int PP[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, QQ[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
 #pragma unroll
     for (int j = 0; j < KS; ++j) {                      // fully unrolled: buffers and fragment sets stay register names
@@ -4812,6 +4814,7 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
         }
         __syncthreads();
     }
+    SPLIT_STAMP(2)
     // ---- the gates meet: wave (= gate) writes its 8 tiles, wave w reads the four gates of row tile w
     float4* ex = reinterpret_cast<float4*>(lds);
 #pragma unroll
@@ -4844,6 +4847,7 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
         st4(h_out + row * ldh + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
         if (hp_next) st4(hp_next + row * ldhp + unit, make_float4(hn[0], hn[1], hn[2], hn[3]));
     }
+    SPLIT_STAMP(3)
 }
 
 // [w_ih | 0 | w_hh] rows (4H x K fp32, row stride ldw) -> the split step kernel's chunks of bf16 pieces:
