@@ -257,9 +257,9 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
             roll = "rollout inference: %s GEMM operands" % lp
         elif terms:
             mlp_split = (getattr(a, "_fast", None) or {}).get("mlp_wt_split") is not None
-            roll = ("rollout inference: f32 (the reference's): fp32 operands, fp32 accumulation; %s gate products formed "
+            roll = ("rollout inference: f32 (the reference's): fp32 operands, fp32 accumulation; %s products formed "
                     "from the exact three-way bf16 split of both fp32 operands on the bf16 matrix cores, %s"
-                    % ("MLP and LSTM" if mlp_split else "MLP on the fp32 matrix cores, LSTM",
+                    % ("MLP and LSTM-gate" if mlp_split else "MLP on the fp32 matrix cores, LSTM-gate",
                        "all 9 piece pairs = every bit of every fp32 product" if terms == 9 else
                        "6 of 9 piece pairs (the three below 2^-26 of a product left out)"))
         else:
