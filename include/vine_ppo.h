@@ -547,6 +547,9 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
  * vine_rollout_post_blocks(N) (the rows it holds) to the next launch that can carry the fold as a side job of one workgroup
  * -- vine_mlp3_elu_f32_fin, the first kernel of the next rollout step -- which must run before anything reads `*counter`. */
 int32_t vine_rollout_post_blocks(int64_t N);
+/* The fold of vine_rollout_post_defer's per-workgroup rows as a launch of its own (one 256-thread workgroup): what
+ * vine_rollout_post runs behind its per-env pass, for a caller whose next launch cannot carry the fold as a side job. */
+int vine_rollout_finalize(float* meter, float max_size, int64_t* counter, const float* scratch, int32_t blocks, void* stream);
 int vine_rollout_post_defer(int64_t N, int64_t H, const float* rew, const int64_t* reset, const uint8_t* timeouts,
                             const float* values, float reward_shift, float reward_scale, float gamma_bootstrap,
                             float* shaped_out, uint8_t* dones_out, float* cur_rewards, float* cur_lengths, float* h_state,

@@ -121,3 +121,88 @@ def test_multi_gpu_code_path_on_one_rank(monkeypatch):
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- collective probe
+class _StubEvent:
+    """An event whose query() never (or after `after` polls) answers: the replayed collective that a peer never joins."""
+    def __init__(self, after=None):
+        self.after, self.polls = after, 0
+
+    def query(self):
+        self.polls += 1
+        return self.after is not None and self.polls > self.after
+
+
+def _fake_clock():
+    t = {"now": 0.0}
+    return (lambda: t["now"]), (lambda dt: t.__setitem__("now", t["now"] + dt))
+
+
+def test_wait_bounded_times_out_on_an_event_that_never_completes():
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import wait_bounded
+    clock, sleep = _fake_clock()
+    ev = _StubEvent()
+    assert wait_bounded(ev.query, 2.0, clock=clock, sleep=sleep, poll_s=0.25) is False
+    assert 8 <= ev.polls <= 10 and clock() >= 2.0                 # it polled until the deadline, no longer
+    ev = _StubEvent(after=3)
+    assert wait_bounded(ev.query, 2.0, clock=clock, sleep=sleep, poll_s=0.25) is True and ev.polls == 4
+
+
+def test_collective_probe_never_replays_unless_every_rank_captured():
+    """a capture refused on ONE rank must keep every rank from replaying the probe graph."""
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import collective_probe_protocol
+    calls = []
+
+    def agree_other_rank_failed(ok):
+        calls.append(("agree", ok))
+        return False                                                # MIN over the ranks: a peer reported 0
+
+    def replay(handle):
+        calls.append(("replay",))
+        return "ok"
+    ok, why = collective_probe_protocol(lambda: (True, "captured", object()), replay, agree_other_rank_failed,
+                                        abort=lambda m: calls.append(("abort", m)))
+    assert ok is False and "another rank" in why
+    assert calls == [("agree", True)]                               # no replay, one agreement, no abort
+    # this rank's own refusal: it still joins the (one) agreement collective, so the ranks stay matched
+    calls.clear()
+    ok, why = collective_probe_protocol(lambda: (False, "capture refused: x", None), replay,
+                                        lambda v: (calls.append(("agree", v)), False)[1], abort=lambda m: calls.append(("abort", m)))
+    assert ok is False and why == "capture refused: x" and calls == [("agree", False)]
+
+
+def test_collective_probe_timeout_branch_falls_back_or_aborts():
+    from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import collective_probe_protocol, wait_bounded
+    clock, sleep = _fake_clock()
+
+    def replay_hung(handle):                                        # the bounded wait on a stubbed event that never fires
+        return "ok" if wait_bounded(_StubEvent().query, 5.0, clock=clock, sleep=sleep, poll_s=0.5) else "timeout"
+    logs, aborts, agreed = [], [], []
+
+    def agree(v):
+        agreed.append(v)
+        return v if len(agreed) == 1 else False                     # stage 1: all captured; stage 2: MIN is 0 (this rank timed out)
+    ok, why = collective_probe_protocol(lambda: (True, "captured", object()), replay_hung, agree, abort=aborts.append,
+                                        log=logs.append)
+    assert ok is False and "timeout" in why and agreed == [True, False] and not aborts and logs
+    # the ranks no longer answer after the hang: the process must end with a clear message, not wait forever
+    agreed.clear()
+
+    def agree_dead(v):
+        agreed.append(v)
+        return True if len(agreed) == 1 else None
+    ok, why = collective_probe_protocol(lambda: (True, "captured", object()), replay_hung, agree_dead, abort=aborts.append,
+                                        log=logs.append)
+    assert ok is False and len(aborts) == 1 and "VINE_COLLECTIVE_IN_GRAPH=0" in aborts[0]
+    # and the good case: two agreements, both true
+    ok, why = collective_probe_protocol(lambda: (True, "captured", object()), lambda h: "ok", lambda v: v, abort=aborts.append)
+    assert ok is True and len(aborts) == 1
+
+
+def test_agree_bounded_on_cpu_single_rank_and_gloo_pair():
+    """_agree_bounded answers like _capture_agreed when the collective completes (single rank: no collective at all)."""
+    from tests.test_ppo import make_agent
+    agent, _ = make_agent(num_envs=16, minibatch=64, seed=1, multi_gpu=False, max_epochs=1)
+    assert agent._agree_bounded(True, 1.0) is True and agent._agree_bounded(False, 1.0) is False
+    assert agent._collective_capture_ok() is False and agent.collective_capture["probe"] in ("no device", "disabled")

@@ -224,6 +224,27 @@ def test_clip_grad_norm_under_loss_scaling(scale, gain):
         torch.testing.assert_close(p.grad / s, r.grad, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("bad", [float("inf"), float("nan")])
+def test_clip_grad_norm_with_a_non_finite_gradient_flags_the_overflow(bad):
+    """an inf / NaN gradient gives a non-finite norm and coef = 0 / NaN -- without the flag Adam would take a
+    zero-gradient step (moments decay) where rl_games' unscale_ + clip + scaler.step skips.  The flag must be raised by the
+    clip itself, whoever delivered the gradients (check_grads off, bypassed batch)."""
+    from vine_robot_isaacgymenvs_amd.learning.flat_adam import FlatAdam
+    torch.manual_seed(5)
+    params = [torch.nn.Parameter(torch.randn(40, 3)), torch.nn.Parameter(torch.randn(17))]
+    opt = FlatAdam(params, lr=1e-3)
+    opt.enable_loss_scaling(init_scale=1024.0)
+    opt.check_grads = False
+    for p in params:
+        p.grad.copy_(torch.randn_like(p) * 1024.0)
+    assert float(opt.found_inf) == 0.0
+    opt.clip_grad_norm_(1.0)
+    assert float(opt.found_inf) == 0.0                      # finite gradients: the flag stays down
+    params[0].grad[3, 1] = bad
+    norm = opt.clip_grad_norm_(1.0)
+    assert not torch.isfinite(norm) and float(opt.found_inf) >= 1.0
+
+
 def test_training_runs_and_checkpoint_roundtrip(tmp_path):
     agent, cfg = make_agent(num_envs=16, minibatch=64, max_epochs=2)
     agent.nn_dir = str(tmp_path)

@@ -253,6 +253,7 @@ PPO_PROTOTYPES = {
     "vine_rollout_post": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 7 + [C.c_float, _VP, _VP, _I64,
                                                                                                   C.c_int32, _VP, _VP]),
     "vine_rollout_post_blocks": (C.c_int32, [_I64]),
+    "vine_rollout_finalize": (C.c_int, [_VP, C.c_float, _VP, _VP, C.c_int32, _VP]),
     "vine_rollout_post_defer": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 6 + [_VP, _I64, C.c_int32, _VP, _VP]),
     "vine_gae": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP]),
     "vine_dataset_assemble": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, C.c_float,

@@ -2847,7 +2847,8 @@ __global__ __launch_bounds__(64) void ds_finalize_kernel(int blocks, long long n
         double mean = rmean[0], var = rvar[0], cnt = rcount[0];
         for (int k = 0; k < 2; ++k) {                     // value_mean_std(values), then value_mean_std(returns)
             const double bmean = tot[2 * k] / nb;
-            const double bvar = n > 1 ? (tot[2 * k + 1] - nb * bmean * bmean) / (nb - 1.0) : 0.0;
+            double bvar = n > 1 ? (tot[2 * k + 1] - nb * bmean * bmean) / (nb - 1.0) : 0.0;
+            bvar = bvar > 0.0 ? bvar : 0.0;               // (sum of squares form: a constant series can round below zero; x.var() cannot)
             const double delta = bmean - mean, t = cnt + nb;
             const double m2 = var * cnt + bvar * nb + delta * delta * cnt * nb / t;
             mean += delta * nb / t;
@@ -3668,7 +3669,11 @@ __device__ __forceinline__ void ln_heads_loss_body(
     float myp[NH], mymean = 0.0f, myrstd = 0.0f;
 #pragma unroll
     for (int h = 0; h < NH; ++h) myp[h] = 0.0f;
-#pragma unroll
+    // (fp32 rows come from memory in both passes over them: their pass loops stay rolled -- unrolled, the compiler hoists
+    // every pass's 4 x 16-B row loads to the front and the <5, 4, float, float> instantiation spilled 193 VGPRs to scratch,
+    // VERDICT r4; the 16-bit form indexes its packed row registers by p and needs the unrolled loop)
+    constexpr int PASS_UNROLL = X16 ? NP : 1;
+#pragma unroll PASS_UNROLL
     for (int p = 0; p < NP; ++p) {
         float xa[4][4];
         LHL_ROW(p, r0 + 4 * p + sub, xa)
@@ -3796,7 +3801,7 @@ __device__ __forceinline__ void ln_heads_loss_body(
 #pragma unroll
             for (int h = 0; h < NH; ++h) dw[h][j][u] = 0.0f;
         }
-#pragma unroll
+#pragma unroll PASS_UNROLL
     for (int p = 0; p < NP; ++p) {
         const int src = (lane & 48) | p;                        // the lane of this row that holds pass p's values
         float ghr[NH];
@@ -6384,6 +6389,13 @@ int vine_rollout_post(int64_t N, int64_t H, const float* rew, const int64_t* res
                        (int)h_op_bf16);
     hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(256), 0, s, meter, max_size, (long long*)counter,
                        (const float*)scratch, (int)blocks);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_rollout_finalize(float* meter, float max_size, int64_t* counter, const float* scratch, int32_t blocks, void* stream) {
+    if (!meter || !counter || !scratch || blocks <= 0 || blocks > ROLLOUT_POST_BLOCKS) return VINE_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, meter, max_size,
+                       (long long*)counter, scratch, (int)blocks);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -50,6 +50,58 @@ class _Range:
             torch.cuda.nvtx.range_pop()
 
 
+def wait_bounded(done, timeout_s, clock=time.monotonic, sleep=time.sleep, poll_s=0.002):
+    """Poll ``done()`` (an event's ``query``, a work handle's ``is_completed``) until it answers True or ``timeout_s``
+    has passed; returns whether it answered.  The waits on the first captured collectives use this instead of an
+    unbounded ``synchronize``: a replayed RCCL node that a peer never joins would otherwise hang the job silently."""
+    deadline = clock() + float(timeout_s)
+    while True:
+        if done():
+            return True
+        if clock() >= deadline:
+            return False
+        sleep(poll_s)
+
+
+PROBE_EXIT_CODE = 3
+
+
+def collective_probe_protocol(capture, replay, agree, abort, log=print):
+    """Decide, with every rank, whether the gradient all-reduce may live inside a captured graph (VERDICT r4 item 6,
+    ADVICE r4).  Two agreed stages, so that no rank ever replays a collective a peer will not join:
+
+      1. ``capture()`` -> (ok, why, handle): capture the throw-away graph (nothing executes).  ``agree(ok)``: MIN over
+         the ranks -- unless ALL of them captured, nobody replays.
+      2. ``replay(handle)`` -> "ok" | "wrong sum" | "timeout": replay with a BOUNDED wait.  ``agree(result == "ok")``.
+
+    ``agree`` returns True / False, or None when the agreement collective itself did not answer within its deadline.  A
+    replay that timed out leaves an unfinished collective on this rank's stream: if the ranks can still agree they all
+    fall back to the eager collective between per-step graphs; if not, ``abort(message)`` ends the process with a
+    non-zero code and the instruction to relaunch with VINE_COLLECTIVE_IN_GRAPH=0 (a process that has touched the GPU is
+    never re-executed in place).  Returns (in_graph, why)."""
+    ok, why, handle = capture()
+    every = agree(bool(ok))
+    if every is None:
+        abort("collective probe: the ranks could not agree on the capture outcome (%s); relaunch with "
+              "VINE_COLLECTIVE_IN_GRAPH=0" % why)
+        return False, "no agreement after capture: " + why
+    if not every:
+        return False, (why if not ok else "another rank could not capture the all-reduce")
+    res = replay(handle)
+    good = res == "ok"
+    if res == "timeout":
+        log("collective probe: the captured all-reduce did not complete within its deadline on this rank; asking the "
+            "other ranks to fall back to the eager collective")
+    every = agree(good)
+    if every is None:
+        abort("collective probe: a replayed all-reduce hung (%s) and the ranks no longer answer; relaunch with "
+              "VINE_COLLECTIVE_IN_GRAPH=0 (all-reduce between per-step graphs)" % res)
+        return False, "captured all-reduce: %s, no agreement" % res
+    if not every:
+        return False, ("captured all-reduce: %s" % res if not good else "another rank's captured all-reduce failed")
+    return True, "captured all-reduce replays correctly"
+
+
 def swap_and_flatten01(arr):
     """[T, N, ...] -> [N*T, ...] with index = env * T + t (each env's steps contiguous)."""
     if arr is None:
@@ -524,7 +576,11 @@ class A2CAgent:
                 and f["U"] == 64 and f["F"] <= 32 and obs.is_contiguous() and obs.dtype == torch.float32
                 and tuple(W.shape for W, _ in f["mlp"][1:]) == ((128, 256), (64, 128)) and f["mlp"][0][0].shape[0] == 256)
         f32k = bool(f["f32_mfma"]) and obs.is_contiguous() and obs.dtype == torch.float32 and n_mlp == 3
-        assert f32k or getattr(self, "_pending_fin", None) is None, "a deferred rollout finalize needs the fp32 MLP launch"
+        if not f32k and getattr(self, "_pending_fin", None) is not None:
+            # a deferred meter fold with no fp32 MLP launch to ride on (a caller changed the inference path between the
+            # post-step kernel and this forward): run it as the one-workgroup launch it used to be -- never drop it
+            fused._check(lib.vine_rollout_finalize(*self._pending_fin, st), "vine_rollout_finalize")
+            self._pending_fin = None
         if f32k:
             # fp32 (the reference's rollout precision) on the matrix cores: normalisation + the three layers in one launch
             (W1, b1), (W2, b2), (W3, b3) = f["mlp"]
@@ -632,7 +688,8 @@ class A2CAgent:
         vms = m.value_mean_std if self.normalize_value else None
         # the head kernel reads the value normaliser's float64 statistics itself (vine_policy_head_rms: the module's own
         # mean.float(), sqrt(var.float() + eps)); the two-float form stays for other callers of vine_policy_head
-        head_rms = vms is not None and vms.running_mean.numel() == 1 and vms.running_mean.dtype == torch.float64
+        head_rms = (vms is not None and vms.running_mean.numel() == 1 and vms.running_mean.dtype == torch.float64
+                    and os.environ.get("VINE_POLICY_HEAD_RMS", "1") != "0")
         if vms is not None and not head_rms:
             vmean = vms.running_mean.float()
             vstd = torch.sqrt(vms.running_var.float() + vms.epsilon)
@@ -1374,20 +1431,51 @@ class A2CAgent:
         self.graph_status["update"] = "graph (per optimiser step: Adam of the previous step + forward / backward; all-reduce between graphs)"
         return True
 
+    def _agree_bounded(self, ok, timeout_s):
+        """``_capture_agreed`` with a deadline: True / False = the MIN over the ranks, None = no answer in time."""
+        if not self.multi_gpu:
+            return bool(ok)
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, async_op=True)
+        if self.is_cuda:
+            # (the work handle of an NCCL collective completes when its kernel has run: poll it, and the stream behind it)
+            ev = torch.cuda.Event()
+            work.wait()                                   # orders the current stream behind the collective; does not block the host
+            ev.record(torch.cuda.current_stream(self.device))
+            if not wait_bounded(ev.query, timeout_s):
+                return None
+        elif not wait_bounded(work.is_completed, timeout_s):
+            return None
+        return bool(flag.item() > 0.5)
+
+    def _abort_job(self, message):
+        """Last resort of the collective probe: say why and leave with a non-zero code WITHOUT running destructors that
+        would wait for the stuck stream (never an exec: the process has initialised the GPU)."""
+        print("FATAL (rank %d): %s" % (self.rank, message), flush=True)
+        os._exit(PROBE_EXIT_CODE)
+
     def _collective_capture_ok(self):
-        """May the RCCL gradient all-reduce live INSIDE a captured graph?  Decided once per agent, by all ranks together:
-        a throw-away graph holding one ``all_reduce`` of a small tensor on this rank's stream is captured and replayed
-        twice, and its result checked (SUM over the ranks).  Any refusal -- config ``collective_in_graph: False``, env
-        ``VINE_COLLECTIVE_IN_GRAPH=0``, a capture error, a wrong sum, on ANY rank -- keeps the collective eager between
-        per-step graphs.  ``self.collective_capture`` records the outcome (bench line: ``ppo.collective_in_graph``)."""
+        """May the RCCL gradient all-reduce live INSIDE a captured graph?  Decided once per agent, by all ranks together
+        (``collective_probe_protocol``): a throw-away graph holding one ``all_reduce`` of a small tensor on this rank's
+        stream is captured; only if EVERY rank captured it is it replayed (twice, each wait bounded by
+        ``collective_probe_timeout_s`` / VINE_COLLECTIVE_PROBE_TIMEOUT, default 10 s) and its result checked (SUM over the
+        ranks).  Any refusal -- config ``collective_in_graph: False``, env ``VINE_COLLECTIVE_IN_GRAPH=0``, a capture error,
+        a wrong sum, a timeout, on ANY rank -- keeps the collective eager between per-step graphs.
+        ``self.collective_capture`` records the outcome (bench line: ``collective_in_graph``)."""
         state = getattr(self, "_coll_capture", None)
         if state is not None:
             return state
         want = bool(self.config.get("collective_in_graph", True)) and os.environ.get("VINE_COLLECTIVE_IN_GRAPH", "1") != "0"
-        ok, why = False, "disabled"
-        if want and self.is_cuda and dist.get_backend() != "nccl":
-            why = "backend %s cannot be captured" % dist.get_backend()     # (gloo rehearsals: host-side collective)
-        elif want and self.is_cuda:
+        timeout_s = float(os.environ.get("VINE_COLLECTIVE_PROBE_TIMEOUT", self.config.get("collective_probe_timeout_s", 10.0)))
+        expect = float(self.rank_size * (self.rank_size + 1) // 2)
+
+        def capture():
+            if not want:
+                return False, "disabled", None
+            if not self.is_cuda:
+                return False, "no device", None
+            if dist.get_backend() != "nccl":
+                return False, "backend %s cannot be captured" % dist.get_backend(), None     # (gloo rehearsals)
             try:
                 probe = torch.full((256,), float(dist.get_rank() + 1), device=self.device)
                 keep = probe.clone()
@@ -1395,21 +1483,28 @@ class A2CAgent:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     dist.all_reduce(probe, op=dist.ReduceOp.SUM)
-                expect = float(self.rank_size * (self.rank_size + 1) // 2)
-                ok = True
-                for _ in range(2):
-                    probe.copy_(keep)
-                    g.replay()
-                    torch.cuda.synchronize(self.device)
-                    ok = ok and bool((probe == expect).all())
-                why = "captured all-reduce replays correctly" if ok else "captured all-reduce gave a wrong sum"
-                del g
+                return True, "captured", (g, probe, keep)
             except RuntimeError as err:
-                ok, why = False, "capture refused: %s" % str(err)[:160]
                 torch.cuda.synchronize(self.device)
-        ok = self._capture_agreed(ok)
+                return False, "capture refused: %s" % str(err)[:160], None
+
+        def replay(handle):
+            g, probe, keep = handle
+            stream = torch.cuda.current_stream(self.device)
+            for _ in range(2):
+                probe.copy_(keep)
+                g.replay()
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                if not wait_bounded(ev.query, timeout_s):
+                    return "timeout"
+                if not bool((probe == expect).all()):
+                    return "wrong sum"
+            return "ok"
+
+        ok, why = collective_probe_protocol(capture, replay, lambda v: self._agree_bounded(v, timeout_s), self._abort_job)
         self._coll_capture = ok
-        self.collective_capture = {"in_graph": ok, "probe": why}
+        self.collective_capture = {"in_graph": ok, "probe": why, "timeout_s": timeout_s}
         return ok
 
     def _update_epoch_graphed(self, rows_out):
@@ -1441,6 +1536,16 @@ class A2CAgent:
                 return False
         with _Range("update_graph_mini_epoch"):
             rec["G"].replay()
+        if self.multi_gpu and not rec.get("replayed"):
+            # the first replay of a graph that holds real collectives: bounded wait (a hang inside a replayed RCCL node
+            # would otherwise be silent); afterwards the graph has proven itself and replays are not waited for
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            t = float((getattr(self, "collective_capture", None) or {}).get("timeout_s", 10.0))
+            if not wait_bounded(ev.query, t):
+                self._abort_job("the first replay of the mini-epoch graph (gradient all-reduces captured) did not finish "
+                                "within %.0f s; relaunch with VINE_COLLECTIVE_IN_GRAPH=0 (all-reduce between per-step graphs)" % t)
+            rec["replayed"] = True
         rows_out.copy_(rec["stats"])
         self.graph_status["update"] = ("graph (1 per mini-epoch, all-reduces captured)" if self.multi_gpu
                                        else "graph (1 per mini-epoch)")
@@ -1525,10 +1630,21 @@ class A2CAgent:
         self.obs = self.env_reset()["obs"].to(self.device)
         self.broadcast_parameters()
         total_time = 0.0
+        t_last = time.perf_counter()
         while True:
             self.epoch_num += 1
             epoch_num = self.epoch_num
             play_time, update_time, stats = self.train_epoch()
+            # rl_games logs the host's wall clock.  With the deferred wait train_epoch hands back the DEVICE's split of the
+            # previous iteration; the scalars this loop reads below synchronise every iteration anyway, so the wall time
+            # between two returns is one whole iteration including the host gap: the split is rescaled to it (as
+            # bench_support does), and `fps total`, performance/* and total_time (the x-axis of rewards/time) are wall-clock
+            # figures again
+            t_now = time.perf_counter()
+            wall, t_last = t_now - t_last, t_now
+            if play_time + update_time > 0:
+                k = wall / (play_time + update_time)
+                play_time, update_time = play_time * k, update_time * k
             sum_time = play_time + update_time
             total_time += sum_time
             curr_frames = self.curr_frames * self.rank_size

@@ -317,6 +317,9 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         "extra_native_f32_mfma_rollout": native_f32_rollout,
         "extra_split6_rollout": split6_rollout,
         "replicas_in_sync": in_sync,
+        # several ranks: where the gradient all-reduce ran (inside the mini-epoch graph, or eagerly between per-step graphs)
+        # and what the collective probe said -- top level, next to replicas_in_sync (also under ppo.collective_in_graph)
+        "collective_in_graph": getattr(agent, "collective_capture", None) if (world > 1 or conf["multi_gpu"]) else None,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
                      "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},
         "ppo_iters_per_sec": steps / elapsed,

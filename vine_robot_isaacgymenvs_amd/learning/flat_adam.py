@@ -96,10 +96,14 @@ class FlatAdam:
         """``torch.nn.utils.clip_grad_norm_`` over the flat gradient block (the padding is zero).  With device-side loss
         scaling the block holds ``scale * g`` until the Adam kernel unscales it, so the threshold applies to the UNSCALED
         norm -- rl_games calls ``scaler.unscale_`` before clipping (``truncate_grads: True``); no host synchronisation.
-        A non-finite norm leaves a non-finite block behind: the overflow flag makes the step skip and clear it."""
+        A non-finite norm (an inf / NaN anywhere in the block) would give coef = 0 or NaN: finite entries become 0 and Adam
+        would take a zero-gradient step that decays the moments -- rl_games' unscale_ + clip + scaler.step SKIPS such a step.
+        With loss scaling the overflow flag is therefore raised here (whoever delivered the gradients: also a bypassed
+        batch or ``check_grads = False``), so the Adam kernel skips, clears the block and backs the scale off."""
         norm = torch.linalg.vector_norm(self.flat_grads)
         if self.amp_state is not None:
             norm = norm / self.amp_state[0]
+            self.found_inf.add_((~torch.isfinite(norm)).to(torch.float32))
         coef = (float(max_norm) / (norm + 1e-6)).clamp(max=1.0)
         self.flat_grads.mul_(coef)
         return norm
