@@ -1884,7 +1884,7 @@ def test_pending_rollout_fold_runs_as_its_own_launch_when_nothing_can_carry_it()
     for a, b in zip(*res):
         assert torch.equal(a, b)
     assert int(res[0][7]) == 6
-    assert lib.vine_rollout_finalize(None, 100.0, None, None, 1, st) == -2
+    assert lib.vine_rollout_finalize(None, 100.0, None, None, 1, st) == -1      # VINE_ERR_INVALID_ARG
 
 
 # --------------------------------------------------------------------------- GradScaler semantics on the device
