@@ -2270,9 +2270,21 @@ def test_mlp3_elu_f32_split_against_float64_torch(F, n, terms):
         a = torch.nn.functional.elu(a @ W.double().t() + b.double())
     err = float((x[:, :64].double() - a).abs().max())
     err_ref = float((x_ref[:, :64].double() - a).abs().max())
-    print("terms 0x%x: max |y - f64| %.3e (native fp32 MFMA kernel %.3e), max |y| %.2f" % (terms, err, err_ref, float(a.abs().max())))
+    rms, rms_ref = float((x[:, :64].double() - a).pow(2).mean().sqrt()), float((x_ref[:, :64].double() - a).pow(2).mean().sqrt())
+    print("terms 0x%x: max |y - f64| %.3e (native fp32 MFMA kernel %.3e), rms %.3e (native %.3e), max |y| %.2f"
+          % (terms, err, err_ref, rms, rms_ref, float(a.abs().max())))
     assert err < 2e-5 * max(1.0, float(a.abs().max()))
     assert err <= 1.5 * err_ref + 1e-7
+    assert rms <= rms_ref                 # (not above the native fp32 matrix-core kernel's rms error)
+    if (terms & 0xff) == 6:               # ... and the 6-pair form as accurate as the exact-product 9-pair form
+        x9 = torch.full((n, ldx), 7.0, device=dev)
+        assert lib.vine_mlp3_elu_f32_split(n, x9.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
+                                           wt.data_ptr(), bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr(), 1.0,
+                                           (terms & ~0xff) | 9, None, 0.0, None, None, 0, st) == 0
+        torch.cuda.synchronize()
+        e9 = float((x9[:, :64].double() - a).abs().max())
+        r9 = float((x9[:, :64].double() - a).pow(2).mean().sqrt())
+        assert err <= 1.15 * e9 + 1e-9 and rms <= 1.01 * r9
     assert torch.equal(x[:, 64:], x_ref[:, 64:])                       # observation block; nothing else touched
     assert torch.equal(x[:, 64:64 + F], xn) and float(x[:, 64 + F:96].abs().max()) == 0.0
     bad = lib.vine_mlp3_elu_f32_split(n + 8, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5,
@@ -2358,6 +2370,7 @@ def test_lstm_step_f32_split_against_float64_torch(terms):
     c = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
     h = torch.sigmoid(o) * torch.tanh(c)
     err_c, err_h = float((c_out.double() - c).abs().max()), float((h_out.double() - h).abs().max())
+    rms_c, rms_h = float((c_out.double() - c).pow(2).mean().sqrt()), float((h_out.double() - h).pow(2).mean().sqrt())
     # the native fp32 matrix-core kernel on the same operands
     wt = torch.empty(4 * H * K, device=dev)
     assert lib.vine_lstm_tile_weights_f32(H, K, wcat.data_ptr(), wcat.stride(0), wt.data_ptr(), st) == 0
@@ -2366,10 +2379,23 @@ def test_lstm_step_f32_split_against_float64_torch(terms):
                                   H, c_ref.data_ptr(), None, 0, st) == 0
     torch.cuda.synchronize()
     ref_c, ref_h = float((c_ref.double() - c).abs().max()), float((h_ref.double() - h).abs().max())
-    print("terms 0x%x: max |c - f64| %.3e (native fp32 MFMA %.3e), max |h - f64| %.3e (native %.3e)"
-          % (terms, err_c, ref_c, err_h, ref_h))
+    ref_rms_c, ref_rms_h = float((c_ref.double() - c).pow(2).mean().sqrt()), float((h_ref.double() - h).pow(2).mean().sqrt())
+    print("terms 0x%x: max |c - f64| %.3e (native fp32 MFMA %.3e), max |h - f64| %.3e (native %.3e); rms %.3e / %.3e (native %.3e / %.3e)"
+          % (terms, err_c, ref_c, err_h, ref_h, rms_c, rms_h, ref_rms_c, ref_rms_h))
     assert err_c < 1e-5 and err_h < 1e-5
     assert err_c <= 1.5 * ref_c + 1e-7 and err_h <= 1.5 * ref_h + 1e-7
+    # VERDICT r4 item 7 (the criterion the 6-pair default rests on): the rms error against float64 is NOT ABOVE the native
+    # fp32 matrix-core instruction's on the same inputs (the max over 5e5 outputs is a noisy statistic: within 1.5x above)
+    assert rms_c <= ref_rms_c and rms_h <= ref_rms_h
+    if (terms & 0xff) == 6:
+        # ... and the 6-pair form is as accurate as the exact-product 9-pair form: same max and rms error to 1 %
+        h9, c9 = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
+        assert lib.vine_lstm_step_f32_split(N, H, K, xh.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c_prev.data_ptr(),
+                                            h9.data_ptr(), H, c9.data_ptr(), None, 0, (terms & ~0xff) | 9, st) == 0
+        torch.cuda.synchronize()
+        e9_c, e9_h = float((c9.double() - c).abs().max()), float((h9.double() - h).abs().max())
+        r9_c, r9_h = float((c9.double() - c).pow(2).mean().sqrt()), float((h9.double() - h).pow(2).mean().sqrt())
+        assert err_c <= 1.01 * e9_c + 1e-9 and err_h <= 1.01 * e9_h + 1e-9 and rms_c <= 1.01 * r9_c and rms_h <= 1.01 * r9_h
     assert torch.equal(nxt[:, 96:], h_out) and float(nxt[:, :96].abs().max()) == 0.0
     # in place on the cell state (what the rollout does) gives the same result
     c_io = c_prev.clone()

@@ -261,7 +261,8 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
                     "from the exact three-way bf16 split of both fp32 operands on the bf16 matrix cores, %s"
                     % ("MLP and LSTM-gate" if mlp_split else "MLP on the fp32 matrix cores, LSTM-gate",
                        "all 9 piece pairs = every bit of every fp32 product" if terms == 9 else
-                       "6 of 9 piece pairs (the three below 2^-26 of a product left out)"))
+                       "6 of 9 piece pairs (the three below 2^-24 of a product left out: error against float64 equal to the "
+                       "9-pair form's and below the native fp32 MFMA instruction's, profiles/r05/split_terms_error.txt)"))
         else:
             roll = "rollout inference: f32 (the reference's; fp32 matrix-core kernels)"
         return upd + "; " + roll
@@ -291,7 +292,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         return {"update_precision": describe(agent2), "value": frames * steps / e2, "unit": "env-steps/s",
                 "ppo_iters_per_sec": steps / e2, "rollout_ms": p2 * k2 / steps * 1e3, "update_ms": u2 * k2 / steps * 1e3}
 
-    other = lp16_rollout = native_f32_rollout = split6_rollout = None
+    other = lp16_rollout = native_f32_rollout = split_other_rollout = None
     if world == 1 and not getattr(args, "no_secondary", False) and not agent.mixed_precision:
         # the same PPO iteration in the OTHER update precision (fp32 <-> 16-bit operands), and -- an extra, NARROWER than the
         # reference's fp32 rollout -- with 16-bit GEMM operands in the rollout inference as well (the round-2 configuration);
@@ -302,7 +303,8 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         if agent.fused_mixed and not agent.rollout_lp16 and (agent._fast or {}).get("f32_split", 0):
             # the rollout's LSTM step on the native fp32 matrix-core instruction, and the 6-pair form of the split
             native_f32_rollout = rerun(rollout_f32_terms=0)
-            split6_rollout = rerun(rollout_f32_terms=6)
+            other_terms = 9 if (agent._fast or {}).get("f32_split", 0) == 6 else 6
+            split_other_rollout = (other_terms, rerun(rollout_f32_terms=other_terms))
     ppo_kernels = None
     if world == 1 and agent.fused_mixed and not getattr(args, "no_secondary", False):
         try:
@@ -315,7 +317,9 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         "other_precision": other,
         "extra_lp16_rollout": lp16_rollout,
         "extra_native_f32_mfma_rollout": native_f32_rollout,
-        "extra_split6_rollout": split6_rollout,
+        # the other form of the split products (9 = all piece pairs when the default is 6, and the other way round)
+        ("extra_split%d_rollout" % split_other_rollout[0]) if split_other_rollout else "extra_split_other_rollout":
+            split_other_rollout[1] if split_other_rollout else None,
         "replicas_in_sync": in_sync,
         # several ranks: where the gradient all-reduce ran (inside the mini-epoch graph, or eagerly between per-step graphs)
         # and what the collective probe said -- top level, next to replicas_in_sync (also under ppo.collective_in_graph)
