@@ -764,32 +764,14 @@ __device__ __forceinline__ void unpack_lp16x8(uint4 r, float (&v)[8]) {
 
 // CT: storage type of the saved cell states (see the forward kernel; with lp16_t, c_T comes from `c_last` in fp32);
 // GT: type of the incoming gradient w.r.t. the hidden states (float, or lp16_t as written by ln_heads_loss_kernel).
-// Round 5, HOIST (trunk_phases_kernel only; T = 4): the first product of the MLP backward pass -- gz3_pre [rows, 64] =
-// dG [rows, 4H] Wt0^T, K = 4H -- is formed HERE, from the dG rows that sit in LDS as the recurrent product's operand, instead of
-// by the MLP phase from a second pass over dG in memory (67 MB of reads per optimiser step, 13 of that phase's 25 us).  Wave w
-// owns output tile (w >> 1) x row tile (w & 1) of every step: one more fragment (Wt0, rows in mlp3_tile_row order, straight
-// from the row-major tensor through a buffer descriptor) and one more MFMA per k-step, fed through the SAME register ring as
-// the w_hh fragments (virtual stream of 3 fragments per k-step).  The product over dG_{t+1} runs inside step t's matrix loop;
-// dG_0 gets a tail loop whose first fragments are requested in place of step 0's wrap-around prefetch.  Same MFMA sequence on
-// the same operands in the same k order as mlp3_bwd_elu_mfma_body's stage 1: bit-identical.  Results (fp32) wait in LDS for
-// the MLP phase: steps 1 .. 3 behind the two dG buffers, step 0 in dG buffer 1 (dead after step 0's matrix loop).
-constexpr int SEQ_BWD_PITCH = 4 * SEQ_H + 8;
-constexpr int HOIST_PRE_OFF = 2 * SEQ_ROWS * SEQ_BWD_PITCH * 2;              // bytes: behind dgl[2]; [3][32][64] fp32 = 24 KB
-constexpr int HOIST_PRE0_OFF = SEQ_ROWS * SEQ_BWD_PITCH * 2;                 // bytes: dgl[1]; [32][64] fp32
-__device__ __forceinline__ int mlp3_tile_unit(int r) {      // inverse of mlp3_tile_row: LDS / tile row -> unit
-    return (r & ~31) | ((r & 12) << 1) | ((r & 16) >> 2) | (r & 3);
-}
-template <int RING, typename CT, typename GT, bool HOIST = false>
+template <int RING, typename CT, typename GT>
 __device__ __forceinline__ void lstm_seq_bwd_body(
     int T, long long B, const GT* __restrict__ g_out, const uint4* __restrict__ Wt, const lp16_t* __restrict__ gates,
     const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
-    lp16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last,
-    const lp16_t* __restrict__ Wt0 = nullptr, long long ldw0 = 0) {
+    lp16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
     constexpr int H = SEQ_H, K = 4 * H, KSTEPS = K / 32, NF = KSTEPS * 2;
-    constexpr int NJ = HOIST ? 3 : 2, NFV = KSTEPS * NJ;        // the virtual stream the ring walks
     constexpr int PITCH = K + 8;
-    static_assert(PITCH == SEQ_BWD_PITCH, "LDS map");
-    static_assert(NFV % RING == 0, "the ring must close on a step boundary");
+    static_assert(NF % RING == 0, "the ring must close on a step boundary");
     extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
     lp16_t (*dgl)[SEQ_ROWS * PITCH] = reinterpret_cast<lp16_t (*)[SEQ_ROWS * PITCH]>(seq_lds);     // [2][32 rows][4H + 8]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -800,18 +782,9 @@ __device__ __forceinline__ void lstm_seq_bwd_body(
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(Wt) + (long long)w * NF * 1024), 0, NF * 1024, 0x00020000);
     const int wlane = lane * 16;
-    // HOIST: this wave's Wt0 fragment of k-step kk = rows mlp3_tile_unit(16 (w >> 1) + col), k = 32 kk + 8 lq .. + 8
-    const int ptile = w >> 1, prt = w & 1;
-    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<lp16_t*>(Wt0), 0, HOIST ? (int)(64 * ldw0 * 2) : 0, 0x00020000);
-    const int plane = HOIST ? (int)((mlp3_tile_unit(16 * ptile + col) * ldw0 + 8 * lq) * 2) : 0;
-#define SEQ_PFRAG(kk) seq_load_frag(prsrc, plane, (kk) * 64)
-    // virtual fragment fv -> its load (HOIST: k-step fv / 3, members 0, 1 = the w_hh fragments 2 kk, 2 kk + 1, member 2 = Wt0)
-#define SEQ_VFRAG(fv) (HOIST ? (((fv) % 3) == 2 ? SEQ_PFRAG((fv) / 3) : SEQ_WFRAG(2 * ((fv) / 3) + ((fv) % 3))) : SEQ_WFRAG(fv))
     uint4 ring[RING];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) ring[i] = SEQ_VFRAG(i);
-    f32x4_t accp = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < RING; ++i) ring[i] = SEQ_WFRAG(i);
     unsigned dmask[2];
     float dcarry[2][8], cnew[2][8], bsum[4][8];
 #pragma unroll
@@ -833,9 +806,10 @@ __device__ __forceinline__ void lstm_seq_bwd_body(
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int e = 0; e < 8; ++e) bsum[g][e] = 0.0f;
-#pragma unroll 1
-    for (int t = T - 1; t >= 0; --t) {
-        const bool first = t == T - 1;
+    // (round 5: the first step -- no matrix loop -- is its own instance of the step: `first` is a compile-time constant in
+    // both instances, 2-8 VGPRs fewer in every backward kernel and one spill fewer in the four-phase launch)
+    auto step = [&](const int t, auto first_c) __attribute__((always_inline)) {
+        constexpr bool first = decltype(first_c)::value;
         // operands of the pointwise part: those of row tile 0 are requested ahead of the matrix loop (their HBM round
         // trip hides under it), those of row tile 1 when tile 0's arithmetic starts (registers: 32 fewer live in the loop)
         float4 go4[2][2], cp4[2][2];
@@ -864,36 +838,21 @@ __device__ __forceinline__ void lstm_seq_bwd_body(
             seq_barrier();                                       // dG_{t+1} complete in dgl[(t + 1) & 1]
             const lp16_t* xb = dgl[(t + 1) & 1];
             if (t == T - 2) { BSTAMP(5) }
-            if (HOIST) accp = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 const lp16x8_t a0 = *reinterpret_cast<const lp16x8_t*>(xb + col * PITCH + 32 * kk + 8 * lq);
                 const lp16x8_t a1 = *reinterpret_cast<const lp16x8_t*>(xb + (16 + col) * PITCH + 32 * kk + 8 * lq);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int f = kk * NJ + j, slot = f % RING;
+                for (int j = 0; j < 2; ++j) {
+                    const int f = kk * 2 + j, slot = f % RING;
                     const lp16x8_t wf = __builtin_bit_cast(lp16x8_t, ring[slot]);
-                    if (j < 2) {
-                        acc[j][0] = MFMA_LP16(wf, a0, acc[j][0]);
-                        acc[j][1] = MFMA_LP16(wf, a1, acc[j][1]);
-                    } else {
-                        accp = MFMA_LP16(wf, prt ? a1 : a0, accp);      // gz3_pre of step t + 1's rows, this wave's tile
-                    }
-                    if (!(ablate & 2)) {
-                        if (HOIST && f + RING >= NFV) {
-                            // wrap-around: the next (earlier) step's first fragments -- behind step 0 the tail loop's
-                            if (t == 0) ring[slot] = SEQ_PFRAG(f + RING - NFV);
-                            else ring[slot] = SEQ_VFRAG(f + RING - NFV);
-                        } else {
-                            ring[slot] = SEQ_VFRAG((f + RING) % NFV);
-                        }
-                    }
+                    acc[j][0] = MFMA_LP16(wf, a0, acc[j][0]);
+                    acc[j][1] = MFMA_LP16(wf, a1, acc[j][1]);
+                    if (!(ablate & 2)) ring[slot] = SEQ_WFRAG((f + RING) % NF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (t == T - 2) { BSTAMP(6) }
-            if (HOIST)      // rows (16 prt + col) of step t + 1, tile rows 16 ptile + 4 lq .. + 3  (t + 1 >= 1: behind the dG buffers)
-                *reinterpret_cast<f32x4_t*>(seq_lds + HOIST_PRE_OFF + ((t * SEQ_ROWS + 16 * prt + col) * 64 + 16 * ptile + 4 * lq) * 4) = accp;
         }
         lp16_t* dgn = dgl[t & 1];
         SEQ_BWD_LOAD(1)
@@ -951,30 +910,16 @@ __device__ __forceinline__ void lstm_seq_bwd_body(
                     for (int g = 0; g < 4; ++g) {
                         const uint4 v = make_uint4(lo[g].x, lo[g].y, pk[g].x, pk[g].y);
                         if (!(ablate & 1)) *reinterpret_cast<uint4*>(dgp + g * H) = v;
-                        if (HOIST || t > 0) *reinterpret_cast<uint4*>(row + g * H) = v;
+                        if (t > 0) *reinterpret_cast<uint4*>(row + g * H) = v;
                     }
                 }
             }
         }
         if (t == T - 2) { BSTAMP(7) }
-    }
-    if (HOIST) {
-        // tail: dG_0 (dgl[0], complete behind this barrier) x Wt0 -- the ring holds fragments 0 .. RING - 1 of the Wt0 stream
-        // (requested in place of step 0's wrap-around prefetch); dgl[1] is dead from here on and receives the result
-        seq_barrier();
-        const lp16_t* xb = dgl[0] + (16 * prt + col) * PITCH + 8 * lq;
-        accp = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            const lp16x8_t ap = *reinterpret_cast<const lp16x8_t*>(xb + 32 * kk);
-            accp = MFMA_LP16(__builtin_bit_cast(lp16x8_t, ring[kk % RING]), ap, accp);
-            if (kk + RING < KSTEPS) ring[kk % RING] = SEQ_PFRAG(kk + RING);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        *reinterpret_cast<f32x4_t*>(seq_lds + HOIST_PRE0_OFF + ((16 * prt + col) * 64 + 16 * ptile + 4 * lq) * 4) = accp;
-    }
-#undef SEQ_VFRAG
-#undef SEQ_PFRAG
+    };
+    step(T - 1, std::true_type{});
+#pragma unroll 1
+    for (int t = T - 2; t >= 0; --t) step(t, std::false_type{});
     if (bias_partial) {
         float* outp = bias_partial + (long long)blockIdx.x * 4 * H + U0;
 #pragma unroll
@@ -1811,9 +1756,7 @@ __global__ __launch_bounds__(256) void linear_bwd_elu_mfma_chunked_kernel(
 // chunked kernel (weight chunk double-buffered in LDS, dG fragments double-buffered in registers); the two small
 // weights are requested at the start and parked in LDS after stage 1.  Column sums: DPP row sums over the 16 rows of
 // a wave (dpp_row_sum16), then across the waves through LDS -- fixed order, no atomics.
-// PRE (round 5, trunk_phases_kernel with the hoisted first product): stage 1 is not computed here -- its fp32 result for this
-// workgroup's 128 samples waits in LDS where lstm_seq_bwd_body<.., HOIST> left it (sample = 4 seq + t; tile-row order).
-template <int C3, int C2, int C1, int NCH, int NW, bool PRE = false>
+template <int C3, int C2, int C1, int NCH, int NW>
 __device__ __forceinline__ void mlp3_bwd_elu_mfma_body(
     long long n, const lp16_t* __restrict__ G, long long ldg, const lp16_t* __restrict__ Wt0, long long ldw0,
     const lp16_t* __restrict__ Wt1, long long ldw1, const lp16_t* __restrict__ Wt2, long long ldw2,
@@ -1859,11 +1802,9 @@ __device__ __forceinline__ void mlp3_bwd_elu_mfma_body(
 #define MB_LOAD_G(ch)                                                                                          \
     _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                           \
         gq[(ch) % 3][k_] = *reinterpret_cast<const lp16x8_t*>(grow + (ch) * CK + 32 * k_);
-    if (!PRE) {
-        MB_LOAD_W(0)
-        MB_LOAD_G(0)
-        if (NCH > 1) { MB_LOAD_G(1) }
-    }
+    MB_LOAD_W(0)
+    MB_LOAD_G(0)
+    if (NCH > 1) { MB_LOAD_G(1) }
     // the stored activations of this lane's units (ELU' of the three layers): requested here, 56 registers, so that their
     // 29 MB travel under stage 1's stream instead of as 14 exposed round trips in the finishing steps (31.3 -> us)
     uint4 pa3[C3 / 32], pa2[C2 / 32], pa1[C1 / 32];
@@ -1873,18 +1814,10 @@ __device__ __forceinline__ void mlp3_bwd_elu_mfma_body(
     for (int kp = 0; kp < C2 / 32; ++kp) pa2[kp] = *reinterpret_cast<const uint4*>(a2 + b * C2 + 32 * kp + 8 * q);
 #pragma unroll
     for (int kp = 0; kp < C1 / 32; ++kp) pa1[kp] = *reinterpret_cast<const uint4*>(a1 + b * C1 + 32 * kp + 8 * q);
-    f32x4_t acc[4];
-    if (PRE) {
-        static_assert(!PRE || (NW == 8 && C3 == 64), "the hoisted product is laid out for 8 waves x 16 samples, T = 4");
-        const int smp = 16 * wave + i, seq = smp >> 2, tt = smp & 3;
-        const unsigned char* src = lds_raw + (tt ? HOIST_PRE_OFF + (((tt - 1) * SEQ_ROWS + seq) * 64) * 4 : HOIST_PRE0_OFF + seq * 64 * 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = *reinterpret_cast<const f32x4_t*>(src + (16 * t + 4 * q) * 4);
-        __syncthreads();                                         // every wave has its rows: the LDS block is free for w1l / w2l / red
-    } else {
     MB_STORE_W(0)
     __syncthreads();
     // ---- stage 1: C3 = 64 units = tiles (pair kk, ut), K0 streamed
+    f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -1901,7 +1834,6 @@ __device__ __forceinline__ void mlp3_bwd_elu_mfma_body(
         }
         if (c + 1 < NCH) { MB_STORE_W((c + 1) & 1) }            // buffer (c+1)&1 was last read before the previous barrier
         __syncthreads();
-    }
     }
 #undef MB_LOAD_W
 #undef MB_STORE_W
@@ -4067,7 +3999,6 @@ struct TrunkPhasesArgs {
     const lp16_t* a3; long long a3_stride; const lp16_t* a2; const lp16_t* a1; float alpha;
     lp16_t* gz3; lp16_t* gz2; lp16_t* gz1; float* part3; float* part2; float* part1;
 };
-template <bool HOIST>
 __global__ __launch_bounds__(512) void trunk_phases_kernel(const TrunkPhasesArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char trunk_lds[];
     TRUNK_STAMP(0)
@@ -4085,16 +4016,12 @@ __global__ __launch_bounds__(512) void trunk_phases_kernel(const TrunkPhasesArgs
                                              1 /* the loss rows are folded by the column-sum launch (VineLossFinalize) */);
     __syncthreads();      // dh of this workgroup's rows
     TRUNK_STAMP(2)
-#ifndef SEQ_BWD_HOIST_RING
-#define SEQ_BWD_HOIST_RING 8
-#endif
-    lstm_seq_bwd_body<HOIST ? SEQ_BWD_HOIST_RING : SEQ_BWD_RING, lp16_t, lp16_t, HOIST>(a.T, a.B, a.dx, a.w_hh_tiled, a.gates, a.c_all, a.c0, a.done, a.dG,
-                                                           a.bias_partial, a.ablate, a.c_last, a.wt0, a.ldw0);
-    __syncthreads();      // dG of this workgroup's rows (HOIST: and the first MLP-backward product, in LDS)
+    lstm_seq_bwd_body<SEQ_BWD_RING, lp16_t, lp16_t>(a.T, a.B, a.dx, a.w_hh_tiled, a.gates, a.c_all, a.c0, a.done, a.dG,
+                                                    a.bias_partial, a.ablate, a.c_last);
+    __syncthreads();      // dG of this workgroup's rows
     TRUNK_STAMP(3)
-    mlp3_bwd_elu_mfma_body<64, 128, 256, 8, 8, HOIST>(a.B * a.T, a.dG, 4 * SEQ_H, a.wt0, a.ldw0, a.wt1, a.ldw1, a.wt2, a.ldw2,
-                                                     a.a3, a.a3_stride, a.a2, a.a1, a.alpha, a.gz3, a.gz2, a.gz1, a.part3, a.part2,
-                                                     a.part1);
+    mlp3_bwd_elu_mfma_body<64, 128, 256, 8, 8>(a.B * a.T, a.dG, 4 * SEQ_H, a.wt0, a.ldw0, a.wt1, a.ldw1, a.wt2, a.ldw2, a.a3,
+                                              a.a3_stride, a.a2, a.a1, a.alpha, a.gz3, a.gz2, a.gz1, a.part3, a.part2, a.part1);
     TRUNK_STAMP(4)
 }
 #undef LHL_COL
@@ -5850,15 +5777,8 @@ int vine_trunk_phases(const VineTrunkArgs* p, void* stream) {
     a.alpha = q.alpha; a.gz3 = (lp16_t*)q.gz3; a.gz2 = (lp16_t*)q.gz2; a.gz1 = (lp16_t*)q.gz1; a.part3 = q.part3; a.part2 = q.part2;
     a.part1 = q.part1;
     const size_t lds = 160 * 1024;      // the LSTM forward phase with its weight cache: 63 + 96 KB (the other phases need less)
-    // VINE_TRUNK_HOIST=0: the MLP phase forms its first product from a second pass over dG in memory (round 4's form)
-    static const bool hoist = [] { const char* e = getenv("VINE_TRUNK_HOIST"); return !e || atoi(e) != 0; }();
-    if (hoist) {
-        if (!ensure_dyn_lds(reinterpret_cast<const void*>(&trunk_phases_kernel<true>), lds)) return VINE_ERR_DEVICE;
-        hipLaunchKernelGGL(trunk_phases_kernel<true>, dim3((unsigned)(q.B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream, a);
-    } else {
-        if (!ensure_dyn_lds(reinterpret_cast<const void*>(&trunk_phases_kernel<false>), lds)) return VINE_ERR_DEVICE;
-        hipLaunchKernelGGL(trunk_phases_kernel<false>, dim3((unsigned)(q.B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream, a);
-    }
+    if (!ensure_dyn_lds(reinterpret_cast<const void*>(&trunk_phases_kernel), lds)) return VINE_ERR_DEVICE;
+    hipLaunchKernelGGL(trunk_phases_kernel, dim3((unsigned)(q.B / SEQ_ROWS)), dim3(512), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 
