@@ -142,6 +142,16 @@ def pmc_traffic(kernel):
         return None, None
 
 
+def trace_kernel_us(kernel):
+    """Average duration of this instantiation in the committed kernel trace of its PMC summary (the figure the live
+    `kernel_ms` has to agree with)."""
+    _f, d = _pmc_summary(kernel)
+    try:
+        return d["kernel_stats"]["avg_ns"] / 1e3
+    except (KeyError, TypeError):
+        return None
+
+
 def pmc_valu_per_wave(kernel):
     """VALU instructions one wave issues per env step (SQ_INSTS_VALU / SQ_WAVES of the committed PMC pass)."""
     _f, d = _pmc_summary(kernel)
@@ -464,6 +474,9 @@ def main():
             "roofline": {"bound": "valu", "kernel": env.step_kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
+                         "kernel_ms_method": ("HIP events around every eager launch of the timed region" if (mode == "env" or args.no_graph)
+                                              else "64 launches replayed from a hipGraph, one event pair around 8 replays"),
+                         "trace_kernel_us": trace_kernel_us(kernel_instance(env)),
                          "compute": compute_roofline(env.step_kernel_name, n, kernel_ms, kernel_instance(env))},
         }
         out.update(extra)

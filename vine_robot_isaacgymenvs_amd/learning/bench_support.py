@@ -126,7 +126,85 @@ def ppo_kernel_rooflines(device, B=8192, T=4, H=256, width=92, wpad=96, sets=4):
     return res
 
 
-def ppo_iteration_rate(env, cfg, steps=5, warmup=3, amp=None, use_graphs=True):
+def ppo_path_rooflines(agent):
+    """Rows for the kernels that are ON the timed path, keyed by the kernel names of the graph-replayed trace (VERDICT r4 item
+    3).  bench.py cannot trace or count by itself: the in-situ duration of a kernel (``in_situ_us``: rocprofv3 kernel trace of
+    `bench.py --mode ppo` with the iteration replayed from hipGraphs) and its HBM-side traffic (``traffic_bytes`` = (2 x
+    FETCH_SIZE + WRITE_SIZE) x 1024, separate counter passes; the x2 is MI355X_MICROARCH.md's gfx950 correction) come from the
+    newest committed ``profiles/rNN/ppo_traffic_*_pmc_summary.json`` (scripts/profile_ppo_traffic.sh), named in ``source``.
+    ``algorithmic_bytes`` are computed here from the shapes of the agent that just ran (formulas below, DESIGN.md section 7);
+    ``hbm_frac`` = algorithmic bytes / in-situ duration / 8 TB/s; ``launches_per_iteration`` x ``in_situ_us`` is the kernel's
+    share of the iteration.  Everything reproduces by hand from the named file."""
+    import glob
+    import json
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    files = sorted(glob.glob(os.path.join(repo, "profiles", "r*", "ppo_traffic_*pmc_summary.json")), reverse=True)
+    if not files:
+        return None
+    prof = json.load(open(files[0]))
+    net = agent.model.a2c_network
+    n = agent.minibatch_size                      # samples per optimiser step
+    T = agent.seq_len
+    B = n // T                                    # sequences per optimiser step
+    H = net.rnn_units
+    F = agent.obs_shape[0]
+    U1, U2, U3 = net.units
+    wpad = (U3 + F + 15) // 16 * 16               # LSTM input block [MLP out | obs | pad]
+    A = agent.actions_num
+    steps = agent.mini_epochs_num * agent.num_minibatches
+    N = agent.num_actors
+    lp = 2                                        # bytes of the 16-bit operand format
+    # LSTM forward ("h once"): x, h0 / c0 (fp32), weights, done flags in; h [B, T+1, H], c_1..c_{T-1} (16 bit) + c_T (fp32), gates out
+    fwd = B * T * wpad * lp + 2 * B * H * 4 + 4 * H * (wpad + H) * lp + B * T + B * (T + 1) * H * lp + ((T - 1) * B * H * lp + B * H * 4) + T * B * 4 * H * lp
+    # LayerNorm + heads + loss + backward: h rows and the per-sample loss inputs in; dh, heads, mu / sigma refresh out
+    loss = n * H * lp + n * (3 * A + 4) * 4 + n * H * lp + n * (A + 1) * 4 + 2 * n * A * 4
+    # LSTM backward: dh, gates, cell states, w_hh, done flags in; dG out
+    bwd = n * H * lp + T * B * 4 * H * lp + (2 * B * H * 4 + (T - 1) * B * H * lp) + 4 * H * H * lp + B * T + n * 4 * H * lp
+    # MLP backward: dG (second pass) and the three stored activations in; the three pre-activation gradients out
+    mlpb = n * 4 * H * lp + 2 * n * (U1 + U2 + U3) * lp + (U3 * 4 * H + U2 * U3 + U1 * U2) * lp
+    # LSTM weight gradients: dG and [x | h] in, 32 row slices of the [4H, wpad + H] fp32 product out
+    wcat = n * 4 * H * lp + n * wpad * lp + B * T * H * lp + 32 * 4 * H * (wpad + H) * 4
+    # MLP forward: observations (fp32) in, three activations out (+ the LSTM operand's observation block)
+    mlpf = n * F * 4 + n * (U1 + U2 + U3 + 32) * lp
+    rows = [
+        ("trunk_phases_kernel", fwd + loss + bwd + mlpb, steps,
+         {"phases": {"lstm_forward": fwd, "layernorm_heads_loss": loss, "lstm_backward": bwd, "mlp_backward": mlpb}}),
+        ("wgrad_cat_wide_kernel", wcat, steps, {}),
+        ("mlp3_elu_mfma_kernel", mlpf, steps, {}),
+        ("vine_step_quad_kernel", 320 * N if F == 28 else 280 * N, agent.horizon_length, {"bound": "valu"}),
+    ]
+    out = []
+    for name, algo, launches, more in rows:
+        key = next((k for k in prof if k.startswith(name)), None)
+        if key is None:
+            continue
+        r = prof[key]
+        us = r["avg_ns"] / 1e3
+        row = {"kernel": key, "in_situ_us": us, "launches_per_iteration": launches, "algorithmic_bytes": int(algo),
+               "achieved_GBs": algo / us / 1e3, "peak_GBs": 8000.0, "hbm_frac": algo / us / 1e3 / 8000.0,
+               "traffic_bytes": r.get("traffic_bytes"), "source": os.path.relpath(files[0], repo)}
+        if r.get("traffic_bytes"):
+            row["traffic_over_algorithmic"] = r["traffic_bytes"] / algo
+            row["traffic_hbm_frac"] = r["traffic_bytes"] / us / 1e3 / 8000.0
+        row.update(more)
+        out.append(row)
+    # MFMA-bound rows from the same trace: the rollout's LSTM step (fp32 products from bf16 pieces)
+    terms = (getattr(agent, "_fast", None) or {}).get("f32_split", 0)
+    key = next((k for k in prof if k.startswith("lstm_step_split_kernel") or k.startswith("lstm_step_nsplit_kernel")), None)
+    if key is not None and terms:
+        kt = 9 if ", 9>" in key else 6
+        us = prof[key]["avg_ns"] / 1e3
+        flop32 = 2.0 * N * (wpad + H) * 4 * H
+        out.append({"kernel": key, "bound": "mfma", "in_situ_us": us, "launches_per_iteration": agent.horizon_length + 1,
+                    "algorithmic_fp32_flops": flop32, "executed_bf16_flops": kt * flop32,
+                    "achieved_TFLOPs": kt * flop32 / us / 1e6, "peak_TFLOPs": 2500.0, "frac": kt * flop32 / us / 1e6 / 2500.0,
+                    "delivered_fp32_TFLOPs": flop32 / us / 1e6, "traffic_bytes": prof[key].get("traffic_bytes"),
+                    "source": os.path.relpath(files[0], repo)})
+    return out
+
+
+def ppo_iteration_rate(env, cfg, steps=20, warmup=3, amp=None, use_graphs=True):
     """Whole PPO iterations (rollout with policy inference + GAE + every optimiser step) on ``env`` with the packaged
     train config: the same quantity as the bench line's ``value`` for another task configuration (bench.py `configs`)."""
     import copy
@@ -230,9 +308,33 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     torch.cuda.synchronize()
     env_only_s = time.perf_counter() - t1
     env_only_kernel_ms = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+    # the same kernel as the DEVICE runs it inside the rollout graph: 64 launches captured into one hipGraph and replayed,
+    # timed by ONE pair of events around the replays -- event pairs around single eager launches are host-bound (25.7 us for
+    # a kernel whose trace duration is 23.1 us); the graph form leaves only the ~1 us between two nodes
+    graph_kernel_ms = None
+    if conf["use_graphs"] and getattr(env, "graph_capturable", True):
+        try:
+            gcap = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gcap, capture_error_mode="thread_local"):
+                for i in range(64):
+                    orig(pool[i % 16], env.obs_buf)
+            gcap.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                gcap.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            graph_kernel_ms = e0.elapsed_time(e1) / (8 * 64)
+            del gcap
+        except RuntimeError:
+            torch.cuda.synchronize()
     # kernel duration inside the timed region when it was launched eagerly; otherwise (launches live inside the
-    # replayed hipGraph, where no event can be recorded) the same kernel timed back-to-back just above
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / len(events) if events else env_only_kernel_ms
+    # replayed hipGraph, where no event can be recorded) the same kernel replayed back to back from a graph just above
+    kernel_ms = (sum(a.elapsed_time(b) for a, b in events) / len(events) if events
+                 else (graph_kernel_ms if graph_kernel_ms is not None else env_only_kernel_ms))
     in_sync = None
     if world > 1:       # replicas must hold identical weights and learning rate after all-reduced updates
         import torch.distributed as dist
@@ -308,8 +410,8 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
     ppo_kernels = None
     if world == 1 and agent.fused_mixed and not getattr(args, "no_secondary", False):
         try:
-            ppo_kernels = ppo_kernel_rooflines(agent.device)
-        except (AssertionError, RuntimeError) as err:
+            ppo_kernels = ppo_path_rooflines(agent)
+        except (AssertionError, RuntimeError, KeyError, ValueError) as err:
             ppo_kernels = "unavailable: %s" % str(err)[:100]
     extra = {
         "update_precision": precision,
@@ -325,6 +427,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         # and what the collective probe said -- top level, next to replicas_in_sync (also under ppo.collective_in_graph)
         "collective_in_graph": getattr(agent, "collective_capture", None) if (world > 1 or conf["multi_gpu"]) else None,
         "env_only": {"env_steps_per_sec": env.num_envs * world * n_env_only / env_only_s, "kernel_ms": env_only_kernel_ms,
+                     "graph_replayed_kernel_ms": graph_kernel_ms,
                      "steps": n_env_only, "note": "VecTask.step alone on resident random actions, per-rank x ranks"},
         "ppo_iters_per_sec": steps / elapsed,
         "rollout_env_steps_per_sec": frames * world * steps / max(play, 1e-9),
