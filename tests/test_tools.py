@@ -53,3 +53,56 @@ def test_bench_matches_pmc_summaries_by_instantiation():
     assert abs(c["valu_issue_frac"] - per_wave * 1024 / (ms * 1e-3) / (1024 * 2.4e9 / 2)) < 1e-12
     assert 0.15 < c["valu_issue_frac"] < 0.3 and abs(c["flop_frac"] - 27149.0 * 16384 / (ms * 1e-3) / 157.3e12) < 1e-12
     assert json.dumps(c)          # serialisable
+
+
+def test_traffic_summary_and_on_path_rooflines_reproduce_by_hand(tmp_path, monkeypatch, capsys):
+    """scripts/pmc_traffic_summary.py on a hand-made pair of counter passes + a kernel-stats table (the x2 FETCH_SIZE
+    correction, per-dispatch sums over the XCD rows, the in-situ duration from the graphed trace), and
+    bench_support.ppo_path_rooflines on the newest COMMITTED summary: every figure of a row follows from the file it names
+    and from the shapes of the agent."""
+    import types
+    root = tmp_path / "ppo_traffic_x"
+    for sub in ("pmc_fetch/a", "pmc_write/a", "trace/a"):
+        (root / sub).mkdir(parents=True)
+    hdr = "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+    k = "(anonymous namespace)::trunk_phases_kernel((anonymous namespace)::TrunkPhasesArgs)"
+    k2 = "void (anonymous namespace)::wgrad_cat_wide_kernel<6, 2>(int, int)"
+    (root / "pmc_fetch/a/1_counter_collection.csv").write_text(
+        hdr + '1,"%s",FETCH_SIZE,100\n1,"%s",FETCH_SIZE,50\n2,"%s",FETCH_SIZE,170\n3,"%s",FETCH_SIZE,10\n' % (k, k, k, k2))
+    (root / "pmc_write/a/1_counter_collection.csv").write_text(
+        hdr + '1,"%s",WRITE_SIZE,200\n2,"%s",WRITE_SIZE,220\n3,"%s",WRITE_SIZE,40\n' % (k, k, k2))
+    (root / "trace/a/1_kernel_stats.csv").write_text(
+        'Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n"%s",4,600000,150000,75.0,1,2,0\n"%s",4,200000,50000,25.0,1,2,0\n' % (k, k2))
+    mod = _load(os.path.join(REPO, "scripts", "pmc_traffic_summary.py"), "pmc_traffic_summary")
+    monkeypatch.setattr(sys, "argv", ["pmc_traffic_summary.py", str(root)])
+    mod.main()
+    out = json.load(open(root / "pmc_summary.json"))
+    t = out["trunk_phases_kernel"]
+    assert t["pmc_launches"] == 2 and t["FETCH_SIZE_KiB"] == 160.0 and t["WRITE_SIZE_KiB"] == 210.0      # (100 + 50 | 170) / 2
+    assert t["traffic_bytes"] == (2 * 160.0 + 210.0) * 1024 and t["avg_ns"] == 150000.0
+    assert abs(t["hbm_frac_of_8TBs"] - t["traffic_bytes"] / 150000.0 / 8000.0) < 1e-15
+    assert out["wgrad_cat_wide_kernel<6, 2>"]["traffic_bytes"] == (2 * 10 + 40) * 1024
+    capsys.readouterr()
+    # ---- the bench rows, from the committed profile
+    sys.path.insert(0, REPO)
+    from vine_robot_isaacgymenvs_amd.learning import bench_support
+    net = types.SimpleNamespace(rnn_units=256, units=[256, 128, 64])
+    agent = types.SimpleNamespace(model=types.SimpleNamespace(a2c_network=net), minibatch_size=32768, seq_len=4, obs_shape=(28,),
+                                  actions_num=2, mini_epochs_num=4, num_minibatches=8, num_actors=16384, horizon_length=16,
+                                  _fast={"f32_split": 6})
+    rows = bench_support.ppo_path_rooflines(agent)
+    assert rows, "no committed profiles/r*/ppo_traffic_*_pmc_summary.json"
+    by = {r["kernel"].split("<")[0]: r for r in rows}
+    prof = json.load(open(os.path.join(REPO, rows[0]["source"])))
+    tr = by["trunk_phases_kernel"]
+    assert tr["launches_per_iteration"] == 32 and tr["in_situ_us"] == prof["trunk_phases_kernel"]["avg_ns"] / 1e3
+    # the LSTM forward phase's bytes by hand: x + h0, c0 + weights + done flags in; h [B, T + 1, H], c, gates out (B = 8192, T = 4)
+    B, T, H, wpad = 8192, 4, 256, 96
+    fwd = B * T * wpad * 2 + 2 * B * H * 4 + 4 * H * (wpad + H) * 2 + B * T + B * (T + 1) * H * 2 + ((T - 1) * B * H * 2 + B * H * 4) + T * B * 4 * H * 2
+    assert tr["phases"]["lstm_forward"] == fwd == 132874240
+    assert tr["algorithmic_bytes"] == sum(tr["phases"].values())
+    assert abs(tr["hbm_frac"] - tr["algorithmic_bytes"] / tr["in_situ_us"] / 1e3 / 8000.0) < 1e-12
+    assert tr["traffic_bytes"] == prof["trunk_phases_kernel"]["traffic_bytes"]
+    assert 0.9 < tr["traffic_over_algorithmic"] < 1.3                  # the counters agree with the byte formulas
+    assert by["vine_step_quad_kernel"]["algorithmic_bytes"] == 320 * 16384 and by["vine_step_quad_kernel"]["bound"] == "valu"
+    assert any(r.get("bound") == "mfma" for r in rows) and json.dumps(rows)
