@@ -592,6 +592,43 @@ int vine_adam_step_amp(int64_t n, float* params, float* grads, float* exp_avg, f
 int vine_adaptive_lr(float* lr, const float* kl, float kl_scale, float kl_threshold, float min_lr, float max_lr,
                      void* stream);
 
+/* One ROLLOUT step in one launch (round 5): policy head -> vine_step -> rollout bookkeeping, for the PPO loop around the env
+ * (rl_games play_steps_rnn; in-tree text common_agent.py:257-317).  What three launches did -- vine_policy_head (LayerNorm +
+ * mu / value heads of the LSTM output rows, Gaussian sampling, neglogp, value un-normalisation), vine_step, vine_rollout_post
+ * (reward shaping + time-out bootstrap, done flags, episode accumulators, LSTM-state rows of finished envs cleared) -- the
+ * four-lanes-per-env step kernel does in its prologue and epilogue: the sampled action never leaves the registers, the
+ * value is still there when the bootstrap needs it, and two of the five launches of a rollout step (and their ~1.5 us
+ * boundaries) are gone.  Same formulas and the same Philox keys as the separate kernels (include/vine_ppo.h); the LayerNorm
+ * is two-pass (mean, then centred moments) over 64 units per lane.  A == 2 actions, H == 256.
+ *   y [N, 256] fp32: LSTM output rows;  hw [3][256], hc [3]: vine_rollout_head_prep's products gamma_u w_k[u] (k = mu_0, mu_1,
+ *   value) and constants sum_u beta_u w_k[u] + b_k;  logstd [2];  value_mean / value_var: float64 scalars of the value
+ *   normaliser (NULL: values are not un-normalised), value_eps its epsilon;  seed / counter: the head's Philox key and the
+ *   rollout counter (device scalar, read only);  *_out: the step's rows of the rollout buffers.
+ *   reward_shift / reward_scale / gamma_bootstrap, shaped_out [N], dones_out [N] u8, cur_rewards / cur_lengths [N] in/out,
+ *   h_state / c_state [N, 256] (rows of finished envs cleared), h_op (nullable; fp32, row stride h_op_stride floats): the
+ *   operand copy of h the next inference step reads, partial [vine_step_rollout_blocks(h)][3]: per-workgroup {sum of finished
+ *   returns, sum of finished lengths, count} for vine_rollout_finalize / the fold that rides in the next MLP launch.
+ * Returns VINE_ERR_UNSUPPORTED when the handle's configuration does not run the four-lane kernel. */
+typedef struct VineRolloutArgs {
+    const float* y; const float* hw; const float* hc; const float* logstd;
+    const double* value_mean; const double* value_var;
+    float ln_eps, value_eps;
+    uint64_t seed; const int64_t* counter;
+    float* mu_out; float* sigma_out; float* value_out; float* action_out; float* neglogp_out;
+    float reward_shift, reward_scale, gamma_bootstrap; int32_t reserved;
+    float* shaped_out; uint8_t* dones_out; float* cur_rewards; float* cur_lengths;
+    float* h_state; float* c_state; float* h_op; int64_t h_op_stride;
+    float* partial;
+} VineRolloutArgs;
+struct VineHandle;      /* include/vine.h */
+int vine_step_rollout(struct VineHandle* h, const VineRolloutArgs* args, float* obs, float* rew, int64_t* reset, int64_t* progress,
+                      uint8_t* timeouts, void* stream);
+int32_t vine_step_rollout_blocks(struct VineHandle* h);
+int32_t vine_step_rollout_args_size(void);      /* sizeof(VineRolloutArgs): checked against the ctypes mirror */
+int vine_rollout_head_prep(const float* ln_gamma, const float* ln_beta, const float* w_mu, const float* b_mu, const float* w_v,
+                           const float* b_v, float* hw, float* hc, void* stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,7 @@ def test_ppo_header_symbols_exported_and_mirrored(hip_lib):
     text = open(os.path.join(REPO, "include", "vine_ppo.h")).read()
     assert int(re.search(r"#define VINE_PPO_PARTIAL_BLOCKS (\d+)", text).group(1)) == abi.PPO_PARTIAL_BLOCKS
     assert hip_lib.vine_trunk_args_size() == C.sizeof(abi.TrunkArgs)      # VineTrunkArgs <-> its ctypes mirror
+    assert hip_lib.vine_step_rollout_args_size() == C.sizeof(abi.RolloutArgs)      # VineRolloutArgs likewise
     m = re.search(r"#define VINE_ROLLOUT_POST_SCRATCH_FLOATS \((\d+) \* (\d+)\)", text)
     assert int(m.group(1)) * int(m.group(2)) == abi.ROLLOUT_POST_SCRATCH_FLOATS
 

@@ -1805,7 +1805,8 @@ def test_rollout_plumbing_switches_are_bit_identical(monkeypatch):
     from vine_robot_isaacgymenvs_amd.learning.a2c_continuous import A2CAgent
     from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
 
-    def run(fin, copybatch, head_rms):
+    def run(fin, copybatch, head_rms, step_fused=0, rollouts=3):
+        monkeypatch.setenv("VINE_ROLLOUT_STEP_FUSED", str(step_fused))      # (round 5's one-launch step: compared below)
         monkeypatch.setenv("VINE_ROLLOUT_FIN_RIDE", str(fin))
         monkeypatch.setenv("VINE_ROLLOUT_COPYBATCH", str(copybatch))
         monkeypatch.setenv("VINE_POLICY_HEAD_RMS", str(head_rms))
@@ -1823,7 +1824,7 @@ def test_rollout_plumbing_switches_are_bit_identical(monkeypatch):
         vms.running_mean.fill_(0.37); vms.running_var.fill_(2.3)          # a head that really un-normalises
         agent.set_eval()
         with torch.no_grad():
-            for _ in range(3):
+            for _ in range(rollouts):
                 agent.play_steps_rnn()
         torch.cuda.synchronize()
         out = {k: v.clone() for k, v in agent.buf.items()}
@@ -1831,11 +1832,12 @@ def test_rollout_plumbing_switches_are_bit_identical(monkeypatch):
                    cur_r=agent.current_rewards.clone(), cur_l=agent.current_lengths.clone(), dones=agent.dones.clone(),
                    h=agent.mb_rnn_states[0].clone(), c=agent.mb_rnn_states[1].clone(), h_live=agent.rnn_states[0].clone())
         pend = agent._pending_fin
+        launches = agent.rollout_step_launches
         env.close()
-        return out, pend
+        return out, (pend, launches)
 
-    base, pend = run(1, 1, 1)
-    assert pend is None                                               # the last-values forward carried the last fold
+    base, (pend, launches) = run(1, 1, 1)
+    assert pend is None and launches == 5                             # the last-values forward carried the last fold
     assert int(base["counter"]) == 48 and float(base["meter"][1]) > 0 and float(base["meter"][3]) > 0     # episodes finished (20-step limit)
     for combo in ((0, 1, 1), (1, 0, 1), (0, 0, 1)):
         other, _ = run(*combo)
@@ -1848,6 +1850,18 @@ def test_rollout_plumbing_switches_are_bit_identical(monkeypatch):
             torch.testing.assert_close(other[k], base[k], rtol=2e-6, atol=2e-6, msg=k)
         else:
             assert torch.equal(base[k], other[k]), k
+    # round 5: head + env step + bookkeeping as ONE launch per step (vine_step_rollout; the default): same keys and formulas,
+    # LayerNorm sums in another order -> the first step agrees to round-off, flags and counters of the whole run exactly
+    # (the trajectories drift apart at the step kernel's own sensitivity to 1e-7 action differences: compared step 0 only)
+    base1, _ = run(1, 1, 1, rollouts=1)
+    one, (pend1, launches1) = run(1, 1, 1, step_fused=1, rollouts=1)
+    assert pend1 is None and launches1 == 3
+    assert torch.equal(one["counter"], base1["counter"]) and int(one["counter"]) == 16
+    for k in ("mus", "values", "actions", "neglogpacs", "rewards"):
+        torch.testing.assert_close(one[k][0], base1[k][0], rtol=1e-4, atol=1e-4, msg=k)
+    assert torch.equal(one["dones"][:2], base1["dones"][:2]) and torch.equal(one["obses"][0], base1["obses"][0])
+    torch.testing.assert_close(one["obses"][1], base1["obses"][1], rtol=1e-3, atol=1e-3)
+    assert torch.equal(one["cur_l"], base1["cur_l"])              # episode lengths: the same envs finished at the same steps
 
 
 @pytest.mark.gpu
@@ -1885,6 +1899,110 @@ def test_pending_rollout_fold_runs_as_its_own_launch_when_nothing_can_carry_it()
         assert torch.equal(a, b)
     assert int(res[0][7]) == 6
     assert lib.vine_rollout_finalize(None, 100.0, None, None, 1, st) == -1      # VINE_ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overrides", [[], ["task.env.CREATE_PIPE=True"], ["OBSERVATION_TYPE=TIP_AND_CART_AND_OBJ_INFO", "vine_randomize=False"]])
+def test_rollout_step_in_one_launch_matches_the_three_launches(overrides):
+    """Round 5: vine_step_rollout (policy head + env step + rollout bookkeeping inside the four-lane step kernel) against
+    vine_policy_head_rms -> vine_step -> vine_rollout_post on a twin env: same Philox keys and formulas, so the sampled
+    actions agree to fp32 round-off (the LayerNorm sums run over 4 lanes x 64 units instead of 16 x 16), everything the step
+    derives from them to the step kernel's own sensitivity, flags / counters exactly; finished envs get their LSTM-state rows
+    cleared and their episode totals into the per-workgroup rows."""
+    import ctypes as C
+    from vine_robot_isaacgymenvs_amd import abi, load_config
+    from vine_robot_isaacgymenvs_amd.abi import ROLLOUT_POST_SCRATCH_FLOATS
+    from vine_robot_isaacgymenvs_amd.tasks import isaacgym_task_map
+    lib = fused._lib()
+    dev = torch.device("cuda:0")
+    N, H, A = 1024, 256, 2
+    st = torch.cuda.current_stream().cuda_stream
+
+    def make():
+        cfg = load_config(overrides=["num_envs=%d" % N, "task.env.CREATE_PIPE=False", "task.env.maxEpisodeLength=6"] + overrides)
+        cfg["task"]["seed"] = 42
+        return isaacgym_task_map["Vine5LinkMovingBase"](cfg=cfg["task"], rl_device="cuda:0", sim_device="cuda:0",
+                                                      graphics_device_id=0, headless=True)
+    ea, eb = make(), make()
+    assert eb.rollout_step_blocks() == N * 4 // 256
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    gamma, beta = 1.0 + 0.1 * rnd(H), 0.1 * rnd(H)
+    w_mu, b_mu, w_v, b_v = 0.1 * rnd(A, H), 0.1 * rnd(A), 0.1 * rnd(1, H), 0.1 * rnd(1)
+    logstd = torch.tensor([-0.3, 0.2], device=dev)
+    vmean = torch.tensor([0.37], device=dev, dtype=torch.float64)
+    vvar = torch.tensor([2.3], device=dev, dtype=torch.float64)
+    counter = torch.tensor([3], device=dev, dtype=torch.int64)
+    hw, hc = torch.empty(3 * H, device=dev), torch.empty(3, device=dev)
+    assert lib.vine_rollout_head_prep(gamma.data_ptr(), beta.data_ptr(), w_mu.data_ptr(), b_mu.data_ptr(), w_v.data_ptr(),
+                                      b_v.data_ptr(), hw.data_ptr(), hc.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    torch.testing.assert_close(hw.view(3, H), gamma * torch.cat([w_mu, w_v]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(hc, torch.cat([(beta * w_mu).sum(1) + b_mu, (beta * w_v).sum(1) + b_v]), rtol=1e-5, atol=1e-6)
+
+    def state():
+        return dict(mu=torch.empty(N, A, device=dev), sigma=torch.empty(N, A, device=dev), value=torch.empty(N, 1, device=dev),
+                    action=torch.empty(N, A, device=dev), nlp=torch.empty(N, device=dev), shaped=torch.empty(N, 1, device=dev),
+                    dones=torch.empty(N, device=dev, dtype=torch.uint8), cur_r=torch.zeros(N, 1, device=dev),
+                    cur_l=torch.zeros(N, device=dev), h=torch.ones(1, N, H, device=dev), c=torch.ones(1, N, H, device=dev),
+                    hop=torch.ones(N, 352, device=dev), scratch=torch.zeros(ROLLOUT_POST_SCRATCH_FLOATS, device=dev),
+                    obs=torch.empty(N, ea.num_obs, device=dev), meter=torch.zeros(8, device=dev))
+    sa, sb = state(), state()
+    n_done = 0
+    for step in range(8):                       # 6-step episodes: every env finishes (time-out bootstrap) inside the run
+        y = rnd(N, H)
+        for s_ in (sa, sb):
+            s_["h"].fill_(1.0); s_["c"].fill_(1.0); s_["hop"].fill_(1.0)
+        # ---- A: three launches
+        assert lib.vine_policy_head_rms(N, A, H, y.data_ptr(), w_mu.data_ptr(), b_mu.data_ptr(), w_v.data_ptr(), b_v.data_ptr(),
+                                        logstd.data_ptr(), vmean.data_ptr(), vvar.data_ptr(), 1e-5, 12345, counter.data_ptr(),
+                                        sa["mu"].data_ptr(), sa["sigma"].data_ptr(), sa["value"].data_ptr(), sa["action"].data_ptr(),
+                                        sa["nlp"].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, st) == 0
+        ea.step_into(sa["action"], sa["obs"])
+        assert lib.vine_rollout_post_defer(N, H, ea.rew_buf.data_ptr(), ea.reset_buf.data_ptr(), ea.timeout_buf.data_ptr(),
+                                           sa["value"].data_ptr(), 0.0, 0.01, 0.99, sa["shaped"].data_ptr(), sa["dones"].data_ptr(),
+                                           sa["cur_r"].data_ptr(), sa["cur_l"].data_ptr(), sa["h"].data_ptr(), sa["c"].data_ptr(),
+                                           sa["hop"].data_ptr() + 4 * 96, 352, 0, sa["scratch"].data_ptr(), st) == 0
+        # ---- B: one launch
+        ra = abi.RolloutArgs()
+        ra.y, ra.hw, ra.hc, ra.logstd = y.data_ptr(), hw.data_ptr(), hc.data_ptr(), logstd.data_ptr()
+        ra.value_mean, ra.value_var, ra.ln_eps, ra.value_eps = vmean.data_ptr(), vvar.data_ptr(), 1e-5, 1e-5
+        ra.seed, ra.counter = 12345, counter.data_ptr()
+        ra.mu_out, ra.sigma_out, ra.value_out = sb["mu"].data_ptr(), sb["sigma"].data_ptr(), sb["value"].data_ptr()
+        ra.action_out, ra.neglogp_out = sb["action"].data_ptr(), sb["nlp"].data_ptr()
+        ra.reward_shift, ra.reward_scale, ra.gamma_bootstrap = 0.0, 0.01, 0.99
+        ra.shaped_out, ra.dones_out = sb["shaped"].data_ptr(), sb["dones"].data_ptr()
+        ra.cur_rewards, ra.cur_lengths = sb["cur_r"].data_ptr(), sb["cur_l"].data_ptr()
+        ra.h_state, ra.c_state, ra.h_op, ra.h_op_stride = sb["h"].data_ptr(), sb["c"].data_ptr(), sb["hop"].data_ptr() + 4 * 96, 352
+        ra.partial = sb["scratch"].data_ptr()
+        eb.step_rollout_into(ra, sb["obs"])
+        torch.cuda.synchronize()
+        for k in ("mu", "value", "action", "nlp"):
+            torch.testing.assert_close(sb[k], sa[k], rtol=2e-6, atol=2e-6, msg="step %d %s" % (step, k))
+        assert torch.equal(sb["sigma"], sa["sigma"])
+        assert torch.equal(eb.reset_buf, ea.reset_buf) and torch.equal(eb.timeout_buf, ea.timeout_buf), step
+        assert torch.equal(eb.progress_buf, ea.progress_buf) and torch.equal(sb["dones"], sa["dones"])
+        torch.testing.assert_close(sb["obs"], sa["obs"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(eb.rew_buf, ea.rew_buf, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(sb["shaped"], sa["shaped"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sb["cur_r"], sa["cur_r"], rtol=1e-4, atol=1e-4)
+        assert torch.equal(sb["cur_l"], sa["cur_l"])
+        for k in ("h", "c", "hop"):
+            assert torch.equal(sb[k], sa[k]), (step, k)          # rows of finished envs cleared, nothing else touched
+        done = ea.reset_buf != 0
+        assert float(sb["h"][0][done].abs().max() if done.any() else 0.0) == 0.0
+        pa = sa["scratch"][:lib.vine_rollout_post_blocks(N) * 3].view(-1, 3).sum(0)
+        pb = sb["scratch"][:eb.rollout_step_blocks() * 3].view(-1, 3).sum(0)
+        torch.testing.assert_close(pb, pa, rtol=1e-4, atol=1e-4)
+        assert float(pb[2]) == float(done.sum())
+        n_done += int(done.sum())
+        counter += 1
+    assert int(ea.progress_buf.max()) <= 6 and n_done >= N          # every env finished an episode (time-outs) inside the run
+    # the fused entry refuses what it does not cover
+    bad = abi.RolloutArgs()
+    assert lib.vine_step_rollout(eb._handle, C.addressof(bad), sb["obs"].data_ptr(), eb.rew_buf.data_ptr(), eb.reset_buf.data_ptr(),
+                                 eb.progress_buf.data_ptr(), eb.timeout_buf.data_ptr(), st) == -1
+    ea.close(); eb.close()
 
 
 # --------------------------------------------------------------------------- GradScaler semantics on the device

@@ -253,6 +253,10 @@ PPO_PROTOTYPES = {
     "vine_rollout_post": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 7 + [C.c_float, _VP, _VP, _I64,
                                                                                                   C.c_int32, _VP, _VP]),
     "vine_rollout_post_blocks": (C.c_int32, [_I64]),
+    "vine_step_rollout": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_step_rollout_blocks": (C.c_int32, [_VP]),
+    "vine_step_rollout_args_size": (C.c_int32, []),
+    "vine_rollout_head_prep": (C.c_int, [_VP] * 9),
     "vine_rollout_finalize": (C.c_int, [_VP, C.c_float, _VP, _VP, C.c_int32, _VP]),
     "vine_rollout_post_defer": (C.c_int, [_I64, _I64] + [_VP] * 4 + [C.c_float] * 3 + [_VP] * 6 + [_VP, _I64, C.c_int32, _VP, _VP]),
     "vine_gae": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP]),
@@ -268,6 +272,16 @@ PPO_PROTOTYPES = {
                                      C.c_float, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP]),
     "vine_adaptive_lr": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, _VP]),
 }
+
+
+class RolloutArgs(C.Structure):
+    """VineRolloutArgs of include/vine_ppo.h (vine_step_rollout)."""
+    _fields_ = ([(k, C.c_void_p) for k in ("y", "hw", "hc", "logstd", "value_mean", "value_var")] +
+                [("ln_eps", C.c_float), ("value_eps", C.c_float), ("seed", C.c_uint64), ("counter", C.c_void_p)] +
+                [(k, C.c_void_p) for k in ("mu_out", "sigma_out", "value_out", "action_out", "neglogp_out")] +
+                [("reward_shift", C.c_float), ("reward_scale", C.c_float), ("gamma_bootstrap", C.c_float), ("reserved", C.c_int32)] +
+                [(k, C.c_void_p) for k in ("shaped_out", "dones_out", "cur_rewards", "cur_lengths", "h_state", "c_state", "h_op")] +
+                [("h_op_stride", C.c_int64), ("partial", C.c_void_p)])
 
 
 class TrunkArgs(C.Structure):

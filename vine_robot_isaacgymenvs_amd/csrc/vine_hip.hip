@@ -26,6 +26,7 @@
 #include <new>
 
 #include "../../include/vine.h"
+#include "../../include/vine_ppo.h"      // VineRolloutArgs (vine_step_rollout)
 
 #define NL VINE_NUM_LINKS
 #define ND VINE_NUM_DOFS
@@ -1186,7 +1187,20 @@ __device__ __forceinline__ float quad_scan_incl(float v, int t) {
 #ifdef VSQ_TIMING
 __device__ unsigned long long vsq_t[1024 * 8];      // (debug build: 8 time stamps per wave, scripts/ubench/step_phases.py)
 #endif
-template <int OBS_TYPE, bool RANDOMIZE, int OBST>   // OBST bit 0: shelf, bit 1: pipe
+// ROLL (round 5, vine_step_rollout): the rollout step's policy head in front of the step and its bookkeeping behind it, in
+// this launch -- see include/vine.h.  The plain step (ROLL = false) is a separate instantiation and is not touched.
+struct RollArgs {
+    const float* y; const float* hw; const float* hc; const float* logstd;
+    const double* vmean; const double* vvar;
+    float ln_eps, veps;
+    unsigned seed_lo, seed_hi; const long long* counter;
+    float* mu_out; float* sigma_out; float* value_out; float* action_out; float* neglogp_out;
+    float shift, scale, gamma_b;
+    float* shaped; unsigned char* dones; float* cur_r; float* cur_l;
+    float* h_state; float* c_state; float* h_op; long long h_op_stride;
+    float* partial;
+};
+template <int OBS_TYPE, bool RANDOMIZE, int OBST, bool ROLL = false>   // OBST bit 0: shelf, bit 1: pipe
 __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, float* __restrict__ st,
                                                              const float* __restrict__ actions, float* __restrict__ obs,
                                                              float* __restrict__ rew, long long* __restrict__ reset,
@@ -1194,7 +1208,7 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                                                              unsigned char* __restrict__ timeouts,
                                                              float* __restrict__ reward_matrix,
                                                              const float* __restrict__ reset_values,
-                                                             unsigned long long* __restrict__ counters) {
+                                                             unsigned long long* __restrict__ counters, const RollArgs R) {
     static_assert(OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO || OBS_TYPE == VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, "");
     constexpr int NOBS = OBS_TYPE == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO ? 28 : 18;
     constexpr bool SHELF = (OBST & 1) != 0, PIPE = (OBST & 2) != 0, CONTACT = OBST != 0;
@@ -1205,13 +1219,26 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
     if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 0] = wall_clock64();
 #endif
     const unsigned long long step = step_of(P, counters);
+    float roll_sr = 0.0f, roll_sl = 0.0f, roll_cnt = 0.0f;      // (ROLL) this lane's finished-episode totals
     if (e < n) {
         // ---- everything the step needs from memory is requested FIRST, in one batch, and waited for once (behind the
         // pure-ALU random-number work below).  The prologue used to be four dependent stages -- per-lane constants fetched
         // one kernel-argument word at a time behind branches (the compiler sinks an unpinned P.x[i] into the arm of the
         // select that needs it: ~45 scalar loads, each with its own wait), the action load, the action-noise Philox, then
         // the state loads, with the body-state fields behind `if (progress == 0)` -- and took 6 of the kernel's 24 us.
-        const float2 act = reinterpret_cast<const float2*>(actions)[e];
+        float2 act = make_float2(0.0f, 0.0f);
+        float4 yq[ROLL ? 16 : 1];      // ROLL: this lane's 64 units {16 i + 4 t .. + 3 : i < 16} of the env's LSTM output row
+        float roll_cr = 0.0f, roll_cl = 0.0f;
+        if (ROLL) {
+            // (interleaved: the four lanes of a quad read 64 contiguous bytes per load -- 16 lines per wave instruction; with
+            // 64 consecutive units per lane every lane of the wave sat on its own line)
+            const float4* yr = reinterpret_cast<const float4*>(R.y + (size_t)e * 256) + t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) yq[i] = yr[4 * i];
+            roll_cr = R.cur_r[e]; roll_cl = R.cur_l[e];
+        } else {
+            act = reinterpret_cast<const float2*>(actions)[e];
+        }
         float smoothed = ST(VF_SMOOTHED_U);
         // relative joint coordinates: lane t holds joint t (dof 1 + t), everyone dof 5 and the cart
         float q_own = ST(VF_Q0 + 1 + t), qd_own = ST(VF_QD0 + 1 + t);
@@ -1318,6 +1345,54 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
 #ifdef VSQ_TIMING
         if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 3] = wall_clock64();
 #endif
+        float roll_value = 0.0f;
+        if (ROLL) {
+            // ---- policy head (vine_policy_head's formulas, ppo_kernels.hip): LayerNorm of the row (two passes: mean, then
+            // centred second moment and the three centred dot products with gamma_u w_k[u]), mu / value, sampling
+            float s1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s1 += (yq[i].x + yq[i].y) + (yq[i].z + yq[i].w);
+            const float mean = quad_sum(s1) * (1.0f / 256.0f);
+            float q2 = 0.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+            const float4* hw0 = reinterpret_cast<const float4*>(R.hw) + t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 w0 = hw0[4 * i], w1 = hw0[64 + 4 * i], w2 = hw0[128 + 4 * i];
+                const float c0 = yq[i].x - mean, c1 = yq[i].y - mean, c2 = yq[i].z - mean, c3 = yq[i].w - mean;
+                q2 += (c0 * c0 + c1 * c1) + (c2 * c2 + c3 * c3);
+                d0 += (c0 * w0.x + c1 * w0.y) + (c2 * w0.z + c3 * w0.w);
+                d1 += (c0 * w1.x + c1 * w1.y) + (c2 * w1.z + c3 * w1.w);
+                d2 += (c0 * w2.x + c1 * w2.y) + (c2 * w2.z + c3 * w2.w);
+            }
+            const float rstd = rsqrtf(quad_sum(q2) * (1.0f / 256.0f) + R.ln_eps);
+            const float m0 = rstd * quad_sum(d0) + R.hc[0], m1 = rstd * quad_sum(d1) + R.hc[1];
+            float v = rstd * quad_sum(d2) + R.hc[2];
+            if (R.vmean) {      // RunningMeanStd's own float64 statistics: mean.float(), sqrt(var.float() + eps)
+                const float vm = (float)R.vmean[0], vs = sqrtf((float)R.vvar[0] + R.veps);
+                v = fminf(fmaxf(v, -5.0f), 5.0f) * vs + vm;
+            }
+            roll_value = v;
+            unsigned r[4];
+            philox4x32_10((unsigned)e, (unsigned)(unsigned long long)R.counter[0], 0x504f4c59u, 0u, R.seed_lo, R.seed_hi, r);
+            const float u1 = 1.0f - (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+            const float u2 = (float)(r[1] >> 8) * (1.0f / 16777216.0f);
+            const float rad = sqrtf(-2.0f * __logf(u1));
+            float sn_, cs_;
+            __sincosf(6.283185307179586f * u2, &sn_, &cs_);
+            const float e0 = rad * cs_, e1 = rad * sn_;
+            const float ls0 = R.logstd[0], ls1 = R.logstd[1], sg0 = __expf(ls0), sg1 = __expf(ls1);
+            act = make_float2(m0 + sg0 * e0, m1 + sg1 * e1);
+            if (t == 0) {
+                float nlp = 0.9189385332046727f * 2.0f;
+                nlp += 0.5f * e0 * e0 + ls0;
+                nlp += 0.5f * e1 * e1 + ls1;
+                reinterpret_cast<float2*>(R.mu_out)[e] = make_float2(m0, m1);
+                reinterpret_cast<float2*>(R.sigma_out)[e] = make_float2(sg0, sg1);
+                reinterpret_cast<float2*>(R.action_out)[e] = act;
+                R.value_out[e] = v;
+                R.neglogp_out[e] = nlp;
+            }
+        }
         // ---- VecTask.step: clamp actions (vec_task.py:333); pre_physics_step (V5:922-945), replicated on the quad
         float a0 = clampf(act.x, P.clip_act), a1 = clampf(act.y, P.clip_act);
         if (RANDOMIZE && P.act_noise != 0.0f) {
@@ -1860,6 +1935,48 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                 if (SHELF) ST(VF_CONTACT_MEAN) = cmean;
             }
         }
+        if (ROLL) {
+            // ---- vine_rollout_post's bookkeeping (play_steps_rnn; common_agent.py:293-306): shaped reward with the time-out
+            // bootstrap, done flag, episode accumulators; the LSTM-state rows of a finished env are cleared by its four lanes
+            const bool done = rst != 0;
+            const float cr = roll_cr + total, cl = roll_cl + 1.0f;
+            if (t == 0) {
+                float sh = (total + R.shift) * R.scale;
+                if (R.gamma_b != 0.0f && to) sh += R.gamma_b * roll_value;
+                R.shaped[e] = sh;
+                R.dones[e] = done ? 1 : 0;
+                R.cur_r[e] = done ? 0.0f : cr;
+                R.cur_l[e] = done ? 0.0f : cl;
+                if (done) { roll_sr = cr; roll_sl = cl; roll_cnt = 1.0f; }
+            }
+            if (done) {
+                const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float4* hr = reinterpret_cast<float4*>(R.h_state + (size_t)e * 256) + t;
+                float4* cr4 = reinterpret_cast<float4*>(R.c_state + (size_t)e * 256) + t;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { hr[4 * i] = z; cr4[4 * i] = z; }
+                if (R.h_op) {
+                    float4* orow = reinterpret_cast<float4*>(R.h_op + (size_t)e * R.h_op_stride) + t;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) orow[4 * i] = z;
+                }
+            }
+        }
+    }
+    if (ROLL) {
+        // one {sum of finished returns, sum of finished lengths, count} row per workgroup, fixed order (no atomics)
+        __shared__ float roll_red[4][3];
+        float v3[3] = {roll_sr, roll_sl, roll_cnt};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v3[k] += __shfl_xor(v3[k], off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { roll_red[threadIdx.x >> 6][0] = v3[0]; roll_red[threadIdx.x >> 6][1] = v3[1]; roll_red[threadIdx.x >> 6][2] = v3[2]; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            R.partial[blockIdx.x * 3 + threadIdx.x] = (roll_red[0][threadIdx.x] + roll_red[1][threadIdx.x]) +
+                                                      (roll_red[2][threadIdx.x] + roll_red[3][threadIdx.x]);
     }
 #ifdef VSQ_TIMING
     if ((threadIdx.x & 63) == 0) vsq_t[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = wall_clock64();
@@ -2347,9 +2464,9 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     if (use_quad_kernel(h)) {
         const int qblocks = 1 << h->P.glog;
 #define LAUNCH_QUAD_O(OT, RND, OB)                                                                                         \
-    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB>), dim3(qblocks), dim3(VSQ_THREADS), 0, s, h->P, h->state, actions, obs, rew, \
+    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB, false>), dim3(qblocks), dim3(VSQ_THREADS), 0, s, h->P, h->state, actions, obs, rew, \
                        (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,              \
-                       h->reset_values, h->counters)
+                       h->reset_values, h->counters, RollArgs{})
 #define LAUNCH_QUAD(OT, RND)                        \
     do {                                            \
         if (obst == 0) LAUNCH_QUAD_O(OT, RND, 0);   \
@@ -2395,6 +2512,107 @@ int vine_step(VineHandle* h, const float* actions, float* obs, float* rew, int64
     HIP_TRY(hipGetLastError());
     return VINE_OK;
 }
+
+// ---- vine_step_rollout: policy head + step + rollout bookkeeping in one launch of the four-lane kernel (include/vine.h)
+__global__ __launch_bounds__(256) void rollout_head_prep_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                const float* __restrict__ w_mu, const float* __restrict__ b_mu,
+                                                                const float* __restrict__ w_v, const float* __restrict__ b_v,
+                                                                float* __restrict__ hw, float* __restrict__ hc) {
+    // hw[k][u] = gamma_u w_k[u], hc[k] = sum_u beta_u w_k[u] + b_k  (k = mu_0, mu_1, value; 256 units, one per thread)
+    __shared__ float red[3][4];
+    const int u = threadIdx.x;
+    const float g = gamma[u], b = beta[u];
+    const float w[3] = {w_mu[u], w_mu[256 + u], w_v[u]};
+    float part[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        hw[k * 256 + u] = g * w[k];
+        float v = b * w[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        part[k] = v;
+    }
+    if ((u & 63) == 0) { red[0][u >> 6] = part[0]; red[1][u >> 6] = part[1]; red[2][u >> 6] = part[2]; }
+    __syncthreads();
+    if (u < 3) hc[u] = ((red[u][0] + red[u][1]) + (red[u][2] + red[u][3])) + (u < 2 ? b_mu[u] : b_v[0]);
+}
+
+int vine_rollout_head_prep(const float* ln_gamma, const float* ln_beta, const float* w_mu, const float* b_mu, const float* w_v,
+                           const float* b_v, float* hw, float* hc, void* stream) {
+    if (!ln_gamma || !ln_beta || !w_mu || !b_mu || !w_v || !b_v || !hw || !hc) return fail(VINE_ERR_INVALID_ARG, "null argument to vine_rollout_head_prep");
+    hipLaunchKernelGGL(rollout_head_prep_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ln_gamma, ln_beta, w_mu, b_mu, w_v, b_v,
+                       hw, hc);
+    HIP_TRY(hipGetLastError());
+    return VINE_OK;
+}
+
+int32_t vine_step_rollout_args_size(void) { return (int32_t)sizeof(VineRolloutArgs); }
+
+int32_t vine_step_rollout_blocks(VineHandle* h) {
+    if (!h || !use_quad_kernel(h)) return 0;
+    return (int32_t)(((long long)h->P.n * 4 + VSQ_THREADS - 1) / VSQ_THREADS);      // the workgroups that own envs
+}
+
+int vine_step_rollout(VineHandle* h, const VineRolloutArgs* a, float* obs, float* rew, int64_t* reset, int64_t* progress,
+                      uint8_t* timeouts, void* stream) {
+    if (!h || !a || !obs || !rew || !reset || !progress || !timeouts || !a->y || !a->hw || !a->hc || !a->logstd || !a->counter ||
+        !a->mu_out || !a->sigma_out || !a->value_out || !a->action_out || !a->neglogp_out || !a->shaped_out || !a->dones_out ||
+        !a->cur_rewards || !a->cur_lengths || !a->h_state || !a->c_state || !a->partial ||
+        ((a->value_mean == nullptr) != (a->value_var == nullptr)) || (a->h_op && a->h_op_stride < 256))
+        return fail(VINE_ERR_INVALID_ARG, "null or inconsistent argument to vine_step_rollout");
+    if (((uintptr_t)a->y | (uintptr_t)a->hw | (uintptr_t)a->h_state | (uintptr_t)a->c_state | (uintptr_t)a->h_op) & 15 ||
+        ((uintptr_t)a->mu_out | (uintptr_t)a->sigma_out | (uintptr_t)a->action_out) & 7 || (a->h_op && (a->h_op_stride & 3)))
+        return fail(VINE_ERR_INVALID_ARG, "vine_step_rollout: misaligned row pointer");
+    if (!use_quad_kernel(h)) return fail(VINE_ERR_UNSUPPORTED, "vine_step_rollout needs the four-lanes-per-env step kernel");
+    DeviceGuard guard(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (step_grid_log2(h) != h->P.glog) {
+        const int64_t now = vine_get_step_count(h);
+        if (now < 0) return fail(VINE_ERR_DEVICE, "step count unreadable");
+        h->P.glog = step_grid_log2(h);
+        const int rc = vine_set_step_count(h, now);
+        if (rc != VINE_OK) return rc;
+    }
+    if (h->refresh_body) {
+        h->refresh_body = false;
+        hipLaunchKernelGGL(vine_refresh_body_kernel, dim3((h->P.n + 255) / 256), dim3(256), 0, s, h->P, h->state,
+                           (const long long*)progress);
+    }
+    RollArgs R;
+    R.y = a->y; R.hw = a->hw; R.hc = a->hc; R.logstd = a->logstd; R.vmean = a->value_mean; R.vvar = a->value_var;
+    R.ln_eps = a->ln_eps; R.veps = a->value_eps; R.seed_lo = (unsigned)a->seed; R.seed_hi = (unsigned)(a->seed >> 32);
+    R.counter = (const long long*)a->counter; R.mu_out = a->mu_out; R.sigma_out = a->sigma_out; R.value_out = a->value_out;
+    R.action_out = a->action_out; R.neglogp_out = a->neglogp_out; R.shift = a->reward_shift; R.scale = a->reward_scale;
+    R.gamma_b = a->gamma_bootstrap; R.shaped = a->shaped_out; R.dones = a->dones_out; R.cur_r = a->cur_rewards;
+    R.cur_l = a->cur_lengths; R.h_state = a->h_state; R.c_state = a->c_state; R.h_op = a->h_op; R.h_op_stride = a->h_op_stride;
+    R.partial = a->partial;
+    const int qblocks = 1 << h->P.glog;
+    const bool rnd = (h->P.flags & VINE_FLAG_VINE_RANDOMIZE) != 0;
+    const int obst = ((h->P.flags & VINE_FLAG_CREATE_SHELF) ? 1 : 0) | ((h->P.flags & VINE_FLAG_CREATE_PIPE) ? 2 : 0);
+#define LAUNCH_ROLL_O(OT, RND, OB)                                                                                         \
+    hipLaunchKernelGGL((vine_step_quad_kernel<OT, RND, OB, true>), dim3(qblocks), dim3(VSQ_THREADS), 0, s, h->P, h->state, (const float*)nullptr, obs, rew, \
+                       (long long*)reset, (long long*)progress, (unsigned char*)timeouts, h->reward_matrix,              \
+                       h->reset_values, h->counters, R)
+#define LAUNCH_ROLL(OT, RND)                        \
+    do {                                            \
+        if (obst == 0) LAUNCH_ROLL_O(OT, RND, 0);   \
+        else if (obst == 1) LAUNCH_ROLL_O(OT, RND, 1); \
+        else if (obst == 2) LAUNCH_ROLL_O(OT, RND, 2); \
+        else LAUNCH_ROLL_O(OT, RND, 3);             \
+    } while (0)
+    if (h->P.obs_type == VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO) {
+        if (rnd) LAUNCH_ROLL(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, true);
+        else LAUNCH_ROLL(VINE_OBS_POS_AND_FD_VEL_AND_OBJ_INFO, false);
+    } else {
+        if (rnd) LAUNCH_ROLL(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, true);
+        else LAUNCH_ROLL(VINE_OBS_TIP_AND_CART_AND_OBJ_INFO, false);
+    }
+#undef LAUNCH_ROLL
+#undef LAUNCH_ROLL_O
+    HIP_TRY(hipGetLastError());
+    return VINE_OK;
+}
+
 
 int vine_reset_idx(VineHandle* h, const int64_t* env_ids, int64_t n, float* rew, int64_t* reset, int64_t* progress,
                    void* stream) {

@@ -756,6 +756,25 @@ class A2CAgent:
                          and obs.dtype == torch.float32 and os.environ.get("VINE_ROLLOUT_FIN_RIDE", "1") != "0")
         post_blocks = int(lib.vine_rollout_post_blocks(N)) if defer_fin else 0
         self._pending_fin = None
+        # Round 5: policy head + env step + bookkeeping as ONE launch (vine_step_rollout: a rollout step is 3 launches instead
+        # of 5) where the task runs the four-lanes-per-env kernel and the head has the default shape; VINE_ROLLOUT_STEP_FUSED=0
+        # / `rollout_step_fused: False` = the three launches
+        roll_blocks = int(env.rollout_step_blocks()) if hasattr(env, "rollout_step_blocks") else 0
+        step_fused = bool(defer_fin and direct and head_rms and fast and self._fast["ln_in_head"] and A == 2 and H == 256
+                          and h_op_bf16 == 0 and roll_blocks > 0 and roll_blocks * 3 <= self._post_scratch.numel()
+                          and self.config.get("rollout_step_fused", True)
+                          and os.environ.get("VINE_ROLLOUT_STEP_FUSED", "1") != "0")
+        if step_fused:
+            if getattr(self, "_roll_head", None) is None:
+                self._roll_head = (torch.empty(3 * H, device=self.device), torch.empty(3, device=self.device))
+                self._roll_args = []
+            hw, hc = self._roll_head
+            fused._check(lib.vine_rollout_head_prep(net.layer_norm.weight.data_ptr(), net.layer_norm.bias.data_ptr(),
+                                                    net.mu.weight.data_ptr(), net.mu.bias.data_ptr(), net.value.weight.data_ptr(),
+                                                    net.value.bias.data_ptr(), hw.data_ptr(), hc.data_ptr(), st),
+                         "vine_rollout_head_prep")
+            self._roll_args.clear()
+        self.rollout_step_launches = 3 if step_fused else (5 if defer_fin else 6)
         for n in range(self.horizon_length):
             if n % self.seq_len == 0 and not (batched and n == 0):
                 if batched:          # both states in one launch
@@ -775,10 +794,32 @@ class A2CAgent:
                 # (direct: the env and the post-step kernel wrote slot n themselves, one step ago)
                 buf["obses"][n].copy_(obs)
                 buf["dones"][n].copy_(self.dones)
+            last = n + 1 == self.horizon_length
+            if step_fused:
+                ra = abi.RolloutArgs()
+                ra.y, ra.hw, ra.hc, ra.logstd = y.data_ptr(), hw.data_ptr(), hc.data_ptr(), net.sigma.data_ptr()
+                ra.value_mean, ra.value_var = vms.running_mean.data_ptr(), vms.running_var.data_ptr()
+                ra.ln_eps, ra.value_eps = float(net.layer_norm.eps), float(vms.epsilon)
+                ra.seed, ra.counter = int(self.head_seed), self.roll_counter.data_ptr()
+                ra.mu_out, ra.sigma_out, ra.value_out = buf["mus"][n].data_ptr(), buf["sigmas"][n].data_ptr(), buf["values"][n].data_ptr()
+                ra.action_out, ra.neglogp_out = buf["actions"][n].data_ptr(), buf["neglogpacs"][n].data_ptr()
+                ra.reward_shift, ra.reward_scale, ra.gamma_bootstrap = float(self.reward_shift), float(self.reward_scale), gamma_b
+                ra.shaped_out = buf["rewards"][n].data_ptr()
+                ra.dones_out = (self.dones if last else buf["dones"][n + 1]).data_ptr()
+                ra.cur_rewards, ra.cur_lengths = self.current_rewards.data_ptr(), self.current_lengths.data_ptr()
+                ra.h_state, ra.c_state = self.rnn_states[0].data_ptr(), self.rnn_states[1].data_ptr()
+                # the operand copy of h that the NEXT step reads (the buffer _infer just switched to)
+                ra.h_op = self._fast["xh2"][self._fast["cur"]].data_ptr() + 4 * self._fast["XW"]
+                ra.h_op_stride = h_op_stride
+                ra.partial = self._post_scratch.data_ptr()
+                self._roll_args.append(ra)          # (the launch copies the struct; kept for the record only)
+                obs = env.step_rollout_into(ra, self._obs_last if last else buf["obses"][n + 1])
+                self._pending_fin = (self.meter.data_ptr(), float(self.games_to_track), self.roll_counter.data_ptr(),
+                                     self._post_scratch.data_ptr(), roll_blocks)
+                continue
             head(y, n, buf["values"][n], buf["mus"][n], buf["sigmas"][n], buf["actions"][n], buf["neglogpacs"][n])
             # the env kernel clamps to +-clipActions itself (vec_task.py:333); with the [-1, 1] action space
             # rl_games' preprocess_actions (clamp + affine rescale) is the identity on top of that
-            last = n + 1 == self.horizon_length
             if direct:
                 # next observation and next done flags straight into their rollout-buffer slots (the last ones into
                 # the tensors the next iteration starts from)

@@ -242,6 +242,26 @@ class Vine5LinkMovingBase(VecTask):
                                          self.timeout_buf.data_ptr(), self._stream()), self._lib)
         self.num_steps += 1
 
+    def rollout_step_blocks(self):
+        """Rows of the per-workgroup episode sums ``step_rollout_into`` writes (0: this configuration does not run the
+        four-lanes-per-env kernel, the fused rollout step is not available)."""
+        return 0 if self.mat is not None else int(self._lib.vine_step_rollout_blocks(self._handle))
+
+    def step_rollout_into(self, args, obs_out):
+        """One ROLLOUT step in one launch (``vine_step_rollout``, include/vine_ppo.h): the policy head on the LSTM output
+        rows in front of the step, the rollout bookkeeping behind it -- an extension for the PPO loop (the trainer's
+        ``_rollout_body_fused``); ``VecTask.step`` / ``step_into`` are untouched.  ``args``: abi.RolloutArgs; the
+        observation goes to ``obs_out`` and the buffers are re-bound exactly as ``step_into`` does."""
+        import ctypes as C
+        native.check(self._lib.vine_step_rollout(self._handle, C.addressof(args), obs_out.data_ptr(), self.rew_buf.data_ptr(),
+                                                 self.reset_buf.data_ptr(), self.progress_buf.data_ptr(),
+                                                 self.timeout_buf.data_ptr(), self._stream()), self._lib)
+        self.num_steps += 1
+        self.obs_buf = obs_out
+        self.obs_dict["obs"] = obs_out.to(self.rl_device)
+        self.extras["time_outs"] = self.timeout_buf.to(self.rl_device)
+        return obs_out
+
     def reset_idx(self, env_ids):
         """V5:774-839 for callers outside the step (reset_done, V5:715-718)."""
         ids = torch.as_tensor(env_ids, device=self.device).to(torch.long).contiguous()
