@@ -884,7 +884,10 @@ __device__ __forceinline__ void lstm_seq_bwd_body(
                     const int e = 4 * ut + u;
                     float dh = gout[u];
                     if (!first) dh += keep_n * acc[ut][rt][u];
-                    const float dc = first ? 0.0f : keep_n * dcarry[rt][e];
+                    float dc = first ? 0.0f : keep_n * dcarry[rt][e];
+                    // (with `first` a compile-time constant the product above would be contracted into the sum below as one
+                    // fma -- the step kernels, where it sits behind a select, round it separately: keep the two bit-identical)
+                    if (!first) asm volatile("" : "+v"(dc));
                     const float tc = tanhf_(cnew[rt][e]);
                     const float d_o = dh * tc;
                     const float d_c = dc + dh * go[u] * (1.0f - tc * tc);
