@@ -2,7 +2,7 @@
 # HBM-side traffic (FETCH_SIZE, WRITE_SIZE: separate passes, kernel-trace only) of every kernel of real PPO iterations,
 # beside the kernel trace of the PRODUCTION (graph-replayed) path of the same tree.  Run on the GPU box via gpurun:
 #     scripts/profile_ppo_traffic.sh <tag> [extra bench args]
-# -> gpurun_out/ppo_traffic_<tag>/{kernel_stats.csv,pmc_summary.json,summary.txt}
+# -> gpurun_out/ppo_traffic_<tag>/{kernel_stats.csv,pmc_summary.json,summary.txt}; committed as profiles/rNN/ppo_traffic_<tag>_<N>envs_*
 # The counter passes run the iteration eagerly (--no-graph: the same kernels with the same arguments, one dispatch record
 # each); the in-situ durations come from the graphed trace.
 set -o pipefail

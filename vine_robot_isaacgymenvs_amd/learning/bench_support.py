@@ -139,7 +139,9 @@ def ppo_path_rooflines(agent):
     import json
     import os
     repo = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    files = sorted(glob.glob(os.path.join(repo, "profiles", "r*", "ppo_traffic_*pmc_summary.json")), reverse=True)
+    # the newest committed profile taken at this env count (file names carry it: ppo_traffic_<tag>_<N>envs_pmc_summary.json)
+    files = sorted(glob.glob(os.path.join(repo, "profiles", "r*", "ppo_traffic_*_%denvs_pmc_summary.json" % agent.num_actors)),
+                   reverse=True)
     if not files:
         return None
     prof = json.load(open(files[0]))
