@@ -105,4 +105,7 @@ def test_traffic_summary_and_on_path_rooflines_reproduce_by_hand(tmp_path, monke
     assert tr["traffic_bytes"] == prof["trunk_phases_kernel"]["traffic_bytes"]
     assert 0.9 < tr["traffic_over_algorithmic"] < 1.3                  # the counters agree with the byte formulas
     assert by["vine_step_quad_kernel"]["algorithmic_bytes"] == 320 * 16384 and by["vine_step_quad_kernel"]["bound"] == "valu"
+    agent.rollout_step_launches = 3                                    # the one-launch rollout step: the ROLL instantiation's row
+    roll = {r["kernel"].split("<")[0]: r for r in bench_support.ppo_path_rooflines(agent)}["vine_step_quad_kernel"]
+    assert roll["kernel"].endswith(", true>") and roll["algorithmic_bytes"] == 320 * 16384 + 16384 * (256 * 4 + 9 * 4 + 1)
     assert any(r.get("bound") == "mfma" for r in rows) and json.dumps(rows)

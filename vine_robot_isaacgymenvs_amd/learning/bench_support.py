@@ -174,11 +174,19 @@ def ppo_path_rooflines(agent):
          {"phases": {"lstm_forward": fwd, "layernorm_heads_loss": loss, "lstm_backward": bwd, "mlp_backward": mlpb}}),
         ("wgrad_cat_wide_kernel", wcat, steps, {}),
         ("mlp3_elu_mfma_kernel", mlpf, steps, {}),
-        ("vine_step_quad_kernel", 320 * N if F == 28 else 280 * N, agent.horizon_length, {"bound": "valu"}),
     ]
+    # the step kernel of the rollout: since round 5 the instantiation with the policy head and the rollout bookkeeping inside
+    # (last template argument true: + the LSTM output rows in, mu / sigma / value / action / neglogp / shaped reward / done out)
+    roll = getattr(agent, "rollout_step_launches", 5) == 3
+    env_bytes = (320 if F == 28 else 280) * N + (N * H * 4 + N * (3 * A + 3) * 4 + N if roll else 0)
+    rows.append(("vine_step_quad_kernel", env_bytes, agent.horizon_length,
+                 {"bound": "valu", "policy_head_and_bookkeeping_inside": roll}))
     out = []
     for name, algo, launches, more in rows:
-        key = next((k for k in prof if k.startswith(name)), None)
+        cands = [k for k in prof if k.startswith(name)]
+        if name == "vine_step_quad_kernel":
+            cands = [k for k in cands if k.rstrip(">").endswith(", true" if roll else ", false")] or ([] if roll else cands)
+        key = cands[0] if cands else None
         if key is None:
             continue
         r = prof[key]
