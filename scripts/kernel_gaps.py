@@ -7,7 +7,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]) for r in rows), key=lambda e: e[0])
 # steady state: from the third-last GAE launch (one per PPO iteration) to the last Adam launch
-gae = [i for i, e in enumerate(ev) if "gae_kernel" in e[2]]
+gae = [i for i, e in enumerate(ev) if "ds_gae_partial_kernel" in e[2]]
 adam = [i for i, e in enumerate(ev) if "adam_kernel" in e[2]]
 if len(gae) >= 3 and adam:
     ev = ev[gae[-3]:adam[-1] + 1]
@@ -31,7 +31,7 @@ for (a, b), v in sorted(by.items(), key=lambda kv: -sum(kv[1]))[:14]:
 
 # the glue between the rollout graph and the update graphs: from the GAE launch to the first Adam launch after it
 names = [e[2] for e in ev]
-for gi in [i for i, nme in enumerate(names) if "gae_kernel" in nme][:3]:
+for gi in [i for i, nme in enumerate(names) if "ds_gae_partial_kernel" in nme][:3]:
     aj = next((j for j in range(gi, len(ev)) if "adam_kernel" in names[j]), None)
     if aj is None:
         break
