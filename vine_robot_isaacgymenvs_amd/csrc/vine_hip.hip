@@ -400,29 +400,20 @@ __device__ __forceinline__ PipePose pipe_pose(float pipe_y, float pipe_z, float 
     const float hcy = 0.5f * PIPE_OUTER, hcz = 0.5f * PIPE_LEN;
     return PipePose{pipe_y, pipe_z, ct, st, pipe_y + hcy * ct - hcz * st, pipe_z + hcy * st + hcz * ct};
 }
+__device__ __forceinline__ unsigned pipe_broad_phase(float z0, float z1, float py, float pz, float sp, float cp,
+                                                     const PipePose& T);
+// nearbits: pipe_broad_phase of this link when the caller has it already (the four-lane kernel), PIPE_BROAD_HERE otherwise
+#define PIPE_BROAD_HERE 0xffffffffu
 __device__ __forceinline__ bool pipe_link_contact(const DevParams& P, float z0, float z1, float py, float pz, float pvy,
                                                   float pvz, float sp, float cp, float om, const PipePose& T, float& fy_tot,
-                                                  float& fz_tot, float& mom) {
+                                                  float& fz_tot, float& mom, unsigned nearbits = PIPE_BROAD_HERE) {
     const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
     const float pipe_y = T.y, pipe_z = T.z, ct = T.ct, st = T.st;
     const float dy = -sp, dz = cp, ly = cp, lz = sp;
-    // radius of the tube's bounding circle + the link's (half-length 0.05, lateral reach 0.0719 about the axis midpoint)
-    const float rsum = 0.18748f + 0.0877f + 1.0e-4f;       // hypot(0.0777, 0.170625) + hypot(0.05, 0.0719)
-    const float my = py + 0.04425f * dy - T.ccy, mz = pz + 0.04425f * dz - T.ccz;     // axis midpoint - tube centre
-    if (!(my * my + mz * mz < rsum * rsum)) return false;
-    // level 2: the rectangle's box in the pipe frame.  Local axis / lateral directions, local joint position.
-    const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;          // d in the pipe frame; l = (dlz, -dly)
-    const float gy0 = py - pipe_y, gz0 = pz - pipe_z;
-    const float jy = gy0 * ct + gz0 * st, jz = -gy0 * st + gz0 * ct;
-    const float ay0 = z0 * dly, ay1 = z1 * dly, by0 = LINK_Y0 * dlz, by1 = LINK_Y1 * dlz;
-    const float az0 = z0 * dlz, az1 = z1 * dlz, bz0 = LINK_Y0 * -dly, bz1 = LINK_Y1 * -dly;
-    const float ymin = jy + fminf(ay0, ay1) + fminf(by0, by1) - PIPE_CULL_EPS;
-    const float ymax = jy + fmaxf(ay0, ay1) + fmaxf(by0, by1) + PIPE_CULL_EPS;
-    const float zmin = jz + fminf(az0, az1) + fminf(bz0, bz1) - PIPE_CULL_EPS;
-    const float zmax = jz + fmaxf(az0, az1) + fmaxf(bz0, bz1) + PIPE_CULL_EPS;
-    const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
-    const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
-    const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
+    // broad phase (pipe_broad_phase below): (1) bounding circles of the link and of the tube, (2) the rectangle's box in the
+    // pipe frame against each wall's box
+    if (nearbits == PIPE_BROAD_HERE) nearbits = pipe_broad_phase(z0, z1, py, pz, sp, cp, T);
+    const bool near0 = (nearbits & 1u) != 0, near1 = (nearbits & 2u) != 0;
     if (!(near0 || near1)) return false;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -587,16 +578,20 @@ __device__ __forceinline__ void shelf_link_contact_coop(const DevParams& P, int 
         }
     }
 }
-__device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t, float z0, float z1, float py, float pz,
-                                                       float pvy, float pvz, float sp, float cp, float om, const PipePose& T,
-                                                       float& fy_tot, float& fz_tot, float& mom) {
-    const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
+// The broad phase of one (link, tube) pair -- levels 1 and 2 of pipe_link_contact, the same expressions -- as bit 0 / bit 1 =
+// the link's box reaches wall 0 / wall 1.  Round 5: the four-lane kernel evaluates it ONCE per link, on the lane that owns
+// the link (link 4: on every lane), and broadcasts the two bits to the lanes that share the link's narrow phase; the
+// cooperative form used to repeat it on all four lanes for each of its links (~45 instructions x 3 links per substep).
+__device__ __forceinline__ unsigned pipe_broad_phase(float z0, float z1, float py, float pz, float sp, float cp,
+                                                     const PipePose& T) {
     const float pipe_y = T.y, pipe_z = T.z, ct = T.ct, st = T.st;
-    const float dy = -sp, dz = cp, ly = cp, lz = sp;
-    const float rsum = 0.18748f + 0.0877f + 1.0e-4f;
-    const float my = py + 0.04425f * dy - T.ccy, mz = pz + 0.04425f * dz - T.ccz;
-    if (!(my * my + mz * mz < rsum * rsum)) return;
-    const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;
+    const float dy = -sp, dz = cp;
+    // radius of the tube's bounding circle + the link's (half-length 0.05, lateral reach 0.0719 about the axis midpoint)
+    const float rsum = 0.18748f + 0.0877f + 1.0e-4f;       // hypot(0.0777, 0.170625) + hypot(0.05, 0.0719)
+    const float my = py + 0.04425f * dy - T.ccy, mz = pz + 0.04425f * dz - T.ccz;     // axis midpoint - tube centre
+    if (!(my * my + mz * mz < rsum * rsum)) return 0u;
+    // level 2: the rectangle's box in the pipe frame.  Local axis / lateral directions, local joint position.
+    const float dly = dy * ct + dz * st, dlz = -dy * st + dz * ct;          // d in the pipe frame; l = (dlz, -dly)
     const float gy0 = py - pipe_y, gz0 = pz - pipe_z;
     const float jy = gy0 * ct + gz0 * st, jz = -gy0 * st + gz0 * ct;
     const float ay0 = z0 * dly, ay1 = z1 * dly, by0 = LINK_Y0 * dlz, by1 = LINK_Y1 * dlz;
@@ -608,6 +603,15 @@ __device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t
     const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
     const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
     const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
+    return (near0 ? 1u : 0u) | (near1 ? 2u : 0u);
+}
+__device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t, float z0, float z1, float py, float pz,
+                                                       float pvy, float pvz, float sp, float cp, float om, const PipePose& T,
+                                                       float& fy_tot, float& fz_tot, float& mom, unsigned nearbits) {
+    const float wall_lo[2] = {0.0f, PIPE_OUTER - PIPE_WALL};
+    const float pipe_y = T.y, pipe_z = T.z, ct = T.ct, st = T.st;
+    const float dy = -sp, dz = cp, ly = cp, lz = sp;
+    const bool near0 = (nearbits & 1u) != 0, near1 = (nearbits & 2u) != 0;      // (pipe_broad_phase of this link)
     if (!(near0 || near1)) return;
 #pragma unroll
     for (int slot = 0; slot < 2; ++slot) {
@@ -1569,17 +1573,21 @@ __global__ __launch_bounds__(256) void vine_step_quad_kernel(const DevParams P, 
                     }
                     float c2y = 0.0f, c2z = 0.0f, cm2 = 0.0f, c1y = 0.0f, c1z = 0.0f, cm1 = 0.0f;
                     if (PIPE) {
-                        if (t < VSQ_PIPE_COOP_FROM) pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom);
+                        // broad phase: link t's on lane t (z0 = 0, z1 = L for t >= 1), link 4's on every lane; two bits per
+                        // link, broadcast over the quad to the lanes that share a cooperative link's narrow phase
+                        const unsigned nb_own = pipe_broad_phase(z0, z1, py, pz, sn, cs, pipeT);
+                        const unsigned nb4 = pipe_broad_phase(0.0f, L, p4y, p4z, sn4, cs4, pipeT);
+                        if (t < VSQ_PIPE_COOP_FROM) pipe_link_contact(P, z0, z1, py, pz, pvy, pvz, sn, cs, w, pipeT, fy, fz, mom, nb_own);
 #if VSQ_PIPE_COOP_FROM <= 1
                         pipe_link_contact_coop(P, t, 0.0f, L, qbcast<1>(py), qbcast<1>(pz), qbcast<1>(pvy), qbcast<1>(pvz),
-                                               qbcast<1>(sn), qbcast<1>(cs), qbcast<1>(w), pipeT, c1y, c1z, cm1);
+                                               qbcast<1>(sn), qbcast<1>(cs), qbcast<1>(w), pipeT, c1y, c1z, cm1, qbcast_u<1>(nb_own));
 #endif
 #if VSQ_PIPE_COOP_FROM <= 2
                         pipe_link_contact_coop(P, t, 0.0f, L, qbcast<2>(py), qbcast<2>(pz), qbcast<2>(pvy), qbcast<2>(pvz),
-                                               qbcast<2>(sn), qbcast<2>(cs), qbcast<2>(w), pipeT, c2y, c2z, cm2);
+                                               qbcast<2>(sn), qbcast<2>(cs), qbcast<2>(w), pipeT, c2y, c2z, cm2, qbcast_u<2>(nb_own));
 #endif
-                        pipe_link_contact_coop(P, t, 0.0f, L, p3y, p3z, pv3y, pv3z, sn3, cs3, w3, pipeT, c3y, c3z, cm3);
-                        pipe_link_contact_coop(P, t, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, pipeT, c4y, c4z, cm4);
+                        pipe_link_contact_coop(P, t, 0.0f, L, p3y, p3z, pv3y, pv3z, sn3, cs3, w3, pipeT, c3y, c3z, cm3, qbcast_u<3>(nb_own));
+                        pipe_link_contact_coop(P, t, 0.0f, L, p4y, p4z, pv4y, pv4z, sn4, cs4, w4, pipeT, c4y, c4z, cm4, nb4);
                     }
                     {   // fold the cooperative partial sums: link 3's totals go to lane 3's slots, link 4's to every lane
                         f4y = quad_sum(c4y); f4z = quad_sum(c4z); mom4 = quad_sum(cm4);
