@@ -457,6 +457,7 @@ __device__ __forceinline__ bool pipe_link_contact(const DevParams& P, float z0, 
         if (w == 0 ? near0 : near1) {
 #pragma unroll
             for (int cidx = 0; cidx < 4; ++cidx) {
+                if (!(nearbits & ((cidx & 2) ? 8u : 4u))) continue;      // this end of the tube is outside the link's box
                 const float pyl = wall_lo[w] + ((cidx & 1) ? PIPE_WALL : 0.0f), pzl = (cidx & 2) ? PIPE_LEN : 0.0f;
                 const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
                 const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
@@ -603,7 +604,11 @@ __device__ __forceinline__ unsigned pipe_broad_phase(float z0, float z1, float p
     const bool zin = zmin < PIPE_LEN && zmax > 0.0f;
     const bool near0 = zin && ymin < PIPE_WALL && ymax > 0.0f;
     const bool near1 = zin && ymin < PIPE_OUTER && ymax > PIPE_OUTER - PIPE_WALL;
-    return (near0 ? 1u : 0u) | (near1 ? 2u : 0u);
+    // bits 2, 3: the box reaches the tube's end z = 0 / z = PIPE_LEN.  A wall's corners lie on those two lines, and a corner
+    // inside the link's rectangle lies inside the rectangle's box: a link deep inside the tube (a trained vine's links 3 and
+    // 4, most of the time) cannot contain any corner, and its corner tests -- a third of a cooperative link's narrow phase --
+    // are skipped.  Exact: the box carries the same rounding margin as above.
+    return (near0 ? 1u : 0u) | (near1 ? 2u : 0u) | (zmin < 0.0f ? 4u : 0u) | (zmax > PIPE_LEN ? 8u : 0u);
 }
 __device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t, float z0, float z1, float py, float pz,
                                                        float pvy, float pvz, float sp, float cp, float om, const PipePose& T,
@@ -643,9 +648,10 @@ __device__ __forceinline__ void pipe_link_contact_coop(const DevParams& P, int t
             }
         }
     }
+    const bool my_end = (nearbits & ((t & 2) ? 8u : 4u)) != 0;      // can this lane's corner (end t >> 1 of the tube) lie in the link's box?
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-        if (w == 0 ? near0 : near1) {                        // corner t of wall w
+        if ((w == 0 ? near0 : near1) && my_end) {            // corner t of wall w
             const float pyl = wall_lo[w] + ((t & 1) ? PIPE_WALL : 0.0f), pzl = (t & 2) ? PIPE_LEN : 0.0f;
             const float ry = pipe_y + pyl * ct - pzl * st - py, rz = pipe_z + pyl * st + pzl * ct - pz;
             const float zl = ry * dy + rz * dz, yl = ry * ly + rz * lz;
