@@ -123,7 +123,9 @@ def _pmc_summary(kernel):
         except ValueError:
             continue
         name = d.get("kernel_stats", {}).get("name", "")
-        if kernel in name or (old and old in name):
+        # (since round 5 the four-lane kernel has a fourth template argument -- the policy head / bookkeeping inside -- and the
+        # plain step is its `false` instantiation)
+        if kernel in name or (kernel[:-1] + ", false>") in name or (old and old in name):
             return f, d
     return None, None
 
