@@ -374,7 +374,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
                     % ("MLP and LSTM-gate" if mlp_split else "MLP on the fp32 matrix cores, LSTM-gate",
                        "all 9 piece pairs = every bit of every fp32 product" if terms == 9 else
                        "6 of 9 piece pairs (the three below 2^-24 of a product left out: error against float64 equal to the "
-                       "9-pair form's and below the native fp32 MFMA instruction's, profiles/r05/split_terms_error.txt)"))
+                       "9-pair form's, profiles/r05/split_terms_error.txt)"))
         else:
             roll = "rollout inference: f32 (the reference's; fp32 matrix-core kernels)"
         return upd + "; " + roll
