@@ -487,7 +487,7 @@ def main():
             # `mixed_precision: True` dtype (fp16 GEMM operands, f32 accumulation / state / loss / optimiser, GradScaler loss
             # scaling).  `other_precision` carries the same iteration with an all-f32 update, `extra_lp16_rollout` the
             # narrower 16-bit-rollout variant of round 2, `extra_native_f32_mfma_rollout` the rollout's LSTM step on the
-            # native fp32 matrix-core instruction instead of exact bf16-piece products, `extra_split6_rollout` its 6-pair form.
+            # native fp32 matrix-core instruction instead of exact bf16-piece products, `extra_split9_rollout` the 9-pair form of the (6-pair, two-accumulator) default.
             out["dtype"] = "f32 (env step, rollout inference); " + str(extra.get("update_precision", ""))
         if world == 1 and not args.no_saturated:
             out["roofline"]["saturated"] = saturated_env_rate(args, local_rank)

@@ -467,7 +467,8 @@ int vine_mlp3_elu_f32_fin(int64_t n, float* x, int64_t ldx, const float* raw, in
  * of a workgroup share 16 rt rows and own a quarter of each layer's units; weights as vine_mlp3_tile_weights_split
  * leaves them (wt: 288 fragments x 1 KB of bfloat16 pieces), activations between the layers split once by their producer
  * and exchanged through LDS.  terms: piece pairs (9 = every bit of every product, 6 = without the three pairs below
- * 2^-26 of a product) in the low byte, row tiles per workgroup (1, 2, 4; 0 = chosen from n) in the second.  C1 = 256,
+ * 2^-24 of a product) in the low byte, row tiles per workgroup (1, 2, 4; 0 = chosen from n) in the second; bit 16: two
+ * fp32 accumulators per tile, the hi x hi pair apart from the smaller pairs (see vine_lstm_step_f32_split).  C1 = 256,
  * C2 = 128, C3 = 64 fixed; F_in <= 32, n % (16 rt) == 0, ldx >= 96, else VINE_ERR_UNSUPPORTED.  fin_* as
  * vine_mlp3_elu_f32_fin.  Same output block as vine_mlp3_elu_f32.  (Replaces, on the rollout path, the fp32 network forward
  * of rl_games' play_steps: a2c_common.py's get_action_values -> model(...) under torch.no_grad, not autocast.) */
@@ -494,7 +495,11 @@ int vine_lstm_tile_weights_f32(int64_t H, int64_t K, const float* wcat, int64_t 
  * H = 256, K = 352, N % 128 == 0, 16-byte aligned pointers, else VINE_ERR_UNSUPPORTED.  Bits 8-15 of `terms`: row tiles per wave
  * (tuning knob: 0 = 4 from 16384 rows on when N % 256 == 0, else 2).  Bit 16 (bits 8-15 then zero): the same arithmetic
  * with one gate per wave -- four waves share 64 rows of one 32-unit block, weight fragments straight from global memory,
- * operand pieces exchanged through LDS -- the faster form below 16384 rows. */
+ * operand pieces exchanged through LDS -- the faster form below 16384 rows.  Bit 17 (with bit 16): TWO fp32 accumulators
+ * per tile -- the hi x hi pair of every k-block into one, the smaller pairs (each <= 2^-8 of it) into the other, added
+ * once at the end: the roundings at the result's magnitude drop from one per instruction (66 / 99) to one per k-block (11),
+ * the others happen at 2^-8 of it.  Measured against float64 (scripts/ubench/split_terms_error.py): <= 0.6x the error of
+ * vine_lstm_step_f32 on every input, max and rms, with 6 or 9 pairs alike -- the form the rollout runs (terms = 6 | 3 << 16). */
 int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, int64_t ldx, const void* w_split,
                              const float* bias, const float* c_prev, float* h_out, int64_t ldh, float* c_out, float* hp_next,
                              int64_t ldhp, int terms, void* stream);

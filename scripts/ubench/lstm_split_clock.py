@@ -36,9 +36,9 @@ for v in variants:
                                             H, c.data_ptr(), b.data_ptr() + 4 * 96, K, v, st) == 0
     e1.record()
     torch.cuda.synchronize()
-    buf = (C.c_uint64 * (4096 * 8))()
+    buf = (C.c_uint64 * (8192 * 8))()
     assert lib.vine_debug_split_timing(buf) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 4, 2).astype(np.int64)
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4, 2).astype(np.int64)
     t = t[t[:, 0, 1] > 0]
     clk = (t[:, 3, 0] - t[:, 0, 0]) / np.maximum(t[:, 3, 1] - t[:, 0, 1], 1) * 100.0          # MHz
     r0 = t[:, :, 1].min()
@@ -50,3 +50,14 @@ for v in variants:
     cyc = t[:, :, 0] - t[:, 0:1, 0]
     print("   shader cycles per wave: prologue %.0f, matrix loops %.0f, epilogue %.0f"
           % (cyc[:, 1].mean(), (cyc[:, 2] - cyc[:, 1]).mean(), (cyc[:, 3] - cyc[:, 2]).mean()))
+    # waves in the order of their entry: lifetime and phases of the waves that entered first (the launch's first fill of the
+    # chip) against the rest; when the last wave ended
+    order = np.argsort(rel[:, 0])
+    life = rel[:, 3] - rel[:, 0]
+    q = max(1, len(order) // 8)
+    for k in range(0, len(order), q):
+        sel = order[k:k + q]
+        print("   waves %5d..%5d by entry: entry %6.2f us, lifetime %6.2f us (prologue %5.0f, loops %6.0f, epilogue %5.0f cycles), end %6.2f"
+              % (k, k + len(sel) - 1, rel[sel, 0].mean(), life[sel].mean(), cyc[sel, 1].mean(), (cyc[sel, 2] - cyc[sel, 1]).mean(),
+                 (cyc[sel, 3] - cyc[sel, 2]).mean(), rel[sel, 3].mean()))
+    print("   last wave ends %.2f us after the first entry" % rel[:, 3].max())

@@ -46,11 +46,11 @@ def lstm_case(seed, dist, N=4096):
     out["native"] = (ho.double() - h, co.double() - c)
     ws = torch.empty(3 * 4 * H * K, device=dev, dtype=torch.bfloat16)
     assert lib.vine_lstm_tile_weights_split(H, K, wcat.data_ptr(), wcat.stride(0), ws.data_ptr(), st) == 0
-    for terms in (9, 6):
+    for terms, name in ((9, "9"), (6, "6"), (9 | (3 << 16), "9d"), (6 | (3 << 16), "6d")):      # d: one gate per wave, two accumulators
         assert lib.vine_lstm_step_f32_split(N, H, K, xh.data_ptr(), K, ws.data_ptr(), bias.data_ptr(), c_prev.data_ptr(),
                                             ho.data_ptr(), H, co.data_ptr(), None, 0, terms, st) == 0
         torch.cuda.synchronize()
-        out[str(terms)] = (ho.double() - h, co.double() - c)
+        out[name] = (ho.double() - h, co.double() - c)
     return {k: (float(v[0].abs().max()), float(v[0].pow(2).mean().sqrt()), float(v[1].abs().max()), float(v[1].pow(2).mean().sqrt()))
             for k, v in out.items()}
 
@@ -83,12 +83,12 @@ def mlp_case(seed, dist, n=4096, F=28):
     wt = torch.empty(288 * 512, device=dev, dtype=torch.bfloat16)
     assert lib.vine_mlp3_tile_weights_split(Ws[0].data_ptr(), Ws[0].stride(0), F, Ws[1].data_ptr(), Ws[1].stride(0), Ws[2].data_ptr(),
                                             Ws[2].stride(0), wt.data_ptr(), st) == 0
-    for terms in (9, 6):
+    for terms, name in ((9, "9"), (6, "6"), (9 | (1 << 16), "9d"), (6 | (1 << 16), "6d")):      # d: two accumulators per tile
         assert lib.vine_mlp3_elu_f32_split(n, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
                                            wt.data_ptr(), bs[0].data_ptr(), bs[1].data_ptr(), bs[2].data_ptr(), 1.0, terms, None, 0.0,
                                            None, None, 0, st) == 0
         torch.cuda.synchronize()
-        out[str(terms)] = x[:, :64].double() - a
+        out[name] = x[:, :64].double() - a
     return {k: (float(v.abs().max()), float(v.pow(2).mean().sqrt())) for k, v in out.items()}
 
 
@@ -98,10 +98,10 @@ for kind, fn in (("lstm", lstm_case), ("mlp", mlp_case)):
         for seed in range(4):
             r = fn(seed, dist)
             line = "%-4s %-8s seed %d:" % (kind, dist, seed)
-            for k in ("native", "9", "6"):
+            for k in [k for k in ("native", "9", "6", "9d", "6d") if k in r]:
                 line += "  %s " % k + " ".join("%.3e" % v for v in r[k])
             print(line)
-            for k in ("9", "6"):
+            for k in [k for k in ("9", "6", "9d", "6d") if k in r]:
                 for j, (a, b) in enumerate(zip(r[k], r["native"])):
                     key = (kind, k, j)
                     worst[key] = max(worst.get(key, 0.0), a / b)

@@ -2343,12 +2343,16 @@ def test_mlp3_elu_f32_against_float64_torch(F):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("F,n,terms", [(28, 1024, 9 + 256 * 1), (18, 1024, 9 + 256 * 2), (28, 4096, 9), (28, 16384, 9),
-                                       (18, 8192, 9), (28, 2048, 6 + 256 * 4), (28, 4096, 6)])
+                                       (18, 8192, 9), (28, 2048, 6 + 256 * 4), (28, 4096, 6),
+                                       (28, 16384, 6 + (1 << 16)), (18, 4096, 6 + (1 << 16)), (28, 1024, 6 + 256 + (1 << 16)),
+                                       (28, 2048, 9 + 256 * 2 + (1 << 16)), (18, 8192, 9 + (1 << 16))])
 def test_mlp3_elu_f32_split_against_float64_torch(F, n, terms):
     """vine_mlp3_elu_f32_split (products formed exactly from bf16 pieces on the bf16 matrix cores, four waves sharing the rows
     and splitting the units, activations exchanged through LDS as pieces) against the float64 torch composition: held to
     the native fp32 kernel's bound AND to that kernel's own error on the same inputs; the observation block is bit-identical
-    to the native kernel's.  ``terms``: piece pairs in the low byte, row tiles per workgroup in the second (0: from n)."""
+    to the native kernel's.  ``terms``: piece pairs in the low byte, row tiles per workgroup in the second (0: from n);
+    bit 16: two accumulators per tile (what the rollout runs) -- then BOTH the max and the rms error must be at or below the
+    native kernel's (the criterion the 6-pair default rests on)."""
     from vine_robot_isaacgymenvs_amd import native
     lib = native.load()
     dev = torch.device("cuda:0")
@@ -2394,6 +2398,8 @@ def test_mlp3_elu_f32_split_against_float64_torch(F, n, terms):
     assert err < 2e-5 * max(1.0, float(a.abs().max()))
     assert err <= 1.5 * err_ref + 1e-7
     assert rms <= rms_ref                 # (not above the native fp32 matrix-core kernel's rms error)
+    if terms >> 16:
+        assert err <= err_ref and rms <= 0.6 * rms_ref
     if (terms & 0xff) == 6:               # ... and the 6-pair form as accurate as the exact-product 9-pair form
         x9 = torch.full((n, ldx), 7.0, device=dev)
         assert lib.vine_mlp3_elu_f32_split(n, x9.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5, 5.0,
@@ -2402,7 +2408,7 @@ def test_mlp3_elu_f32_split_against_float64_torch(F, n, terms):
         torch.cuda.synchronize()
         e9 = float((x9[:, :64].double() - a).abs().max())
         r9 = float((x9[:, :64].double() - a).pow(2).mean().sqrt())
-        assert err <= 1.15 * e9 + 1e-9 and rms <= 1.01 * r9
+        assert err <= (1.3 if terms >> 16 else 1.15) * e9 + 1e-9 and rms <= 1.01 * r9
     assert torch.equal(x[:, 64:], x_ref[:, 64:])                       # observation block; nothing else touched
     assert torch.equal(x[:, 64:64 + F], xn) and float(x[:, 64 + F:96].abs().max()) == 0.0
     bad = lib.vine_mlp3_elu_f32_split(n + 8, x.data_ptr(), ldx, raw.data_ptr(), F, mean.data_ptr(), var.data_ptr(), 1e-5,
@@ -2450,14 +2456,17 @@ def test_lstm_step_f32_against_float64_torch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("terms", [9, 6, 9 + (2 << 8), 6 + (4 << 8), 9 + (4 << 8), 9 + (1 << 16), 6 + (1 << 16)])
+@pytest.mark.parametrize("terms", [9, 6, 9 + (2 << 8), 6 + (4 << 8), 9 + (4 << 8), 9 + (1 << 16), 6 + (1 << 16),
+                                   9 + (3 << 16), 6 + (3 << 16)])
 def test_lstm_step_f32_split_against_float64_torch(terms):
     """vine_lstm_step_f32_split (fp32 operands split exactly into three bf16 pieces, every piece product exact in the
     fp32 accumulator of the bf16 matrix cores) against float64 torch: the pre-activations must be at least as close to the
     float64 product as those of the native fp32 matrix-core kernel (9 terms: no bit of a product is dropped), and
     h / c within the same 1e-5 the native kernel is held to.  Operand magnitudes span 2^-20 .. 2^6 so that a piece that
     were rounded away would show.  ``terms``: piece pairs in the low byte, row tiles per wave (a tuning knob) in the second.
-    Bit 16 of ``terms``: the one-gate-per-wave kernel (four waves share 64 rows, operand pieces exchanged through LDS)."""
+    Bit 16 of ``terms``: the one-gate-per-wave kernel (four waves share 64 rows, operand pieces exchanged through LDS);
+    bit 17: with two accumulators per tile (what the rollout runs) -- then BOTH the max and the rms error of h and c must be
+    at or below the native kernel's (the criterion the 6-pair default rests on)."""
     from vine_robot_isaacgymenvs_amd import native
     lib = native.load()
     dev = torch.device("cuda:0")
@@ -2505,6 +2514,9 @@ def test_lstm_step_f32_split_against_float64_torch(terms):
     # VERDICT r4 item 7 (the criterion the 6-pair default rests on): the rms error against float64 is NOT ABOVE the native
     # fp32 matrix-core instruction's on the same inputs (the max over 5e5 outputs is a noisy statistic: within 1.5x above)
     assert rms_c <= ref_rms_c and rms_h <= ref_rms_h
+    dual = (terms >> 17) & 1
+    if dual:
+        assert err_c <= ref_c and err_h <= ref_h and rms_c <= 0.75 * ref_rms_c and rms_h <= 0.75 * ref_rms_h
     if (terms & 0xff) == 6:
         # ... and the 6-pair form is as accurate as the exact-product 9-pair form: same max and rms error to 1 %
         h9, c9 = torch.empty(N, H, device=dev), torch.empty(N, H, device=dev)
@@ -2513,7 +2525,8 @@ def test_lstm_step_f32_split_against_float64_torch(terms):
         torch.cuda.synchronize()
         e9_c, e9_h = float((c9.double() - c).abs().max()), float((h9.double() - h).abs().max())
         r9_c, r9_h = float((c9.double() - c).pow(2).mean().sqrt()), float((h9.double() - h).pow(2).mean().sqrt())
-        assert err_c <= 1.01 * e9_c + 1e-9 and err_h <= 1.01 * e9_h + 1e-9 and rms_c <= 1.01 * r9_c and rms_h <= 1.01 * r9_h
+        tol = 1.3 if dual else 1.01       # (with two accumulators the dropped pairs are a visible share of a SMALLER error)
+        assert err_c <= tol * e9_c + 1e-9 and err_h <= tol * e9_h + 1e-9 and rms_c <= 1.01 * r9_c and rms_h <= 1.01 * r9_h
     assert torch.equal(nxt[:, 96:], h_out) and float(nxt[:, :96].abs().max()) == 0.0
     # in place on the cell state (what the rollout does) gives the same result
     c_io = c_prev.clone()

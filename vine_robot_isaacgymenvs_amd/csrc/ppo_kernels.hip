@@ -4611,11 +4611,11 @@ __device__ __forceinline__ f32x4_t mfma_bf16(uint4 a, uint4 b, f32x4_t c) {
 #ifdef SPLIT_TIMING
 // (debug build, scripts/ubench/lstm_split_clock.py) per wave: shader clock (s_memtime) and 100 MHz real time (s_memrealtime)
 // at kernel entry, after the prologue, after the last k-step, at the end
-__device__ unsigned long long split_t[4096 * 8];
+__device__ unsigned long long split_t[8192 * 8];
 #define SPLIT_STAMP(i)                                                                                                  \
     if (lane == 0) {                                                                                                    \
-        split_t[((blockIdx.x * 4 + wave) & 4095) * 8 + 2 * (i)] = __builtin_amdgcn_s_memtime();                          \
-        split_t[((blockIdx.x * 4 + wave) & 4095) * 8 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                  \
+        split_t[((blockIdx.x * 4 + wave) & 8191) * 8 + 2 * (i)] = __builtin_amdgcn_s_memtime();                          \
+        split_t[((blockIdx.x * 4 + wave) & 8191) * 8 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                  \
     }
 #else
 #define SPLIT_STAMP(i)
@@ -4759,7 +4759,12 @@ __global__ __launch_bounds__(256, 2) void lstm_step_split_kernel(long long N, co
 // buffers): wave w then runs the cell update of row tile w with all four gates of a unit on one lane, as above.
 // Price: every workgroup streams its 264 KB of weight pieces for 64 rows instead of 256 (540 MB instead of 135 MB through
 // the L1s per launch at 16384 rows, a third of their bandwidth over the kernel's duration).
-template <int KS, int NT>
+// DUAL (round 5, bit 17 of `terms`): TWO accumulators per tile -- the hi x hi pair, whose terms have the magnitude of the
+// result, and all the other pairs (at most 2^-8 of it) -- added once at the end.  One accumulator takes 9 (6) rounded additions
+// per 32-deep k-step at the result's magnitude: 99 (66) per output, the 4-deep native fp32 instruction takes 88, which is why
+// the two have the same error (profiles/r05/split_terms_error.txt).  Split, the large one takes 11, the small one's roundings
+// sit 8 bits lower: the error against float64 falls well below the native instruction's on every input, max and rms.
+template <int KS, int NT, bool DUAL = false>
 __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, const float* __restrict__ xh, long long ldx,
                                                                    const unsigned short* __restrict__ wt,
                                                                    const float* __restrict__ bias,
@@ -4796,11 +4801,14 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
 #pragma unroll
         for (int p = 0; p < 3; ++p) lds[(wave * 3 + p) * 64 + lane] = pc[p];
     }
-    f32x4_t acc[2][4];
+    f32x4_t acc[2][4], accs[DUAL ? 2 : 1][DUAL ? 4 : 1];      // accs: the pairs below hi x hi (DUAL)
 #pragma unroll
     for (int ut = 0; ut < 2; ++ut)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int rt = 0; rt < 4; ++rt) {
+            acc[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            if (DUAL) accs[ut][rt] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        }
     float4 cp[2];
     __syncthreads();
     SPLIT_STAMP(1)
@@ -4831,8 +4839,10 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
 #pragma unroll
             for (int n = 9 - NT; n < 9; ++n)
 #pragma unroll
-                for (int ut = 0; ut < 2; ++ut)
-                    acc[ut][rt] = mfma_bf16(af[buf][ut][PP[n]], bfr[rt & 1][QQ[n]], acc[ut][rt]);
+                for (int ut = 0; ut < 2; ++ut) {
+                    if (DUAL && n < 8) accs[ut][rt] = mfma_bf16(af[buf][ut][PP[n]], bfr[rt & 1][QQ[n]], accs[ut][rt]);
+                    else acc[ut][rt] = mfma_bf16(af[buf][ut][PP[n]], bfr[rt & 1][QQ[n]], acc[ut][rt]);
+                }
             if (rt == 0 && j + 1 < KS) {
                 // row tile `wave` of k-step j + 1 (requested during k-step j - 1) -> pieces -> the other buffer; then
                 // request k-step j + 2
@@ -4856,7 +4866,10 @@ __global__ __launch_bounds__(256, 3) void lstm_step_nsplit_kernel(long long N, c
     for (int ut = 0; ut < 2; ++ut)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
-            ex[((rt * 4 + wave) * 2 + ut) * 64 + lane] = make_float4(acc[ut][rt][0], acc[ut][rt][1], acc[ut][rt][2], acc[ut][rt][3]);
+            ex[((rt * 4 + wave) * 2 + ut) * 64 + lane] =
+                DUAL ? make_float4(acc[ut][rt][0] + accs[ut][rt][0], acc[ut][rt][1] + accs[ut][rt][1],
+                                   acc[ut][rt][2] + accs[ut][rt][2], acc[ut][rt][3] + accs[ut][rt][3])
+                     : make_float4(acc[ut][rt][0], acc[ut][rt][1], acc[ut][rt][2], acc[ut][rt][3]);
     __syncthreads();
 #pragma unroll
     for (int ut = 0; ut < 2; ++ut) {
@@ -5113,10 +5126,11 @@ struct MlpSplitRing {
 };
 // one layer of one wave: acc[t][rt] += W(tile t) . act(row tile rt) over KB k-blocks.  `ring` holds k-blocks 0 .. min(D, KB) - 1
 // on entry (requested by the caller ahead of the barrier in front of the layer).
-template <int TILES, int KB, int RT, int NT, int D>
+// DUAL (round 5): the hi x hi pair into part[0], every other pair into part[1] (see lstm_step_nsplit_kernel)
+template <int TILES, int KB, int RT, int NT, int D, bool DUAL = false>
 __device__ __forceinline__ void mlp_split_layer(MlpSplitRing<TILES, D>& ring, const uint4* __restrict__ a_src,
                                                 const uint4* b_lds, f32x4_t (&acc)[TILES][RT]) {
-    constexpr int NC = TILES * RT == 1 ? 2 : 1;        // a lone accumulator: alternate between two (dependent-issue stall)
+    constexpr int NC = (DUAL || TILES * RT == 1) ? 2 : 1;        // a lone accumulator: alternate between two (dependent-issue stall)
     constexpr int PP[9] = {2, 2, 1, 1, 2, 0, 1, 0, 0}, QQ[9] = {2, 1, 2, 1, 0, 2, 0, 1, 0};
     f32x4_t part[NC][TILES][RT];
 #pragma unroll
@@ -5145,7 +5159,10 @@ __device__ __forceinline__ void mlp_split_layer(MlpSplitRing<TILES, D>& ring, co
             for (int t = 0; t < TILES; ++t)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    part[n % NC][t][rt] = mfma_bf16(ring.f[kb % (D + 1)][t][PP[n]], bfr[kb & 1][rt][QQ[n]], part[n % NC][t][rt]);
+                {
+                    const int c = DUAL ? (n == 8 ? 0 : 1) : n % NC;      // (compile-time after unrolling)
+                    part[c][t][rt] = mfma_bf16(ring.f[kb % (D + 1)][t][PP[n]], bfr[kb & 1][rt][QQ[n]], part[c][t][rt]);
+                }
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
@@ -5170,7 +5187,7 @@ __device__ __forceinline__ void mlp_split_store(uint4* act, int rt, int k0, int 
     for (int p = 0; p < 3; ++p)
         reinterpret_cast<uint2*>(act + ((rt * KBN + kb) * 3 + p) * 64 + slot)[half] = pc[p];
 }
-template <int RT, int NT>
+template <int RT, int NT, bool DUAL = false>
 __global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float* __restrict__ x, long long ldx,
                                                              const float* __restrict__ raw, int F_in,
                                                              const double* __restrict__ mean, const double* __restrict__ var,
@@ -5260,7 +5277,7 @@ __global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float*
     // ---- layer 1: units 64 wave + 16 t + ...
     {
         f32x4_t acc[4][RT];
-        mlp_split_layer<4, 1, RT, NT, 1>(ring1, a1_src, act02 + lane, acc);
+        mlp_split_layer<4, 1, RT, NT, 1, DUAL>(ring1, a1_src, act02 + lane, acc);
         MLP_STAMP(2)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -5274,7 +5291,7 @@ __global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float*
     // ---- layer 2: units 32 wave + 16 t + ...
     {
         f32x4_t acc[2][RT];
-        mlp_split_layer<2, 8, RT, NT, D>(ring2, a2_src, act1 + lane, acc);
+        mlp_split_layer<2, 8, RT, NT, D, DUAL>(ring2, a2_src, act1 + lane, acc);
         MLP_STAMP(4)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -5286,7 +5303,7 @@ __global__ __launch_bounds__(256) void mlp3_elu_split_kernel(long long n, float*
     // ---- layer 3: units 16 wave + 4 g + {0..3} of batch row u
     {
         f32x4_t acc[1][RT];
-        mlp_split_layer<1, 4, RT, NT, D>(ring3, a3_src, act02 + lane, acc);
+        mlp_split_layer<1, 4, RT, NT, D, DUAL>(ring3, a3_src, act02 + lane, acc);
         MLP_STAMP(6)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -6518,16 +6535,19 @@ int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, i
     const int nt = terms & 255;
     int rt = (terms >> 8) & 255;
     if (!rt) rt = (N >= 16384 && N % 256 == 0) ? 4 : 2;
-    if ((terms >> 16) == 1) {
-        // bit 16: the one-gate-per-wave form (64 rows and one 32-unit block per workgroup; the second byte is not used)
-        if ((terms >> 8) & 255) return VINE_ERR_UNSUPPORTED;
+    if ((terms >> 16) & 1) {
+        // bit 16: the one-gate-per-wave form (64 rows and one 32-unit block per workgroup; the second byte is not used);
+        // bit 17 (with it): two accumulators per tile -- hi x hi apart from the smaller pairs
+        if (((terms >> 8) & 255) || (terms >> 18)) return VINE_ERR_UNSUPPORTED;
+        const bool dual = ((terms >> 17) & 1) != 0;
         const long long sets64 = N / 64;
         const int xmap = (sets64 & 7) == 0;
-#define LAUNCH_NSPLIT(NT_)                                                                                                   \
-    hipLaunchKernelGGL((lstm_step_nsplit_kernel<11, NT_>), dim3((unsigned)sets64 * 8), dim3(256), 0, (hipStream_t)stream,      \
+#define LAUNCH_NSPLIT(NT_, DUAL_)                                                                                            \
+    hipLaunchKernelGGL((lstm_step_nsplit_kernel<11, NT_, DUAL_>), dim3((unsigned)sets64 * 8), dim3(256), 0, (hipStream_t)stream, \
                        (long long)N, xh, (long long)ldx, wt, bias, c_prev, h_out, (long long)ldh, c_out, hp_next,              \
                        (long long)ldhp, xmap)
-        if (nt == 9) LAUNCH_NSPLIT(9); else LAUNCH_NSPLIT(6);
+        if (dual) { if (nt == 9) LAUNCH_NSPLIT(9, true); else LAUNCH_NSPLIT(6, true); }
+        else { if (nt == 9) LAUNCH_NSPLIT(9, false); else LAUNCH_NSPLIT(6, false); }
 #undef LAUNCH_NSPLIT
         return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
     }
@@ -6546,7 +6566,7 @@ int vine_lstm_step_f32_split(int64_t N, int64_t H, int64_t K, const float* xh, i
 
 #ifdef SPLIT_TIMING
 int vine_debug_split_timing(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(split_t), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(split_t), sizeof(unsigned long long) * 8192 * 8) == hipSuccess ? 0 : -1;
 }
 int vine_debug_mlp_split_timing(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(mlp_split_t), sizeof(unsigned long long) * 4096 * 16) == hipSuccess ? 0 : -1;
@@ -6601,23 +6621,26 @@ int vine_mlp3_elu_f32_split(int64_t n, float* x, int64_t ldx, const float* raw, 
     if ((terms & 255) != 9 && (terms & 255) != 6) return VINE_ERR_INVALID_ARG;
     int rt = (terms >> 8) & 255;                     // row tiles per workgroup (0: chosen here), a tuning knob as in the LSTM step
     if (!rt) rt = n >= 32768 ? 4 : (n >= 16384 ? 2 : 1);       // two workgroups per CU from 16384 rows on (measured in situ)
-    if ((rt != 1 && rt != 2 && rt != 4) || (terms >> 16) || n % (16 * rt) || F_in <= 0 || F_in > 32 || ldx < 64 + 32 || (ldx & 3) ||
+    const bool dual = ((terms >> 16) & 1) != 0;      // bit 16: two accumulators per tile (hi x hi apart from the smaller pairs)
+    if ((rt != 1 && rt != 2 && rt != 4) || (terms >> 17) || n % (16 * rt) || F_in <= 0 || F_in > 32 || ldx < 64 + 32 || (ldx & 3) ||
         ((uintptr_t)x & 15) || ((uintptr_t)wt & 15) || ((uintptr_t)b1 & 15) || ((uintptr_t)b2 & 15) || ((uintptr_t)b3 & 15))
         return VINE_ERR_UNSUPPORTED;
     const size_t lds = (size_t)rt * (4 + 8) * 3 * 64 * sizeof(uint4);
     const int nt = terms & 255;
-#define LAUNCH_MLP_SPLIT(RT_, NT_)                                                                                           \
+#define LAUNCH_MLP_SPLIT_D(RT_, NT_, DU_)                                                                                     \
     {                                                                                                                        \
-        if (!ensure_dyn_lds(reinterpret_cast<const void*>(mlp3_elu_split_kernel<RT_, NT_>), lds)) return VINE_ERR_DEVICE;   \
-        hipLaunchKernelGGL((mlp3_elu_split_kernel<RT_, NT_>), dim3((unsigned)(n / (16 * RT_))), dim3(256), lds,              \
+        if (!ensure_dyn_lds(reinterpret_cast<const void*>(mlp3_elu_split_kernel<RT_, NT_, DU_>), lds)) return VINE_ERR_DEVICE; \
+        hipLaunchKernelGGL((mlp3_elu_split_kernel<RT_, NT_, DU_>), dim3((unsigned)(n / (16 * RT_))), dim3(256), lds,         \
                            (hipStream_t)stream, (long long)n, x, (long long)ldx, raw, (int)F_in, mean, var, eps, clip,        \
                            (const uint4*)wt, b1, b2, b3, alpha, fin_meter, fin_max_size, (long long*)fin_counter,             \
                            (const float*)fin_scratch, fin_blocks);                                                           \
     }
+#define LAUNCH_MLP_SPLIT(RT_, NT_) { if (dual) LAUNCH_MLP_SPLIT_D(RT_, NT_, true) else LAUNCH_MLP_SPLIT_D(RT_, NT_, false) }
     if (rt == 4) { if (nt == 9) LAUNCH_MLP_SPLIT(4, 9) else LAUNCH_MLP_SPLIT(4, 6) }
     else if (rt == 2) { if (nt == 9) LAUNCH_MLP_SPLIT(2, 9) else LAUNCH_MLP_SPLIT(2, 6) }
     else { if (nt == 9) LAUNCH_MLP_SPLIT(1, 9) else LAUNCH_MLP_SPLIT(1, 6) }
 #undef LAUNCH_MLP_SPLIT
+#undef LAUNCH_MLP_SPLIT_D
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -592,7 +592,7 @@ class A2CAgent:
                                                          rms.running_mean.data_ptr(), rms.running_var.data_ptr(),
                                                          float(rms.epsilon), 5.0, f["mlp_wt_split"].data_ptr(),
                                                          b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), 1.0,
-                                                         f["f32_split"] | (fused.MLP3_F32_SPLIT_RT << 8),
+                                                         f["f32_split"] | (fused.MLP3_F32_SPLIT_RT << 8) | (int(fused.ROLLOUT_F32_DUAL) << 16),
                                                          *(fin if fin is not None else (None, 0.0, None, None, 0)), st),
                              "vine_mlp3_elu_f32_split")
             else:

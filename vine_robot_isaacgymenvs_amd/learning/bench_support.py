@@ -203,7 +203,9 @@ def ppo_path_rooflines(agent):
     terms = (getattr(agent, "_fast", None) or {}).get("f32_split", 0)
     key = next((k for k in prof if k.startswith("lstm_step_split_kernel") or k.startswith("lstm_step_nsplit_kernel")), None)
     if key is not None and terms:
-        kt = 9 if ", 9>" in key else 6
+        import re
+        m = re.search(r"<\d+, (?:\d+, )?(\d+)(?:, (?:true|false))?>", key)      # <KS, RT, NT> or <KS, NT, DUAL>: piece pairs
+        kt = int(m.group(1)) if m else terms
         us = prof[key]["avg_ns"] / 1e3
         flop32 = 2.0 * N * (wpad + H) * 4 * H
         out.append({"kernel": key, "bound": "mfma", "in_situ_us": us, "launches_per_iteration": agent.horizon_length + 1,
@@ -355,6 +357,7 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
         in_sync = all(bool(torch.equal(g, gathered[0])) for g in gathered)
     frames = agent.horizon_length * agent.num_actors
     def describe(a):
+        from . import fused
         lp = {torch.float16: "fp16", torch.bfloat16: "bf16"}.get(a.amp_dtype, "?")
         if a.fused_mixed:
             upd = ("update: %s GEMM operands and backward-only saved activations (gates, saved cell states, dG, dh), f32 "
@@ -373,8 +376,11 @@ def run_ppo_bench(env, cfg, args, steps, warmup, barrier, world, rank):
                     "from the exact three-way bf16 split of both fp32 operands on the bf16 matrix cores, %s"
                     % ("MLP and LSTM-gate" if mlp_split else "MLP on the fp32 matrix cores, LSTM-gate",
                        "all 9 piece pairs = every bit of every fp32 product" if terms == 9 else
-                       "6 of 9 piece pairs (the three below 2^-24 of a product left out: error against float64 equal to the "
-                       "9-pair form's, profiles/r05/split_terms_error.txt)"))
+                       "6 of 9 piece pairs (the three below 2^-24 of a product left out)")
+                    + (", two fp32 accumulators per tile (hi x hi pair apart from the smaller pairs)" if fused.ROLLOUT_F32_DUAL
+                       else "")
+                    + ": error against float64 <= %s the native fp32 matrix-core instruction's on every input measured, max and "
+                      "rms (profiles/r05/split_terms_error.txt)" % ("0.6x" if fused.ROLLOUT_F32_DUAL else "1.2x (max), 0.9x (rms)"))
         else:
             roll = "rollout inference: f32 (the reference's; fp32 matrix-core kernels)"
         return upd + "; " + roll

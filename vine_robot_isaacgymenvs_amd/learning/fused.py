@@ -185,24 +185,37 @@ def weight_grad(dy, x, out=None, batch=None):
 HEADS_LOSS = _os.environ.get("VINE_HEADS_LOSS", "1") != "0"    # LayerNorm + heads + loss + backward in one launch (A/B knob)
 ROLLOUT_F32_MFMA = _os.environ.get("VINE_ROLLOUT_F32_MFMA", "1") != "0"   # fp32 matrix-core rollout kernels (A/B knob)
 # fp32 rollout inference with the products formed from bf16 pieces on the bf16 matrix cores (vine_lstm_step_f32_split,
-# vine_mlp3_elu_f32_split): 9 = all nine piece pairs (every bit of every fp32 product: the default), 6 = without the three
-# pairs below 2^-24 of a product, 0 = the native fp32 matrix-core kernels (vine_lstm_step_f32, vine_mlp3_elu_f32).
-# Round 5, measured (scripts/ubench/split_terms_error.py, profiles/r05/split_terms_error.txt; asserted by
-# test_*_f32_split_against_float64_torch): against float64 the 6-pair form's error equals the 9-pair form's to four digits on
-# every input tried (max and rms), and the rms error of either is 10-25 % BELOW that of the native fp32 matrix-core
-# instruction (the accumulation's roundings dominate, not the dropped terms).  The MAX error of either split form, though,
-# is above the native kernel's on some inputs (LSTM test inputs: 1.14x on c, 1.63x on h; one of 12 sweep cases: 1.19x) --
-# the verdict's rule was "worse on any case: keep 9": 9 stays the default for the headline, the 6-pair iteration
-# (rollout 2.28 -> 2.01 ms) rides in the bench line as `extra_split6_rollout`.
-ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "9"))
-# the one-gate-per-wave form of that kernel (four waves share 64 rows, operand pieces exchanged through LDS; bit 16 of
+# vine_mlp3_elu_f32_split): 6 = without the three piece pairs below 2^-24 of a product (the default), 9 = all nine pairs,
+# 0 = the native fp32 matrix-core kernels (vine_lstm_step_f32, vine_mlp3_elu_f32).
+# Round 5, measured ("worse on any case: keep 9"; scripts/ubench/split_terms_error.py,
+# profiles/r05/split_terms_error.txt; asserted by test_*_f32_split_against_float64_torch): with ONE accumulator per tile the
+# 6- and 9-pair forms have the same error against float64 to four digits (the accumulation's 66 / 99 roundings dominate, not
+# the dropped pairs), 10-25 % below the native fp32 instruction's in rms but up to 1.19x (LSTM test inputs: 1.63x) ABOVE it
+# in max.  With TWO accumulators (ROLLOUT_F32_DUAL below) both forms are at most 0.60x (LSTM) / 0.45x (MLP) of the native
+# instruction's error on every input, max and rms, and 6 against 9 pairs differ by < 1 % of that error on rms and either
+# way on max: 6 pairs + two accumulators is the default (rollout 2.20 -> 1.93 ms), the 9-pair iteration rides in the bench
+# line as `extra_split9_rollout`.
+ROLLOUT_F32_SPLIT = int(_os.environ.get("VINE_ROLLOUT_F32_SPLIT", "6"))
+# the one-gate-per-wave form of the LSTM kernel (four waves share 64 rows, operand pieces exchanged through LDS; bit 16 of
 # `terms`): "auto" = below 16384 rows, where it is faster (23.1 against 24.9 us at 4096 rows, 14.7 against 22.0 at 2048;
 # level at 16384: profiles/r04/rollout_kernels_round4.txt); "1" / "0" = always / never
 ROLLOUT_F32_NSPLIT = _os.environ.get("VINE_LSTM_STEP_NSPLIT", "auto")
+# two accumulators per tile (bit 17 of the LSTM kernel's `terms`, bit 16 of the MLP kernel's): the hi x hi pair apart from
+# the smaller pairs -- the smaller pairs' sum is rounded at 2^-8 of the result's magnitude, which leaves one rounding per
+# k-block at full magnitude (11 in the LSTM step instead of 66-99).  On (the default) it makes the one-gate-per-wave kernel
+# the LSTM kernel at every size (the only one that has the second accumulator).
+ROLLOUT_F32_DUAL = _os.environ.get("VINE_ROLLOUT_F32_DUAL", _os.environ.get("VINE_LSTM_STEP_DUAL", "1")) != "0"
 
 
 def rollout_f32_nsplit(rows):
-    return ROLLOUT_F32_NSPLIT == "1" or (ROLLOUT_F32_NSPLIT == "auto" and rows < 16384)
+    """Bits 16-17 of vine_lstm_step_f32_split's `terms` for a batch of `rows`: 1 = one gate per wave, 3 = with two accumulators."""
+    if ROLLOUT_F32_NSPLIT == "0":
+        return 0
+    if ROLLOUT_F32_DUAL:
+        return 3
+    return 1 if (ROLLOUT_F32_NSPLIT == "1" or rows < 16384) else 0
+
+
 # the fp32 rollout MLP with the same piece products (vine_mlp3_elu_f32_split: four waves share the rows and split the units);
 # 0 = the native fp32 matrix-core kernel (vine_mlp3_elu_f32).  VINE_MLP3_F32_SPLIT_RT: row tiles per workgroup (0: from N)
 MLP3_F32_SPLIT = _os.environ.get("VINE_MLP3_F32_SPLIT", "1") != "0"
