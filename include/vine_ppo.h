@@ -334,6 +334,14 @@ int vine_dataset_assemble(int32_t T, int64_t N, const float* rewards, const floa
 #define VINE_RMS_BLOCKS 128
 int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, double* running_var, double* count,
                     double* scratch, void* stream);
+/* The same for k consecutive batches of n rows each (x [k n, F]) in three launches instead of 2 k: the batch sums of all k
+ * at once, then the k merges IN ORDER -- bit-identical to k calls of vine_rms_update on the slices.  snap_mean / snap_var
+ * [k, F] receive the running moments as they stand after batch 0, 1, ..: the optimiser steps of PPO's first mini-epoch
+ * (rl_games updates the observation normaliser in every training forward of it: the `running_mean_std` of
+ * a2c_common / models.py) each normalise with the moments their own forward would have left.
+ * scratch: k * (VINE_RMS_BLOCKS + 1) * 2 * F doubles. */
+int vine_rms_update_multi(int32_t k, int64_t n, int64_t F, const float* x, double* running_mean, double* running_var,
+                          double* count, double* scratch, double* snap_mean, double* snap_var, void* stream);
 
 /* RunningMeanStd of rl_games in eval mode: out = clamp((x - mean) / sqrt(var + eps), +-clip) for x [n,F] packed,
  * float64 statistics; out rows out_stride elements apart (a column block of a wider buffer), fp32 or bfloat16. */

@@ -727,6 +727,32 @@ def test_running_mean_std_kernels_match_torch_composition(F_):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("F_,n,k", [(28, 32768, 8), (18, 2048, 4), (28, 130, 3), (1, 2, 2)])
+def test_running_mean_std_updates_of_a_mini_epoch_at_once_are_bit_identical(F_, n, k):
+    """vine_rms_update_multi (the k training-mode updates of PPO's first mini-epoch in three launches at its head) against k
+    calls of vine_rms_update on the slices: every intermediate state (what step i normalises with) and the final module
+    state are bit-identical."""
+    from vine_robot_isaacgymenvs_amd.learning.running_mean_std import RunningMeanStd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(F_ + n)
+    a, b = RunningMeanStd((F_,)).to(dev), RunningMeanStd((F_,)).to(dev)
+    a.train(); b.train()
+    warm = torch.randn(777, F_, device=dev) * 3.0 - 1.0
+    a.update_kernels(warm); b.update_kernels(warm)            # (not the initial state)
+    x = torch.randn(k * n, F_, device=dev) * torch.linspace(0.1, 9.0, F_, device=dev) + 3.0
+    mean, var = a.update_kernels_multi(x, k)
+    for i in range(k):
+        b.update_kernels(x[i * n:(i + 1) * n])
+        assert torch.equal(mean[i], b.running_mean) and torch.equal(var[i], b.running_var), i
+    for name in ("running_mean", "running_var", "count"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    a.eval()
+    assert a.update_kernels_multi(x, k) is None and torch.equal(a.count, b.count)      # eval mode: nothing happens
+    from vine_robot_isaacgymenvs_amd import native
+    assert native.load().vine_rms_update_multi(0, n, F_, x.data_ptr(), None, None, None, None, None, None, None) == -1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,K,N", [(32768, 256, 128), (16384, 128, 64), (64, 32, 64)])
 def test_linear_elu_mfma_matches_gemm_plus_bias_elu(n, K, N):
     """Matrix-core Linear + bias + ELU against torch GEMM (same bf16 operands, fp32 out) + vine_bias_elu; output
@@ -1467,6 +1493,9 @@ def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
         for _ in range(5):                   # 1 eager + capture/first replay + 3 further replays
             _, _, stats = agent.train_epoch()
         torch.cuda.synchronize()
+        if use_graphs and scope == "epoch" and mixed:
+            # the first mini-epoch's graph holds the normaliser updates of all its steps at its head (vine_rms_update_multi)
+            assert agent._upd_graphs[("epoch", True)]["keep"][-1] is not None
         if use_graphs:
             # per-step form: (step, with / without the RMS update) graphs, each led by the previous step's Adam, + the
             # un-led first step of an update + the trailing Adam graph

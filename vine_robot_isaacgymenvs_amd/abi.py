@@ -263,6 +263,7 @@ PPO_PROTOTYPES = {
     "vine_dataset_assemble": (C.c_int, [C.c_int32, _I64, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _VP, _VP, C.c_float,
                                         C.c_int32, C.c_int32, _VP, _VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_rms_update": (C.c_int, [_I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "vine_rms_update_multi": (C.c_int, [C.c_int32, _I64, _I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "vine_normalize_obs": (C.c_int, [_I64, _I64, _VP, _VP, _VP, C.c_float, C.c_float, _VP, _I64, C.c_int32, _VP]),
     "vine_adam_step": (C.c_int, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_float, _VP, _VP]),

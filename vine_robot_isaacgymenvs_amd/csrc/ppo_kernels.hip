@@ -2966,6 +2966,9 @@ __global__ __launch_bounds__(256) void ds_assemble_kernel(int T, long long N, co
 //   finalize: batch mean / unbiased variance from the partials (fixed order), merged into the running moments
 __global__ __launch_bounds__(256) void rms_partial_kernel(long long n, int F, const float* __restrict__ x,
                                                           double* __restrict__ partial) {
+    // (vine_rms_update_multi: blockIdx.y = the batch, n rows each, its own rows of `partial`)
+    x += (long long)blockIdx.y * n * F;
+    partial += (long long)blockIdx.y * gridDim.x * 2 * F;
     // 256 / F row lanes x F columns (252 of 256 lanes busy at F = 28); consecutive lanes read consecutive floats
     const int rlanes = 256 / F;
     const int rl = threadIdx.x / F, c = threadIdx.x - rl * F;
@@ -3003,13 +3006,11 @@ __global__ __launch_bounds__(256) void rms_partial_kernel(long long n, int F, co
     }
 }
 
-__global__ __launch_bounds__(256) void rms_finalize_kernel(int blocks, int F, long long n,
-                                                           const double* __restrict__ partial,
-                                                           double* __restrict__ running_mean,
-                                                           double* __restrict__ running_var, double* __restrict__ count) {
-    // 64 column lanes x 4 row lanes over the partial rows, folded through LDS in a fixed order
+// the per-workgroup rows of rms_partial_kernel -> the batch's column sums of x and x^2 (valid in the threads rl == 0, c < F):
+// 64 column lanes x 4 row lanes over the partial rows, folded through LDS in a fixed order
+__device__ __forceinline__ void rms_fold(int blocks, int F, const double* __restrict__ partial, double& s, double& ss) {
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    double s = 0.0, ss = 0.0;
+    s = 0.0; ss = 0.0;
     if (c < F) {
         int b = rl;
         for (; b + 28 < blocks; b += 32) {                  // 8 partial rows in flight per thread, same order
@@ -3031,19 +3032,73 @@ __global__ __launch_bounds__(256) void rms_finalize_kernel(int blocks, int F, lo
     red[0][rl][c] = s;
     red[1][rl][c] = ss;
     __syncthreads();
-    const double cnt = count[0], nb = (double)n;
     if (rl == 0 && c < F) {
         s = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
         ss = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
-        const double bmean = s / nb;
-        const double bvar = n > 1 ? (ss - nb * bmean * bmean) / (nb - 1.0) : 0.0;      // unbiased, like x.var(0)
-        const double delta = bmean - running_mean[c], tot = cnt + nb;
-        const double m2 = running_var[c] * cnt + bvar * nb + delta * delta * cnt * nb / tot;
-        running_mean[c] += delta * nb / tot;
-        running_var[c] = m2 / tot;
+    }
+}
+// Chan et al. merge of a batch's column sums into the running moments of column c (count: before the merge).
+// (not inlined: ONE body for the single and the k-batch kernels, so that contraction into fmas cannot differ between them)
+__device__ __attribute__((noinline)) void rms_merge(double s, double ss, long long n, double cnt, double& mean, double& var) {
+    const double nb = (double)n;
+    const double bmean = s / nb;
+    const double bvar = n > 1 ? (ss - nb * bmean * bmean) / (nb - 1.0) : 0.0;      // unbiased, like x.var(0)
+    const double delta = bmean - mean, tot = cnt + nb;
+    const double m2 = var * cnt + bvar * nb + delta * delta * cnt * nb / tot;
+    mean += delta * nb / tot;
+    var = m2 / tot;
+}
+
+__global__ __launch_bounds__(256) void rms_finalize_kernel(int blocks, int F, long long n,
+                                                           const double* __restrict__ partial,
+                                                           double* __restrict__ running_mean,
+                                                           double* __restrict__ running_var, double* __restrict__ count) {
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double s, ss;
+    rms_fold(blocks, F, partial, s, ss);
+    const double cnt = count[0];
+    if (rl == 0 && c < F) {
+        double mean = running_mean[c], var = running_var[c];
+        rms_merge(s, ss, n, cnt, mean, var);
+        running_mean[c] = mean;
+        running_var[c] = var;
     }
     __syncthreads();
-    if (threadIdx.x == 0) count[0] = cnt + nb;
+    if (threadIdx.x == 0) count[0] = cnt + (double)n;
+}
+
+// vine_rms_update_multi: workgroup b folds the partial rows of batch b into sums[b][2F] ...
+__global__ __launch_bounds__(256) void rms_fold_multi_kernel(int blocks, int F, const double* __restrict__ partial,
+                                                             double* __restrict__ sums) {
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double s, ss;
+    rms_fold(blocks, F, partial + (long long)blockIdx.x * blocks * 2 * F, s, ss);
+    if (rl == 0 && c < F) {
+        sums[(long long)blockIdx.x * 2 * F + c] = s;
+        sums[(long long)blockIdx.x * 2 * F + F + c] = ss;
+    }
+}
+// ... and one wave merges the k batches IN ORDER into the running moments (the same arithmetic, batch after batch, as k
+// calls of vine_rms_update), leaving the moments after batch b in snap_mean / snap_var [b][F]
+__global__ __launch_bounds__(64) void rms_merge_multi_kernel(int k, int F, long long n, const double* __restrict__ sums,
+                                                             double* __restrict__ running_mean, double* __restrict__ running_var,
+                                                             double* __restrict__ count, double* __restrict__ snap_mean,
+                                                             double* __restrict__ snap_var) {
+    const int c = threadIdx.x;
+    double cnt = count[0];
+    if (c < F) {
+        double mean = running_mean[c], var = running_var[c];
+        for (int b = 0; b < k; ++b) {
+            rms_merge(sums[(long long)b * 2 * F + c], sums[(long long)b * 2 * F + F + c], n, cnt, mean, var);
+            cnt += (double)n;
+            snap_mean[(long long)b * F + c] = mean;
+            snap_var[(long long)b * F + c] = var;
+        }
+        running_mean[c] = mean;
+        running_var[c] = var;
+    }
+    __syncthreads();
+    if (c == 0) count[0] = count[0] + (double)k * (double)n;
 }
 
 // out = elu(z + bias): the activation of a Linear whose GEMM ran without an epilogue (bf16 operands, fp32 output)
@@ -6152,6 +6207,22 @@ int vine_rms_update(int64_t n, int64_t F, const float* x, double* running_mean, 
     hipLaunchKernelGGL(rms_partial_kernel, dim3(blocks), dim3(256), 0, s, (long long)n, (int)F, x, scratch);
     hipLaunchKernelGGL(rms_finalize_kernel, dim3(1), dim3(256), 0, s, blocks, (int)F, (long long)n, scratch, running_mean,
                        running_var, count);
+    return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
+}
+
+int vine_rms_update_multi(int32_t k, int64_t n, int64_t F, const float* x, double* running_mean, double* running_var,
+                          double* count, double* scratch, double* snap_mean, double* snap_var, void* stream) {
+    if (k <= 0 || n <= 0 || F <= 0 || !x || !running_mean || !running_var || !count || !scratch || !snap_mean || !snap_var)
+        return VINE_ERR_INVALID_ARG;
+    if (F > 64 || k > 65535) return VINE_ERR_UNSUPPORTED;
+    int blocks = (int)((n + 3) / 4);
+    if (blocks > VINE_RMS_BLOCKS) blocks = VINE_RMS_BLOCKS;
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = scratch + (size_t)k * VINE_RMS_BLOCKS * 2 * F;
+    hipLaunchKernelGGL(rms_partial_kernel, dim3(blocks, k), dim3(256), 0, s, (long long)n, (int)F, x, scratch);
+    hipLaunchKernelGGL(rms_fold_multi_kernel, dim3(k), dim3(256), 0, s, blocks, (int)F, scratch, sums);
+    hipLaunchKernelGGL(rms_merge_multi_kernel, dim3(1), dim3(64), 0, s, (int)k, (int)F, (long long)n, sums, running_mean,
+                       running_var, count, snap_mean, snap_var);
     return hipGetLastError() == hipSuccess ? VINE_OK : VINE_ERR_DEVICE;
 }
 

@@ -1156,25 +1156,27 @@ class A2CAgent:
         return mb
 
     # ------------------------------------------------------------------ update (R3, R4, R6)
-    def _fused_grad_half(self, mb, obs_n=None, stats_out=None):
+    def _fused_grad_half(self, mb, obs_n=None, stats_out=None, norm_stats=None):
         """Forward, ONE kernel for the whole PPO loss and its gradient w.r.t. the head outputs, hand-written backward
         into the flat gradient block; the minibatch KL is parked next to the gradients so that one all-reduce
         averages both.  -> (stats[8], mu, logstd)"""
         self._amp_covered = False
-        out = self._fused_grad_half_body(mb, obs_n, stats_out)
+        out = self._fused_grad_half_body(mb, obs_n, stats_out, norm_stats)
         if self._amp is not None:
             # loss-scaled fp16 backward: unless every parameter gradient ended in the overflow-checked column-sum launch
             # the optimiser looks for non-finite gradients itself before it steps
             self.optimizer.check_grads = not self._amp_covered
         return out
 
-    def _fused_grad_half_body(self, mb, obs_n, stats_out):
+    def _fused_grad_half_body(self, mb, obs_n, stats_out, norm_stats=None):
         net = self.model.a2c_network
         hb = (net.mu.bias.grad, net.value.bias.grad)
         ext = all(g is not None and g.is_cuda for g in hb)     # head-bias gradients straight from the loss kernel
         batch_dict = {"obs": mb["obs"] if obs_n is None else obs_n, "obs_is_normalized": obs_n is not None,
                       "rnn_states": mb["rnn_states"], "seq_length": self.seq_len, "dones": mb["dones"],
                       "head_bias_external": ext}
+        if norm_stats is not None:
+            batch_dict["obs_norm_stats"] = norm_stats
         pack = None
         if ext and fused.HEADS_LOSS and self.fused_mixed:
             # LayerNorm + heads + loss + their backward inside the trunk node (one launch instead of three)
@@ -1592,6 +1594,22 @@ class A2CAgent:
                                        else "graph (1 per mini-epoch)")
         return True
 
+    def _rms_updates_ahead(self, nb):
+        """The observation normaliser's training-mode updates of all ``nb`` optimiser steps of the first mini-epoch in three
+        launches at its head (``vine_rms_update_multi``) instead of two in front of every step: a step's update depends on
+        the minibatch's observations and on the statistics after the previous step only, never on the weights.  Returns
+        (mean [nb, F], var [nb, F]) -- step i normalises with row i, bit-identical to updating in front of it -- or None
+        when the per-step path has to run (``VINE_RMS_AHEAD=0``, shapes the kernels do not cover)."""
+        if os.environ.get("VINE_RMS_AHEAD", "1") == "0" or not self.normalize_input:
+            return None
+        rms, obs = self.model.running_mean_std, self.dataset["obs"]
+        net = self.model.a2c_network
+        first = obs[:self.minibatch_size]
+        if not (obs.shape[0] == nb * self.minibatch_size and obs.is_contiguous() and rms.training and rms._use_kernels(first)
+                and net.op_weight_lookup is not None and net.trunk_supported(first, self.seq_len)):
+            return None
+        return rms.update_kernels_multi(obs, nb)
+
     def _capture_update_epoch(self, key):
         if not hasattr(self, "_upd_graphs"):
             self._upd_graphs = {}
@@ -1603,15 +1621,18 @@ class A2CAgent:
         stats_all = torch.zeros((nb, 8), device=self.device, dtype=torch.float32)     # (never allocate zeros in capture)
         keep = []
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            ahead = self._rms_updates_ahead(nb) if key[1] else None
             for i in range(nb):
                 mb = self.get_minibatch(i)
                 # statistics straight into their row, step counter and learning-rate schedule inside the Adam launch
-                stats, mu_d, _logstd_d = self._fused_grad_half(mb, stats_out=stats_all[i])
+                stats, mu_d, _logstd_d = self._fused_grad_half(mb, stats_out=stats_all[i],
+                                                               norm_stats=None if ahead is None else (ahead[0][i], ahead[1][i]))
                 if self.multi_gpu:
                     # gradients + KL + overflow flag, SUM over the ranks (RCCL over xGMI): a node of the graph
                     dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)
                 self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
                 keep.append((mb, stats, mu_d))
+            keep.append(ahead)
         rec = {"G": g, "stats": stats_all, "keep": keep}
         self._upd_graphs[key] = rec
         return rec

@@ -188,8 +188,14 @@ class ModelA2CContinuousLogStd(nn.Module):
                 and rms._use_kernels(raw) and net.trunk_supported(raw, T)):
             # mixed-precision trunk: update the running statistics here (training mode), let the trunk normalise the
             # raw observations itself (one launch for normalisation + MLP)
-            rms.update_kernels(raw)
-            obs, norm = raw, (rms.running_mean, rms.running_var, rms.epsilon)
+            ahead = input_dict.get("obs_norm_stats")
+            if ahead is not None:
+                # (the mini-epoch graph ran the statistics updates of all its steps up front -- vine_rms_update_multi --
+                # and hands each step the moments its own update would have left)
+                obs, norm = raw, (ahead[0], ahead[1], rms.epsilon)
+            else:
+                rms.update_kernels(raw)
+                obs, norm = raw, (rms.running_mean, rms.running_var, rms.epsilon)
         else:
             obs = raw if input_dict.get("obs_is_normalized", False) else self.norm_obs(raw)
         if net.trunk_supported(obs, T):

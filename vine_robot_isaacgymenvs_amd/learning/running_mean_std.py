@@ -50,6 +50,26 @@ class RunningMeanStd(nn.Module):
                                          self.count.data_ptr(), scratch.data_ptr(),
                                          torch.cuda.current_stream(x.device).cuda_stream), lib)
 
+    def update_kernels_multi(self, x, k):
+        """``k`` consecutive training-mode updates, one per slice of ``x`` [k n, F], in three launches
+        (``vine_rms_update_multi``: bit-identical to k calls of ``update_kernels`` on the slices).  Returns
+        (mean [k, F], var [k, F]): the running moments as they stand after slice 0, 1, ...; None in eval mode."""
+        if not self.training:
+            return None
+        from .. import native
+        from ..abi import RMS_BLOCKS
+        lib = native.load()
+        x = x.contiguous()
+        rows, F = x.shape
+        assert rows % k == 0
+        scratch = torch.empty(k * (RMS_BLOCKS + 1) * 2 * F, device=x.device, dtype=torch.float64)
+        snap = torch.empty((2, k, F), device=x.device, dtype=torch.float64)
+        native.check(lib.vine_rms_update_multi(k, rows // k, F, x.data_ptr(), self.running_mean.data_ptr(),
+                                               self.running_var.data_ptr(), self.count.data_ptr(), scratch.data_ptr(),
+                                               snap[0].data_ptr(), snap[1].data_ptr(),
+                                               torch.cuda.current_stream(x.device).cuda_stream), lib)
+        return snap[0], snap[1]
+
     def _forward_kernels(self, x):
         from .. import native
         lib = native.load()
