@@ -107,9 +107,9 @@ def test_multi_gpu_code_path_on_one_rank(monkeypatch):
                 cc = agent.collective_capture
                 print("collective capture:", cc, agent.graph_status["update"])
                 assert agent.graph_status["update"].startswith(
-                    "graph (1 per mini-epoch, all-reduces captured" if cc["in_graph"] else "graph (per optimiser step"), agent.graph_status
+                    "graph (1 per iteration, all-reduces captured" if cc["in_graph"] else "graph (per optimiser step"), agent.graph_status
             else:
-                assert agent.graph_status["update"].startswith("graph (1 per mini-epoch)"), agent.graph_status
+                assert agent.graph_status["update"].startswith("graph (1 per iteration)"), agent.graph_status
             flat = torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone()
             assert torch.isfinite(flat).all()
             results.append((flat, float(agent.lr)))

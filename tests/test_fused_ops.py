@@ -1465,9 +1465,10 @@ def test_fused_update_equals_stock_update():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mixed,scope", [(False, "epoch"), (True, "epoch"), (True, "step")])
+@pytest.mark.parametrize("mixed,scope", [(False, "epoch"), (True, "epoch"), (True, "step"), (True, "all"), (False, "all")])
 def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
-    """From the second iteration on the update is replayed from hipGraphs: on one rank a whole mini-epoch per graph
+    """From the second iteration on the update is replayed from hipGraphs: on one rank the whole update as ONE graph (scope
+    "all", the default), a whole mini-epoch per graph
     (scope "epoch": one graph with and one without the running-statistics update), or one graph per optimiser step
     (scope "step", the form used with several ranks: [Adam + schedule of the previous step | forward / backward], the
     all-reduce issued between two such graphs, one trailing Adam graph).  Five iterations with and without graphs must leave the same parameters, learning rate and loss
@@ -1493,13 +1494,15 @@ def test_graphed_update_equals_eager_update(mixed, scope, monkeypatch):
         for _ in range(5):                   # 1 eager + capture/first replay + 3 further replays
             _, _, stats = agent.train_epoch()
         torch.cuda.synchronize()
-        if use_graphs and scope == "epoch" and mixed:
+        if use_graphs and scope in ("epoch", "all") and mixed:
             # the first mini-epoch's graph holds the normaliser updates of all its steps at its head (vine_rms_update_multi)
-            assert agent._upd_graphs[("epoch", True)]["keep"][-1] is not None
+            nb = agent.num_minibatches
+            assert agent._upd_graphs[(scope, True)]["keep"][nb] is not None
+            assert agent.graph_status["update"] == "graph (1 per %s)" % ("iteration" if scope == "all" else "mini-epoch")
         if use_graphs:
             # per-step form: (step, with / without the RMS update) graphs, each led by the previous step's Adam, + the
             # un-led first step of an update + the trailing Adam graph
-            assert len(agent._upd_graphs) == (2 if scope == "epoch" else 2 * agent.num_minibatches + 1)
+            assert len(agent._upd_graphs) == (1 if scope == "all" else 2 if scope == "epoch" else 2 * agent.num_minibatches + 1)
             assert not getattr(agent, "_update_graphs_failed", False)
         outs.append((torch.cat([p.detach().flatten() for p in agent.model.parameters()]).clone(), float(agent.lr),
                      {k: float(v) for k, v in stats.items()}, agent.model.running_mean_std.running_mean.clone()))

@@ -1322,9 +1322,14 @@ class A2CAgent:
         # several ranks: the same, with the gradient all-reduce of every step captured INSIDE the graph, when RCCL accepts
         # a capture on this stack (probed once, collectively: ``_collective_capture_ok``); otherwise one graph per step with
         # the collective issued eagerly between them
-        whole_epoch = (graphed and os.environ.get("VINE_UPD_GRAPH", "epoch") == "epoch"
+        scope = os.environ.get("VINE_UPD_GRAPH", "all")
+        whole_epoch = (graphed and scope in ("all", "epoch")
                        and (not self.multi_gpu or self._collective_capture_ok()))
-        for mini_ep in range(self.mini_epochs_num):
+        # round 5: ALL mini-epochs of the update as one graph (one replay per iteration instead of four: the device sat
+        # idle for ~9 us in front of every replay, and each was followed by a copy of its loss statistics); the
+        # learning-rate schedule and the step counter live in the Adam launch, so nothing happens on the host in between
+        all_done = whole_epoch and scope == "all" and self._update_epoch_graphed(rows, n_epochs=self.mini_epochs_num)
+        for mini_ep in range(0 if not all_done else self.mini_epochs_num, self.mini_epochs_num):
             nb = self.num_minibatches
             if whole_epoch and self._update_epoch_graphed(rows[mini_ep * nb:(mini_ep + 1) * nb]):
                 if self.normalize_input:
@@ -1550,16 +1555,17 @@ class A2CAgent:
         self.collective_capture = {"in_graph": ok, "probe": why, "timeout_s": timeout_s}
         return ok
 
-    def _update_epoch_graphed(self, rows_out):
-        """All optimiser steps of one mini-epoch as one graph replay.  Several ranks: the RCCL all-reduce of every step is
+    def _update_epoch_graphed(self, rows_out, n_epochs=1):
+        """All optimiser steps of one mini-epoch (``n_epochs`` > 1: of that many, i.e. of the whole update) as one graph
+        replay.  Several ranks: the RCCL all-reduce of every step is
         a node of that graph (``_collective_capture_ok``); if the capture is refused on any rank all of them fall back to
         one graph per step with the collective between the graphs (``_update_step_graphed``)."""
-        key = ("epoch", bool(self.normalize_input and self.model.running_mean_std.training))
+        key = ("epoch" if n_epochs == 1 else "all", bool(self.normalize_input and self.model.running_mean_std.training))
         rec = self._upd_graphs.get(key) if hasattr(self, "_upd_graphs") else None
         if rec is None:
             err = None
             try:
-                rec = self._capture_update_epoch(key)
+                rec = self._capture_update_epoch(key, n_epochs, rows_out)
             except RuntimeError as e:
                 err = e
             if not self._capture_agreed(rec is not None):
@@ -1589,9 +1595,13 @@ class A2CAgent:
                 self._abort_job("the first replay of the mini-epoch graph (gradient all-reduces captured) did not finish "
                                 "within %.0f s; relaunch with VINE_COLLECTIVE_IN_GRAPH=0 (all-reduce between per-step graphs)" % t)
             rec["replayed"] = True
-        rows_out.copy_(rec["stats"])
-        self.graph_status["update"] = ("graph (1 per mini-epoch, all-reduces captured)" if self.multi_gpu
-                                       else "graph (1 per mini-epoch)")
+        if rec["stats"].data_ptr() != rows_out.data_ptr():      # (the whole-update graph writes the iteration's rows itself)
+            rows_out.copy_(rec["stats"])
+        if n_epochs > 1 and self.normalize_input:
+            self.model.running_mean_std.eval()                   # (as the per-mini-epoch loop leaves the module)
+        per = "iteration" if n_epochs > 1 else "mini-epoch"
+        self.graph_status["update"] = ("graph (1 per %s, all-reduces captured)" % per if self.multi_gpu
+                                       else "graph (1 per %s)" % per)
         return True
 
     def _rms_updates_ahead(self, nb):
@@ -1610,7 +1620,7 @@ class A2CAgent:
             return None
         return rms.update_kernels_multi(obs, nb)
 
-    def _capture_update_epoch(self, key):
+    def _capture_update_epoch(self, key, n_epochs=1, rows_out=None):
         if not hasattr(self, "_upd_graphs"):
             self._upd_graphs = {}
             self._upd_pool = torch.cuda.graph_pool_handle()
@@ -1618,21 +1628,33 @@ class A2CAgent:
         g = torch.cuda.CUDAGraph()
         pool = None if os.environ.get("VINE_UPD_POOL") == "separate" else self._upd_pool
         nb = self.num_minibatches
-        stats_all = torch.zeros((nb, 8), device=self.device, dtype=torch.float32)     # (never allocate zeros in capture)
+        # one mini-epoch: a buffer of the graph's own, copied into the iteration's rows after every replay; the whole update:
+        # the iteration's rows themselves (a persistent buffer of the agent: self._stat_rows)
+        stats_all = (rows_out if n_epochs > 1 else
+                     torch.zeros((nb, 8), device=self.device, dtype=torch.float32))     # (never allocate zeros in capture)
         keep = []
-        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-            ahead = self._rms_updates_ahead(nb) if key[1] else None
-            for i in range(nb):
-                mb = self.get_minibatch(i)
-                # statistics straight into their row, step counter and learning-rate schedule inside the Adam launch
-                stats, mu_d, _logstd_d = self._fused_grad_half(mb, stats_out=stats_all[i],
-                                                               norm_stats=None if ahead is None else (ahead[0][i], ahead[1][i]))
-                if self.multi_gpu:
-                    # gradients + KL + overflow flag, SUM over the ranks (RCCL over xGMI): a node of the graph
-                    dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)
-                self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
-                keep.append((mb, stats, mu_d))
-            keep.append(ahead)
+        rms_training = bool(key[1])
+        try:
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                for ep in range(n_epochs):
+                    ahead = self._rms_updates_ahead(nb) if (rms_training and ep == 0) else None
+                    for i in range(nb):
+                        mb = self.get_minibatch(i)
+                        # statistics straight into their row, step counter and learning-rate schedule inside the Adam launch
+                        stats, mu_d, _logstd_d = self._fused_grad_half(
+                            mb, stats_out=stats_all[ep * nb + i],
+                            norm_stats=None if ahead is None else (ahead[0][i], ahead[1][i]))
+                        if self.multi_gpu:
+                            # gradients + KL + overflow flag, SUM over the ranks (RCCL over xGMI): a node of the graph
+                            dist.all_reduce(self.optimizer.comm_buffer, op=dist.ReduceOp.SUM)
+                        self.optimizer.step(grad_scale=1.0 / self.rank_size, lr_schedule=self._lr_schedule_args())
+                        keep.append((mb, stats, mu_d))
+                    keep.append(ahead)
+                    if n_epochs > 1 and self.normalize_input:
+                        self.model.running_mean_std.eval()      # statistics are updated during the first mini-epoch only
+        finally:
+            if n_epochs > 1 and self.normalize_input and rms_training:
+                self.model.running_mean_std.train()              # (the caller switches it after the replay)
         rec = {"G": g, "stats": stats_all, "keep": keep}
         self._upd_graphs[key] = rec
         return rec
