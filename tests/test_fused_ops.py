@@ -1682,7 +1682,7 @@ def test_ragged_sizes_through_the_whole_path(n_env, mb, obs_type, mixed):
     torch.cuda.synchronize()
     assert all(torch.isfinite(p).all() for p in agent.model.parameters())
     assert all(np.isfinite(float(v)) for v in stats.values())
-    assert agent._fast is not None and len(agent._upd_graphs) == 2      # mini-epoch graphs: with / without the RMS update
+    assert agent._fast is not None and list(agent._upd_graphs) == [("all", True)]      # the whole update: one graph
     env.close()
 
 
