@@ -644,15 +644,29 @@ __device__ __forceinline__ void lstm_seq_fwd_body(
             const int op = kk < KS1 ? XP : HP;
             const lp16x8_t a0 = *reinterpret_cast<const lp16x8_t*>(ob + col * op + 8 * lq);
             const lp16x8_t a1 = *reinterpret_cast<const lp16x8_t*>(ob + (16 + col) * op + 8 * lq);
+#ifdef SEQ_FWD_HALF_STREAM
+            uint4 wr_prev = make_uint4(0, 0, 0, 0);
+#endif
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int f = kk * 8 + j, slot = f % RING;
+#ifdef SEQ_FWD_HALF_STREAM
+                // (timing experiment, debug build only: the odd fragments are never loaded -- each even one is used twice --
+                // = the weight stream of a 2-CU column split, with none of its other costs; results are garbage)
+                const uint4 wr = (f & 1) ? wr_prev : ring[slot];      // (the even fragment's registers: its slot is reloading)
+                wr_prev = wr;
+#else
                 const uint4 wr = ring[slot];
+#endif
                 const lp16x8_t wf = __builtin_bit_cast(lp16x8_t, wr);
                 acc[j >> 1][j & 1][0] = MFMA_LP16(wf, a0, acc[j >> 1][j & 1][0]);
                 acc[j >> 1][j & 1][1] = MFMA_LP16(wf, a1, acc[j >> 1][j & 1][1]);
                 if (f < NC && t == 0) wcache[f * 64] = wr;       // (wave-private LDS copy for the later steps)
+#ifdef SEQ_FWD_HALF_STREAM
+                if (!(ablate & 2) && !(f & 1)) {
+#else
                 if (!(ablate & 2)) {
+#endif
                     const int fn = (f + RING) % NF;              // the fragment RING places further down the stream (folded: unrolled)
                     if (fn < NC && f + RING >= NF) ring[slot] = wcache[fn * 64];      // next step's: cached in step 0
                     else ring[slot] = SEQ_WFRAG(fn);
