@@ -453,6 +453,13 @@ __global__ __launch_bounds__(256) void lstm_step_mfma64_kernel(
 __device__ __forceinline__ float dpp_i2f(int x);
 __device__ __forceinline__ int dpp_f2i(float x);
 constexpr int SEQ_ROWS = 32;           // sequences per workgroup
+// Row skew of the 16-bit LDS operand images that are read as MFMA fragments (lane = row + 16 x chunk, one ds_read_b128): on
+// gfx950 such a read is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- over 64 banks,
+// and the 16 pieces of a group tile the banks only when the row pitch is an ODD multiple of 32 bytes (round 5: the pitches
+// were K + 8 elements = an odd multiple of 16 bytes, right for groups of 8 consecutive lanes: SQ_LDS_BANK_CONFLICT was 36 % of
+// SQ_LDS_IDX_ACTIVE in the four-phase launch, 45 % in the one-launch MLP)
+constexpr int LDS_SKEW = 16;           // elements (32 bytes); K is a multiple of 32 elements everywhere it is used
+constexpr int SEQ_FWD_NC = 11;         // weight fragments per wave kept in LDS by the forward kernel (88 KB)
 constexpr int SEQ_H = 256;             // hidden units (8 waves x 32)
 #ifndef SEQ_BWD_RING
 #define SEQ_BWD_RING 8      // weight ring of the backward kernel: 16 does not fit the register file without spills (76.7 us against 65.3 us per 4-step sequence)
@@ -544,7 +551,7 @@ __device__ __forceinline__ void lstm_seq_fwd_body(
     // need nothing from the step before, so the one workgroup barrier per step sits BEHIND them: a wave that finishes its
     // pointwise epilogue early runs the next step's x part while the slowest wave is still storing (the waves reach the
     // barrier up to 2 us apart: per-step stamps, profiles/r03/update_kernel_experiments.txt).
-    constexpr int XP = KX + 8, HP = H + 8;
+    constexpr int XP = KX + LDS_SKEW, HP = H + LDS_SKEW;
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
     // (dynamic: T x 6.5 KB + 33 KB + 4 KB goes past the 64 KB a kernel gets without asking)
     extern __shared__ __attribute__((aligned(16))) unsigned char seqf_lds[];
@@ -784,7 +791,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(
     const CT* __restrict__ c_all, const float* __restrict__ c0, const unsigned char* __restrict__ done,
     lp16_t* __restrict__ dG, float* __restrict__ bias_partial, int ablate, const float* __restrict__ c_last) {
     constexpr int H = SEQ_H, K = 4 * H, KSTEPS = K / 32, NF = KSTEPS * 2;
-    constexpr int PITCH = K + 8;
+    constexpr int PITCH = K + LDS_SKEW;
     static_assert(NF % RING == 0, "the ring must close on a step boundary");
     extern __shared__ __attribute__((aligned(16))) unsigned char seq_lds[];
     lp16_t (*dgl)[SEQ_ROWS * PITCH] = reinterpret_cast<lp16_t (*)[SEQ_ROWS * PITCH]>(seq_lds);     // [2][32 rows][4H + 8]
@@ -1410,7 +1417,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))
                                                             lp16_t* __restrict__ act1, lp16_t* __restrict__ act2,
                                                             lp16_t* out, long long out_stride, int ldw1,
                                                             const CopyBatchArgs side, int side_blocks) {
-    constexpr int P1 = 32 + 8, P2 = C1 + 8, P3 = C2 + 8;
+    constexpr int P1 = 32 + LDS_SKEW, P2 = C1 + LDS_SKEW, P3 = C2 + LDS_SKEW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     lp16_t* w1l = reinterpret_cast<lp16_t*>(lds_raw);            // [C1][P1], rows in tile order
     lp16_t* w2l = w1l + C1 * P1;                                 // [C2][P2], rows in tile order
@@ -1780,7 +1787,7 @@ __device__ __forceinline__ void mlp3_bwd_elu_mfma_body(
     const lp16_t* __restrict__ a3, long long a3_stride, const lp16_t* __restrict__ a2, const lp16_t* __restrict__ a1,
     float alpha, lp16_t* __restrict__ gz3, lp16_t* __restrict__ gz2, lp16_t* __restrict__ gz1,
     float* __restrict__ part3, float* __restrict__ part2, float* __restrict__ part1) {
-    constexpr int CK = 128, PC = CK + 8, P1 = C3 + 8, P2 = C2 + 8, TH = 64 * NW;
+    constexpr int CK = 128, PC = CK + LDS_SKEW, P1 = C3 + LDS_SKEW, P2 = C2 + LDS_SKEW, TH = 64 * NW;
     constexpr int NPC = C3 * (CK / 8) / TH;                     // weight pieces of a chunk per thread
     constexpr int N1 = C2 * (C3 / 8) / TH, N2 = C1 * (C2 / 8) / TH;
     static_assert(C3 == 64 && C3 * (CK / 8) % TH == 0 && C2 * (C3 / 8) % TH == 0 && C1 * (C2 / 8) % TH == 0, "shapes");
@@ -4074,7 +4081,7 @@ struct TrunkPhasesArgs {
 __global__ __launch_bounds__(512) void trunk_phases_kernel(const TrunkPhasesArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char trunk_lds[];
     TRUNK_STAMP(0)
-    lstm_seq_fwd_body<3, 22, lp16_t, lp16_t, 12>(a.T, a.B, a.x, a.ldx, nullptr, 0, a.w_tiled, a.bias, a.c0, a.done, a.h_out, a.c_all,
+    lstm_seq_fwd_body<3, 22, lp16_t, lp16_t, SEQ_FWD_NC>(a.T, a.B, a.x, a.ldx, nullptr, 0, a.w_tiled, a.bias, a.c0, a.done, a.h_out, a.c_all,
                                                  a.gates, a.ablate, a.c_last, a.h0);
     __syncthreads();      // this workgroup's hidden states are written (h_out slots 1 .. T of its 32 sequences)
     TRUNK_STAMP(1)
@@ -5623,15 +5630,15 @@ int vine_lstm_seq_forward_mfma(int64_t B, int64_t T, int64_t H, int64_t KX, cons
     static const bool wcache_on = [] { const char* e = getenv("VINE_SEQ_FWD_WCACHE"); return !(e && e[0] == '0'); }();      // A/B knob
 #define VINE_SEQ_FWD_T(KS1, RING, CT, HT)                                                                               \
     do {                                                                                                                \
-        const size_t rows_ = 4 * SEQ_H * sizeof(float) + ((size_t)2 * SEQ_ROWS * (SEQ_H + 8) +                           \
-                                                          (size_t)T * SEQ_ROWS * (32 * KS1 + 8)) * sizeof(lp16_t);       \
-        /* the LDS weight cache (12 fragments per wave = 96 KB) when the operand rows leave room for it */               \
-        const bool cache_ = wcache_on && T > 1 && rows_ + (size_t)8 * 12 * 1024 <= 160 * 1024;                          \
-        const size_t lds_ = rows_ + (cache_ ? (size_t)8 * 12 * 1024 : 0);                                               \
+        const size_t rows_ = 4 * SEQ_H * sizeof(float) + ((size_t)2 * SEQ_ROWS * (SEQ_H + LDS_SKEW) +                    \
+                                                          (size_t)T * SEQ_ROWS * (32 * KS1 + LDS_SKEW)) * sizeof(lp16_t); \
+        /* the LDS weight cache (SEQ_FWD_NC fragments per wave = 88 KB) when the operand rows leave room for it */        \
+        const bool cache_ = wcache_on && T > 1 && rows_ + (size_t)8 * SEQ_FWD_NC * 1024 <= 160 * 1024;                   \
+        const size_t lds_ = rows_ + (cache_ ? (size_t)8 * SEQ_FWD_NC * 1024 : 0);                                        \
         if (cache_) {                                                                                                   \
-            if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT, 12>), lds_))      \
+            if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_fwd_kernel<KS1, RING, CT, HT, SEQ_FWD_NC>), lds_)) \
                 return VINE_ERR_DEVICE;                                                                                 \
-            hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT, 12>), grid, block, lds_, s, (int)T, (long long)B, \
+            hipLaunchKernelGGL((lstm_seq_fwd_kernel<KS1, RING, CT, HT, SEQ_FWD_NC>), grid, block, lds_, s, (int)T, (long long)B, \
                                (const lp16_t*)x, (long long)ldx, (lp16_t*)hp, (long long)hp_stride,                     \
                                (const uint4*)w_tiled, bias, c0, done, (HT*)h_out, (CT*)c_all, (lp16_t*)gates, ablate,   \
                                c_last, h0);                                                                             \
@@ -5670,7 +5677,7 @@ int vine_lstm_seq_backward_mfma(int64_t B, int64_t T, int64_t H, const void* g_o
         return VINE_ERR_INVALID_ARG;
     if ((B % SEQ_ROWS) || H != SEQ_H || T > 8) return VINE_ERR_UNSUPPORTED;
     constexpr int RING = SEQ_BWD_RING;
-    const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(lp16_t);          // 129 KiB: one workgroup per CU
+    const size_t lds = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + LDS_SKEW) * sizeof(lp16_t);   // 130 KiB: one workgroup per CU
     const int ablate = seq_ablate();
 #define VINE_SEQ_BWD(CT, GT)                                                                                              \
     {                                                                                                                     \
@@ -5750,7 +5757,7 @@ int vine_mlp3_elu_mfma_prep(int64_t n, void* x, int64_t ldx, const float* raw, i
         if ((long long)side_blocks > (long long)MLP3_SIDE_ITEMS * (n / 64)) return VINE_ERR_UNSUPPORTED;
     }
     const int threads = (n % 128 == 0 && n >= 32768) ? 512 : 256;        // 8 waves per CU when one round covers the chip
-    const size_t lds = ((size_t)256 * 40 + 128 * 264 + 64 * 136) * sizeof(lp16_t);
+    const size_t lds = ((size_t)256 * (32 + LDS_SKEW) + 128 * (256 + LDS_SKEW) + 64 * (128 + LDS_SKEW)) * sizeof(lp16_t);
     if (!ensure_dyn_lds(threads == 512 ? reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 8>)
                                        : reinterpret_cast<const void*>(&mlp3_elu_mfma_kernel<256, 128, 64, 4>), lds))
         return VINE_ERR_DEVICE;
@@ -5778,7 +5785,8 @@ int vine_mlp3_bwd_elu_mfma(int64_t n, const void* dG, int64_t lddg, int64_t K0, 
         return VINE_ERR_INVALID_ARG;
     if (C3 != 64 || C2 != 128 || C1 != 256 || K0 != 1024 || (n & 63)) return VINE_ERR_UNSUPPORTED;
     const int nw = (n % 128 == 0 && n >= 32768) ? 8 : 4;
-    const size_t lds = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(lp16_t) + (size_t)nw * (64 + 128 + 256) * sizeof(float);
+    const size_t lds = ((size_t)2 * 64 * (128 + LDS_SKEW) + 128 * (64 + LDS_SKEW) + 256 * (128 + LDS_SKEW)) * sizeof(lp16_t) +
+                       (size_t)nw * (64 + 128 + 256) * sizeof(float);
     if (!ensure_dyn_lds(nw == 8 ? reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 8>)
                                 : reinterpret_cast<const void*>(&mlp3_bwd_elu_mfma_kernel<64, 128, 256, 8, 4>), 160 * 1024))
         return VINE_ERR_DEVICE;
@@ -5810,8 +5818,9 @@ int vine_lstm_seq_backward_mlp3_mfma(int64_t B, int64_t T, int64_t H, const void
     // 16-bit saved cell states and hidden-state gradient (the update's configuration)
     if ((B % SEQ_ROWS) || H != SEQ_H || T != 4) return VINE_ERR_UNSUPPORTED;
     constexpr int RING = SEQ_BWD_RING;
-    const size_t lds_lstm = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + 8) * sizeof(lp16_t);
-    const size_t lds_mlp = ((size_t)2 * 64 * 136 + 128 * 72 + 256 * 136) * sizeof(lp16_t) + (size_t)8 * (64 + 128 + 256) * sizeof(float);
+    const size_t lds_lstm = (size_t)2 * SEQ_ROWS * (4 * SEQ_H + LDS_SKEW) * sizeof(lp16_t);
+    const size_t lds_mlp = ((size_t)2 * 64 * (128 + LDS_SKEW) + 128 * (64 + LDS_SKEW) + 256 * (128 + LDS_SKEW)) * sizeof(lp16_t) +
+                           (size_t)8 * (64 + 128 + 256) * sizeof(float);
     const size_t lds = lds_lstm > lds_mlp ? lds_lstm : lds_mlp;
     if (!ensure_dyn_lds(reinterpret_cast<const void*>(&lstm_seq_bwd_mlp3_bwd_kernel<RING, lp16_t, lp16_t>), 160 * 1024))
         return VINE_ERR_DEVICE;
